@@ -1,0 +1,67 @@
+"""Seeded generators shared by the CPU and GPU test suites (distributions follow
+/root/reference/ezpz/src/tests/proptests.rs:25-147)."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+def arb_ids(rng, k, hi=32):
+    return [int(v) for v in rng.integers(0, hi, size=k)]
+
+
+def arb_scalar(rng):
+    return float(rng.integers(-1000, 1000)) / 10.0
+
+
+def arb_angle_kind(rng, other_only=False):
+    c = 2 if other_only else int(rng.integers(0, 3))
+    if c == 0:
+        return "parallel"
+    if c == 1:
+        return "perpendicular"
+    return ("deg" if rng.integers(0, 2) else "rad", float(rng.integers(-360, 361)))
+
+
+def arb_constraint(rng, kind, hi=32):
+    """One random constraint of `kind` with ids drawn from [0, hi) (duplicates allowed, like arb_id())."""
+    ids = arb_ids(rng, O.KIND_NUM_IDS[kind], hi)
+    param, tag = 0.0, 0
+    if kind == O.LINE_TANGENT_TO_CIRCLE:
+        tag = int(rng.integers(1, 3))
+    elif kind == O.CIRCLE_TANGENT_TO_CIRCLE:
+        tag = int(rng.integers(1, 3))
+    elif kind in (O.DISTANCE, O.VERTICAL_DISTANCE, O.HORIZONTAL_DISTANCE, O.FIXED, O.CIRCLE_RADIUS, O.ARC_RADIUS,
+                  O.POINT_LINE_DISTANCE, O.VERTICAL_POINT_LINE_DISTANCE, O.HORIZONTAL_POINT_LINE_DISTANCE,
+                  O.ARC_LENGTH):
+        param = arb_scalar(rng)
+    elif kind in (O.LINES_AT_ANGLE, O.POINTS_AT_ANGLE):
+        tag, param = O._angle(arb_angle_kind(rng))
+    elif kind == O.ARC_ANGLE:
+        tag, param = O._angle(arb_angle_kind(rng, other_only=True))
+    return O._mk(kind, ids, param, tag=tag)
+
+
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def keyed_uniform(seed, n_systems, n_vars, lo, hi, integer=False):
+    """Counter-based PRNG keyed (seed, system, var) -> uniform [lo, hi)."""
+    sys_idx = np.arange(n_systems, dtype=np.uint64)[:, None]
+    var_idx = np.arange(n_vars, dtype=np.uint64)[None, :]
+    x = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)) ^ (sys_idx * np.uint64(0xD1B54A32D192ED03)) ^ (
+        var_idx * np.uint64(0x8CB92BA72F3D8DD7))
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    if integer:
+        return np.floor(lo + u * (hi - lo))
+    return lo + u * (hi - lo)
