@@ -1,0 +1,20 @@
+"""ezpz_amd: the MI355X-native Newton / Levenberg-Marquardt constraint-solve path of KittyCAD/ezpz.
+
+A C-ABI shared library (include/ezpz_amd.h; HIP kernels for gfx950 + C++ host symbolic phase) and this
+thin host mirror of the `ezpz` crate's solve API.  There is no CPU fallback: importing works anywhere the
+library builds, solving needs a HIP device.
+"""
+from . import textual
+from ._lib import CONSTRAINT_DTYPE, STATUS_DTYPE, lib
+from .api import (Angle, AngleKind, CircleSide, Config, Constraint, ConstraintRequest, DatumCircle, DatumCircularArc,
+                  DatumDistance, DatumLineSegment, DatumPoint, FailureOutcome, IdGenerator, LineSide,
+                  NonLinearSystemError, RawResult, SolveOutcome, System, Warning, WarningContent, analyze, device_count, solve,
+                  solve_records, stack_records)
+
+__all__ = [
+    "Angle", "AngleKind", "CircleSide", "Config", "Constraint", "ConstraintRequest", "DatumCircle", "DatumCircularArc",
+    "DatumDistance", "DatumLineSegment", "DatumPoint", "FailureOutcome", "IdGenerator", "LineSide",
+    "NonLinearSystemError", "RawResult", "SolveOutcome", "System", "Warning", "WarningContent", "analyze",
+    "device_count", "solve",
+    "solve_records", "stack_records", "textual", "lib", "CONSTRAINT_DTYPE", "STATUS_DTYPE",
+]

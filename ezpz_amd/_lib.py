@@ -1,0 +1,111 @@
+"""ctypes binding of include/ezpz_amd.h.  The library is required: there is no Python/CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+CONSTRAINT_DTYPE = np.dtype(
+    [("kind", "<u2"), ("tag", "u1"), ("flags", "u1"), ("priority", "<u4"), ("ids", "<u4", (8,)), ("param", "<f8"),
+     ("weight", "<f8")]
+)
+assert CONSTRAINT_DTYPE.itemsize == 56
+STATUS_DTYPE = np.dtype(
+    [("iterations", "<u4"), ("converged", "<u4"), ("n_unsatisfied", "<u4"), ("n_warnings", "<u4"),
+     ("final_residual_inf", "<f8"), ("final_lambda", "<f8")]
+)
+assert STATUS_DTYPE.itemsize == 32
+
+
+class CConfig(C.Structure):
+    _fields_ = [("max_iterations", C.c_uint64), ("residual_tolerance", C.c_double), ("step_tolerance", C.c_double),
+                ("initial_lambda", C.c_double)]
+
+
+class CWarning(C.Structure):
+    _fields_ = [("about_constraint", C.c_int32), ("content", C.c_int32)]
+
+
+class COutcome(C.Structure):
+    _fields_ = [("error", C.c_int32), ("err_constraint_id", C.c_int32), ("err_variable", C.c_int64),
+                ("iterations", C.c_uint64), ("converged", C.c_int32), ("priority_solved", C.c_uint32),
+                ("n_unsatisfied", C.c_uint64), ("n_warnings", C.c_uint64), ("num_vars", C.c_uint64),
+                ("num_eqs", C.c_uint64), ("final_lambda", C.c_double), ("final_residual_inf", C.c_double)]
+
+
+class CSystemInfo(C.Structure):
+    _fields_ = [("n_constraints", C.c_uint64), ("n_vars", C.c_uint64), ("n_rows", C.c_uint64), ("nnz_j", C.c_uint64),
+                ("nnz_a", C.c_uint64), ("nnz_l", C.c_uint64), ("n_levels", C.c_uint64), ("n_components", C.c_uint64),
+                ("program_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("team_size", C.c_uint32),
+                ("workspace_in_lds", C.c_uint32)]
+
+
+# every symbol include/ezpz_amd.h declares
+EXPORTS = [
+    "ezpz_default_config", "ezpz_device_count", "ezpz_error_string", "ezpz_system_create", "ezpz_system_destroy",
+    "ezpz_system_info", "ezpz_system_solve_batch_device", "ezpz_system_solve_batch", "ezpz_solve_inner", "ezpz_solve",
+    "ezpz_problem_parse", "ezpz_problem_destroy", "ezpz_problem_num_constraints", "ezpz_problem_num_vars",
+    "ezpz_problem_constraints", "ezpz_problem_guesses", "ezpz_problem_num_labels", "ezpz_problem_label",
+    "ezpz_analyze", "ezpz_system_eval_batch", "ezpz_system_jacobian_pattern",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads (building first if the sources are newer) libezpz_amd.so.  Raises if it cannot be built/loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if os.environ.get("EZPZ_AMD_NO_BUILD") != "1":
+        path = _build.build()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -m ezpz_amd.build` (needs hipcc)")
+    L = C.CDLL(path)
+    vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
+    L.ezpz_default_config.restype = None
+    L.ezpz_default_config.argtypes = [C.POINTER(CConfig)]
+    L.ezpz_device_count.restype = C.c_int
+    L.ezpz_error_string.restype = C.c_char_p
+    L.ezpz_error_string.argtypes = [C.c_int]
+    L.ezpz_system_create.restype = C.c_int
+    L.ezpz_system_create.argtypes = [vp, sz, sz, C.c_int, u32, C.POINTER(vp), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int64)]
+    L.ezpz_system_destroy.restype = None
+    L.ezpz_system_destroy.argtypes = [vp]
+    L.ezpz_system_info.restype = C.c_int
+    L.ezpz_system_info.argtypes = [vp, C.POINTER(CSystemInfo)]
+    L.ezpz_analyze.restype = C.c_int
+    L.ezpz_analyze.argtypes = [vp, sz, sz, C.POINTER(CSystemInfo), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.ezpz_system_eval_batch.restype = C.c_int
+    L.ezpz_system_eval_batch.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.ezpz_system_jacobian_pattern.restype = C.c_int
+    L.ezpz_system_jacobian_pattern.argtypes = [vp, vp, vp]
+    L.ezpz_system_solve_batch_device.restype = C.c_int
+    L.ezpz_system_solve_batch_device.argtypes = [vp, vp, sz, C.POINTER(CConfig), vp, vp, vp, vp, u32, vp]
+    L.ezpz_system_solve_batch.restype = C.c_int
+    L.ezpz_system_solve_batch.argtypes = [vp, vp, sz, C.POINTER(CConfig), vp, vp, vp, vp, u32]
+    L.ezpz_solve_inner.restype = C.c_int
+    L.ezpz_solve_inner.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(CConfig), vp, vp, vp, sz, C.POINTER(COutcome)]
+    L.ezpz_solve.restype = C.c_int
+    L.ezpz_solve.argtypes = [vp, sz, vp, vp, sz, C.POINTER(CConfig), vp, vp, vp, sz, C.POINTER(COutcome)]
+    L.ezpz_problem_parse.restype = C.c_int
+    L.ezpz_problem_parse.argtypes = [C.c_char_p, sz, C.POINTER(vp), C.c_char_p, sz]
+    L.ezpz_problem_destroy.restype = None
+    L.ezpz_problem_destroy.argtypes = [vp]
+    L.ezpz_problem_num_constraints.restype = sz
+    L.ezpz_problem_num_constraints.argtypes = [vp]
+    L.ezpz_problem_num_vars.restype = sz
+    L.ezpz_problem_num_vars.argtypes = [vp]
+    L.ezpz_problem_constraints.restype = vp
+    L.ezpz_problem_constraints.argtypes = [vp]
+    L.ezpz_problem_guesses.restype = vp
+    L.ezpz_problem_guesses.argtypes = [vp]
+    L.ezpz_problem_num_labels.restype = sz
+    L.ezpz_problem_num_labels.argtypes = [vp, C.c_int]
+    L.ezpz_problem_label.restype = C.c_char_p
+    L.ezpz_problem_label.argtypes = [vp, C.c_int, sz]
+    _lib = L
+    return L

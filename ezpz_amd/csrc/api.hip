@@ -1,0 +1,716 @@
+// C ABI implementation (include/ezpz_amd.h): system lifetime, kernel dispatch, and the host-side
+// orchestration the reference keeps above its numeric core --
+//   solve_inner                 reference ezpz/src/lib.rs:265-356
+//   solve_with_priority_inner   reference ezpz/src/lib.rs:148-263
+//   lint                        reference ezpz/src/warnings.rs:34-60
+//   set_from_initial_values     reference ezpz/src/constraints.rs:146-193
+// All numeric work runs in lm_solve_kernel on the GPU; there is no CPU solver in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ezpz_amd.h"
+#include "kinds.hpp"
+#include "lm_kernel.hip.hpp"
+#include "program.hpp"
+
+using namespace ezpz;
+
+namespace {
+
+constexpr size_t kLdsBytesMax = 160 * 1024;  // MI355X: 160 KiB LDS per CU
+constexpr int kNumCUs = 256;
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) {                        \
+            (void)hipGetLastError();                   \
+            return EZPZ_ERR_HIP;                       \
+        }                                              \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t count) {
+        if (count <= cap) return EZPZ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(count, 16);
+        if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) {
+            (void)hipGetLastError();
+            return EZPZ_ERR_HIP;
+        }
+        cap = want;
+        return EZPZ_OK;
+    }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+
+struct EzpzSystem {
+    int device = 0;
+    ProgramCounts counts;
+    EzpzSystemInfo info{};
+    void* dev_program = nullptr;  // single allocation holding every list
+    ProgramView view{};
+    uint32_t team_size = 0;
+    bool wg_team = false;
+    bool lds_ws = true;
+    uint32_t ws_doubles = 0;
+    uint32_t block_threads = 256;
+    size_t lds_bytes = 0;
+    // grow-only scratch for the host-pointer entry points
+    std::mutex mu;
+    DevBuf<double> x_dev;
+    DevBuf<EzpzStatus> st_dev;
+    DevBuf<uint8_t> mask_dev;
+    DevBuf<uint64_t> log_dev;
+    DevBuf<double> gws_dev;
+    std::vector<uint32_t> host_colj_ptr, host_colj_items;  // (slot,row) per variable, for jacobian_pattern
+    ~EzpzSystem() {
+        if (dev_program) (void)hipFree(dev_program);
+    }
+};
+
+namespace {
+
+uint32_t pow2_ceil(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Team shape: small systems share a wavefront (sub-wave teams, no barriers); larger ones take a whole
+// workgroup; systems whose state exceeds the LDS fall back to a global-memory workspace.
+void choose_team(EzpzSystem& s, uint32_t requested) {
+    const ProgramCounts& c = s.counts;
+    const uint64_t doubles = 3ull * c.n_vars + 2ull * c.n_rows + c.zj + c.zlo + 2;
+    s.ws_doubles = (uint32_t)((doubles + 1) & ~1ull);
+    const size_t ws_bytes = (size_t)s.ws_doubles * 8;
+    const uint32_t width = std::max<uint32_t>(1, std::max(c.n_cons, c.n_vars));
+    uint32_t team = requested;
+    if (team == 0) {
+        if (width <= 64 && ws_bytes <= 32 * 1024)
+            team = std::min<uint32_t>(64, std::max<uint32_t>(8, pow2_ceil(width)));
+        else
+            team = std::min<uint32_t>(1024, std::max<uint32_t>(128, pow2_ceil((width + 1) / 2)));
+    }
+    if (team <= 64) {
+        team = std::max<uint32_t>(8, pow2_ceil(team));
+        if (ws_bytes > kLdsBytesMax - 1024) team = 256;  // cannot be a sub-wave team
+    }
+    if (team <= 64) {
+        s.wg_team = false;
+        s.lds_ws = true;
+        s.team_size = team;
+        uint32_t threads = 256;
+        while (threads > 64 && (size_t)(threads / team) * ws_bytes > kLdsBytesMax - 512) threads >>= 1;
+        if ((size_t)(threads / team) * ws_bytes > kLdsBytesMax - 512) threads = team;  // one team per block
+        s.block_threads = std::max(threads, team);
+        s.lds_bytes = (size_t)(s.block_threads / team) * ws_bytes + 16;
+    } else {
+        team = std::min<uint32_t>(1024, (team + 63) & ~63u);
+        s.wg_team = true;
+        s.team_size = team;
+        s.block_threads = team;
+        s.lds_ws = ws_bytes + 512 <= kLdsBytesMax;
+        s.lds_bytes = s.lds_ws ? ws_bytes + 32 * 8 + 16 : 48 * 8;
+    }
+}
+
+template <int TEAM, bool WG, bool LDSWS>
+int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+    auto kernel = lm_solve_kernel<TEAM, WG, LDSWS>;
+    if (s.lds_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)s.lds_bytes));
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(s.block_threads), s.lds_bytes, stream, args);
+    HIP_TRY(hipGetLastError());
+    return EZPZ_OK;
+}
+
+int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
+    if (args.batch == 0) return EZPZ_OK;
+    uint32_t grid;
+    if (!s.wg_team) {
+        const uint32_t tpb = s.block_threads / s.team_size;
+        uint64_t blocks = (args.batch + tpb - 1) / tpb;
+        grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)kNumCUs * 32);
+        switch (s.team_size) {
+        case 8:
+            return launch_variant<8, false, true>(s, args, grid, stream);
+        case 16:
+            return launch_variant<16, false, true>(s, args, grid, stream);
+        case 32:
+            return launch_variant<32, false, true>(s, args, grid, stream);
+        default:
+            return launch_variant<64, false, true>(s, args, grid, stream);
+        }
+    }
+    const uint32_t per_cu = s.lds_ws ? (uint32_t)std::max<size_t>(1, kLdsBytesMax / std::max<size_t>(s.lds_bytes, 1))
+                                     : 2048u / s.block_threads;
+    grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)kNumCUs * std::min<uint32_t>(per_cu, 8) * 2);
+    if (s.lds_ws) return launch_variant<64, true, true>(s, args, grid, stream);
+    {
+        int rc = s.gws_dev.ensure((size_t)grid * s.ws_doubles);
+        if (rc != EZPZ_OK) return rc;
+        args.gws = s.gws_dev.p;
+    }
+    return launch_variant<64, true, false>(s, args, grid, stream);
+}
+
+void fill_cfg(SolveArgs& a, const EzpzConfig* cfg) {
+    EzpzConfig d;
+    ezpz_default_config(&d);
+    if (!cfg) cfg = &d;
+    a.max_iterations = (uint32_t)std::min<uint64_t>(cfg->max_iterations, 0xFFFFFFFFull);
+    a.residual_tolerance = cfg->residual_tolerance;
+    a.step_tolerance = cfg->step_tolerance;
+    a.initial_lambda = cfg->initial_lambda;
+}
+
+template <class T>
+size_t append(std::vector<unsigned char>& blob, const std::vector<T>& v) {
+    size_t off = (blob.size() + 15) & ~size_t(15);
+    blob.resize(off + std::max<size_t>(v.size() * sizeof(T), 16));
+    if (!v.empty()) std::memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ezpz_default_config(EzpzConfig* cfg) {
+    cfg->max_iterations = 35;  // solver.rs:72-81
+    cfg->residual_tolerance = 1e-8;
+    cfg->step_tolerance = 1e-12;
+    cfg->initial_lambda = 1e-9;
+}
+
+int ezpz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* ezpz_error_string(int err) {
+    switch (err) {
+    case EZPZ_OK: return "ok";
+    case EZPZ_ERR_NOT_FOUND: return "ID not found";
+    case EZPZ_ERR_WRONG_NUMBER_GUESSES: return "There should be exactly 1 guess per variable";
+    case EZPZ_ERR_MISSING_GUESS: return "Constraint references a variable that does not appear in the initial guesses";
+    case EZPZ_ERR_MATRIX: return "Could not create matrix: variable id out of range";
+    case EZPZ_ERR_EMPTY_SYSTEM: return "Cannot solve an empty system";
+    case EZPZ_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU fallback)";
+    case EZPZ_ERR_HIP: return "HIP runtime error";
+    case EZPZ_ERR_TOO_LARGE: return "system too large for this build";
+    case EZPZ_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case EZPZ_ERR_PARSE: return "could not parse problem text";
+    case EZPZ_ERR_TEXT_MISSING_GUESS: return "No guess was given for a point";
+    case EZPZ_ERR_TEXT_UNUSED_GUESSES: return "You gave a guess for points which weren't defined";
+    case EZPZ_ERR_TEXT_UNDEFINED_POINT: return "You referred to a point that was never defined";
+    default: return "unknown error";
+    }
+}
+
+int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
+                       EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable) {
+    if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    Program P;
+    BuildError be;
+    if (!build_program(cs, n_cs, n_vars, P, be)) {
+        if (err_constraint) *err_constraint = be.constraint;
+        if (err_variable) *err_variable = be.variable;
+        return be.code;
+    }
+    if (ezpz_device_count() <= device || device < 0) return EZPZ_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<EzpzSystem> s(new EzpzSystem());
+    s->device = device;
+    s->counts = P.c;
+    s->host_colj_ptr = P.colj_ptr;
+    s->host_colj_items = P.colj_items;
+    choose_team(*s, team_size);
+
+    std::vector<unsigned char> blob;
+    size_t o_cons = append(blob, P.cons);
+    size_t o_colj_ptr = append(blob, P.colj_ptr), o_colj_items = append(blob, P.colj_items);
+    size_t o_apair_ptr = append(blob, P.apair_ptr), o_apairs = append(blob, P.apairs);
+    size_t o_lvl_cptr = append(blob, P.lvl_cptr), o_lvl_cols = append(blob, P.lvl_cols);
+    size_t o_lvl_sptr = append(blob, P.lvl_sptr), o_l_col = append(blob, P.l_col);
+    size_t o_lpair_ptr = append(blob, P.lpair_ptr), o_lpairs = append(blob, P.lpairs);
+    size_t o_fwd_ptr = append(blob, P.fwd_ptr), o_fwd_items = append(blob, P.fwd_items);
+    size_t o_bwd_ptr = append(blob, P.bwd_ptr), o_bwd_items = append(blob, P.bwd_items);
+    HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
+    HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    unsigned char* base = static_cast<unsigned char*>(s->dev_program);
+    auto u32 = [&](size_t off) { return reinterpret_cast<const uint32_t*>(base + off); };
+    ProgramView& v = s->view;
+    v.cons = reinterpret_cast<const DevCon*>(base + o_cons);
+    v.colj_ptr = u32(o_colj_ptr);
+    v.colj_items = u32(o_colj_items);
+    v.apair_ptr = u32(o_apair_ptr);
+    v.apairs = u32(o_apairs);
+    v.lvl_cptr = u32(o_lvl_cptr);
+    v.lvl_cols = u32(o_lvl_cols);
+    v.lvl_sptr = u32(o_lvl_sptr);
+    v.l_col = u32(o_l_col);
+    v.lpair_ptr = u32(o_lpair_ptr);
+    v.lpairs = u32(o_lpairs);
+    v.fwd_ptr = u32(o_fwd_ptr);
+    v.fwd_items = u32(o_fwd_items);
+    v.bwd_ptr = u32(o_bwd_ptr);
+    v.bwd_items = u32(o_bwd_items);
+    v.n_cons = P.c.n_cons;
+    v.n_vars = P.c.n_vars;
+    v.n_rows = P.c.n_rows;
+    v.zj = P.c.zj;
+    v.zlo = P.c.zlo;
+    v.n_levels = P.c.n_levels;
+
+    EzpzSystemInfo& info = s->info;
+    info.n_constraints = P.c.n_cons;
+    info.n_vars = P.c.n_vars;
+    info.n_rows = P.c.n_rows;
+    info.nnz_j = P.c.zj;
+    info.nnz_a = P.c.za;
+    info.nnz_l = (uint64_t)P.c.zlo + P.c.n_vars;
+    info.n_levels = P.c.n_levels;
+    info.n_components = P.c.n_components;
+    info.program_bytes = blob.size();
+    info.workspace_bytes = (uint64_t)s->ws_doubles * 8;
+    info.team_size = s->team_size;
+    info.workspace_in_lds = s->lds_ws ? 1 : 0;
+    *out = s.release();
+    return EZPZ_OK;
+}
+
+void ezpz_system_destroy(EzpzSystem* sys) {
+    if (!sys) return;
+    (void)hipSetDevice(sys->device);
+    delete sys;
+}
+
+int ezpz_system_info(const EzpzSystem* sys, EzpzSystemInfo* info) {
+    if (!sys || !info) return EZPZ_ERR_INVALID_ARGUMENT;
+    *info = sys->info;
+    return EZPZ_OK;
+}
+
+int ezpz_analyze(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, EzpzSystemInfo* info, int32_t* err_constraint,
+                 int64_t* err_variable) {
+    if (!info) return EZPZ_ERR_INVALID_ARGUMENT;
+    Program P;
+    BuildError be;
+    if (!build_program(cs, n_cs, n_vars, P, be)) {
+        if (err_constraint) *err_constraint = be.constraint;
+        if (err_variable) *err_variable = be.variable;
+        return be.code;
+    }
+    EzpzSystem tmp;
+    tmp.counts = P.c;
+    choose_team(tmp, 0);
+    std::memset(info, 0, sizeof(*info));
+    info->n_constraints = P.c.n_cons;
+    info->n_vars = P.c.n_vars;
+    info->n_rows = P.c.n_rows;
+    info->nnz_j = P.c.zj;
+    info->nnz_a = P.c.za;
+    info->nnz_l = (uint64_t)P.c.zlo + P.c.n_vars;
+    info->n_levels = P.c.n_levels;
+    info->n_components = P.c.n_components;
+    info->program_bytes = P.cons.size() * sizeof(DevCon) +
+                          4 * (P.colj_ptr.size() + P.colj_items.size() + P.apair_ptr.size() + P.apairs.size() +
+                               P.lvl_cptr.size() + P.lvl_cols.size() + P.lvl_sptr.size() + P.l_col.size() +
+                               P.lpair_ptr.size() + P.lpairs.size() + P.fwd_ptr.size() + P.fwd_items.size() +
+                               P.bwd_ptr.size() + P.bwd_items.size());
+    info->workspace_bytes = (uint64_t)tmp.ws_doubles * 8;
+    info->team_size = tmp.team_size;
+    info->workspace_in_lds = tmp.lds_ws ? 1 : 0;
+    return EZPZ_OK;
+}
+
+int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t* cols) {
+    if (!sys || !rows || !cols) return EZPZ_ERR_INVALID_ARGUMENT;
+    for (uint32_t v = 0; v < sys->counts.n_vars; ++v)
+        for (uint32_t q = sys->host_colj_ptr[v]; q < sys->host_colj_ptr[v + 1]; ++q) {
+            uint32_t slot = sys->host_colj_items[2 * q];
+            rows[slot] = sys->host_colj_items[2 * q + 1];
+            cols[slot] = v;
+        }
+    return EZPZ_OK;
+}
+
+int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, double* r_out, double* jv_out,
+                           uint32_t* degenerate_count_out) {
+    if (!sys || !x || !r_out || !jv_out) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return EZPZ_OK;
+    std::lock_guard<std::mutex> lock(sys->mu);
+    HIP_TRY(hipSetDevice(sys->device));
+    const size_t n = sys->counts.n_vars, m = sys->counts.n_rows, zj = sys->counts.zj;
+    DevBuf<double> xd, rd, jd;
+    DevBuf<uint32_t> dd;
+    int rc;
+    if ((rc = xd.ensure(batch * std::max<size_t>(n, 1))) != EZPZ_OK) return rc;
+    if ((rc = rd.ensure(batch * std::max<size_t>(m, 1))) != EZPZ_OK) return rc;
+    if ((rc = jd.ensure(batch * std::max<size_t>(zj, 1))) != EZPZ_OK) return rc;
+    if ((rc = dd.ensure(batch)) != EZPZ_OK) return rc;
+    HIP_TRY(hipMemcpy(xd.p, x, batch * n * sizeof(double), hipMemcpyHostToDevice));
+    EvalArgs e{};
+    e.p = sys->view;
+    e.x = xd.p;
+    e.r_out = rd.p;
+    e.jv_out = jd.p;
+    e.deg_out = dd.p;
+    e.batch = batch;
+    uint32_t grid = (uint32_t)std::min<size_t>(batch, 4096);
+    hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(256), 0, nullptr, e);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(r_out, rd.p, batch * m * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(jv_out, jd.p, batch * zj * sizeof(double), hipMemcpyDeviceToHost));
+    if (degenerate_count_out)
+        HIP_TRY(hipMemcpy(degenerate_count_out, dd.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return EZPZ_OK;
+}
+
+int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
+                                   double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
+                                   uint64_t* warn_log_dev, uint32_t warn_cap, void* stream) {
+    if (!sys || (batch && (!x_out_dev || !status_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch && sys->counts.n_vars && !x0_dev) return EZPZ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(sys->device));
+    SolveArgs a{};
+    a.p = sys->view;
+    a.x0 = x0_dev;
+    a.x_out = x_out_dev;
+    a.status = status_dev;
+    a.unsat_mask = unsat_mask_dev;
+    a.warn_log = warn_cap ? warn_log_dev : nullptr;
+    a.warn_cap = warn_cap;
+    a.gws = nullptr;
+    a.batch = batch;
+    a.ws_doubles = sys->ws_doubles;
+    fill_cfg(a, cfg);
+    return launch(*sys, a, static_cast<hipStream_t>(stream));
+}
+
+int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out,
+                            EzpzStatus* status, uint8_t* unsat_mask, uint64_t* warn_log, uint32_t warn_cap) {
+    if (!sys) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return EZPZ_OK;
+    std::lock_guard<std::mutex> lock(sys->mu);
+    HIP_TRY(hipSetDevice(sys->device));
+    const size_t n = sys->counts.n_vars, C = sys->counts.n_cons;
+    int rc;
+    if ((rc = sys->x_dev.ensure(batch * std::max<size_t>(n, 1))) != EZPZ_OK) return rc;
+    if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
+    if (unsat_mask && (rc = sys->mask_dev.ensure(batch * std::max<size_t>(C, 1))) != EZPZ_OK) return rc;
+    if (warn_log && warn_cap && (rc = sys->log_dev.ensure(batch * (size_t)warn_cap)) != EZPZ_OK) return rc;
+    if (n) HIP_TRY(hipMemcpy(sys->x_dev.p, x0, batch * n * sizeof(double), hipMemcpyHostToDevice));
+    rc = ezpz_system_solve_batch_device(sys, sys->x_dev.p, batch, cfg, sys->x_dev.p, sys->st_dev.p,
+                                        unsat_mask ? sys->mask_dev.p : nullptr,
+                                        (warn_log && warn_cap) ? sys->log_dev.p : nullptr, warn_cap, nullptr);
+    if (rc != EZPZ_OK) return rc;
+    HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy(x_out, sys->x_dev.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (unsat_mask && C) HIP_TRY(hipMemcpy(unsat_mask, sys->mask_dev.p, batch * C, hipMemcpyDeviceToHost));
+    if (warn_log && warn_cap)
+        HIP_TRY(hipMemcpy(warn_log, sys->log_dev.p, batch * (size_t)warn_cap * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return EZPZ_OK;
+}
+
+}  // extern "C"
+
+// ---- solve_inner / solve: host orchestration ---------------------------------------------------------------------
+namespace {
+
+// Small LRU of analysed topologies keyed by the request bytes, so that repeated solve() calls on one
+// problem (what ezpz-cli's 100-run loop does, main.rs:96-98) skip the symbolic phase.
+struct CacheEntry {
+    uint64_t hash;
+    std::vector<unsigned char> key;
+    size_t n_vars;
+    EzpzSystem* sys;
+};
+std::mutex g_cache_mu;
+std::list<CacheEntry> g_cache;
+constexpr size_t kCacheMax = 16;
+
+int cached_system(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, EzpzSystem** out, int32_t* ec, int64_t* ev) {
+    const uint64_t h = topology_hash(cs, n_cs, n_vars);
+    const size_t bytes = n_cs * sizeof(EzpzConstraint);
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    for (auto it = g_cache.begin(); it != g_cache.end(); ++it) {
+        if (it->hash == h && it->n_vars == n_vars && it->key.size() == bytes &&
+            std::memcmp(it->key.data(), cs, bytes) == 0) {
+            g_cache.splice(g_cache.begin(), g_cache, it);
+            *out = g_cache.front().sys;
+            return EZPZ_OK;
+        }
+    }
+    EzpzSystem* sys = nullptr;
+    int rc = ezpz_system_create(cs, n_cs, n_vars, 0, 0, &sys, ec, ev);
+    if (rc != EZPZ_OK) return rc;
+    CacheEntry e;
+    e.hash = h;
+    e.key.assign(reinterpret_cast<const unsigned char*>(cs), reinterpret_cast<const unsigned char*>(cs) + bytes);
+    e.n_vars = n_vars;
+    e.sys = sys;
+    g_cache.push_front(std::move(e));
+    while (g_cache.size() > kCacheMax) {
+        ezpz_system_destroy(g_cache.back().sys);
+        g_cache.pop_back();
+    }
+    *out = sys;
+    return EZPZ_OK;
+}
+
+struct WarnSink {
+    EzpzWarning* buf;
+    size_t cap;
+    uint64_t count;
+    void push(int32_t about, int32_t content) {
+        if (buf && count < cap) {
+            buf[count].about_constraint = about;
+            buf[count].content = content;
+        }
+        ++count;
+    }
+};
+
+double angle_to_degrees(uint8_t tag, double val) {  // datatypes.rs:58-64
+    return tag == EZPZ_ANGLE_OTHER_DEG ? val : val * (180.0 / 3.14159265358979323846264338327950288);
+}
+bool nearly_eq(double a, double b) { return std::fabs(a - b) < 1e-4; }  // warnings.rs:85-87
+
+void lint(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t n, WarnSink& w) {  // warnings.rs:34-60
+    for (size_t i = 0; i < n; ++i) {
+        const EzpzConstraint& c = cs[i];
+        if (c.kind != EZPZ_LINES_AT_ANGLE) continue;
+        if (c.tag != EZPZ_ANGLE_OTHER_DEG && c.tag != EZPZ_ANGLE_OTHER_RAD) continue;
+        double deg = angle_to_degrees(c.tag, c.param);
+        int32_t id = (int32_t)(orig_ids ? orig_ids[i] : i);
+        if (nearly_eq(deg, 0.0) || nearly_eq(deg, 360.0) || nearly_eq(deg, 180.0))
+            w.push(id, EZPZ_WARN_SHOULD_BE_PARALLEL);
+        else if (nearly_eq(deg, 90.0) || nearly_eq(deg, -90.0))
+            w.push(id, EZPZ_WARN_SHOULD_BE_PERPENDICULAR);
+    }
+}
+
+// constraints.rs:146-193
+void set_from_initial_values(EzpzConstraint& c, const std::vector<double>& iv) {
+    auto X = [&](int k) { return iv[c.ids[k]]; };
+    if (c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE && c.tag == EZPZ_SIDE_UNDEFINED) {
+        double ux = X(2) - X(0), uy = X(3) - X(1);
+        double vx = X(4) - X(0), vy = X(5) - X(1);
+        c.tag = (ux * vy - uy * vx >= 0.0) ? EZPZ_LINE_LEFT : EZPZ_LINE_RIGHT;
+    } else if (c.kind == EZPZ_CIRCLE_TANGENT_TO_CIRCLE && c.tag == EZPZ_SIDE_UNDEFINED) {
+        double dist = std::hypot(X(0) - X(3), X(1) - X(4));
+        double a_r = X(2), b_r = X(5);
+        double r_int = std::fabs(std::fabs(a_r - b_r) - dist);
+        double r_ext = std::fabs(a_r + b_r - dist);
+        c.tag = (r_int < r_ext) ? EZPZ_CIRCLE_INTERIOR : EZPZ_CIRCLE_EXTERIOR;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
+                     const double* guesses, size_t n_guesses, const EzpzConfig* cfg, double* x_out,
+                     uint64_t* unsat_ids, EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out) {
+    if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    out->num_vars = n_guesses;
+    uint64_t num_eqs = 0;
+    for (size_t i = 0; i < n_cs; ++i) num_eqs += (uint64_t)residual_dim(cs[i].kind);
+    out->num_eqs = num_eqs;
+    WarnSink sink{warn_buf, warn_cap, 0};
+    lint(cs, orig_ids, n_cs, sink);
+    out->n_warnings = sink.count;
+    EzpzConfig dcfg;
+    if (!cfg) {
+        ezpz_default_config(&dcfg);
+        cfg = &dcfg;
+    }
+    // validate_variables (solver.rs:142-189): every id a constraint's rows mention must appear among the
+    // guess ids.  Values are then addressed by id (Layout::index_of, solver.rs:107-109), so an id that is
+    // present but >= n_guesses cannot be placed in the matrix (faer CreationError in the reference).
+    bool dense = true;
+    for (size_t i = 0; i < n_guesses && var_ids; ++i)
+        if (var_ids[i] != i) dense = false;
+    if (!dense) {
+        uint32_t max_id = 0;
+        for (size_t i = 0; i < n_guesses; ++i) max_id = std::max(max_id, var_ids[i]);
+        std::vector<uint8_t> present((size_t)max_id + 1, 0);
+        for (size_t i = 0; i < n_guesses; ++i) present[var_ids[i]] = 1;
+        for (size_t i = 0; i < n_cs; ++i) {
+            if (cs[i].kind >= EZPZ_NUM_KINDS) continue;
+            const KindInfo& K = kKinds[cs[i].kind];
+            for (int r = 0; r < K.n_rows; ++r)
+                for (int e = 0; e < K.n_nz[r]; ++e) {
+                    uint32_t v = cs[i].ids[K.nz[r][e]];
+                    if (v > max_id || !present[v]) {
+                        out->error = EZPZ_ERR_MISSING_GUESS;
+                        out->err_constraint_id = (int32_t)(orig_ids ? orig_ids[i] : i);
+                        out->err_variable = v;
+                        return out->error;
+                    }
+                }
+        }
+    }
+    EzpzSystem* sys = nullptr;
+    int32_t ec = -1;
+    int64_t ev = -1;
+    int rc = cached_system(cs, n_cs, n_guesses, &sys, &ec, &ev);
+    if (rc != EZPZ_OK) {
+        if (rc == EZPZ_ERR_MISSING_GUESS && !dense) rc = EZPZ_ERR_MATRIX;  // id has a guess but no column
+        out->error = rc;
+        if (rc == EZPZ_ERR_MISSING_GUESS) {
+            out->err_constraint_id = (int32_t)((orig_ids && ec >= 0) ? orig_ids[ec] : ec);
+            out->err_variable = ev;
+        }
+        return rc;
+    }
+    if (num_eqs == 0 && cfg->max_iterations > 0) {  // newton.rs:54
+        out->error = EZPZ_ERR_EMPTY_SYSTEM;
+        return out->error;
+    }
+    // Every evaluation sweep may warn about every constraint: size the log so nothing is dropped.
+    uint64_t want_log = (uint64_t)n_cs * (2 + 2 * std::min<uint64_t>(cfg->max_iterations, 1u << 20));
+    uint32_t log_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want_log, 1), 1u << 22);
+    std::vector<uint64_t> log(log_cap);
+    std::vector<uint8_t> mask(std::max<size_t>(n_cs, 1));
+    std::vector<double> x(std::max<size_t>(n_guesses, 1));
+    EzpzStatus st{};
+    rc = ezpz_system_solve_batch(sys, guesses, 1, cfg, x.data(), &st, mask.data(), log.data(), log_cap);
+    if (rc != EZPZ_OK) {
+        out->error = rc;
+        return rc;
+    }
+    // Degenerate warnings in the reference's chronological order: sweep number, then constraint position;
+    // about_constraint is the position inside this tier's slice (solver.rs:327,:343).
+    uint32_t nlog = std::min<uint32_t>(st.n_warnings, log_cap);
+    std::sort(log.begin(), log.begin() + nlog);
+    for (uint32_t i = 0; i < nlog; ++i) sink.push((int32_t)(log[i] & 0xFFFFFFFFu), EZPZ_WARN_DEGENERATE);
+    sink.count += st.n_warnings - nlog;
+    out->n_warnings = sink.count;
+    uint64_t n_unsat = 0;
+    for (size_t i = 0; i < n_cs; ++i) {
+        if (mask[i]) {
+            if (unsat_ids) unsat_ids[n_unsat] = orig_ids ? orig_ids[i] : i;
+            ++n_unsat;
+        }
+    }
+    out->n_unsatisfied = n_unsat;
+    uint32_t lowest = 0;  // lib.rs:340-344
+    for (size_t i = 0; i < n_cs; ++i) lowest = std::max(lowest, cs[i].priority);
+    out->priority_solved = lowest;
+    out->iterations = st.iterations;
+    out->converged = (int32_t)st.converged;
+    out->final_lambda = st.final_lambda;
+    out->final_residual_inf = st.final_residual_inf;
+    if (x_out && n_guesses) std::memcpy(x_out, x.data(), n_guesses * sizeof(double));
+    return EZPZ_OK;
+}
+
+int ezpz_solve(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+               size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
+               size_t warn_cap, EzpzOutcome* out) {
+    if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    if (n_reqs == 0) {  // lib.rs:155-170
+        if (x_out && n_guesses) std::memcpy(x_out, guesses, n_guesses * sizeof(double));
+        out->converged = 1;
+        out->num_vars = n_guesses;
+        return EZPZ_OK;
+    }
+    // initial_values[id] = guess (lib.rs:172-180), then side inference (lib.rs:183-186)
+    size_t max_id = 0;
+    for (size_t i = 0; i < n_guesses; ++i) max_id = std::max<size_t>(max_id, var_ids ? var_ids[i] : i);
+    std::vector<double> initial_values(max_id + 1, 0.0);
+    for (size_t i = 0; i < n_guesses; ++i) initial_values[var_ids ? var_ids[i] : i] = guesses[i];
+    std::vector<EzpzConstraint> reqs(reqs_in, reqs_in + n_reqs);
+    for (auto& c : reqs) {
+        if ((c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE || c.kind == EZPZ_CIRCLE_TANGENT_TO_CIRCLE) &&
+            c.tag == EZPZ_SIDE_UNDEFINED) {
+            bool ok = n_guesses > 0;
+            int cnt = c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE ? 7 : 6;
+            for (int k = 0; k < cnt; ++k)
+                if (c.ids[k] > max_id) ok = false;  // the reference would panic on this index; leave Undefined
+            if (ok) set_from_initial_values(c, initial_values);
+        }
+    }
+    // distinct priorities, ascending (lib.rs:199-203)
+    std::vector<uint32_t> prios;
+    for (auto& c : reqs) prios.push_back(c.priority);
+    std::sort(prios.begin(), prios.end());
+    prios.erase(std::unique(prios.begin(), prios.end()), prios.end());
+
+    std::vector<EzpzConstraint> subset;
+    std::vector<uint64_t> subset_ids;
+    std::vector<double> x_try(std::max<size_t>(n_guesses, 1));
+    std::vector<uint64_t> unsat_try(n_reqs + 1);
+    std::vector<EzpzWarning> warn_try(std::max<size_t>(warn_cap, 1));
+    bool have_res = false;
+    int rc_final = EZPZ_OK;
+    auto adopt = [&](const EzpzOutcome& o) {
+        *out = o;
+        if (warn_buf && warn_cap) {
+            size_t nw = (size_t)std::min<uint64_t>(o.n_warnings, warn_cap);
+            std::memcpy(warn_buf, warn_try.data(), nw * sizeof(EzpzWarning));
+        }
+    };
+    for (uint32_t curr_max_priority : prios) {
+        subset.clear();
+        subset_ids.clear();
+        for (size_t i = 0; i < n_reqs; ++i) {
+            if (reqs[i].priority <= curr_max_priority) {
+                subset.push_back(reqs[i]);
+                subset_ids.push_back(i);
+            }
+        }
+        EzpzOutcome o;
+        int rc = ezpz_solve_inner(subset.data(), subset_ids.data(), subset.size(), var_ids, guesses, n_guesses, cfg,
+                                  x_try.data(), unsat_try.data(), warn_try.data(), warn_cap, &o);
+        if (rc == EZPZ_OK) {
+            if (o.n_unsatisfied > 0 && have_res) break;  // lib.rs:232-234
+            adopt(o);
+            if (x_out && n_guesses) std::memcpy(x_out, x_try.data(), n_guesses * sizeof(double));
+            if (unsat_ids) std::memcpy(unsat_ids, unsat_try.data(), (size_t)o.n_unsatisfied * sizeof(uint64_t));
+            have_res = true;
+            if (o.n_unsatisfied > 0) break;
+        } else {
+            if (!have_res) {  // lib.rs:239-244
+                adopt(o);
+                rc_final = rc;
+            }
+            break;
+        }
+    }
+    return rc_final;
+}
+
+}  // extern "C"

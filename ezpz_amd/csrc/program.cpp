@@ -1,0 +1,449 @@
+// Host symbolic phase (see program.hpp).  Plain C++17, no device code.
+#include "program.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "kinds.hpp"
+
+namespace ezpz {
+
+int residual_dim(uint16_t kind) { return kind < EZPZ_NUM_KINDS ? kKinds[kind].n_rows : 1; }
+int kind_num_ids(uint16_t kind) { return kind < EZPZ_NUM_KINDS ? kKinds[kind].n_ids : 0; }
+
+uint64_t topology_hash(const EzpzConstraint* cs, size_t n_cs, size_t n_vars) {
+    // FNV-1a over the whole request bytes (params and weights live in the program too).
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)n_vars;
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(cs);
+    for (size_t i = 0; i < n_cs * sizeof(EzpzConstraint); ++i) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// Minimum-degree ordering of one connected component of the JtJ graph (exact degrees, explicit
+// elimination graph).  Components in constraint sketches are small; beyond `kMinDegLimit` vertices we
+// keep the natural order instead.
+constexpr size_t kMinDegLimit = 4096;
+
+void order_component(const std::vector<uint32_t>& verts, const std::vector<std::vector<uint32_t>>& adj,
+                     std::vector<uint32_t>& local_id, std::vector<uint32_t>& out_order) {
+    const size_t k = verts.size();
+    if (k <= 2 || k > kMinDegLimit) {
+        for (uint32_t v : verts) out_order.push_back(v);
+        return;
+    }
+    for (size_t i = 0; i < k; ++i) local_id[verts[i]] = (uint32_t)i;
+    std::vector<std::vector<uint32_t>> g(k);
+    for (size_t i = 0; i < k; ++i) {
+        for (uint32_t w : adj[verts[i]]) g[i].push_back(local_id[w]);
+        std::sort(g[i].begin(), g[i].end());
+    }
+    std::vector<char> gone(k, 0);
+    std::vector<uint32_t> merged;
+    for (size_t step = 0; step < k; ++step) {
+        size_t best = k;
+        size_t best_deg = (size_t)-1;
+        for (size_t i = 0; i < k; ++i) {
+            if (!gone[i] && g[i].size() < best_deg) {
+                best_deg = g[i].size();
+                best = i;
+            }
+        }
+        gone[best] = 1;
+        out_order.push_back(verts[best]);
+        const std::vector<uint32_t> nb = g[best];
+        for (uint32_t u : nb) {
+            // g[u] = (g[u] \ {best}) U (nb \ {u})
+            merged.clear();
+            std::set_union(g[u].begin(), g[u].end(), nb.begin(), nb.end(), std::back_inserter(merged));
+            std::vector<uint32_t>& gu = g[u];
+            gu.clear();
+            for (uint32_t w : merged)
+                if (w != u && w != best) gu.push_back(w);
+        }
+        g[best].clear();
+    }
+}
+
+}  // namespace
+
+bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& P, BuildError& err) {
+    P = Program();
+    if (n_cs > 0x7FFFFFF0u || n_vars > 0x7FFFFFF0u) {
+        err.code = EZPZ_ERR_TOO_LARGE;
+        err.message = "more than 2^31 constraints or variables";
+        return false;
+    }
+    // ---- validate (solver.rs:142-189) + row numbering (solver.rs:226-253) --------------------------
+    uint64_t m64 = 0;
+    for (size_t i = 0; i < n_cs; ++i) {
+        const EzpzConstraint& c = cs[i];
+        if (c.kind >= EZPZ_NUM_KINDS) {
+            err.code = EZPZ_ERR_INVALID_ARGUMENT;
+            err.constraint = (int32_t)i;
+            err.message = "unknown constraint kind";
+            return false;
+        }
+        const KindInfo& K = kKinds[c.kind];
+        for (int r = 0; r < K.n_rows; ++r) {
+            for (int e = 0; e < K.n_nz[r]; ++e) {
+                uint32_t v = c.ids[K.nz[r][e]];
+                if (v >= n_vars) {
+                    err.code = EZPZ_ERR_MISSING_GUESS;
+                    err.constraint = (int32_t)i;
+                    err.variable = v;
+                    return false;
+                }
+            }
+        }
+        m64 += K.n_rows;
+    }
+    if (m64 > 0x7FFFFFF0u) {
+        err.code = EZPZ_ERR_TOO_LARGE;
+        return false;
+    }
+    const uint32_t n = (uint32_t)n_vars, C = (uint32_t)n_cs, m = (uint32_t)m64;
+    P.c.n_cons = C;
+    P.c.n_vars = n;
+    P.c.n_rows = m;
+
+    // ---- constraint table + Jacobian slots -----------------------------------------------------------
+    // Slots are constraint-contiguous; within a row equal column ids share one slot (the reference
+    // deduplicates (row,col) pairs and accumulates partials into the shared cell, solver.rs:255-260,:418).
+    std::vector<DevCon> cons(C);
+    // column view of J, built in row order so b = -Jt r sums rows ascending
+    std::vector<std::vector<uint32_t>> colj(n);  // (jslot,row) flattened
+    // row view: cols and slots per row (unique)
+    std::vector<uint32_t> row_ptr(m + 1, 0), row_col, row_slot;
+    row_col.reserve((size_t)m * 4);
+    row_slot.reserve((size_t)m * 4);
+    uint32_t row_num = 0, jslot = 0;
+    for (uint32_t i = 0; i < C; ++i) {
+        const EzpzConstraint& c = cs[i];
+        const KindInfo& K = kKinds[c.kind];
+        DevCon& d = cons[i];
+        std::memset(&d, 0, sizeof(d));
+        std::memcpy(d.ids, c.ids, sizeof(d.ids));
+        for (int k = K.n_ids; k < 8; ++k) d.ids[k] = 0;  // never dereference garbage
+        d.param = c.param;
+        d.weight = c.weight;
+        d.row0 = row_num;
+        d.jbase = jslot;
+        d.pos = i;
+        d.kind = (uint8_t)c.kind;
+        d.tag = c.tag;
+        d.nrows = K.n_rows;
+        uint32_t local = 0;
+        int e_global = 0;
+        for (int r = 0; r < K.n_rows; ++r) {
+            uint32_t first_local_of_row = local;
+            for (int e = 0; e < K.n_emit[r]; ++e, ++e_global) {
+                uint32_t col = c.ids[K.emit[r][e]];
+                // search earlier entries of this row for the same column
+                int dup = -1;
+                for (int e2 = 0; e2 < e; ++e2)
+                    if (c.ids[K.emit[r][e2]] == col) {
+                        dup = e2;
+                        break;
+                    }
+                if (dup >= 0) {
+                    d.jloc[e_global] = (uint8_t)((d.jloc[e_global - e + dup] & 0x7F) | 0x80);
+                } else {
+                    d.jloc[e_global] = (uint8_t)local;
+                    row_col.push_back(col);
+                    row_slot.push_back(jslot + local);
+                    colj[col].push_back(jslot + local);
+                    colj[col].push_back(row_num);
+                    ++local;
+                }
+            }
+            (void)first_local_of_row;
+            ++row_num;
+            row_ptr[row_num] = (uint32_t)row_col.size();
+        }
+        d.nslots = (uint8_t)local;
+        jslot += local;
+    }
+    P.c.zj = jslot;
+
+    // ---- JtJ graph, connected components ----------------------------------------------------------------
+    std::vector<std::vector<uint32_t>> adj(n);
+    for (uint32_t r = 0; r < m; ++r) {
+        for (uint32_t a = row_ptr[r]; a < row_ptr[r + 1]; ++a)
+            for (uint32_t b = row_ptr[r]; b < row_ptr[r + 1]; ++b)
+                if (a != b) adj[row_col[a]].push_back(row_col[b]);
+    }
+    uint64_t za = n;
+    for (uint32_t v = 0; v < n; ++v) {
+        std::sort(adj[v].begin(), adj[v].end());
+        adj[v].erase(std::unique(adj[v].begin(), adj[v].end()), adj[v].end());
+        for (uint32_t w : adj[v])
+            if (w < v) ++za;
+    }
+    P.c.za = (uint32_t)za;
+    std::vector<uint32_t> comp(n, NONE);
+    std::vector<uint32_t> order;  // position -> var
+    order.reserve(n);
+    {
+        std::vector<uint32_t> stack, verts, local_id(n, 0);
+        uint32_t ncomp = 0;
+        for (uint32_t s = 0; s < n; ++s) {
+            if (comp[s] != NONE) continue;
+            verts.clear();
+            stack.clear();
+            stack.push_back(s);
+            comp[s] = ncomp;
+            while (!stack.empty()) {
+                uint32_t v = stack.back();
+                stack.pop_back();
+                verts.push_back(v);
+                for (uint32_t w : adj[v])
+                    if (comp[w] == NONE) {
+                        comp[w] = ncomp;
+                        stack.push_back(w);
+                    }
+            }
+            std::sort(verts.begin(), verts.end());
+            order_component(verts, adj, local_id, order);
+            ++ncomp;
+        }
+        P.c.n_components = ncomp;
+    }
+    std::vector<uint32_t> pos(n);
+    for (uint32_t k = 0; k < n; ++k) pos[order[k]] = k;
+
+    // ---- symbolic Cholesky in elimination order: etree, row patterns, levels ------------------------------
+    std::vector<std::vector<uint32_t>> upper(n);  // upper[k] = positions i<k adjacent to k
+    for (uint32_t k = 0; k < n; ++k) {
+        for (uint32_t w : adj[order[k]])
+            if (pos[w] < k) upper[k].push_back(pos[w]);
+        std::sort(upper[k].begin(), upper[k].end());
+    }
+    std::vector<uint32_t> parent(n, NONE), ancestor(n, NONE);
+    for (uint32_t k = 0; k < n; ++k) {
+        for (uint32_t i0 : upper[k]) {
+            uint32_t i = i0;
+            while (i != NONE && i < k) {
+                uint32_t inext = ancestor[i];
+                ancestor[i] = k;
+                if (inext == NONE) parent[i] = k;
+                i = inext;
+            }
+        }
+    }
+    std::vector<std::vector<uint32_t>> rowpat(n);   // columns j<k with L(k,j) != 0, ascending
+    std::vector<std::vector<uint32_t>> colrows(n);  // rows k>j with L(k,j) != 0, ascending
+    {
+        std::vector<uint32_t> flag(n, NONE);
+        uint64_t zlo = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            flag[k] = k;
+            for (uint32_t i0 : upper[k]) {
+                for (uint32_t i = i0; flag[i] != k; i = parent[i]) {
+                    rowpat[k].push_back(i);
+                    flag[i] = k;
+                }
+            }
+            std::sort(rowpat[k].begin(), rowpat[k].end());
+            zlo += rowpat[k].size();
+            for (uint32_t j : rowpat[k]) colrows[j].push_back(k);
+            if (zlo > 0x3FFFFFFFull) {
+                err.code = EZPZ_ERR_TOO_LARGE;
+                err.message = "Cholesky factor has more than 2^30 entries";
+                return false;
+            }
+        }
+        P.c.zlo = (uint32_t)zlo;
+    }
+    std::vector<uint32_t> level(n, 0);
+    uint32_t nlev = n ? 1 : 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        if (parent[j] != NONE) level[parent[j]] = std::max(level[parent[j]], level[j] + 1);
+        nlev = std::max(nlev, level[j] + 1);
+    }
+    P.c.n_levels = nlev;
+    // columns grouped by level
+    std::vector<uint32_t> colorder(n);
+    std::iota(colorder.begin(), colorder.end(), 0u);
+    std::stable_sort(colorder.begin(), colorder.end(), [&](uint32_t a, uint32_t b) { return level[a] < level[b]; });
+    P.lvl_cptr.assign(nlev + 1, 0);
+    P.lvl_sptr.assign(nlev + 1, 0);
+    P.lvl_cols.resize(n);
+    std::vector<uint32_t> col_slot0(n, 0);  // first offdiag slot of column (position space)
+    {
+        uint32_t slot = 0, idx = 0;
+        for (uint32_t lv = 0; lv < nlev; ++lv) {
+            P.lvl_cptr[lv] = idx;
+            P.lvl_sptr[lv] = slot;
+            while (idx < n && level[colorder[idx]] == lv) {
+                uint32_t j = colorder[idx];
+                P.lvl_cols[idx] = order[j];
+                col_slot0[j] = slot;
+                slot += (uint32_t)colrows[j].size();
+                ++idx;
+            }
+        }
+        P.lvl_cptr[nlev] = idx;
+        P.lvl_sptr[nlev] = slot;
+    }
+    const uint32_t zlo = P.c.zlo;
+    // slot lookup per row: rowslot[k][t] = slot of (k, rowpat[k][t])
+    std::vector<std::vector<uint32_t>> rowslot(n);
+    for (uint32_t k = 0; k < n; ++k) rowslot[k].resize(rowpat[k].size());
+    P.l_col.assign(zlo, 0);
+    {
+        std::vector<uint32_t> fill(n, 0);  // how many entries of rowpat[k] have been assigned
+        // colrows[j] ascending in k and rowpat[k] ascending in j: entry (k,j) index within rowpat[k] found by search
+        for (uint32_t j = 0; j < n; ++j) {
+            uint32_t s = col_slot0[j];
+            for (uint32_t k : colrows[j]) {
+                auto it = std::lower_bound(rowpat[k].begin(), rowpat[k].end(), j);
+                rowslot[k][(size_t)(it - rowpat[k].begin())] = s;
+                P.l_col[s] = order[j];
+                ++s;
+            }
+        }
+        (void)fill;
+    }
+    auto find_slot = [&](uint32_t k, uint32_t j) -> uint32_t {  // k > j positions
+        auto it = std::lower_bound(rowpat[k].begin(), rowpat[k].end(), j);
+        if (it == rowpat[k].end() || *it != j) return NONE;
+        return rowslot[k][(size_t)(it - rowpat[k].begin())];
+    };
+
+    // ---- column view of J -------------------------------------------------------------------------------------
+    P.colj_ptr.assign(n + 1, 0);
+    for (uint32_t v = 0; v < n; ++v) P.colj_ptr[v + 1] = P.colj_ptr[v] + (uint32_t)(colj[v].size() / 2);
+    P.colj_items.reserve((size_t)P.c.zj * 2);
+    for (uint32_t v = 0; v < n; ++v) P.colj_items.insert(P.colj_items.end(), colj[v].begin(), colj[v].end());
+
+    // ---- J-slot pairs for the strict lower part of JtJ, keyed by L slot ----------------------------------------------
+    {
+        std::vector<uint32_t> cnt(zlo + 1, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                P.apair_ptr.assign(zlo + 1, 0);
+                for (uint32_t s = 0; s < zlo; ++s) P.apair_ptr[s + 1] = P.apair_ptr[s] + cnt[s];
+                P.c.n_apairs = P.apair_ptr[zlo];
+                P.apairs.assign((size_t)P.c.n_apairs * 2, 0);
+                std::fill(cnt.begin(), cnt.end(), 0);
+            }
+            for (uint32_t r = 0; r < m; ++r) {
+                for (uint32_t a = row_ptr[r]; a < row_ptr[r + 1]; ++a) {
+                    for (uint32_t b = row_ptr[r]; b < row_ptr[r + 1]; ++b) {
+                        uint32_t pa = pos[row_col[a]], pb = pos[row_col[b]];
+                        if (pa <= pb) continue;  // (row pa, col pb), pa > pb
+                        uint32_t s = find_slot(pa, pb);
+                        if (s == NONE) {
+                            err.code = EZPZ_ERR_INVALID_ARGUMENT;
+                            err.message = "internal: JtJ entry outside L pattern";
+                            return false;
+                        }
+                        if (pass == 1) {
+                            size_t o = ((size_t)P.apair_ptr[s] + cnt[s]) * 2;
+                            P.apairs[o] = row_slot[a];
+                            P.apairs[o + 1] = row_slot[b];
+                        }
+                        ++cnt[s];
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- Cholesky pair lists: L(i,j) -= sum_k L(i,k) L(j,k), k < j ---------------------------------------------------
+    {
+        uint64_t total = 0;
+        P.lpair_ptr.assign(zlo + 1, 0);
+        // count
+        for (uint32_t j = 0; j < n; ++j) {
+            uint32_t s = col_slot0[j];
+            for (uint32_t k : colrows[j]) {
+                // |{c in rowpat[k], c<j} ^ rowpat[j]|
+                const auto& A = rowpat[k];
+                const auto& B = rowpat[j];
+                size_t ia = 0, ib = 0, cntp = 0;
+                while (ia < A.size() && ib < B.size() && A[ia] < j) {
+                    if (A[ia] == B[ib]) {
+                        ++cntp;
+                        ++ia;
+                        ++ib;
+                    } else if (A[ia] < B[ib])
+                        ++ia;
+                    else
+                        ++ib;
+                }
+                P.lpair_ptr[s + 1] = (uint32_t)cntp;
+                total += cntp;
+                ++s;
+            }
+        }
+        if (total > 0x7FFFFFFFull) {
+            err.code = EZPZ_ERR_TOO_LARGE;
+            err.message = "sparse Cholesky needs more than 2^31 multiply-adds per factorisation";
+            return false;
+        }
+        for (uint32_t s = 0; s < zlo; ++s) P.lpair_ptr[s + 1] += P.lpair_ptr[s];
+        P.c.n_lpairs = total;
+        P.lpairs.assign((size_t)total * 2, 0);
+        for (uint32_t j = 0; j < n; ++j) {
+            uint32_t s = col_slot0[j];
+            for (uint32_t k : colrows[j]) {
+                const auto& A = rowpat[k];
+                const auto& B = rowpat[j];
+                size_t ia = 0, ib = 0;
+                size_t o = (size_t)P.lpair_ptr[s] * 2;
+                while (ia < A.size() && ib < B.size() && A[ia] < j) {
+                    if (A[ia] == B[ib]) {
+                        P.lpairs[o++] = rowslot[k][ia];
+                        P.lpairs[o++] = rowslot[j][ib];
+                        ++ia;
+                        ++ib;
+                    } else if (A[ia] < B[ib])
+                        ++ia;
+                    else
+                        ++ib;
+                }
+                ++s;
+            }
+        }
+    }
+
+    // ---- rows / columns of L for the triangular solves (indexed by variable id) -----------------------------------------
+    P.fwd_ptr.assign(n + 1, 0);
+    P.bwd_ptr.assign(n + 1, 0);
+    for (uint32_t v = 0; v < n; ++v) {
+        P.fwd_ptr[v + 1] = P.fwd_ptr[v] + (uint32_t)rowpat[pos[v]].size();
+        P.bwd_ptr[v + 1] = P.bwd_ptr[v] + (uint32_t)colrows[pos[v]].size();
+    }
+    P.fwd_items.assign((size_t)zlo * 2, 0);
+    P.bwd_items.assign((size_t)zlo * 2, 0);
+    for (uint32_t v = 0; v < n; ++v) {
+        uint32_t k = pos[v];
+        size_t o = (size_t)P.fwd_ptr[v] * 2;
+        for (size_t t = 0; t < rowpat[k].size(); ++t) {
+            P.fwd_items[o++] = rowslot[k][t];
+            P.fwd_items[o++] = order[rowpat[k][t]];
+        }
+        o = (size_t)P.bwd_ptr[v] * 2;
+        uint32_t s = col_slot0[k];
+        for (uint32_t rk : colrows[k]) {
+            P.bwd_items[o++] = s++;
+            P.bwd_items[o++] = order[rk];
+        }
+    }
+
+    // ---- kind-sort the constraint table (wave-uniform evaluator branches) -------------------------------------------------
+    std::stable_sort(cons.begin(), cons.end(), [](const DevCon& a, const DevCon& b) { return a.kind < b.kind; });
+    P.cons = std::move(cons);
+    return true;
+}
+
+}  // namespace ezpz

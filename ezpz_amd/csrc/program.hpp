@@ -1,0 +1,76 @@
+// Host-side symbolic phase: turns one tier of constraints into the device "topology program".
+//
+// This is the MI355X-side counterpart of Model::new (reference ezpz/src/solver.rs:192-300): where the
+// reference builds a CSC pattern and asks faer for a SymbolicLlt, we emit flat index lists that the LM
+// kernel walks with one lane per list:
+//   * constraint table (kind-sorted, with the Jacobian slot of every partial it emits),
+//   * column view of J            -> diag(JtJ) and b = -Jt r,
+//   * J-slot pair lists           -> strict lower part of JtJ, stored directly in L's slots,
+//   * elimination-tree levels     -> level-scheduled sparse Cholesky (pair lists per L entry),
+//   * row / column lists of L     -> forward / backward substitution.
+// Nothing here depends on variable values, so it is computed once per topology and cached.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ezpz_amd.h"
+
+namespace ezpz {
+
+// One constraint as the kernel sees it.  96 bytes.
+struct DevCon {
+    uint32_t ids[8];
+    double param;
+    double weight;
+    uint32_t row0;   // first residual row (rows are numbered in request order, solver.rs:226-253)
+    uint32_t jbase;  // first Jacobian slot owned by this constraint
+    uint32_t pos;    // position in the caller's constraint list (for unsat mask / warnings)
+    uint8_t kind, tag, nrows, nslots;
+    uint8_t jloc[16];  // per emitted partial: slot offset from jbase; bit 7 = accumulate into an earlier entry's slot
+    uint8_t pad[16];
+};
+static_assert(sizeof(DevCon) == 96, "DevCon layout");
+
+struct ProgramCounts {
+    uint32_t n_cons = 0, n_vars = 0, n_rows = 0;
+    uint32_t zj = 0;       // Jacobian slots (= nnz(J) of the reference's deduplicated CSC)
+    uint32_t zlo = 0;      // strictly-lower entries of L
+    uint32_t za = 0;       // nnz(lower(JtJ + lambda I)) incl. diagonal
+    uint32_t n_levels = 0;
+    uint32_t n_components = 0;
+    uint64_t n_apairs = 0, n_lpairs = 0;
+};
+
+struct Program {
+    ProgramCounts c;
+    std::vector<DevCon> cons;                          // kind-sorted
+    std::vector<uint32_t> colj_ptr, colj_items;        // per var: (jslot,row)*
+    std::vector<uint32_t> apair_ptr, apairs;           // per L offdiag slot: (ja,jb)*
+    std::vector<uint32_t> lvl_cptr, lvl_cols;          // per level: vars whose column is eliminated there
+    std::vector<uint32_t> lvl_sptr;                    // per level: first offdiag slot
+    std::vector<uint32_t> l_col;                       // per offdiag slot: var of its column
+    std::vector<uint32_t> lpair_ptr, lpairs;           // per offdiag slot: (slot_ik, slot_jk)*
+    std::vector<uint32_t> fwd_ptr, fwd_items;          // per var j: (slot(j,k), var k)*  -- row of L
+    std::vector<uint32_t> bwd_ptr, bwd_items;          // per var j: (slot(i,j), var i)*  -- column of L
+};
+
+struct BuildError {
+    int code = EZPZ_OK;
+    int32_t constraint = -1;
+    int64_t variable = -1;
+    std::string message;
+};
+
+// residual_dim, constraints.rs:954-993
+int residual_dim(uint16_t kind);
+// number of ids a kind uses
+int kind_num_ids(uint16_t kind);
+
+// Builds the program.  Returns false and fills `err` on MissingGuess / bad ids / size limits.
+bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& out, BuildError& err);
+
+// 64-bit topology hash (kinds, tags, ids; not params/weights) for the host-side program cache.
+uint64_t topology_hash(const EzpzConstraint* cs, size_t n_cs, size_t n_vars);
+
+}  // namespace ezpz

@@ -1,0 +1,225 @@
+/*
+ * ezpz_amd.h -- C ABI of the MI355X-native ezpz constraint-solve path.
+ *
+ * This is the drop-in boundary for ONE path of KittyCAD/ezpz: the Newton / Levenberg-Marquardt
+ * constraint-solve loop.  The reference has no FFI seam of its own (it is a pure-Rust crate); the
+ * seam is the public function `ezpz::solve` and, inside it, `solve_inner` -> `Model::new` +
+ * `Model::solve_levenberg_marquardt`.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference checkout).  A Rust shim binding these symbols is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, caller owns every buffer, nothing throws, return value is
+ * 0 (EZPZ_OK) or a negative EzpzError that mirrors `NonLinearSystemError` (ezpz/src/error.rs:35-86).
+ * All arithmetic is IEEE fp64.  The library needs a HIP device (gfx950); without one every solve
+ * entry point returns EZPZ_ERR_NO_DEVICE -- there is no CPU fallback.
+ */
+#ifndef EZPZ_AMD_H
+#define EZPZ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Constraint, ezpz/src/constraints.rs:37-93 (kind = enum declaration order) ------------------ */
+enum EzpzKind {
+    EZPZ_LINE_TANGENT_TO_CIRCLE = 0,          /* ids: line p0.x p0.y p1.x p1.y, circle c.x c.y radius; tag = EzpzLineSide */
+    EZPZ_CIRCLE_TANGENT_TO_CIRCLE = 1,        /* ids: a.cx a.cy a.r b.cx b.cy b.r; tag = EzpzCircleSide */
+    EZPZ_DISTANCE = 2,                        /* ids: p0 p1; param = distance */
+    EZPZ_DISTANCE_VAR = 3,                    /* ids: p q D */
+    EZPZ_VERTICAL_DISTANCE = 4,               /* ids: p0 p1; param */
+    EZPZ_HORIZONTAL_DISTANCE = 5,             /* ids: p0 p1; param */
+    EZPZ_VERTICAL = 6,                        /* ids: line */
+    EZPZ_HORIZONTAL = 7,                      /* ids: line */
+    EZPZ_LINES_AT_ANGLE = 8,                  /* ids: line0 line1; tag = EzpzAngleKind; param = angle value */
+    EZPZ_FIXED = 9,                           /* ids: var; param = value */
+    EZPZ_SCALAR_EQUAL = 10,                   /* ids: a b */
+    EZPZ_POINTS_COINCIDENT = 11,              /* ids: p0 p1 */
+    EZPZ_CIRCLE_RADIUS = 12,                  /* ids: c.x c.y radius; param */
+    EZPZ_LINES_EQUAL_LENGTH = 13,             /* ids: line0 line1 */
+    EZPZ_ARC_RADIUS = 14,                     /* ids: arc; param */
+    EZPZ_ARC = 15,                            /* ids: arc */
+    EZPZ_MIDPOINT = 16,                       /* ids: line, point */
+    EZPZ_POINT_LINE_DISTANCE = 17,            /* ids: point, line; param */
+    EZPZ_VERTICAL_POINT_LINE_DISTANCE = 18,   /* ids: point, line; param */
+    EZPZ_HORIZONTAL_POINT_LINE_DISTANCE = 19, /* ids: point, line; param */
+    EZPZ_SYMMETRIC = 20,                      /* ids: line, a, b */
+    EZPZ_POINT_ARC_COINCIDENT = 21,           /* ids: arc, point */
+    EZPZ_ARC_LENGTH = 22,                     /* ids: arc; param */
+    EZPZ_ARC_ANGLE = 23,                      /* ids: arc; tag = EZPZ_ANGLE_OTHER_DEG/RAD; param */
+    EZPZ_POINTS_AT_ANGLE = 24,                /* ids: p0 p1 p2; tag = EzpzAngleKind; param */
+    EZPZ_NUM_KINDS = 25
+};
+/* datum id order: point = x,y; line = p0,p1; circle = center,radius; arc = center,start,end
+ * (struct field order of ezpz/src/datatypes/inputs.rs). */
+
+enum EzpzLineSide { EZPZ_SIDE_UNDEFINED = 0, EZPZ_LINE_LEFT = 1, EZPZ_LINE_RIGHT = 2 };   /* constraints.rs:109-116 */
+enum EzpzCircleSide { EZPZ_CIRCLE_EXTERIOR = 1, EZPZ_CIRCLE_INTERIOR = 2 };             /* constraints.rs:122-129 */
+enum EzpzAngleKind {                                                                     /* datatypes.rs:9-29 */
+    EZPZ_ANGLE_PARALLEL = 0,
+    EZPZ_ANGLE_PERPENDICULAR = 1,
+    EZPZ_ANGLE_OTHER_DEG = 2,
+    EZPZ_ANGLE_OTHER_RAD = 3
+};
+
+/* ConstraintRequest {constraint, priority, weight}, ezpz/src/constraint_request.rs.  56 bytes. */
+typedef struct EzpzConstraint {
+    uint16_t kind; /* EzpzKind */
+    uint8_t tag;
+    uint8_t flags; /* reserved, 0 */
+    uint32_t priority;
+    uint32_t ids[8];
+    double param;
+    double weight;
+} EzpzConstraint;
+
+/* Config, ezpz/src/solver.rs:31-81 */
+typedef struct EzpzConfig {
+    uint64_t max_iterations;   /* default 35 */
+    double residual_tolerance; /* default 1e-8 */
+    double step_tolerance;     /* default 1e-12 */
+    double initial_lambda;     /* default 1e-9 */
+} EzpzConfig;
+
+/* NonLinearSystemError, ezpz/src/error.rs:35-86 (+ library conditions <= -100) */
+enum EzpzError {
+    EZPZ_OK = 0,
+    EZPZ_ERR_NOT_FOUND = -1,
+    EZPZ_ERR_WRONG_NUMBER_GUESSES = -2,
+    EZPZ_ERR_MISSING_GUESS = -3,
+    EZPZ_ERR_MATRIX = -4, /* FaerMatrix: a variable id outside [0, n_vars) */
+    EZPZ_ERR_EMPTY_SYSTEM = -8,
+    EZPZ_ERR_NO_DEVICE = -100,
+    EZPZ_ERR_HIP = -101,
+    EZPZ_ERR_TOO_LARGE = -102,
+    EZPZ_ERR_INVALID_ARGUMENT = -103,
+    EZPZ_ERR_PARSE = -110,           /* textual front end: winnow parse failure */
+    EZPZ_ERR_TEXT_MISSING_GUESS = -111,  /* TextualError, error.rs:10-33 */
+    EZPZ_ERR_TEXT_UNUSED_GUESSES = -112,
+    EZPZ_ERR_TEXT_UNDEFINED_POINT = -113
+};
+
+/* Warning / WarningContent, ezpz/src/warnings.rs:8-32 */
+enum EzpzWarningContent { EZPZ_WARN_DEGENERATE = 0, EZPZ_WARN_SHOULD_BE_PARALLEL = 1, EZPZ_WARN_SHOULD_BE_PERPENDICULAR = 2 };
+typedef struct EzpzWarning {
+    int32_t about_constraint;
+    int32_t content;
+} EzpzWarning;
+
+/* Per-system result of the device LM loop: SuccessfulSolve (solver/newton.rs:18-24) plus what
+ * solve_inner derives (lib.rs:305-327).  32 bytes. */
+typedef struct EzpzStatus {
+    uint32_t iterations;
+    uint32_t converged;
+    uint32_t n_unsatisfied;
+    uint32_t n_warnings;       /* Degenerate warnings the model produced (every evaluation, no dedup) */
+    double final_residual_inf; /* max |weighted r| at exit */
+    double final_lambda;
+} EzpzStatus;
+
+/* SolveOutcome (solve_outcome.rs:12-26) / FailureOutcome (:126-136) in flat form. */
+typedef struct EzpzOutcome {
+    int32_t error; /* EzpzError; != 0 => FailureOutcome */
+    int32_t err_constraint_id;
+    int64_t err_variable;
+    uint64_t iterations;
+    int32_t converged;
+    uint32_t priority_solved;
+    uint64_t n_unsatisfied;
+    uint64_t n_warnings;
+    uint64_t num_vars;
+    uint64_t num_eqs;
+    double final_lambda;
+    double final_residual_inf;
+} EzpzOutcome;
+
+/* Sizes of one analysed topology (host symbolic phase), for roofline accounting. */
+typedef struct EzpzSystemInfo {
+    uint64_t n_constraints, n_vars, n_rows;
+    uint64_t nnz_j;  /* zJ */
+    uint64_t nnz_a;  /* zA: nnz(lower(JtJ + lambda I)) */
+    uint64_t nnz_l;  /* zL: nnz(L) incl. diagonal */
+    uint64_t n_levels;      /* elimination-tree height */
+    uint64_t n_components;  /* connected components of the variable graph */
+    uint64_t program_bytes; /* device-resident topology program */
+    uint64_t workspace_bytes; /* per-system LDS / global workspace */
+    uint32_t team_size;     /* lanes cooperating on one system */
+    uint32_t workspace_in_lds;
+} EzpzSystemInfo;
+
+typedef struct EzpzSystem EzpzSystem; /* opaque: one analysed topology, resident on one device */
+
+void ezpz_default_config(EzpzConfig* cfg); /* Config::default(), solver.rs:72-81 */
+int ezpz_device_count(void);
+const char* ezpz_error_string(int err);
+
+/* ---- symbolic phase ------------------------------------------------------------------------------
+ * Replaces Model::new (ezpz/src/solver.rs:192-300): validate_variables (:142-189), row numbering,
+ * Jacobian sparsity, and the symbolic Cholesky of JtJ + lambda I that faer's SymbolicLlt does there.
+ * `cs` is one priority tier, already side-resolved, in request order; ids index the value vector
+ * directly (Layout::index_of, solver.rs:107-109).  On MissingGuess, err_constraint/err_variable
+ * receive the offending position in `cs` and the id.  `team_size` 0 = choose automatically. */
+int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
+                       EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);
+void ezpz_system_destroy(EzpzSystem* sys);
+int ezpz_system_info(const EzpzSystem* sys, EzpzSystemInfo* info);
+
+/* Host-only analysis (no device needed): the same symbolic phase, sizes only. */
+int ezpz_analyze(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, EzpzSystemInfo* info, int32_t* err_constraint,
+                 int64_t* err_variable);
+
+/* ---- evaluation only (kernel K1 of the design: residual + Jacobian sweep) -----------------------------
+ * Replaces Model::residual + Model::refresh_jacobian (ezpz/src/solver.rs:318-440) for `batch` value
+ * vectors: r_out [batch][n_rows] weighted residuals, jv_out [batch][nnz_j] weighted Jacobian values in
+ * slot order; ezpz_system_jacobian_pattern gives the (row, col) of every slot.  Host pointers. */
+int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, double* r_out, double* jv_out,
+                           uint32_t* degenerate_count_out);
+int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t* cols);
+
+/* ---- numeric phase -------------------------------------------------------------------------------
+ * Replaces Model::solve_levenberg_marquardt (ezpz/src/solver/newton.rs:29-145) followed by the
+ * unsatisfied check of solve_inner (ezpz/src/lib.rs:305-327), for `batch` independent systems that
+ * share the analysed topology.  x0 / x_out are AoS [batch][n_vars] and may alias.  unsat_mask is
+ * optional ([batch][n_cs] bytes, 1 = unsatisfied, indexed by position in `cs`); warn_log is optional
+ * ([batch][warn_cap] entries (pass << 32 | position), chronological once sorted).
+ * The _device form takes device pointers and only enqueues on `stream` (a hipStream_t; NULL = default);
+ * the host form copies in, runs, copies out and synchronises. */
+int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
+                                   double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
+                                   uint64_t* warn_log_dev, uint32_t warn_cap, void* stream);
+int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out,
+                            EzpzStatus* status, uint8_t* unsat_mask, uint64_t* warn_log, uint32_t warn_cap);
+
+/* ---- solve_inner, ezpz/src/lib.rs:265-356: one tier, one system -----------------------------------
+ * lint (warnings.rs:34-60) + Model::new + LM + unsatisfied list.  orig_ids (may be NULL) are the
+ * ConstraintEntry.id values reported in `unsat_ids` and lint warnings. */
+int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
+                     const double* guesses, size_t n_guesses, const EzpzConfig* cfg, double* x_out,
+                     uint64_t* unsat_ids, EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out);
+
+/* ---- ezpz::solve, ezpz/src/lib.rs:80-87 -> solve_with_priority_inner (:148-263) ---------------------
+ * Side inference from the guesses (constraints.rs:146-193), priority tiers, returns the last fully
+ * satisfied tier.  guesses are (id, value) pairs exactly as the reference takes them.  x_out has
+ * n_guesses entries, unsat_ids up to n_reqs, warn_buf up to warn_cap. */
+int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+               size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
+               size_t warn_cap, EzpzOutcome* out);
+
+/* ---- textual front end, ezpz/src/textual.rs:43-49 (Problem: FromStr) + executor.rs:40-445 ------------ */
+typedef struct EzpzProblem EzpzProblem; /* opaque: parsed + lowered problem text */
+int ezpz_problem_parse(const char* text, size_t len, EzpzProblem** out, char* errbuf, size_t errcap);
+void ezpz_problem_destroy(EzpzProblem* p);
+size_t ezpz_problem_num_constraints(const EzpzProblem* p);
+size_t ezpz_problem_num_vars(const EzpzProblem* p);
+const EzpzConstraint* ezpz_problem_constraints(const EzpzProblem* p);
+const double* ezpz_problem_guesses(const EzpzProblem* p); /* values by id (id == index) */
+/* label tables, executor.rs:521-566: kind 0 = points, 1 = circles, 2 = arcs */
+size_t ezpz_problem_num_labels(const EzpzProblem* p, int kind);
+const char* ezpz_problem_label(const EzpzProblem* p, int kind, size_t index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EZPZ_AMD_H */

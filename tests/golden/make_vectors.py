@@ -1,0 +1,50 @@
+"""Generates tests/golden/oracle_vectors.json from the CPU oracle (which is itself pinned to the reference's
+known answers by tests/test_oracle_pins.py).  Inputs -> expected outputs for every reference fixture plus
+jittered variants, consumed by the GPU parity tests.  Run: python tests/golden/make_vectors.py"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import gen  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from oracle import textual as T  # noqa: E402
+
+
+def main():
+    out = {}
+    for path in sorted(glob.glob(os.path.join(HERE, "test_cases", "*", "*.md"))):
+        case = os.path.relpath(path, os.path.join(HERE, "test_cases"))
+        if case.startswith("massive"):
+            continue
+        cs = T.load(open(path).read())
+        variants = [cs.guesses]
+        jit = gen.keyed_uniform(0x657A707A, 3, cs.num_vars, -0.1, 0.1)
+        variants += [cs.guesses + jit[k] for k in range(3)]
+        recs = []
+        for g in variants:
+            o = O.solve(cs.constraints, g)
+            recs.append({
+                "guesses": [float(v) for v in g],
+                "final_values": [float(v) for v in o.final_values],
+                "iterations": o.iterations,
+                "converged": o.converged,
+                "unsatisfied": o.unsatisfied,
+                "n_warnings": len(o.warnings),
+                "final_residual_inf": o.final_residual_inf,
+            })
+        out[case] = recs
+    with open(os.path.join(HERE, "oracle_vectors.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", len(out), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol include/ezpz_amd.h
+declares, the C++ text front end agrees with the oracle's loader, the host symbolic phase reproduces the
+sizes SURVEY.md 8(d) states, and the host mirror packs the same records as the oracle's constructors.
+No compute entry point is called here (that needs a GPU; see tests/test_gpu_parity.py)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, read_case
+from oracle import oracle as O
+from oracle import textual as T
+
+import ezpz_amd as E
+from ezpz_amd._lib import EXPORTS
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ezpz_amd.h")).read()
+    declared = set(re.findall(r"\b(ezpz_[a-z_]+)\s*\(", header))
+    assert declared == set(EXPORTS), declared ^ set(EXPORTS)
+    L = E.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_struct_layouts_match_the_header():
+    from ezpz_amd._lib import CConfig, COutcome, CSystemInfo, CWarning
+
+    assert E.CONSTRAINT_DTYPE.itemsize == 56 and O.CONSTRAINT_DTYPE == E.CONSTRAINT_DTYPE
+    assert E.STATUS_DTYPE.itemsize == 32
+    assert C.sizeof(CConfig) == 32 and C.sizeof(CWarning) == 8 and C.sizeof(COutcome) == 80
+    assert C.sizeof(CSystemInfo) == 88
+
+
+def test_default_config():
+    from ezpz_amd._lib import CConfig
+
+    c = CConfig()
+    E.lib().ezpz_default_config(C.byref(c))
+    assert (c.max_iterations, c.residual_tolerance, c.step_tolerance, c.initial_lambda) == (35, 1e-8, 1e-12, 1e-9)
+    assert E.Config() == E.Config(35, 1e-8, 1e-12, 1e-9)
+    assert E.Config().with_max_iterations(200).with_convergence_tolerance(1e-10).max_iterations == 200
+
+
+def test_cpp_front_end_matches_oracle_loader_on_every_fixture():
+    files = sorted(glob.glob(os.path.join(GOLDEN, "test_cases", "*", "*.md")))
+    assert len(files) == 29
+    for f in files:
+        text = open(f).read()
+        a = E.textual.Problem.from_str(text).to_constraint_system()
+        b = T.load(text)
+        assert a.records.tobytes() == b.constraints.tobytes(), f
+        assert np.array_equal(a.guesses, b.guesses), f
+        assert (a.inner_points, a.inner_circles, a.inner_arcs) == (b.inner_points, b.inner_circles, b.inner_arcs)
+
+
+@pytest.mark.parametrize("bad", [
+    "# constraints\npoint p\n\n\n# guesses\np roughly (0,0)\n",
+    "# constraints\npoint p \n\n# guesses\np roughly (0,0)\n",
+    "# constraints\nfrobnicate(p)\n\n# guesses\np roughly (0,0)\n",
+    "# constraints\npoint p\n\n# guesses\np about (0,0)\n",
+])
+def test_cpp_front_end_rejects_malformed_text(bad):
+    with pytest.raises(E.textual.TextualError) as e:
+        E.textual.Problem.from_str(bad)
+    assert e.value.code == -110
+
+
+def test_cpp_front_end_textual_errors():
+    """executor.rs:673-744"""
+    for text, code in [("# constraints\npoint p\n\n# guesses\nq roughly (0,0)\n", -111),
+                       ("# constraints\npoint p\n\n# guesses\np roughly (0,0)\nghost roughly (1,1)\n", -112),
+                       ("# constraints\npoint p\nmissing.x = 2.5\n\n# guesses\np roughly (0,0)\n", -113)]:
+        with pytest.raises(E.textual.TextualError) as e:
+            E.textual.Problem.from_str(text)
+        assert e.value.code == code
+
+
+def test_symbolic_sizes_massive_and_square():
+    """massive N=500 -> C=m=n=2000, zJ=2500, zA=2500, zL=2500; square -> 10/10/8, zJ=40, A dense 8x8."""
+    cs = T.load(T.gen_big_problem(500))
+    i = E.analyze(cs.constraints, cs.num_vars)
+    assert (i["n_constraints"], i["n_rows"], i["n_vars"], i["nnz_j"], i["nnz_a"], i["nnz_l"]) == (2000, 2000, 2000, 2500, 2500, 2500)
+    assert i["n_levels"] == 2 and i["workspace_in_lds"] == 1
+    sq = T.load(read_case("square"))
+    j = E.analyze(sq.constraints, sq.num_vars)
+    assert (j["n_constraints"], j["n_rows"], j["n_vars"], j["nnz_j"], j["nnz_a"], j["nnz_l"]) == (10, 10, 8, 40, 36, 36)
+
+
+def test_symbolic_phase_reports_missing_guess():
+    """solver.rs:142-189: first id (row0 then row1, constraint order) that has no guess."""
+    with pytest.raises(E.NonLinearSystemError) as e:
+        E.analyze([O.fixed(0, 1.0), O.points_coincident((0, 1), (2, 7))], 4)
+    assert (e.value.code, e.value.constraint_id, e.value.variable) == (-3, 1, 7)
+
+
+def test_host_mirror_packs_the_same_records_as_the_oracle_constructors():
+    ids = E.IdGenerator()
+    p0, p1, p2, p3 = (E.DatumPoint.new(ids) for _ in range(4))
+    l0, l1 = E.DatumLineSegment.new(p0, p1), E.DatumLineSegment.new(p2, p3)
+    circ = E.DatumCircle(p2, E.DatumDistance.new(ids.next_id()))
+    circ2 = E.DatumCircle(p3, E.DatumDistance.new(ids.next_id()))
+    arc = E.DatumCircularArc(p0, p1, p2)
+    t = lambda p: (p.x_id, p.y_id)
+    pairs = [
+        (E.Constraint.LineTangentToCircle(l0, circ, E.LineSide.Right), O.line_tangent_to_circle(t(p0), t(p1), t(p2), 8, O.LINE_RIGHT)),
+        (E.Constraint.CircleTangentToCircle(circ, circ2, E.CircleSide.Interior), O.circle_tangent_to_circle(t(p2), 8, t(p3), 9, O.CIRCLE_INTERIOR)),
+        (E.Constraint.Distance(p0, p1, 2.5), O.distance(t(p0), t(p1), 2.5)),
+        (E.Constraint.DistanceVar(p0, p1, circ.radius), O.distance_var(t(p0), t(p1), 8)),
+        (E.Constraint.VerticalDistance(p0, p1, 1.0), O.vertical_distance(t(p0), t(p1), 1.0)),
+        (E.Constraint.HorizontalDistance(p0, p1, 1.0), O.horizontal_distance(t(p0), t(p1), 1.0)),
+        (E.Constraint.Vertical(l0), O.vertical(t(p0), t(p1))),
+        (E.Constraint.Horizontal(l0), O.horizontal(t(p0), t(p1))),
+        (E.Constraint.LinesAtAngle(l0, l1, E.AngleKind.Other(E.Angle.from_degrees(30))), O.lines_at_angle(t(p0), t(p1), t(p2), t(p3), ("deg", 30.0))),
+        (E.Constraint.lines_parallel([l0, l1]), O.lines_at_angle(t(p0), t(p1), t(p2), t(p3), "parallel")),
+        (E.Constraint.lines_perpendicular([l0, l1]), O.lines_at_angle(t(p0), t(p1), t(p2), t(p3), "perpendicular")),
+        (E.Constraint.Fixed(3, 1.5), O.fixed(3, 1.5)),
+        (E.Constraint.ScalarEqual(8, 9), O.scalar_equal(8, 9)),
+        (E.Constraint.PointsCoincident(p0, p1), O.points_coincident(t(p0), t(p1))),
+        (E.Constraint.CircleRadius(circ, 2.0), O.circle_radius(t(p2), 8, 2.0)),
+        (E.Constraint.LinesEqualLength(l0, l1), O.lines_equal_length(t(p0), t(p1), t(p2), t(p3))),
+        (E.Constraint.ArcRadius(arc, 5.0), O.arc_radius(t(p0), t(p1), t(p2), 5.0)),
+        (E.Constraint.Arc(arc), O.arc(t(p0), t(p1), t(p2))),
+        (E.Constraint.Midpoint(l0, p2), O.midpoint(t(p0), t(p1), t(p2))),
+        (E.Constraint.PointLineDistance(p2, l0, 1.0), O.point_line_distance(t(p2), t(p0), t(p1), 1.0)),
+        (E.Constraint.VerticalPointLineDistance(p2, l0, 1.0), O.vertical_point_line_distance(t(p2), t(p0), t(p1), 1.0)),
+        (E.Constraint.HorizontalPointLineDistance(p2, l0, 1.0), O.horizontal_point_line_distance(t(p2), t(p0), t(p1), 1.0)),
+        (E.Constraint.Symmetric(l0, p2, p3), O.symmetric(t(p0), t(p1), t(p2), t(p3))),
+        (E.Constraint.PointArcCoincident(arc, p3), O.point_arc_coincident(t(p0), t(p1), t(p2), t(p3))),
+        (E.Constraint.ArcLength(arc, 3.0), O.arc_length(t(p0), t(p1), t(p2), 3.0)),
+        (E.Constraint.ArcAngle(arc, E.Angle.from_radians(0.5)), O.arc_angle(t(p0), t(p1), t(p2), ("rad", 0.5))),
+        (E.Constraint.PointsAtAngle(p0, p1, p2, E.AngleKind.Other(E.Angle.from_radians(0.25))), O.points_at_angle(t(p0), t(p1), t(p2), ("rad", 0.25))),
+    ]
+    assert sorted({c.kind for c, _ in pairs}) == list(range(25))
+    for mine, theirs in pairs:
+        assert E.ConstraintRequest.highest_priority(mine).record().tobytes() == theirs.tobytes(), mine
+    req = E.ConstraintRequest.new(E.Constraint.Fixed(0, 1.0), 3).with_weight(2.0)
+    assert req.record().tobytes() == O.fixed(0, 1.0, priority=3, weight=2.0).tobytes()
+
+
+def test_solve_without_a_device_fails_loudly():
+    """No CPU fallback: without a HIP device solve() raises NonLinearSystemError(EZPZ_ERR_NO_DEVICE)."""
+    if E.device_count() > 0:
+        pytest.skip("a device is present")
+    with pytest.raises(E.FailureOutcome) as e:
+        E.solve([E.ConstraintRequest.highest_priority(E.Constraint.Fixed(0, 1.0))], [(0, 0.5)])
+    assert e.value.error.code == -100
+
+
+def test_product_never_imports_the_oracle():
+    for path in glob.glob(os.path.join(ROOT, "ezpz_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+            src = open(path).read()
+            assert "oracle" not in src.lower() or path.endswith("kinds.hpp"), path
