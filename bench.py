@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the LM constraint-solve hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by torch.distributed.run, one rank
+per GPU) prints ONE JSON line on rank 0.
+
+  metric   solves/sec on the 2000-row massive_parallel_system (BASELINE.json), plus iters-to-converge
+  step     one launch of the LM kernel over a batch of `--batch` independent replicas of the workload system
+           (jittered initial guesses), inputs already resident in HBM
+  value    whole-job solves/s = N * batch * K / max-over-ranks wall time of the K timed steps
+  scaling  weak: every rank owns its own shard of `--batch` systems; the path has no data-path collective
+           (systems are independent), so none is issued inside the timed region
+  roofline HBM: algorithmic bytes per launch (SURVEY.md 8d BYTES formula x systems per launch) / average kernel
+           duration measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak
+  cpu_baseline  the CPU oracle (a C port of the reference algorithm, sparse Cholesky, per-call setup like the
+           reference) timed on 1 host core with the CLI protocol on a bounded sample -- a reported baseline only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(info: dict, k: int) -> int:
+    """BYTES = (1+k)(56C + 8n + 8m + 8zJ) + k(12zJ + 8m + 16zA + 24zL + 48n)."""
+    C, n, m = info["n_constraints"], info["n_vars"], info["n_rows"]
+    zj, za, zl = info["nnz_j"], info["nnz_a"], info["nnz_l"]
+    return (1 + k) * (56 * C + 8 * n + 8 * m + 8 * zj) + k * (12 * zj + 8 * m + 16 * za + 24 * zl + 48 * n)
+
+
+def make_workload(name: str):
+    """Returns (description, constraint records, file guesses, jitter amplitude, expected iterations or None)."""
+    from oracle import oracle as O  # record helpers for side resolution only (test infrastructure, not timed)
+    from oracle import textual as T
+
+    if name.startswith("massive"):
+        lines = int(name[len("massive"):] or 500)
+        cs = T.load(T.gen_big_problem(lines))
+        return f"massive_parallel_system gen_big_problem.py {lines} ({4 * lines} rows x {4 * lines} vars)", cs.constraints, cs.guesses, 0.25, 2
+    path = os.path.join(ROOT, "tests", "golden", "test_cases", name, "problem.md")
+    cs = T.load(open(path).read())
+    recs = cs.constraints.copy()
+    for i in range(len(recs)):
+        recs[i] = O.set_from_initial_values(recs[i], cs.guesses)
+    return f"test_cases/{name} ({cs.num_vars} vars)", recs, cs.guesses, 0.1, None
+
+
+def cpu_baseline(records, guesses, budget_s: float):
+    """Oracle (`kind: port`) timed on one core with the CLI protocol (ezpz-cli/src/main.rs:86-100)."""
+    from oracle import oracle as O
+
+    secs, iters = O.time_solves(records, guesses, repeats=20, linsolve=O.LINSOLVE_SPARSE)
+    per = max(secs / 20.0, 1e-7)
+    repeats = int(min(max(budget_s / per, 100), 200000))
+    secs, iters = O.time_solves(records, guesses, repeats=repeats, linsolve=O.LINSOLVE_SPARSE)
+    return {"value": repeats / secs, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"{repeats} back-to-back full solve() calls (setup + sparse LLT + LM, {iters} iterations each) "
+                      f"of the same system on 1 core in {secs:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="systems per launch per GPU")
+    ap.add_argument("--workload", default="massive500", help="massive<lines> or a test_cases/ directory name")
+    ap.add_argument("--team", type=int, default=0, help="override lanes per system (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--check", type=int, default=1, help="verify the results of the last step against the oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ezpz_amd as E
+    import gen
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    desc, records, guesses, jitter, expect_iters = make_workload(args.workload)
+    n = len(guesses)
+    system = E.System(records, n, device=local_rank, team_size=args.team)
+    info = system.info()
+
+    # synthetic inputs: replicas of the system with keyed-PRNG jitter on the guesses, resident in HBM
+    B = args.batch
+    x0_host = guesses[None, :] + gen.keyed_uniform(0x657A707A + rank, B, n, -jitter, jitter)
+    x0_host[0] = guesses
+    x0 = torch.from_numpy(x0_host).to(dev)
+    x_out = torch.empty_like(x0)
+    status = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        system.solve_batch_device(x0.data_ptr(), B, x_out.data_ptr(), status.data_ptr(), 0, stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # one kernel per step, back to back on this stream
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    st = status.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+    iters = np.unique(st["iterations"]).tolist()
+    ok = bool(np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0))
+    if expect_iters is not None:
+        ok = ok and iters == [expect_iters]
+    checked = None
+    if args.check and rank == 0:
+        from oracle import oracle as O
+
+        sample = np.arange(0, B, max(1, B // 16))[:16]
+        rc, xo, it, conv, nun = O.solve_batch(records, x0_host[sample], linsolve=O.LINSOLVE_SPARSE)
+        xg = x_out[torch.from_numpy(sample).to(dev)].cpu().numpy()
+        err = float(np.max(np.abs(xg - xo) / np.maximum(1.0, np.abs(xo))))
+        checked = {"systems": int(len(sample)), "max_rel_err": err,
+                   "iterations_equal": bool(np.array_equal(st["iterations"][sample], it))}
+        ok = ok and err <= 1e-6 and checked["iterations_equal"]
+
+    if rank == 0:
+        k = int(round(float(np.mean(st["iterations"]))))
+        bytes_per_solve = algorithmic_bytes(info, k)
+        achieved = bytes_per_solve * B / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.workload}:batch{B}")
+        line = {
+            "metric": "solves/sec on 2000-row massive_parallel_system @1/2/4/8 GPU; iters-to-converge",
+            "value": world * B * args.steps / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "iters_to_converge": iters if len(iters) != 1 else iters[0],
+            "results_ok": ok,
+            "config": {
+                "workload": desc,
+                "systems_per_launch_per_gpu": B,
+                "rows": info["n_rows"], "vars": info["n_vars"], "constraints": info["n_constraints"],
+                "nnz_j": info["nnz_j"], "nnz_a": info["nnz_a"], "nnz_l": info["nnz_l"], "levels": info["n_levels"],
+                "team_size": info["team_size"], "workspace_in_lds": bool(info["workspace_in_lds"]),
+                "parallelism": f"batch-sharded x{world}, no collective on the data path",
+                "inputs": "resident in HBM; guesses = file guesses + keyed U(-%.2f,%.2f)" % (jitter, jitter),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "lm_solve_kernel",
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_solve": bytes_per_solve,
+                "solves_per_launch": B,
+            },
+        }
+        if checked:
+            line["oracle_check"] = checked
+        if args.cpu_seconds > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(records, guesses, args.cpu_seconds)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,34 @@ void order_component(const std::vector<uint32_t>& verts, const std::vector<std::
     }
 }
 
+// Number of strictly-lower entries of the Cholesky factor of one component under the elimination order `ord`
+// (symbolic elimination with an elimination tree; O(nnz(L))).
+uint64_t component_fill(const std::vector<uint32_t>& ord, const std::vector<std::vector<uint32_t>>& adj,
+                        std::vector<uint32_t>& local_id) {
+    const size_t k = ord.size();
+    for (size_t i = 0; i < k; ++i) local_id[ord[i]] = (uint32_t)i;
+    std::vector<uint32_t> parent(k, NONE), ancestor(k, NONE), flag(k, NONE);
+    uint64_t fill = 0;
+    for (uint32_t p = 0; p < k; ++p) {
+        flag[p] = p;
+        for (uint32_t w : adj[ord[p]]) {
+            uint32_t i = local_id[w];
+            if (i >= p) continue;
+            // etree update (Liu) and row-pattern count in one walk
+            for (uint32_t j = i; flag[j] != p; j = parent[j]) {
+                flag[j] = p;
+                ++fill;
+                if (parent[j] == NONE) {
+                    parent[j] = p;
+                    break;
+                }
+            }
+        }
+    }
+    (void)ancestor;
+    return fill;
+}
+
 }  // namespace
 
 bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& P, BuildError& err) {
@@ -188,11 +216,14 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
             if (w < v) ++za;
     }
     P.c.za = (uint32_t)za;
+    // Elimination order, per connected component: minimum degree, unless the request order already gives a
+    // factor that is no denser -- then the variables are eliminated in id order, which makes the factorisation
+    // operation-for-operation the textbook left-looking Cholesky of the matrix as the caller numbered it.
     std::vector<uint32_t> comp(n, NONE);
     std::vector<uint32_t> order;  // position -> var
     order.reserve(n);
     {
-        std::vector<uint32_t> stack, verts, local_id(n, 0);
+        std::vector<uint32_t> stack, verts, local_id(n, 0), cand;
         uint32_t ncomp = 0;
         for (uint32_t s = 0; s < n; ++s) {
             if (comp[s] != NONE) continue;
@@ -211,7 +242,10 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
                     }
             }
             std::sort(verts.begin(), verts.end());
-            order_component(verts, adj, local_id, order);
+            cand.clear();
+            order_component(verts, adj, local_id, cand);
+            if (cand != verts && component_fill(verts, adj, local_id) <= component_fill(cand, adj, local_id)) cand = verts;
+            order.insert(order.end(), cand.begin(), cand.end());
             ++ncomp;
         }
         P.c.n_components = ncomp;

@@ -31,7 +31,18 @@ def main():
         recs = []
         for g in variants:
             o = O.solve(cs.constraints, g)
+            # Conditioning of the answer itself: how far the oracle's own result moves when the inputs are
+            # perturbed by one ulp.  Under-determined systems are regularised only by lambda ~ 1e-9..1e-10, so
+            # rounding noise in the null space is amplified by ~1/lambda and 1e-6 agreement is not defined there.
+            sens = 0.0
+            for t in range(4):
+                rng = np.random.default_rng(1234 + t)
+                o2 = O.solve(cs.constraints, g * (1.0 + rng.uniform(-1.0, 1.0, len(g)) * 2.0 ** -52))
+                if o2.iterations == o.iterations:
+                    sens = max(sens, float(np.max(np.abs(o2.final_values - o.final_values)
+                                                  / np.maximum(1.0, np.abs(o.final_values)))))
             recs.append({
+                "ulp_sensitivity": sens,
                 "guesses": [float(v) for v in g],
                 "final_values": [float(v) for v in o.final_values],
                 "iterations": o.iterations,

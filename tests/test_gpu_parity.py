@@ -95,7 +95,11 @@ def test_golden_vectors(E):
             assert got.converged == rec["converged"], case
             assert got.unsatisfied == rec["unsatisfied"], case
             assert len(got.warnings) == rec["n_warnings"], case
-            assert_x_close(got.final_values, rec["final_values"])
+            # 1e-6 relative, widened only where the oracle's own answer moves by more than that under a one-ulp
+            # input perturbation (under-determined fixtures; see make_vectors.py), never beyond the reference's
+            # own test tolerance of 1e-4.
+            tol = min(1e-4, max(REL, 20.0 * rec["ulp_sensitivity"]))
+            assert_x_close(got.final_values, rec["final_values"], tol)
             assert abs(got.final_residual_inf - rec["final_residual_inf"]) <= 1e-9, case
 
 
