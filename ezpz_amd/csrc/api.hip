@@ -69,8 +69,10 @@ struct EzpzSystem {
     void* dev_program = nullptr;  // single allocation holding every list
     ProgramView view{};
     uint32_t team_size = 0;
-    bool wg_team = false;
+    int mode = MODE_SUB;  // TeamMode
     bool lds_ws = true;
+    bool prog_in_lds = false;
+    uint32_t prog_lds_doubles = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
     size_t lds_bytes = 0;
@@ -95,47 +97,48 @@ uint32_t pow2_ceil(uint32_t v) {
     return p;
 }
 
-// Team shape: small systems share a wavefront (sub-wave teams, no barriers); larger ones take a whole
-// workgroup; systems whose state exceeds the LDS fall back to a global-memory workspace.
-void choose_team(EzpzSystem& s, uint32_t requested) {
-    const ProgramCounts& c = s.counts;
+constexpr size_t kProgLdsMax = 16 * 1024;  // stage the topology program into LDS when it is this small
+
+uint32_t workspace_doubles(const ProgramCounts& c) {
     const uint64_t doubles = 3ull * c.n_vars + 2ull * c.n_rows + c.zj + c.zlo + 2;
-    s.ws_doubles = (uint32_t)((doubles + 1) & ~1ull);
+    return (uint32_t)((doubles + 1) & ~1ull);
+}
+
+// Sub-wavefront team for small systems: lanes per system.
+uint32_t auto_sub_team(uint32_t width) { return std::min<uint32_t>(64, std::max<uint32_t>(8, pow2_ceil((width + 1) / 2))); }
+// Workgroup size for large systems.
+uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(1024, std::max<uint32_t>(128, pow2_ceil((width + 1) / 2))); }
+
+// Fixes the launch shape once the program (and so the workspace size) is known.
+void finish_team(EzpzSystem& s, size_t blob_bytes) {
+    s.ws_doubles = workspace_doubles(s.counts);
     const size_t ws_bytes = (size_t)s.ws_doubles * 8;
-    const uint32_t width = std::max<uint32_t>(1, std::max(c.n_cons, c.n_vars));
-    uint32_t team = requested;
-    if (team == 0) {
-        if (width <= 64 && ws_bytes <= 32 * 1024)
-            team = std::min<uint32_t>(64, std::max<uint32_t>(8, pow2_ceil(width)));
-        else
-            team = std::min<uint32_t>(1024, std::max<uint32_t>(128, pow2_ceil((width + 1) / 2)));
-    }
-    if (team <= 64) {
-        team = std::max<uint32_t>(8, pow2_ceil(team));
-        if (ws_bytes > kLdsBytesMax - 1024) team = 256;  // cannot be a sub-wave team
-    }
-    if (team <= 64) {
-        s.wg_team = false;
+    if (s.mode == MODE_SUB) {
+        const uint32_t team = s.team_size;
         s.lds_ws = true;
-        s.team_size = team;
+        s.prog_in_lds = blob_bytes <= kProgLdsMax;
+        s.prog_lds_doubles = s.prog_in_lds ? (uint32_t)((blob_bytes + 15) / 16 * 2) : 0;
+        const size_t prog_bytes = (size_t)s.prog_lds_doubles * 8;
         uint32_t threads = 256;
-        while (threads > 64 && (size_t)(threads / team) * ws_bytes > kLdsBytesMax - 512) threads >>= 1;
-        if ((size_t)(threads / team) * ws_bytes > kLdsBytesMax - 512) threads = team;  // one team per block
+        while (threads > 64 && prog_bytes + (size_t)(threads / team) * ws_bytes > 64 * 1024) threads >>= 1;
         s.block_threads = std::max(threads, team);
-        s.lds_bytes = (size_t)(s.block_threads / team) * ws_bytes + 16;
+        s.lds_bytes = prog_bytes + (size_t)(s.block_threads / team) * ws_bytes + 16;
     } else {
-        team = std::min<uint32_t>(1024, (team + 63) & ~63u);
-        s.wg_team = true;
-        s.team_size = team;
-        s.block_threads = team;
-        s.lds_ws = ws_bytes + 512 <= kLdsBytesMax;
-        s.lds_bytes = s.lds_ws ? ws_bytes + 32 * 8 + 16 : 48 * 8;
+        s.block_threads = s.team_size;
+        s.prog_in_lds = false;
+        s.prog_lds_doubles = 0;
+        s.lds_ws = ws_bytes + 1024 <= kLdsBytesMax;
+        s.lds_bytes = s.lds_ws ? ws_bytes + 64 * 8 + 16 : 80 * 8;
     }
 }
 
-template <int TEAM, bool WG, bool LDSWS>
+bool sub_team_fits(const ProgramCounts& c, uint32_t team) {
+    return team <= 64 && (size_t)workspace_doubles(c) * 8 * (64 / team) <= 60 * 1024;
+}
+
+template <int TEAM, int MODE, bool LDSWS, bool PLDS>
 int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
-    auto kernel = lm_solve_kernel<TEAM, WG, LDSWS>;
+    auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS>;
     if (s.lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)s.lds_bytes));
@@ -145,34 +148,40 @@ int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hi
     return EZPZ_OK;
 }
 
+template <int TEAM>
+int launch_sub(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+    return s.prog_in_lds ? launch_variant<TEAM, MODE_SUB, true, true>(s, args, grid, stream)
+                         : launch_variant<TEAM, MODE_SUB, true, false>(s, args, grid, stream);
+}
+
 int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
     uint32_t grid;
-    if (!s.wg_team) {
+    if (s.mode == MODE_SUB) {
         const uint32_t tpb = s.block_threads / s.team_size;
         uint64_t blocks = (args.batch + tpb - 1) / tpb;
         grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)kNumCUs * 32);
         switch (s.team_size) {
-        case 8:
-            return launch_variant<8, false, true>(s, args, grid, stream);
-        case 16:
-            return launch_variant<16, false, true>(s, args, grid, stream);
-        case 32:
-            return launch_variant<32, false, true>(s, args, grid, stream);
-        default:
-            return launch_variant<64, false, true>(s, args, grid, stream);
+        case 4: return launch_sub<4>(s, args, grid, stream);
+        case 8: return launch_sub<8>(s, args, grid, stream);
+        case 16: return launch_sub<16>(s, args, grid, stream);
+        case 32: return launch_sub<32>(s, args, grid, stream);
+        default: return launch_sub<64>(s, args, grid, stream);
         }
     }
     const uint32_t per_cu = s.lds_ws ? (uint32_t)std::max<size_t>(1, kLdsBytesMax / std::max<size_t>(s.lds_bytes, 1))
                                      : 2048u / s.block_threads;
     grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)kNumCUs * std::min<uint32_t>(per_cu, 8) * 2);
-    if (s.lds_ws) return launch_variant<64, true, true>(s, args, grid, stream);
-    {
+    if (!s.lds_ws) {
         int rc = s.gws_dev.ensure((size_t)grid * s.ws_doubles);
         if (rc != EZPZ_OK) return rc;
         args.gws = s.gws_dev.p;
     }
-    return launch_variant<64, true, false>(s, args, grid, stream);
+    if (s.mode == MODE_PART)
+        return s.lds_ws ? launch_variant<64, MODE_PART, true, false>(s, args, grid, stream)
+                        : launch_variant<64, MODE_PART, false, false>(s, args, grid, stream);
+    return s.lds_ws ? launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream)
+                    : launch_variant<64, MODE_WGB, false, false>(s, args, grid, stream);
 }
 
 void fill_cfg(SolveArgs& a, const EzpzConfig* cfg) {
@@ -233,63 +242,73 @@ const char* ezpz_error_string(int err) {
     }
 }
 
-int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
-                       EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable) {
-    if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    Program P;
+// Symbolic phase + launch-shape decision shared by ezpz_system_create and ezpz_analyze.
+static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t team_size, EzpzSystem& s,
+                        Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable) {
     BuildError be;
-    if (!build_program(cs, n_cs, n_vars, P, be)) {
+    const uint32_t width = (uint32_t)std::max<size_t>(1, std::max(n_cs, n_vars));
+    auto fail = [&]() {
         if (err_constraint) *err_constraint = be.constraint;
         if (err_variable) *err_variable = be.variable;
         return be.code;
+    };
+    bool want_sub = team_size ? team_size <= 64 : width <= 64;
+    if (want_sub) {
+        if (!build_program(cs, n_cs, n_vars, P, be, 1)) return fail();
+        uint32_t team = team_size ? std::max<uint32_t>(4, pow2_ceil(team_size)) : auto_sub_team(width);
+        if (sub_team_fits(P.c, team)) {
+            s.mode = MODE_SUB;
+            s.team_size = team;
+        } else {
+            want_sub = false;
+            team_size = 0;
+        }
     }
-    if (ezpz_device_count() <= device || device < 0) return EZPZ_ERR_NO_DEVICE;
-    HIP_TRY(hipSetDevice(device));
-    std::unique_ptr<EzpzSystem> s(new EzpzSystem());
-    s->device = device;
-    s->counts = P.c;
-    s->host_colj_ptr = P.colj_ptr;
-    s->host_colj_items = P.colj_items;
-    choose_team(*s, team_size);
+    if (!want_sub) {
+        uint32_t team = team_size ? std::min<uint32_t>(1024, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
+                                  : auto_wg_team(width);
+        if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
+        s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;
+        s.team_size = team;
+    }
+    s.counts = P.c;
+    s.host_colj_ptr = P.colj_ptr;
+    s.host_colj_items = P.colj_items;
 
-    std::vector<unsigned char> blob;
-    size_t o_cons = append(blob, P.cons);
-    size_t o_colj_ptr = append(blob, P.colj_ptr), o_colj_items = append(blob, P.colj_items);
-    size_t o_apair_ptr = append(blob, P.apair_ptr), o_apairs = append(blob, P.apairs);
-    size_t o_lvl_cptr = append(blob, P.lvl_cptr), o_lvl_cols = append(blob, P.lvl_cols);
-    size_t o_lvl_sptr = append(blob, P.lvl_sptr), o_l_col = append(blob, P.l_col);
-    size_t o_lpair_ptr = append(blob, P.lpair_ptr), o_lpairs = append(blob, P.lpairs);
-    size_t o_fwd_ptr = append(blob, P.fwd_ptr), o_fwd_items = append(blob, P.fwd_items);
-    size_t o_bwd_ptr = append(blob, P.bwd_ptr), o_bwd_items = append(blob, P.bwd_items);
-    HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
-    HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    unsigned char* base = static_cast<unsigned char*>(s->dev_program);
-    auto u32 = [&](size_t off) { return reinterpret_cast<const uint32_t*>(base + off); };
-    ProgramView& v = s->view;
-    v.cons = reinterpret_cast<const DevCon*>(base + o_cons);
-    v.colj_ptr = u32(o_colj_ptr);
-    v.colj_items = u32(o_colj_items);
-    v.apair_ptr = u32(o_apair_ptr);
-    v.apairs = u32(o_apairs);
-    v.lvl_cptr = u32(o_lvl_cptr);
-    v.lvl_cols = u32(o_lvl_cols);
-    v.lvl_sptr = u32(o_lvl_sptr);
-    v.l_col = u32(o_l_col);
-    v.lpair_ptr = u32(o_lpair_ptr);
-    v.lpairs = u32(o_lpairs);
-    v.fwd_ptr = u32(o_fwd_ptr);
-    v.fwd_items = u32(o_fwd_items);
-    v.bwd_ptr = u32(o_bwd_ptr);
-    v.bwd_items = u32(o_bwd_items);
+    blob.clear();
+    ProgramView& v = s.view;
+    v.o_cons = (uint32_t)append(blob, P.cons);
+    v.o_parts = (uint32_t)append(blob, P.parts);
+    v.o_colj_ptr = (uint32_t)append(blob, P.colj_ptr);
+    v.o_colj_items = (uint32_t)append(blob, P.colj_items);
+    v.o_apair_ptr = (uint32_t)append(blob, P.apair_ptr);
+    v.o_apairs = (uint32_t)append(blob, P.apairs);
+    v.o_lvl_cptr = (uint32_t)append(blob, P.lvl_cptr);
+    v.o_lvl_cols = (uint32_t)append(blob, P.lvl_cols);
+    v.o_lvl_sptr = (uint32_t)append(blob, P.lvl_sptr);
+    v.o_l_col = (uint32_t)append(blob, P.l_col);
+    v.o_lpair_ptr = (uint32_t)append(blob, P.lpair_ptr);
+    v.o_lpairs = (uint32_t)append(blob, P.lpairs);
+    v.o_fwd_ptr = (uint32_t)append(blob, P.fwd_ptr);
+    v.o_fwd_items = (uint32_t)append(blob, P.fwd_items);
+    v.o_bwd_ptr = (uint32_t)append(blob, P.bwd_ptr);
+    v.o_bwd_items = (uint32_t)append(blob, P.bwd_items);
+    blob.resize((blob.size() + 15) & ~size_t(15));
+    if (blob.size() > 0xFFFFFFF0ull) {
+        be.code = EZPZ_ERR_TOO_LARGE;
+        return fail();
+    }
+    v.blob_bytes = (uint32_t)blob.size();
     v.n_cons = P.c.n_cons;
     v.n_vars = P.c.n_vars;
     v.n_rows = P.c.n_rows;
     v.zj = P.c.zj;
     v.zlo = P.c.zlo;
-    v.n_levels = P.c.n_levels;
+    v.n_parts = P.c.n_parts;
+    finish_team(s, blob.size());
 
-    EzpzSystemInfo& info = s->info;
+    EzpzSystemInfo& info = s.info;
+    std::memset(&info, 0, sizeof(info));
     info.n_constraints = P.c.n_cons;
     info.n_vars = P.c.n_vars;
     info.n_rows = P.c.n_rows;
@@ -299,9 +318,30 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
     info.n_levels = P.c.n_levels;
     info.n_components = P.c.n_components;
     info.program_bytes = blob.size();
-    info.workspace_bytes = (uint64_t)s->ws_doubles * 8;
-    info.team_size = s->team_size;
-    info.workspace_in_lds = s->lds_ws ? 1 : 0;
+    info.workspace_bytes = (uint64_t)s.ws_doubles * 8;
+    info.team_size = s.team_size;
+    info.workspace_in_lds = s.lds_ws ? 1 : 0;
+    info.team_mode = (uint32_t)s.mode;
+    info.n_partitions = P.c.n_parts;
+    info.program_in_lds = s.prog_in_lds ? 1 : 0;
+    return EZPZ_OK;
+}
+
+int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
+                       EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable) {
+    if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<EzpzSystem> s(new EzpzSystem());
+    Program P;
+    std::vector<unsigned char> blob;
+    int rc = analyze_into(cs, n_cs, n_vars, team_size, *s, P, blob, err_constraint, err_variable);
+    if (rc != EZPZ_OK) return rc;
+    if (ezpz_device_count() <= device || device < 0) return EZPZ_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    s->device = device;
+    HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
+    HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    s->view.base = static_cast<const unsigned char*>(s->dev_program);
     *out = s.release();
     return EZPZ_OK;
 }
@@ -321,33 +361,12 @@ int ezpz_system_info(const EzpzSystem* sys, EzpzSystemInfo* info) {
 int ezpz_analyze(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, EzpzSystemInfo* info, int32_t* err_constraint,
                  int64_t* err_variable) {
     if (!info) return EZPZ_ERR_INVALID_ARGUMENT;
-    Program P;
-    BuildError be;
-    if (!build_program(cs, n_cs, n_vars, P, be)) {
-        if (err_constraint) *err_constraint = be.constraint;
-        if (err_variable) *err_variable = be.variable;
-        return be.code;
-    }
     EzpzSystem tmp;
-    tmp.counts = P.c;
-    choose_team(tmp, 0);
-    std::memset(info, 0, sizeof(*info));
-    info->n_constraints = P.c.n_cons;
-    info->n_vars = P.c.n_vars;
-    info->n_rows = P.c.n_rows;
-    info->nnz_j = P.c.zj;
-    info->nnz_a = P.c.za;
-    info->nnz_l = (uint64_t)P.c.zlo + P.c.n_vars;
-    info->n_levels = P.c.n_levels;
-    info->n_components = P.c.n_components;
-    info->program_bytes = P.cons.size() * sizeof(DevCon) +
-                          4 * (P.colj_ptr.size() + P.colj_items.size() + P.apair_ptr.size() + P.apairs.size() +
-                               P.lvl_cptr.size() + P.lvl_cols.size() + P.lvl_sptr.size() + P.l_col.size() +
-                               P.lpair_ptr.size() + P.lpairs.size() + P.fwd_ptr.size() + P.fwd_items.size() +
-                               P.bwd_ptr.size() + P.bwd_items.size());
-    info->workspace_bytes = (uint64_t)tmp.ws_doubles * 8;
-    info->team_size = tmp.team_size;
-    info->workspace_in_lds = tmp.lds_ws ? 1 : 0;
+    Program P;
+    std::vector<unsigned char> blob;
+    int rc = analyze_into(cs, n_cs, n_vars, 0, tmp, P, blob, err_constraint, err_variable);
+    if (rc != EZPZ_OK) return rc;
+    *info = tmp.info;
     return EZPZ_OK;
 }
 
@@ -411,6 +430,7 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.gws = nullptr;
     a.batch = batch;
     a.ws_doubles = sys->ws_doubles;
+    a.prog_lds_doubles = sys->prog_lds_doubles;
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }

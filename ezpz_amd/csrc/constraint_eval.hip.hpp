@@ -49,13 +49,19 @@ struct Rot {
 __device__ __forceinline__ V2 rot_apply(Rot r, V2 v) { return V2{(r.c * v.x) - (r.s * v.y), (r.s * v.x) + (r.c * v.y)}; }
 __device__ __forceinline__ Rot rot_inv(Rot r) { return Rot{r.c, -r.s}; }
 // rotation_for_angle_kind, constraints.rs:2641-2647; Angle::to_radians, datatypes.rs:66-72
-__device__ __forceinline__ Rot rot_for(uint32_t tag, double val) {
+__device__ __noinline__ Rot sincos_of(double a) {  // {cos, sin} of a (libm::sin / libm::cos in the reference)
+    double s, c;
+    sincos(a, &s, &c);
+    return Rot{c, s};
+}
+__device__ __noinline__ double pow_1p5(double v) { return pow(v, 1.5); }
+// Not inlined: sincos / atan2 / fmod / pow bring large OCML bodies whose registers would otherwise be live across
+// every branch of the evaluator switch (189 -> 124 VGPRs for the sweeps on gfx950).
+__device__ __noinline__ Rot rot_for(uint32_t tag, double val) {
     if (tag == EZPZ_ANGLE_PARALLEL) return Rot{1.0, 0.0};
     if (tag == EZPZ_ANGLE_PERPENDICULAR) return Rot{0.0, 1.0};
     double rad = (tag == EZPZ_ANGLE_OTHER_DEG) ? val * (PI / 180.0) : val;
-    double s, c;
-    sincos(rad, &s, &c);
-    return Rot{c, s};
+    return sincos_of(rad);
 }
 // f64::signum: +1 for +0.0, -1 for -0.0, NaN stays NaN
 __device__ __forceinline__ double signum(double x) { return isnan(x) ? x : copysign(1.0, x); }
@@ -64,7 +70,7 @@ __device__ __forceinline__ double rem_euclid(double x, double m) {
     return r < 0.0 ? r + fabs(m) : r;
 }
 // classify_point_arc_coincident, constraints.rs:2593-2606: 0 interior, 1 start, 2 end
-__device__ __forceinline__ int classify_pac(V2 s, V2 e, V2 p) {
+__device__ __noinline__ int classify_pac(V2 s, V2 e, V2 p) {
     const double two_pi = 2.0 * PI;
     double a_sp = rem_euclid(signed_angle(s, p), two_pi);
     double a_se = rem_euclid(signed_angle(s, e), two_pi);
@@ -211,7 +217,8 @@ __device__ __forceinline__ bool con_residual(const DevCon& c, XP xs, double& r0,
         double r2 = ux * ux + uy * uy;
         if (r2 <= EPS * EPS) return true;
         double alpha = c.param / sqrt(r2);
-        double sa = sin(alpha), ca = cos(alpha);
+        Rot sc = sincos_of(alpha);
+        double sa = sc.s, ca = sc.c;
         r0 = (XV(4) - cx) - (ca * ux - sa * uy);
         r1 = (XV(5) - cy) - (sa * ux + ca * uy);
         return false;
@@ -455,7 +462,7 @@ __device__ __forceinline__ bool con_jacobian(const DevCon& c, XP xs, const JacWr
         double px = XV(0), py = XV(1), p0x = XV(2), p0y = XV(3), p1x = XV(4), p1y = XV(5);
         double ex = -p0x + p1x, ey = p0y - p1y;
         double euclid = hypot(ex, ey);
-        double denom = pow(ex * ex + ey * ey, 1.5);
+        double denom = pow_1p5(ex * ex + ey * ey);
         double common = (p0x * p1y - p0y * p1x + px * (p0y - p1y) + py * (-p0x + p1x));
         w.template put<0>((p0y - p1y) / euclid);
         w.template put<1>((-p0x + p1x) / euclid);
@@ -611,7 +618,8 @@ __device__ __forceinline__ bool con_jacobian(const DevCon& c, XP xs, const JacWr
         double d = c.param;
         double r = sqrt(r2);
         double alpha = d / r;
-        double sa = sin(alpha), ca = cos(alpha);
+        Rot sc = sincos_of(alpha);
+        double sa = sc.s, ca = sc.c;
         double rux = ca * ux - sa * uy, ruy = sa * ux + ca * uy;
         double k = d / (r2 * r);
         w.template put<0>(-ca - ruy * ux * k);

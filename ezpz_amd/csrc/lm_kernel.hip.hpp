@@ -7,16 +7,19 @@
 //     faer's transpose/matmul/add/Llt/solve reference ezpz/src/solver/newton.rs:73-102
 //     the unsatisfied check of solve_inner  reference ezpz/src/lib.rs:305-327
 //
-// Team shapes (template):
-//   TEAM in {8,16,32,64}, WG=false : sub-wavefront / one-wavefront teams, several systems per 64-wide wave,
-//                                    no s_barrier anywhere (lanes of a wave run in lockstep; LDS is in-order),
-//                                    reductions by DPP/bpermute shuffles.
-//   WG=true                        : the whole workgroup (128..1024 lanes) is one team; phases are separated
-//                                    by s_barrier, reductions go wave-shuffle -> LDS -> all lanes.
-//   LDSWS=false                    : state lives in a per-workgroup global-memory workspace (systems too big
-//                                    for the 160 KB LDS).
+// Team modes (template):
+//   SUB   TEAM in {4,8,16,32,64} lanes per system, several systems per 64-wide wavefront.  No s_barrier
+//         anywhere: lanes of a wave run in lockstep and the LDS serves a wave's accesses in issue order;
+//         reductions are DPP/bpermute shuffles.  Small programs are staged into LDS once per workgroup (PLDS).
+//   PART  one workgroup per system, every wavefront owns a *partition* (a balanced union of connected
+//         components: its own constraints, variables, Jacobian slots, Cholesky columns).  All phases of an
+//         LM iteration are wave-local; the only workgroup barriers are the two reductions per iteration that
+//         the reference's global LM control needs (sum r^2 / max|r|, and Cholesky-failed / max|d|).
+//   WGB   one workgroup per system, all lanes cooperate on one partition with s_barrier between phases
+//         (systems dominated by one large connected component).
+//   LDSWS=false  state lives in a per-workgroup global-memory workspace (systems too big for 160 KB of LDS).
 // HBM traffic is only x0 in, x*/status/mask out (AoS rows, contiguous per team); the topology program is
-// shared by every team and stays L2 resident.
+// shared by every team and stays L2 (or LDS) resident.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,16 +27,55 @@
 
 namespace ezpz {
 
+enum TeamMode { MODE_SUB = 0, MODE_PART = 1, MODE_WGB = 2 };
+
+// Byte offsets of every list inside the program blob (one device allocation, optionally copied to LDS).
 struct ProgramView {
+    const unsigned char* base;
+    uint32_t o_cons, o_parts;
+    uint32_t o_colj_ptr, o_colj_items;
+    uint32_t o_apair_ptr, o_apairs;
+    uint32_t o_lvl_cptr, o_lvl_cols, o_lvl_sptr, o_l_col;
+    uint32_t o_lpair_ptr, o_lpairs;
+    uint32_t o_fwd_ptr, o_fwd_items;
+    uint32_t o_bwd_ptr, o_bwd_items;
+    uint32_t blob_bytes;
+    uint32_t n_cons, n_vars, n_rows, zj, zlo, n_parts;
+};
+
+// Typed pointers into the blob (global or LDS).
+struct Prog {
     const DevCon* cons;
+    const PartDesc* parts;
     const uint32_t *colj_ptr, *colj_items;
     const uint32_t *apair_ptr, *apairs;
     const uint32_t *lvl_cptr, *lvl_cols, *lvl_sptr, *l_col;
     const uint32_t *lpair_ptr, *lpairs;
     const uint32_t *fwd_ptr, *fwd_items;
     const uint32_t *bwd_ptr, *bwd_items;
-    uint32_t n_cons, n_vars, n_rows, zj, zlo, n_levels;
 };
+
+__device__ __forceinline__ Prog make_prog(const ProgramView& v, const unsigned char* b) {
+    Prog p;
+    p.cons = reinterpret_cast<const DevCon*>(b + v.o_cons);
+    p.parts = reinterpret_cast<const PartDesc*>(b + v.o_parts);
+    auto u = [&](uint32_t o) { return reinterpret_cast<const uint32_t*>(b + o); };
+    p.colj_ptr = u(v.o_colj_ptr);
+    p.colj_items = u(v.o_colj_items);
+    p.apair_ptr = u(v.o_apair_ptr);
+    p.apairs = u(v.o_apairs);
+    p.lvl_cptr = u(v.o_lvl_cptr);
+    p.lvl_cols = u(v.o_lvl_cols);
+    p.lvl_sptr = u(v.o_lvl_sptr);
+    p.l_col = u(v.o_l_col);
+    p.lpair_ptr = u(v.o_lpair_ptr);
+    p.lpairs = u(v.o_lpairs);
+    p.fwd_ptr = u(v.o_fwd_ptr);
+    p.fwd_items = u(v.o_fwd_items);
+    p.bwd_ptr = u(v.o_bwd_ptr);
+    p.bwd_items = u(v.o_bwd_items);
+    return p;
+}
 
 struct SolveArgs {
     ProgramView p;
@@ -45,7 +87,8 @@ struct SolveArgs {
     double* gws;           // global workspace (LDSWS=false), ws_doubles per workgroup
     uint64_t batch;
     uint32_t warn_cap;
-    uint32_t ws_doubles;   // doubles per team workspace (incl. the small int area, rounded to 2 doubles)
+    uint32_t ws_doubles;        // doubles per team workspace (incl. the small int area, rounded to 2 doubles)
+    uint32_t prog_lds_doubles;  // LDS doubles reserved for the staged program (PLDS), 0 otherwise
     uint32_t max_iterations;
     double residual_tolerance, step_tolerance, initial_lambda;
 };
@@ -55,140 +98,120 @@ namespace dev {
 constexpr double LM_LAMBDA_INCR = 10.0;  // newton.rs:15
 constexpr double LM_LAMBDA_DECR = 0.1;   // newton.rs:16
 
-template <int TEAM, bool WG>
+struct OpSum {
+    __device__ __forceinline__ double operator()(double a, double b) const { return a + b; }
+};
+struct OpMax {  // libm::fmax (NaN-ignoring), newton.rs:53,:108
+    __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); }
+};
+
+template <int TEAM, int MODE>
 struct Team {
-    int lane;        // lane within the team
-    int size;        // lanes in the team
-    double* red;     // WG only: 2 x 16 doubles of LDS scratch
+    int lane;     // lane inside the unit that walks a phase (team for SUB, wave for PART, workgroup for WGB)
+    int stride;   // lanes in that unit
+    double* red;  // PART/WGB: 2 (flip) x 2 (values) x 16 (waves) doubles of LDS scratch
     int red_flip;
 
-    __device__ __forceinline__ void sync() const {
-        if constexpr (WG) {
+    // Orders one phase's LDS/global writes before the next phase's reads inside the unit.
+    __device__ __forceinline__ void phase_sync() const {
+        if constexpr (MODE == MODE_WGB) {
             __syncthreads();
         } else {
             // Lanes of one wavefront execute in lockstep and the LDS services a wave's accesses in issue
-            // order, so no hardware barrier is needed; only the compiler must not move LDS accesses across.
+            // order, so no hardware barrier is needed; only the compiler must not move accesses across.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    // Whole-team rendezvous (cooperative loads/stores of x).
+    __device__ __forceinline__ void team_sync() const {
+        if constexpr (MODE == MODE_SUB)
+            phase_sync();
+        else
+            __syncthreads();
+    }
 
-    template <class Op>
-    __device__ __forceinline__ double reduce(double v, Op op) {
-        if constexpr (!WG) {
+    // Two team-wide reductions for the price of one rendezvous; every lane gets both results.
+    template <class OpA, class OpB>
+    __device__ __forceinline__ void reduce2(double& a, double& b, OpA opa, OpB opb) {
+        if constexpr (MODE == MODE_SUB) {
 #pragma unroll
-            for (int off = TEAM / 2; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, TEAM));
-            return __shfl(v, 0, TEAM);
+            for (int off = TEAM / 2; off > 0; off >>= 1) {
+                a = opa(a, __shfl_xor(a, off, TEAM));
+                b = opb(b, __shfl_xor(b, off, TEAM));
+            }
+            a = __shfl(a, 0, TEAM);
+            b = __shfl(b, 0, TEAM);
         } else {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
-            double* buf = red + (red_flip ? 16 : 0);
+            for (int off = 32; off > 0; off >>= 1) {
+                a = opa(a, __shfl_xor(a, off, 64));
+                b = opb(b, __shfl_xor(b, off, 64));
+            }
+            double* buf = red + (red_flip ? 32 : 0);
             red_flip ^= 1;
             const int wave = threadIdx.x >> 6;
             const int nwaves = (blockDim.x + 63) >> 6;
-            if ((threadIdx.x & 63) == 0) buf[wave] = v;
+            if ((threadIdx.x & 63) == 0) {
+                buf[wave] = a;
+                buf[16 + wave] = b;
+            }
             __syncthreads();
-            double acc = buf[0];
-            for (int w = 1; w < nwaves; ++w) acc = op(acc, buf[w]);
-            return acc;  // the other buffer is used by the next reduction, so no trailing barrier is needed
+            a = buf[0];
+            b = buf[16];
+            for (int w = 1; w < nwaves; ++w) {
+                a = opa(a, buf[w]);
+                b = opb(b, buf[16 + w]);
+            }
+            // the next reduction uses the other half of `red`, so no trailing barrier is needed
         }
-    }
-    __device__ __forceinline__ double sum(double v) {
-        return reduce(v, [](double a, double b) { return a + b; });
-    }
-    __device__ __forceinline__ double max(double v) {
-        return reduce(v, [](double a, double b) { return fmax(a, b); });  // libm::fmax, newton.rs:53,:108
     }
 };
 
-// Residual sweep: r[row] = weight * residual (solver.rs:327-355).  One lane per constraint.  With
-// `unweighted` the raw residuals are stored and nothing is logged (the unsatisfied check, lib.rs:305-327).
-template <class T, class WP>
-__device__ __forceinline__ void sweep_residual(const T& tm, const SolveArgs& a, WP ws, uint32_t o_x, uint32_t o_r,
-                                               int* nwarn, uint64_t sys, uint32_t pass, bool unweighted,
-                                               WP out = nullptr) {
-    if (!out) out = ws;
-    for (uint32_t ci = tm.lane; ci < a.p.n_cons; ci += tm.size) {
-        const DevCon& c = a.p.cons[ci];
-        double r0, r1;
-        bool deg = con_residual(c, ws + o_x, r0, r1);
-        const double wgt = unweighted ? 1.0 : c.weight;
-        const uint32_t row0 = c.row0;
-        out[o_r + row0] = wgt * r0;
-        if (c.nrows > 1) out[o_r + row0 + 1] = wgt * r1;
-        if (deg && !unweighted) {
-            int idx = atomicAdd(nwarn, 1);
-            if (a.warn_log && (uint32_t)idx < a.warn_cap)
-                a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
-        }
-    }
-}
-
-// Jacobian sweep (solver.rs:359-440): weighted partials straight into their precomputed slots.
-template <class T, class WP>
-__device__ __forceinline__ void sweep_jacobian(const T& tm, const SolveArgs& a, WP ws, uint32_t o_x, uint32_t o_j,
-                                               int* nwarn, uint64_t sys, uint32_t pass, WP out = nullptr) {
-    if (!out) out = ws;
-    for (uint32_t ci = tm.lane; ci < a.p.n_cons; ci += tm.size) {
-        const DevCon& c = a.p.cons[ci];
-        JacWriter<WP> w;
-        w.jv = out + o_j;
-        w.jbase = c.jbase;
-        const uint32_t* loc = reinterpret_cast<const uint32_t*>(c.jloc);
-        w.loc[0] = loc[0];
-        w.loc[1] = loc[1];
-        w.loc[2] = loc[2];
-        w.loc[3] = loc[3];
-        w.weight = c.weight;
-        bool deg = con_jacobian(c, ws + o_x, w);
-        if (deg) {
-            int idx = atomicAdd(nwarn, 1);
-            if (a.warn_log && (uint32_t)idx < a.warn_cap)
-                a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
-        }
-    }
-}
-
-template <class T, class WP>
-__device__ __forceinline__ double sum_squares(T& tm, WP ws, uint32_t off, uint32_t m) {
-    double acc = 0.0;
-    for (uint32_t i = tm.lane; i < m; i += tm.size) {
-        double v = ws[off + i];
-        acc += v * v;
-    }
-    return tm.sum(acc);
-}
-
-template <class T, class WP>
-__device__ __forceinline__ double max_abs(T& tm, WP ws, uint32_t off, uint32_t m) {
-    // reduce(fmax) over |.|: NaN-ignoring like libm::fmax; an all-NaN input yields NaN.  Lanes without an
-    // element seed with NaN, which fmax drops, so the result only depends on real elements.
-    double acc = (tm.lane < (int)m) ? fabs(ws[off + tm.lane]) : __builtin_nan("");
-    for (uint32_t i = tm.lane + tm.size; i < m; i += tm.size) acc = fmax(acc, fabs(ws[off + i]));
-    return tm.max(acc);
-}
-
 }  // namespace dev
 
-template <int TEAM, bool WG, bool LDSWS>
-__global__ void __launch_bounds__(WG ? 1024 : 256) lm_solve_kernel(const SolveArgs a) {
+template <int TEAM, int MODE, bool LDSWS, bool PLDS>
+__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SUB ? 4 : 1)
+    lm_solve_kernel(const SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using namespace dev;
-    Team<TEAM, WG> tm;
+    Team<TEAM, MODE> tm;
     const int tid = threadIdx.x;
-    tm.size = WG ? (int)blockDim.x : TEAM;
-    tm.lane = WG ? tid : (tid % TEAM);
     tm.red_flip = 0;
-    const uint32_t teams_per_block = WG ? 1u : (uint32_t)(blockDim.x / TEAM);
-    const uint32_t team_in_block = WG ? 0u : (uint32_t)(tid / TEAM);
-    const uint32_t n = a.p.n_vars, m = a.p.n_rows, zj = a.p.zj, zlo = a.p.zlo, nlev = a.p.n_levels;
+    if constexpr (MODE == MODE_SUB) {
+        tm.lane = tid % TEAM;
+        tm.stride = TEAM;
+    } else if constexpr (MODE == MODE_PART) {
+        tm.lane = tid & 63;
+        tm.stride = 64;
+    } else {
+        tm.lane = tid;
+        tm.stride = (int)blockDim.x;
+    }
+    // lanes that cooperate on whole-system vectors (x load / store)
+    const int tlane = (MODE == MODE_SUB) ? tm.lane : tid;
+    const int tsize = (MODE == MODE_SUB) ? TEAM : (int)blockDim.x;
+    const uint32_t teams_per_block = (MODE == MODE_SUB) ? (uint32_t)(blockDim.x / TEAM) : 1u;
+    const uint32_t team_in_block = (MODE == MODE_SUB) ? (uint32_t)(tid / TEAM) : 0u;
+    const uint32_t n = a.p.n_vars, m = a.p.n_rows, zj = a.p.zj, zlo = a.p.zlo;
 
-    // workspace carve-up (doubles)
+    // ---- topology program: global/L2, or staged once per workgroup into LDS ----------------------------------
+    const unsigned char* pbase = a.p.base;
+    if constexpr (PLDS) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.p.base);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < a.p.blob_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        pbase = reinterpret_cast<const unsigned char*>(smem);
+    }
+    const Prog P = make_prog(a.p, pbase);
+
+    // ---- workspace carve-up (doubles) ----------------------------------------------------------------------------
     double* ws;
     if constexpr (LDSWS) {
-        ws = smem + (size_t)team_in_block * a.ws_doubles;
-        tm.red = smem + (size_t)teams_per_block * a.ws_doubles;
+        ws = smem + a.prog_lds_doubles + (size_t)team_in_block * a.ws_doubles;
+        tm.red = smem + a.prog_lds_doubles + (size_t)teams_per_block * a.ws_doubles;
     } else {
         ws = a.gws + (size_t)blockIdx.x * a.ws_doubles;
         tm.red = smem;
@@ -198,23 +221,32 @@ __global__ void __launch_bounds__(WG ? 1024 : 256) lm_solve_kernel(const SolveAr
     uint32_t o_rn = n + m;
     const uint32_t o_j = n + 2 * m;
     const uint32_t o_d = o_j + zj;   // Cholesky diagonal, by variable
-    const uint32_t o_l = o_d + n;    // strictly-lower L entries, level grouped
+    const uint32_t o_l = o_d + n;    // strictly-lower L entries, (partition, level) grouped
     const uint32_t o_v = o_l + zlo;  // b, then y, then d (by variable)
     const uint32_t o_i = o_v + n;    // small int area
     int* nwarn;
     if constexpr (LDSWS) {
         nwarn = reinterpret_cast<int*>(ws + o_i);
     } else {
-        nwarn = reinterpret_cast<int*>(smem + 32);  // LDS even when the bulk state is in global memory
+        nwarn = reinterpret_cast<int*>(smem + 64);  // LDS even when the bulk state is in global memory
     }
+
+    // ---- this unit's partition --------------------------------------------------------------------------------------
+    const PartDesc part = P.parts[(MODE == MODE_PART) ? (uint32_t)(tid >> 6) : 0u];
+    const uint32_t con0 = part.con0, con1 = part.con1;
+    const uint32_t* lvl_cptr = P.lvl_cptr + part.lvl0;
+    const uint32_t* lvl_sptr = P.lvl_sptr + part.lvl0;
+    const uint32_t nlev = part.nlev;
+    const uint32_t call0 = lvl_cptr[0], call1 = lvl_cptr[nlev];  // all of the partition's variables (lvl_cols entries)
+    const uint32_t sall0 = lvl_sptr[0], sall1 = lvl_sptr[nlev];  // all of its strictly-lower L slots
 
     const uint64_t n_teams = (uint64_t)gridDim.x * teams_per_block;
     for (uint64_t sys = (uint64_t)blockIdx.x * teams_per_block + team_in_block; sys < a.batch; sys += n_teams) {
-        // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------
+        // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
         const double* x0 = a.x0 + sys * n;
-        for (uint32_t i = tm.lane; i < n; i += tm.size) ws[o_x + i] = x0[i];
-        if (tm.lane == 0) *nwarn = 0;
-        tm.sync();
+        for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[i];
+        if (tlane == 0) *nwarn = 0;
+        tm.team_sync();
 
         // The LM loop of newton.rs:29-145 as a three-mode state machine, so that each of the two big
         // evaluators is instantiated exactly once (register pressure / code size):
@@ -227,108 +259,136 @@ __global__ void __launch_bounds__(WG ? 1024 : 256) lm_solve_kernel(const SolveAr
         uint32_t pass = 0;
         uint32_t it = 0;
         double residual_sq = 0.0;
+        double largest = 0.0;  // max |r| of the current residual vector
         double lambda = a.initial_lambda;
         double step_inf_norm = 0.0;
-        double final_inf = 0.0;
         uint32_t iterations = a.max_iterations;
         uint32_t converged = 0;
         for (;;) {
             if (mode == STEP) {
                 if (it >= a.max_iterations) {  // newton.rs:141-144
                     mode = FINAL;
-                } else {
-                    // convergence on max |r| (newton.rs:50-60)
-                    double largest = max_abs(tm, ws, o_r, m);
-                    if (largest <= a.residual_tolerance) {
-                        iterations = it;
-                        converged = 1;
-                        mode = FINAL;
-                    }
+                } else if (largest <= a.residual_tolerance) {  // newton.rs:50-60
+                    iterations = it;
+                    converged = 1;
+                    mode = FINAL;
                 }
             }
             if (mode == STEP) {
-                // ---- A = JtJ + lambda I (into L's storage) and b = Jt(-r)  (newton.rs:77-84) --------------------
-                for (uint32_t v = tm.lane; v < n; v += tm.size) {
+                // ---- A = JtJ + lambda I (into L's storage) and b = Jt(-r)  (newton.rs:77-84) ---------------------
+                for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
+                    const uint32_t v = P.lvl_cols[ci];
                     double acc = 0.0, b = 0.0;
-                    for (uint32_t q = a.p.colj_ptr[v]; q < a.p.colj_ptr[v + 1]; ++q) {
-                        double jv = ws[o_j + a.p.colj_items[2 * q]];
+                    for (uint32_t q = P.colj_ptr[v]; q < P.colj_ptr[v + 1]; ++q) {
+                        double jv = ws[o_j + P.colj_items[2 * q]];
                         acc += jv * jv;
-                        b += jv * -ws[o_r + a.p.colj_items[2 * q + 1]];
+                        b += jv * -ws[o_r + P.colj_items[2 * q + 1]];
                     }
                     ws[o_d + v] = acc + lambda;
                     ws[o_v + v] = b;
                 }
-                for (uint32_t s = tm.lane; s < zlo; s += tm.size) {
+                for (uint32_t s = sall0 + tm.lane; s < sall1; s += tm.stride) {
                     double acc = 0.0;
-                    for (uint32_t q = a.p.apair_ptr[s]; q < a.p.apair_ptr[s + 1]; ++q)
-                        acc += ws[o_j + a.p.apairs[2 * q]] * ws[o_j + a.p.apairs[2 * q + 1]];
+                    for (uint32_t q = P.apair_ptr[s]; q < P.apair_ptr[s + 1]; ++q)
+                        acc += ws[o_j + P.apairs[2 * q]] * ws[o_j + P.apairs[2 * q + 1]];
                     ws[o_l + s] = acc;
                 }
-                tm.sync();
-                // ---- level-scheduled sparse Cholesky + forward substitution (newton.rs:87-102) -------------------
+                tm.phase_sync();
+                // ---- level-scheduled sparse Cholesky + forward substitution (newton.rs:87-102) --------------------
                 double bad = 0.0;
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
-                    const uint32_t c0 = a.p.lvl_cptr[lv], c1 = a.p.lvl_cptr[lv + 1];
-                    const uint32_t s0 = a.p.lvl_sptr[lv], s1 = a.p.lvl_sptr[lv + 1];
-                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.size) {
-                        const uint32_t v = a.p.lvl_cols[ci];
+                    const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
+                    const uint32_t s0 = lvl_sptr[lv], s1 = lvl_sptr[lv + 1];
+                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
+                        const uint32_t v = P.lvl_cols[ci];
                         double acc = ws[o_d + v];
-                        for (uint32_t q = a.p.fwd_ptr[v]; q < a.p.fwd_ptr[v + 1]; ++q) {
-                            double l = ws[o_l + a.p.fwd_items[2 * q]];
+                        for (uint32_t q = P.fwd_ptr[v]; q < P.fwd_ptr[v + 1]; ++q) {
+                            double l = ws[o_l + P.fwd_items[2 * q]];
                             acc -= l * l;
                         }
                         if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
                         ws[o_d + v] = sqrt(acc);
                     }
-                    for (uint32_t s = s0 + tm.lane; s < s1; s += tm.size) {
+                    for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride) {
                         double acc = ws[o_l + s];
-                        for (uint32_t q = a.p.lpair_ptr[s]; q < a.p.lpair_ptr[s + 1]; ++q)
-                            acc -= ws[o_l + a.p.lpairs[2 * q]] * ws[o_l + a.p.lpairs[2 * q + 1]];
+                        for (uint32_t q = P.lpair_ptr[s]; q < P.lpair_ptr[s + 1]; ++q)
+                            acc -= ws[o_l + P.lpairs[2 * q]] * ws[o_l + P.lpairs[2 * q + 1]];
                         ws[o_l + s] = acc;
                     }
-                    tm.sync();
-                    for (uint32_t s = s0 + tm.lane; s < s1; s += tm.size)
-                        ws[o_l + s] = ws[o_l + s] / ws[o_d + a.p.l_col[s]];
-                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.size) {
-                        const uint32_t v = a.p.lvl_cols[ci];
+                    tm.phase_sync();
+                    for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride)
+                        ws[o_l + s] = ws[o_l + s] / ws[o_d + P.l_col[s]];
+                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
+                        const uint32_t v = P.lvl_cols[ci];
                         double acc = ws[o_v + v];
-                        for (uint32_t q = a.p.fwd_ptr[v]; q < a.p.fwd_ptr[v + 1]; ++q)
-                            acc -= ws[o_l + a.p.fwd_items[2 * q]] * ws[o_v + a.p.fwd_items[2 * q + 1]];
+                        for (uint32_t q = P.fwd_ptr[v]; q < P.fwd_ptr[v + 1]; ++q)
+                            acc -= ws[o_l + P.fwd_items[2 * q]] * ws[o_v + P.fwd_items[2 * q + 1]];
                         ws[o_v + v] = acc / ws[o_d + v];
                     }
-                    tm.sync();
+                    tm.phase_sync();
                 }
-                if (tm.max(bad) > 0.0) {  // numeric failure => lambda *= 10, burn the iteration (newton.rs:96-99)
+                // ---- backward substitution (garbage but harmless if the factorisation failed) ---------------------------
+                for (uint32_t lv = nlev; lv-- > 0;) {
+                    const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
+                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
+                        const uint32_t v = P.lvl_cols[ci];
+                        double acc = ws[o_v + v];
+                        for (uint32_t q = P.bwd_ptr[v]; q < P.bwd_ptr[v + 1]; ++q)
+                            acc -= ws[o_l + P.bwd_items[2 * q]] * ws[o_v + P.bwd_items[2 * q + 1]];
+                        ws[o_v + v] = acc / ws[o_d + v];
+                    }
+                    tm.phase_sync();
+                }
+                // ---- ||d||_inf and "did any pivot fail": one rendezvous (newton.rs:96-99, :108) ------------------------------
+                double dmax = __builtin_nan("");  // fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax)
+                for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride)
+                    dmax = fmax(dmax, fabs(ws[o_v + P.lvl_cols[ci]]));
+                tm.reduce2(bad, dmax, OpMax(), OpMax());
+                if (bad > 0.0) {  // numeric failure => lambda *= 10, burn the iteration
                     lambda *= LM_LAMBDA_INCR;
                     ++it;
                     continue;
                 }
-                // ---- backward substitution ----------------------------------------------------------------------
-                for (uint32_t lv = nlev; lv-- > 0;) {
-                    const uint32_t c0 = a.p.lvl_cptr[lv], c1 = a.p.lvl_cptr[lv + 1];
-                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.size) {
-                        const uint32_t v = a.p.lvl_cols[ci];
-                        double acc = ws[o_v + v];
-                        for (uint32_t q = a.p.bwd_ptr[v]; q < a.p.bwd_ptr[v + 1]; ++q)
-                            acc -= ws[o_l + a.p.bwd_items[2 * q]] * ws[o_v + a.p.bwd_items[2 * q + 1]];
-                        ws[o_v + v] = acc / ws[o_d + v];
-                    }
-                    tm.sync();
+                step_inf_norm = (n > 0) ? dmax : 0.0;
+                // ---- tentative step (newton.rs:111-114) ---------------------------------------------------------------------
+                for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
+                    const uint32_t v = P.lvl_cols[ci];
+                    ws[o_x + v] = ws[o_x + v] + ws[o_v + v];
                 }
-                // ---- tentative step (newton.rs:108-114) --------------------------------------------------------------
-                step_inf_norm = (n > 0) ? max_abs(tm, ws, o_v, n) : 0.0;
-                for (uint32_t i = tm.lane; i < n; i += tm.size) ws[o_x + i] = ws[o_x + i] + ws[o_v + i];
-                tm.sync();
+                tm.phase_sync();
             }
-            if (mode == FINAL) final_inf = (m > 0) ? max_abs(tm, ws, o_r, m) : 0.0;
 
-            // ---- the one residual sweep: EVAL0 -> r, STEP -> r_next, FINAL -> unweighted into r_next ------------------
+            // ---- the one residual sweep: EVAL0 -> r, STEP -> r_next, FINAL -> unweighted into r_next ---------------------
+            // r[row] = weight * residual (solver.rs:327-355); one lane per constraint of the partition.
             const uint32_t o_dst = (mode == EVAL0) ? o_r : o_rn;
-            sweep_residual(tm, a, ws, o_x, o_dst, nwarn, sys, pass, mode == FINAL);
+            double sq = 0.0;
+            double mx = __builtin_nan("");
+            for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                const DevCon& c = P.cons[ci];
+                double r0, r1;
+                const bool deg = con_residual(c, ws + o_x, r0, r1);
+                const double wgt = (mode == FINAL) ? 1.0 : c.weight;
+                const uint32_t row0 = c.row0;
+                const double w0 = wgt * r0;
+                ws[o_dst + row0] = w0;
+                sq += w0 * w0;
+                mx = fmax(mx, fabs(w0));
+                if (c.nrows > 1) {
+                    const double w1 = wgt * r1;
+                    ws[o_dst + row0 + 1] = w1;
+                    sq += w1 * w1;
+                    mx = fmax(mx, fabs(w1));
+                }
+                if (deg && mode != FINAL) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
+                    int idx = atomicAdd(nwarn, 1);
+                    if (a.warn_log && (uint32_t)idx < a.warn_cap)
+                        a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
+                }
+            }
             ++pass;
-            tm.sync();
+            tm.phase_sync();
             if (mode == FINAL) break;
-            const double sq = sum_squares(tm, ws, o_dst, m);
+            tm.reduce2(sq, mx, OpSum(), OpMax());  // sum r^2 (newton.rs:116,:235) and max |r| (newton.rs:50-53)
             const bool accept = (mode == EVAL0) || (sq < residual_sq);  // strict, newton.rs:118
             if (accept) {
                 if (mode == STEP) {
@@ -337,15 +397,36 @@ __global__ void __launch_bounds__(WG ? 1024 : 256) lm_solve_kernel(const SolveAr
                     o_rn = t;
                     lambda *= LM_LAMBDA_DECR;
                 }
-                // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121) ------------------------------
-                sweep_jacobian(tm, a, ws, o_x, o_j, nwarn, sys, pass);
+                // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121; solver.rs:359-440) ------------------
+                for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                    const DevCon& c = P.cons[ci];
+                    JacWriter<double*> w;
+                    w.jv = ws + o_j;
+                    w.jbase = c.jbase;
+                    const uint32_t* loc = reinterpret_cast<const uint32_t*>(c.jloc);
+                    w.loc[0] = loc[0];
+                    w.loc[1] = loc[1];
+                    w.loc[2] = loc[2];
+                    w.loc[3] = loc[3];
+                    w.weight = c.weight;
+                    const bool deg = con_jacobian(c, ws + o_x, w);
+                    if (deg) {
+                        int idx = atomicAdd(nwarn, 1);
+                        if (a.warn_log && (uint32_t)idx < a.warn_cap)
+                            a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
+                    }
+                }
                 ++pass;
                 residual_sq = sq;
+                largest = mx;
             } else {  // reject: revert, raise lambda (newton.rs:124-131)
-                for (uint32_t i = tm.lane; i < n; i += tm.size) ws[o_x + i] = ws[o_x + i] - ws[o_v + i];
+                for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
+                    const uint32_t v = P.lvl_cols[ci];
+                    ws[o_x + v] = ws[o_x + v] - ws[o_v + v];
+                }
                 lambda *= LM_LAMBDA_INCR;
             }
-            tm.sync();
+            tm.phase_sync();
             if (mode == STEP) {
                 if (step_inf_norm <= a.step_tolerance) {  // newton.rs:134-139
                     iterations = it;
@@ -358,34 +439,35 @@ __global__ void __launch_bounds__(WG ? 1024 : 256) lm_solve_kernel(const SolveAr
             if (mode == EVAL0) mode = STEP;
         }
 
-        // ---- unsatisfied list from the unweighted residuals in r_next (lib.rs:305-327, :358-370) + write-back -------
+        // ---- unsatisfied list from the unweighted residuals in r_next (lib.rs:305-327, :358-370) + write-back ------------
         double unsat_cnt = 0.0;
-        for (uint32_t ci = tm.lane; ci < a.p.n_cons; ci += tm.size) {
-            const DevCon& c = a.p.cons[ci];
+        double dummy = 0.0;
+        for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+            const DevCon& c = P.cons[ci];
             const uint32_t row0 = c.row0;
             bool sat = fabs(ws[o_rn + row0]) < EPS;
             if (c.nrows > 1) sat = sat && (fabs(ws[o_rn + row0 + 1]) < EPS);
             if (!sat) unsat_cnt += 1.0;
             if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + c.pos] = sat ? 0 : 1;
         }
-        unsat_cnt = tm.sum(unsat_cnt);
+        tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());  // also the rendezvous before the cooperative store of x
         double* xo = a.x_out + sys * n;
-        for (uint32_t i = tm.lane; i < n; i += tm.size) xo[i] = ws[o_x + i];
-        if (tm.lane == 0) {
+        for (uint32_t i = tlane; i < n; i += tsize) xo[i] = ws[o_x + i];
+        if (tlane == 0) {
             EzpzStatus st;
             st.iterations = iterations;
             st.converged = converged;
             st.n_unsatisfied = (uint32_t)unsat_cnt;
             st.n_warnings = (uint32_t)*nwarn;
-            st.final_residual_inf = final_inf;
+            st.final_residual_inf = (m > 0) ? largest : 0.0;
             st.final_lambda = lambda;
             a.status[sys] = st;
         }
-        tm.sync();  // the workspace is reused by the next system of this team
+        tm.team_sync();  // the workspace is reused by the next system of this team
     }
 }
 
-// Evaluation-only kernel (K1): one workgroup per value vector, state in global memory.
+// Evaluation-only kernel (K1): one workgroup per value vector, everything in global memory.
 struct EvalArgs {
     ProgramView p;
     const double* x;
@@ -398,24 +480,30 @@ struct EvalArgs {
 __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs e) {
     using namespace dev;
     __shared__ int nwarn;
-    Team<64, true> tm;
-    tm.size = (int)blockDim.x;
-    tm.lane = (int)threadIdx.x;
-    tm.red = nullptr;
-    tm.red_flip = 0;
-    SolveArgs a{};
-    a.p = e.p;
-    a.warn_log = nullptr;
-    a.warn_cap = 0;
+    const Prog P = make_prog(e.p, e.p.base);
     for (uint64_t sys = blockIdx.x; sys < e.batch; sys += gridDim.x) {
         if (threadIdx.x == 0) nwarn = 0;
         __syncthreads();
         const double* xs = e.x + sys * e.p.n_vars;
         double* r = e.r_out + sys * e.p.n_rows;
         double* jv = e.jv_out + sys * e.p.zj;
-        // the sweeps index one base pointer by offset; give each its own base
-        sweep_residual(tm, a, const_cast<double*>(xs), 0u, (uint32_t)0, &nwarn, sys, 0u, false, r);
-        sweep_jacobian(tm, a, const_cast<double*>(xs), 0u, (uint32_t)0, &nwarn, sys, 1u, jv);
+        for (uint32_t ci = threadIdx.x; ci < e.p.n_cons; ci += blockDim.x) {
+            const DevCon& c = P.cons[ci];
+            double r0, r1;
+            if (con_residual(c, xs, r0, r1)) atomicAdd(&nwarn, 1);
+            r[c.row0] = c.weight * r0;
+            if (c.nrows > 1) r[c.row0 + 1] = c.weight * r1;
+            JacWriter<double*> w;
+            w.jv = jv;
+            w.jbase = c.jbase;
+            const uint32_t* loc = reinterpret_cast<const uint32_t*>(c.jloc);
+            w.loc[0] = loc[0];
+            w.loc[1] = loc[1];
+            w.loc[2] = loc[2];
+            w.loc[3] = loc[3];
+            w.weight = c.weight;
+            if (con_jacobian(c, xs, w)) atomicAdd(&nwarn, 1);
+        }
         __syncthreads();
         if (threadIdx.x == 0 && e.deg_out) e.deg_out[sys] = (uint32_t)nwarn;
         __syncthreads();

@@ -102,7 +102,8 @@ uint64_t component_fill(const std::vector<uint32_t>& ord, const std::vector<std:
 
 }  // namespace
 
-bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& P, BuildError& err) {
+bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& P, BuildError& err,
+                   uint32_t want_parts) {
     P = Program();
     if (n_cs > 0x7FFFFFF0u || n_vars > 0x7FFFFFF0u) {
         err.code = EZPZ_ERR_TOO_LARGE;
@@ -297,36 +298,76 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
         P.c.zlo = (uint32_t)zlo;
     }
     std::vector<uint32_t> level(n, 0);
-    uint32_t nlev = n ? 1 : 0;
-    for (uint32_t j = 0; j < n; ++j) {
+    for (uint32_t j = 0; j < n; ++j)
         if (parent[j] != NONE) level[parent[j]] = std::max(level[parent[j]], level[j] + 1);
-        nlev = std::max(nlev, level[j] + 1);
+
+    // ---- partitions: balanced unions of components, one per wavefront (longest-processing-time first) -------
+    const uint32_t ncomp = P.c.n_components;
+    std::vector<uint32_t> part_of_comp(ncomp, 0);
+    uint32_t n_parts = 1;
+    if (want_parts > 1 && ncomp >= want_parts) {
+        std::vector<uint64_t> w(ncomp, 0);
+        for (uint32_t v = 0; v < n; ++v) w[comp[v]] += 1 + rowpat[pos[v]].size();
+        for (uint32_t i = 0; i < C; ++i) w[comp[cs[i].ids[kKinds[cs[i].kind].nz[0][0]]]] += 4;
+        std::vector<uint32_t> by_weight(ncomp);
+        std::iota(by_weight.begin(), by_weight.end(), 0u);
+        std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+        std::vector<uint64_t> load(want_parts, 0);
+        uint64_t total = 0;
+        for (uint32_t c : by_weight) {
+            uint32_t best = 0;
+            for (uint32_t p = 1; p < want_parts; ++p)
+                if (load[p] < load[best]) best = p;
+            part_of_comp[c] = best;
+            load[best] += w[c];
+            total += w[c];
+        }
+        uint64_t worst = *std::max_element(load.begin(), load.end());
+        if (worst * want_parts <= total + total / 3 + 64) {
+            n_parts = want_parts;
+        } else {
+            std::fill(part_of_comp.begin(), part_of_comp.end(), 0u);  // one component dominates: keep one partition
+        }
     }
-    P.c.n_levels = nlev;
-    // columns grouped by level
+    P.c.n_parts = n_parts;
+    auto part_of_pos = [&](uint32_t k) { return part_of_comp[comp[order[k]]]; };
+    // columns grouped by (partition, level)
     std::vector<uint32_t> colorder(n);
     std::iota(colorder.begin(), colorder.end(), 0u);
-    std::stable_sort(colorder.begin(), colorder.end(), [&](uint32_t a, uint32_t b) { return level[a] < level[b]; });
-    P.lvl_cptr.assign(nlev + 1, 0);
-    P.lvl_sptr.assign(nlev + 1, 0);
+    std::stable_sort(colorder.begin(), colorder.end(), [&](uint32_t a, uint32_t b) {
+        uint32_t pa = part_of_pos(a), pb = part_of_pos(b);
+        return pa != pb ? pa < pb : level[a] < level[b];
+    });
+    P.parts.assign(n_parts, PartDesc{0, 0, 0, 0});
+    P.lvl_cptr.clear();
+    P.lvl_sptr.clear();
     P.lvl_cols.resize(n);
     std::vector<uint32_t> col_slot0(n, 0);  // first offdiag slot of column (position space)
+    uint32_t nlev = 0;
     {
         uint32_t slot = 0, idx = 0;
-        for (uint32_t lv = 0; lv < nlev; ++lv) {
-            P.lvl_cptr[lv] = idx;
-            P.lvl_sptr[lv] = slot;
-            while (idx < n && level[colorder[idx]] == lv) {
-                uint32_t j = colorder[idx];
-                P.lvl_cols[idx] = order[j];
-                col_slot0[j] = slot;
-                slot += (uint32_t)colrows[j].size();
-                ++idx;
+        for (uint32_t p = 0; p < n_parts; ++p) {
+            P.parts[p].lvl0 = (uint32_t)P.lvl_cptr.size();
+            uint32_t lv = 0;
+            while (idx < n && part_of_pos(colorder[idx]) == p) {
+                P.lvl_cptr.push_back(idx);
+                P.lvl_sptr.push_back(slot);
+                while (idx < n && part_of_pos(colorder[idx]) == p && level[colorder[idx]] == lv) {
+                    uint32_t j = colorder[idx];
+                    P.lvl_cols[idx] = order[j];
+                    col_slot0[j] = slot;
+                    slot += (uint32_t)colrows[j].size();
+                    ++idx;
+                }
+                ++lv;
             }
+            P.parts[p].nlev = lv;
+            P.lvl_cptr.push_back(idx);  // closing entry of this partition's slice
+            P.lvl_sptr.push_back(slot);
+            nlev = std::max(nlev, lv);
         }
-        P.lvl_cptr[nlev] = idx;
-        P.lvl_sptr[nlev] = slot;
     }
+    P.c.n_levels = nlev;
     const uint32_t zlo = P.c.zlo;
     // slot lookup per row: rowslot[k][t] = slot of (k, rowpat[k][t])
     std::vector<std::vector<uint32_t>> rowslot(n);
@@ -475,7 +516,19 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     }
 
     // ---- kind-sort the constraint table (wave-uniform evaluator branches) -------------------------------------------------
-    std::stable_sort(cons.begin(), cons.end(), [](const DevCon& a, const DevCon& b) { return a.kind < b.kind; });
+    auto part_of_con = [&](const DevCon& d) { return part_of_comp[comp[d.ids[kKinds[d.kind].nz[0][0]]]]; };
+    std::stable_sort(cons.begin(), cons.end(), [&](const DevCon& a, const DevCon& b) {
+        uint32_t pa = part_of_con(a), pb = part_of_con(b);
+        return pa != pb ? pa < pb : a.kind < b.kind;
+    });
+    {
+        uint32_t i = 0;
+        for (uint32_t p = 0; p < n_parts; ++p) {
+            P.parts[p].con0 = i;
+            while (i < C && part_of_con(cons[i]) == p) ++i;
+            P.parts[p].con1 = i;
+        }
+    }
     P.cons = std::move(cons);
     return true;
 }

@@ -32,23 +32,32 @@ struct DevCon {
 };
 static_assert(sizeof(DevCon) == 96, "DevCon layout");
 
+// A partition of the system: a union of connected components that one wavefront can own end to end
+// (its constraints, variables, Jacobian slots and Cholesky columns are disjoint from every other partition's).
+struct PartDesc {
+    uint32_t con0, con1;  // constraint range (table is sorted by partition, then kind)
+    uint32_t lvl0, nlev;  // this partition's slice of lvl_cptr / lvl_sptr (nlev + 1 entries each)
+};
+
 struct ProgramCounts {
     uint32_t n_cons = 0, n_vars = 0, n_rows = 0;
     uint32_t zj = 0;       // Jacobian slots (= nnz(J) of the reference's deduplicated CSC)
     uint32_t zlo = 0;      // strictly-lower entries of L
     uint32_t za = 0;       // nnz(lower(JtJ + lambda I)) incl. diagonal
-    uint32_t n_levels = 0;
+    uint32_t n_levels = 0;  // elimination-tree height (max over partitions)
     uint32_t n_components = 0;
+    uint32_t n_parts = 1;
     uint64_t n_apairs = 0, n_lpairs = 0;
 };
 
 struct Program {
     ProgramCounts c;
-    std::vector<DevCon> cons;                          // kind-sorted
+    std::vector<DevCon> cons;                          // sorted by (partition, kind)
+    std::vector<PartDesc> parts;
     std::vector<uint32_t> colj_ptr, colj_items;        // per var: (jslot,row)*
     std::vector<uint32_t> apair_ptr, apairs;           // per L offdiag slot: (ja,jb)*
-    std::vector<uint32_t> lvl_cptr, lvl_cols;          // per level: vars whose column is eliminated there
-    std::vector<uint32_t> lvl_sptr;                    // per level: first offdiag slot
+    std::vector<uint32_t> lvl_cptr, lvl_cols;          // per (partition, level): vars whose column is eliminated there
+    std::vector<uint32_t> lvl_sptr;                    // per (partition, level): first offdiag slot
     std::vector<uint32_t> l_col;                       // per offdiag slot: var of its column
     std::vector<uint32_t> lpair_ptr, lpairs;           // per offdiag slot: (slot_ik, slot_jk)*
     std::vector<uint32_t> fwd_ptr, fwd_items;          // per var j: (slot(j,k), var k)*  -- row of L
@@ -67,8 +76,11 @@ int residual_dim(uint16_t kind);
 // number of ids a kind uses
 int kind_num_ids(uint16_t kind);
 
-// Builds the program.  Returns false and fills `err` on MissingGuess / bad ids / size limits.
-bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& out, BuildError& err);
+// Builds the program.  `want_parts` > 1 asks for that many balanced partitions (one per wavefront of a
+// workgroup team); if the components cannot be balanced the program comes back with a single partition.
+// Returns false and fills `err` on MissingGuess / bad ids / size limits.
+bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& out, BuildError& err,
+                   uint32_t want_parts = 1);
 
 // 64-bit topology hash (kinds, tags, ids; not params/weights) for the host-side program cache.
 uint64_t topology_hash(const EzpzConstraint* cs, size_t n_cs, size_t n_vars);

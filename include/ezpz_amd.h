@@ -147,6 +147,10 @@ typedef struct EzpzSystemInfo {
     uint64_t workspace_bytes; /* per-system LDS / global workspace */
     uint32_t team_size;     /* lanes cooperating on one system */
     uint32_t workspace_in_lds;
+    uint32_t team_mode;     /* 0 sub-wavefront teams, 1 wavefront-partitioned workgroup, 2 barrier workgroup */
+    uint32_t n_partitions;  /* partitions (balanced unions of components), one per wavefront in mode 1 */
+    uint32_t program_in_lds;
+    uint32_t reserved;
 } EzpzSystemInfo;
 
 typedef struct EzpzSystem EzpzSystem; /* opaque: one analysed topology, resident on one device */

@@ -150,7 +150,7 @@ def test_square_full_size_batch_properties(E):
     assert_x_close(x[sample], xo)
 
 
-@pytest.mark.parametrize("team", [8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("team", [4, 8, 16, 32, 64, 128, 256])
 def test_team_shapes_agree(E, team):
     """Every team shape runs the same program; results must not depend on it beyond rounding of reductions."""
     text = read_case("two_rectangles")
@@ -189,6 +189,44 @@ def test_massive_parallel_system_batch(E):
     assert np.all(st["final_residual_inf"] <= 1e-9)
     info = sysobj.info()
     assert (info["nnz_j"], info["nnz_a"], info["nnz_l"], info["n_levels"]) == (2500, 2500, 2500, 2)
+    assert info["team_mode"] == 1 and info["n_partitions"] == info["team_size"] // 64  # wavefront-partitioned
+
+
+def _chain_system(n_pts):
+    """One connected component: a polyline with fixed first point, segment lengths and alternating directions."""
+    cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
+    guesses = [0.0, 0.0]
+    for k in range(1, n_pts):
+        a, b = (2 * (k - 1), 2 * k - 1), (2 * k, 2 * k + 1)
+        cons.append(O.distance(a, b, 1.0))
+        cons.append(O.horizontal(a, b) if k % 2 else O.vertical(a, b))
+        guesses += [0.55 * k + 0.1, 0.45 * k - 0.1]
+    return O.stack(cons), np.asarray(guesses)
+
+
+@pytest.mark.parametrize("team", [0, 256, 1024])
+def test_single_large_component_uses_barrier_workgroup(E, team):
+    """A system that cannot be partitioned (one connected component) runs with all lanes on one partition."""
+    recs, g = _chain_system(120)
+    sysobj = E.System(recs, len(g), team_size=team)
+    info = sysobj.info()
+    assert info["n_components"] == 1 and info["team_mode"] == 2 and info["n_partitions"] == 1
+    x0 = g[None, :] + gen.keyed_uniform(5, 6, len(g), -0.05, 0.05)
+    x, st, _ = sysobj.solve_batch(x0)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0)
+    assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv)
+    assert np.array_equal(st["n_unsatisfied"], nun)
+    assert_x_close(x, xo)
+
+
+@pytest.mark.parametrize("team", [128, 512])
+def test_partitioned_workgroup_matches_barrier_workgroup(E, team):
+    """two_rectangles has two components: the wavefront-partitioned mode must agree with every other mode."""
+    text = read_case("two_rectangles")
+    ref = T.load(text)
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(9, 64, ref.num_vars, -0.2, 0.2)
+    sysobj, x, st = _batch_vs_oracle(E, text, x0, team_size=team)
+    assert sysobj.info()["team_mode"] in (1, 2)
 
 
 def test_committed_massive_fixture_and_overconstrained_variant(E):
