@@ -83,7 +83,7 @@ struct EzpzSystem {
     DevBuf<uint8_t> mask_dev;
     DevBuf<uint64_t> log_dev;
     DevBuf<double> gws_dev;
-    std::vector<uint32_t> host_colj_ptr, host_colj_items;  // (slot,row) per variable, for jacobian_pattern
+    std::vector<uint32_t> host_var_of, host_row_of, host_slot_row, host_slot_col;  // internal -> caller numbering
     ~EzpzSystem() {
         if (dev_program) (void)hipFree(dev_program);
     }
@@ -97,7 +97,7 @@ uint32_t pow2_ceil(uint32_t v) {
     return p;
 }
 
-constexpr size_t kProgLdsMax = 16 * 1024;  // stage the topology program into LDS when it is this small
+constexpr size_t kProgLdsMax = 24 * 1024;  // sub-wavefront teams: stage the whole program into LDS when it is this small
 
 uint32_t workspace_doubles(const ProgramCounts& c) {
     const uint64_t doubles = 3ull * c.n_vars + 2ull * c.n_rows + c.zj + c.zlo + 2;
@@ -109,26 +109,25 @@ uint32_t auto_sub_team(uint32_t width) { return std::min<uint32_t>(64, std::max<
 // Workgroup size for large systems.
 uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(1024, std::max<uint32_t>(128, pow2_ceil((width + 1) / 2))); }
 
-// Fixes the launch shape once the program (and so the workspace size) is known.
-void finish_team(EzpzSystem& s, size_t blob_bytes) {
+// Fixes the launch shape once the program (and so the workspace size) is known.  `stage_bytes` > 0 means
+// that many leading bytes of the blob are copied to LDS by every workgroup (16-bit index lists).
+void finish_team(EzpzSystem& s, size_t stage_bytes) {
     s.ws_doubles = workspace_doubles(s.counts);
     const size_t ws_bytes = (size_t)s.ws_doubles * 8;
+    s.prog_in_lds = stage_bytes > 0;
+    s.prog_lds_doubles = (uint32_t)((stage_bytes + 15) / 16 * 2);
+    const size_t prog_bytes = (size_t)s.prog_lds_doubles * 8;
     if (s.mode == MODE_SUB) {
         const uint32_t team = s.team_size;
         s.lds_ws = true;
-        s.prog_in_lds = blob_bytes <= kProgLdsMax;
-        s.prog_lds_doubles = s.prog_in_lds ? (uint32_t)((blob_bytes + 15) / 16 * 2) : 0;
-        const size_t prog_bytes = (size_t)s.prog_lds_doubles * 8;
         uint32_t threads = 256;
         while (threads > 64 && prog_bytes + (size_t)(threads / team) * ws_bytes > 64 * 1024) threads >>= 1;
         s.block_threads = std::max(threads, team);
         s.lds_bytes = prog_bytes + (size_t)(s.block_threads / team) * ws_bytes + 16;
     } else {
         s.block_threads = s.team_size;
-        s.prog_in_lds = false;
-        s.prog_lds_doubles = 0;
-        s.lds_ws = ws_bytes + 1024 <= kLdsBytesMax;
-        s.lds_bytes = s.lds_ws ? ws_bytes + 64 * 8 + 16 : 80 * 8;
+        s.lds_ws = prog_bytes + ws_bytes + 1024 <= kLdsBytesMax;
+        s.lds_bytes = s.lds_ws ? prog_bytes + ws_bytes + 64 * 8 + 16 : prog_bytes + 80 * 8;
     }
 }
 
@@ -177,11 +176,15 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         if (rc != EZPZ_OK) return rc;
         args.gws = s.gws_dev.p;
     }
-    if (s.mode == MODE_PART)
-        return s.lds_ws ? launch_variant<64, MODE_PART, true, false>(s, args, grid, stream)
-                        : launch_variant<64, MODE_PART, false, false>(s, args, grid, stream);
-    return s.lds_ws ? launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream)
-                    : launch_variant<64, MODE_WGB, false, false>(s, args, grid, stream);
+    const bool staged = s.prog_in_lds;
+    if (s.mode == MODE_PART) {
+        if (!s.lds_ws) return launch_variant<64, MODE_PART, false, false>(s, args, grid, stream);
+        return staged ? launch_variant<64, MODE_PART, true, true>(s, args, grid, stream)
+                      : launch_variant<64, MODE_PART, true, false>(s, args, grid, stream);
+    }
+    if (!s.lds_ws) return launch_variant<64, MODE_WGB, false, false>(s, args, grid, stream);
+    return staged ? launch_variant<64, MODE_WGB, true, true>(s, args, grid, stream)
+                  : launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream);
 }
 
 void fill_cfg(SolveArgs& a, const EzpzConfig* cfg) {
@@ -272,40 +275,68 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         s.team_size = team;
     }
     s.counts = P.c;
-    s.host_colj_ptr = P.colj_ptr;
-    s.host_colj_items = P.colj_items;
+    s.host_var_of = P.var_of;
+    s.host_row_of = P.row_of;
+    s.host_slot_row = P.slot_row;
+    s.host_slot_col = P.slot_col;
 
-    blob.clear();
+    // ---- pack the blob: [index lists][partitions][constraint table] ---------------------------------------------
+    // The lists go first so that a workgroup can stage exactly them in LDS; they are 16-bit when staged.
+    const bool small_counts = P.c.n_vars < 65536 && P.c.n_rows < 65536 && P.c.zj < 65536 && P.c.zlo < 65536 &&
+                              P.c.n_apairs < 65536 && P.c.n_lpairs < 65536 && P.c.n_cons < 65536;
     ProgramView& v = s.view;
-    v.o_cons = (uint32_t)append(blob, P.cons);
-    v.o_parts = (uint32_t)append(blob, P.parts);
-    v.o_colj_ptr = (uint32_t)append(blob, P.colj_ptr);
-    v.o_colj_items = (uint32_t)append(blob, P.colj_items);
-    v.o_apair_ptr = (uint32_t)append(blob, P.apair_ptr);
-    v.o_apairs = (uint32_t)append(blob, P.apairs);
-    v.o_lvl_cptr = (uint32_t)append(blob, P.lvl_cptr);
-    v.o_lvl_cols = (uint32_t)append(blob, P.lvl_cols);
-    v.o_lvl_sptr = (uint32_t)append(blob, P.lvl_sptr);
-    v.o_l_col = (uint32_t)append(blob, P.l_col);
-    v.o_lpair_ptr = (uint32_t)append(blob, P.lpair_ptr);
-    v.o_lpairs = (uint32_t)append(blob, P.lpairs);
-    v.o_fwd_ptr = (uint32_t)append(blob, P.fwd_ptr);
-    v.o_fwd_items = (uint32_t)append(blob, P.fwd_items);
-    v.o_bwd_ptr = (uint32_t)append(blob, P.bwd_ptr);
-    v.o_bwd_items = (uint32_t)append(blob, P.bwd_items);
-    blob.resize((blob.size() + 15) & ~size_t(15));
+    auto pack = [&](bool idx16) {
+        blob.clear();
+        auto put = [&](const std::vector<uint32_t>& src) -> uint32_t {
+            if (!idx16) return (uint32_t)append(blob, src);
+            std::vector<uint16_t> t(src.begin(), src.end());
+            return (uint32_t)append(blob, t);
+        };
+        v.o_colj_ptr = put(P.colj_ptr);
+        v.o_colj_items = put(P.colj_items);
+        v.o_apair_ptr = put(P.apair_ptr);
+        v.o_apairs = put(P.apairs);
+        v.o_lvl_cptr = put(P.lvl_cptr);
+        v.o_lvl_sptr = put(P.lvl_sptr);
+        v.o_l_col = put(P.l_col);
+        v.o_lpair_ptr = put(P.lpair_ptr);
+        v.o_lpairs = put(P.lpairs);
+        v.o_fwd_ptr = put(P.fwd_ptr);
+        v.o_fwd_items = put(P.fwd_items);
+        v.o_bwd_ptr = put(P.bwd_ptr);
+        v.o_bwd_items = put(P.bwd_items);
+        v.o_var_of = (uint32_t)append(blob, P.var_of);
+        blob.resize((blob.size() + 15) & ~size_t(15));
+        const size_t lists_bytes = blob.size();
+        v.o_parts = (uint32_t)append(blob, P.parts);
+        v.o_cons = (uint32_t)append(blob, P.cons);
+        blob.resize((blob.size() + 15) & ~size_t(15));
+        return lists_bytes;
+    };
+    size_t stage_bytes = 0;
+    if (small_counts) {
+        const size_t lists_bytes = pack(true);
+        const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
+        if (s.mode == MODE_SUB) {
+            if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
+        } else if (lists_bytes + ws_bytes + 2048 <= kLdsBytesMax) {
+            stage_bytes = lists_bytes;
+        }
+    }
+    if (stage_bytes == 0) pack(false);
     if (blob.size() > 0xFFFFFFF0ull) {
         be.code = EZPZ_ERR_TOO_LARGE;
         return fail();
     }
     v.blob_bytes = (uint32_t)blob.size();
+    v.stage_bytes = (uint32_t)stage_bytes;
     v.n_cons = P.c.n_cons;
     v.n_vars = P.c.n_vars;
     v.n_rows = P.c.n_rows;
     v.zj = P.c.zj;
     v.zlo = P.c.zlo;
     v.n_parts = P.c.n_parts;
-    finish_team(s, blob.size());
+    finish_team(s, stage_bytes);
 
     EzpzSystemInfo& info = s.info;
     std::memset(&info, 0, sizeof(info));
@@ -372,12 +403,10 @@ int ezpz_analyze(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, EzpzSyste
 
 int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t* cols) {
     if (!sys || !rows || !cols) return EZPZ_ERR_INVALID_ARGUMENT;
-    for (uint32_t v = 0; v < sys->counts.n_vars; ++v)
-        for (uint32_t q = sys->host_colj_ptr[v]; q < sys->host_colj_ptr[v + 1]; ++q) {
-            uint32_t slot = sys->host_colj_items[2 * q];
-            rows[slot] = sys->host_colj_items[2 * q + 1];
-            cols[slot] = v;
-        }
+    for (uint32_t s = 0; s < sys->counts.zj; ++s) {
+        rows[s] = sys->host_slot_row[s];
+        cols[s] = sys->host_slot_col[s];
+    }
     return EZPZ_OK;
 }
 
@@ -395,7 +424,11 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
     if ((rc = rd.ensure(batch * std::max<size_t>(m, 1))) != EZPZ_OK) return rc;
     if ((rc = jd.ensure(batch * std::max<size_t>(zj, 1))) != EZPZ_OK) return rc;
     if ((rc = dd.ensure(batch)) != EZPZ_OK) return rc;
-    HIP_TRY(hipMemcpy(xd.p, x, batch * n * sizeof(double), hipMemcpyHostToDevice));
+    // the evaluators address values / rows by the program's internal numbering
+    std::vector<double> xin(batch * std::max<size_t>(n, 1)), rin(batch * std::max<size_t>(m, 1));
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t k = 0; k < n; ++k) xin[b * n + k] = x[b * n + sys->host_var_of[k]];
+    HIP_TRY(hipMemcpy(xd.p, xin.data(), batch * n * sizeof(double), hipMemcpyHostToDevice));
     EvalArgs e{};
     e.p = sys->view;
     e.x = xd.p;
@@ -406,7 +439,9 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
     uint32_t grid = (uint32_t)std::min<size_t>(batch, 4096);
     hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(256), 0, nullptr, e);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(r_out, rd.p, batch * m * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rin.data(), rd.p, batch * m * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t k = 0; k < m; ++k) r_out[b * m + sys->host_row_of[k]] = rin[b * m + k];
     HIP_TRY(hipMemcpy(jv_out, jd.p, batch * zj * sizeof(double), hipMemcpyDeviceToHost));
     if (degenerate_count_out)
         HIP_TRY(hipMemcpy(degenerate_count_out, dd.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost));

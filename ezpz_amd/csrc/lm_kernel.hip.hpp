@@ -23,6 +23,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "constraint_eval.hip.hpp"
 
 namespace ezpz {
@@ -35,37 +37,44 @@ struct ProgramView {
     uint32_t o_cons, o_parts;
     uint32_t o_colj_ptr, o_colj_items;
     uint32_t o_apair_ptr, o_apairs;
-    uint32_t o_lvl_cptr, o_lvl_cols, o_lvl_sptr, o_l_col;
+    uint32_t o_lvl_cptr, o_var_of, o_lvl_sptr, o_l_col;
     uint32_t o_lpair_ptr, o_lpairs;
     uint32_t o_fwd_ptr, o_fwd_items;
     uint32_t o_bwd_ptr, o_bwd_items;
     uint32_t blob_bytes;
+    uint32_t stage_bytes;  // leading bytes of the blob to copy into LDS (index lists, or the whole blob); 0 = none
     uint32_t n_cons, n_vars, n_rows, zj, zlo, n_parts;
 };
 
-// Typed pointers into the blob (global or LDS).
+// Typed pointers into the blob.  Index lists are 16-bit when they are staged in LDS (every count < 65536),
+// 32-bit otherwise; the constraint table and the partition descriptors keep their layout.
+template <class IDX>
 struct Prog {
     const DevCon* cons;
     const PartDesc* parts;
-    const uint32_t *colj_ptr, *colj_items;
-    const uint32_t *apair_ptr, *apairs;
-    const uint32_t *lvl_cptr, *lvl_cols, *lvl_sptr, *l_col;
-    const uint32_t *lpair_ptr, *lpairs;
-    const uint32_t *fwd_ptr, *fwd_items;
-    const uint32_t *bwd_ptr, *bwd_items;
+    const IDX *colj_ptr, *colj_items;
+    const IDX *apair_ptr, *apairs;
+    const IDX *lvl_cptr, *lvl_sptr, *l_col;
+    const uint32_t* var_of;
+    const IDX *lpair_ptr, *lpairs;
+    const IDX *fwd_ptr, *fwd_items;
+    const IDX *bwd_ptr, *bwd_items;
 };
 
-__device__ __forceinline__ Prog make_prog(const ProgramView& v, const unsigned char* b) {
-    Prog p;
-    p.cons = reinterpret_cast<const DevCon*>(b + v.o_cons);
-    p.parts = reinterpret_cast<const PartDesc*>(b + v.o_parts);
-    auto u = [&](uint32_t o) { return reinterpret_cast<const uint32_t*>(b + o); };
+// `lists` addresses the index lists (LDS copy or global blob), `tables` the constraint table / partitions.
+template <class IDX>
+__device__ __forceinline__ Prog<IDX> make_prog(const ProgramView& v, const unsigned char* lists,
+                                               const unsigned char* tables) {
+    Prog<IDX> p;
+    p.cons = reinterpret_cast<const DevCon*>(tables + v.o_cons);
+    p.parts = reinterpret_cast<const PartDesc*>(tables + v.o_parts);
+    auto u = [&](uint32_t o) { return reinterpret_cast<const IDX*>(lists + o); };
     p.colj_ptr = u(v.o_colj_ptr);
     p.colj_items = u(v.o_colj_items);
     p.apair_ptr = u(v.o_apair_ptr);
     p.apairs = u(v.o_apairs);
     p.lvl_cptr = u(v.o_lvl_cptr);
-    p.lvl_cols = u(v.o_lvl_cols);
+    p.var_of = reinterpret_cast<const uint32_t*>(lists + v.o_var_of);
     p.lvl_sptr = u(v.o_lvl_sptr);
     p.l_col = u(v.o_l_col);
     p.lpair_ptr = u(v.o_lpair_ptr);
@@ -75,6 +84,19 @@ __device__ __forceinline__ Prog make_prog(const ProgramView& v, const unsigned c
     p.bwd_ptr = u(v.o_bwd_ptr);
     p.bwd_items = u(v.o_bwd_items);
     return p;
+}
+
+// One wide, fully parallel load of a constraint record (6 x 16 B in flight) instead of field-by-field
+// dependent loads: the sweeps are latency bound on exactly this.
+__device__ __forceinline__ DevCon load_con(const DevCon* p) {
+    union {
+        DevCon c;
+        uint4 q[6];
+    } u;
+    const uint4* src = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) u.q[i] = src[i];
+    return u.c;
 }
 
 struct SolveArgs {
@@ -171,6 +193,23 @@ struct Team {
 
 }  // namespace dev
 
+// Constraint record access: a wide by-value load when the table is in global memory, a plain reference when
+// it sits in LDS (sub-wavefront teams with a staged program), where field-by-field reads are cheap.
+template <bool WIDE>
+struct ConRef;
+template <>
+struct ConRef<true> {
+    DevCon c;
+    __device__ __forceinline__ explicit ConRef(const DevCon* p) : c(load_con(p)) {}
+    __device__ __forceinline__ const DevCon& get() const { return c; }
+};
+template <>
+struct ConRef<false> {
+    const DevCon* p;
+    __device__ __forceinline__ explicit ConRef(const DevCon* q) : p(q) {}
+    __device__ __forceinline__ const DevCon& get() const { return *p; }
+};
+
 template <int TEAM, int MODE, bool LDSWS, bool PLDS>
 __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SUB ? 4 : 1)
     lm_solve_kernel(const SolveArgs a) {
@@ -196,16 +235,21 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
     const uint32_t team_in_block = (MODE == MODE_SUB) ? (uint32_t)(tid / TEAM) : 0u;
     const uint32_t n = a.p.n_vars, m = a.p.n_rows, zj = a.p.zj, zlo = a.p.zlo;
 
-    // ---- topology program: global/L2, or staged once per workgroup into LDS ----------------------------------
-    const unsigned char* pbase = a.p.base;
+    // ---- topology program: global/L2, or staged once per workgroup into LDS -------------------------------------
+    // PLDS: the leading `stage_bytes` of the blob (the index lists; for sub-wavefront teams the whole blob incl. the
+    // constraint table) are copied to LDS and the lists are 16-bit.
+    using idx_t = typename std::conditional<PLDS, uint16_t, uint32_t>::type;
+    const unsigned char* lbase = a.p.base;
+    const unsigned char* tbase = a.p.base;
     if constexpr (PLDS) {
         const uint4* src = reinterpret_cast<const uint4*>(a.p.base);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < a.p.blob_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = tid; i < a.p.stage_bytes / 16; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
-        pbase = reinterpret_cast<const unsigned char*>(smem);
+        lbase = reinterpret_cast<const unsigned char*>(smem);
+        if constexpr (MODE == MODE_SUB) tbase = lbase;
     }
-    const Prog P = make_prog(a.p, pbase);
+    const Prog<idx_t> P = make_prog<idx_t>(a.p, lbase, tbase);
 
     // ---- workspace carve-up (doubles) ----------------------------------------------------------------------------
     double* ws;
@@ -234,17 +278,17 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
     // ---- this unit's partition --------------------------------------------------------------------------------------
     const PartDesc part = P.parts[(MODE == MODE_PART) ? (uint32_t)(tid >> 6) : 0u];
     const uint32_t con0 = part.con0, con1 = part.con1;
-    const uint32_t* lvl_cptr = P.lvl_cptr + part.lvl0;
-    const uint32_t* lvl_sptr = P.lvl_sptr + part.lvl0;
+    const idx_t* lvl_cptr = P.lvl_cptr + part.lvl0;
+    const idx_t* lvl_sptr = P.lvl_sptr + part.lvl0;
     const uint32_t nlev = part.nlev;
-    const uint32_t call0 = lvl_cptr[0], call1 = lvl_cptr[nlev];  // all of the partition's variables (lvl_cols entries)
+    const uint32_t call0 = lvl_cptr[0], call1 = lvl_cptr[nlev];  // all of the partition's (internal) variables
     const uint32_t sall0 = lvl_sptr[0], sall1 = lvl_sptr[nlev];  // all of its strictly-lower L slots
 
     const uint64_t n_teams = (uint64_t)gridDim.x * teams_per_block;
     for (uint64_t sys = (uint64_t)blockIdx.x * teams_per_block + team_in_block; sys < a.batch; sys += n_teams) {
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
         const double* x0 = a.x0 + sys * n;
-        for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[i];
+        for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[P.var_of[i]];
         if (tlane == 0) *nwarn = 0;
         tm.team_sync();
 
@@ -277,7 +321,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
             if (mode == STEP) {
                 // ---- A = JtJ + lambda I (into L's storage) and b = Jt(-r)  (newton.rs:77-84) ---------------------
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
-                    const uint32_t v = P.lvl_cols[ci];
+                    const uint32_t v = ci;  // internal variable numbering = schedule order
                     double acc = 0.0, b = 0.0;
                     for (uint32_t q = P.colj_ptr[v]; q < P.colj_ptr[v + 1]; ++q) {
                         double jv = ws[o_j + P.colj_items[2 * q]];
@@ -300,7 +344,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                     const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
                     const uint32_t s0 = lvl_sptr[lv], s1 = lvl_sptr[lv + 1];
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
-                        const uint32_t v = P.lvl_cols[ci];
+                        const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_d + v];
                         for (uint32_t q = P.fwd_ptr[v]; q < P.fwd_ptr[v + 1]; ++q) {
                             double l = ws[o_l + P.fwd_items[2 * q]];
@@ -319,7 +363,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                     for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride)
                         ws[o_l + s] = ws[o_l + s] / ws[o_d + P.l_col[s]];
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
-                        const uint32_t v = P.lvl_cols[ci];
+                        const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_v + v];
                         for (uint32_t q = P.fwd_ptr[v]; q < P.fwd_ptr[v + 1]; ++q)
                             acc -= ws[o_l + P.fwd_items[2 * q]] * ws[o_v + P.fwd_items[2 * q + 1]];
@@ -331,7 +375,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                 for (uint32_t lv = nlev; lv-- > 0;) {
                     const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
-                        const uint32_t v = P.lvl_cols[ci];
+                        const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_v + v];
                         for (uint32_t q = P.bwd_ptr[v]; q < P.bwd_ptr[v + 1]; ++q)
                             acc -= ws[o_l + P.bwd_items[2 * q]] * ws[o_v + P.bwd_items[2 * q + 1]];
@@ -342,7 +386,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                 // ---- ||d||_inf and "did any pivot fail": one rendezvous (newton.rs:96-99, :108) ------------------------------
                 double dmax = __builtin_nan("");  // fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax)
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride)
-                    dmax = fmax(dmax, fabs(ws[o_v + P.lvl_cols[ci]]));
+                    dmax = fmax(dmax, fabs(ws[o_v + ci]));
                 tm.reduce2(bad, dmax, OpMax(), OpMax());
                 if (bad > 0.0) {  // numeric failure => lambda *= 10, burn the iteration
                     lambda *= LM_LAMBDA_INCR;
@@ -352,7 +396,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                 step_inf_norm = (n > 0) ? dmax : 0.0;
                 // ---- tentative step (newton.rs:111-114) ---------------------------------------------------------------------
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
-                    const uint32_t v = P.lvl_cols[ci];
+                    const uint32_t v = ci;  // internal variable numbering = schedule order
                     ws[o_x + v] = ws[o_x + v] + ws[o_v + v];
                 }
                 tm.phase_sync();
@@ -364,7 +408,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
             double sq = 0.0;
             double mx = __builtin_nan("");
             for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                const DevCon& c = P.cons[ci];
+                const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
+                const DevCon& c = cref.get();
                 double r0, r1;
                 const bool deg = con_residual(c, ws + o_x, r0, r1);
                 const double wgt = (mode == FINAL) ? 1.0 : c.weight;
@@ -399,7 +444,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                 }
                 // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121; solver.rs:359-440) ------------------
                 for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                    const DevCon& c = P.cons[ci];
+                    const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
+                    const DevCon& c = cref.get();
                     JacWriter<double*> w;
                     w.jv = ws + o_j;
                     w.jbase = c.jbase;
@@ -421,7 +467,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                 largest = mx;
             } else {  // reject: revert, raise lambda (newton.rs:124-131)
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
-                    const uint32_t v = P.lvl_cols[ci];
+                    const uint32_t v = ci;  // internal variable numbering = schedule order
                     ws[o_x + v] = ws[o_x + v] - ws[o_v + v];
                 }
                 lambda *= LM_LAMBDA_INCR;
@@ -452,7 +498,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
         }
         tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());  // also the rendezvous before the cooperative store of x
         double* xo = a.x_out + sys * n;
-        for (uint32_t i = tlane; i < n; i += tsize) xo[i] = ws[o_x + i];
+        for (uint32_t i = tlane; i < n; i += tsize) xo[P.var_of[i]] = ws[o_x + i];
         if (tlane == 0) {
             EzpzStatus st;
             st.iterations = iterations;
@@ -480,7 +526,7 @@ struct EvalArgs {
 __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs e) {
     using namespace dev;
     __shared__ int nwarn;
-    const Prog P = make_prog(e.p, e.p.base);
+    const Prog<uint32_t> P = make_prog<uint32_t>(e.p, e.p.base, e.p.base);
     for (uint64_t sys = blockIdx.x; sys < e.batch; sys += gridDim.x) {
         if (threadIdx.x == 0) nwarn = 0;
         __syncthreads();

@@ -341,7 +341,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     P.parts.assign(n_parts, PartDesc{0, 0, 0, 0});
     P.lvl_cptr.clear();
     P.lvl_sptr.clear();
-    P.lvl_cols.resize(n);
+    std::vector<uint32_t> lvl_cols(n);
     std::vector<uint32_t> col_slot0(n, 0);  // first offdiag slot of column (position space)
     uint32_t nlev = 0;
     {
@@ -354,7 +354,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
                 P.lvl_sptr.push_back(slot);
                 while (idx < n && part_of_pos(colorder[idx]) == p && level[colorder[idx]] == lv) {
                     uint32_t j = colorder[idx];
-                    P.lvl_cols[idx] = order[j];
+                    lvl_cols[idx] = order[j];
                     col_slot0[j] = slot;
                     slot += (uint32_t)colrows[j].size();
                     ++idx;
@@ -529,6 +529,73 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
             P.parts[p].con1 = i;
         }
     }
+
+    // ---- internal renumbering ---------------------------------------------------------------------------------------
+    // Every state array of the kernel is addressed through these lists only, so the numbering is ours to choose:
+    // variables in schedule order (lvl_cols becomes the identity and is dropped), rows and Jacobian slots in
+    // constraint-table order.  Lane l of a phase then touches word l of its array: no index load, no LDS bank
+    // conflict.  List orders are unchanged, so every floating-point sum is formed in the same order as before.
+    P.var_of = lvl_cols;
+    std::vector<uint32_t> ivar(n);
+    for (uint32_t k = 0; k < n; ++k) ivar[P.var_of[k]] = k;
+    std::vector<uint32_t> new_row(m), new_slot(P.c.zj);
+    P.row_of.assign(m, 0);
+    {
+        uint32_t run_row = 0, run_slot = 0;
+        for (DevCon& d : cons) {
+            const uint32_t r0 = run_row, s0 = run_slot;
+            for (uint32_t r = 0; r < d.nrows; ++r) {
+                new_row[d.row0 + r] = run_row;
+                P.row_of[run_row] = d.row0 + r;
+                ++run_row;
+            }
+            for (uint32_t t = 0; t < d.nslots; ++t) new_slot[d.jbase + t] = run_slot++;
+            d.row0 = r0;
+            d.jbase = s0;
+            const KindInfo& K = kKinds[d.kind];
+            for (int k = 0; k < K.n_ids; ++k) {
+                // ids a kind never dereferences (not in `nonzeroes`) may be out of range: leave them at 0
+                d.ids[k] = d.ids[k] < n ? ivar[d.ids[k]] : 0;
+            }
+        }
+    }
+    P.slot_row.assign(P.c.zj, 0);
+    P.slot_col.assign(P.c.zj, 0);
+    {
+        std::vector<uint32_t> ptr(n + 1, 0), items;
+        items.reserve(P.colj_items.size());
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t v = P.var_of[k];
+            for (uint32_t q = P.colj_ptr[v]; q < P.colj_ptr[v + 1]; ++q) {
+                const uint32_t s_new = new_slot[P.colj_items[2 * q]], row_old = P.colj_items[2 * q + 1];
+                items.push_back(s_new);
+                items.push_back(new_row[row_old]);
+                P.slot_row[s_new] = row_old;
+                P.slot_col[s_new] = v;
+            }
+            ptr[k + 1] = (uint32_t)(items.size() / 2);
+        }
+        P.colj_ptr.swap(ptr);
+        P.colj_items.swap(items);
+    }
+    for (uint32_t& s2 : P.apairs) s2 = new_slot[s2];
+    for (uint32_t& v : P.l_col) v = ivar[v];
+    auto renumber_rows_of_l = [&](std::vector<uint32_t>& ptr_in, std::vector<uint32_t>& items_in) {
+        std::vector<uint32_t> ptr(n + 1, 0), items;
+        items.reserve(items_in.size());
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t v = P.var_of[k];
+            for (uint32_t q = ptr_in[v]; q < ptr_in[v + 1]; ++q) {
+                items.push_back(items_in[2 * q]);
+                items.push_back(ivar[items_in[2 * q + 1]]);
+            }
+            ptr[k + 1] = (uint32_t)(items.size() / 2);
+        }
+        ptr_in.swap(ptr);
+        items_in.swap(items);
+    };
+    renumber_rows_of_l(P.fwd_ptr, P.fwd_items);
+    renumber_rows_of_l(P.bwd_ptr, P.bwd_items);
     P.cons = std::move(cons);
     return true;
 }

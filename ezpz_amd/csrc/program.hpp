@@ -19,7 +19,7 @@
 namespace ezpz {
 
 // One constraint as the kernel sees it.  96 bytes.
-struct DevCon {
+struct alignas(16) DevCon {
     uint32_t ids[8];
     double param;
     double weight;
@@ -54,9 +54,14 @@ struct Program {
     ProgramCounts c;
     std::vector<DevCon> cons;                          // sorted by (partition, kind)
     std::vector<PartDesc> parts;
-    std::vector<uint32_t> colj_ptr, colj_items;        // per var: (jslot,row)*
+    std::vector<uint32_t> colj_ptr, colj_items;        // per internal var: (jslot,row)*
     std::vector<uint32_t> apair_ptr, apairs;           // per L offdiag slot: (ja,jb)*
-    std::vector<uint32_t> lvl_cptr, lvl_cols;          // per (partition, level): vars whose column is eliminated there
+    // Internal numbering (chosen so that consecutive lanes touch consecutive LDS words): variables are numbered
+    // in elimination-schedule order (partition, level, column), rows and Jacobian slots in constraint-table order.
+    std::vector<uint32_t> var_of;                      // internal variable -> caller's variable id
+    std::vector<uint32_t> row_of;                      // internal row -> caller's row (request order)
+    std::vector<uint32_t> slot_row, slot_col;          // internal Jacobian slot -> caller's (row, variable id)
+    std::vector<uint32_t> lvl_cptr;                    // per (partition, level): first internal variable eliminated there
     std::vector<uint32_t> lvl_sptr;                    // per (partition, level): first offdiag slot
     std::vector<uint32_t> l_col;                       // per offdiag slot: var of its column
     std::vector<uint32_t> lpair_ptr, lpairs;           // per offdiag slot: (slot_ik, slot_jk)*
