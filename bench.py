@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--team", type=int, default=0, help="override lanes per system (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--check", type=int, default=1, help="verify the results of the last step against the oracle")
+    ap.add_argument("--extras", type=int, default=1, help="also report PCIe-inclusive rate, single-solve latency (and, "
+                    "for N>1, the rate with the RCCL scatter/gather of the batch) -- never part of `value`")
     args = ap.parse_args()
 
     import numpy as np
@@ -137,6 +139,45 @@ def main():
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    extras = {}
+    if args.extras:
+        # (1) host-pointer entry point: H2D + kernel + D2H per call (pageable host memory) -- the PCIe-inclusive rate
+        if rank == 0:
+            hb = min(B, 1024)
+            system.solve_batch(x0_host[:hb])
+            th = time.perf_counter()
+            for _ in range(3):
+                system.solve_batch(x0_host[:hb])
+            extras["pcie_inclusive_solves_per_s"] = 3 * hb / (time.perf_counter() - th)
+            extras["pcie_inclusive_batch"] = hb
+            # (2) one system per launch, back to back on the stream: device-side latency of a single solve
+            one_x = x0[:1].clone()
+            one_o = torch.empty_like(one_x)
+            one_s = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+            for _ in range(10):
+                system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            tl = time.perf_counter()
+            for _ in range(200):
+                system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            extras["single_solve_latency_us"] = (time.perf_counter() - tl) / 200 * 1e6
+        # (3) N>1: whole batch starts and ends on rank 0; one RCCL scatter + one gather around the solve
+        if world > 1:
+            from ezpz_amd.distributed import solve_batch_sharded
+
+            full = torch.cat([x0] * world, dim=0) if rank == 0 else None
+            solve_batch_sharded(system, full, n, device=dev)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            te = time.perf_counter()
+            reps = max(1, min(args.steps, 10))
+            for _ in range(reps):
+                solve_batch_sharded(system, full, n, device=dev)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            extras["with_rccl_scatter_gather_solves_per_s"] = world * B * reps / (time.perf_counter() - te)
 
     st = status.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
     iters = np.unique(st["iterations"]).tolist()
@@ -202,6 +243,8 @@ def main():
         }
         if checked:
             line["oracle_check"] = checked
+        if extras:
+            line["extras"] = extras
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(records, guesses, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

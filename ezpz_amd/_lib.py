@@ -48,7 +48,7 @@ EXPORTS = [
     "ezpz_system_info", "ezpz_system_solve_batch_device", "ezpz_system_solve_batch", "ezpz_solve_inner", "ezpz_solve",
     "ezpz_problem_parse", "ezpz_problem_destroy", "ezpz_problem_num_constraints", "ezpz_problem_num_vars",
     "ezpz_problem_constraints", "ezpz_problem_guesses", "ezpz_problem_num_labels", "ezpz_problem_label",
-    "ezpz_analyze", "ezpz_system_eval_batch", "ezpz_system_jacobian_pattern",
+    "ezpz_analyze", "ezpz_system_eval_batch", "ezpz_system_jacobian_pattern", "ezpz_cache_clear",
 ]
 
 _lib = None
@@ -59,8 +59,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if os.environ.get("EZPZ_AMD_NO_BUILD") != "1":
+    path = os.environ.get("EZPZ_AMD_LIB") or _build.LIB  # EZPZ_AMD_LIB: A/B-test another build of the library
+    if path == _build.LIB and os.environ.get("EZPZ_AMD_NO_BUILD") != "1":
         path = _build.build()
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -m ezpz_amd.build` (needs hipcc)")
@@ -78,6 +78,8 @@ def lib():
     L.ezpz_system_destroy.argtypes = [vp]
     L.ezpz_system_info.restype = C.c_int
     L.ezpz_system_info.argtypes = [vp, C.POINTER(CSystemInfo)]
+    L.ezpz_cache_clear.restype = None
+    L.ezpz_cache_clear.argtypes = []
     L.ezpz_analyze.restype = C.c_int
     L.ezpz_analyze.argtypes = [vp, sz, sz, C.POINTER(CSystemInfo), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.ezpz_system_eval_batch.restype = C.c_int

@@ -26,9 +26,19 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+CLI = os.path.join(HERE, "ezpz-amd")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or stale():
         cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    cli_src = os.path.join(CSRC, "cli.cpp")
+    if force or not os.path.exists(CLI) or os.path.getmtime(CLI) < max(os.path.getmtime(cli_src), os.path.getmtime(LIB)):
+        # the reference's CLI (ezpz-cli) restated on the C ABI; a plain host program linked against the library
+        cmd = [hipcc(), "-O2", "-std=c++17", "-o", CLI, cli_src, "-L" + HERE, "-lezpz_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

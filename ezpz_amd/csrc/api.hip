@@ -107,7 +107,7 @@ uint32_t workspace_doubles(const ProgramCounts& c) {
 // Sub-wavefront team for small systems: lanes per system.
 uint32_t auto_sub_team(uint32_t width) { return std::min<uint32_t>(64, std::max<uint32_t>(8, pow2_ceil((width + 1) / 2))); }
 // Workgroup size for large systems.
-uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(1024, std::max<uint32_t>(128, pow2_ceil((width + 1) / 2))); }
+uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(512, std::max<uint32_t>(128, pow2_ceil((width + 3) / 4))); }
 
 // Fixes the launch shape once the program (and so the workspace size) is known.  `stage_bytes` > 0 means
 // that many leading bytes of the blob are copied to LDS by every workgroup (16-bit index lists).
@@ -592,6 +592,12 @@ void set_from_initial_values(EzpzConstraint& c, const std::vector<double>& iv) {
 }  // namespace
 
 extern "C" {
+
+void ezpz_cache_clear(void) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    for (auto& e : g_cache) ezpz_system_destroy(e.sys);
+    g_cache.clear();
+}
 
 int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
                      const double* guesses, size_t n_guesses, const EzpzConfig* cfg, double* x_out,

@@ -211,6 +211,11 @@ int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_id
                size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
                size_t warn_cap, EzpzOutcome* out);
 
+/* ezpz_solve / ezpz_solve_inner keep a small cache of analysed topologies keyed by the request bytes, so that
+ * repeated solves of one problem (ezpz-cli's 100-run loop, main.rs:96-98) skip the symbolic phase.  This drops
+ * it (used to time cold solves). */
+void ezpz_cache_clear(void);
+
 /* ---- textual front end, ezpz/src/textual.rs:43-49 (Problem: FromStr) + executor.rs:40-445 ------------ */
 typedef struct EzpzProblem EzpzProblem; /* opaque: parsed + lowered problem text */
 int ezpz_problem_parse(const char* text, size_t len, EzpzProblem** out, char* errbuf, size_t errcap);

@@ -301,3 +301,27 @@ def test_object_api_mirrors_the_crate(E):
     with pytest.raises(E.FailureOutcome) as e:
         E.solve([E.ConstraintRequest.highest_priority(E.Constraint.Fixed(0, 0.0))], [], E.Config())
     assert e.value.error.code == -3 and (e.value.error.constraint_id, e.value.error.variable) == (0, 0)
+
+
+def test_cli_equivalent_driver(E):
+    """ezpz-cli/src/main.rs:240-300: stdout carries the problem size, iterations and the timing lines."""
+    import subprocess
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "ezpz_amd", "ezpz-amd")
+    assert os.path.exists(exe), "build() must produce the CLI"
+    for case, size in (("tiny", "Problem size: 4 rows, 4 vars"), ("arc_radius", "Problem size: 4 rows, 8 vars"),
+                       ("circle", "Problem size: 5 rows, 5 vars")):
+        path = os.path.join(GOLDEN, "test_cases", case, "problem.md")
+        out = subprocess.run([exe, "-f", path, "--show-points"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert size in out.stdout
+        assert "Iterations needed: " in out.stdout and "Solved up to priority: 0" in out.stdout
+        assert "(mean over 100 iterations)" in out.stdout and "solves per second" in out.stdout
+        assert "Points:" in out.stdout
+    # stdin form (main.rs:225-238) and a parse error
+    text = read_case("tiny")
+    out = subprocess.run([exe, "-f", "-"], input=text, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "Iterations needed: 1" in out.stdout
+    bad = subprocess.run([exe, "-f", "-"], input="nonsense", capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "Error" in bad.stderr
