@@ -60,6 +60,30 @@ struct DevBuf {
     }
 };
 
+// Grow-only pinned, device-mapped host buffer (zero-copy path of small solves).
+struct PinnedBuf {
+    unsigned char* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return EZPZ_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(bytes + bytes / 2, 64 * 1024);
+        if (hipHostMalloc((void**)&p, want, hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            return EZPZ_ERR_HIP;
+        }
+        cap = want;
+        return EZPZ_OK;
+    }
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+
+constexpr size_t kZeroCopyBytes = 1 << 20;  // calls moving less than this skip DMA and use mapped host memory
+
 }  // namespace
 
 struct EzpzSystem {
@@ -83,6 +107,7 @@ struct EzpzSystem {
     DevBuf<uint8_t> mask_dev;
     DevBuf<uint64_t> log_dev;
     DevBuf<double> gws_dev;
+    PinnedBuf pinned;
     std::vector<uint32_t> host_var_of, host_row_of, host_slot_row, host_slot_col;  // internal -> caller numbering
     ~EzpzSystem() {
         if (dev_program) (void)hipFree(dev_program);
@@ -477,20 +502,52 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     std::lock_guard<std::mutex> lock(sys->mu);
     HIP_TRY(hipSetDevice(sys->device));
     const size_t n = sys->counts.n_vars, C = sys->counts.n_cons;
+    const bool want_log = warn_log && warn_cap;
+    const size_t x_bytes = batch * std::max<size_t>(n, 1) * sizeof(double);
+    const size_t st_bytes = batch * sizeof(EzpzStatus);
+    const size_t mask_bytes = unsat_mask ? ((batch * std::max<size_t>(C, 1) + 15) & ~size_t(15)) : 0;
+    const size_t log_bytes = want_log ? batch * (size_t)warn_cap * sizeof(uint64_t) : 0;
     int rc;
+    if (x_bytes + st_bytes + mask_bytes <= kZeroCopyBytes) {
+        // Small call (the solve() case): no DMA at all.  The kernel reads the guesses from, and writes the
+        // results to, pinned host memory mapped into the device address space; one launch + one stream sync.
+        const size_t total = x_bytes + st_bytes + mask_bytes + log_bytes;
+        if ((rc = sys->pinned.ensure(total)) != EZPZ_OK) return rc;
+        unsigned char* h = sys->pinned.p;
+        double* hx = reinterpret_cast<double*>(h);
+        EzpzStatus* hst = reinterpret_cast<EzpzStatus*>(h + x_bytes);
+        uint8_t* hmask = h + x_bytes + st_bytes;
+        uint64_t* hlog = reinterpret_cast<uint64_t*>(h + x_bytes + st_bytes + mask_bytes);
+        if (n) std::memcpy(hx, x0, batch * n * sizeof(double));
+        rc = ezpz_system_solve_batch_device(sys, hx, batch, cfg, hx, hst, unsat_mask ? hmask : nullptr,
+                                            want_log ? hlog : nullptr, warn_cap, nullptr);
+        if (rc != EZPZ_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        std::memcpy(status, hst, st_bytes);
+        if (n) std::memcpy(x_out, hx, batch * n * sizeof(double));
+        if (unsat_mask && C) std::memcpy(unsat_mask, hmask, batch * C);
+        if (want_log) {
+            // only the entries the kernel wrote are meaningful: n_warnings per system, capped
+            for (size_t b = 0; b < batch; ++b) {
+                size_t cnt = std::min<size_t>(hst[b].n_warnings, warn_cap);
+                std::memcpy(warn_log + b * warn_cap, hlog + b * warn_cap, cnt * sizeof(uint64_t));
+            }
+        }
+        return EZPZ_OK;
+    }
     if ((rc = sys->x_dev.ensure(batch * std::max<size_t>(n, 1))) != EZPZ_OK) return rc;
     if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
     if (unsat_mask && (rc = sys->mask_dev.ensure(batch * std::max<size_t>(C, 1))) != EZPZ_OK) return rc;
-    if (warn_log && warn_cap && (rc = sys->log_dev.ensure(batch * (size_t)warn_cap)) != EZPZ_OK) return rc;
+    if (want_log && (rc = sys->log_dev.ensure(batch * (size_t)warn_cap)) != EZPZ_OK) return rc;
     if (n) HIP_TRY(hipMemcpy(sys->x_dev.p, x0, batch * n * sizeof(double), hipMemcpyHostToDevice));
     rc = ezpz_system_solve_batch_device(sys, sys->x_dev.p, batch, cfg, sys->x_dev.p, sys->st_dev.p,
-                                        unsat_mask ? sys->mask_dev.p : nullptr,
-                                        (warn_log && warn_cap) ? sys->log_dev.p : nullptr, warn_cap, nullptr);
+                                        unsat_mask ? sys->mask_dev.p : nullptr, want_log ? sys->log_dev.p : nullptr,
+                                        warn_cap, nullptr);
     if (rc != EZPZ_OK) return rc;
     HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
     if (n) HIP_TRY(hipMemcpy(x_out, sys->x_dev.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
     if (unsat_mask && C) HIP_TRY(hipMemcpy(unsat_mask, sys->mask_dev.p, batch * C, hipMemcpyDeviceToHost));
-    if (warn_log && warn_cap)
+    if (want_log)
         HIP_TRY(hipMemcpy(warn_log, sys->log_dev.p, batch * (size_t)warn_cap * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return EZPZ_OK;
 }
@@ -662,11 +719,12 @@ int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t 
     // Every evaluation sweep may warn about every constraint: size the log so nothing is dropped.
     uint64_t want_log = (uint64_t)n_cs * (2 + 2 * std::min<uint64_t>(cfg->max_iterations, 1u << 20));
     uint32_t log_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want_log, 1), 1u << 22);
-    std::vector<uint64_t> log(log_cap);
+    std::unique_ptr<uint64_t[]> log_store(new uint64_t[log_cap]);  // uninitialised: only written entries are read
+    uint64_t* log = log_store.get();
     std::vector<uint8_t> mask(std::max<size_t>(n_cs, 1));
     std::vector<double> x(std::max<size_t>(n_guesses, 1));
     EzpzStatus st{};
-    rc = ezpz_system_solve_batch(sys, guesses, 1, cfg, x.data(), &st, mask.data(), log.data(), log_cap);
+    rc = ezpz_system_solve_batch(sys, guesses, 1, cfg, x.data(), &st, mask.data(), log, log_cap);
     if (rc != EZPZ_OK) {
         out->error = rc;
         return rc;
@@ -674,7 +732,7 @@ int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t 
     // Degenerate warnings in the reference's chronological order: sweep number, then constraint position;
     // about_constraint is the position inside this tier's slice (solver.rs:327,:343).
     uint32_t nlog = std::min<uint32_t>(st.n_warnings, log_cap);
-    std::sort(log.begin(), log.begin() + nlog);
+    std::sort(log, log + nlog);
     for (uint32_t i = 0; i < nlog; ++i) sink.push((int32_t)(log[i] & 0xFFFFFFFFu), EZPZ_WARN_DEGENERATE);
     sink.count += st.n_warnings - nlog;
     out->n_warnings = sink.count;

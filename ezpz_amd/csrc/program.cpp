@@ -13,12 +13,16 @@ int residual_dim(uint16_t kind) { return kind < EZPZ_NUM_KINDS ? kKinds[kind].n_
 int kind_num_ids(uint16_t kind) { return kind < EZPZ_NUM_KINDS ? kKinds[kind].n_ids : 0; }
 
 uint64_t topology_hash(const EzpzConstraint* cs, size_t n_cs, size_t n_vars) {
-    // FNV-1a over the whole request bytes (params and weights live in the program too).
-    uint64_t h = 1469598103934665603ull ^ (uint64_t)n_vars;
+    // 64-bit multiply-xorshift over the request 8 bytes at a time (params and weights live in the program too, so
+    // they are part of the key).  sizeof(EzpzConstraint) == 56 is a multiple of 8.
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n_vars;
+    const size_t words = n_cs * sizeof(EzpzConstraint) / 8;
     const unsigned char* p = reinterpret_cast<const unsigned char*>(cs);
-    for (size_t i = 0; i < n_cs * sizeof(EzpzConstraint); ++i) {
-        h ^= p[i];
-        h *= 1099511628211ull;
+    for (size_t i = 0; i < words; ++i) {
+        uint64_t w;
+        std::memcpy(&w, p + 8 * i, 8);
+        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 29;
     }
     return h;
 }
