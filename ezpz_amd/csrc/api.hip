@@ -293,7 +293,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
     }
     if (!want_sub) {
-        uint32_t team = team_size ? std::min<uint32_t>(1024, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
+        uint32_t team = team_size ? std::min<uint32_t>(512, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
                                   : auto_wg_team(width);
         if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
         s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;

@@ -117,6 +117,36 @@ struct SolveArgs {
 
 namespace dev {
 
+// One load for an (a, b) index pair of a list.
+__device__ __forceinline__ void load_pair(const uint16_t* items, uint32_t q, uint32_t& a, uint32_t& b) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(items + 2 * q);
+    a = w & 0xFFFFu;
+    b = w >> 16;
+}
+__device__ __forceinline__ void load_pair(const uint32_t* items, uint32_t q, uint32_t& a, uint32_t& b) {
+    const uint2 w = *reinterpret_cast<const uint2*>(items + 2 * q);
+    a = w.x;
+    b = w.y;
+}
+
+// Walks the pair list [q0, q1) four entries at a time: the four index loads are independent, then the eight
+// value loads are independent, and only then are the terms folded in list order (`fold(k)` for valid k).  The
+// kernel is bound by the latency of dependent LDS hops, and this turns 1 + 2L hops per list into 3 per chunk
+// while keeping every floating-point sum in exactly the same order.
+#define EZPZ_FOR_PAIRS4(items, q0, q1, A, B, LOADVALS, FOLD)                       \
+    for (uint32_t q_ = (q0); q_ < (q1); q_ += 4) {                                 \
+        uint32_t A[4], B[4];                                                       \
+        bool ok_[4];                                                               \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                            \
+            ok_[k] = q_ + k < (q1);                                                \
+            load_pair((items), ok_[k] ? q_ + k : q_, A[k], B[k]);                  \
+        }                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) { LOADVALS; }                \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                            \
+            if (ok_[k]) { FOLD; }                                                  \
+        }                                                                          \
+    }
+
 constexpr double LM_LAMBDA_INCR = 10.0;  // newton.rs:15
 constexpr double LM_LAMBDA_DECR = 0.1;   // newton.rs:16
 
@@ -211,7 +241,7 @@ struct ConRef<false> {
 };
 
 template <int TEAM, int MODE, bool LDSWS, bool PLDS>
-__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SUB ? 4 : 1)
+__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB ? 4 : 1)
     lm_solve_kernel(const SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using namespace dev;
@@ -284,6 +314,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
     const uint32_t call0 = lvl_cptr[0], call1 = lvl_cptr[nlev];  // all of the partition's (internal) variables
     const uint32_t sall0 = lvl_sptr[0], sall1 = lvl_sptr[nlev];  // all of its strictly-lower L slots
 
+    // (A variant that kept the first four rounds of constraint records in VGPRs across sweeps and systems was
+    // measured slower -- 54 vs 38 us per 2000x2000 system -- and is not kept; records are re-read per sweep.)
     const uint64_t n_teams = (uint64_t)gridDim.x * teams_per_block;
     for (uint64_t sys = (uint64_t)blockIdx.x * teams_per_block + team_in_block; sys < a.batch; sys += n_teams) {
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
@@ -323,18 +355,24 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
                     const uint32_t v = ci;  // internal variable numbering = schedule order
                     double acc = 0.0, b = 0.0;
-                    for (uint32_t q = P.colj_ptr[v]; q < P.colj_ptr[v + 1]; ++q) {
-                        double jv = ws[o_j + P.colj_items[2 * q]];
-                        acc += jv * jv;
-                        b += jv * -ws[o_r + P.colj_items[2 * q + 1]];
+                    {
+                        const uint32_t q0 = P.colj_ptr[v], q1 = P.colj_ptr[v + 1];
+                        double jv[4], rv[4];
+                        EZPZ_FOR_PAIRS4(P.colj_items, q0, q1, sl, rw,
+                                        (jv[k] = ws[o_j + sl[k]], rv[k] = ws[o_r + rw[k]]),
+                                        (acc += jv[k] * jv[k], b += jv[k] * -rv[k]))
                     }
                     ws[o_d + v] = acc + lambda;
                     ws[o_v + v] = b;
                 }
                 for (uint32_t s = sall0 + tm.lane; s < sall1; s += tm.stride) {
                     double acc = 0.0;
-                    for (uint32_t q = P.apair_ptr[s]; q < P.apair_ptr[s + 1]; ++q)
-                        acc += ws[o_j + P.apairs[2 * q]] * ws[o_j + P.apairs[2 * q + 1]];
+                    {
+                        const uint32_t q0 = P.apair_ptr[s], q1 = P.apair_ptr[s + 1];
+                        double va[4], vb[4];
+                        EZPZ_FOR_PAIRS4(P.apairs, q0, q1, ia, ib, (va[k] = ws[o_j + ia[k]], vb[k] = ws[o_j + ib[k]]),
+                                        (acc += va[k] * vb[k]))
+                    }
                     ws[o_l + s] = acc;
                 }
                 tm.phase_sync();
@@ -346,17 +384,22 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
                         const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_d + v];
-                        for (uint32_t q = P.fwd_ptr[v]; q < P.fwd_ptr[v + 1]; ++q) {
-                            double l = ws[o_l + P.fwd_items[2 * q]];
-                            acc -= l * l;
+                        {
+                            const uint32_t q0 = P.fwd_ptr[v], q1 = P.fwd_ptr[v + 1];
+                            double l[4];
+                            EZPZ_FOR_PAIRS4(P.fwd_items, q0, q1, sl, vk, (l[k] = ws[o_l + sl[k]]), (acc -= l[k] * l[k]))
                         }
                         if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
                         ws[o_d + v] = sqrt(acc);
                     }
                     for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride) {
                         double acc = ws[o_l + s];
-                        for (uint32_t q = P.lpair_ptr[s]; q < P.lpair_ptr[s + 1]; ++q)
-                            acc -= ws[o_l + P.lpairs[2 * q]] * ws[o_l + P.lpairs[2 * q + 1]];
+                        {
+                            const uint32_t q0 = P.lpair_ptr[s], q1 = P.lpair_ptr[s + 1];
+                            double va[4], vb[4];
+                            EZPZ_FOR_PAIRS4(P.lpairs, q0, q1, ia, ib, (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_l + ib[k]]),
+                                            (acc -= va[k] * vb[k]))
+                        }
                         ws[o_l + s] = acc;
                     }
                     tm.phase_sync();
@@ -365,8 +408,12 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
                         const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_v + v];
-                        for (uint32_t q = P.fwd_ptr[v]; q < P.fwd_ptr[v + 1]; ++q)
-                            acc -= ws[o_l + P.fwd_items[2 * q]] * ws[o_v + P.fwd_items[2 * q + 1]];
+                        {
+                            const uint32_t q0 = P.fwd_ptr[v], q1 = P.fwd_ptr[v + 1];
+                            double va[4], vb[4];
+                            EZPZ_FOR_PAIRS4(P.fwd_items, q0, q1, sl, vk, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
+                                            (acc -= va[k] * vb[k]))
+                        }
                         ws[o_v + v] = acc / ws[o_d + v];
                     }
                     tm.phase_sync();
@@ -377,8 +424,12 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
                         const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_v + v];
-                        for (uint32_t q = P.bwd_ptr[v]; q < P.bwd_ptr[v + 1]; ++q)
-                            acc -= ws[o_l + P.bwd_items[2 * q]] * ws[o_v + P.bwd_items[2 * q + 1]];
+                        {
+                            const uint32_t q0 = P.bwd_ptr[v], q1 = P.bwd_ptr[v + 1];
+                            double va[4], vb[4];
+                            EZPZ_FOR_PAIRS4(P.bwd_items, q0, q1, sl, vi, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vi[k]]),
+                                            (acc -= va[k] * vb[k]))
+                        }
                         ws[o_v + v] = acc / ws[o_d + v];
                     }
                     tm.phase_sync();
@@ -407,9 +458,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
             const uint32_t o_dst = (mode == EVAL0) ? o_r : o_rn;
             double sq = 0.0;
             double mx = __builtin_nan("");
-            for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
-                const DevCon& c = cref.get();
+            auto residual_of = [&](const DevCon& c) {
                 double r0, r1;
                 const bool deg = con_residual(c, ws + o_x, r0, r1);
                 const double wgt = (mode == FINAL) ? 1.0 : c.weight;
@@ -429,6 +478,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                     if (a.warn_log && (uint32_t)idx < a.warn_cap)
                         a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
                 }
+            };
+            for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
+                residual_of(cref.get());
             }
             ++pass;
             tm.phase_sync();
@@ -443,9 +496,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                     lambda *= LM_LAMBDA_DECR;
                 }
                 // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121; solver.rs:359-440) ------------------
-                for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                    const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
-                    const DevCon& c = cref.get();
+                auto jacobian_of = [&](const DevCon& c) {
                     JacWriter<double*> w;
                     w.jv = ws + o_j;
                     w.jbase = c.jbase;
@@ -461,6 +512,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
                         if (a.warn_log && (uint32_t)idx < a.warn_cap)
                             a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
                     }
+                };
+                for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                    const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
+                    jacobian_of(cref.get());
                 }
                 ++pass;
                 residual_sq = sq;
@@ -488,14 +543,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 1024, MODE == MODE_SU
         // ---- unsatisfied list from the unweighted residuals in r_next (lib.rs:305-327, :358-370) + write-back ------------
         double unsat_cnt = 0.0;
         double dummy = 0.0;
-        for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-            const DevCon& c = P.cons[ci];
+        auto unsat_of = [&](const DevCon& c) {
             const uint32_t row0 = c.row0;
             bool sat = fabs(ws[o_rn + row0]) < EPS;
             if (c.nrows > 1) sat = sat && (fabs(ws[o_rn + row0 + 1]) < EPS);
             if (!sat) unsat_cnt += 1.0;
             if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + c.pos] = sat ? 0 : 1;
-        }
+        };
+        for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) unsat_of(P.cons[ci]);
         tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());  // also the rendezvous before the cooperative store of x
         double* xo = a.x_out + sys * n;
         for (uint32_t i = tlane; i < n; i += tsize) xo[P.var_of[i]] = ws[o_x + i];

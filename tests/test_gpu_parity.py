@@ -204,7 +204,7 @@ def _chain_system(n_pts):
     return O.stack(cons), np.asarray(guesses)
 
 
-@pytest.mark.parametrize("team", [0, 256, 1024])
+@pytest.mark.parametrize("team", [0, 256, 512])
 def test_single_large_component_uses_barrier_workgroup(E, team):
     """A system that cannot be partitioned (one connected component) runs with all lanes on one partition."""
     recs, g = _chain_system(120)
