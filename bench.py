@@ -100,22 +100,35 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    desc, records, guesses, jitter, expect_iters = make_workload(args.workload)
-    n = len(guesses)
-    system = E.System(records, n, device=local_rank, team_size=args.team)
-    info = system.info()
-
-    # synthetic inputs: replicas of the system with keyed-PRNG jitter on the guesses, resident in HBM
-    B = args.batch
-    x0_host = guesses[None, :] + gen.keyed_uniform(0x657A707A + rank, B, n, -jitter, jitter)
-    x0_host[0] = guesses
-    x0 = torch.from_numpy(x0_host).to(dev)
-    x_out = torch.empty_like(x0)
-    status = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
+    # BASELINE configs[4] flavour: system i uses [circle_tangent, parallelogram, arc_radius][i mod 3]; the batch is
+    # grouped by topology (one launch per topology per step).  Everything else is a single-topology batch.
+    names = ["circle_tangent", "parallelogram", "arc_radius"] if args.workload == "mixed" else [args.workload]
     stream = torch.cuda.current_stream(dev)
+    parts = []
+    for k, name in enumerate(names):
+        desc_k, records_k, guesses_k, jitter_k, expect_k = make_workload(name)
+        n_k = len(guesses_k)
+        B_k = args.batch // len(names) + (1 if k < args.batch % len(names) else 0)
+        system_k = E.System(records_k, n_k, device=local_rank, team_size=args.team)
+        # synthetic inputs: replicas of the system with keyed-PRNG jitter on the guesses, resident in HBM
+        x0_host_k = guesses_k[None, :] + gen.keyed_uniform(0x657A707A + rank + 101 * k, B_k, n_k, -jitter_k, jitter_k)
+        x0_host_k[0] = guesses_k
+        x0_k = torch.from_numpy(x0_host_k).to(dev)
+        parts.append(dict(desc=desc_k, records=records_k, guesses=guesses_k, jitter=jitter_k, expect=expect_k, n=n_k,
+                          B=B_k, system=system_k, info=system_k.info(), x0_host=x0_host_k, x0=x0_k,
+                          x_out=torch.empty_like(x0_k), status=torch.zeros((B_k, 32), dtype=torch.uint8, device=dev)))
+    # the single-topology names used below refer to the first (usually only) part
+    p0 = parts[0]
+    desc, records, guesses, jitter, expect_iters = p0["desc"], p0["records"], p0["guesses"], p0["jitter"], p0["expect"]
+    n, system, info, B = p0["n"], p0["system"], p0["info"], args.batch
+    x0_host, x0, x_out, status = p0["x0_host"], p0["x0"], p0["x_out"], p0["status"]
+    if len(parts) > 1:
+        desc = "mixed: " + " + ".join(p["desc"] for p in parts)
 
     def step():
-        system.solve_batch_device(x0.data_ptr(), B, x_out.data_ptr(), status.data_ptr(), 0, stream.cuda_stream)
+        for p in parts:
+            p["system"].solve_batch_device(p["x0"].data_ptr(), p["B"], p["x_out"].data_ptr(), p["status"].data_ptr(), 0,
+                                           stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -179,7 +192,7 @@ def main():
             dist.barrier()
             extras["with_rccl_scatter_gather_solves_per_s"] = world * B * reps / (time.perf_counter() - te)
 
-    st = status.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+    st = np.concatenate([p["status"].cpu().numpy().view(E.STATUS_DTYPE).reshape(-1) for p in parts])
     iters = np.unique(st["iterations"]).tolist()
     ok = bool(np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0))
     if expect_iters is not None:
@@ -188,18 +201,26 @@ def main():
     if args.check and rank == 0:
         from oracle import oracle as O
 
-        sample = np.arange(0, B, max(1, B // 16))[:16]
-        rc, xo, it, conv, nun = O.solve_batch(records, x0_host[sample], linsolve=O.LINSOLVE_SPARSE)
-        xg = x_out[torch.from_numpy(sample).to(dev)].cpu().numpy()
-        err = float(np.max(np.abs(xg - xo) / np.maximum(1.0, np.abs(xo))))
-        checked = {"systems": int(len(sample)), "max_rel_err": err,
-                   "iterations_equal": bool(np.array_equal(st["iterations"][sample], it))}
+        err, it_equal, n_checked = 0.0, True, 0
+        for p in parts:
+            Bp = p["B"]
+            sample = np.arange(0, Bp, max(1, Bp // 16))[:16]
+            rc, xo, it, conv, nun = O.solve_batch(p["records"], p["x0_host"][sample], linsolve=O.LINSOLVE_SPARSE)
+            xg = p["x_out"][torch.from_numpy(sample).to(dev)].cpu().numpy()
+            stp = p["status"].cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+            err = max(err, float(np.max(np.abs(xg - xo) / np.maximum(1.0, np.abs(xo)))))
+            it_equal = it_equal and bool(np.array_equal(stp["iterations"][sample], it))
+            n_checked += len(sample)
+        checked = {"systems": int(n_checked), "max_rel_err": err, "iterations_equal": it_equal}
         ok = ok and err <= 1e-6 and checked["iterations_equal"]
 
     if rank == 0:
-        k = int(round(float(np.mean(st["iterations"]))))
-        bytes_per_solve = algorithmic_bytes(info, k)
-        achieved = bytes_per_solve * B / (kernel_ms * 1e-3) / 1e9
+        launch_bytes = 0
+        for p in parts:
+            stp = p["status"].cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+            launch_bytes += algorithmic_bytes(p["info"], int(round(float(np.mean(stp["iterations"]))))) * p["B"]
+        bytes_per_solve = launch_bytes / B
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -235,7 +256,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "lm_solve_kernel",
+                "kernel": "lm_solve_kernel" + (f" x{len(parts)} (one launch per topology)" if len(parts) > 1 else ""),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_solve": bytes_per_solve,
                 "solves_per_launch": B,

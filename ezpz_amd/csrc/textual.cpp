@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -472,10 +473,15 @@ void lower(const InstrList& instrs, const std::vector<Guess>& guesses, EzpzProbl
     if (!gs.empty()) throw TextErr{EZPZ_ERR_TEXT_UNUSED_GUESSES, gs.begin()->first};
 
     const uint32_t np = (uint32_t)pts.size();
-    auto index_of = [](const std::vector<std::string>& v, const std::string& s) -> int {
-        for (size_t i = 0; i < v.size(); ++i)
-            if (v[i] == s) return (int)i;
-        return -1;
+    // first position of a label (`.position()` in the reference), through a hash map so that large generated
+    // problems (gen_big_problem.py 50000 declares 100 000 points) lower in linear time
+    std::unordered_map<std::string, int> first_pos[3];
+    for (int t = 0; t < 3; ++t)
+        for (size_t i = 0; i < P.labels[t].size(); ++i) first_pos[t].emplace(P.labels[t][i], (int)i);
+    auto index_of = [&](const std::vector<std::string>& v, const std::string& s) -> int {
+        const int t = (&v == &pts) ? 0 : ((&v == &circles) ? 1 : 2);
+        auto it = first_pos[t].find(s);
+        return it == first_pos[t].end() ? -1 : it->second;
     };
     auto point_ids = [&](int i) { return Pt{(uint32_t)(2 * i), (uint32_t)(2 * i + 1)}; };
     auto circle_center = [&](int i) { return Pt{2 * np + 3 * (uint32_t)i, 2 * np + 3 * (uint32_t)i + 1}; };

@@ -472,6 +472,11 @@ def to_constraint_system(p: Problem) -> ConstraintSystem:  # executor.rs:40-445
         raise TextualError("UnusedGuesses", sorted(guessmap_scalars))
 
     n_points = len(p.inner_points)
+    # first position of each label (list.index semantics) in O(1)
+    pos_points, pos_circles, pos_arcs = {}, {}, {}
+    for table, labels in ((pos_points, p.inner_points), (pos_circles, p.inner_circles), (pos_arcs, p.inner_arcs)):
+        for i, lab in enumerate(labels):
+            table.setdefault(lab, i)
 
     def point_ids(i):
         return (2 * i, 2 * i + 1)
@@ -485,26 +490,23 @@ def to_constraint_system(p: Problem) -> ConstraintSystem:  # executor.rs:40-445
         return {"start": (s, s + 1), "end": (s + 2, s + 3), "center": (s + 4, s + 5)}
 
     def datum_point(label: str):  # executor.rs:121-174
-        if label in p.inner_points:
-            return point_ids(p.inner_points.index(label))
-        for i, c in enumerate(p.inner_circles):
-            if f"{c}.center" == label:
-                return circle_ids(i)[0]
-        for i, a in enumerate(p.inner_arcs):
-            if f"{a}.center" == label:
-                return arc_ids(i)["center"]
-        for i, a in enumerate(p.inner_arcs):
-            if f"{a}.a" == label:
-                return arc_ids(i)["start"]
-        for i, a in enumerate(p.inner_arcs):
-            if f"{a}.b" == label:
-                return arc_ids(i)["end"]
+        if label in pos_points:
+            return point_ids(pos_points[label])
+        if label.endswith(".center"):
+            base = label[: -len(".center")]
+            if base in pos_circles:
+                return circle_ids(pos_circles[base])[0]
+            if base in pos_arcs:
+                return arc_ids(pos_arcs[base])["center"]
+        if label.endswith(".a") and label[:-2] in pos_arcs:
+            return arc_ids(pos_arcs[label[:-2]])["start"]
+        if label.endswith(".b") and label[:-2] in pos_arcs:
+            return arc_ids(pos_arcs[label[:-2]])["end"]
         raise TextualError("UndefinedPoint", label)
 
     def datum_distance(label: str):  # executor.rs:175-187
-        for i, c in enumerate(p.inner_circles):
-            if f"{c}.radius" == label:
-                return circle_ids(i)[1]
+        if label.endswith(".radius") and label[: -len(".radius")] in pos_circles:
+            return circle_ids(pos_circles[label[: -len(".radius")]])[1]
         raise TextualError("UndefinedPoint", label)
 
     def datum_arc(label: str):
@@ -533,21 +535,21 @@ def to_constraint_system(p: Problem) -> ConstraintSystem:  # executor.rs:40-445
         elif k == "fix":  # executor.rs:259-289
             _, label, comp, value = ins
             sel = 0 if comp == "x" else 1
-            if label in p.inner_points:
-                cs.append(O.fixed(point_ids(p.inner_points.index(label))[sel], value))
+            if label in pos_points:
+                cs.append(O.fixed(point_ids(pos_points[label])[sel], value))
             elif label.endswith(".center"):
                 circ = label[: -len(".center")]
-                if circ in p.inner_circles:
-                    cs.append(O.fixed(circle_ids(p.inner_circles.index(circ))[0][sel], value))
+                if circ in pos_circles:
+                    cs.append(O.fixed(circle_ids(pos_circles[circ])[0][sel], value))
             else:
                 raise TextualError("UndefinedPoint", label)
         elif k == "fixcenter":  # executor.rs:290-320
             _, obj, comp, value = ins
             sel = 0 if comp == "x" else 1
-            if obj in p.inner_circles:
-                cs.append(O.fixed(circle_ids(p.inner_circles.index(obj))[0][sel], value))
-            elif obj in p.inner_arcs:
-                cs.append(O.fixed(arc_ids(p.inner_arcs.index(obj))["center"][sel], value))
+            if obj in pos_circles:
+                cs.append(O.fixed(circle_ids(pos_circles[obj])[0][sel], value))
+            elif obj in pos_arcs:
+                cs.append(O.fixed(arc_ids(pos_arcs[obj])["center"][sel], value))
             else:
                 raise TextualError("UndefinedPoint", obj)
         elif k == "vertical":
