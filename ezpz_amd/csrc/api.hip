@@ -96,6 +96,7 @@ struct EzpzSystem {
     int mode = MODE_SUB;  // TeamMode
     bool lds_ws = true;
     bool prog_in_lds = false;
+    bool unit_weights = true;
     uint32_t prog_lds_doubles = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
@@ -212,6 +213,8 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                   : launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream);
 }
 
+unsigned long long* g_stamps = nullptr;  // diagnostic builds only (tools/stamps.py sets it through ezpz_debug_set_stamps)
+
 void fill_cfg(SolveArgs& a, const EzpzConfig* cfg) {
     EzpzConfig d;
     ezpz_default_config(&d);
@@ -300,6 +303,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         s.team_size = team;
     }
     s.counts = P.c;
+    s.unit_weights = true;
+    for (const DevCon& d : P.cons)
+        if (d.weight != 1.0) s.unit_weights = false;
     s.host_var_of = P.var_of;
     s.host_row_of = P.row_of;
     s.host_slot_row = P.slot_row;
@@ -491,6 +497,8 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.batch = batch;
     a.ws_doubles = sys->ws_doubles;
     a.prog_lds_doubles = sys->prog_lds_doubles;
+    a.stamps = g_stamps;
+    a.unit_weights = sys->unit_weights ? 1u : 0u;
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }
@@ -649,6 +657,10 @@ void set_from_initial_values(EzpzConstraint& c, const std::vector<double>& iv) {
 }  // namespace
 
 extern "C" {
+
+#ifdef EZPZ_STAMPS
+void ezpz_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = dev_buf; }
+#endif
 
 void ezpz_cache_clear(void) {
     std::lock_guard<std::mutex> lock(g_cache_mu);

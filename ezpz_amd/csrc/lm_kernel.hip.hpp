@@ -112,8 +112,25 @@ struct SolveArgs {
     uint32_t ws_doubles;        // doubles per team workspace (incl. the small int area, rounded to 2 doubles)
     uint32_t prog_lds_doubles;  // LDS doubles reserved for the staged program (PLDS), 0 otherwise
     uint32_t max_iterations;
+    uint32_t unit_weights;  // every constraint weight == 1.0 (the common case): weighted r == unweighted r
     double residual_tolerance, step_tolerance, initial_lambda;
+    unsigned long long* stamps;  // diagnostic builds (-DEZPZ_STAMPS) only: (id, s_memtime) pairs of block 0, lane 0
 };
+
+#ifdef EZPZ_STAMPS
+#define EZPZ_STAMP(id)                                                                     \
+    do {                                                                                   \
+        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 120) {            \
+            a.stamps[2 * stamp_n] = (id);                                                  \
+            a.stamps[2 * stamp_n + 1] = __builtin_readcyclecounter();                      \
+            ++stamp_n;                                                                     \
+        }                                                                                  \
+    } while (0)
+#else
+#define EZPZ_STAMP(id) \
+    do {               \
+    } while (0)
+#endif
 
 namespace dev {
 
@@ -157,6 +174,27 @@ struct OpMax {  // libm::fmax (NaN-ignoring), newton.rs:53,:108
     __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); }
 };
 
+// Cross-lane moves inside a row of 16 lanes without touching the LDS crossbar (DPP modifiers on v_mov):
+// quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror.  After the four steps every lane of a row holds
+// the row's reduction (the two mirror steps work because all lanes of a quad / half-row already agree).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int WIDTH, class Op>
+__device__ __forceinline__ double reduce_lanes(double v, Op op) {
+    if constexpr (WIDTH >= 2) v = op(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
+    if constexpr (WIDTH >= 4) v = op(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]
+    if constexpr (WIDTH >= 8) v = op(v, dpp_move<0x141>(v));  // row_half_mirror
+    if constexpr (WIDTH >= 16) v = op(v, dpp_move<0x140>(v)); // row_mirror
+    if constexpr (WIDTH >= 32) v = op(v, __shfl_xor(v, 16, 64));
+    if constexpr (WIDTH >= 64) v = op(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
 template <int TEAM, int MODE>
 struct Team {
     int lane;     // lane inside the unit that walks a phase (team for SUB, wave for PART, workgroup for WGB)
@@ -188,19 +226,13 @@ struct Team {
     template <class OpA, class OpB>
     __device__ __forceinline__ void reduce2(double& a, double& b, OpA opa, OpB opb) {
         if constexpr (MODE == MODE_SUB) {
-#pragma unroll
-            for (int off = TEAM / 2; off > 0; off >>= 1) {
-                a = opa(a, __shfl_xor(a, off, TEAM));
-                b = opb(b, __shfl_xor(b, off, TEAM));
-            }
-            a = __shfl(a, 0, TEAM);
-            b = __shfl(b, 0, TEAM);
+            // every lane of the team ends with the same bits: each step combines two values that are already
+            // identical across the lanes that hold them, and the operators are commutative
+            a = reduce_lanes<TEAM>(a, opa);
+            b = reduce_lanes<TEAM>(b, opb);
         } else {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                a = opa(a, __shfl_xor(a, off, 64));
-                b = opb(b, __shfl_xor(b, off, 64));
-            }
+            a = reduce_lanes<64>(a, opa);
+            b = reduce_lanes<64>(b, opb);
             double* buf = red + (red_flip ? 32 : 0);
             red_flip ^= 1;
             const int wave = threadIdx.x >> 6;
@@ -319,10 +351,15 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
     const uint64_t n_teams = (uint64_t)gridDim.x * teams_per_block;
     for (uint64_t sys = (uint64_t)blockIdx.x * teams_per_block + team_in_block; sys < a.batch; sys += n_teams) {
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
+#ifdef EZPZ_STAMPS
+        int stamp_n = 0;
+#endif
+        EZPZ_STAMP(1);
         const double* x0 = a.x0 + sys * n;
         for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[P.var_of[i]];
         if (tlane == 0) *nwarn = 0;
         tm.team_sync();
+        EZPZ_STAMP(2);
 
         // The LM loop of newton.rs:29-145 as a three-mode state machine, so that each of the two big
         // evaluators is instantiated exactly once (register pressure / code size):
@@ -336,6 +373,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
         uint32_t it = 0;
         double residual_sq = 0.0;
         double largest = 0.0;  // max |r| of the current residual vector
+        double unsat_cnt = 0.0;
+        bool r_is_at_x = true;  // the current r was evaluated at exactly the current x (false after a rejected step)
         double lambda = a.initial_lambda;
         double step_inf_norm = 0.0;
         uint32_t iterations = a.max_iterations;
@@ -376,6 +415,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                     ws[o_l + s] = acc;
                 }
                 tm.phase_sync();
+                EZPZ_STAMP(10);
                 // ---- level-scheduled sparse Cholesky + forward substitution (newton.rs:87-102) --------------------
                 double bad = 0.0;
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
@@ -418,6 +458,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                     }
                     tm.phase_sync();
                 }
+                EZPZ_STAMP(11);
                 // ---- backward substitution (garbage but harmless if the factorisation failed) ---------------------------
                 for (uint32_t lv = nlev; lv-- > 0;) {
                     const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
@@ -434,11 +475,13 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                     }
                     tm.phase_sync();
                 }
+                EZPZ_STAMP(12);
                 // ---- ||d||_inf and "did any pivot fail": one rendezvous (newton.rs:96-99, :108) ------------------------------
                 double dmax = __builtin_nan("");  // fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax)
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride)
                     dmax = fmax(dmax, fabs(ws[o_v + ci]));
                 tm.reduce2(bad, dmax, OpMax(), OpMax());
+                EZPZ_STAMP(13);
                 if (bad > 0.0) {  // numeric failure => lambda *= 10, burn the iteration
                     lambda *= LM_LAMBDA_INCR;
                     ++it;
@@ -451,9 +494,23 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                     ws[o_x + v] = ws[o_x + v] + ws[o_v + v];
                 }
                 tm.phase_sync();
+                EZPZ_STAMP(14);
             }
 
-            // ---- the one residual sweep: EVAL0 -> r, STEP -> r_next, FINAL -> unweighted into r_next ---------------------
+            if (mode == FINAL && r_is_at_x && a.unit_weights) {
+                // every weight is 1 and r was evaluated at this x: r already holds the unweighted residuals, so the
+                // unsatisfied check reads it instead of re-evaluating every constraint
+                for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                    const DevCon& c = P.cons[ci];
+                    const uint32_t row0 = c.row0;
+                    bool sat = fabs(ws[o_r + row0]) < EPS;
+                    if (c.nrows > 1) sat = sat && (fabs(ws[o_r + row0 + 1]) < EPS);
+                    if (!sat) unsat_cnt += 1.0;
+                    if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + c.pos] = sat ? 0 : 1;
+                }
+                break;
+            }
+            // ---- the one residual sweep: EVAL0 -> r, STEP -> r_next, FINAL -> unsatisfied test on unweighted values ---------------------
             // r[row] = weight * residual (solver.rs:327-355); one lane per constraint of the partition.
             const uint32_t o_dst = (mode == EVAL0) ? o_r : o_rn;
             double sq = 0.0;
@@ -461,7 +518,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
             auto residual_of = [&](const DevCon& c) {
                 double r0, r1;
                 const bool deg = con_residual(c, ws + o_x, r0, r1);
-                const double wgt = (mode == FINAL) ? 1.0 : c.weight;
+                if (mode == FINAL) {  // unsatisfied check on the unweighted residuals (lib.rs:305-327, :358-370)
+                    bool sat = fabs(r0) < EPS;
+                    if (c.nrows > 1) sat = sat && (fabs(r1) < EPS);
+                    if (!sat) unsat_cnt += 1.0;
+                    if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + c.pos] = sat ? 0 : 1;
+                    return;
+                }
+                const double wgt = c.weight;
                 const uint32_t row0 = c.row0;
                 const double w0 = wgt * r0;
                 ws[o_dst + row0] = w0;
@@ -473,7 +537,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                     sq += w1 * w1;
                     mx = fmax(mx, fabs(w1));
                 }
-                if (deg && mode != FINAL) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
+                if (deg) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
                     int idx = atomicAdd(nwarn, 1);
                     if (a.warn_log && (uint32_t)idx < a.warn_cap)
                         a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
@@ -485,8 +549,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
             }
             ++pass;
             tm.phase_sync();
+            EZPZ_STAMP(20);
             if (mode == FINAL) break;
-            tm.reduce2(sq, mx, OpSum(), OpMax());  // sum r^2 (newton.rs:116,:235) and max |r| (newton.rs:50-53)
+            tm.reduce2(sq, mx, OpSum(), OpMax());
+            EZPZ_STAMP(21);  // sum r^2 (newton.rs:116,:235) and max |r| (newton.rs:50-53)
             const bool accept = (mode == EVAL0) || (sq < residual_sq);  // strict, newton.rs:118
             if (accept) {
                 if (mode == STEP) {
@@ -520,7 +586,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                 ++pass;
                 residual_sq = sq;
                 largest = mx;
+                r_is_at_x = true;
             } else {  // reject: revert, raise lambda (newton.rs:124-131)
+                r_is_at_x = false;  // x is now (x + d) - d, which may differ from the x of r in the last bit
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
                     const uint32_t v = ci;  // internal variable numbering = schedule order
                     ws[o_x + v] = ws[o_x + v] - ws[o_v + v];
@@ -528,6 +596,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                 lambda *= LM_LAMBDA_INCR;
             }
             tm.phase_sync();
+            EZPZ_STAMP(22);
             if (mode == STEP) {
                 if (step_inf_norm <= a.step_tolerance) {  // newton.rs:134-139
                     iterations = it;
@@ -540,18 +609,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
             if (mode == EVAL0) mode = STEP;
         }
 
-        // ---- unsatisfied list from the unweighted residuals in r_next (lib.rs:305-327, :358-370) + write-back ------------
-        double unsat_cnt = 0.0;
+        // ---- write-back -----------------------------------------------------------------------------------------------
         double dummy = 0.0;
-        auto unsat_of = [&](const DevCon& c) {
-            const uint32_t row0 = c.row0;
-            bool sat = fabs(ws[o_rn + row0]) < EPS;
-            if (c.nrows > 1) sat = sat && (fabs(ws[o_rn + row0 + 1]) < EPS);
-            if (!sat) unsat_cnt += 1.0;
-            if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + c.pos] = sat ? 0 : 1;
-        };
-        for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) unsat_of(P.cons[ci]);
+        EZPZ_STAMP(30);
         tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());  // also the rendezvous before the cooperative store of x
+        EZPZ_STAMP(31);
         double* xo = a.x_out + sys * n;
         for (uint32_t i = tlane; i < n; i += tsize) xo[P.var_of[i]] = ws[o_x + i];
         if (tlane == 0) {
@@ -565,6 +627,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
             a.status[sys] = st;
         }
         tm.team_sync();  // the workspace is reused by the next system of this team
+        EZPZ_STAMP(32);
     }
 }
 
