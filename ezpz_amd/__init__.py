@@ -9,12 +9,12 @@ from ._lib import CONSTRAINT_DTYPE, STATUS_DTYPE, lib
 from .api import (Angle, AngleKind, CircleSide, Config, Constraint, ConstraintRequest, DatumCircle, DatumCircularArc,
                   DatumDistance, DatumLineSegment, DatumPoint, FailureOutcome, IdGenerator, LineSide,
                   NonLinearSystemError, RawResult, SolveOutcome, System, Warning, WarningContent, analyze, device_count, solve,
-                  solve_records, stack_records)
+                  solve_batch, solve_records, stack_records)
 
 __all__ = [
     "Angle", "AngleKind", "CircleSide", "Config", "Constraint", "ConstraintRequest", "DatumCircle", "DatumCircularArc",
     "DatumDistance", "DatumLineSegment", "DatumPoint", "FailureOutcome", "IdGenerator", "LineSide",
     "NonLinearSystemError", "RawResult", "SolveOutcome", "System", "Warning", "WarningContent", "analyze",
     "device_count", "solve",
-    "solve_records", "stack_records", "textual", "lib", "CONSTRAINT_DTYPE", "STATUS_DTYPE",
+    "solve_batch", "solve_records", "stack_records", "textual", "lib", "CONSTRAINT_DTYPE", "STATUS_DTYPE",
 ]

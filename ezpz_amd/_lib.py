@@ -49,6 +49,7 @@ EXPORTS = [
     "ezpz_problem_parse", "ezpz_problem_destroy", "ezpz_problem_num_constraints", "ezpz_problem_num_vars",
     "ezpz_problem_constraints", "ezpz_problem_guesses", "ezpz_problem_num_labels", "ezpz_problem_label",
     "ezpz_analyze", "ezpz_system_eval_batch", "ezpz_system_jacobian_pattern", "ezpz_cache_clear",
+    "ezpz_solve_batch",
 ]
 
 _lib = None
@@ -78,6 +79,9 @@ def lib():
     L.ezpz_system_destroy.argtypes = [vp]
     L.ezpz_system_info.restype = C.c_int
     L.ezpz_system_info.argtypes = [vp, C.POINTER(CSystemInfo)]
+    L.ezpz_solve_batch.restype = C.c_int
+    L.ezpz_solve_batch.argtypes = [vp, sz, sz, vp, sz, C.POINTER(CConfig), vp, vp, vp, vp, C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int64)]
     L.ezpz_cache_clear.restype = None
     L.ezpz_cache_clear.argtypes = []
     L.ezpz_analyze.restype = C.c_int

@@ -535,6 +535,28 @@ def solve(reqs: Iterable[ConstraintRequest], initial_guesses: Sequence[Tuple[Id,
     return SolveOutcome(raw)
 
 
+def solve_batch(reqs, x0: np.ndarray, config: Optional[Config] = None, want_mask: bool = False):
+    """`ezpz::solve` semantics (side inference, priority tiers) for a batch of guess vectors sharing one request list.
+
+    reqs: ConstraintRequests or 56-byte records; x0: [batch, n_vars].  Returns (x, status, priority_solved, mask|None)."""
+    recs = stack_records([r.record() if isinstance(r, ConstraintRequest) else r for r in reqs]
+                         if not isinstance(reqs, np.ndarray) else reqs)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    batch, n = x0.shape
+    cfg = (config or Config())._c()
+    x = np.empty_like(x0)
+    st = np.zeros(batch, dtype=STATUS_DTYPE)
+    prio = np.zeros(batch, dtype=np.uint32)
+    mask = np.zeros((batch, max(len(recs), 1)), dtype=np.uint8) if want_mask else None
+    ec, ev = C.c_int32(-1), C.c_int64(-1)
+    rc = lib().ezpz_solve_batch(recs.ctypes.data if len(recs) else None, len(recs), n, x0.ctypes.data, batch,
+                                C.byref(cfg), x.ctypes.data, st.ctypes.data, prio.ctypes.data,
+                                mask.ctypes.data if want_mask else None, C.byref(ec), C.byref(ev))
+    if rc != 0:
+        raise NonLinearSystemError(rc, ec.value, ev.value)
+    return x, st, prio, mask
+
+
 class System:
     """One analysed topology resident on a device: `ezpz_system_create` + batched solves.
 

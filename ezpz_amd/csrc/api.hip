@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <list>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -842,6 +843,118 @@ int ezpz_solve(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var
         }
     }
     return rc_final;
+}
+
+int ezpz_solve_batch(const EzpzConstraint* reqs_in, size_t n_reqs, size_t n_vars, const double* x0, size_t batch,
+                     const EzpzConfig* cfg, double* x_out, EzpzStatus* status, uint32_t* priority_solved,
+                     uint8_t* unsat_mask, int32_t* err_constraint, int64_t* err_variable) {
+    if ((batch && (!x_out || !status)) || (batch && n_vars && !x0)) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return EZPZ_OK;
+    if (n_reqs == 0) {  // lib.rs:155-170
+        if (n_vars) std::memcpy(x_out, x0, batch * n_vars * sizeof(double));
+        for (size_t b = 0; b < batch; ++b) {
+            status[b] = EzpzStatus{};
+            status[b].converged = 1;
+            if (priority_solved) priority_solved[b] = 0;
+        }
+        return EZPZ_OK;
+    }
+    // ---- per-system side inference, systems grouped by the sides they infer ------------------------------------------
+    std::vector<size_t> undefined;  // requests whose side is inferred
+    for (size_t i = 0; i < n_reqs; ++i) {
+        const EzpzConstraint& c = reqs_in[i];
+        if ((c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE || c.kind == EZPZ_CIRCLE_TANGENT_TO_CIRCLE) &&
+            c.tag == EZPZ_SIDE_UNDEFINED) {
+            bool ok = true;
+            const int cnt = c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE ? 7 : 6;
+            for (int k = 0; k < cnt; ++k)
+                if (c.ids[k] >= n_vars) ok = false;
+            if (ok) undefined.push_back(i);
+        }
+    }
+    std::map<std::vector<uint8_t>, std::vector<size_t>> groups;
+    {
+        std::vector<double> iv(n_vars);
+        std::vector<uint8_t> key(undefined.size());
+        for (size_t b = 0; b < batch; ++b) {
+            if (!undefined.empty()) {
+                std::memcpy(iv.data(), x0 + b * n_vars, n_vars * sizeof(double));
+                for (size_t u = 0; u < undefined.size(); ++u) {
+                    EzpzConstraint c = reqs_in[undefined[u]];
+                    set_from_initial_values(c, iv);
+                    key[u] = c.tag;
+                }
+            }
+            groups[key].push_back(b);
+        }
+    }
+    std::vector<uint32_t> prios;
+    for (size_t i = 0; i < n_reqs; ++i) prios.push_back(reqs_in[i].priority);
+    std::sort(prios.begin(), prios.end());
+    prios.erase(std::unique(prios.begin(), prios.end()), prios.end());
+
+    std::vector<EzpzConstraint> reqs(reqs_in, reqs_in + n_reqs), subset;
+    std::vector<size_t> subset_ids;
+    std::vector<double> xin, xres;
+    std::vector<EzpzStatus> stres;
+    std::vector<uint8_t> maskres;
+    for (auto& g : groups) {
+        for (size_t u = 0; u < undefined.size(); ++u) reqs[undefined[u]].tag = g.first[u];
+        std::vector<size_t> active = g.second;
+        std::vector<char> have_res(batch, 0);
+        bool first_tier = true;
+        for (uint32_t curr_max_priority : prios) {
+            if (active.empty()) break;
+            subset.clear();
+            subset_ids.clear();
+            uint32_t lowest = 0;
+            for (size_t i = 0; i < n_reqs; ++i)
+                if (reqs[i].priority <= curr_max_priority) {
+                    subset.push_back(reqs[i]);
+                    subset_ids.push_back(i);
+                    lowest = std::max(lowest, reqs[i].priority);
+                }
+            EzpzSystem* sys = nullptr;
+            int32_t ec = -1;
+            int64_t ev = -1;
+            int rc = cached_system(subset.data(), subset.size(), n_vars, &sys, &ec, &ev);
+            if (rc != EZPZ_OK) {
+                if (first_tier) {  // lib.rs:239-244: no earlier tier to fall back to
+                    if (err_constraint) *err_constraint = ec >= 0 ? (int32_t)subset_ids[(size_t)ec] : -1;
+                    if (err_variable) *err_variable = ev;
+                    return rc;
+                }
+                break;  // every system of the group keeps its previous tier
+            }
+            const size_t na = active.size(), ns = subset.size();
+            xin.resize(na * std::max<size_t>(n_vars, 1));
+            xres.resize(xin.size());
+            stres.resize(na);
+            maskres.assign(na * std::max<size_t>(ns, 1), 0);
+            for (size_t a = 0; a < na; ++a)
+                std::memcpy(xin.data() + a * n_vars, x0 + active[a] * n_vars, n_vars * sizeof(double));
+            rc = ezpz_system_solve_batch(sys, xin.data(), na, cfg, xres.data(), stres.data(), maskres.data(), nullptr, 0);
+            if (rc != EZPZ_OK) return rc;
+            std::vector<size_t> still;
+            for (size_t a = 0; a < na; ++a) {
+                const size_t b = active[a];
+                const bool unsat = stres[a].n_unsatisfied > 0;
+                if (unsat && have_res[b]) continue;  // lib.rs:232-234: keep the previous, satisfied tier
+                std::memcpy(x_out + b * n_vars, xres.data() + a * n_vars, n_vars * sizeof(double));
+                status[b] = stres[a];
+                if (priority_solved) priority_solved[b] = lowest;
+                if (unsat_mask) {
+                    std::memset(unsat_mask + b * n_reqs, 0, n_reqs);
+                    for (size_t k = 0; k < ns; ++k) unsat_mask[b * n_reqs + subset_ids[k]] = maskres[a * ns + k];
+                }
+                have_res[b] = 1;
+                if (!unsat) still.push_back(b);
+            }
+            active.swap(still);
+            first_tier = false;
+        }
+    }
+    return EZPZ_OK;
 }
 
 }  // extern "C"

@@ -211,6 +211,17 @@ int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_id
                size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
                size_t warn_cap, EzpzOutcome* out);
 
+/* ---- ezpz::solve for a batch (new; SURVEY.md 8f #3: priority tiers + weights end-to-end on device batches) --------
+ * `batch` systems share the request list and differ in their guesses (x0 AoS [batch][n_vars], id == index).  Per
+ * system exactly the semantics of ezpz_solve: LineSide / CircleSide inferred from that system's own guesses
+ * (constraints.rs:146-193; systems are grouped by the inferred sides), cumulative priority tiers each re-solved from
+ * the original guesses (lib.rs:215-246), the last fully satisfied tier is returned.  priority_solved [batch] and
+ * unsat_mask [batch][n_reqs] (indexed by position in `reqs`) are optional.  Topology-level errors (missing guess ...)
+ * in the first tier fail the call; in a later tier every system keeps its previous tier, like the reference. */
+int ezpz_solve_batch(const EzpzConstraint* reqs, size_t n_reqs, size_t n_vars, const double* x0, size_t batch,
+                     const EzpzConfig* cfg, double* x_out, EzpzStatus* status, uint32_t* priority_solved,
+                     uint8_t* unsat_mask, int32_t* err_constraint, int64_t* err_variable);
+
 /* ezpz_solve / ezpz_solve_inner keep a small cache of analysed topologies keyed by the request bytes, so that
  * repeated solves of one problem (ezpz-cli's 100-run loop, main.rs:96-98) skip the symbolic phase.  This drops
  * it (used to time cold solves). */

@@ -399,3 +399,38 @@ def test_random_systems_fuzz_parity(E):
         checked += 1
         kinds_seen.update(int(c["kind"]) for c in cons)
     assert checked >= 150 and determined_checked >= 20 and len(kinds_seen) == O.NUM_KINDS, (checked, determined_checked, unstable, sorted(kinds_seen))
+
+
+def test_batch_solve_with_priorities_and_inferred_sides(E):
+    """lib.rs:148-263 per system of a batch: sides inferred from each system's own guesses, cumulative priority tiers
+    from the original guesses, last fully satisfied tier wins (tests.rs:49-106 semantics, batched)."""
+    p0, p1, center, radius = (0, 1), (2, 3), (4, 5), 6
+    reqs = [
+        O.fixed(1, 3.0), O.fixed(3, 3.0), O.circle_radius(center, radius, 1.5),
+        O.line_tangent_to_circle(p0, p1, center, radius, O.SIDE_UNDEFINED),
+        O.fixed(4, 2.0, priority=1),              # satisfiable refinement
+        O.fixed(5, 100.0, priority=2),            # contradicts the tangent: tier 2 is unsatisfied -> tier 1 is returned
+        O.fixed(0, 0.0, priority=1, weight=2.0),
+    ]
+    rng = np.random.default_rng(5)
+    B = 96
+    x0 = np.tile(np.array([0.0, 3.0, 5.0, 3.0, 2.0, 1.5, 1.5]), (B, 1)) + rng.uniform(-0.2, 0.2, (B, 7))
+    x0[::2, 5] += 3.0  # half of the circles start above the line (Left), half below (Right)
+    x, st, prio, mask = E.solve_batch(O.stack(reqs), x0, want_mask=True)
+    sides = set()
+    for b in range(B):
+        want = OracleAdapter().solve(reqs, list(enumerate(x0[b])))
+        assert want.error == 0
+        assert (int(st["iterations"][b]), bool(st["converged"][b])) == (want.iterations, want.converged), b
+        assert int(prio[b]) == want.priority_solved == 1
+        assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied == []
+        assert_x_close(x[b], want.final_values)
+        sides.add(bool(x[b, 5] > 3.0))
+    assert sides == {True, False}
+    # a first-tier topology error fails the call like FailureOutcome
+    with pytest.raises(E.NonLinearSystemError) as e:
+        E.solve_batch(O.stack([O.fixed(0, 1.0), O.fixed(9, 1.0)]), np.zeros((4, 3)))
+    assert (e.value.code, e.value.constraint_id, e.value.variable) == (-3, 1, 9)
+    # no requests: guesses are echoed
+    x, st, prio, _ = E.solve_batch(np.zeros(0, dtype=E.CONSTRAINT_DTYPE), x0[:5])
+    assert np.array_equal(x, x0[:5]) and np.all(st["converged"] == 1) and np.all(st["iterations"] == 0)
