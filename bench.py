@@ -176,6 +176,20 @@ def main():
                 system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
             torch.cuda.synchronize(dev)
             extras["single_solve_latency_us"] = (time.perf_counter() - tl) / 200 * 1e6
+            # (2b) FreedomAnalysis (find_dof.rs) of the solved batch, device to device
+            Bf = p0["B"]
+            fa_mask = torch.zeros((Bf, n), dtype=torch.uint8, device=dev)
+            fa_cnt = torch.zeros(Bf, dtype=torch.int32, device=dev)
+            fa = lambda: system.freedom_batch_device(x_out.data_ptr(), Bf, fa_mask.data_ptr(), 0, fa_cnt.data_ptr(),
+                                                     stream.cuda_stream)
+            fa()
+            torch.cuda.synchronize(dev)
+            tf = time.perf_counter()
+            for _ in range(5):
+                fa()
+            torch.cuda.synchronize(dev)
+            extras["freedom_analyses_per_s"] = 5 * Bf / (time.perf_counter() - tf)
+            extras["underconstrained_systems"] = int((fa_cnt > 0).sum().item())
         # (3) N>1: whole batch starts and ends on rank 0; one RCCL scatter + one gather around the solve
         if world > 1:
             from ezpz_amd.distributed import solve_batch_sharded

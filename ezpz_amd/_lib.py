@@ -50,6 +50,9 @@ EXPORTS = [
     "ezpz_problem_constraints", "ezpz_problem_guesses", "ezpz_problem_num_labels", "ezpz_problem_label",
     "ezpz_analyze", "ezpz_system_eval_batch", "ezpz_system_jacobian_pattern", "ezpz_cache_clear",
     "ezpz_solve_batch",
+    "ezpz_solve_analysis",
+    "ezpz_system_freedom_batch",
+    "ezpz_system_freedom_batch_device",
 ]
 
 _lib = None
@@ -82,6 +85,10 @@ def lib():
     L.ezpz_solve_batch.restype = C.c_int
     L.ezpz_solve_batch.argtypes = [vp, sz, sz, vp, sz, C.POINTER(CConfig), vp, vp, vp, vp, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int64)]
+    L.ezpz_system_freedom_batch.restype = C.c_int
+    L.ezpz_system_freedom_batch.argtypes = [vp, vp, sz, vp, vp]
+    L.ezpz_system_freedom_batch_device.restype = C.c_int
+    L.ezpz_system_freedom_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.ezpz_cache_clear.restype = None
     L.ezpz_cache_clear.argtypes = []
     L.ezpz_analyze.restype = C.c_int
@@ -98,6 +105,8 @@ def lib():
     L.ezpz_solve_inner.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(CConfig), vp, vp, vp, sz, C.POINTER(COutcome)]
     L.ezpz_solve.restype = C.c_int
     L.ezpz_solve.argtypes = [vp, sz, vp, vp, sz, C.POINTER(CConfig), vp, vp, vp, sz, C.POINTER(COutcome)]
+    L.ezpz_solve_analysis.restype = C.c_int
+    L.ezpz_solve_analysis.argtypes = list(L.ezpz_solve.argtypes) + [vp, C.POINTER(C.c_uint64)]
     L.ezpz_problem_parse.restype = C.c_int
     L.ezpz_problem_parse.argtypes = [C.c_char_p, sz, C.POINTER(vp), C.c_char_p, sz]
     L.ezpz_problem_destroy.restype = None

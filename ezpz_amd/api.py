@@ -417,6 +417,7 @@ class RawResult:
     num_eqs: int
     final_lambda: float
     final_residual_inf: float
+    underconstrained: Optional[List[int]] = None  # FreedomAnalysis; None = not requested
 
 
 class NonLinearSystemError(Exception):
@@ -502,8 +503,10 @@ def _split_guesses(guesses):
     return ids, vals
 
 
-def solve_records(records, guesses, config: Optional[Config] = None, warn_cap: int = 4096) -> RawResult:
-    """`ezpz_solve` on a record array; never raises for solver errors (error code in the result)."""
+def solve_records(records, guesses, config: Optional[Config] = None, warn_cap: int = 4096,
+                  analysis: bool = False) -> RawResult:
+    """`ezpz_solve` (or `ezpz_solve_analysis`) on a record array; never raises for solver errors (error code in the
+    result)."""
     a = stack_records(records)
     ids, vals = _split_guesses(guesses)
     n = len(vals)
@@ -512,11 +515,18 @@ def solve_records(records, guesses, config: Optional[Config] = None, warn_cap: i
     unsat = np.zeros(max(len(a), 1), dtype=np.uint64)
     warns = (CWarning * max(warn_cap, 1))()
     out = COutcome()
-    lib().ezpz_solve(a.ctypes.data if len(a) else None, len(a), ids.ctypes.data if n else None,
-                     vals.ctypes.data if n else None, n, C.byref(cfg), x_out.ctypes.data, unsat.ctypes.data,
-                     C.cast(warns, C.c_void_p), warn_cap, C.byref(out))
+    args = (a.ctypes.data if len(a) else None, len(a), ids.ctypes.data if n else None,
+            vals.ctypes.data if n else None, n, C.byref(cfg), x_out.ctypes.data, unsat.ctypes.data,
+            C.cast(warns, C.c_void_p), warn_cap, C.byref(out))
+    under = np.zeros(max(n, 1), dtype=np.uint32)
+    n_under = C.c_uint64(0)
+    if analysis:
+        lib().ezpz_solve_analysis(*args, under.ctypes.data, C.byref(n_under))
+    else:
+        lib().ezpz_solve(*args)
     nw = min(int(out.n_warnings), warn_cap)
     return RawResult(
+        underconstrained=under[: n_under.value].astype(int).tolist() if analysis else None,
         error=out.error, err_constraint_id=out.err_constraint_id, err_variable=out.err_variable,
         final_values=x_out[:n].copy(), iterations=int(out.iterations), converged=bool(out.converged),
         unsatisfied=unsat[: int(out.n_unsatisfied)].astype(int).tolist(),
@@ -533,6 +543,40 @@ def solve(reqs: Iterable[ConstraintRequest], initial_guesses: Sequence[Tuple[Id,
         err = NonLinearSystemError(raw.error, raw.err_constraint_id, raw.err_variable)
         raise FailureOutcome(err, [Warning(a, c) for a, c in raw.warnings], raw.num_vars, raw.num_eqs)
     return SolveOutcome(raw)
+
+
+class FreedomAnalysis:
+    """analysis.rs:24-77"""
+
+    def __init__(self, underconstrained: List[int]):
+        self._under = list(underconstrained)
+
+    def is_underconstrained(self) -> bool:
+        return bool(self._under)
+
+    def underconstrained(self) -> List[int]:
+        return self._under
+
+    def into_underconstrained(self) -> List[int]:
+        return self._under
+
+
+class SolveOutcomeFreedomAnalysis:
+    """solve_outcome.rs: `analysis` + `outcome`."""
+
+    def __init__(self, raw: RawResult):
+        self.analysis = FreedomAnalysis(raw.underconstrained or [])
+        self.outcome = SolveOutcome(raw)
+
+
+def solve_analysis(reqs: Iterable[ConstraintRequest], initial_guesses: Sequence[Tuple[Id, float]],
+                   config: Optional[Config] = None) -> SolveOutcomeFreedomAnalysis:
+    """`ezpz::solve_analysis` (lib.rs:134-146)."""
+    raw = solve_records([r.record() for r in reqs], list(initial_guesses), config, analysis=True)
+    if raw.error != 0:
+        err = NonLinearSystemError(raw.error, raw.err_constraint_id, raw.err_variable)
+        raise FailureOutcome(err, [Warning(a, c) for a, c in raw.warnings], raw.num_vars, raw.num_eqs)
+    return SolveOutcomeFreedomAnalysis(raw)
 
 
 def solve_batch(reqs, x0: np.ndarray, config: Optional[Config] = None, want_mask: bool = False):
@@ -619,6 +663,25 @@ class System:
         J = np.zeros((batch, m, n))
         J[:, rows[:zj], cols[:zj]] = jv[:, :zj]
         return r[:, :m], J, deg
+
+    def freedom_batch(self, x: np.ndarray):
+        """FreedomAnalysis (find_dof.rs) of each value vector.  Returns (mask [batch, n] uint8, participation)."""
+        n = self.n_vars
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, max(n, 1))
+        batch = x.shape[0]
+        mask = np.zeros((batch, max(n, 1)), np.uint8)
+        part = np.zeros((batch, max(n, 1)))
+        rc = lib().ezpz_system_freedom_batch(self._h, x.ctypes.data, batch, mask.ctypes.data, part.ctypes.data)
+        if rc != 0:
+            raise NonLinearSystemError(rc)
+        return mask, part
+
+    def freedom_batch_device(self, x_ptr: int, batch: int, mask_ptr: int, part_ptr: int = 0, count_ptr: int = 0,
+                             stream: int = 0) -> None:
+        rc = lib().ezpz_system_freedom_batch_device(self._h, x_ptr, batch, mask_ptr, part_ptr or None,
+                                                    count_ptr or None, stream or None)
+        if rc != 0:
+            raise NonLinearSystemError(rc)
 
     def solve_batch_device(self, x0_ptr: int, batch: int, x_out_ptr: int, status_ptr: int, mask_ptr: int = 0,
                            stream: int = 0, config: Optional[Config] = None) -> None:

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/ezpz_amd.h"
+#include "freedom.hip.hpp"
 #include "kinds.hpp"
 #include "lm_kernel.hip.hpp"
 #include "program.hpp"
@@ -111,6 +112,18 @@ struct EzpzSystem {
     DevBuf<double> gws_dev;
     PinnedBuf pinned;
     std::vector<uint32_t> host_var_of, host_row_of, host_slot_row, host_slot_col;  // internal -> caller numbering
+    // FreedomAnalysis program (built on first use) and its scratch
+    struct Freedom {
+        bool built = false;
+        bool lane = false;
+        uint32_t ncomp = 0, ws = 0, max_n = 0, group = 1, threads = 64;
+        DevBuf<FreedomComp> comps;
+        DevBuf<uint32_t> lists;  // items | comp_vars | col_ptr | col_slots
+        uint32_t o_vars = 0, o_col_ptr = 0, o_col_slots = 0;
+        DevBuf<double> x_int, jv, part, gws;
+        DevBuf<uint8_t> mask;
+        DevBuf<uint32_t> count;
+    } freedom;
     ~EzpzSystem() {
         if (dev_program) (void)hipFree(dev_program);
     }
@@ -669,10 +682,229 @@ void ezpz_cache_clear(void) {
     g_cache.clear();
 }
 
-int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
+}  // extern "C"
+
+// ---- FreedomAnalysis (solver/find_dof.rs, analysis.rs) ----------------------------------------------------------------
+namespace {
+
+// Connected components of the Jacobian's row/variable graph and, per component, the dense placement of its slots.
+int build_freedom(EzpzSystem* sys) {
+    auto& F = sys->freedom;
+    if (F.built) return EZPZ_OK;
+    const uint32_t n = sys->counts.n_vars, m = sys->counts.n_rows, zj = sys->counts.zj;
+    std::vector<uint32_t> parent(n + m);
+    for (uint32_t i = 0; i < n + m; ++i) parent[i] = i;
+    auto find = [&](uint32_t a) {
+        while (parent[a] != a) {
+            parent[a] = parent[parent[a]];
+            a = parent[a];
+        }
+        return a;
+    };
+    for (uint32_t s = 0; s < zj; ++s) {
+        uint32_t a = find(sys->host_slot_col[s]), b = find(n + sys->host_slot_row[s]);
+        if (a != b) parent[std::max(a, b)] = std::min(a, b);
+    }
+    std::vector<uint32_t> comp_of(n + m, UINT32_MAX), lidx(n + m, 0);
+    std::vector<FreedomComp> comps;
+    std::vector<uint32_t> col_count(n, 0);
+    for (uint32_t s = 0; s < zj; ++s) col_count[sys->host_slot_col[s]]++;
+    for (uint32_t v = 0; v < n; ++v) {  // components in order of their smallest variable; local columns ascending
+        if (!col_count[v]) continue;
+        uint32_t r = find(v);
+        if (comp_of[r] == UINT32_MAX) {
+            comp_of[r] = (uint32_t)comps.size();
+            comps.push_back(FreedomComp{0, 0, 0, 0, 0, 0});
+        }
+        comp_of[v] = comp_of[r];
+        lidx[v] = comps[comp_of[v]].n++;
+    }
+    for (uint32_t r = 0; r < m; ++r) {
+        uint32_t root = find(n + r);
+        if (comp_of[root] == UINT32_MAX) continue;  // a row without entries
+        comp_of[n + r] = comp_of[root];
+        lidx[n + r] = comps[comp_of[root]].m++;
+    }
+    uint32_t var_total = 0, ws = 0, max_n = 0;
+    for (auto& c : comps) {
+        c.var0 = var_total;
+        var_total += c.n;
+        const uint64_t w = (uint64_t)c.m * c.n + 2ull * c.n * c.n + 2ull * c.n;
+        if (w > (1ull << 31)) return EZPZ_ERR_TOO_LARGE;
+        ws = std::max<uint32_t>(ws, (uint32_t)w);
+        max_n = std::max(max_n, c.n);
+    }
+    std::vector<uint32_t> comp_vars(std::max<uint32_t>(var_total, 1));
+    for (uint32_t v = 0; v < n; ++v)
+        if (col_count[v]) comp_vars[comps[comp_of[v]].var0 + lidx[v]] = v;
+    // slots grouped by component
+    std::vector<uint32_t> per_comp(comps.size() + 1, 0);
+    for (uint32_t s = 0; s < zj; ++s) per_comp[comp_of[sys->host_slot_col[s]] + 1]++;
+    for (size_t c = 0; c < comps.size(); ++c) per_comp[c + 1] += per_comp[c];
+    for (size_t c = 0; c < comps.size(); ++c) {
+        comps[c].item0 = per_comp[c];
+        comps[c].item1 = per_comp[c];
+    }
+    std::vector<uint32_t> items(2 * std::max<uint32_t>(zj, 1));
+    for (uint32_t s = 0; s < zj; ++s) {
+        const uint32_t v = sys->host_slot_col[s], r = sys->host_slot_row[s];
+        FreedomComp& c = comps[comp_of[v]];
+        items[2 * c.item1] = s;
+        items[2 * c.item1 + 1] = lidx[v] * c.m + lidx[n + r];
+        c.item1++;
+    }
+    std::vector<uint32_t> col_ptr(n + 1, 0), col_slots(std::max<uint32_t>(zj, 1));
+    for (uint32_t v = 0; v < n; ++v) col_ptr[v + 1] = col_ptr[v] + col_count[v];
+    {
+        std::vector<uint32_t> next(col_ptr.begin(), col_ptr.end() - 1);
+        for (uint32_t s = 0; s < zj; ++s) col_slots[next[sys->host_slot_col[s]]++] = s;
+    }
+    // one allocation for the four index lists
+    std::vector<uint32_t> lists;
+    lists.insert(lists.end(), items.begin(), items.end());
+    F.o_vars = (uint32_t)lists.size();
+    lists.insert(lists.end(), comp_vars.begin(), comp_vars.end());
+    F.o_col_ptr = (uint32_t)lists.size();
+    lists.insert(lists.end(), col_ptr.begin(), col_ptr.end());
+    F.o_col_slots = (uint32_t)lists.size();
+    lists.insert(lists.end(), col_slots.begin(), col_slots.end());
+    int rc;
+    if ((rc = F.comps.ensure(std::max<size_t>(comps.size(), 1))) != EZPZ_OK) return rc;
+    if ((rc = F.lists.ensure(lists.size())) != EZPZ_OK) return rc;
+    if (!comps.empty())
+        HIP_TRY(hipMemcpy(F.comps.p, comps.data(), comps.size() * sizeof(FreedomComp), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(F.lists.p, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    F.ncomp = (uint32_t)comps.size();
+    F.ws = std::max<uint32_t>(ws, 1);
+    F.max_n = max_n;
+    // LANE: a lane per (system, component) with 128 private workspaces in <= 64 KiB of LDS
+    F.lane = F.ws <= 64;
+    if (F.lane) {
+        F.threads = 128;
+        F.group = F.ncomp >= 128 ? 1 : 128 / std::max<uint32_t>(F.ncomp, 1);
+    } else {
+        F.threads = max_n <= 64 ? 64 : 256;
+        F.group = 1;
+    }
+    F.built = true;
+    return EZPZ_OK;
+}
+
+// x_dev: final values, caller order.  Everything on `stream`.
+int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* mask_dev, double* part_dev,
+                   uint32_t* count_dev, hipStream_t stream) {
+    auto& F = sys->freedom;
+    const size_t n = sys->counts.n_vars, zj = sys->counts.zj;
+    if (n == 0 || sys->counts.n_rows == 0) return EZPZ_ERR_EMPTY_SYSTEM;  // find_dof.rs:43-44
+    int rc = build_freedom(sys);
+    if (rc != EZPZ_OK) return rc;
+    if ((rc = F.x_int.ensure(batch * n)) != EZPZ_OK) return rc;
+    if ((rc = F.jv.ensure(batch * std::max<size_t>(zj, 1))) != EZPZ_OK) return rc;
+    if (!part_dev) {
+        if ((rc = F.part.ensure(batch * n)) != EZPZ_OK) return rc;
+        part_dev = F.part.p;
+    }
+    const uint32_t* var_of = reinterpret_cast<const uint32_t*>(sys->view.base + sys->view.o_var_of);
+    const uint64_t total = (uint64_t)batch * n;
+    hipLaunchKernelGGL(gather_values_kernel, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0,
+                       stream, x_dev, var_of, F.x_int.p, (uint32_t)n, total);
+    EvalArgs e{};
+    e.p = sys->view;
+    e.x = F.x_int.p;
+    e.r_out = nullptr;
+    e.jv_out = F.jv.p;
+    e.deg_out = nullptr;
+    e.batch = batch;
+    hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)std::min<size_t>(batch, 8192)), dim3(256), 0, stream, e);
+    FreedomArgs a{};
+    a.jv = F.jv.p;
+    a.comps = F.comps.p;
+    a.items = F.lists.p;
+    a.comp_vars = F.lists.p + F.o_vars;
+    a.col_ptr = F.lists.p + F.o_col_ptr;
+    a.col_slots = F.lists.p + F.o_col_slots;
+    a.part = part_dev;
+    a.mask = mask_dev;
+    a.n_under = count_dev;
+    a.batch = batch;
+    a.n = (uint32_t)n;
+    a.zj = (uint32_t)zj;
+    a.ncomp = F.ncomp;
+    a.ws = F.ws;
+    a.group = F.group;
+    const size_t head = (2 * (size_t)F.group + (F.group + 1) / 2 + 16) * sizeof(double);
+    if (F.lane) {
+        const size_t lds = head + (size_t)F.threads * F.ws * sizeof(double);
+        const uint32_t grid = (uint32_t)std::min<size_t>((batch + F.group - 1) / F.group, 1u << 16);
+        HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(freedom_kernel<true>, dim3(grid), dim3(F.threads), lds, stream, a);
+    } else {
+        size_t lds = head + (size_t)F.ws * sizeof(double);
+        uint32_t grid = (uint32_t)std::min<size_t>(batch, 1u << 16);
+        if (lds > 128 * 1024) {  // workspace of the largest component does not fit LDS: global, bounded to 4 GiB
+            lds = head;
+            const size_t per = (size_t)F.ws * sizeof(double);
+            grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(batch, 1024), (4ull << 30) / per));
+            if ((rc = F.gws.ensure((size_t)grid * F.ws)) != EZPZ_OK) return rc;
+            a.gws = F.gws.p;
+        }
+        HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(freedom_kernel<false>, dim3(grid), dim3(F.threads), lds, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return EZPZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ezpz_system_freedom_batch_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* under_mask_dev,
+                                     double* participation_dev, uint32_t* n_under_dev, void* stream) {
+    if (!sys || (batch && (!x_dev || !under_mask_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return EZPZ_OK;
+    std::lock_guard<std::mutex> lock(sys->mu);
+    HIP_TRY(hipSetDevice(sys->device));
+    return freedom_device(sys, x_dev, batch, under_mask_dev, participation_dev, n_under_dev, (hipStream_t)stream);
+}
+
+int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, uint8_t* under_mask,
+                              double* participation) {
+    if (!sys || (batch && (!x || !under_mask))) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return EZPZ_OK;
+    std::lock_guard<std::mutex> lock(sys->mu);
+    HIP_TRY(hipSetDevice(sys->device));
+    auto& F = sys->freedom;
+    const size_t n = sys->counts.n_vars;
+    if (n == 0 || sys->counts.n_rows == 0) return EZPZ_ERR_EMPTY_SYSTEM;
+    int rc;
+    DevBuf<double> xd;
+    if ((rc = xd.ensure(batch * n)) != EZPZ_OK) return rc;
+    if ((rc = F.mask.ensure(batch * n)) != EZPZ_OK) return rc;
+    if ((rc = F.part.ensure(batch * n)) != EZPZ_OK) return rc;
+    HIP_TRY(hipMemcpy(xd.p, x, batch * n * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = freedom_device(sys, xd.p, batch, F.mask.p, F.part.p, nullptr, nullptr)) != EZPZ_OK) return rc;
+    HIP_TRY(hipMemcpy(under_mask, F.mask.p, batch * n, hipMemcpyDeviceToHost));
+    if (participation) HIP_TRY(hipMemcpy(participation, F.part.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
+    return EZPZ_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+}  // extern "C"
+
+namespace {
+
+int solve_inner_impl(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
                      const double* guesses, size_t n_guesses, const EzpzConfig* cfg, double* x_out,
-                     uint64_t* unsat_ids, EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out) {
+                     uint64_t* unsat_ids, EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out,
+                     uint32_t* under_out, uint64_t* n_under_out) {
     if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (n_under_out) *n_under_out = 0;
     std::memset(out, 0, sizeof(*out));
     out->num_vars = n_guesses;
     uint64_t num_eqs = 0;
@@ -764,15 +996,63 @@ int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t 
     out->converged = (int32_t)st.converged;
     out->final_lambda = st.final_lambda;
     out->final_residual_inf = st.final_residual_inf;
+    if (under_out) {  // lib.rs:328-338: A::analyze(model); an error fails the tier
+        std::vector<uint8_t> free_mask(std::max<size_t>(n_guesses, 1));
+        rc = ezpz_system_freedom_batch(sys, x.data(), 1, free_mask.data(), nullptr);
+        if (rc != EZPZ_OK) {
+            out->error = rc;
+            return rc;
+        }
+        uint64_t k = 0;
+        for (size_t v = 0; v < n_guesses; ++v)
+            if (free_mask[v]) under_out[k++] = (uint32_t)v;
+        *n_under_out = k;
+    }
     if (x_out && n_guesses) std::memcpy(x_out, x.data(), n_guesses * sizeof(double));
     return EZPZ_OK;
 }
 
-int ezpz_solve(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+int solve_impl(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+               size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
+               size_t warn_cap, EzpzOutcome* out, uint32_t* under_out, uint64_t* n_under_out);
+
+}  // namespace
+
+extern "C" {
+
+int ezpz_solve_inner(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
+                     const double* guesses, size_t n_guesses, const EzpzConfig* cfg, double* x_out,
+                     uint64_t* unsat_ids, EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out) {
+    return solve_inner_impl(cs, orig_ids, n_cs, var_ids, guesses, n_guesses, cfg, x_out, unsat_ids, warn_buf,
+                            warn_cap, out, nullptr, nullptr);
+}
+
+int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
                size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
                size_t warn_cap, EzpzOutcome* out) {
+    return solve_impl(reqs, n_reqs, var_ids, guesses, n_guesses, cfg, x_out, unsat_ids, warn_buf, warn_cap, out,
+                      nullptr, nullptr);
+}
+
+int ezpz_solve_analysis(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+                        size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids,
+                        EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out, uint32_t* under_out,
+                        uint64_t* n_under_out) {
+    if (!under_out || !n_under_out) return EZPZ_ERR_INVALID_ARGUMENT;
+    return solve_impl(reqs, n_reqs, var_ids, guesses, n_guesses, cfg, x_out, unsat_ids, warn_buf, warn_cap, out,
+                      under_out, n_under_out);
+}
+
+}  // extern "C"
+
+namespace {
+
+int solve_impl(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+               size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
+               size_t warn_cap, EzpzOutcome* out, uint32_t* under_out, uint64_t* n_under_out) {
     if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
     std::memset(out, 0, sizeof(*out));
+    if (n_under_out) *n_under_out = 0;  // A::no_constraints(), lib.rs:157,250
     if (n_reqs == 0) {  // lib.rs:155-170
         if (x_out && n_guesses) std::memcpy(x_out, guesses, n_guesses * sizeof(double));
         out->converged = 1;
@@ -806,6 +1086,8 @@ int ezpz_solve(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var
     std::vector<double> x_try(std::max<size_t>(n_guesses, 1));
     std::vector<uint64_t> unsat_try(n_reqs + 1);
     std::vector<EzpzWarning> warn_try(std::max<size_t>(warn_cap, 1));
+    std::vector<uint32_t> under_try(under_out ? n_guesses + 1 : 0);
+    uint64_t n_under_try = 0;
     bool have_res = false;
     int rc_final = EZPZ_OK;
     auto adopt = [&](const EzpzOutcome& o) {
@@ -825,11 +1107,16 @@ int ezpz_solve(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var
             }
         }
         EzpzOutcome o;
-        int rc = ezpz_solve_inner(subset.data(), subset_ids.data(), subset.size(), var_ids, guesses, n_guesses, cfg,
-                                  x_try.data(), unsat_try.data(), warn_try.data(), warn_cap, &o);
+        int rc = solve_inner_impl(subset.data(), subset_ids.data(), subset.size(), var_ids, guesses, n_guesses, cfg,
+                                  x_try.data(), unsat_try.data(), warn_try.data(), warn_cap, &o,
+                                  under_out ? under_try.data() : nullptr, &n_under_try);
         if (rc == EZPZ_OK) {
             if (o.n_unsatisfied > 0 && have_res) break;  // lib.rs:232-234
             adopt(o);
+            if (under_out) {
+                std::memcpy(under_out, under_try.data(), (size_t)n_under_try * sizeof(uint32_t));
+                *n_under_out = n_under_try;
+            }
             if (x_out && n_guesses) std::memcpy(x_out, x_try.data(), n_guesses * sizeof(double));
             if (unsat_ids) std::memcpy(unsat_ids, unsat_try.data(), (size_t)o.n_unsatisfied * sizeof(uint64_t));
             have_res = true;
@@ -844,6 +1131,10 @@ int ezpz_solve(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var
     }
     return rc_final;
 }
+
+}  // namespace
+
+extern "C" {
 
 int ezpz_solve_batch(const EzpzConstraint* reqs_in, size_t n_reqs, size_t n_vars, const double* x0, size_t batch,
                      const EzpzConfig* cfg, double* x_out, EzpzStatus* status, uint32_t* priority_solved,

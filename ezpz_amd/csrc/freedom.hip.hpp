@@ -1,0 +1,356 @@
+// FreedomAnalysis on the device: which variables of a solved system are underconstrained.
+//
+// Reference: ezpz/src/solver/find_dof.rs:14-103 (Model::freedom_analysis) and ezpz/src/analysis.rs:24-77.  The
+// reference densifies the weighted Jacobian the LM loop left behind, takes a column-pivoted QR, reads the rank off the
+// diagonal of R with tolerance 1e-8 * max|R_ii|, builds a null-space basis by back substitution, orthonormalises it and
+// flags every variable whose squared row norm in that basis (its "participation") exceeds (1e-3 * max participation)^2.
+//
+// Here the same algorithm runs per connected component of the Jacobian's bipartite row/variable graph: J is block
+// diagonal over components, so the pivoted QR of J is the interleaving of the pivoted QRs of the blocks, the rank
+// tolerance needs only the largest column norm of J (= the first, largest pivot) and the participation -- the diagonal
+// of the orthogonal projector onto null(J), which does not depend on the basis -- is block diagonal too.  Dense work
+// drops from m*n*n to sum m_c*n_c*n_c (2000x2000: 32 MB and 1.6e10 flops -> 500 blocks of 4x4).
+//
+// Two layouts, one code body (freedom_component<Ctx>):
+//   LANE  one lane per (system, component), private workspace interleaved in LDS, no synchronisation
+//   TEAM  one workgroup per system, components in sequence, lanes over columns, workspace in LDS or global memory
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ezpz {
+
+struct FreedomComp {
+    uint32_t m, n;          // rows / variables of the component
+    uint32_t item0, item1;  // its Jacobian slots: items[2i] = internal slot, items[2i+1] = lcol * m + lrow
+    uint32_t var0;          // comp_vars[var0 + lcol] = caller's variable id
+    uint32_t pad;
+};
+
+struct FreedomArgs {
+    const double* jv;  // [batch][zj] weighted Jacobian values at the final point, internal slot order
+    const FreedomComp* comps;
+    const uint32_t* items;
+    const uint32_t* comp_vars;
+    const uint32_t* col_ptr;  // per caller variable: the slots of its column
+    const uint32_t* col_slots;
+    double* part;       // [batch][n] out: participation
+    uint8_t* mask;      // [batch][n] out: 1 = underconstrained
+    uint32_t* n_under;  // [batch] out, may be null
+    double* gws;        // TEAM: global workspace [gridDim][ws], null when the workspace is in LDS
+    uint64_t batch;
+    uint32_t n, zj, ncomp;
+    uint32_t ws;     // workspace doubles of the largest component
+    uint32_t group;  // LANE: systems per workgroup
+};
+
+constexpr double kFreedomRankTol = 1e-8;  // find_dof.rs:12
+constexpr double kFreedomVarTol = 1e-3;   // find_dof.rs:98
+
+// Gathers caller-ordered values into the program's internal variable order for eval_kernel.
+__global__ void __launch_bounds__(256) gather_values_kernel(const double* x, const uint32_t* var_of, double* x_int,
+                                                            uint32_t n, uint64_t total) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = i / n;
+        const uint32_t k = (uint32_t)(i - b * n);
+        x_int[i] = x[b * n + var_of[k]];
+    }
+}
+
+namespace freedom {
+
+struct Ws {
+    double* p;
+    uint32_t stride;
+    __device__ __forceinline__ double& operator()(uint32_t e) const { return p[(size_t)e * stride]; }
+};
+
+struct LaneCtx {
+    __device__ __forceinline__ uint32_t id() const { return 0; }
+    __device__ __forceinline__ uint32_t count() const { return 1; }
+    __device__ __forceinline__ void sync() const {}
+    __device__ __forceinline__ double sum(double v) const { return v; }
+    __device__ __forceinline__ void argmax(double&, uint32_t&) const {}
+};
+
+struct BlockCtx {
+    double* red;  // LDS scratch, 16 doubles
+    __device__ __forceinline__ uint32_t id() const { return threadIdx.x; }
+    __device__ __forceinline__ uint32_t count() const { return blockDim.x; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ double sum(double v) const {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (blockDim.x > 64) {
+            const uint32_t nw = blockDim.x >> 6;
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+            __syncthreads();
+            v = 0.0;
+            for (uint32_t w = 0; w < nw; ++w) v += red[w];
+        }
+        return v;
+    }
+    // largest value, smallest index among equals; every lane gets the result
+    __device__ void argmax(double& v, uint32_t& i) const {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(v, off);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)i, off);
+            if (ov > v || (ov == v && oi < i)) {
+                v = ov;
+                i = oi;
+            }
+        }
+        if (blockDim.x > 64) {
+            const uint32_t nw = blockDim.x >> 6;
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) {
+                red[threadIdx.x >> 6] = v;
+                red[8 + (threadIdx.x >> 6)] = (double)i;
+            }
+            __syncthreads();
+            v = red[0];
+            i = (uint32_t)red[8];
+            for (uint32_t w = 1; w < nw; ++w) {
+                const double ov = red[w];
+                const uint32_t oi = (uint32_t)red[8 + w];
+                if (ov > v || (ov == v && oi < i)) {
+                    v = ov;
+                    i = oi;
+                }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void atomic_max_nonneg(unsigned long long* slot, double v) {
+    if (v == v) atomicMax(slot, (unsigned long long)__double_as_longlong(v));  // libm::fmax ignores NaN
+}
+
+// Workspace of one m x n component, doubles: A[m*n] | NS[n*n] | Q[n*n] | perm[n] | tau[n]
+__host__ __device__ inline uint32_t component_ws(uint32_t m, uint32_t n) { return m * n + 2 * n * n + 2 * n; }
+
+template <class C>
+__device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd, const uint32_t* __restrict__ items,
+                                  const double* __restrict__ jv, const double tol, const uint32_t* __restrict__ vars,
+                                  double* __restrict__ part, unsigned long long* partmax) {
+    const uint32_t m = cd.m, n = cd.n, mn = m * n;
+    const uint32_t oNS = mn, oQ = mn + n * n, oPerm = mn + 2 * n * n, oTau = oPerm + n;
+    const uint32_t id = ctx.id(), cnt = ctx.count();
+#define A_(i, j) W((j) * m + (i))
+#define NS_(i, j) W(oNS + (j) * n + (i))
+#define Q_(i, j) W(oQ + (j) * n + (i))
+#define PERM_(j) ((uint32_t)W(oPerm + (j)))
+    for (uint32_t e = id; e < mn; e += cnt) W(e) = 0.0;
+    for (uint32_t j = id; j < n; j += cnt) W(oPerm + j) = (double)j;
+    ctx.sync();
+    for (uint32_t it = cd.item0 + id; it < cd.item1; it += cnt) W(items[2 * it + 1]) = jv[items[2 * it]];
+    ctx.sync();
+    // ---- column-pivoted Householder QR (find_dof.rs:35 ColPivQr) ------------------------------------------------------
+    const uint32_t ndiag = m < n ? m : n;
+    for (uint32_t k = 0; k < ndiag; ++k) {
+        double bv = -1.0;
+        uint32_t bj = k;
+        for (uint32_t j = k + id; j < n; j += cnt) {
+            double s = 0.0;
+            for (uint32_t i = k; i < m; ++i) {
+                const double a = A_(i, j);
+                s += a * a;
+            }
+            if (s > bv) {
+                bv = s;
+                bj = j;
+            }
+        }
+        ctx.argmax(bv, bj);
+        if (!(bv > 0.0)) break;  // nothing left (or NaN): the remaining diagonal is exactly zero
+        if (bj != k) {
+            for (uint32_t i = id; i < m; i += cnt) {
+                const double t = A_(i, k);
+                A_(i, k) = A_(i, bj);
+                A_(i, bj) = t;
+            }
+            if (id == 0) {
+                const double t = W(oPerm + k);
+                W(oPerm + k) = W(oPerm + bj);
+                W(oPerm + bj) = t;
+            }
+        }
+        ctx.sync();
+        const double norm = sqrt(bv);
+        const double alpha = A_(k, k);
+        const double beta = alpha >= 0.0 ? -norm : norm;
+        const double denom = alpha - beta;
+        const double tau = (beta - alpha) / beta;
+        ctx.sync();
+        for (uint32_t i = k + 1 + id; i < m; i += cnt) A_(i, k) /= denom;
+        if (id == 0) A_(k, k) = beta;
+        ctx.sync();
+        for (uint32_t j = k + 1 + id; j < n; j += cnt) {
+            double dot = A_(k, j);
+            for (uint32_t i = k + 1; i < m; ++i) dot += A_(i, k) * A_(i, j);
+            dot *= tau;
+            A_(k, j) -= dot;
+            for (uint32_t i = k + 1; i < m; ++i) A_(i, j) -= dot * A_(i, k);
+        }
+        ctx.sync();
+    }
+    // ---- rank and null-space basis (find_dof.rs:38-77) --------------------------------------------------------------
+    uint32_t rank = 0;
+    while (rank < ndiag && fabs(A_(rank, rank)) > tol) ++rank;
+    const uint32_t nullity = n - rank;
+    if (nullity == 0) {
+        for (uint32_t j = id; j < n; j += cnt) part[vars[j]] = 0.0;
+        ctx.sync();
+        return;
+    }
+    for (uint32_t e = id; e < n * nullity; e += cnt) {
+        W(oNS + e) = 0.0;
+        W(oQ + e) = 0.0;
+    }
+    ctx.sync();
+    for (uint32_t fc = id; fc < nullity; fc += cnt) {
+        const uint32_t fv = rank + fc;
+        NS_(PERM_(fv), fc) = 1.0;
+        for (uint32_t i = rank; i-- > 0;) {
+            double rhs = A_(i, fv);
+            for (uint32_t j = i + 1; j < rank; ++j) rhs += A_(i, j) * NS_(PERM_(j), fc);
+            NS_(PERM_(i), fc) = -rhs / A_(i, i);
+        }
+    }
+    ctx.sync();
+    // ---- thin Q of the basis (find_dof.rs:79) ------------------------------------------------------------------------
+    for (uint32_t k = 0; k < nullity; ++k) {
+        double s = 0.0;
+        for (uint32_t i = k + id; i < n; i += cnt) {
+            const double a = NS_(i, k);
+            s += a * a;
+        }
+        s = ctx.sum(s);
+        const double norm = sqrt(s);
+        const double alpha = NS_(k, k);
+        const double beta = alpha >= 0.0 ? -norm : norm;
+        const double denom = alpha - beta;
+        const double tau = norm > 0.0 ? (beta - alpha) / beta : 0.0;
+        ctx.sync();
+        if (tau != 0.0) {
+            for (uint32_t i = k + 1 + id; i < n; i += cnt) NS_(i, k) /= denom;
+            if (id == 0) NS_(k, k) = beta;
+        }
+        if (id == 0) W(oTau + k) = tau;
+        ctx.sync();
+        if (tau != 0.0)
+            for (uint32_t j = k + 1 + id; j < nullity; j += cnt) {
+                double dot = NS_(k, j);
+                for (uint32_t i = k + 1; i < n; ++i) dot += NS_(i, k) * NS_(i, j);
+                dot *= tau;
+                NS_(k, j) -= dot;
+                for (uint32_t i = k + 1; i < n; ++i) NS_(i, j) -= dot * NS_(i, k);
+            }
+        ctx.sync();
+    }
+    for (uint32_t j = id; j < nullity; j += cnt) {  // Q(:,j) = H_0 .. H_j e_j (later reflectors leave e_j alone)
+        Q_(j, j) = 1.0;
+        for (uint32_t k = j + 1; k-- > 0;) {
+            const double tau = W(oTau + k);
+            if (tau == 0.0) continue;
+            double dot = Q_(k, j);
+            for (uint32_t i = k + 1; i < n; ++i) dot += NS_(i, k) * Q_(i, j);
+            dot *= tau;
+            Q_(k, j) -= dot;
+            for (uint32_t i = k + 1; i < n; ++i) Q_(i, j) -= dot * NS_(i, k);
+        }
+    }
+    ctx.sync();
+    // ---- participation (find_dof.rs:90-95) --------------------------------------------------------------------------
+    double local_max = 0.0;
+    for (uint32_t i = id; i < n; i += cnt) {
+        double sq = 0.0;
+        for (uint32_t j = 0; j < nullity; ++j) {
+            const double q = Q_(i, j);
+            sq += q * q;
+        }
+        part[vars[i]] = sq;
+        if (sq > local_max) local_max = sq;
+    }
+    atomic_max_nonneg(partmax, local_max);
+    ctx.sync();
+#undef A_
+#undef NS_
+#undef Q_
+#undef PERM_
+}
+
+}  // namespace freedom
+
+template <bool LANE>
+__global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
+    using namespace freedom;
+    extern __shared__ double fr_lds[];
+    const uint32_t G = LANE ? a.group : 1;
+    unsigned long long* sysmax = reinterpret_cast<unsigned long long*>(fr_lds);  // largest column norm per system
+    unsigned long long* partmax = sysmax + G;                                    // largest participation per system
+    uint32_t* under = reinterpret_cast<uint32_t*>(partmax + G);                   // [G] (rounded up to doubles)
+    double* red = fr_lds + 2 * G + (G + 1) / 2;
+    double* wsl = red + 16;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * G; base < a.batch; base += (uint64_t)gridDim.x * G) {
+        const uint32_t nsys = (uint32_t)((a.batch - base) < G ? (a.batch - base) : G);
+        for (uint32_t g = tid; g < G; g += nthr) {
+            sysmax[g] = 0;
+            partmax[g] = 0;
+            under[g] = 0;
+        }
+        __syncthreads();
+        // largest |R_ii| of the pivoted QR = largest column norm; a variable in no row is a null vector by itself
+        for (uint32_t idx = tid; idx < nsys * a.n; idx += nthr) {
+            const uint32_t g = idx / a.n, v = idx - g * a.n;
+            const double* jvs = a.jv + (base + g) * a.zj;
+            const uint32_t p0 = a.col_ptr[v], p1 = a.col_ptr[v + 1];
+            if (p0 == p1) {
+                a.part[(base + g) * a.n + v] = 1.0;
+                atomic_max_nonneg(&partmax[g], 1.0);
+            } else {
+                double s = 0.0;
+                for (uint32_t p = p0; p < p1; ++p) {
+                    const double e = jvs[a.col_slots[p]];
+                    s += e * e;
+                }
+                atomic_max_nonneg(&sysmax[g], sqrt(s));
+            }
+        }
+        __syncthreads();
+        if (LANE) {
+            for (uint32_t item = tid; item < nsys * a.ncomp; item += nthr) {
+                const uint32_t g = item / a.ncomp, c = item - g * a.ncomp;
+                const double tol = kFreedomRankTol * __longlong_as_double((long long)sysmax[g]);
+                const FreedomComp cd = a.comps[c];
+                freedom_component(LaneCtx{}, Ws{wsl + tid, nthr}, cd, a.items, a.jv + (base + g) * a.zj, tol,
+                                  a.comp_vars + cd.var0, a.part + (base + g) * a.n, &partmax[g]);
+            }
+        } else {
+            const double tol = kFreedomRankTol * __longlong_as_double((long long)sysmax[0]);
+            double* w = a.gws ? a.gws + (size_t)blockIdx.x * a.ws : wsl;
+            for (uint32_t c = 0; c < a.ncomp; ++c) {
+                const FreedomComp cd = a.comps[c];
+                freedom_component(BlockCtx{red}, Ws{w, 1}, cd, a.items, a.jv + base * a.zj, tol, a.comp_vars + cd.var0,
+                                  a.part + base * a.n, &partmax[0]);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nsys * a.n; idx += nthr) {  // find_dof.rs:96-103
+            const uint32_t g = idx / a.n;
+            const double var_tol = kFreedomVarTol * __longlong_as_double((long long)partmax[g]);
+            const bool free_var = a.part[base * a.n + idx] > var_tol * var_tol;
+            a.mask[base * a.n + idx] = free_var ? 1 : 0;
+            if (free_var) atomicAdd(&under[g], 1u);
+        }
+        __syncthreads();
+        if (a.n_under)
+            for (uint32_t g = tid; g < nsys; g += nthr) a.n_under[base + g] = under[g];
+        __syncthreads();
+    }
+}
+
+}  // namespace ezpz

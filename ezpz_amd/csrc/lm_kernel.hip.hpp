@@ -655,8 +655,10 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs e) {
             const DevCon& c = P.cons[ci];
             double r0, r1;
             if (con_residual(c, xs, r0, r1)) atomicAdd(&nwarn, 1);
-            r[c.row0] = c.weight * r0;
-            if (c.nrows > 1) r[c.row0 + 1] = c.weight * r1;
+            if (e.r_out) {
+                r[c.row0] = c.weight * r0;
+                if (c.nrows > 1) r[c.row0 + 1] = c.weight * r1;
+            }
             JacWriter<double*> w;
             w.jv = jv;
             w.jbase = c.jbase;

@@ -211,6 +211,23 @@ int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_id
                size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids, EzpzWarning* warn_buf,
                size_t warn_cap, EzpzOutcome* out);
 
+/* ---- FreedomAnalysis (reference ezpz/src/solver/find_dof.rs:14-103, analysis.rs:24-77) ----------
+ * ezpz_solve_analysis replaces ezpz::solve_analysis (lib.rs:134-146): ezpz_solve plus, for the tier that is returned,
+ * the indices of the underconstrained variables (ascending; under_out has room for n_guesses entries).
+ * ezpz_system_freedom_batch[_device] analyse `batch` value vectors of one topology (normally the final values of a
+ * batch solve): under_mask [batch][n_vars] gets 1 where the variable is underconstrained, participation
+ * [batch][n_vars] (optional) the squared row norms of the orthonormal null-space basis (find_dof.rs:90-95).  The
+ * Jacobian is re-evaluated at the values given (the reference reuses the LM loop's last refresh, which is the
+ * Jacobian at the final values). */
+int ezpz_solve_analysis(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+                        size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids,
+                        EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out, uint32_t* under_out,
+                        uint64_t* n_under_out);
+int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, uint8_t* under_mask,
+                              double* participation);
+int ezpz_system_freedom_batch_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* under_mask_dev,
+                                     double* participation_dev, uint32_t* n_under_dev, void* stream);
+
 /* ---- ezpz::solve for a batch (new; SURVEY.md 8f #3: priority tiers + weights end-to-end on device batches) --------
  * `batch` systems share the request list and differ in their guesses (x0 AoS [batch][n_vars], id == index).  Per
  * system exactly the semantics of ezpz_solve: LineSide / CircleSide inferred from that system's own guesses

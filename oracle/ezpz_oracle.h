@@ -146,6 +146,17 @@ int orc_solve(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids,
               size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out, uint64_t* unsat_ids,
               OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out);
 
+/* lib.rs:134-146 solve_analysis: orc_solve plus FreedomAnalysis (solver/find_dof.rs) of the tier that is returned.
+ * under_out receives up to n_guesses variable indices (ascending). */
+int orc_solve_analysis(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+                       size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out, uint64_t* unsat_ids,
+                       OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out, uint32_t* under_out,
+                       uint64_t* n_under_out);
+/* find_dof.rs:31-103 on a dense column-major m x n Jacobian; participation_out (optional, n) = squared row norms of
+ * the orthonormal null-space basis. */
+int orc_freedom_analysis_dense(const double* jac_colmajor, size_t m, size_t n, uint32_t* under_out,
+                               uint64_t* n_under_out, double* participation_out);
+
 /* CLI timing protocol (ezpz-cli/src/main.rs:86-100): `repeats` back-to-back full solves; returns seconds. */
 double orc_time_solves(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
                        size_t n_guesses, const OrcConfig* cfg, int linsolve, int repeats, uint64_t* iterations_out);

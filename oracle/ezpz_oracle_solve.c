@@ -606,6 +606,149 @@ static int solve_levenberg_marquardt(Model* md, double* x, const OrcConfig* cfg,
     return rc;
 }
 
+
+/* ---- FreedomAnalysis: solver/find_dof.rs ---------------------------------------------------------------------------
+ * Column-pivoted Householder QR of the dense weighted Jacobian, rank from the diagonal of R (find_dof.rs:36-49),
+ * null-space basis by back substitution (:51-70), un-permute (:72-77), orthonormalise (thin Q, :79), variables whose
+ * squared row norm in that basis exceeds (1e-3 * max)^2 are underconstrained (:82-103).  faer 0.24.0's ColPivQr / Qr
+ * are replaced by textbook Householder QR; the row norms are the diagonal of the orthogonal projector onto null(J)
+ * and so do not depend on the basis either implementation picks. */
+#define FREEDOM_TOLERANCE_BASE 1E-8
+
+/* Householder vector for x[0..len): on return x[0] = beta (the R entry), v = (1, x[1..]) scaled, returns tau. */
+static double householder(double* x, size_t len) {
+    double norm = 0.0;
+    for (size_t i = 0; i < len; ++i) norm = hypot(norm, x[i]);
+    if (norm == 0.0) return 0.0;
+    double alpha = x[0];
+    double beta = alpha >= 0.0 ? -norm : norm;
+    double denom = alpha - beta;
+    for (size_t i = 1; i < len; ++i) x[i] /= denom;
+    x[0] = beta;
+    return (beta - alpha) / beta;
+}
+
+/* a[0..len) -= tau * v * (v . a), v = (1, vtail) */
+static void apply_reflector(const double* vtail, double tau, double* a, size_t len) {
+    if (tau == 0.0) return;
+    double dot = a[0];
+    for (size_t i = 1; i < len; ++i) dot += vtail[i] * a[i];
+    dot *= tau;
+    a[0] -= dot;
+    for (size_t i = 1; i < len; ++i) a[i] -= dot * vtail[i];
+}
+
+int orc_freedom_analysis_dense(const double* jac_colmajor, size_t m, size_t n, uint32_t* under_out,
+                               uint64_t* n_under_out, double* participation_out) {
+    *n_under_out = 0;
+    if (participation_out)
+        for (size_t i = 0; i < n; ++i) participation_out[i] = 0.0;
+    const size_t ndiag = m < n ? m : n;
+    if (ndiag == 0) return ORC_ERR_EMPTY_SYSTEM; /* find_dof.rs:43-44: reduce over an empty diagonal */
+    double* a = (double*)malloc(m * n * sizeof(double));
+    size_t* perm = (size_t*)malloc(n * sizeof(size_t));
+    double* tmp = (double*)malloc((m + n) * sizeof(double));
+    memcpy(a, jac_colmajor, m * n * sizeof(double));
+    for (size_t j = 0; j < n; ++j) perm[j] = j;
+    for (size_t k = 0; k < ndiag; ++k) {
+        /* pivot: remaining column of largest norm (first wins ties) */
+        size_t best = k;
+        double best_norm = -1.0;
+        for (size_t j = k; j < n; ++j) {
+            double nj = 0.0;
+            for (size_t i = k; i < m; ++i) nj = hypot(nj, a[j * m + i]);
+            if (nj > best_norm) {
+                best_norm = nj;
+                best = j;
+            }
+        }
+        if (best != k) {
+            memcpy(tmp, a + k * m, m * sizeof(double));
+            memcpy(a + k * m, a + best * m, m * sizeof(double));
+            memcpy(a + best * m, tmp, m * sizeof(double));
+            size_t t = perm[k];
+            perm[k] = perm[best];
+            perm[best] = t;
+        }
+        double tau = householder(a + k * m + k, m - k);
+        for (size_t j = k + 1; j < n; ++j) apply_reflector(a + k * m + k, tau, a + j * m + k, m - k);
+    }
+#define R_(i, j) a[(j) * m + (i)]
+    double largest_diagonal = fabs(R_(0, 0));
+    for (size_t i = 1; i < ndiag; ++i) largest_diagonal = fmax(largest_diagonal, fabs(R_(i, i)));
+    const double tolerance = FREEDOM_TOLERANCE_BASE * largest_diagonal;
+    size_t rank = 0;
+    while (rank < ndiag && fabs(R_(rank, rank)) > tolerance) rank++;
+    const size_t nullity = n - rank;
+    free(tmp);
+    if (nullity == 0) {
+        free(a);
+        free(perm);
+        return ORC_OK;
+    }
+    /* permuted null-space basis, then rows back to variable order */
+    double* ns = (double*)calloc(n * nullity, sizeof(double)); /* column-major n x nullity */
+    double* z = (double*)calloc(n, sizeof(double));
+    for (size_t fc = 0; fc < nullity; ++fc) {
+        const size_t free_var = rank + fc;
+        memset(z, 0, n * sizeof(double));
+        z[free_var] = 1.0;
+        for (size_t i = rank; i-- > 0;) {
+            double rhs = free_var < n && i < m ? R_(i, free_var) : 0.0;
+            for (size_t j = i + 1; j < rank; ++j) rhs += R_(i, j) * z[j];
+            z[i] = -rhs / R_(i, i);
+        }
+        for (size_t i = 0; i < n; ++i) ns[fc * n + perm[i]] = z[i];
+    }
+#undef R_
+    /* thin Q of ns: Householder QR, then Q = H_0 .. H_{k-1} [I; 0] */
+    double* taus = (double*)calloc(nullity, sizeof(double));
+    for (size_t k = 0; k < nullity; ++k) {
+        taus[k] = householder(ns + k * n + k, n - k);
+        for (size_t j = k + 1; j < nullity; ++j) apply_reflector(ns + k * n + k, taus[k], ns + j * n + k, n - k);
+    }
+    double* q = (double*)calloc(n * nullity, sizeof(double));
+    for (size_t j = 0; j < nullity; ++j) {
+        double* col = q + j * n;
+        col[j] = 1.0;
+        for (size_t k = nullity; k-- > 0;) apply_reflector(ns + k * n + k, taus[k], col + k, n - k);
+    }
+    double* participation = z;
+    double max_participation = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        double sq = 0.0;
+        for (size_t j = 0; j < nullity; ++j) sq += q[j * n + i] * q[j * n + i];
+        participation[i] = sq;
+        if (participation_out) participation_out[i] = sq;
+        max_participation = fmax(max_participation, sq);
+    }
+    const double var_tol = 1e-3 * max_participation;
+    const double squared_tol = var_tol * var_tol;
+    uint64_t cnt = 0;
+    for (size_t j = 0; j < n; ++j)
+        if (participation[j] > squared_tol) under_out[cnt++] = (uint32_t)j;
+    *n_under_out = cnt;
+    free(a);
+    free(perm);
+    free(ns);
+    free(z);
+    free(taus);
+    free(q);
+    return ORC_OK;
+}
+
+/* Model::freedom_analysis, find_dof.rs:14-29: the Jacobian cache as the LM loop left it, densified. */
+static int model_freedom_analysis(const Model* md, uint32_t* under_out, uint64_t* n_under_out) {
+    const size_t m = md->m, n = md->n;
+    double* dense = (double*)calloc(m * n + 1, sizeof(double));
+    if (!dense) return ORC_ERR_INTERNAL;
+    for (size_t c = 0; c < n; ++c)
+        for (size_t p = md->col_ptr[c]; p < md->col_ptr[c + 1]; ++p) dense[c * m + md->row_idx[p]] = md->vals[p];
+    int rc = orc_freedom_analysis_dense(dense, m, n, under_out, n_under_out, NULL);
+    free(dense);
+    return rc;
+}
+
 /* lib.rs:358-370 */
 static int is_satisfied(int residual_dim, const double r[3]) {
     int sat0 = fabs(r[0]) < EPSILON;
@@ -622,9 +765,10 @@ static int is_satisfied(int residual_dim, const double r[3]) {
 }
 
 /* lib.rs:265-356 */
-int orc_solve_inner(const OrcConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
-                    const double* guesses, size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out,
-                    uint64_t* unsat_ids, OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out) {
+static int solve_inner_impl(const OrcConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
+                            const double* guesses, size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out,
+                            uint64_t* unsat_ids, OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out,
+                            uint32_t* under_out, uint64_t* n_under_out) {
     memset(out, 0, sizeof(*out));
     out->num_vars = n_guesses;
     size_t num_eqs = 0;
@@ -665,6 +809,15 @@ int orc_solve_inner(const OrcConstraint* cs, const uint64_t* orig_ids, size_t n_
         }
     }
     out->n_unsatisfied = n_unsat;
+    if (under_out) { /* lib.rs:328-338: A::analyze(model), an error fails the tier */
+        rc = model_freedom_analysis(&md, under_out, n_under_out);
+        if (rc != ORC_OK) {
+            out->error = rc;
+            free(values);
+            model_free(&md);
+            return rc;
+        }
+    }
     uint32_t lowest_priority = 0; /* lib.rs:340-344: max priority in the subset */
     for (size_t i = 0; i < n_cs; ++i)
         if (cs[i].priority > lowest_priority) lowest_priority = cs[i].priority;
@@ -677,16 +830,25 @@ int orc_solve_inner(const OrcConstraint* cs, const uint64_t* orig_ids, size_t n_
     return ORC_OK;
 }
 
+int orc_solve_inner(const OrcConstraint* cs, const uint64_t* orig_ids, size_t n_cs, const uint32_t* var_ids,
+                    const double* guesses, size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out,
+                    uint64_t* unsat_ids, OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out) {
+    return solve_inner_impl(cs, orig_ids, n_cs, var_ids, guesses, n_guesses, cfg, linsolve, x_out, unsat_ids,
+                            warn_buf, warn_cap, out, NULL, NULL);
+}
+
 static int u32_cmp(const void* a, const void* b) {
     uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 
 /* lib.rs:148-263 */
-int orc_solve(const OrcConstraint* reqs_in, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
-              size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out, uint64_t* unsat_ids,
-              OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out) {
+static int solve_impl(const OrcConstraint* reqs_in, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+                      size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out, uint64_t* unsat_ids,
+                      OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out, uint32_t* under_out,
+                      uint64_t* n_under_out) {
     memset(out, 0, sizeof(*out));
+    if (n_under_out) *n_under_out = 0; /* A::no_constraints(), lib.rs:157,250 */
     if (n_reqs == 0) { /* lib.rs:155-170 */
         if (x_out) memcpy(x_out, guesses, n_guesses * sizeof(double));
         out->converged = 1;
@@ -726,6 +888,8 @@ int orc_solve(const OrcConstraint* reqs_in, size_t n_reqs, const uint32_t* var_i
     double* x_try = (double*)malloc((n_guesses + 1) * sizeof(double));
     uint64_t* unsat_try = (uint64_t*)malloc((n_reqs + 1) * sizeof(uint64_t));
     OrcWarning* warn_try = warn_cap ? (OrcWarning*)malloc(warn_cap * sizeof(OrcWarning)) : NULL;
+    uint32_t* under_try = under_out ? (uint32_t*)malloc((n_guesses + 1) * sizeof(uint32_t)) : NULL;
+    uint64_t n_under_try = 0;
     int have_res = 0;
     int rc = ORC_OK;
     for (size_t pi = 0; pi < n_prios; ++pi) {
@@ -739,14 +903,18 @@ int orc_solve(const OrcConstraint* reqs_in, size_t n_reqs, const uint32_t* var_i
             }
         }
         OrcOutcome o;
-        int r = orc_solve_inner(subset, subset_ids, ns, var_ids, guesses, n_guesses, cfg, linsolve, x_try, unsat_try,
-                                warn_try, warn_cap, &o);
+        int r = solve_inner_impl(subset, subset_ids, ns, var_ids, guesses, n_guesses, cfg, linsolve, x_try, unsat_try,
+                                 warn_try, warn_cap, &o, under_try, &n_under_try);
         if (r == ORC_OK) {
             if (o.n_unsatisfied > 0 && have_res) break; /* lib.rs:232-234: return previous res */
             /* adopt this outcome */
             *out = o;
             if (x_out) memcpy(x_out, x_try, n_guesses * sizeof(double));
             if (unsat_ids) memcpy(unsat_ids, unsat_try, o.n_unsatisfied * sizeof(uint64_t));
+            if (under_out) {
+                memcpy(under_out, under_try, n_under_try * sizeof(uint32_t));
+                *n_under_out = n_under_try;
+            }
             if (warn_buf && warn_cap) {
                 size_t nw = o.n_warnings < warn_cap ? (size_t)o.n_warnings : warn_cap;
                 memcpy(warn_buf, warn_try, nw * sizeof(OrcWarning));
@@ -772,7 +940,24 @@ int orc_solve(const OrcConstraint* reqs_in, size_t n_reqs, const uint32_t* var_i
     free(x_try);
     free(unsat_try);
     free(warn_try);
+    free(under_try);
     return rc;
+}
+
+int orc_solve(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+              size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out, uint64_t* unsat_ids,
+              OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out) {
+    return solve_impl(reqs, n_reqs, var_ids, guesses, n_guesses, cfg, linsolve, x_out, unsat_ids, warn_buf, warn_cap,
+                      out, NULL, NULL);
+}
+
+/* lib.rs:134-146 solve_analysis (A = FreedomAnalysis) */
+int orc_solve_analysis(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+                       size_t n_guesses, const OrcConfig* cfg, int linsolve, double* x_out, uint64_t* unsat_ids,
+                       OrcWarning* warn_buf, size_t warn_cap, OrcOutcome* out, uint32_t* under_out,
+                       uint64_t* n_under_out) {
+    return solve_impl(reqs, n_reqs, var_ids, guesses, n_guesses, cfg, linsolve, x_out, unsat_ids, warn_buf, warn_cap,
+                      out, under_out, n_under_out);
 }
 
 static double now_seconds(void) {

@@ -144,6 +144,7 @@ class Outcome:
     num_eqs: int
     final_lambda: float = 0.0
     final_residual_inf: float = 0.0
+    underconstrained: Optional[List[int]] = None  # FreedomAnalysis (analysis.rs:24-31); None = not requested
 
     def is_satisfied(self) -> bool:
         return not self.unsatisfied
@@ -183,6 +184,10 @@ def lib():
         L.orc_solve.restype = C.c_int
         L.orc_solve.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(_Config), C.c_int, vp, vp, vp,
                                 C.c_size_t, C.POINTER(_Outcome)]
+        L.orc_solve_analysis.restype = C.c_int
+        L.orc_solve_analysis.argtypes = list(L.orc_solve.argtypes) + [vp, C.POINTER(C.c_uint64)]
+        L.orc_freedom_analysis_dense.restype = C.c_int
+        L.orc_freedom_analysis_dense.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.POINTER(C.c_uint64), vp]
         L.orc_solve_inner.restype = C.c_int
         L.orc_solve_inner.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(_Config), C.c_int, vp,
                                       vp, vp, C.c_size_t, C.POINTER(_Outcome)]
@@ -393,8 +398,9 @@ def _split_guesses(guesses):
 
 
 def solve(reqs, guesses, config: Optional[Config] = None, linsolve: int = LINSOLVE_DENSE,
-          warn_cap: int = 4096) -> Outcome:
-    """`ezpz::solve` (lib.rs:80-87) on the CPU oracle.  guesses: [(id, value), ...] or a float array."""
+          warn_cap: int = 4096, analysis: bool = False) -> Outcome:
+    """`ezpz::solve` (lib.rs:80-87) or, with analysis=True, `ezpz::solve_analysis` (lib.rs:134-146) on the CPU
+    oracle.  guesses: [(id, value), ...] or a float array."""
     cfg = (config or Config())._c()
     a = stack(reqs)
     ids, vals = _split_guesses(guesses)
@@ -403,11 +409,18 @@ def solve(reqs, guesses, config: Optional[Config] = None, linsolve: int = LINSOL
     unsat = np.zeros(max(len(a), 1), dtype=np.uint64)
     warns = (_Warning * max(warn_cap, 1))()
     out = _Outcome()
-    lib().orc_solve(a.ctypes.data if len(a) else None, len(a), ids.ctypes.data if n else None,
-                    vals.ctypes.data if n else None, n, C.byref(cfg), linsolve, x_out.ctypes.data,
-                    unsat.ctypes.data, C.cast(warns, C.c_void_p), warn_cap, C.byref(out))
+    under = np.zeros(max(n, 1), dtype=np.uint32)
+    n_under = C.c_uint64(0)
+    args = (a.ctypes.data if len(a) else None, len(a), ids.ctypes.data if n else None,
+            vals.ctypes.data if n else None, n, C.byref(cfg), linsolve, x_out.ctypes.data,
+            unsat.ctypes.data, C.cast(warns, C.c_void_p), warn_cap, C.byref(out))
+    if analysis:
+        lib().orc_solve_analysis(*args, under.ctypes.data, C.byref(n_under))
+    else:
+        lib().orc_solve(*args)
     nw = min(int(out.n_warnings), warn_cap)
     return Outcome(
+        underconstrained=under[: n_under.value].astype(int).tolist() if analysis else None,
         error=out.error,
         err_constraint_id=out.err_constraint_id,
         err_variable=out.err_variable,
@@ -422,6 +435,19 @@ def solve(reqs, guesses, config: Optional[Config] = None, linsolve: int = LINSOL
         final_lambda=out.final_lambda,
         final_residual_inf=out.final_residual_inf,
     )
+
+
+def freedom_analysis_dense(jac: np.ndarray):
+    """find_dof.rs:31-103 on a dense m x n Jacobian.  Returns (underconstrained indices, participation [n])."""
+    jac = np.asfortranarray(jac, dtype=np.float64)
+    m, n = jac.shape
+    under = np.zeros(max(n, 1), dtype=np.uint32)
+    part = np.zeros(max(n, 1))
+    cnt = C.c_uint64(0)
+    rc = lib().orc_freedom_analysis_dense(jac.ctypes.data, m, n, under.ctypes.data, C.byref(cnt), part.ctypes.data)
+    if rc != 0:
+        raise ValueError(rc)
+    return under[: cnt.value].astype(int).tolist(), part[:n]
 
 
 def time_solves(reqs, guesses, repeats: int = 100, config: Optional[Config] = None,

@@ -15,7 +15,7 @@ class OracleAdapter:
 
     def solve(self, reqs, guesses, config=None):
         cfg = O.Config(**(config or {}))
-        return O.solve(list(reqs), guesses, cfg, linsolve=self.linsolve)
+        return O.solve(list(reqs), guesses, cfg, linsolve=self.linsolve, analysis=True)
 
     def run_text(self, text, config=None):
         cs = T.load(text)
@@ -38,13 +38,13 @@ class GpuAdapter:
     def solve(self, reqs, guesses, config=None):
         E = self.E
         cfg = E.Config(**(config or {}))
-        return E.solve_records(O.stack(list(reqs)), guesses, cfg)
+        return E.solve_records(O.stack(list(reqs)), guesses, cfg, analysis=True)
 
     def run_text(self, text, config=None):
         E = self.E
         system = E.textual.Problem.from_str(text).to_constraint_system()
         cfg = E.Config(**(config or {}))
-        return E.solve_records(system.records, system.variables(), cfg), system
+        return E.solve_records(system.records, system.variables(), cfg, analysis=True), system
 
     def run(self, case, filename="problem.md", config=None):
         return self.run_text(read_case(case, filename), config)

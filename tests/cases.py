@@ -9,7 +9,8 @@ Adapter protocol (see tests/adapters.py):
     A.solve(reqs, guesses, config=None) -> result   (reqs: list of 56-byte constraint records)
     A.run(case, filename="problem.md", config=None) -> (result, system)
     result: error, err_constraint_id, err_variable, final_values, iterations, converged, unsatisfied,
-            warnings [(about_constraint, content)], priority_solved, num_vars, num_eqs
+            warnings [(about_constraint, content)], priority_solved, num_vars, num_eqs,
+            underconstrained (FreedomAnalysis; the adapters always run solve_analysis like tests.rs `run`)
     system: point(values, label), circle(values, label), arc(values, label)
 """
 import math
@@ -27,6 +28,16 @@ def nearly_eq(l, r):
 def points_eq(l, r):
     d = math.hypot(l[0] - r[0], l[1] - r[1])
     assert d < EPSILON, f"LHS was {l}, RHS was {r}, dist was {d}"
+
+
+def freedom(out, expected):
+    """`solved.analysis` of tests.rs `run` (= solve_with_config_analysis): expected None means only
+    `is_underconstrained()` is asserted, a list is `underconstrained()` exactly ([] = not underconstrained)."""
+    assert out.underconstrained is not None, "adapter did not run the freedom analysis"
+    if expected is None:
+        assert out.underconstrained
+    else:
+        assert list(out.underconstrained) == expected, out.underconstrained
 
 
 def dist(a, b):
@@ -381,6 +392,7 @@ def points_at_angle_sign_distinguishable(A):
 def coincident(A):
     """tests.rs:130-138"""
     out, s = A.run("coincident")
+    freedom(out, [])  # tests.rs:134
     assert not out.unsatisfied
     points_eq(s.point(out.final_values, "p"), (3.0, 3.0))
     points_eq(s.point(out.final_values, "q"), (3.0, 3.0))
@@ -389,6 +401,7 @@ def coincident(A):
 def symmetric(A):
     """tests.rs:147-160"""
     out, s = A.run("symmetric")
+    freedom(out, [])  # :151
     assert not out.unsatisfied
     v = out.final_values
     points_eq(s.point(v, "p"), (0.0, 0.0))
@@ -400,6 +413,7 @@ def symmetric(A):
 def perpdist(A):
     """tests.rs:162-184"""
     out, s = A.run("perpdist")
+    freedom(out, [4, 5])  # :178-183
     assert not out.unsatisfied
     v = out.final_values
     points_eq(s.point(v, "p"), (0.0, 0.0))
@@ -410,6 +424,7 @@ def perpdist(A):
 def perpdist_negative(A):
     """tests.rs:186-207"""
     out, s = A.run("perpdist_negative")
+    freedom(out, [4, 5])  # :192-197
     assert not out.unsatisfied
     v = out.final_values
     points_eq(s.point(v, "p"), (0.0, 0.0))
@@ -420,6 +435,7 @@ def perpdist_negative(A):
 def midpoint(A):
     """tests.rs:209-218"""
     out, s = A.run("midpoint")
+    freedom(out, [])  # :213
     assert not out.unsatisfied
     v = out.final_values
     points_eq(s.point(v, "p"), (0.0, 0.0))
@@ -430,6 +446,7 @@ def midpoint(A):
 def underconstrained(A):
     """tests.rs:220-230"""
     out, s = A.run("underconstrained")
+    freedom(out, [0, 1])  # :223-225
     assert not out.unsatisfied
     points_eq(s.point(out.final_values, "p"), (1.0, 1.0))
     points_eq(s.point(out.final_values, "q"), (0.0, 0.0))
@@ -438,6 +455,7 @@ def underconstrained(A):
 def tiny(A):
     """tests.rs:232-239; CLI size pin ezpz-cli/src/main.rs:277 (4 rows, 4 vars)"""
     out, s = A.run("tiny")
+    freedom(out, [])  # :236
     assert not out.unsatisfied
     assert (out.num_eqs, out.num_vars) == (4, 4)
     points_eq(s.point(out.final_values, "p"), (0.0, 0.0))
@@ -447,6 +465,7 @@ def tiny(A):
 def inconsistent(A):
     """tests.rs:241-253"""
     out, s = A.run("inconsistent")
+    freedom(out, [])  # :249
     assert out.unsatisfied
     points_eq(s.point(out.final_values, "o"), (0.0, 0.0))
     points_eq(s.point(out.final_values, "p"), (2.5, 2.5))
@@ -455,6 +474,7 @@ def inconsistent(A):
 def circle(A):
     """tests.rs:286-299"""
     out, s = A.run("circle")
+    freedom(out, [])  # :290
     assert not out.unsatisfied
     points_eq(s.point(out.final_values, "p"), (5.0, 5.0))
     c = s.circle(out.final_values, "a")
@@ -465,6 +485,7 @@ def circle(A):
 def circle_center(A):
     """tests.rs:301-311"""
     out, s = A.run("circle_center")
+    freedom(out, [])  # :306
     assert not out.unsatisfied
     c = s.circle(out.final_values, "a")
     nearly_eq(c["radius"], 1.0)
@@ -474,6 +495,7 @@ def circle_center(A):
 def circle_tangent(A):
     """tests.rs:313-325"""
     out, s = A.run("circle_tangent")
+    freedom(out, [])  # :319
     assert not out.unsatisfied
     points_eq(s.point(out.final_values, "p"), (0.0, 3.0))
     points_eq(s.point(out.final_values, "q"), (5.0, 3.0))
@@ -485,6 +507,7 @@ def circle_tangent(A):
 def circle_tangent_other_dir(A):
     """tests.rs:327-339"""
     out, s = A.run("circle_tangent_other_dir")
+    freedom(out, [])  # :333
     assert not out.unsatisfied
     points_eq(s.point(out.final_values, "p"), (0.0, 3.0))
     points_eq(s.point(out.final_values, "q"), (5.0, 3.0))
@@ -496,6 +519,7 @@ def circle_tangent_other_dir(A):
 def two_rectangles(A):
     """tests.rs:563-578"""
     out, s = A.run("two_rectangles")
+    freedom(out, [])  # :567
     assert not out.unsatisfied
     exp = [(1.0, 1.0), (5.0, 1.0), (5.0, 4.0), (1.0, 4.0), (2.0, 2.0), (6.0, 2.0), (6.0, 6.0), (2.0, 6.0)]
     for i, e in enumerate(exp):
@@ -507,6 +531,7 @@ def angle_constraints(A):
     for f in ("angle_parallel", "angle_parallel_manual"):
         out, s = A.run(f)
         assert not out.unsatisfied
+        freedom(out, [])  # :585
         v = out.final_values
         points_eq(s.point(v, "p0"), (0.0, 0.0))
         points_eq(s.point(v, "p1"), (4.0, 4.0))
@@ -517,6 +542,7 @@ def angle_constraints(A):
 def perpendicular(A):
     """tests.rs:593-602"""
     out, s = A.run("perpendicular")
+    freedom(out, [])  # :597
     assert not out.unsatisfied
     v = out.final_values
     points_eq(s.point(v, "p0"), (0.0, 0.0))
@@ -528,6 +554,7 @@ def perpendicular(A):
 def nonsquare(A):
     """tests.rs:604-611"""
     out, s = A.run("nonsquare")
+    freedom(out, [])  # :608
     assert not out.unsatisfied
     points_eq(s.point(out.final_values, "p"), (0.0, 0.0))
     points_eq(s.point(out.final_values, "q"), (0.0, 0.0))
@@ -536,6 +563,7 @@ def nonsquare(A):
 def square(A):
     """tests.rs:613-626"""
     out, s = A.run("square")
+    freedom(out, [])  # :617
     assert not out.unsatisfied
     v = out.final_values
     a, b, c, d = (s.point(v, l) for l in "abcd")
@@ -546,6 +574,7 @@ def square(A):
 def parallelogram(A):
     """tests.rs:628-646"""
     out, s = A.run("parallelogram")
+    freedom(out, [4, 5, 6, 7])  # :633-637
     v = out.final_values
     a, b, c, d = (s.point(v, l) for l in "abcd")
     nearly_eq(a[1] - c[1], b[1] - d[1])
@@ -555,6 +584,7 @@ def parallelogram(A):
 def underdetermined_lines(A):
     """tests.rs:648-665"""
     out, s = A.run("underdetermined_lines")
+    freedom(out, [5])  # :655-660
     assert not out.unsatisfied
     v = out.final_values
     points_eq(s.point(v, "p0"), (0.0, 0.0))
@@ -565,6 +595,7 @@ def underdetermined_lines(A):
 def arc_radius(A):
     """tests.rs:667-688; CLI size pin ezpz-cli/src/main.rs:298 (4 rows, 8 vars)"""
     out, s = A.run("arc_radius")
+    freedom(out, [0, 1, 2, 3, 4, 5])  # :671-683
     assert not out.unsatisfied
     assert (out.num_eqs, out.num_vars) == (4, 8)
     arc = s.arc(out.final_values, "a")
@@ -576,6 +607,7 @@ def arc_radius(A):
 def parc_coincident(A):
     """tests.rs:690-703"""
     out, s = A.run("parc_coincident")
+    freedom(out, None)  # :695
     assert not out.unsatisfied
     arc = s.arc(out.final_values, "a")
     points_eq(arc["center"], (0.0, 0.0))
@@ -587,6 +619,7 @@ def parc_coincident(A):
 def arc_equidistant(A):
     """tests.rs:705-728"""
     out, s = A.run("arc_equidistant")
+    freedom(out, [0, 1, 2, 3, 4, 5])  # :709-720
     assert not out.unsatisfied
     arc = s.arc(out.final_values, "a")
     points_eq(arc["center"], (0.0, 0.0))
@@ -596,6 +629,7 @@ def arc_equidistant(A):
 def chamfer_square(A):
     """tests.rs:730-740"""
     out, s = A.run("chamfer_square")
+    freedom(out, [])  # :734
     assert not out.unsatisfied
     v = out.final_values
     for l, e in zip("abcde", [(0.0, 40.0), (30.0, 40.0), (40.0, 30.0), (40.0, 0.0), (0.0, 0.0)]):

@@ -434,3 +434,102 @@ def test_batch_solve_with_priorities_and_inferred_sides(E):
     # no requests: guesses are echoed
     x, st, prio, _ = E.solve_batch(np.zeros(0, dtype=E.CONSTRAINT_DTYPE), x0[:5])
     assert np.array_equal(x, x0[:5]) and np.all(st["converged"] == 1) and np.all(st["iterations"] == 0)
+
+
+# ---- FreedomAnalysis (solver/find_dof.rs) on the device ----------------------------------------------------------------
+def _freedom_vs_oracle(E, recs, n, X, atol=1e-9):
+    """Device analysis of every row of X against the oracle's dense QR of the same (device-evaluated) Jacobian."""
+    sysobj = E.System(recs, n)
+    mask, part = sysobj.freedom_batch(X)
+    _, J, _ = sysobj.eval_batch(X)
+    for b in range(X.shape[0]):
+        under, want = O.freedom_analysis_dense(J[b])
+        assert np.allclose(part[b], want, atol=atol), (b, float(np.abs(part[b] - want).max()))
+        assert np.nonzero(mask[b])[0].tolist() == under, b
+    return sysobj, mask, part
+
+
+@pytest.mark.parametrize("case", ["underdetermined_lines", "parallelogram", "arc_radius", "perpdist", "square",
+                                  "two_rectangles", "circle_tangent", "chamfer_square", "arc_equidistant"])
+def test_freedom_participation_matches_oracle_on_fixtures(E, case):
+    ref = T.load(read_case(case))
+    want = O.solve(ref.constraints, ref.guesses, analysis=True)
+    X = want.final_values[None, :] + gen.keyed_uniform(21, 33, ref.num_vars, -0.05, 0.05)
+    X[0] = want.final_values
+    # ezpz_system_* take side-resolved constraints
+    recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
+    _, mask, _ = _freedom_vs_oracle(E, recs, ref.num_vars, X)
+    assert np.nonzero(mask[0])[0].tolist() == want.underconstrained
+
+
+def test_freedom_lane_mode_on_block_systems(E):
+    """Many small components: one lane per (system, component).  An under-constrained variant of the
+    massive_parallel_system generator (every 7th block loses a constraint) against the oracle's dense QR."""
+    ref = T.load(T.gen_big_problem(60))
+    keep = [c for i, c in enumerate(ref.constraints) if not (i % 28 == 3)]
+    n = ref.num_vars
+    X = ref.guesses[None, :] + gen.keyed_uniform(31, 5, n, -0.2, 0.2)
+    sysobj, mask, part = _freedom_vs_oracle(E, O.stack(keep), n, X)
+    assert mask.any() and not mask.all()
+    # full size (BASELINE configs[1]): fully constrained, so nothing is free; and the solved batch agrees
+    ref = T.load(T.gen_big_problem(500))
+    sysobj = E.System(ref.constraints, ref.num_vars)
+    x, st, _ = sysobj.solve_batch(np.tile(ref.guesses, (64, 1)))
+    mask, part = sysobj.freedom_batch(x)
+    assert not mask.any() and np.all(part == 0.0)
+
+
+def test_freedom_workgroup_mode_with_global_workspace(E):
+    """One 240-variable component: the dense workspace (1.4 MB) lives in global memory, lanes work on columns."""
+    recs, g = _chain_system(120)
+    recs = recs[:-1]  # drop the last direction constraint: the last point may swing on its circle
+    X = g[None, :] + gen.keyed_uniform(41, 3, len(g), -0.05, 0.05)
+    sysobj = E.System(recs, len(g))
+    x, st, _ = sysobj.solve_batch(X)
+    assert np.all(st["n_unsatisfied"] == 0)
+    _, mask, _ = _freedom_vs_oracle(E, recs, len(g), x, atol=1e-8)
+    assert np.all(mask[:, -2:].any(axis=1)) and np.all(mask[:, :-2] == 0)  # only the last point is free
+
+
+def test_freedom_random_systems(E):
+    """The fuzz generator's systems (all 25 kinds, repeated ids, isolated variables) through the analysis."""
+    rng = np.random.default_rng(99)
+    checked = unstable = 0
+    for trial in range(120):
+        n = int(rng.integers(4, 20))
+        cons = [gen.arb_constraint(rng, int(rng.integers(0, O.NUM_KINDS)), hi=n) for _ in range(int(rng.integers(1, 10)))]
+        recs = O.stack(cons)
+        X = rng.uniform(-5, 5, (4, n))
+        sysobj = E.System(recs, n)
+        mask, part = sysobj.freedom_batch(X)
+        _, J, _ = sysobj.eval_batch(X)
+        for b in range(4):
+            if not np.all(np.isfinite(J[b])):
+                continue
+            sv = np.linalg.svd(J[b], compute_uv=False)
+            big = sv.max() if sv.size else 0.0
+            if big == 0.0 or np.any((sv > 1e-10 * big) & (sv < 1e-6 * big)):
+                unstable += 1  # a singular value near the 1e-8 rank threshold: the rank itself is ill-defined
+                continue
+            under, want = O.freedom_analysis_dense(J[b])
+            assert np.allclose(part[b], want, atol=1e-7), (trial, b, float(np.abs(part[b] - want).max()))
+            near = np.abs(want - (1e-3 * want.max()) ** 2) < 1e-9
+            got = np.nonzero(mask[b])[0].tolist()
+            assert [v for v in got if not near[v]] == [v for v in under if not near[v]], (trial, b)
+            checked += 1
+    assert checked >= 300, (checked, unstable)
+
+
+def test_solve_analysis_object_api_and_priority_tiers(E):
+    """lib.rs:134-146 through the crate mirror; the analysis follows the tier that is returned."""
+    ids = E.IdGenerator()
+    p = E.DatumPoint.new(ids)
+    reqs = [E.ConstraintRequest.highest_priority(E.Constraint.Fixed(p.x_id, 1.0)),
+            E.ConstraintRequest.new(E.Constraint.Fixed(p.y_id, 2.0), 1),
+            E.ConstraintRequest.new(E.Constraint.Fixed(p.y_id, 3.0), 1)]
+    out = E.solve_analysis(reqs, [(p.x_id, 0.0), (p.y_id, 0.0)])
+    assert out.outcome.priority_solved() == 0 and out.analysis.is_underconstrained()
+    assert out.analysis.underconstrained() == [1]
+    out = E.solve_analysis(reqs[:2], [(p.x_id, 0.0), (p.y_id, 0.0)])
+    assert out.outcome.priority_solved() == 1 and not out.analysis.is_underconstrained()
+    assert E.solve_analysis([], [(0, 0.5)]).analysis.underconstrained() == []

@@ -154,3 +154,53 @@ def test_side_inference():
     cc = O.circle_tangent_to_circle((0, 1), 2, (3, 4), 5)
     assert O.set_from_initial_values(cc, [0, 0, 2, 4, 0, 3])["tag"] == O.CIRCLE_EXTERIOR
     assert O.set_from_initial_values(cc, [0, 0, 5, 1, 0, 2])["tag"] == O.CIRCLE_INTERIOR
+
+
+# ---- FreedomAnalysis (solver/find_dof.rs) -----------------------------------------------------------------------------
+def _projector_participation(J, tol=1e-8):
+    """diag of the orthogonal projector onto null(J), by SVD (independent of any QR)."""
+    u, sv, vt = np.linalg.svd(J)
+    rank = int(np.sum(sv > tol * max(sv.max(), 1e-300))) if sv.size else 0
+    N = vt[rank:].T
+    return (N * N).sum(axis=1), J.shape[1] - rank
+
+
+def test_freedom_analysis_dense_matches_svd_projector():
+    """find_dof.rs:31-103: the participation is the diagonal of the projector onto null(J), whatever basis is used."""
+    rng = np.random.default_rng(77)
+    for trial in range(60):
+        m, n = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        J = rng.uniform(-2, 2, (m, n)) * (rng.uniform(0, 1, (m, n)) < 0.6)
+        if trial % 3 == 0 and m > 1:
+            J[-1] = J[0] * 2.0  # dependent row
+        if trial % 4 == 0 and n > 1:
+            J[:, -1] = 0.0  # a variable nothing constrains
+        under, part = O.freedom_analysis_dense(J)
+        want, nullity = _projector_participation(J)
+        assert np.allclose(part, want, atol=1e-9), (trial, part, want)
+        thr = (1e-3 * want.max()) ** 2
+        assert under == [j for j in range(n) if want[j] > thr and nullity > 0]
+
+
+def test_freedom_analysis_known_structures():
+    # x0 fixed, x1 - x2 = 0: x1 and x2 move together, x0 does not
+    J = np.array([[1.0, 0, 0], [0, 1.0, -1.0]])
+    under, part = O.freedom_analysis_dense(J)
+    assert under == [1, 2] and np.allclose(part, [0, 0.5, 0.5])
+    # square full rank: nothing is free
+    assert O.freedom_analysis_dense(np.eye(4))[0] == []
+    # wide zero matrix: everything is free
+    assert O.freedom_analysis_dense(np.zeros((2, 3)))[0] == [0, 1, 2]
+    # no rows or no columns: EmptySystemNotAllowed (find_dof.rs:43-44)
+    with pytest.raises(ValueError):
+        O.freedom_analysis_dense(np.zeros((0, 3)))
+
+
+def test_solve_analysis_follows_the_returned_tier():
+    """lib.rs:139-146 + :215-246: the analysis belongs to the tier whose outcome is returned."""
+    reqs = [O.fixed(0, 1.0, priority=0), O.fixed(1, 2.0, priority=1), O.fixed(1, 3.0, priority=1)]
+    out = O.solve(reqs, [(0, 0.0), (1, 0.0)], analysis=True)
+    assert out.priority_solved == 0 and out.underconstrained == [1]  # tier 1 is contradictory, tier 0 leaves x1 free
+    out = O.solve(reqs[:2], [(0, 0.0), (1, 0.0)], analysis=True)
+    assert out.priority_solved == 1 and out.underconstrained == []
+    assert O.solve([], [(0, 0.5)], analysis=True).underconstrained == []  # A::no_constraints()
