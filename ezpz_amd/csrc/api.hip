@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -352,9 +353,56 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         v.o_bwd_items = put(P.bwd_items);
         v.o_var_of = (uint32_t)append(blob, P.var_of);
         blob.resize((blob.size() + 15) & ~size_t(15));
+        // Workgroup teams read the constraint table from L2 in every sweep: 32-byte records + side arrays.  The
+        // distinct jloc patterns (one per duplicate-id shape, normally a handful) are staged with the lists.
+        v.packed = 0;
+        v.o_pos = v.o_weights = v.o_patterns = 0;
+        std::vector<PackedCon> packed;
+        if (idx16 && s.mode != MODE_SUB) {
+            std::vector<std::array<uint8_t, 16>> patterns;
+            packed.resize(P.cons.size());
+            bool ok = true;
+            for (size_t i = 0; i < P.cons.size() && ok; ++i) {
+                const DevCon& d = P.cons[i];
+                std::array<uint8_t, 16> pat;
+                std::memcpy(pat.data(), d.jloc, 16);
+                size_t k = 0;
+                while (k < patterns.size() && patterns[k] != pat) ++k;
+                if (k == patterns.size()) patterns.push_back(pat);
+                if (k > 255) ok = false;
+                PackedCon& q = packed[i];
+                for (int e = 0; e < 8; ++e) q.ids[e] = (uint16_t)d.ids[e];
+                q.param = d.param;
+                q.row0 = (uint16_t)d.row0;
+                q.jbase = (uint16_t)d.jbase;
+                q.kind = d.kind;
+                q.tag = d.tag;
+                q.nrows = d.nrows;
+                q.pattern = (uint8_t)k;
+            }
+            if (ok) {
+                v.packed = 1;
+                v.o_patterns = (uint32_t)append(blob, patterns);
+                blob.resize((blob.size() + 15) & ~size_t(15));
+            }
+        }
         const size_t lists_bytes = blob.size();
         v.o_parts = (uint32_t)append(blob, P.parts);
-        v.o_cons = (uint32_t)append(blob, P.cons);
+        blob.resize((blob.size() + 15) & ~size_t(15));
+        if (v.packed) {
+            v.o_cons = (uint32_t)append(blob, packed);
+            std::vector<uint32_t> pos(P.cons.size());
+            std::vector<double> weights(P.cons.size());
+            for (size_t i = 0; i < P.cons.size(); ++i) {
+                pos[i] = P.cons[i].pos;
+                weights[i] = P.cons[i].weight;
+            }
+            v.o_pos = (uint32_t)append(blob, pos);
+            blob.resize((blob.size() + 15) & ~size_t(15));
+            v.o_weights = (uint32_t)append(blob, weights);
+        } else {
+            v.o_cons = (uint32_t)append(blob, P.cons);
+        }
         blob.resize((blob.size() + 15) & ~size_t(15));
         return lists_bytes;
     };
@@ -364,7 +412,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
         if (s.mode == MODE_SUB) {
             if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
-        } else if (lists_bytes + ws_bytes + 2048 <= kLdsBytesMax) {
+        } else if (v.packed && lists_bytes + ws_bytes + 2048 <= kLdsBytesMax) {
             stage_bytes = lists_bytes;
         }
     }

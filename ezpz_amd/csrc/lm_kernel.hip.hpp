@@ -41,6 +41,8 @@ struct ProgramView {
     uint32_t o_lpair_ptr, o_lpairs;
     uint32_t o_fwd_ptr, o_fwd_items;
     uint32_t o_bwd_ptr, o_bwd_items;
+    uint32_t o_pos, o_weights, o_patterns;  // side arrays of a packed constraint table
+    uint32_t packed;                        // constraint table holds 32-byte PackedCon records
     uint32_t blob_bytes;
     uint32_t stage_bytes;  // leading bytes of the blob to copy into LDS (index lists, or the whole blob); 0 = none
     uint32_t n_cons, n_vars, n_rows, zj, zlo, n_parts;
@@ -51,6 +53,10 @@ struct ProgramView {
 template <class IDX>
 struct Prog {
     const DevCon* cons;
+    const PackedCon* pcons;       // packed form (same offset) + its side arrays
+    const uint32_t* con_pos;
+    const double* con_weight;
+    const uint4* patterns;        // in the staged part of the blob
     const PartDesc* parts;
     const IDX *colj_ptr, *colj_items;
     const IDX *apair_ptr, *apairs;
@@ -67,6 +73,10 @@ __device__ __forceinline__ Prog<IDX> make_prog(const ProgramView& v, const unsig
                                                const unsigned char* tables) {
     Prog<IDX> p;
     p.cons = reinterpret_cast<const DevCon*>(tables + v.o_cons);
+    p.pcons = reinterpret_cast<const PackedCon*>(tables + v.o_cons);
+    p.con_pos = reinterpret_cast<const uint32_t*>(tables + v.o_pos);
+    p.con_weight = reinterpret_cast<const double*>(tables + v.o_weights);
+    p.patterns = reinterpret_cast<const uint4*>(lists + v.o_patterns);
     p.parts = reinterpret_cast<const PartDesc*>(tables + v.o_parts);
     auto u = [&](uint32_t o) { return reinterpret_cast<const IDX*>(lists + o); };
     p.colj_ptr = u(v.o_colj_ptr);
@@ -86,17 +96,43 @@ __device__ __forceinline__ Prog<IDX> make_prog(const ProgramView& v, const unsig
     return p;
 }
 
-// One wide, fully parallel load of a constraint record (6 x 16 B in flight) instead of field-by-field
+// One wide, fully parallel load of a constraint record (5 x 16 B in flight) instead of field-by-field
 // dependent loads: the sweeps are latency bound on exactly this.
 __device__ __forceinline__ DevCon load_con(const DevCon* p) {
     union {
         DevCon c;
-        uint4 q[6];
+        uint4 q[5];
     } u;
     const uint4* src = reinterpret_cast<const uint4*>(p);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) u.q[i] = src[i];
+    for (int i = 0; i < 5; ++i) u.q[i] = src[i];
     return u.c;
+}
+
+// Packed record -> the in-register DevCon the evaluators take.  jloc is left to the Jacobian sweep (pattern index is
+// parked in nslots); pos is fetched by the rare paths that need it.
+__device__ __forceinline__ DevCon load_packed(const PackedCon* p, const double* weights, uint32_t ci, bool unit_weights) {
+    const uint4* src = reinterpret_cast<const uint4*>(p + ci);
+    const uint4 q0 = src[0], q1 = src[1];
+    DevCon c;
+    c.ids[0] = q0.x & 0xFFFFu;
+    c.ids[1] = q0.x >> 16;
+    c.ids[2] = q0.y & 0xFFFFu;
+    c.ids[3] = q0.y >> 16;
+    c.ids[4] = q0.z & 0xFFFFu;
+    c.ids[5] = q0.z >> 16;
+    c.ids[6] = q0.w & 0xFFFFu;
+    c.ids[7] = q0.w >> 16;
+    c.param = __hiloint2double((int)q1.y, (int)q1.x);
+    c.row0 = q1.z & 0xFFFFu;
+    c.jbase = q1.z >> 16;
+    c.kind = (uint8_t)(q1.w & 0xFFu);
+    c.tag = (uint8_t)((q1.w >> 8) & 0xFFu);
+    c.nrows = (uint8_t)((q1.w >> 16) & 0xFFu);
+    c.nslots = (uint8_t)(q1.w >> 24);
+    c.weight = unit_weights ? 1.0 : weights[ci];
+    c.pos = ci;
+    return c;
 }
 
 struct SolveArgs {
@@ -257,19 +293,34 @@ struct Team {
 
 // Constraint record access: a wide by-value load when the table is in global memory, a plain reference when
 // it sits in LDS (sub-wavefront teams with a staged program), where field-by-field reads are cheap.
-template <bool WIDE>
+// How a sweep gets at constraint `ci`: 0 = in place (table in LDS, sub-wavefront teams), 1 = one wide load of the
+// 80-byte record, 2 = 32-byte packed record + side arrays.
+template <int FORM, class PROG>
 struct ConRef;
-template <>
-struct ConRef<true> {
-    DevCon c;
-    __device__ __forceinline__ explicit ConRef(const DevCon* p) : c(load_con(p)) {}
-    __device__ __forceinline__ const DevCon& get() const { return c; }
-};
-template <>
-struct ConRef<false> {
+template <class PROG>
+struct ConRef<0, PROG> {
     const DevCon* p;
-    __device__ __forceinline__ explicit ConRef(const DevCon* q) : p(q) {}
+    __device__ __forceinline__ ConRef(const PROG& P, uint32_t ci, bool) : p(P.cons + ci) {}
     __device__ __forceinline__ const DevCon& get() const { return *p; }
+    __device__ __forceinline__ uint32_t pos(const PROG&, uint32_t) const { return p->pos; }
+    __device__ __forceinline__ uint4 jloc(const PROG&) const { return *reinterpret_cast<const uint4*>(p->jloc); }
+};
+template <class PROG>
+struct ConRef<1, PROG> {
+    DevCon c;
+    __device__ __forceinline__ ConRef(const PROG& P, uint32_t ci, bool) : c(load_con(P.cons + ci)) {}
+    __device__ __forceinline__ const DevCon& get() const { return c; }
+    __device__ __forceinline__ uint32_t pos(const PROG&, uint32_t) const { return c.pos; }
+    __device__ __forceinline__ uint4 jloc(const PROG&) const { return *reinterpret_cast<const uint4*>(c.jloc); }
+};
+template <class PROG>
+struct ConRef<2, PROG> {
+    DevCon c;
+    __device__ __forceinline__ ConRef(const PROG& P, uint32_t ci, bool unit_weights)
+        : c(load_packed(P.pcons, P.con_weight, ci, unit_weights)) {}
+    __device__ __forceinline__ const DevCon& get() const { return c; }
+    __device__ __forceinline__ uint32_t pos(const PROG& P, uint32_t ci) const { return P.con_pos[ci]; }
+    __device__ __forceinline__ uint4 jloc(const PROG& P) const { return P.patterns[c.nslots]; }
 };
 
 template <int TEAM, int MODE, bool LDSWS, bool PLDS>
@@ -312,6 +363,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
         if constexpr (MODE == MODE_SUB) tbase = lbase;
     }
     const Prog<idx_t> P = make_prog<idx_t>(a.p, lbase, tbase);
+    // constraint records: in place from LDS (sub-wavefront teams with a staged program), 32-byte packed records from
+    // L2 (workgroup teams with staged lists; the host packs the table exactly when PLDS holds), else the wide record
+    constexpr int CON_FORM = PLDS ? (MODE == MODE_SUB ? 0 : 2) : 1;
+    using CRef = ConRef<CON_FORM, Prog<idx_t>>;
+    const bool unit_w = a.unit_weights != 0;
 
     // ---- workspace carve-up (doubles) ----------------------------------------------------------------------------
     double* ws;
@@ -501,12 +557,13 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                 // every weight is 1 and r was evaluated at this x: r already holds the unweighted residuals, so the
                 // unsatisfied check reads it instead of re-evaluating every constraint
                 for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                    const DevCon& c = P.cons[ci];
+                    const CRef cref(P, ci, true);
+                    const DevCon& c = cref.get();
                     const uint32_t row0 = c.row0;
                     bool sat = fabs(ws[o_r + row0]) < EPS;
                     if (c.nrows > 1) sat = sat && (fabs(ws[o_r + row0 + 1]) < EPS);
                     if (!sat) unsat_cnt += 1.0;
-                    if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + c.pos] = sat ? 0 : 1;
+                    if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + cref.pos(P, ci)] = sat ? 0 : 1;
                 }
                 break;
             }
@@ -515,14 +572,15 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
             const uint32_t o_dst = (mode == EVAL0) ? o_r : o_rn;
             double sq = 0.0;
             double mx = __builtin_nan("");
-            auto residual_of = [&](const DevCon& c) {
+            auto residual_of = [&](const CRef& cref, uint32_t ci) {
+                const DevCon& c = cref.get();
                 double r0, r1;
                 const bool deg = con_residual(c, ws + o_x, r0, r1);
                 if (mode == FINAL) {  // unsatisfied check on the unweighted residuals (lib.rs:305-327, :358-370)
                     bool sat = fabs(r0) < EPS;
                     if (c.nrows > 1) sat = sat && (fabs(r1) < EPS);
                     if (!sat) unsat_cnt += 1.0;
-                    if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + c.pos] = sat ? 0 : 1;
+                    if (a.unsat_mask) a.unsat_mask[sys * a.p.n_cons + cref.pos(P, ci)] = sat ? 0 : 1;
                     return;
                 }
                 const double wgt = c.weight;
@@ -540,12 +598,12 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                 if (deg) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
                     int idx = atomicAdd(nwarn, 1);
                     if (a.warn_log && (uint32_t)idx < a.warn_cap)
-                        a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
+                        a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
                 }
             };
             for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
-                residual_of(cref.get());
+                const CRef cref(P, ci, unit_w);
+                residual_of(cref, ci);
             }
             ++pass;
             tm.phase_sync();
@@ -562,26 +620,27 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                     lambda *= LM_LAMBDA_DECR;
                 }
                 // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121; solver.rs:359-440) ------------------
-                auto jacobian_of = [&](const DevCon& c) {
+                auto jacobian_of = [&](const CRef& cref, uint32_t ci) {
+                    const DevCon& c = cref.get();
                     JacWriter<double*> w;
                     w.jv = ws + o_j;
                     w.jbase = c.jbase;
-                    const uint32_t* loc = reinterpret_cast<const uint32_t*>(c.jloc);
-                    w.loc[0] = loc[0];
-                    w.loc[1] = loc[1];
-                    w.loc[2] = loc[2];
-                    w.loc[3] = loc[3];
+                    const uint4 loc = cref.jloc(P);
+                    w.loc[0] = loc.x;
+                    w.loc[1] = loc.y;
+                    w.loc[2] = loc.z;
+                    w.loc[3] = loc.w;
                     w.weight = c.weight;
                     const bool deg = con_jacobian(c, ws + o_x, w);
                     if (deg) {
                         int idx = atomicAdd(nwarn, 1);
                         if (a.warn_log && (uint32_t)idx < a.warn_cap)
-                            a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
+                            a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
                     }
                 };
                 for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                    const ConRef<!(PLDS && MODE == MODE_SUB)> cref(P.cons + ci);
-                    jacobian_of(cref.get());
+                    const CRef cref(P, ci, unit_w);
+                    jacobian_of(cref, ci);
                 }
                 ++pass;
                 residual_sq = sq;
@@ -652,7 +711,13 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs e) {
         double* r = e.r_out + sys * e.p.n_rows;
         double* jv = e.jv_out + sys * e.p.zj;
         for (uint32_t ci = threadIdx.x; ci < e.p.n_cons; ci += blockDim.x) {
-            const DevCon& c = P.cons[ci];
+            DevCon c;
+            if (e.p.packed) {
+                c = load_packed(P.pcons, P.con_weight, ci, false);
+                *reinterpret_cast<uint4*>(c.jloc) = P.patterns[c.nslots];
+            } else {
+                c = load_con(P.cons + ci);
+            }
             double r0, r1;
             if (con_residual(c, xs, r0, r1)) atomicAdd(&nwarn, 1);
             if (e.r_out) {

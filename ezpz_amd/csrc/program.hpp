@@ -18,7 +18,7 @@
 
 namespace ezpz {
 
-// One constraint as the kernel sees it.  96 bytes.
+// One constraint as the kernel sees it.  80 bytes.
 struct alignas(16) DevCon {
     uint32_t ids[8];
     double param;
@@ -28,9 +28,21 @@ struct alignas(16) DevCon {
     uint32_t pos;    // position in the caller's constraint list (for unsat mask / warnings)
     uint8_t kind, tag, nrows, nslots;
     uint8_t jloc[16];  // per emitted partial: slot offset from jbase; bit 7 = accumulate into an earlier entry's slot
-    uint8_t pad[16];
 };
-static_assert(sizeof(DevCon) == 96, "DevCon layout");
+static_assert(sizeof(DevCon) == 80, "DevCon layout");
+
+// The same constraint in 32 bytes, for programs whose every count fits 16 bits and whose constraint table is read
+// from global memory / L2 by workgroup teams: the table is re-read by every residual and Jacobian sweep of every
+// system, and its bytes (not HBM's) are what the massive_parallel_system launch is bound by.  weight, pos and the
+// jloc pattern live in side arrays (weights are read only when some weight != 1, pos only when a mask or a warning
+// is written, the handful of distinct jloc patterns sit in LDS).
+struct alignas(16) PackedCon {
+    uint16_t ids[8];
+    double param;
+    uint16_t row0, jbase;
+    uint8_t kind, tag, nrows, pattern;
+};
+static_assert(sizeof(PackedCon) == 32, "PackedCon layout");
 
 // A partition of the system: a union of connected components that one wavefront can own end to end
 // (its constraints, variables, Jacobian slots and Cholesky columns are disjoint from every other partition's).
