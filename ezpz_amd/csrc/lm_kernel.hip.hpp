@@ -156,15 +156,23 @@ struct SolveArgs {
 #ifdef EZPZ_STAMPS
 #define EZPZ_STAMP(id)                                                                     \
     do {                                                                                   \
-        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 120) {            \
+        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 250) {            \
             a.stamps[2 * stamp_n] = (id);                                                  \
             a.stamps[2 * stamp_n + 1] = __builtin_readcyclecounter();                      \
             ++stamp_n;                                                                     \
         }                                                                                  \
     } while (0)
+#define EZPZ_STAMP_DRAIN(id)                 \
+    do {                                     \
+        __builtin_amdgcn_s_waitcnt(0);       \
+        EZPZ_STAMP(id);                      \
+    } while (0)
 #else
 #define EZPZ_STAMP(id) \
     do {               \
+    } while (0)
+#define EZPZ_STAMP_DRAIN(id) \
+    do {                     \
     } while (0)
 #endif
 
@@ -182,20 +190,22 @@ __device__ __forceinline__ void load_pair(const uint32_t* items, uint32_t q, uin
     b = w.y;
 }
 
-// Walks the pair list [q0, q1) four entries at a time: the four index loads are independent, then the eight
-// value loads are independent, and only then are the terms folded in list order (`fold(k)` for valid k).  The
-// kernel is bound by the latency of dependent LDS hops, and this turns 1 + 2L hops per list into 3 per chunk
-// while keeping every floating-point sum in exactly the same order.
+// Walks the pair list [q0, q1) LIST_CHUNK entries at a time (a constexpr in scope at the use site): the index
+// loads of a chunk are independent, then its value loads are independent, and only then are the terms folded in list
+// order (`fold(k)` for valid k).  This turns 1 + 2L dependent LDS hops per list into 3 per chunk while keeping every
+// floating-point sum in exactly the same order.  Invalid tail entries still cost their instructions, so the chunk
+// follows the typical list length: 4 for the dense little systems of sub-wavefront teams, 2 for the sparse
+// systems of workgroup teams (1-2 entries per list in massive_parallel_system).
 #define EZPZ_FOR_PAIRS4(items, q0, q1, A, B, LOADVALS, FOLD)                       \
-    for (uint32_t q_ = (q0); q_ < (q1); q_ += 4) {                                 \
-        uint32_t A[4], B[4];                                                       \
-        bool ok_[4];                                                               \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                            \
+    for (uint32_t q_ = (q0); q_ < (q1); q_ += LIST_CHUNK) {                        \
+        uint32_t A[LIST_CHUNK], B[LIST_CHUNK];                                     \
+        bool ok_[LIST_CHUNK];                                                      \
+        _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) {                   \
             ok_[k] = q_ + k < (q1);                                                \
             load_pair((items), ok_[k] ? q_ + k : q_, A[k], B[k]);                  \
         }                                                                          \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) { LOADVALS; }                \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                            \
+        _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) { LOADVALS; }       \
+        _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) {                   \
             if (ok_[k]) { FOLD; }                                                  \
         }                                                                          \
     }
@@ -365,6 +375,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
     const Prog<idx_t> P = make_prog<idx_t>(a.p, lbase, tbase);
     // constraint records: in place from LDS (sub-wavefront teams with a staged program), 32-byte packed records from
     // L2 (workgroup teams with staged lists; the host packs the table exactly when PLDS holds), else the wide record
+    constexpr int LIST_CHUNK = (MODE == MODE_SUB) ? 4 : 2;
     constexpr int CON_FORM = PLDS ? (MODE == MODE_SUB ? 0 : 2) : 1;
     using CRef = ConRef<CON_FORM, Prog<idx_t>>;
     const bool unit_w = a.unit_weights != 0;
@@ -602,8 +613,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                 }
             };
             for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                EZPZ_STAMP_DRAIN(40);
                 const CRef cref(P, ci, unit_w);
+                EZPZ_STAMP_DRAIN(41);
                 residual_of(cref, ci);
+                EZPZ_STAMP_DRAIN(42);
             }
             ++pass;
             tm.phase_sync();

@@ -12,7 +12,7 @@ s = E.System(cs.constraints, n)
 dev = torch.device('cuda', 0)
 x0 = torch.from_numpy(cs.guesses[None, :] + gen.keyed_uniform(1, B, n, -0.25, 0.25)).to(dev)
 xo = torch.empty_like(x0); st = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
-buf = torch.zeros(256, dtype=torch.int64, device=dev)
+buf = torch.zeros(512, dtype=torch.int64, device=dev)
 L = E.lib(); L.ezpz_debug_set_stamps.argtypes = [C.c_void_p]; L.ezpz_debug_set_stamps(buf.data_ptr())
 stream = torch.cuda.current_stream(dev).cuda_stream
 for _ in range(3):
@@ -20,7 +20,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 b = buf.cpu().numpy().reshape(-1, 2)
 names = {1: "start", 2: "x loaded", 10: "normal eq", 11: "chol+fwd", 12: "bwd", 13: "reduce(bad,dmax)", 14: "x+=d", 20: "R sweep",
-         21: "reduce(sq,max)", 22: "J sweep / revert", 30: "unsat loop", 31: "reduce(unsat)", 32: "x stored"}
+         21: "reduce(sq,max)", 22: "J sweep / revert", 40: "  r: loop top", 41: "  r: record loaded", 42: "  r: residual done", 30: "unsat loop", 31: "reduce(unsat)", 32: "x stored"}
 prev = None
 for i, t in b:
     if i == 0: break
