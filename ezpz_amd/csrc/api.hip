@@ -100,6 +100,7 @@ struct EzpzSystem {
     bool lds_ws = true;
     bool prog_in_lds = false;
     bool unit_weights = true;
+    bool linear_only = false;  // every constraint is of a linear kind: the evaluators are built without the others
     uint32_t prog_lds_doubles = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
@@ -176,9 +177,9 @@ bool sub_team_fits(const ProgramCounts& c, uint32_t team) {
     return team <= 64 && (size_t)workspace_doubles(c) * 8 * (64 / team) <= 60 * 1024;
 }
 
-template <int TEAM, int MODE, bool LDSWS, bool PLDS>
-int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
-    auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS>;
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN>
+int launch_kernel(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+    auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN>;
     if (s.lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)s.lds_bytes));
@@ -186,6 +187,15 @@ int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hi
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(s.block_threads), s.lds_bytes, stream, args);
     HIP_TRY(hipGetLastError());
     return EZPZ_OK;
+}
+
+// Workgroup teams come in two builds: all 25 kinds, or the nine linear kinds only (`linear_only` topologies).
+template <int TEAM, int MODE, bool LDSWS, bool PLDS>
+int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+    if constexpr (MODE != MODE_SUB) {
+        if (s.linear_only) return launch_kernel<TEAM, MODE, LDSWS, PLDS, true>(s, args, grid, stream);
+    }
+    return launch_kernel<TEAM, MODE, LDSWS, PLDS, false>(s, args, grid, stream);
 }
 
 template <int TEAM>
@@ -319,8 +329,11 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     }
     s.counts = P.c;
     s.unit_weights = true;
-    for (const DevCon& d : P.cons)
+    s.linear_only = true;
+    for (const DevCon& d : P.cons) {
         if (d.weight != 1.0) s.unit_weights = false;
+        if (!kind_is_linear(d.kind)) s.linear_only = false;
+    }
     s.host_var_of = P.var_of;
     s.host_row_of = P.row_of;
     s.host_slot_row = P.slot_row;

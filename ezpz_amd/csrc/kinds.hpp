@@ -50,4 +50,22 @@ static constexpr KindInfo kKinds[25] = {
 };
 // clang-format on
 
+// The nine kinds whose residual is linear in the variables (constant Jacobian, no guard, no libm call).
+inline bool kind_is_linear(uint32_t kind) {
+    switch (kind) {
+    case EZPZ_FIXED:
+    case EZPZ_SCALAR_EQUAL:
+    case EZPZ_VERTICAL:
+    case EZPZ_HORIZONTAL:
+    case EZPZ_VERTICAL_DISTANCE:
+    case EZPZ_HORIZONTAL_DISTANCE:
+    case EZPZ_CIRCLE_RADIUS:
+    case EZPZ_POINTS_COINCIDENT:
+    case EZPZ_MIDPOINT:
+        return true;
+    default:
+        return false;
+    }
+}
+
 }  // namespace ezpz

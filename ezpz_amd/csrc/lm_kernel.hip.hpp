@@ -333,7 +333,9 @@ struct ConRef<2, PROG> {
     __device__ __forceinline__ uint4 jloc(const PROG& P) const { return P.patterns[c.nslots]; }
 };
 
-template <int TEAM, int MODE, bool LDSWS, bool PLDS>
+// LIN: every constraint of the topology is of a linear kind (see con_residual); the evaluators are built without
+// the other sixteen kinds.
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN>
 __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB ? 4 : 1)
     lm_solve_kernel(const SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -586,7 +588,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
             auto residual_of = [&](const CRef& cref, uint32_t ci) {
                 const DevCon& c = cref.get();
                 double r0, r1;
-                const bool deg = con_residual(c, ws + o_x, r0, r1);
+                const bool deg = con_residual<LIN>(c, ws + o_x, r0, r1);
                 if (mode == FINAL) {  // unsatisfied check on the unweighted residuals (lib.rs:305-327, :358-370)
                     bool sat = fabs(r0) < EPS;
                     if (c.nrows > 1) sat = sat && (fabs(r1) < EPS);
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB
                     w.loc[2] = loc.z;
                     w.loc[3] = loc.w;
                     w.weight = c.weight;
-                    const bool deg = con_jacobian(c, ws + o_x, w);
+                    const bool deg = con_jacobian<LIN>(c, ws + o_x, w);
                     if (deg) {
                         int idx = atomicAdd(nwarn, 1);
                         if (a.warn_log && (uint32_t)idx < a.warn_cap)
