@@ -189,12 +189,10 @@ int launch_kernel(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hip
     return EZPZ_OK;
 }
 
-// Workgroup teams come in two builds: all 25 kinds, or the nine linear kinds only (`linear_only` topologies).
+// Every team shape comes in two builds: all 25 kinds, or the nine linear kinds only (`linear_only` topologies).
 template <int TEAM, int MODE, bool LDSWS, bool PLDS>
 int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
-    if constexpr (MODE != MODE_SUB) {
-        if (s.linear_only) return launch_kernel<TEAM, MODE, LDSWS, PLDS, true>(s, args, grid, stream);
-    }
+    if (s.linear_only) return launch_kernel<TEAM, MODE, LDSWS, PLDS, true>(s, args, grid, stream);
     return launch_kernel<TEAM, MODE, LDSWS, PLDS, false>(s, args, grid, stream);
 }
 
@@ -321,7 +319,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
     }
     if (!want_sub) {
-        uint32_t team = team_size ? std::min<uint32_t>(512, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
+        uint32_t team = team_size ? std::min<uint32_t>(1024, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
                                   : auto_wg_team(width);
         if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
         s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;

@@ -336,7 +336,7 @@ struct ConRef<2, PROG> {
 // LIN: every constraint of the topology is of a linear kind (see con_residual); the evaluators are built without
 // the other sixteen kinds.
 template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN>
-__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : 512, MODE == MODE_SUB ? 4 : 1)
+__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), MODE == MODE_SUB ? 4 : 1)
     lm_solve_kernel(const SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using namespace dev;
