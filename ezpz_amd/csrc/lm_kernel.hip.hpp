@@ -654,9 +654,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                             a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
                     }
                 };
-                for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                    const CRef cref(P, ci, unit_w);
-                    jacobian_of(cref, ci);
+                // The nine linear kinds have constant partials (weight x +-1 or +-0.5) and no degenerate guard: after
+                // eval() the refresh of an accepted step (newton.rs:121) would store the same bits again, so the
+                // linear-only build sweeps the Jacobian once per solve.
+                if (!LIN || mode == EVAL0) {
+                    for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                        const CRef cref(P, ci, unit_w);
+                        jacobian_of(cref, ci);
+                    }
                 }
                 ++pass;
                 residual_sq = sq;
