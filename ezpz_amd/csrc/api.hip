@@ -319,7 +319,11 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
     }
     if (!want_sub) {
-        uint32_t team = team_size ? std::min<uint32_t>(1024, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
+        // the general build is compiled for <= 512 lanes (145 VGPRs), the linear-only build for <= 1024 (59 VGPRs)
+        bool lin = true;
+        for (size_t i = 0; i < n_cs; ++i) lin = lin && kind_is_linear(cs[i].kind);
+        const uint32_t max_team = lin ? 1024 : 512;
+        uint32_t team = team_size ? std::min<uint32_t>(max_team, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
                                   : auto_wg_team(width);
         if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
         s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;

@@ -219,7 +219,7 @@ def test_single_large_component_uses_barrier_workgroup(E, team):
     assert_x_close(x, xo)
 
 
-@pytest.mark.parametrize("team", [128, 512])
+@pytest.mark.parametrize("team", [128, 512, 1024])
 def test_partitioned_workgroup_matches_barrier_workgroup(E, team):
     """two_rectangles has two components: the wavefront-partitioned mode must agree with every other mode."""
     text = read_case("two_rectangles")
@@ -227,6 +227,31 @@ def test_partitioned_workgroup_matches_barrier_workgroup(E, team):
     x0 = ref.guesses[None, :] + gen.keyed_uniform(9, 64, ref.num_vars, -0.2, 0.2)
     sysobj, x, st = _batch_vs_oracle(E, text, x0, team_size=team)
     assert sysobj.info()["team_mode"] in (1, 2)
+
+
+def test_linear_only_build_matches_the_general_build(E):
+    """Topologies made of the nine linear kinds run a kernel built without the other evaluators (and sweep the
+    constant Jacobian once); adding one satisfied non-linear constraint on fresh variables switches the same system to
+    the general build.  Both must give the oracle's answer, bit for bit on the shared variables."""
+    ref = T.load(T.gen_big_problem(40))
+    n = ref.num_vars
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(77, 9, n, -0.25, 0.25)
+    lin = E.System(ref.constraints, n, team_size=256)
+    xa, sta, _ = lin.solve_batch(x0)
+    extra = O.stack(list(ref.constraints) + [O.distance((n, n + 1), (n + 2, n + 3), 5.0)])
+    x0b = np.concatenate([x0, np.tile([0.0, 0.0, 3.0, 4.0], (len(x0), 1))], axis=1)
+    gen_sys = E.System(extra, n + 4, team_size=256)
+    xb, stb, _ = gen_sys.solve_batch(x0b)
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert np.array_equal(sta["iterations"], it) and np.array_equal(stb["iterations"], it)
+    assert np.array_equal(xa, xo) and np.array_equal(xb[:, :n], xo)
+    # weights other than 1 scale the constant Jacobian: still one sweep, still exact
+    recs = O.stack(ref.constraints).copy()
+    recs["weight"][::3] = 2.5
+    xw, stw, _ = E.System(recs, n, team_size=256).solve_batch(x0)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert np.array_equal(stw["iterations"], it) and np.array_equal(stw["converged"], conv)
+    assert_x_close(xw, xo)
 
 
 def test_committed_massive_fixture_and_overconstrained_variant(E):
