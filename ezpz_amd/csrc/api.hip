@@ -147,7 +147,26 @@ uint32_t workspace_doubles(const ProgramCounts& c) {
 }
 
 // Sub-wavefront team for small systems: lanes per system.
-uint32_t auto_sub_team(uint32_t width) { return std::min<uint32_t>(64, std::max<uint32_t>(8, pow2_ceil((width + 1) / 2))); }
+// Lanes per system for sub-wavefront teams.  Every system of a batch runs the same program, so with few lanes per
+// system the constraints a wavefront evaluates in one round are of few kinds (less divergence) while each lane's
+// serial share of a phase grows.  Measured on 65 536-system batches, solves/s by lanes per system 1/2/4/8/16:
+//   arc_radius     (cost  5) 1.16/1.58/1.41/0.85/-    G      circle_tangent (cost  9) 0.85/1.00/0.91/0.57/0.32 G
+//   parallelogram  (cost 15) 182/224/278/237/-        M      square         (cost 20) 86/112/140/123/71        M
+//   two_rectangles (cost 24) -/432/545/584/363        M
+// with cost = sum over constraints of 1 (linear kinds), 3 (hypot kinds) or 4 (angle / arc kinds): the best team is
+// the power of two nearest to cost / 4, never below 2.
+uint32_t auto_sub_team(const EzpzConstraint* cs, size_t n_cs) {
+    uint32_t cost = 0;
+    for (size_t i = 0; i < n_cs; ++i) {
+        const uint32_t k = cs[i].kind;
+        const bool angle = k == EZPZ_LINES_AT_ANGLE || k == EZPZ_ARC_ANGLE || k == EZPZ_POINTS_AT_ANGLE ||
+                           k == EZPZ_POINT_ARC_COINCIDENT || k == EZPZ_ARC_LENGTH;
+        cost += kind_is_linear(k) ? 1u : angle ? 4u : 3u;
+    }
+    uint32_t team = 2;
+    while (team < 64 && (double)cost / 4.0 > 1.41421356 * team) team <<= 1;  // nearest power of two on a log scale
+    return team;
+}
 // Workgroup size for large systems.
 uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(512, std::max<uint32_t>(128, pow2_ceil((width + 3) / 4))); }
 
@@ -210,6 +229,8 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         uint64_t blocks = (args.batch + tpb - 1) / tpb;
         grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)kNumCUs * 32);
         switch (s.team_size) {
+        case 1: return launch_sub<1>(s, args, grid, stream);
+        case 2: return launch_sub<2>(s, args, grid, stream);
         case 4: return launch_sub<4>(s, args, grid, stream);
         case 8: return launch_sub<8>(s, args, grid, stream);
         case 16: return launch_sub<16>(s, args, grid, stream);
@@ -309,7 +330,12 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     bool want_sub = team_size ? team_size <= 64 : width <= 64;
     if (want_sub) {
         if (!build_program(cs, n_cs, n_vars, P, be, 1)) return fail();
-        uint32_t team = team_size ? std::max<uint32_t>(4, pow2_ceil(team_size)) : auto_sub_team(width);
+        uint32_t team = team_size ? pow2_ceil(team_size) : auto_sub_team(cs, n_cs);
+        // 64 / team workspaces share a wavefront: keep a wavefront's share of the LDS <= 32 KiB when choosing
+        // automatically (>= 4 wavefronts per CU), and inside the hard limit in any case
+        if (!team_size)
+            while (team < 64 && (size_t)workspace_doubles(P.c) * 8 * (64 / team) > 32 * 1024) team <<= 1;
+        while (team < 64 && !sub_team_fits(P.c, team)) team <<= 1;
         if (sub_team_fits(P.c, team)) {
             s.mode = MODE_SUB;
             s.team_size = team;

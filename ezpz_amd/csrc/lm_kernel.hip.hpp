@@ -301,6 +301,23 @@ struct Team {
 
 }  // namespace dev
 
+// The per-system workspace as the phases index it.  Workgroup teams own one contiguous block of doubles (STRIDE 1).
+// Sub-wavefront teams share a wavefront (64 / TEAM systems side by side) and interleave their workspaces element by
+// element: element e of the wavefront's system t lives at word e * STRIDE + t, STRIDE = 64 / TEAM.  Lanes of
+// different systems that walk the same list entry -- the common case, every system runs the same program -- then
+// touch consecutive words instead of words a whole workspace apart (which collide on a few banks), and with one
+// lane per system (TEAM 1) every access of the wavefront is one conflict-free 512-byte row.
+template <int STRIDE>
+struct WsRef {
+    double* p;
+    __device__ __forceinline__ double& operator[](uint32_t e) const { return p[(size_t)e * STRIDE]; }
+    __device__ __forceinline__ WsRef operator+(uint32_t off) const {
+        WsRef r;
+        r.p = p + (size_t)off * STRIDE;
+        return r;
+    }
+};
+
 // Constraint record access: a wide by-value load when the table is in global memory, a plain reference when
 // it sits in LDS (sub-wavefront teams with a staged program), where field-by-field reads are cheap.
 // How a sweep gets at constraint `ci`: 0 = in place (table in LDS, sub-wavefront teams), 1 = one wide load of the
@@ -383,12 +400,17 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     const bool unit_w = a.unit_weights != 0;
 
     // ---- workspace carve-up (doubles) ----------------------------------------------------------------------------
-    double* ws;
-    if constexpr (LDSWS) {
-        ws = smem + a.prog_lds_doubles + (size_t)team_in_block * a.ws_doubles;
-        tm.red = smem + a.prog_lds_doubles + (size_t)teams_per_block * a.ws_doubles;
+    constexpr int WS_STRIDE = (MODE == MODE_SUB) ? 64 / TEAM : 1;  // systems side by side in a wavefront
+    static_assert(WS_STRIDE == 1 || LDSWS, "interleaved workspaces live in LDS");
+    WsRef<WS_STRIDE> ws;
+    if constexpr (MODE == MODE_SUB) {
+        ws.p = smem + a.prog_lds_doubles + (size_t)(tid >> 6) * WS_STRIDE * a.ws_doubles + (tid & 63) / TEAM;
+        tm.red = nullptr;
+    } else if constexpr (LDSWS) {
+        ws.p = smem + a.prog_lds_doubles;
+        tm.red = smem + a.prog_lds_doubles + a.ws_doubles;
     } else {
-        ws = a.gws + (size_t)blockIdx.x * a.ws_doubles;
+        ws.p = a.gws + (size_t)blockIdx.x * a.ws_doubles;
         tm.red = smem;
     }
     const uint32_t o_x = 0;
@@ -401,7 +423,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     const uint32_t o_i = o_v + n;    // small int area
     int* nwarn;
     if constexpr (LDSWS) {
-        nwarn = reinterpret_cast<int*>(ws + o_i);
+        nwarn = reinterpret_cast<int*>(&ws[o_i]);
     } else {
         nwarn = reinterpret_cast<int*>(smem + 64);  // LDS even when the bulk state is in global memory
     }
@@ -638,7 +660,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121; solver.rs:359-440) ------------------
                 auto jacobian_of = [&](const CRef& cref, uint32_t ci) {
                     const DevCon& c = cref.get();
-                    JacWriter<double*> w;
+                    JacWriter<WsRef<WS_STRIDE>> w;
                     w.jv = ws + o_j;
                     w.jbase = c.jbase;
                     const uint4 loc = cref.jloc(P);
