@@ -150,7 +150,7 @@ def test_square_full_size_batch_properties(E):
     assert_x_close(x[sample], xo)
 
 
-@pytest.mark.parametrize("team", [4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("team", [1, 2, 4, 8, 16, 32, 64, 128, 256])
 def test_team_shapes_agree(E, team):
     """Every team shape runs the same program; results must not depend on it beyond rounding of reductions."""
     text = read_case("two_rectangles")
