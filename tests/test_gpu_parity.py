@@ -159,7 +159,7 @@ def test_team_shapes_agree(E, team):
     sysobj, x, st = _batch_vs_oracle(E, text, x0, team_size=team)
     assert sysobj.info()["team_size"] == max(team, 2)  # 64 workspaces of this system do not fit a wavefront's LDS share
     if team == 1:  # one lane per system on a system that does fit
-        text = read_case("circle_tangent")
+        text = read_case("arc_radius")
         ref = T.load(text)
         x0 = ref.guesses[None, :] + gen.keyed_uniform(8, 300, ref.num_vars, -0.1, 0.1)
         sysobj, x, st = _batch_vs_oracle(E, text, x0, team_size=1)
