@@ -447,7 +447,13 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
 #endif
         EZPZ_STAMP(1);
         const double* x0 = a.x0 + sys * n;
-        for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[P.var_of[i]];
+        if constexpr (MODE == MODE_PART) {
+            // each wavefront loads (and later stores) its own partition's variables only: a wavefront that is already
+            // on the next system never touches values another one has not stored yet
+            for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) ws[o_x + ci] = x0[P.var_of[ci]];
+        } else {
+            for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[P.var_of[i]];
+        }
         if (tlane == 0) *nwarn = 0;
         tm.team_sync();
         EZPZ_STAMP(2);
@@ -466,6 +472,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         double largest = 0.0;  // max |r| of the current residual vector
         double unsat_cnt = 0.0;
         bool r_is_at_x = true;  // the current r was evaluated at exactly the current x (false after a rejected step)
+        bool all_satisfied = false;  // FINAL proved it from max |r| alone: no per-constraint count to reduce
         double lambda = a.initial_lambda;
         double step_inf_norm = 0.0;
         uint32_t iterations = a.max_iterations;
@@ -590,7 +597,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
 
             if (mode == FINAL && r_is_at_x && a.unit_weights) {
                 // every weight is 1 and r was evaluated at this x: r already holds the unweighted residuals, so the
-                // unsatisfied check reads it instead of re-evaluating every constraint
+                // unsatisfied check reads it instead of re-evaluating every constraint -- and when even the largest
+                // |r| is below EPSILON (every converged solve) no constraint can be unsatisfied (lib.rs:358-370)
+                if (largest < EPS) {
+                    all_satisfied = true;
+                    if (a.unsat_mask)
+                        for (uint32_t i = tlane; i < a.p.n_cons; i += tsize) a.unsat_mask[sys * a.p.n_cons + i] = 0;
+                    break;
+                }
                 for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
                     const CRef cref(P, ci, true);
                     const DevCon& c = cref.get();
@@ -714,10 +728,18 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         // ---- write-back -----------------------------------------------------------------------------------------------
         double dummy = 0.0;
         EZPZ_STAMP(30);
-        tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());  // also the rendezvous before the cooperative store of x
+        // the count of unsatisfied constraints; for workgroup teams also the rendezvous before the cooperative store
+        // of x.  Wavefront-partitioned teams store their own partition's values and need neither when the count is
+        // known to be zero (`all_satisfied` is uniform: it derives from the reduced max |r|).
+        constexpr bool OWN_STORE = (MODE == MODE_PART);
+        if (!(all_satisfied && (OWN_STORE || MODE == MODE_SUB))) tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());
         EZPZ_STAMP(31);
         double* xo = a.x_out + sys * n;
-        for (uint32_t i = tlane; i < n; i += tsize) xo[P.var_of[i]] = ws[o_x + i];
+        if constexpr (OWN_STORE) {
+            for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) xo[P.var_of[ci]] = ws[o_x + ci];
+        } else {
+            for (uint32_t i = tlane; i < n; i += tsize) xo[P.var_of[i]] = ws[o_x + i];
+        }
         if (tlane == 0) {
             EzpzStatus st;
             st.iterations = iterations;
@@ -728,7 +750,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
             st.final_lambda = lambda;
             a.status[sys] = st;
         }
-        tm.team_sync();  // the workspace is reused by the next system of this team
+        // the workspace is reused by the next system of this team; wavefront-partitioned teams touch only their own
+        // partition's part of it until the rendezvous that follows the next load
+        if constexpr (MODE != MODE_PART) tm.team_sync();
         EZPZ_STAMP(32);
     }
 }
