@@ -260,6 +260,20 @@ def test_linear_only_build_matches_the_general_build(E):
     assert_x_close(xw, xo)
 
 
+@pytest.mark.parametrize("team", [0, 64, 256])
+def test_variables_without_constraints_pass_through(E, team):
+    """Guesses for variables no constraint mentions come back unchanged (the reference never touches them), in
+    every team shape -- partitioned teams load and store per partition, so every variable must belong to one."""
+    ref = T.load(T.gen_big_problem(100))
+    n = ref.num_vars
+    sysobj = E.System(ref.constraints, n + 7, team_size=team)
+    x0 = np.concatenate([np.tile(ref.guesses, (5, 1)), np.arange(35.0).reshape(5, 7) + 100.0], axis=1)
+    x, st, _ = sysobj.solve_batch(x0)
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert np.array_equal(x, xo) and np.array_equal(x[:, n:], x0[:, n:])
+    assert np.array_equal(st["iterations"], it)
+
+
 def test_committed_massive_fixture_and_overconstrained_variant(E):
     for text in (read_case("massive_parallel_system"), T.gen_big_problem(200, True)):
         ref = T.load(text)
