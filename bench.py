@@ -106,11 +106,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hook (1-GPU boxes): EZPZ_BENCH_BACKEND=gloo runs the N>1 code path -- rendezvous, barriers, max-over-ranks
+    # timing, rank-0 line -- with every rank on GPU (LOCAL_RANK mod device count).  The driver never sets it.
+    backend = os.environ.get("EZPZ_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     # BASELINE configs[4] flavour: system i uses [circle_tangent, parallelogram, arc_radius][i mod 3]; the batch is
     # grouped by topology (one launch per topology per step).  Everything else is a single-topology batch.
@@ -121,7 +128,7 @@ def main():
         desc_k, records_k, guesses_k, jitter_k, expect_k = make_workload(name)
         n_k = len(guesses_k)
         B_k = args.batch // len(names) + (1 if k < args.batch % len(names) else 0)
-        system_k = E.System(records_k, n_k, device=local_rank, team_size=args.team)
+        system_k = E.System(records_k, n_k, device=device_index, team_size=args.team)
         # synthetic inputs: replicas of the system with keyed-PRNG jitter on the guesses, resident in HBM
         x0_host_k = guesses_k[None, :] + gen.keyed_uniform(0x657A707A + rank + 101 * k, B_k, n_k, -jitter_k, jitter_k)
         x0_host_k[0] = guesses_k
@@ -161,7 +168,7 @@ def main():
     elapsed = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # one kernel per step, back to back on this stream
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -217,7 +224,7 @@ def main():
             extras["freedom_analyses_per_s"] = 5 * Bf / (time.perf_counter() - tf)
             extras["underconstrained_systems"] = int((fa_cnt > 0).sum().item())
         # (3) N>1: whole batch starts and ends on rank 0; one RCCL scatter + one gather around the solve
-        if world > 1:
+        if world > 1 and backend == "nccl":
             from ezpz_amd.distributed import solve_batch_sharded
 
             full = torch.cat([x0] * world, dim=0) if rank == 0 else None
