@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libezpz_amd.so")
-SOURCES = ["api.hip", "program.cpp", "textual.cpp"]
+SOURCES = ["api.hip", "solve.cpp", "program.cpp", "textual.cpp"]
 HEADERS = ["program.hpp", "kinds.hpp", "constraint_eval.hip.hpp", "lm_kernel.hip.hpp", "freedom.hip.hpp", "../../include/ezpz_amd.h"]
 # -ffp-contract=off: the reference (Rust) never fuses a*b+c; see constraint_eval.hip.hpp.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]
