@@ -50,6 +50,7 @@ EXPORTS = [
     "ezpz_problem_constraints", "ezpz_problem_guesses", "ezpz_problem_num_labels", "ezpz_problem_label",
     "ezpz_analyze", "ezpz_system_eval_batch", "ezpz_system_jacobian_pattern", "ezpz_cache_clear",
     "ezpz_solve_batch",
+    "ezpz_current_device",
     "ezpz_solve_analysis",
     "ezpz_system_freedom_batch",
     "ezpz_system_freedom_batch_device",
@@ -89,6 +90,8 @@ def lib():
     L.ezpz_system_freedom_batch.argtypes = [vp, vp, sz, vp, vp]
     L.ezpz_system_freedom_batch_device.restype = C.c_int
     L.ezpz_system_freedom_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    L.ezpz_current_device.restype = C.c_int
+    L.ezpz_current_device.argtypes = []
     L.ezpz_cache_clear.restype = None
     L.ezpz_cache_clear.argtypes = []
     L.ezpz_analyze.restype = C.c_int

@@ -295,6 +295,15 @@ int ezpz_device_count(void) {
     return n;
 }
 
+int ezpz_current_device(void) {
+    int dev = -1;
+    if (ezpz_device_count() < 1 || hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return dev;
+}
+
 const char* ezpz_error_string(int err) {
     switch (err) {
     case EZPZ_OK: return "ok";

@@ -29,38 +29,47 @@ struct CacheEntry {
     uint64_t hash;
     std::vector<unsigned char> key;
     size_t n_vars;
-    EzpzSystem* sys;
+    int device;
+    std::shared_ptr<EzpzSystem> sys;
 };
 std::mutex g_cache_mu;
 std::list<CacheEntry> g_cache;
 constexpr size_t kCacheMax = 16;
 
-int cached_system(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, EzpzSystem** out, int32_t* ec, int64_t* ev) {
+// The system comes back shared: solve() is callable from many threads at once (like the reference's), and an entry
+// another thread evicts must outlive the solves still running on it.  Systems live on the calling thread's current
+// HIP device.
+int cached_system(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, std::shared_ptr<EzpzSystem>* out, int32_t* ec,
+                  int64_t* ev) {
     const uint64_t h = topology_hash(cs, n_cs, n_vars);
     const size_t bytes = n_cs * sizeof(EzpzConstraint);
-    std::lock_guard<std::mutex> lock(g_cache_mu);
-    for (auto it = g_cache.begin(); it != g_cache.end(); ++it) {
-        if (it->hash == h && it->n_vars == n_vars && it->key.size() == bytes &&
-            std::memcmp(it->key.data(), cs, bytes) == 0) {
-            g_cache.splice(g_cache.begin(), g_cache, it);
-            *out = g_cache.front().sys;
-            return EZPZ_OK;
+    const int device = ezpz_current_device();
+    if (device < 0) return EZPZ_ERR_NO_DEVICE;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        for (auto it = g_cache.begin(); it != g_cache.end(); ++it) {
+            if (it->hash == h && it->n_vars == n_vars && it->device == device && it->key.size() == bytes &&
+                std::memcmp(it->key.data(), cs, bytes) == 0) {
+                g_cache.splice(g_cache.begin(), g_cache, it);
+                *out = g_cache.front().sys;
+                return EZPZ_OK;
+            }
         }
     }
-    EzpzSystem* sys = nullptr;
-    int rc = ezpz_system_create(cs, n_cs, n_vars, 0, 0, &sys, ec, ev);
+    // the symbolic phase runs outside the lock; two threads racing on a new topology both build it, one entry wins
+    EzpzSystem* raw = nullptr;
+    int rc = ezpz_system_create(cs, n_cs, n_vars, device, 0, &raw, ec, ev);
     if (rc != EZPZ_OK) return rc;
     CacheEntry e;
     e.hash = h;
     e.key.assign(reinterpret_cast<const unsigned char*>(cs), reinterpret_cast<const unsigned char*>(cs) + bytes);
     e.n_vars = n_vars;
-    e.sys = sys;
+    e.device = device;
+    e.sys = std::shared_ptr<EzpzSystem>(raw, [](EzpzSystem* p) { ezpz_system_destroy(p); });
+    *out = e.sys;
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     g_cache.push_front(std::move(e));
-    while (g_cache.size() > kCacheMax) {
-        ezpz_system_destroy(g_cache.back().sys);
-        g_cache.pop_back();
-    }
-    *out = sys;
+    while (g_cache.size() > kCacheMax) g_cache.pop_back();
     return EZPZ_OK;
 }
 
@@ -118,7 +127,6 @@ extern "C" {
 
 void ezpz_cache_clear(void) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
-    for (auto& e : g_cache) ezpz_system_destroy(e.sys);
     g_cache.clear();
 }
 
@@ -171,10 +179,11 @@ int solve_inner_impl(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t 
                 }
         }
     }
-    EzpzSystem* sys = nullptr;
+    std::shared_ptr<EzpzSystem> sys_ref;
     int32_t ec = -1;
     int64_t ev = -1;
-    int rc = cached_system(cs, n_cs, n_guesses, &sys, &ec, &ev);
+    int rc = cached_system(cs, n_cs, n_guesses, &sys_ref, &ec, &ev);
+    EzpzSystem* sys = sys_ref.get();
     if (rc != EZPZ_OK) {
         if (rc == EZPZ_ERR_MISSING_GUESS && !dense) rc = EZPZ_ERR_MATRIX;  // id has a guess but no column
         out->error = rc;
@@ -432,10 +441,11 @@ int ezpz_solve_batch(const EzpzConstraint* reqs_in, size_t n_reqs, size_t n_vars
                     subset_ids.push_back(i);
                     lowest = std::max(lowest, reqs[i].priority);
                 }
-            EzpzSystem* sys = nullptr;
+            std::shared_ptr<EzpzSystem> sys_ref;
             int32_t ec = -1;
             int64_t ev = -1;
-            int rc = cached_system(subset.data(), subset.size(), n_vars, &sys, &ec, &ev);
+            int rc = cached_system(subset.data(), subset.size(), n_vars, &sys_ref, &ec, &ev);
+            EzpzSystem* sys = sys_ref.get();
             if (rc != EZPZ_OK) {
                 if (first_tier) {  // lib.rs:239-244: no earlier tier to fall back to
                     if (err_constraint) *err_constraint = ec >= 0 ? (int32_t)subset_ids[(size_t)ec] : -1;

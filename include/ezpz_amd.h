@@ -157,6 +157,8 @@ typedef struct EzpzSystem EzpzSystem; /* opaque: one analysed topology, resident
 
 void ezpz_default_config(EzpzConfig* cfg); /* Config::default(), solver.rs:72-81 */
 int ezpz_device_count(void);
+/* The calling thread's current HIP device, or -1 without one.  ezpz_solve* keep their cached systems on it. */
+int ezpz_current_device(void);
 const char* ezpz_error_string(int err);
 
 /* ---- symbolic phase ------------------------------------------------------------------------------

@@ -578,3 +578,41 @@ def test_solve_analysis_object_api_and_priority_tiers(E):
     out = E.solve_analysis(reqs[:2], [(p.x_id, 0.0), (p.y_id, 0.0)])
     assert out.outcome.priority_solved() == 1 and not out.analysis.is_underconstrained()
     assert E.solve_analysis([], [(0, 0.5)]).analysis.underconstrained() == []
+
+
+def test_solve_is_reentrant_across_threads_and_cache_evictions(E):
+    """`solve` is callable concurrently (no global state in the reference).  40 distinct topologies from
+    8 threads overflow the 16-entry topology cache, so entries are evicted while other threads still solve on them."""
+    import threading
+
+    topologies = []
+    for k in range(40):
+        npts = 3 + k % 7
+        reqs = [O.fixed(0, 0.0), O.fixed(1, float(k))]
+        guesses = [(0, 0.1), (1, k + 0.2)]
+        for p in range(1, npts):
+            reqs.append(O.distance((2 * p - 2, 2 * p - 1), (2 * p, 2 * p + 1), 1.0 + 0.1 * k))
+            reqs.append(O.horizontal((2 * p - 2, 2 * p - 1), (2 * p, 2 * p + 1)))
+            guesses += [(2 * p, 0.9 * p + 0.3), (2 * p + 1, k + 0.1 * p)]
+        want = O.solve(reqs, guesses)
+        topologies.append((O.stack(reqs), guesses, want))
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(3):
+                for k in range(tid, 40, 4):
+                    recs, guesses, want = topologies[k]
+                    got = E.solve_records(recs, guesses)
+                    assert (got.error, got.iterations, got.converged, got.unsatisfied) == (
+                        0, want.iterations, want.converged, want.unsatisfied), (tid, k)
+                    assert_x_close(got.final_values, want.final_values)
+        except Exception as exc:  # noqa: BLE001 -- reported below, in the main thread
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
