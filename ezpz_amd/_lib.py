@@ -39,7 +39,7 @@ class CSystemInfo(C.Structure):
                 ("nnz_a", C.c_uint64), ("nnz_l", C.c_uint64), ("n_levels", C.c_uint64), ("n_components", C.c_uint64),
                 ("program_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("team_size", C.c_uint32),
                 ("workspace_in_lds", C.c_uint32), ("team_mode", C.c_uint32), ("n_partitions", C.c_uint32),
-                ("program_in_lds", C.c_uint32), ("reserved", C.c_uint32)]
+                ("program_in_lds", C.c_uint32), ("grid_workgroups", C.c_uint32)]
 
 
 # every symbol include/ezpz_amd.h declares

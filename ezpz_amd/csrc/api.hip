@@ -99,6 +99,11 @@ struct EzpzSystem {
     bool prog_in_lds = false;
     bool unit_weights = true;
     bool linear_only = false;  // every constraint is of a linear kind: the evaluators are built without the others
+    uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
+    uint32_t grid_ws_doubles = 0;
+    DevBuf<GridScratch> grid_scratch;
+    DevBuf<GridWgDesc> grid_desc;
+    std::vector<GridWgDesc> host_grid_desc;
     uint32_t prog_lds_doubles = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
@@ -185,8 +190,14 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
         s.lds_bytes = prog_bytes + (size_t)(s.block_threads / team) * ws_bytes + 16;
     } else {
         s.block_threads = s.team_size;
-        s.lds_ws = prog_bytes + ws_bytes + 1024 <= kLdsBytesMax;
-        s.lds_bytes = s.lds_ws ? prog_bytes + ws_bytes + 64 * 8 + 16 : prog_bytes + 80 * 8;
+        if (s.grid_wgs > 1) {
+            s.ws_doubles = s.grid_ws_doubles;
+            s.lds_ws = true;
+            s.lds_bytes = prog_bytes + (size_t)s.ws_doubles * 8 + 64 * 8 + 16;
+        } else {
+            s.lds_ws = prog_bytes + ws_bytes + 1024 <= kLdsBytesMax;
+            s.lds_bytes = s.lds_ws ? prog_bytes + ws_bytes + 64 * 8 + 16 : prog_bytes + 80 * 8;
+        }
     }
 }
 
@@ -219,6 +230,42 @@ int launch_sub(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStr
                          : launch_variant<TEAM, MODE_SUB, true, false>(s, args, grid, stream);
 }
 
+// Grid team: G workgroups per system, all of a launch's workgroups resident at once (cooperative launch), as many
+// systems in flight as the device holds.
+template <bool LIN>
+int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
+    auto kernel = lm_solve_kernel<64, MODE_PART, true, false, LIN>;
+    if (s.lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)s.lds_bytes));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)s.block_threads, s.lds_bytes));
+    const uint64_t capacity = (uint64_t)kNumCUs * (uint64_t)std::max(per_cu, 1);
+    if (capacity < s.grid_wgs) return EZPZ_ERR_TOO_LARGE;
+    const uint32_t slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(args.batch, capacity / s.grid_wgs));
+    int rc;
+    if (s.grid_desc.cap < s.host_grid_desc.size()) {
+        if ((rc = s.grid_desc.ensure(s.host_grid_desc.size())) != EZPZ_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(s.grid_desc.p, s.host_grid_desc.data(), s.host_grid_desc.size() * sizeof(GridWgDesc),
+                               hipMemcpyHostToDevice, stream));
+    }
+    if (s.grid_scratch.cap < slots) {
+        if ((rc = s.grid_scratch.ensure(slots)) != EZPZ_OK) return rc;
+        HIP_TRY(hipMemsetAsync(s.grid_scratch.p, 0, s.grid_scratch.cap * sizeof(GridScratch), stream));
+    }
+    args.grid_scratch = s.grid_scratch.p;
+    args.grid_desc = s.grid_desc.p;
+    args.grid_wgs = s.grid_wgs;
+    void* params[] = {&args};
+    HIP_TRY(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(slots * s.grid_wgs),
+                                       dim3(s.block_threads), params, (unsigned int)s.lds_bytes, stream));
+    return EZPZ_OK;
+}
+
+int launch_grid_team(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
+    return s.linear_only ? launch_grid_kernel<true>(s, args, stream) : launch_grid_kernel<false>(s, args, stream);
+}
+
 int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
     uint32_t grid;
@@ -236,6 +283,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         default: return launch_sub<64>(s, args, grid, stream);
         }
     }
+    if (s.grid_wgs > 1) return launch_grid_team(s, args, stream);
     const uint32_t per_cu = s.lds_ws ? (uint32_t)std::max<size_t>(1, kLdsBytesMax / std::max<size_t>(s.lds_bytes, 1))
                                      : 2048u / s.block_threads;
     grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)kNumCUs * std::min<uint32_t>(per_cu, 8) * 2);
@@ -358,7 +406,63 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const uint32_t max_team = lin ? 1024 : 512;
         uint32_t team = team_size ? std::min<uint32_t>(max_team, (std::max<uint32_t>(team_size, 128) + 63) & ~63u)
                                   : auto_wg_team(width);
-        if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
+        // One large system whose state cannot live in a CU's LDS: spread it over G workgroups (a "grid team"), each
+        // owning team/64 partitions, ~64+ variables per wavefront; falls back to one workgroup when the components
+        // cannot be balanced over that many partitions.
+        uint32_t G = 1;
+        if (!team_size && (3 * n_vars + 2 * n_cs) * 8 > kLdsBytesMax) {
+            while (G < (uint32_t)kGridMaxWgs && (uint64_t)G * 2 * (team / 64) * 64 <= n_vars) G <<= 1;
+        }
+        bool built = false;
+        for (; G > 1 && !built; G >>= 1) {
+            Program Q;
+            BuildError qe;
+            if (!build_program(cs, n_cs, n_vars, Q, qe, G * (team / 64))) {
+                be = qe;
+                return fail();
+            }
+            if (Q.c.n_parts == G * (team / 64)) {
+                P = std::move(Q);
+                built = true;
+                break;
+            }
+        }
+        if (!built) {
+            G = 1;
+            if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
+        }
+        // a grid team keeps each workgroup's share of the state in that workgroup's LDS
+        s.host_grid_desc.clear();
+        if (G > 1) {
+            const uint32_t W = team / 64;
+            uint32_t worst = 0;
+            for (uint32_t g = 0; g < G; ++g) {
+                const PartDesc& first = P.parts[g * W];
+                const PartDesc& last = P.parts[g * W + W - 1];
+                GridWgDesc d{};
+                d.v0 = P.lvl_cptr[first.lvl0];
+                d.nv = P.lvl_cptr[last.lvl0 + last.nlev] - d.v0;
+                d.l0 = P.lvl_sptr[first.lvl0];
+                d.nl = P.lvl_sptr[last.lvl0 + last.nlev] - d.l0;
+                const uint32_t c0 = first.con0, c1 = last.con1, C = P.c.n_cons;
+                d.r0 = c0 < C ? P.cons[c0].row0 : P.c.n_rows;
+                d.nr = (c1 < C ? P.cons[c1].row0 : P.c.n_rows) - d.r0;
+                d.j0 = c0 < C ? P.cons[c0].jbase : P.c.zj;
+                d.nj = (c1 < C ? P.cons[c1].jbase : P.c.zj) - d.j0;
+                worst = std::max(worst, 3 * d.nv + 2 * d.nr + d.nj + d.nl);
+                s.host_grid_desc.push_back(d);
+            }
+            if (((size_t)worst + 4) * 8 + 2048 > 128 * 1024) {  // a share does not fit: one workgroup per system
+                G = 1;
+                s.host_grid_desc.clear();
+                Program Q;
+                if (!build_program(cs, n_cs, n_vars, Q, be, team / 64)) return fail();
+                P = std::move(Q);
+            } else {
+                s.grid_ws_doubles = (worst + 4 + 1) & ~1u;
+            }
+        }
+        s.grid_wgs = G;
         s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;
         s.team_size = team;
     }
@@ -460,7 +564,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
         if (s.mode == MODE_SUB) {
             if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
-        } else if (v.packed && lists_bytes + ws_bytes + 2048 <= kLdsBytesMax) {
+        } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= kLdsBytesMax) {
             stage_bytes = lists_bytes;
         }
     }
@@ -496,6 +600,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     info.team_mode = (uint32_t)s.mode;
     info.n_partitions = P.c.n_parts;
     info.program_in_lds = s.prog_in_lds ? 1 : 0;
+    info.grid_workgroups = s.grid_wgs;
     return EZPZ_OK;
 }
 
@@ -609,6 +714,9 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.prog_lds_doubles = sys->prog_lds_doubles;
     a.stamps = g_stamps;
     a.unit_weights = sys->unit_weights ? 1u : 0u;
+    a.grid_wgs = 1;
+    a.grid_scratch = nullptr;
+    a.grid_desc = nullptr;
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }

@@ -135,6 +135,54 @@ __device__ __forceinline__ DevCon load_packed(const PackedCon* p, const double* 
     return c;
 }
 
+// One large system on many workgroups ("grid team", MODE_PART, each workgroup's share of the state in its LDS):
+// workgroup g of the G that share a system owns partitions [g*W, (g+1)*W) (W wavefronts), and the two scalar
+// reductions of an LM iteration go through this per-system scratch.  Every workgroup publishes its two partials;
+// workgroup 0 alone polls them, folds them in a fixed tree and writes the result to one 64-byte line per workgroup;
+// every other workgroup polls only its own line.  A value travels as a 16-byte (value, sequence number) chunk moved
+// by one device-coherent (sc0 sc1) 128-bit access, so it validates itself and no release/acquire fence (an L2
+// write-back / L1 invalidate each) is needed.  Measured alternatives on 256 workgroups, all 25 us per reduction: a
+// central atomic counter + generation word (256 cross-XCD atomics serialise on one word), everyone polling
+// everyone's flag (all pollers hit the same few lines), release/acquire flags (10 us just to scatter 255 lines).
+// All G workgroups must be resident at once: the host launches cooperatively.
+constexpr int kGridMaxWgs = 256;
+typedef unsigned int gridchunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, seq, 0)
+struct GridScratch {
+    int nwarn[2];                           // Degenerate-warning counters, by parity of the system's index in this slot
+    int pad[14];
+    gridchunk_t arr[2][2][kGridMaxWgs];     // [parity of the sequence number][value][workgroup]: partials
+    gridchunk_t out[2][kGridMaxWgs][4];     // [parity][workgroup]: (a, seq), (b, seq) in one 64-byte line
+};
+
+__device__ __forceinline__ void grid_store(gridchunk_t* p, double v, unsigned int seq) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    gridchunk_t c;
+    c.x = (unsigned int)u;
+    c.y = (unsigned int)(u >> 32);
+    c.z = seq;
+    c.w = 0;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(c) : "memory");
+}
+// Spins until the chunk carries `seq`, returns its value.
+__device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int seq) {
+    gridchunk_t c;
+    for (;;) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(c) : "v"(p) : "memory");
+        if (c.z == seq) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
+}
+
+// What workgroup g of a grid team owns, as contiguous ranges of the program's internal numbering; its LDS workspace
+// holds exactly these (indices are rebased by folding -first into the array offsets).
+struct GridWgDesc {
+    uint32_t v0, nv;  // variables (x, D, d)
+    uint32_t r0, nr;  // residual rows (r, r_next)
+    uint32_t j0, nj;  // Jacobian slots
+    uint32_t l0, nl;  // strictly-lower L slots
+};
+
 struct SolveArgs {
     ProgramView p;
     const double* x0;
@@ -151,6 +199,9 @@ struct SolveArgs {
     uint32_t unit_weights;  // every constraint weight == 1.0 (the common case): weighted r == unweighted r
     double residual_tolerance, step_tolerance, initial_lambda;
     unsigned long long* stamps;  // diagnostic builds (-DEZPZ_STAMPS) only: (id, s_memtime) pairs of block 0, lane 0
+    GridScratch* grid_scratch;   // grid teams: one per system in flight
+    const GridWgDesc* grid_desc; // grid teams: per workgroup of a system
+    uint32_t grid_wgs;           // workgroups per system (1 = every other team shape)
 };
 
 #ifdef EZPZ_STAMPS
@@ -215,9 +266,11 @@ constexpr double LM_LAMBDA_DECR = 0.1;   // newton.rs:16
 
 struct OpSum {
     __device__ __forceinline__ double operator()(double a, double b) const { return a + b; }
+    __device__ __forceinline__ double identity() const { return 0.0; }
 };
 struct OpMax {  // libm::fmax (NaN-ignoring), newton.rs:53,:108
     __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); }
+    __device__ __forceinline__ double identity() const { return __builtin_nan(""); }  // dropped by fmax
 };
 
 // Cross-lane moves inside a row of 16 lanes without touching the LDS crossbar (DPP modifiers on v_mov):
@@ -247,6 +300,9 @@ struct Team {
     int stride;   // lanes in that unit
     double* red;  // PART/WGB: 2 (flip) x 2 (values) x 16 (waves) doubles of LDS scratch
     int red_flip;
+    GridScratch* grid;  // grid teams only
+    uint32_t grid_wgs, grid_wg;
+    unsigned int grid_seq;  // sequence number of the last grid reduction (same on every workgroup of the system)
 
     // Orders one phase's LDS/global writes before the next phase's reads inside the unit.
     __device__ __forceinline__ void phase_sync() const {
@@ -295,6 +351,47 @@ struct Team {
                 b = opb(b, buf[16 + w]);
             }
             // the next reduction uses the other half of `red`, so no trailing barrier is needed
+            if constexpr (MODE == MODE_PART) {
+                if (grid_wgs > 1) {  // grid team: gather at workgroup 0, fold in a fixed tree, scatter the result
+                    const unsigned int seq = ++grid_seq;
+                    const unsigned int par = seq & 1u;
+                    // A workgroup publishes sequence number s+1 only after it has consumed the result of s, and
+                    // workgroup 0 writes the result of s+2 only after every arrival for s+2: parities never collide.
+                    if (threadIdx.x < 2) grid_store(&grid->arr[par][threadIdx.x][grid_wg], threadIdx.x ? b : a, seq);
+                    double* buf2 = red + (red_flip ? 32 : 0);
+                    red_flip ^= 1;
+                    if (grid_wg == 0) {
+                        a = opa.identity();
+                        b = opb.identity();
+                        if (threadIdx.x < grid_wgs) {
+                            a = grid_wait(&grid->arr[par][0][threadIdx.x], seq);
+                            b = grid_wait(&grid->arr[par][1][threadIdx.x], seq);
+                        }
+                        a = reduce_lanes<64>(a, opa);
+                        b = reduce_lanes<64>(b, opb);
+                        if ((threadIdx.x & 63) == 0) {
+                            buf2[wave] = a;
+                            buf2[16 + wave] = b;
+                        }
+                        __syncthreads();
+                        a = buf2[0];
+                        b = buf2[16];
+                        for (int w = 1; w < nwaves; ++w) {
+                            a = opa(a, buf2[w]);
+                            b = opb(b, buf2[16 + w]);
+                        }
+                        if (threadIdx.x < grid_wgs && threadIdx.x > 0) {  // one line per workgroup
+                            grid_store(&grid->out[par][threadIdx.x][0], a, seq);
+                            grid_store(&grid->out[par][threadIdx.x][1], b, seq);
+                        }
+                    } else {
+                        if (threadIdx.x < 2) buf2[16 * threadIdx.x] = grid_wait(&grid->out[par][grid_wg][threadIdx.x], seq);
+                        __syncthreads();
+                        a = buf2[0];
+                        b = buf2[16];
+                    }
+                }
+            }
         }
     }
 };
@@ -399,6 +496,28 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     using CRef = ConRef<CON_FORM, Prog<idx_t>>;
     const bool unit_w = a.unit_weights != 0;
 
+    // ---- grid team geometry (one system on several workgroups, each keeping its share of the state in LDS) ----------
+    constexpr bool GRID_OK = (MODE == MODE_PART && LDSWS && !PLDS);
+    const uint32_t grid_wgs = GRID_OK ? a.grid_wgs : 1u;
+    const uint32_t grid_wg = GRID_OK ? blockIdx.x % grid_wgs : 0u;  // this workgroup inside its system's group
+    const uint32_t grid_slot = blockIdx.x / grid_wgs;               // which system-in-flight
+    tm.grid_wgs = grid_wgs;
+    tm.grid_wg = grid_wg;
+    tm.grid = (GRID_OK && grid_wgs > 1) ? a.grid_scratch + grid_slot : nullptr;
+    tm.grid_seq = 0;
+    if (tm.grid) {  // continue the slot's sequence numbers where the previous launch left them (this workgroup's own)
+        gridchunk_t c0, c1;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(c0)
+                     : "v"(&tm.grid->arr[0][0][grid_wg])
+                     : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(c1)
+                     : "v"(&tm.grid->arr[1][0][grid_wg])
+                     : "memory");
+        tm.grid_seq = c0.z > c1.z ? c0.z : c1.z;
+    }
+
     // ---- workspace carve-up (doubles) ----------------------------------------------------------------------------
     constexpr int WS_STRIDE = (MODE == MODE_SUB) ? 64 / TEAM : 1;  // systems side by side in a wavefront
     static_assert(WS_STRIDE == 1 || LDSWS, "interleaved workspaces live in LDS");
@@ -413,14 +532,29 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         ws.p = a.gws + (size_t)blockIdx.x * a.ws_doubles;
         tm.red = smem;
     }
-    const uint32_t o_x = 0;
+    // offsets of x r r_next Jv D L d inside the workspace; a grid team's workgroup holds only its own ranges and
+    // folds "- first index" into the offsets (unsigned wrap-around, undone as soon as an index is added)
+    uint32_t o_x = 0;
     uint32_t o_r = n;
     uint32_t o_rn = n + m;
-    const uint32_t o_j = n + 2 * m;
-    const uint32_t o_d = o_j + zj;   // Cholesky diagonal, by variable
-    const uint32_t o_l = o_d + n;    // strictly-lower L entries, (partition, level) grouped
-    const uint32_t o_v = o_l + zlo;  // b, then y, then d (by variable)
-    const uint32_t o_i = o_v + n;    // small int area
+    uint32_t o_j = n + 2 * m;
+    uint32_t o_d = o_j + zj;   // Cholesky diagonal, by variable
+    uint32_t o_l = o_d + n;    // strictly-lower L entries, (partition, level) grouped
+    uint32_t o_v = o_l + zlo;  // b, then y, then d (by variable)
+    uint32_t o_i = o_v + n;    // small int area
+    if (GRID_OK && grid_wgs > 1) {
+        const GridWgDesc gd = a.grid_desc[grid_wg];
+        const uint32_t bx = 0, br = gd.nv, brn = br + gd.nr, bj = brn + gd.nr, bd = bj + gd.nj, bl = bd + gd.nv,
+                       bv = bl + gd.nl;
+        o_x = bx - gd.v0;
+        o_r = br - gd.r0;
+        o_rn = brn - gd.r0;
+        o_j = bj - gd.j0;
+        o_d = bd - gd.v0;
+        o_l = bl - gd.l0;
+        o_v = bv - gd.v0;
+        o_i = bv + gd.nv;
+    }
     int* nwarn;
     if constexpr (LDSWS) {
         nwarn = reinterpret_cast<int*>(&ws[o_i]);
@@ -429,7 +563,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     }
 
     // ---- this unit's partition --------------------------------------------------------------------------------------
-    const PartDesc part = P.parts[(MODE == MODE_PART) ? (uint32_t)(tid >> 6) : 0u];
+    const PartDesc part = P.parts[(MODE == MODE_PART) ? grid_wg * (blockDim.x >> 6) + (uint32_t)(tid >> 6) : 0u];
     const uint32_t con0 = part.con0, con1 = part.con1;
     const idx_t* lvl_cptr = P.lvl_cptr + part.lvl0;
     const idx_t* lvl_sptr = P.lvl_sptr + part.lvl0;
@@ -439,8 +573,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
 
     // (A variant that kept the first four rounds of constraint records in VGPRs across sweeps and systems was
     // measured slower -- 54 vs 38 us per 2000x2000 system -- and is not kept; records are re-read per sweep.)
-    const uint64_t n_teams = (uint64_t)gridDim.x * teams_per_block;
-    for (uint64_t sys = (uint64_t)blockIdx.x * teams_per_block + team_in_block; sys < a.batch; sys += n_teams) {
+    const uint64_t n_teams = (uint64_t)(gridDim.x / grid_wgs) * teams_per_block;
+    uint32_t sys_parity = 0;  // grid teams: which of the slot's two warning counters this system uses
+    for (uint64_t sys = (uint64_t)grid_slot * teams_per_block + team_in_block; sys < a.batch;
+         sys += n_teams, sys_parity ^= 1u) {
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
 #ifdef EZPZ_STAMPS
         int stamp_n = 0;
@@ -454,7 +590,13 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         } else {
             for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[P.var_of[i]];
         }
-        if (tlane == 0) *nwarn = 0;
+        const bool grid_team = GRID_OK && grid_wgs > 1;
+        if (grid_team) {
+            // shared by the system's workgroups: zeroed by the host / by workgroup 0 two systems ago (see write-back)
+            nwarn = &tm.grid->nwarn[sys_parity];
+        } else if (tlane == 0) {
+            *nwarn = 0;
+        }
         tm.team_sync();
         EZPZ_STAMP(2);
 
@@ -731,8 +873,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         // the count of unsatisfied constraints; for workgroup teams also the rendezvous before the cooperative store
         // of x.  Wavefront-partitioned teams store their own partition's values and need neither when the count is
         // known to be zero (`all_satisfied` is uniform: it derives from the reduced max |r|).
+        // Grid teams: the reduction's grid barrier is also what lets workgroup 0 read the shared warning counter, so it
+        // is skipped only when no warning can exist (linear-only build).
         constexpr bool OWN_STORE = (MODE == MODE_PART);
-        if (!(all_satisfied && (OWN_STORE || MODE == MODE_SUB))) tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());
+        const bool skip_count = all_satisfied && (OWN_STORE || MODE == MODE_SUB) && (!grid_team || LIN);
+        if (!skip_count) tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());
         EZPZ_STAMP(31);
         double* xo = a.x_out + sys * n;
         if constexpr (OWN_STORE) {
@@ -740,15 +885,19 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         } else {
             for (uint32_t i = tlane; i < n; i += tsize) xo[P.var_of[i]] = ws[o_x + i];
         }
-        if (tlane == 0) {
+        if (tlane == 0 && grid_wg == 0) {
             EzpzStatus st;
             st.iterations = iterations;
             st.converged = converged;
             st.n_unsatisfied = (uint32_t)unsat_cnt;
-            st.n_warnings = (uint32_t)*nwarn;
+            st.n_warnings = grid_team ? (uint32_t)__hip_atomic_load(nwarn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : (uint32_t)*nwarn;
             st.final_residual_inf = (m > 0) ? largest : 0.0;
             st.final_lambda = lambda;
             a.status[sys] = st;
+            // grid teams: this counter serves the slot's system after next; every workgroup passes a grid reduction
+            // of the next system (which this thread joins only after the store) before it can get there
+            if (grid_team) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // the workspace is reused by the next system of this team; wavefront-partitioned teams touch only their own
         // partition's part of it until the rendezvous that follows the next load

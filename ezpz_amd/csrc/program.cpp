@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <queue>
 
 #include "kinds.hpp"
 
@@ -318,13 +319,17 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
         std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
         std::vector<uint64_t> load(want_parts, 0);
         uint64_t total = 0;
+        // least-loaded partition first (ties: lowest index), as a heap: grid teams ask for thousands of partitions
+        using Slot = std::pair<uint64_t, uint32_t>;
+        std::priority_queue<Slot, std::vector<Slot>, std::greater<Slot>> heap;
+        for (uint32_t p = 0; p < want_parts; ++p) heap.push(Slot{0, p});
         for (uint32_t c : by_weight) {
-            uint32_t best = 0;
-            for (uint32_t p = 1; p < want_parts; ++p)
-                if (load[p] < load[best]) best = p;
+            const uint32_t best = heap.top().second;
+            heap.pop();
             part_of_comp[c] = best;
             load[best] += w[c];
             total += w[c];
+            heap.push(Slot{load[best], best});
         }
         uint64_t worst = *std::max_element(load.begin(), load.end());
         if (worst * want_parts <= total + total / 3 + 64) {

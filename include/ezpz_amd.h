@@ -150,7 +150,7 @@ typedef struct EzpzSystemInfo {
     uint32_t team_mode;     /* 0 sub-wavefront teams, 1 wavefront-partitioned workgroup, 2 barrier workgroup */
     uint32_t n_partitions;  /* partitions (balanced unions of components), one per wavefront in mode 1 */
     uint32_t program_in_lds;
-    uint32_t reserved;
+    uint32_t grid_workgroups; /* workgroups that share one system (grid team: one large system on many CUs), else 1 */
 } EzpzSystemInfo;
 
 typedef struct EzpzSystem EzpzSystem; /* opaque: one analysed topology, resident on one device */

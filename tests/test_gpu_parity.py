@@ -283,16 +283,30 @@ def test_committed_massive_fixture_and_overconstrained_variant(E):
         assert_x_close(got.final_values, want.final_values)
 
 
-def test_large_ladder_uses_global_workspace(E):
-    """BASELINE configs[3] at reduced size: one large sparse system whose state does not fit the LDS."""
+def test_large_ladder_grid_team_and_global_workspace(E):
+    """BASELINE configs[3] at reduced size: one large sparse system whose state does not fit one CU's LDS.  By default
+    it is spread over a grid team (many workgroups, each with its share of the state in LDS, grid-wide reductions);
+    with an explicit team size one workgroup solves it out of a global-memory workspace.  Same answer both ways."""
     text = T.gen_big_problem(12000)
     ref = T.load(text)
-    sysobj = E.System(ref.constraints, ref.num_vars)
-    assert sysobj.info()["workspace_in_lds"] == 0
-    x, st, _ = sysobj.solve_batch(ref.guesses[None, :])
     want = O.solve(ref.constraints, ref.guesses, linsolve=O.LINSOLVE_SPARSE)
-    assert (st["iterations"][0], bool(st["converged"][0]), st["n_unsatisfied"][0]) == (want.iterations, want.converged, 0)
-    assert_x_close(x[0], want.final_values)
+    x0 = np.tile(ref.guesses, (3, 1))
+    x0[1] += 0.125
+    x0[2] -= 0.25
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0, linsolve=O.LINSOLVE_SPARSE)
+    for team, grid in ((0, True), (512, False)):
+        sysobj = E.System(ref.constraints, ref.num_vars, team_size=team)
+        info = sysobj.info()
+        assert (info["grid_workgroups"] > 1) == grid
+        assert info["workspace_in_lds"] == (1 if grid else 0)
+        x, st, _ = sysobj.solve_batch(x0)
+        assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv)
+        assert np.all(st["n_unsatisfied"] == 0) and np.all(st["n_warnings"] == 0)
+        assert_x_close(x, xo)
+        # several systems per launch go through the same slots one after the other
+        x2, st2, _ = sysobj.solve_batch(np.tile(x0, (9, 1)))
+        assert np.array_equal(x2, np.tile(x, (9, 1)))
+    assert (st["iterations"][0], bool(st["converged"][0])) == (want.iterations, want.converged)
 
 
 def test_empty_batch_and_ragged_sizes(E):

@@ -12,7 +12,7 @@ s = E.System(cs.constraints, n)
 dev = torch.device('cuda', 0)
 x0 = torch.from_numpy(cs.guesses[None, :] + gen.keyed_uniform(1, B, n, -0.25, 0.25)).to(dev)
 xo = torch.empty_like(x0); st = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
-buf = torch.zeros(512, dtype=torch.int64, device=dev)
+buf = torch.zeros(2048, dtype=torch.int64, device=dev)
 L = E.lib(); L.ezpz_debug_set_stamps.argtypes = [C.c_void_p]; L.ezpz_debug_set_stamps(buf.data_ptr())
 stream = torch.cuda.current_stream(dev).cuda_stream
 for _ in range(3):
@@ -27,3 +27,11 @@ for i, t in b:
     print(f"{names.get(int(i), i):>18}: +{(t - prev) if prev is not None else 0:7d} ticks")
     prev = t
 print("total ticks", b[b[:, 0] > 0][-1, 1] - b[0, 1])
+
+print("--- grid reduction internals (block 0 thread 0) ---")
+d = b[300:]
+prev = None
+for i, t in d:
+    if i == 0: break
+    print(f"{ {50:'enter',51:'published',52:'all flags seen',53:'folded',54:'scattered'}.get(int(i), i):>18}: +{(t - prev) if prev is not None else 0:7d}")
+    prev = t
