@@ -8,9 +8,10 @@
 //     the unsatisfied check of solve_inner  reference ezpz/src/lib.rs:305-327
 //
 // Team modes (template):
-//   SUB   TEAM in {4,8,16,32,64} lanes per system, several systems per 64-wide wavefront.  No s_barrier
-//         anywhere: lanes of a wave run in lockstep and the LDS serves a wave's accesses in issue order;
-//         reductions are DPP/bpermute shuffles.  Small programs are staged into LDS once per workgroup (PLDS).
+//   SUB   TEAM in {1,2,4,...,64} lanes per system, 64/TEAM systems per 64-wide wavefront with their workspaces
+//         interleaved element by element.  No s_barrier anywhere: lanes of a wave run in lockstep and the LDS
+//         serves a wave's accesses in issue order; reductions are DPP shuffles.  Small programs are staged into
+//         LDS once per workgroup (PLDS).
 //   PART  one workgroup per system, every wavefront owns a *partition* (a balanced union of connected
 //         components: its own constraints, variables, Jacobian slots, Cholesky columns).  All phases of an
 //         LM iteration are wave-local; the only workgroup barriers are the two reductions per iteration that
@@ -18,6 +19,9 @@
 //   WGB   one workgroup per system, all lanes cooperate on one partition with s_barrier between phases
 //         (systems dominated by one large connected component).
 //   LDSWS=false  state lives in a per-workgroup global-memory workspace (systems too big for 160 KB of LDS).
+//   grid team    PART with a.grid_wgs > 1: several workgroups share one system, each with its own partitions and
+//         its share of the state in LDS; the two reductions per iteration cross workgroups (see GridScratch).
+//   LIN   build without the sixteen non-linear kinds' evaluators, for topologies that do not use them.
 // HBM traffic is only x0 in, x*/status/mask out (AoS rows, contiguous per team); the topology program is
 // shared by every team and stays L2 (or LDS) resident.
 #pragma once

@@ -191,7 +191,9 @@ int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t
  * optional ([batch][n_cs] bytes, 1 = unsatisfied, indexed by position in `cs`); warn_log is optional
  * ([batch][warn_cap] entries (pass << 32 | position), chronological once sorted).
  * The _device form takes device pointers and only enqueues on `stream` (a hipStream_t; NULL = default);
- * the host form copies in, runs, copies out and synchronises. */
+ * the host form copies in, runs, copies out and synchronises.  Launches on one EzpzSystem must not overlap in time
+ * when the system uses per-system device scratch (a global workspace or a grid team, see EzpzSystemInfo): enqueue
+ * them on one stream, or create one EzpzSystem per stream. */
 int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
                                    double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
                                    uint64_t* warn_log_dev, uint32_t warn_cap, void* stream);
