@@ -773,8 +773,20 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
     if (n) HIP_TRY(hipMemcpy(x_out, sys->x_dev.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
     if (unsat_mask && C) HIP_TRY(hipMemcpy(unsat_mask, sys->mask_dev.p, batch * C, hipMemcpyDeviceToHost));
-    if (want_log)
-        HIP_TRY(hipMemcpy(warn_log, sys->log_dev.p, batch * (size_t)warn_cap * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (want_log) {
+        // the log's capacity is sized for the worst case (every constraint warning in every sweep): bring back only
+        // what each system wrote, or everything when that is small anyway
+        if (log_bytes <= (1u << 20)) {
+            HIP_TRY(hipMemcpy(warn_log, sys->log_dev.p, log_bytes, hipMemcpyDeviceToHost));
+        } else {
+            for (size_t b = 0; b < batch; ++b) {
+                const size_t cnt = std::min<size_t>(status[b].n_warnings, warn_cap);
+                if (cnt)
+                    HIP_TRY(hipMemcpy(warn_log + b * warn_cap, sys->log_dev.p + b * warn_cap, cnt * sizeof(uint64_t),
+                                      hipMemcpyDeviceToHost));
+            }
+        }
+    }
     return EZPZ_OK;
 }
 

@@ -198,7 +198,10 @@ int solve_inner_impl(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t 
         return out->error;
     }
     // Every evaluation sweep may warn about every constraint: size the log so nothing is dropped.
-    uint64_t want_log = (uint64_t)n_cs * (2 + 2 * std::min<uint64_t>(cfg->max_iterations, 1u << 20));
+    // (only the sixteen non-linear kinds have a degenerate guard)
+    uint64_t n_guarded = 0;
+    for (size_t i = 0; i < n_cs; ++i) n_guarded += kind_is_linear(cs[i].kind) ? 0 : 1;
+    uint64_t want_log = n_guarded * (2 + 2 * std::min<uint64_t>(cfg->max_iterations, 1u << 20));
     uint32_t log_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want_log, 1), 1u << 22);
     std::unique_ptr<uint64_t[]> log_store(new uint64_t[log_cap]);  // uninitialised: only written entries are read
     uint64_t* log = log_store.get();
@@ -300,22 +303,40 @@ int solve_impl(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var
     for (size_t i = 0; i < n_guesses; ++i) max_id = std::max<size_t>(max_id, var_ids ? var_ids[i] : i);
     std::vector<double> initial_values(max_id + 1, 0.0);
     for (size_t i = 0; i < n_guesses; ++i) initial_values[var_ids ? var_ids[i] : i] = guesses[i];
-    std::vector<EzpzConstraint> reqs(reqs_in, reqs_in + n_reqs);
-    for (auto& c : reqs) {
+    // (the request list is copied only if some side has to be filled in: 200 000 requests are 11 MB)
+    std::vector<EzpzConstraint> resolved;
+    const EzpzConstraint* reqs = reqs_in;
+    for (size_t i = 0; i < n_reqs; ++i) {
+        const EzpzConstraint& c = reqs_in[i];
         if ((c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE || c.kind == EZPZ_CIRCLE_TANGENT_TO_CIRCLE) &&
             c.tag == EZPZ_SIDE_UNDEFINED) {
             bool ok = n_guesses > 0;
             int cnt = c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE ? 7 : 6;
             for (int k = 0; k < cnt; ++k)
                 if (c.ids[k] > max_id) ok = false;  // the reference would panic on this index; leave Undefined
-            if (ok) set_from_initial_values(c, initial_values);
+            if (ok) {
+                if (resolved.empty()) {
+                    resolved.assign(reqs_in, reqs_in + n_reqs);
+                    reqs = resolved.data();
+                }
+                set_from_initial_values(resolved[i], initial_values);
+            }
         }
     }
-    // distinct priorities, ascending (lib.rs:199-203)
+    // distinct priorities, ascending (lib.rs:199-203); one tier is the common case and needs no sort
     std::vector<uint32_t> prios;
-    for (auto& c : reqs) prios.push_back(c.priority);
-    std::sort(prios.begin(), prios.end());
-    prios.erase(std::unique(prios.begin(), prios.end()), prios.end());
+    {
+        bool one_tier = true;
+        for (size_t i = 1; i < n_reqs && one_tier; ++i) one_tier = reqs[i].priority == reqs[0].priority;
+        if (one_tier) {
+            prios.push_back(reqs[0].priority);
+        } else {
+            for (size_t i = 0; i < n_reqs; ++i) prios.push_back(reqs[i].priority);
+            std::sort(prios.begin(), prios.end());
+            prios.erase(std::unique(prios.begin(), prios.end()), prios.end());
+        }
+    }
+    const bool single_tier = prios.size() == 1;
 
     std::vector<EzpzConstraint> subset;
     std::vector<uint64_t> subset_ids;
@@ -334,17 +355,25 @@ int solve_impl(const EzpzConstraint* reqs_in, size_t n_reqs, const uint32_t* var
         }
     };
     for (uint32_t curr_max_priority : prios) {
-        subset.clear();
-        subset_ids.clear();
-        for (size_t i = 0; i < n_reqs; ++i) {
-            if (reqs[i].priority <= curr_max_priority) {
-                subset.push_back(reqs[i]);
-                subset_ids.push_back(i);
+        const EzpzConstraint* tier = reqs;  // a single tier is the whole list, ids = positions
+        const uint64_t* tier_ids = nullptr;
+        size_t tier_n = n_reqs;
+        if (!single_tier) {
+            subset.clear();
+            subset_ids.clear();
+            for (size_t i = 0; i < n_reqs; ++i) {
+                if (reqs[i].priority <= curr_max_priority) {
+                    subset.push_back(reqs[i]);
+                    subset_ids.push_back(i);
+                }
             }
+            tier = subset.data();
+            tier_ids = subset_ids.data();
+            tier_n = subset.size();
         }
         EzpzOutcome o;
-        int rc = solve_inner_impl(subset.data(), subset_ids.data(), subset.size(), var_ids, guesses, n_guesses, cfg,
-                                  x_try.data(), unsat_try.data(), warn_try.data(), warn_cap, &o,
+        int rc = solve_inner_impl(tier, tier_ids, tier_n, var_ids, guesses, n_guesses, cfg, x_try.data(),
+                                  unsat_try.data(), warn_try.data(), warn_cap, &o,
                                   under_out ? under_try.data() : nullptr, &n_under_try);
         if (rc == EZPZ_OK) {
             if (o.n_unsatisfied > 0 && have_res) break;  // lib.rs:232-234
