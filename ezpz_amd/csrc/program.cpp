@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory_resource>
 #include <numeric>
 #include <queue>
 
@@ -37,21 +38,40 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // keep the natural order instead.
 constexpr size_t kMinDegLimit = 4096;
 
-void order_component(const std::vector<uint32_t>& verts, const std::vector<std::vector<uint32_t>>& adj,
-                     std::vector<uint32_t>& local_id, std::vector<uint32_t>& out_order) {
+// Stable counting sort: perm[i] = the element that comes i-th when ordered by key (< n_keys), ties in `input` order.
+// `input` is the current order (a permutation or identity given as nullptr).
+std::vector<uint32_t> counting_order(const std::vector<uint32_t>& key, uint32_t n_keys, const std::vector<uint32_t>* input) {
+    const size_t n = key.size();
+    std::vector<uint32_t> start((size_t)n_keys + 1, 0), perm(n);
+    for (size_t i = 0; i < n; ++i) ++start[key[i] + 1];
+    for (uint32_t k = 0; k < n_keys; ++k) start[k + 1] += start[k];
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t e = input ? (*input)[i] : (uint32_t)i;
+        perm[start[key[e]]++] = e;
+    }
+    return perm;
+}
+
+// The symbolic phase builds hundreds of thousands of short index lists (one per variable, several times over) and
+// throws them all away at the end: they live in one monotonic arena per build_program call instead of the heap.
+using IVec = std::pmr::vector<uint32_t>;
+using IVecs = std::pmr::vector<IVec>;
+
+void order_component(const std::vector<uint32_t>& verts, const IVecs& adj, std::vector<uint32_t>& local_id,
+                     std::vector<uint32_t>& out_order, std::pmr::memory_resource* pool) {
     const size_t k = verts.size();
     if (k <= 2 || k > kMinDegLimit) {
         for (uint32_t v : verts) out_order.push_back(v);
         return;
     }
     for (size_t i = 0; i < k; ++i) local_id[verts[i]] = (uint32_t)i;
-    std::vector<std::vector<uint32_t>> g(k);
+    IVecs g(k, pool);
     for (size_t i = 0; i < k; ++i) {
         for (uint32_t w : adj[verts[i]]) g[i].push_back(local_id[w]);
         std::sort(g[i].begin(), g[i].end());
     }
-    std::vector<char> gone(k, 0);
-    std::vector<uint32_t> merged;
+    std::pmr::vector<char> gone(k, 0, pool);
+    IVec merged(pool), nb(pool);
     for (size_t step = 0; step < k; ++step) {
         size_t best = k;
         size_t best_deg = (size_t)-1;
@@ -63,12 +83,12 @@ void order_component(const std::vector<uint32_t>& verts, const std::vector<std::
         }
         gone[best] = 1;
         out_order.push_back(verts[best]);
-        const std::vector<uint32_t> nb = g[best];
+        nb.assign(g[best].begin(), g[best].end());
         for (uint32_t u : nb) {
             // g[u] = (g[u] \ {best}) U (nb \ {u})
             merged.clear();
             std::set_union(g[u].begin(), g[u].end(), nb.begin(), nb.end(), std::back_inserter(merged));
-            std::vector<uint32_t>& gu = g[u];
+            IVec& gu = g[u];
             gu.clear();
             for (uint32_t w : merged)
                 if (w != u && w != best) gu.push_back(w);
@@ -79,11 +99,11 @@ void order_component(const std::vector<uint32_t>& verts, const std::vector<std::
 
 // Number of strictly-lower entries of the Cholesky factor of one component under the elimination order `ord`
 // (symbolic elimination with an elimination tree; O(nnz(L))).
-uint64_t component_fill(const std::vector<uint32_t>& ord, const std::vector<std::vector<uint32_t>>& adj,
-                        std::vector<uint32_t>& local_id) {
+uint64_t component_fill(const std::vector<uint32_t>& ord, const IVecs& adj, std::vector<uint32_t>& local_id,
+                        std::pmr::memory_resource* pool) {
     const size_t k = ord.size();
     for (size_t i = 0; i < k; ++i) local_id[ord[i]] = (uint32_t)i;
-    std::vector<uint32_t> parent(k, NONE), ancestor(k, NONE), flag(k, NONE);
+    IVec parent(k, NONE, pool), ancestor(k, NONE, pool), flag(k, NONE, pool);
     uint64_t fill = 0;
     for (uint32_t p = 0; p < k; ++p) {
         flag[p] = p;
@@ -153,7 +173,9 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     // deduplicates (row,col) pairs and accumulates partials into the shared cell, solver.rs:255-260,:418).
     std::vector<DevCon> cons(C);
     // column view of J, built in row order so b = -Jt r sums rows ascending
-    std::vector<std::vector<uint32_t>> colj(n);  // (jslot,row) flattened
+    std::pmr::monotonic_buffer_resource arena(1u << 20);
+    std::pmr::memory_resource* pool = &arena;
+    IVecs colj(n, pool);  // (jslot,row) flattened
     // row view: cols and slots per row (unique)
     std::vector<uint32_t> row_ptr(m + 1, 0), row_col, row_slot;
     row_col.reserve((size_t)m * 4);
@@ -208,7 +230,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     P.c.zj = jslot;
 
     // ---- JtJ graph, connected components ----------------------------------------------------------------
-    std::vector<std::vector<uint32_t>> adj(n);
+    IVecs adj(n, pool);
     for (uint32_t r = 0; r < m; ++r) {
         for (uint32_t a = row_ptr[r]; a < row_ptr[r + 1]; ++a)
             for (uint32_t b = row_ptr[r]; b < row_ptr[r + 1]; ++b)
@@ -249,8 +271,9 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
             }
             std::sort(verts.begin(), verts.end());
             cand.clear();
-            order_component(verts, adj, local_id, cand);
-            if (cand != verts && component_fill(verts, adj, local_id) <= component_fill(cand, adj, local_id)) cand = verts;
+            order_component(verts, adj, local_id, cand, pool);
+            if (cand != verts && component_fill(verts, adj, local_id, pool) <= component_fill(cand, adj, local_id, pool))
+                cand = verts;
             order.insert(order.end(), cand.begin(), cand.end());
             ++ncomp;
         }
@@ -260,7 +283,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     for (uint32_t k = 0; k < n; ++k) pos[order[k]] = k;
 
     // ---- symbolic Cholesky in elimination order: etree, row patterns, levels ------------------------------
-    std::vector<std::vector<uint32_t>> upper(n);  // upper[k] = positions i<k adjacent to k
+    IVecs upper(n, pool);  // upper[k] = positions i<k adjacent to k
     for (uint32_t k = 0; k < n; ++k) {
         for (uint32_t w : adj[order[k]])
             if (pos[w] < k) upper[k].push_back(pos[w]);
@@ -278,8 +301,8 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
             }
         }
     }
-    std::vector<std::vector<uint32_t>> rowpat(n);   // columns j<k with L(k,j) != 0, ascending
-    std::vector<std::vector<uint32_t>> colrows(n);  // rows k>j with L(k,j) != 0, ascending
+    IVecs rowpat(n, pool);   // columns j<k with L(k,j) != 0, ascending
+    IVecs colrows(n, pool);  // rows k>j with L(k,j) != 0, ascending
     {
         std::vector<uint32_t> flag(n, NONE);
         uint64_t zlo = 0;
@@ -341,14 +364,17 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     P.c.n_parts = n_parts;
     auto part_of_pos = [&](uint32_t k) { return part_of_comp[comp[order[k]]]; };
     // columns grouped by (partition, level)
-    std::vector<uint32_t> colorder(n);
+    // stable order by (partition, level), ties in elimination order: two counting passes (level, then partition)
+    std::vector<uint32_t> colorder;
     {
-        // stable order by (partition, level): the key is materialised once (three dependent lookups per column are
-        // too slow inside a comparator for 200 000 columns), ties keep the elimination order through the index
-        std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
-        for (uint32_t k = 0; k < n; ++k) keyed[k] = {((uint64_t)part_of_pos(k) << 32) | level[k], k};
-        std::sort(keyed.begin(), keyed.end());
-        for (uint32_t k = 0; k < n; ++k) colorder[k] = keyed[k].second;
+        std::vector<uint32_t> pkey(n);
+        uint32_t max_level = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            pkey[k] = part_of_pos(k);
+            max_level = std::max(max_level, level[k]);
+        }
+        const std::vector<uint32_t> by_level = counting_order(level, max_level + 1, nullptr);
+        colorder = counting_order(pkey, n_parts, &by_level);
     }
     P.parts.assign(n_parts, PartDesc{0, 0, 0, 0});
     P.lvl_cptr.clear();
@@ -382,7 +408,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     P.c.n_levels = nlev;
     const uint32_t zlo = P.c.zlo;
     // slot lookup per row: rowslot[k][t] = slot of (k, rowpat[k][t])
-    std::vector<std::vector<uint32_t>> rowslot(n);
+    IVecs rowslot(n, pool);
     for (uint32_t k = 0; k < n; ++k) rowslot[k].resize(rowpat[k].size());
     P.l_col.assign(zlo, 0);
     {
@@ -530,12 +556,12 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     // ---- kind-sort the constraint table (wave-uniform evaluator branches) -------------------------------------------------
     auto part_of_con = [&](const DevCon& d) { return part_of_comp[comp[d.ids[kKinds[d.kind].nz[0][0]]]]; };
     {
-        // stable order by (partition, kind): sort (key, position) pairs and move each 80-byte record once
-        std::vector<std::pair<uint64_t, uint32_t>> keyed(C);
-        for (uint32_t i = 0; i < C; ++i) keyed[i] = {((uint64_t)part_of_con(cons[i]) << 8) | cons[i].kind, i};
-        std::sort(keyed.begin(), keyed.end());
+        // stable order by (partition, kind): one counting pass, then every 80-byte record moves once
+        std::vector<uint32_t> key(C);
+        for (uint32_t i = 0; i < C; ++i) key[i] = part_of_con(cons[i]) * (uint32_t)EZPZ_NUM_KINDS + cons[i].kind;
+        const std::vector<uint32_t> perm = counting_order(key, n_parts * (uint32_t)EZPZ_NUM_KINDS, nullptr);
         std::vector<DevCon> sorted(C);
-        for (uint32_t i = 0; i < C; ++i) sorted[i] = cons[keyed[i].second];
+        for (uint32_t i = 0; i < C; ++i) sorted[i] = cons[perm[i]];
         cons.swap(sorted);
     }
     {
