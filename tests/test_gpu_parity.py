@@ -133,7 +133,7 @@ def test_square_batch_file_guesses_and_random_integer_guesses(E):
 
 def test_square_full_size_batch_properties(E):
     """65 536 systems (BASELINE configs[2]): size-independent properties -- every system satisfied, geometry is a
-    4x4 axis-aligned square on (0,0),(4,4), and a strided sample equals the oracle."""
+    4x4 axis-aligned square on (0,0),(4,4) -- and every one of them against the oracle (3 ... 21 iterations)."""
     text = read_case("square")
     ref = T.load(text)
     B = 65536
@@ -144,10 +144,10 @@ def test_square_full_size_batch_properties(E):
     a, b, c, d = x[:, 0:2], x[:, 2:4], x[:, 4:6], x[:, 6:8]
     assert np.all(np.abs(a) < 1e-4) and np.all(np.abs(c - 4.0) < 1e-4)
     assert np.all(np.abs(b - np.array([4.0, 0.0])) < 1e-4) and np.all(np.abs(d - np.array([0.0, 4.0])) < 1e-4)
-    sample = np.arange(0, B, 257)
-    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0[sample])
-    assert np.array_equal(st["iterations"][sample], it)
-    assert_x_close(x[sample], xo)
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0)
+    assert np.array_equal(st["iterations"], it) and len(np.unique(it)) > 10
+    assert np.array_equal(st["converged"], conv) and np.array_equal(st["n_unsatisfied"], nun)
+    assert_x_close(x, xo)
 
 
 @pytest.mark.parametrize("team", [1, 2, 4, 8, 16, 32, 64, 128, 256])
@@ -175,7 +175,7 @@ def test_mixed_topologies_batch(E):
         recs = ref.constraints.copy()
         for i in range(len(recs)):
             recs[i] = O.set_from_initial_values(recs[i], ref.guesses)
-        x0 = ref.guesses[None, :] + gen.keyed_uniform(0x657A707A + k, 1000, ref.num_vars, -0.1, 0.1)
+        x0 = ref.guesses[None, :] + gen.keyed_uniform(0x657A707A + k, 30000, ref.num_vars, -0.1, 0.1)
         sysobj = E.System(recs, ref.num_vars)
         x, st, _ = sysobj.solve_batch(x0)
         rc, xo, it, conv, nun = O.solve_batch(recs, x0)
