@@ -317,6 +317,28 @@ def test_large_ladder_grid_team_and_global_workspace(E):
     assert (st["iterations"][0], bool(st["converged"][0])) == (want.iterations, want.converged)
 
 
+def test_grid_team_with_nonlinear_constraints_and_warnings(E):
+    """The over-constrained ladder (gen_big_problem.py N true: a distance per line, 60 000 rows) on a grid team of the
+    general build: iteration counts and values as the oracle, and the Degenerate warnings of a start with every point
+    coincident are counted across all workgroups and come back in the reference's order."""
+    ref = T.load(T.gen_big_problem(12000, True))
+    sysobj = E.System(ref.constraints, ref.num_vars)
+    assert sysobj.info()["grid_workgroups"] > 1
+    x0 = np.tile(ref.guesses, (3, 1))
+    x0[1] += 0.05
+    x0[2, :] = 1.0
+    x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+    for b in range(3):
+        want = O.solve(ref.constraints, x0[b], linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert (int(st["iterations"][b]), bool(st["converged"][b])) == (want.iterations, want.converged)
+        assert int(st["n_warnings"][b]) == len(want.warnings)
+        assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied
+        assert_x_close(x[b], want.final_values)
+    assert st["n_warnings"][2] == 12000
+    got = E.solve_records(O.stack(ref.constraints), x0[2], warn_cap=1 << 16)
+    assert got.warnings == want.warnings
+
+
 def test_empty_batch_and_ragged_sizes(E):
     text = read_case("tiny")
     ref = T.load(text)
