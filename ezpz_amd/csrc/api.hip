@@ -102,8 +102,11 @@ struct EzpzSystem {
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
     DevBuf<GridScratch> grid_scratch;
-    DevBuf<GridWgDesc> grid_desc;
-    std::vector<GridWgDesc> host_grid_desc;
+    std::vector<unsigned char> grid_blob;       // the workgroups' sub-programs, one after the other
+    std::vector<ProgramView> host_grid_views;   // per workgroup; blob_bytes = offset of its slice in grid_blob
+    size_t grid_stage_bytes = 0;
+    void* dev_grid_blob = nullptr;
+    DevBuf<ProgramView> grid_views;
     uint32_t prog_lds_doubles = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
@@ -131,6 +134,7 @@ struct EzpzSystem {
     } freedom;
     ~EzpzSystem() {
         if (dev_program) (void)hipFree(dev_program);
+        if (dev_grid_blob) (void)hipFree(dev_grid_blob);
     }
 };
 
@@ -190,10 +194,12 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
         s.lds_bytes = prog_bytes + (size_t)(s.block_threads / team) * ws_bytes + 16;
     } else {
         s.block_threads = s.team_size;
-        if (s.grid_wgs > 1) {
+        if (s.grid_wgs > 1) {  // every workgroup stages its own sub-program's lists
             s.ws_doubles = s.grid_ws_doubles;
             s.lds_ws = true;
-            s.lds_bytes = prog_bytes + (size_t)s.ws_doubles * 8 + 64 * 8 + 16;
+            s.prog_in_lds = true;
+            s.prog_lds_doubles = (uint32_t)((s.grid_stage_bytes + 15) / 16 * 2);
+            s.lds_bytes = (size_t)s.prog_lds_doubles * 8 + (size_t)s.ws_doubles * 8 + 64 * 8 + 16;
         } else {
             s.lds_ws = prog_bytes + ws_bytes + 1024 <= kLdsBytesMax;
             s.lds_bytes = s.lds_ws ? prog_bytes + ws_bytes + 64 * 8 + 16 : prog_bytes + 80 * 8;
@@ -234,7 +240,7 @@ int launch_sub(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStr
 // systems in flight as the device holds.
 template <bool LIN>
 int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
-    auto kernel = lm_solve_kernel<64, MODE_PART, true, false, LIN>;
+    auto kernel = lm_solve_kernel<64, MODE_PART, true, true, LIN, true>;
     if (s.lds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)s.lds_bytes));
@@ -244,17 +250,23 @@ int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (capacity < s.grid_wgs) return EZPZ_ERR_TOO_LARGE;
     const uint32_t slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(args.batch, capacity / s.grid_wgs));
     int rc;
-    if (s.grid_desc.cap < s.host_grid_desc.size()) {
-        if ((rc = s.grid_desc.ensure(s.host_grid_desc.size())) != EZPZ_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(s.grid_desc.p, s.host_grid_desc.data(), s.host_grid_desc.size() * sizeof(GridWgDesc),
-                               hipMemcpyHostToDevice, stream));
+    if (!s.dev_grid_blob) {  // first launch: the workgroups' sub-programs and their views
+        HIP_TRY(hipMalloc(&s.dev_grid_blob, s.grid_blob.size()));
+        HIP_TRY(hipMemcpy(s.dev_grid_blob, s.grid_blob.data(), s.grid_blob.size(), hipMemcpyHostToDevice));
+        std::vector<ProgramView> views = s.host_grid_views;
+        for (ProgramView& pv : views) {
+            pv.base = static_cast<const unsigned char*>(s.dev_grid_blob) + pv.blob_bytes;
+            pv.blob_bytes = 0;
+        }
+        if ((rc = s.grid_views.ensure(views.size())) != EZPZ_OK) return rc;
+        HIP_TRY(hipMemcpy(s.grid_views.p, views.data(), views.size() * sizeof(ProgramView), hipMemcpyHostToDevice));
     }
     if (s.grid_scratch.cap < slots) {
         if ((rc = s.grid_scratch.ensure(slots)) != EZPZ_OK) return rc;
         HIP_TRY(hipMemsetAsync(s.grid_scratch.p, 0, s.grid_scratch.cap * sizeof(GridScratch), stream));
     }
     args.grid_scratch = s.grid_scratch.p;
-    args.grid_desc = s.grid_desc.p;
+    args.grid_views = s.grid_views.p;
     args.grid_wgs = s.grid_wgs;
     void* params[] = {&args};
     HIP_TRY(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(slots * s.grid_wgs),
@@ -372,6 +384,157 @@ const char* ezpz_error_string(int err) {
     }
 }
 
+// Serialises a program: [index lists][jloc patterns] | [partitions][constraint table (+ side arrays)].  The lists go
+// first so that a workgroup can stage exactly them in LDS; `idx16` stores them as 16-bit indices.  `pack_table` turns
+// the constraint table into 32-byte PackedCon records + side arrays (workgroup teams read it from L2 in every sweep);
+// it is honoured only with idx16 and at most 256 distinct jloc patterns.  Returns the byte size of the leading
+// (stageable) part; fills every offset of `v` (not base / stage_bytes).
+static size_t pack_program(const Program& P, bool idx16, bool pack_table, std::vector<unsigned char>& blob, ProgramView& v) {
+    blob.clear();
+    auto put = [&](const std::vector<uint32_t>& src) -> uint32_t {
+        if (!idx16) return (uint32_t)append(blob, src);
+        std::vector<uint16_t> t(src.begin(), src.end());
+        return (uint32_t)append(blob, t);
+    };
+    v.o_colj_ptr = put(P.colj_ptr);
+    v.o_colj_items = put(P.colj_items);
+    v.o_apair_ptr = put(P.apair_ptr);
+    v.o_apairs = put(P.apairs);
+    v.o_lvl_cptr = put(P.lvl_cptr);
+    v.o_lvl_sptr = put(P.lvl_sptr);
+    v.o_l_col = put(P.l_col);
+    v.o_lpair_ptr = put(P.lpair_ptr);
+    v.o_lpairs = put(P.lpairs);
+    v.o_fwd_ptr = put(P.fwd_ptr);
+    v.o_fwd_items = put(P.fwd_items);
+    v.o_bwd_ptr = put(P.bwd_ptr);
+    v.o_bwd_items = put(P.bwd_items);
+    v.o_var_of = (uint32_t)append(blob, P.var_of);
+    blob.resize((blob.size() + 15) & ~size_t(15));
+    v.packed = 0;
+    v.o_pos = v.o_weights = v.o_patterns = 0;
+    std::vector<PackedCon> packed;
+    if (idx16 && pack_table) {
+        std::vector<std::array<uint8_t, 16>> patterns;
+        packed.resize(P.cons.size());
+        bool ok = true;
+        for (size_t i = 0; i < P.cons.size() && ok; ++i) {
+            const DevCon& d = P.cons[i];
+            std::array<uint8_t, 16> pat;
+            std::memcpy(pat.data(), d.jloc, 16);
+            size_t k = 0;
+            while (k < patterns.size() && patterns[k] != pat) ++k;
+            if (k == patterns.size()) patterns.push_back(pat);
+            if (k > 255) ok = false;
+            PackedCon& q = packed[i];
+            for (int e = 0; e < 8; ++e) q.ids[e] = (uint16_t)d.ids[e];
+            q.param = d.param;
+            q.row0 = (uint16_t)d.row0;
+            q.jbase = (uint16_t)d.jbase;
+            q.kind = d.kind;
+            q.tag = d.tag;
+            q.nrows = d.nrows;
+            q.pattern = (uint8_t)k;
+        }
+        if (ok) {
+            v.packed = 1;
+            v.o_patterns = (uint32_t)append(blob, patterns);
+            blob.resize((blob.size() + 15) & ~size_t(15));
+        }
+    }
+    const size_t lists_bytes = blob.size();
+    v.o_parts = (uint32_t)append(blob, P.parts);
+    blob.resize((blob.size() + 15) & ~size_t(15));
+    if (v.packed) {
+        v.o_cons = (uint32_t)append(blob, packed);
+        std::vector<uint32_t> pos(P.cons.size());
+        std::vector<double> weights(P.cons.size());
+        for (size_t i = 0; i < P.cons.size(); ++i) {
+            pos[i] = P.cons[i].pos;
+            weights[i] = P.cons[i].weight;
+        }
+        v.o_pos = (uint32_t)append(blob, pos);
+        blob.resize((blob.size() + 15) & ~size_t(15));
+        v.o_weights = (uint32_t)append(blob, weights);
+    } else {
+        v.o_cons = (uint32_t)append(blob, P.cons);
+    }
+    blob.resize((blob.size() + 15) & ~size_t(15));
+    v.blob_bytes = (uint32_t)blob.size();
+    v.n_cons = P.c.n_cons;
+    v.n_vars = P.c.n_vars;
+    v.n_rows = P.c.n_rows;
+    v.zj = P.c.zj;
+    v.zlo = P.c.zlo;
+    v.n_parts = P.c.n_parts;
+    return lists_bytes;
+}
+
+// The program of partitions [p0, p1) alone, renumbered from zero.  The internal numbering is partition-major in every
+// index space (variables, rows, Jacobian slots, L slots, constraints), so a run of partitions is a contiguous range of
+// each and the slice is the same lists minus the range's first index.  A grid team's workgroup runs exactly like a
+// workgroup team on its slice.
+static Program slice_program(const Program& P, uint32_t p0, uint32_t p1) {
+    Program S;
+    const PartDesc& first = P.parts[p0];
+    const PartDesc& last = P.parts[p1 - 1];
+    const uint32_t C = P.c.n_cons;
+    const uint32_t v0 = P.lvl_cptr[first.lvl0], v1 = P.lvl_cptr[last.lvl0 + last.nlev];
+    const uint32_t l0 = P.lvl_sptr[first.lvl0], l1 = P.lvl_sptr[last.lvl0 + last.nlev];
+    const uint32_t c0 = first.con0, c1 = last.con1;
+    const uint32_t r0 = c0 < C ? P.cons[c0].row0 : P.c.n_rows, r1 = c1 < C ? P.cons[c1].row0 : P.c.n_rows;
+    const uint32_t j0 = c0 < C ? P.cons[c0].jbase : P.c.zj, j1 = c1 < C ? P.cons[c1].jbase : P.c.zj;
+    const uint32_t lvl_a = first.lvl0, lvl_b = last.lvl0 + last.nlev + 1;  // this run's entries of lvl_cptr / lvl_sptr
+    S.c = P.c;
+    S.c.n_cons = c1 - c0;
+    S.c.n_vars = v1 - v0;
+    S.c.n_rows = r1 - r0;
+    S.c.zj = j1 - j0;
+    S.c.zlo = l1 - l0;
+    S.c.n_parts = p1 - p0;
+    for (uint32_t p = p0; p < p1; ++p) {
+        PartDesc d = P.parts[p];
+        d.con0 -= c0;
+        d.con1 -= c0;
+        d.lvl0 -= lvl_a;
+        S.parts.push_back(d);
+    }
+    for (uint32_t k = lvl_a; k < lvl_b; ++k) {
+        S.lvl_cptr.push_back(P.lvl_cptr[k] - v0);
+        S.lvl_sptr.push_back(P.lvl_sptr[k] - l0);
+    }
+    // CSR slices: ptr[a..b] rebased, items (x - bx, y - by)
+    auto csr = [](const std::vector<uint32_t>& ptr, const std::vector<uint32_t>& items, uint32_t a, uint32_t b,
+                  uint32_t bx, uint32_t by, std::vector<uint32_t>& optr, std::vector<uint32_t>& oitems) {
+        const uint32_t q0 = ptr[a], q1 = ptr[b];
+        optr.resize(b - a + 1);
+        for (uint32_t k = a; k <= b; ++k) optr[k - a] = ptr[k] - q0;
+        oitems.resize(2 * (size_t)(q1 - q0));
+        for (uint32_t q = q0; q < q1; ++q) {
+            oitems[2 * (q - q0)] = items[2 * q] - bx;
+            oitems[2 * (q - q0) + 1] = items[2 * q + 1] - by;
+        }
+    };
+    csr(P.colj_ptr, P.colj_items, v0, v1, j0, r0, S.colj_ptr, S.colj_items);
+    csr(P.apair_ptr, P.apairs, l0, l1, j0, j0, S.apair_ptr, S.apairs);
+    csr(P.lpair_ptr, P.lpairs, l0, l1, l0, l0, S.lpair_ptr, S.lpairs);
+    csr(P.fwd_ptr, P.fwd_items, v0, v1, l0, v0, S.fwd_ptr, S.fwd_items);
+    csr(P.bwd_ptr, P.bwd_items, v0, v1, l0, v0, S.bwd_ptr, S.bwd_items);
+    S.c.n_apairs = S.apairs.size() / 2;
+    S.c.n_lpairs = S.lpairs.size() / 2;
+    S.l_col.assign(P.l_col.begin() + l0, P.l_col.begin() + l1);
+    for (uint32_t& v : S.l_col) v -= v0;
+    S.var_of.assign(P.var_of.begin() + v0, P.var_of.begin() + v1);
+    S.cons.assign(P.cons.begin() + c0, P.cons.begin() + c1);
+    for (DevCon& d : S.cons) {
+        const KindInfo& K = kKinds[d.kind];
+        for (int k = 0; k < K.n_ids; ++k) d.ids[k] = d.ids[k] >= v0 && d.ids[k] < v1 ? d.ids[k] - v0 : 0;
+        d.row0 -= r0;
+        d.jbase -= j0;
+    }
+    return S;
+}
+
 // Symbolic phase + launch-shape decision shared by ezpz_system_create and ezpz_analyze.
 static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t team_size, EzpzSystem& s,
                         Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable) {
@@ -431,37 +594,6 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             G = 1;
             if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
         }
-        // a grid team keeps each workgroup's share of the state in that workgroup's LDS
-        s.host_grid_desc.clear();
-        if (G > 1) {
-            const uint32_t W = team / 64;
-            uint32_t worst = 0;
-            for (uint32_t g = 0; g < G; ++g) {
-                const PartDesc& first = P.parts[g * W];
-                const PartDesc& last = P.parts[g * W + W - 1];
-                GridWgDesc d{};
-                d.v0 = P.lvl_cptr[first.lvl0];
-                d.nv = P.lvl_cptr[last.lvl0 + last.nlev] - d.v0;
-                d.l0 = P.lvl_sptr[first.lvl0];
-                d.nl = P.lvl_sptr[last.lvl0 + last.nlev] - d.l0;
-                const uint32_t c0 = first.con0, c1 = last.con1, C = P.c.n_cons;
-                d.r0 = c0 < C ? P.cons[c0].row0 : P.c.n_rows;
-                d.nr = (c1 < C ? P.cons[c1].row0 : P.c.n_rows) - d.r0;
-                d.j0 = c0 < C ? P.cons[c0].jbase : P.c.zj;
-                d.nj = (c1 < C ? P.cons[c1].jbase : P.c.zj) - d.j0;
-                worst = std::max(worst, 3 * d.nv + 2 * d.nr + d.nj + d.nl);
-                s.host_grid_desc.push_back(d);
-            }
-            if (((size_t)worst + 4) * 8 + 2048 > 128 * 1024) {  // a share does not fit: one workgroup per system
-                G = 1;
-                s.host_grid_desc.clear();
-                Program Q;
-                if (!build_program(cs, n_cs, n_vars, Q, be, team / 64)) return fail();
-                P = std::move(Q);
-            } else {
-                s.grid_ws_doubles = (worst + 4 + 1) & ~1u;
-            }
-        }
         s.grid_wgs = G;
         s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;
         s.team_size = team;
@@ -478,89 +610,13 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     s.host_slot_row = P.slot_row;
     s.host_slot_col = P.slot_col;
 
-    // ---- pack the blob: [index lists][partitions][constraint table] ---------------------------------------------
-    // The lists go first so that a workgroup can stage exactly them in LDS; they are 16-bit when staged.
+    // ---- pack the blob (pack_program) ----------------------------------------------------------------------------
     const bool small_counts = P.c.n_vars < 65536 && P.c.n_rows < 65536 && P.c.zj < 65536 && P.c.zlo < 65536 &&
                               P.c.n_apairs < 65536 && P.c.n_lpairs < 65536 && P.c.n_cons < 65536;
     ProgramView& v = s.view;
-    auto pack = [&](bool idx16) {
-        blob.clear();
-        auto put = [&](const std::vector<uint32_t>& src) -> uint32_t {
-            if (!idx16) return (uint32_t)append(blob, src);
-            std::vector<uint16_t> t(src.begin(), src.end());
-            return (uint32_t)append(blob, t);
-        };
-        v.o_colj_ptr = put(P.colj_ptr);
-        v.o_colj_items = put(P.colj_items);
-        v.o_apair_ptr = put(P.apair_ptr);
-        v.o_apairs = put(P.apairs);
-        v.o_lvl_cptr = put(P.lvl_cptr);
-        v.o_lvl_sptr = put(P.lvl_sptr);
-        v.o_l_col = put(P.l_col);
-        v.o_lpair_ptr = put(P.lpair_ptr);
-        v.o_lpairs = put(P.lpairs);
-        v.o_fwd_ptr = put(P.fwd_ptr);
-        v.o_fwd_items = put(P.fwd_items);
-        v.o_bwd_ptr = put(P.bwd_ptr);
-        v.o_bwd_items = put(P.bwd_items);
-        v.o_var_of = (uint32_t)append(blob, P.var_of);
-        blob.resize((blob.size() + 15) & ~size_t(15));
-        // Workgroup teams read the constraint table from L2 in every sweep: 32-byte records + side arrays.  The
-        // distinct jloc patterns (one per duplicate-id shape, normally a handful) are staged with the lists.
-        v.packed = 0;
-        v.o_pos = v.o_weights = v.o_patterns = 0;
-        std::vector<PackedCon> packed;
-        if (idx16 && s.mode != MODE_SUB) {
-            std::vector<std::array<uint8_t, 16>> patterns;
-            packed.resize(P.cons.size());
-            bool ok = true;
-            for (size_t i = 0; i < P.cons.size() && ok; ++i) {
-                const DevCon& d = P.cons[i];
-                std::array<uint8_t, 16> pat;
-                std::memcpy(pat.data(), d.jloc, 16);
-                size_t k = 0;
-                while (k < patterns.size() && patterns[k] != pat) ++k;
-                if (k == patterns.size()) patterns.push_back(pat);
-                if (k > 255) ok = false;
-                PackedCon& q = packed[i];
-                for (int e = 0; e < 8; ++e) q.ids[e] = (uint16_t)d.ids[e];
-                q.param = d.param;
-                q.row0 = (uint16_t)d.row0;
-                q.jbase = (uint16_t)d.jbase;
-                q.kind = d.kind;
-                q.tag = d.tag;
-                q.nrows = d.nrows;
-                q.pattern = (uint8_t)k;
-            }
-            if (ok) {
-                v.packed = 1;
-                v.o_patterns = (uint32_t)append(blob, patterns);
-                blob.resize((blob.size() + 15) & ~size_t(15));
-            }
-        }
-        const size_t lists_bytes = blob.size();
-        v.o_parts = (uint32_t)append(blob, P.parts);
-        blob.resize((blob.size() + 15) & ~size_t(15));
-        if (v.packed) {
-            v.o_cons = (uint32_t)append(blob, packed);
-            std::vector<uint32_t> pos(P.cons.size());
-            std::vector<double> weights(P.cons.size());
-            for (size_t i = 0; i < P.cons.size(); ++i) {
-                pos[i] = P.cons[i].pos;
-                weights[i] = P.cons[i].weight;
-            }
-            v.o_pos = (uint32_t)append(blob, pos);
-            blob.resize((blob.size() + 15) & ~size_t(15));
-            v.o_weights = (uint32_t)append(blob, weights);
-        } else {
-            v.o_cons = (uint32_t)append(blob, P.cons);
-        }
-        blob.resize((blob.size() + 15) & ~size_t(15));
-        return lists_bytes;
-    };
     size_t stage_bytes = 0;
     if (small_counts) {
-        const size_t lists_bytes = pack(true);
+        const size_t lists_bytes = pack_program(P, true, s.mode != MODE_SUB, blob, v);
         const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
         if (s.mode == MODE_SUB) {
             if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
@@ -568,19 +624,45 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             stage_bytes = lists_bytes;
         }
     }
-    if (stage_bytes == 0) pack(false);
+    if (stage_bytes == 0) pack_program(P, false, false, blob, v);
     if (blob.size() > 0xFFFFFFF0ull) {
         be.code = EZPZ_ERR_TOO_LARGE;
         return fail();
     }
-    v.blob_bytes = (uint32_t)blob.size();
     v.stage_bytes = (uint32_t)stage_bytes;
-    v.n_cons = P.c.n_cons;
-    v.n_vars = P.c.n_vars;
-    v.n_rows = P.c.n_rows;
-    v.zj = P.c.zj;
-    v.zlo = P.c.zlo;
-    v.n_parts = P.c.n_parts;
+    // ---- grid team: one sub-program per workgroup, every one of them staged like a workgroup team's --------------------------
+    s.grid_blob.clear();
+    s.host_grid_views.clear();
+    s.grid_ws_doubles = 0;
+    s.grid_stage_bytes = 0;
+    if (s.grid_wgs > 1) {
+        const uint32_t W = s.team_size / 64;
+        bool ok = true;
+        std::vector<unsigned char> sub;
+        for (uint32_t g = 0; g < s.grid_wgs && ok; ++g) {
+            const Program S = slice_program(P, g * W, g * W + W);
+            ProgramView sv{};
+            const bool fits16 = S.c.n_vars < 65536 && S.c.n_rows < 65536 && S.c.zj < 65536 && S.c.zlo < 65536 &&
+                                S.c.n_apairs < 65536 && S.c.n_lpairs < 65536 && S.c.n_cons < 65536;
+            const size_t lists_bytes = fits16 ? pack_program(S, true, true, sub, sv) : 0;
+            const uint32_t wsd = workspace_doubles(S.c);
+            if (!fits16 || !sv.packed || lists_bytes + (size_t)wsd * 8 + 2048 > kLdsBytesMax) {
+                ok = false;
+                break;
+            }
+            sv.stage_bytes = (uint32_t)lists_bytes;
+            sv.blob_bytes = (uint32_t)s.grid_blob.size();  // for a grid view: byte offset of this slice in the grid blob
+            s.grid_blob.insert(s.grid_blob.end(), sub.begin(), sub.end());
+            s.grid_blob.resize((s.grid_blob.size() + 255) & ~size_t(255));
+            s.host_grid_views.push_back(sv);
+            s.grid_ws_doubles = std::max(s.grid_ws_doubles, wsd);
+            s.grid_stage_bytes = std::max<size_t>(s.grid_stage_bytes, lists_bytes);
+        }
+        if (!ok || s.grid_blob.size() > 0xFFFFFFF0ull) {  // cannot happen for balanced partitions; be safe
+            be.code = EZPZ_ERR_TOO_LARGE;
+            return fail();
+        }
+    }
     finish_team(s, stage_bytes);
 
     EzpzSystemInfo& info = s.info;
@@ -716,7 +798,7 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.unit_weights = sys->unit_weights ? 1u : 0u;
     a.grid_wgs = 1;
     a.grid_scratch = nullptr;
-    a.grid_desc = nullptr;
+    a.grid_views = nullptr;
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }

@@ -178,15 +178,6 @@ __device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int s
     return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
 }
 
-// What workgroup g of a grid team owns, as contiguous ranges of the program's internal numbering; its LDS workspace
-// holds exactly these (indices are rebased by folding -first into the array offsets).
-struct GridWgDesc {
-    uint32_t v0, nv;  // variables (x, D, d)
-    uint32_t r0, nr;  // residual rows (r, r_next)
-    uint32_t j0, nj;  // Jacobian slots
-    uint32_t l0, nl;  // strictly-lower L slots
-};
-
 struct SolveArgs {
     ProgramView p;
     const double* x0;
@@ -204,7 +195,7 @@ struct SolveArgs {
     double residual_tolerance, step_tolerance, initial_lambda;
     unsigned long long* stamps;  // diagnostic builds (-DEZPZ_STAMPS) only: (id, s_memtime) pairs of block 0, lane 0
     GridScratch* grid_scratch;   // grid teams: one per system in flight
-    const GridWgDesc* grid_desc; // grid teams: per workgroup of a system
+    const ProgramView* grid_views;  // grid teams: the sub-program of each workgroup of a system
     uint32_t grid_wgs;           // workgroups per system (1 = every other team shape)
 };
 
@@ -298,7 +289,7 @@ __device__ __forceinline__ double reduce_lanes(double v, Op op) {
     return v;
 }
 
-template <int TEAM, int MODE>
+template <int TEAM, int MODE, bool GRID = false>
 struct Team {
     int lane;     // lane inside the unit that walks a phase (team for SUB, wave for PART, workgroup for WGB)
     int stride;   // lanes in that unit
@@ -355,7 +346,7 @@ struct Team {
                 b = opb(b, buf[16 + w]);
             }
             // the next reduction uses the other half of `red`, so no trailing barrier is needed
-            if constexpr (MODE == MODE_PART) {
+            if constexpr (GRID) {
                 if (grid_wgs > 1) {  // grid team: gather at workgroup 0, fold in a fixed tree, scatter the result
                     const unsigned int seq = ++grid_seq;
                     const unsigned int par = seq & 1u;
@@ -453,12 +444,14 @@ struct ConRef<2, PROG> {
 
 // LIN: every constraint of the topology is of a linear kind (see con_residual); the evaluators are built without
 // the other sixteen kinds.
-template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN>
+// GRID: the build for grid teams (several workgroups per system; MODE_PART with staged lists only).
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false>
 __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), MODE == MODE_SUB ? 4 : 1)
     lm_solve_kernel(const SolveArgs a) {
+    static_assert(!GRID || (MODE == MODE_PART && LDSWS && PLDS), "grid teams are partitioned teams with staged lists");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using namespace dev;
-    Team<TEAM, MODE> tm;
+    Team<TEAM, MODE, GRID> tm;
     const int tid = threadIdx.x;
     tm.red_flip = 0;
     if constexpr (MODE == MODE_SUB) {
@@ -476,23 +469,29 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     const int tsize = (MODE == MODE_SUB) ? TEAM : (int)blockDim.x;
     const uint32_t teams_per_block = (MODE == MODE_SUB) ? (uint32_t)(blockDim.x / TEAM) : 1u;
     const uint32_t team_in_block = (MODE == MODE_SUB) ? (uint32_t)(tid / TEAM) : 0u;
-    const uint32_t n = a.p.n_vars, m = a.p.n_rows, zj = a.p.zj, zlo = a.p.zlo;
+    // The program this workgroup runs: the launch's, or -- in a grid team -- its own slice of it (its partitions,
+    // renumbered from zero; see slice_program in api.hip).  Rows of x0 / x_out and of the masks stay system-wide.
+    constexpr bool GRID_OK = GRID;
+    ProgramView pv = a.p;
+    if (GRID_OK && a.grid_wgs > 1) pv = a.grid_views[blockIdx.x % a.grid_wgs];
+    const uint32_t n = pv.n_vars, m = pv.n_rows, zj = pv.zj, zlo = pv.zlo;
+    const uint32_t n_row = a.p.n_vars;  // values per system in x0 / x_out
 
     // ---- topology program: global/L2, or staged once per workgroup into LDS -------------------------------------
     // PLDS: the leading `stage_bytes` of the blob (the index lists; for sub-wavefront teams the whole blob incl. the
     // constraint table) are copied to LDS and the lists are 16-bit.
     using idx_t = typename std::conditional<PLDS, uint16_t, uint32_t>::type;
-    const unsigned char* lbase = a.p.base;
-    const unsigned char* tbase = a.p.base;
+    const unsigned char* lbase = pv.base;
+    const unsigned char* tbase = pv.base;
     if constexpr (PLDS) {
-        const uint4* src = reinterpret_cast<const uint4*>(a.p.base);
+        const uint4* src = reinterpret_cast<const uint4*>(pv.base);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < a.p.stage_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = tid; i < pv.stage_bytes / 16; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
         lbase = reinterpret_cast<const unsigned char*>(smem);
         if constexpr (MODE == MODE_SUB) tbase = lbase;
     }
-    const Prog<idx_t> P = make_prog<idx_t>(a.p, lbase, tbase);
+    const Prog<idx_t> P = make_prog<idx_t>(pv, lbase, tbase);
     // constraint records: in place from LDS (sub-wavefront teams with a staged program), 32-byte packed records from
     // L2 (workgroup teams with staged lists; the host packs the table exactly when PLDS holds), else the wide record
     constexpr int LIST_CHUNK = (MODE == MODE_SUB) ? 4 : 2;
@@ -501,7 +500,6 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     const bool unit_w = a.unit_weights != 0;
 
     // ---- grid team geometry (one system on several workgroups, each keeping its share of the state in LDS) ----------
-    constexpr bool GRID_OK = (MODE == MODE_PART && LDSWS && !PLDS);
     const uint32_t grid_wgs = GRID_OK ? a.grid_wgs : 1u;
     const uint32_t grid_wg = GRID_OK ? blockIdx.x % grid_wgs : 0u;  // this workgroup inside its system's group
     const uint32_t grid_slot = blockIdx.x / grid_wgs;               // which system-in-flight
@@ -536,29 +534,16 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         ws.p = a.gws + (size_t)blockIdx.x * a.ws_doubles;
         tm.red = smem;
     }
-    // offsets of x r r_next Jv D L d inside the workspace; a grid team's workgroup holds only its own ranges and
-    // folds "- first index" into the offsets (unsigned wrap-around, undone as soon as an index is added)
-    uint32_t o_x = 0;
+    // offsets of x r r_next Jv D L d inside the workspace (of this workgroup's program: a grid team's workgroup holds
+    // its own slice only)
+    const uint32_t o_x = 0;
     uint32_t o_r = n;
     uint32_t o_rn = n + m;
-    uint32_t o_j = n + 2 * m;
-    uint32_t o_d = o_j + zj;   // Cholesky diagonal, by variable
-    uint32_t o_l = o_d + n;    // strictly-lower L entries, (partition, level) grouped
-    uint32_t o_v = o_l + zlo;  // b, then y, then d (by variable)
-    uint32_t o_i = o_v + n;    // small int area
-    if (GRID_OK && grid_wgs > 1) {
-        const GridWgDesc gd = a.grid_desc[grid_wg];
-        const uint32_t bx = 0, br = gd.nv, brn = br + gd.nr, bj = brn + gd.nr, bd = bj + gd.nj, bl = bd + gd.nv,
-                       bv = bl + gd.nl;
-        o_x = bx - gd.v0;
-        o_r = br - gd.r0;
-        o_rn = brn - gd.r0;
-        o_j = bj - gd.j0;
-        o_d = bd - gd.v0;
-        o_l = bl - gd.l0;
-        o_v = bv - gd.v0;
-        o_i = bv + gd.nv;
-    }
+    const uint32_t o_j = n + 2 * m;
+    const uint32_t o_d = o_j + zj;   // Cholesky diagonal, by variable
+    const uint32_t o_l = o_d + n;    // strictly-lower L entries, (partition, level) grouped
+    const uint32_t o_v = o_l + zlo;  // b, then y, then d (by variable)
+    const uint32_t o_i = o_v + n;    // small int area
     int* nwarn;
     if constexpr (LDSWS) {
         nwarn = reinterpret_cast<int*>(&ws[o_i]);
@@ -567,7 +552,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     }
 
     // ---- this unit's partition --------------------------------------------------------------------------------------
-    const PartDesc part = P.parts[(MODE == MODE_PART) ? grid_wg * (blockDim.x >> 6) + (uint32_t)(tid >> 6) : 0u];
+    const PartDesc part = P.parts[(MODE == MODE_PART) ? (uint32_t)(tid >> 6) : 0u];
     const uint32_t con0 = part.con0, con1 = part.con1;
     const idx_t* lvl_cptr = P.lvl_cptr + part.lvl0;
     const idx_t* lvl_sptr = P.lvl_sptr + part.lvl0;
@@ -586,7 +571,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         int stamp_n = 0;
 #endif
         EZPZ_STAMP(1);
-        const double* x0 = a.x0 + sys * n;
+        const double* x0 = a.x0 + sys * n_row;
         if constexpr (MODE == MODE_PART) {
             // each wavefront loads (and later stores) its own partition's variables only: a wavefront that is already
             // on the next system never touches values another one has not stored yet
@@ -747,7 +732,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 // |r| is below EPSILON (every converged solve) no constraint can be unsatisfied (lib.rs:358-370)
                 if (largest < EPS) {
                     all_satisfied = true;
-                    if (a.unsat_mask)
+                    if (a.unsat_mask && grid_wg == 0)
                         for (uint32_t i = tlane; i < a.p.n_cons; i += tsize) a.unsat_mask[sys * a.p.n_cons + i] = 0;
                     break;
                 }
@@ -883,7 +868,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         const bool skip_count = all_satisfied && (OWN_STORE || MODE == MODE_SUB) && (!grid_team || LIN);
         if (!skip_count) tm.reduce2(unsat_cnt, dummy, OpSum(), OpSum());
         EZPZ_STAMP(31);
-        double* xo = a.x_out + sys * n;
+        double* xo = a.x_out + sys * n_row;
         if constexpr (OWN_STORE) {
             for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) xo[P.var_of[ci]] = ws[o_x + ci];
         } else {
