@@ -105,6 +105,8 @@ struct EzpzSystem {
     std::vector<unsigned char> grid_blob;       // the workgroups' sub-programs, one after the other
     std::vector<ProgramView> host_grid_views;   // per workgroup; blob_bytes = offset of its slice in grid_blob
     size_t grid_stage_bytes = 0;
+    bool lds_attr_set = false;   // hipFuncAttributeMaxDynamicSharedMemorySize raised for this system's kernel build
+    uint64_t grid_capacity = 0;  // workgroups of the grid build the device holds at once (0 = not asked yet)
     void* dev_grid_blob = nullptr;
     DevBuf<ProgramView> grid_views;
     uint32_t prog_lds_doubles = 0;
@@ -212,11 +214,12 @@ bool sub_team_fits(const ProgramCounts& c, uint32_t team) {
 }
 
 template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN>
-int launch_kernel(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+int launch_kernel(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
     auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN>;
-    if (s.lds_bytes > 48 * 1024) {
+    if (s.lds_bytes > 48 * 1024 && !s.lds_attr_set) {  // once per system (one kernel build per system)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)s.lds_bytes));
+        s.lds_attr_set = true;
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(s.block_threads), s.lds_bytes, stream, args);
     HIP_TRY(hipGetLastError());
@@ -225,28 +228,34 @@ int launch_kernel(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hip
 
 // Every team shape comes in two builds: all 25 kinds, or the nine linear kinds only (`linear_only` topologies).
 template <int TEAM, int MODE, bool LDSWS, bool PLDS>
-int launch_variant(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+int launch_variant(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
     if (s.linear_only) return launch_kernel<TEAM, MODE, LDSWS, PLDS, true>(s, args, grid, stream);
     return launch_kernel<TEAM, MODE, LDSWS, PLDS, false>(s, args, grid, stream);
 }
 
 template <int TEAM>
-int launch_sub(const EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+int launch_sub(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
     return s.prog_in_lds ? launch_variant<TEAM, MODE_SUB, true, true>(s, args, grid, stream)
                          : launch_variant<TEAM, MODE_SUB, true, false>(s, args, grid, stream);
 }
 
-// Grid team: G workgroups per system, all of a launch's workgroups resident at once (cooperative launch), as many
-// systems in flight as the device holds.
+std::mutex g_grid_mu;
+hipEvent_t g_grid_event[16] = {};  // per device: completion of the last grid-team launch of this process
+
+// Grid team: G workgroups per system, all of a launch's workgroups resident at once, as many systems in flight as
+// the device holds.
 template <bool LIN>
 int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     auto kernel = lm_solve_kernel<64, MODE_PART, true, true, LIN, true>;
-    if (s.lds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)s.lds_bytes));
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)s.block_threads, s.lds_bytes));
-    const uint64_t capacity = (uint64_t)kNumCUs * (uint64_t)std::max(per_cu, 1);
+    if (s.grid_capacity == 0) {  // once per system: these two runtime calls cost more than the solve
+        if (s.lds_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)s.block_threads, s.lds_bytes));
+        s.grid_capacity = (uint64_t)kNumCUs * (uint64_t)std::max(per_cu, 1);
+    }
+    const uint64_t capacity = s.grid_capacity;
     if (capacity < s.grid_wgs) return EZPZ_ERR_TOO_LARGE;
     const uint32_t slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(args.batch, capacity / s.grid_wgs));
     int rc;
@@ -268,9 +277,21 @@ int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     args.grid_scratch = s.grid_scratch.p;
     args.grid_views = s.grid_views.p;
     args.grid_wgs = s.grid_wgs;
-    void* params[] = {&args};
-    HIP_TRY(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(slots * s.grid_wgs),
-                                       dim3(s.block_threads), params, (unsigned int)s.lds_bytes, stream));
+    // Every workgroup of the launch must become resident (they wait for each other).  slots * G never exceeds what
+    // the device holds, and grid-team launches of this process are chained on one event per device, so two of them
+    // are never half-resident at the same time whatever streams they were enqueued on; other kernels only delay
+    // residency.  (hipLaunchCooperativeKernel gives the same guarantee across processes but costs 21 us per launch,
+    // more than a third of a 200 000-variable solve; another process running grid teams on the same device at the
+    // same time is not supported.)
+    {
+        std::lock_guard<std::mutex> lock(g_grid_mu);
+        hipEvent_t& ev = g_grid_event[s.device & 15];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+        hipLaunchKernelGGL(kernel, dim3(slots * s.grid_wgs), dim3(s.block_threads), s.lds_bytes, stream, args);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev, stream));
+    }
     return EZPZ_OK;
 }
 

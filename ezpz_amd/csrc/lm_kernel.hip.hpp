@@ -148,7 +148,7 @@ __device__ __forceinline__ DevCon load_packed(const PackedCon* p, const double* 
 // write-back / L1 invalidate each) is needed.  Measured alternatives on 256 workgroups, all 25 us per reduction: a
 // central atomic counter + generation word (256 cross-XCD atomics serialise on one word), everyone polling
 // everyone's flag (all pollers hit the same few lines), release/acquire flags (10 us just to scatter 255 lines).
-// All G workgroups must be resident at once: the host launches cooperatively.
+// All G workgroups must be resident at once: see launch_grid_kernel in api.hip.
 constexpr int kGridMaxWgs = 256;
 typedef unsigned int gridchunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, seq, 0)
 struct GridScratch {
