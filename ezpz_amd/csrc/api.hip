@@ -592,28 +592,50 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
                                   : auto_wg_team(width);
         // One large system whose state cannot live in a CU's LDS: spread it over G workgroups (a "grid team"), each
         // owning team/64 partitions, ~64+ variables per wavefront; falls back to one workgroup when the components
-        // cannot be balanced over that many partitions.
+        // cannot be balanced over that many partitions.  Obviously large systems go straight to the grid build; the
+        // others are built for one workgroup first and rebuilt only if their exact state turns out not to fit.
+        const uint32_t W = team / 64;
+        auto grid_wgs_for = [&]() {
+            uint32_t g = 1;
+            while (g < (uint32_t)kGridMaxWgs && (uint64_t)g * 2 * W * 64 <= n_vars) g <<= 1;
+            return g;
+        };
+        auto build_grid = [&](uint32_t g) -> int {  // 1 built, 0 not balanced at any size, -1 error
+            for (; g > 1; g >>= 1) {
+                Program Q;
+                BuildError qe;
+                if (!build_program(cs, n_cs, n_vars, Q, qe, g * W)) {
+                    be = qe;
+                    return -1;
+                }
+                if (Q.c.n_parts == g * W) {
+                    P = std::move(Q);
+                    return (int)g;
+                }
+            }
+            return 0;
+        };
         uint32_t G = 1;
+        bool have_program = false;
         if (!team_size && (3 * n_vars + 2 * n_cs) * 8 > kLdsBytesMax) {
-            while (G < (uint32_t)kGridMaxWgs && (uint64_t)G * 2 * (team / 64) * 64 <= n_vars) G <<= 1;
-        }
-        bool built = false;
-        for (; G > 1 && !built; G >>= 1) {
-            Program Q;
-            BuildError qe;
-            if (!build_program(cs, n_cs, n_vars, Q, qe, G * (team / 64))) {
-                be = qe;
-                return fail();
-            }
-            if (Q.c.n_parts == G * (team / 64)) {
-                P = std::move(Q);
-                built = true;
-                break;
+            const int r = build_grid(grid_wgs_for());
+            if (r < 0) return fail();
+            if (r > 1) {
+                G = (uint32_t)r;
+                have_program = true;
             }
         }
-        if (!built) {
-            G = 1;
-            if (!build_program(cs, n_cs, n_vars, P, be, team / 64)) return fail();
+        if (!have_program) {
+            if (!build_program(cs, n_cs, n_vars, P, be, W)) return fail();
+            if (!team_size && (size_t)workspace_doubles(P.c) * 8 + 4096 > kLdsBytesMax && grid_wgs_for() > 1) {
+                Program one = std::move(P);
+                const int r = build_grid(grid_wgs_for());
+                if (r < 0) return fail();
+                if (r > 1)
+                    G = (uint32_t)r;
+                else
+                    P = std::move(one);
+            }
         }
         s.grid_wgs = G;
         s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;

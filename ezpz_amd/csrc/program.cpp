@@ -247,6 +247,23 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     // Elimination order, per connected component: minimum degree, unless the request order already gives a
     // factor that is no denser -- then the variables are eliminated in id order, which makes the factorisation
     // operation-for-operation the textbook left-looking Cholesky of the matrix as the caller numbered it.
+    // A "component" is what one wavefront / workgroup can own end to end.  The rows of a two-row constraint
+    // (PointsCoincident: an x row and a y row) may touch disjoint sets of variables, i.e. different blocks of JtJ, but
+    // the constraint is evaluated as a whole by whoever owns it: both blocks must land in the same component, or the
+    // owner of the second row's variables would read residuals and Jacobian entries another wavefront is still
+    // writing.  `link` joins the first variable of every row of a constraint for the traversal only (the
+    // factorisation keeps seeing the true, finer block structure: a merged component is just a disconnected graph).
+    IVecs link(n, pool);
+    for (uint32_t i = 0; i < C; ++i) {
+        const KindInfo& K = kKinds[cs[i].kind];
+        for (int r = 1; r < K.n_rows; ++r) {
+            const uint32_t a0 = cs[i].ids[K.nz[0][0]], b0 = cs[i].ids[K.nz[r][0]];
+            if (a0 != b0) {
+                link[a0].push_back(b0);
+                link[b0].push_back(a0);
+            }
+        }
+    }
     std::vector<uint32_t> comp(n, NONE);
     std::vector<uint32_t> order;  // position -> var
     order.reserve(n);
@@ -264,6 +281,11 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
                 stack.pop_back();
                 verts.push_back(v);
                 for (uint32_t w : adj[v])
+                    if (comp[w] == NONE) {
+                        comp[w] = ncomp;
+                        stack.push_back(w);
+                    }
+                for (uint32_t w : link[v])
                     if (comp[w] == NONE) {
                         comp[w] = ncomp;
                         stack.push_back(w);

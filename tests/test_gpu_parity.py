@@ -490,6 +490,55 @@ def test_random_systems_fuzz_parity(E):
     assert checked >= 150 and determined_checked >= 20 and len(kinds_seen) == O.NUM_KINDS, (checked, determined_checked, unstable, sorted(kinds_seen))
 
 
+def _fixture_mosaic(copies, seed, with_perpendicular=False):
+    """One big block-diagonal system: `copies` jittered replicas of each fully determined reference fixture, variable
+    ids shifted so that the replicas are independent components (11 kinds between them).  LM accepts a step for the
+    whole system or not at all, so the mosaic takes 7 iterations (the slowest member alone: `square`, 7) -- or, with
+    `perpendicular` (15 alone) in the mix, 81 iterations of accepted and rejected steps."""
+    names = ["coincident", "symmetric", "midpoint", "tiny", "circle", "circle_center", "circle_tangent",
+             "two_rectangles", "nonsquare", "square", "chamfer_square", "angle_parallel"]
+    if with_perpendicular:
+        names.append("perpendicular")
+    recs, guesses, off = [], [], 0
+    rng = np.random.default_rng(seed)
+    for rep in range(copies):
+        for name in names:
+            ref = T.load(read_case(name))
+            for c in ref.constraints:
+                c = O.set_from_initial_values(c, ref.guesses).copy()
+                c["ids"] = c["ids"] + off  # unused id slots become `off`: a valid variable, never dereferenced
+                recs.append(c)
+            guesses.append(ref.guesses + rng.uniform(-0.02, 0.02, ref.num_vars))
+            off += ref.num_vars
+    return O.stack(recs), np.concatenate(guesses)
+
+
+@pytest.mark.parametrize("copies,team,perp", [(6, 0, False), (6, 256, False), (40, 0, False), (40, 512, False),
+                                              (3, 0, True), (40, 0, True)])
+def test_mosaic_of_fixtures_in_workgroup_and_grid_teams(E, copies, team, perp):
+    """The general (all 25 kinds) build of the workgroup kernels on a system with many kinds per partition: packed
+    records with several partial-slot patterns, the staged-lists and global-workspace variants, and a grid team."""
+    recs, g = _fixture_mosaic(copies, seed=copies, with_perpendicular=perp)
+    assert len(set(int(k) for k in recs["kind"])) >= 11
+    sysobj = E.System(recs, len(g), team_size=team)
+    info = sysobj.info()
+    assert info["team_mode"] in (1, 2)
+    if copies == 40:
+        assert (info["grid_workgroups"] > 1) == (team == 0)
+    cfg = dict(max_iterations=120)
+    x0 = np.stack([g, g + 0.01, g - 0.015])
+    x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    for b in range(3):
+        want = O.solve(recs, x0[b], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        # (40 copies with `perpendicular` do not get there in 120 iterations, on the oracle either: same 120 steps)
+        assert want.error == 0 and want.converged == (not (perp and copies == 40))
+        assert (int(st["iterations"][b]), bool(st["converged"][b])) == (want.iterations, want.converged), b
+        assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied
+        assert int(st["n_warnings"][b]) == len(want.warnings)
+        assert abs(float(st["final_residual_inf"][b]) - want.final_residual_inf) <= 1e-9 * max(1.0, want.final_residual_inf)
+        assert_x_close(x[b], want.final_values)
+
+
 def test_batch_solve_with_priorities_and_inferred_sides(E):
     """lib.rs:148-263 per system of a batch: sides inferred from each system's own guesses, cumulative priority tiers
     from the original guesses, last fully satisfied tier wins (tests.rs:49-106 semantics, batched)."""
