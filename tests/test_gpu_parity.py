@@ -528,6 +528,11 @@ def test_mosaic_of_fixtures_in_workgroup_and_grid_teams(E, copies, team, perp):
     cfg = dict(max_iterations=120)
     x0 = np.stack([g, g + 0.01, g - 0.015])
     x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    # run-to-run determinism: partitions must own every row of their constraints (a two-row constraint's rows can sit
+    # in different blocks of JtJ; when they were split over wavefronts this differed from run to run)
+    for _ in range(3):
+        x2, st2, _ = sysobj.solve_batch(np.tile(x0, (4, 1)), E.Config(**cfg))
+        assert np.array_equal(x2, np.tile(x, (4, 1))) and np.array_equal(st2["iterations"], np.tile(st["iterations"], 4))
     for b in range(3):
         want = O.solve(recs, x0[b], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
         # (40 copies with `perpendicular` do not get there in 120 iterations, on the oracle either: same 120 steps)
