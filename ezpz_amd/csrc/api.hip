@@ -556,6 +556,38 @@ static Program slice_program(const Program& P, uint32_t p0, uint32_t p1) {
     return S;
 }
 
+// Grid team: one sub-program per workgroup (slice_program), packed and staged like a workgroup team's.  False when some
+// slice does not fit a CU's LDS (state + staged lists) or cannot be packed; `s` is then left without grid data.
+static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32_t W) {
+    s.grid_blob.clear();
+    s.host_grid_views.clear();
+    s.grid_ws_doubles = 0;
+    s.grid_stage_bytes = 0;
+    std::vector<unsigned char> sub;
+    for (uint32_t g = 0; g < G; ++g) {
+        const Program S = slice_program(P, g * W, g * W + W);
+        ProgramView sv{};
+        const bool fits16 = S.c.n_vars < 65536 && S.c.n_rows < 65536 && S.c.zj < 65536 && S.c.zlo < 65536 &&
+                            S.c.n_apairs < 65536 && S.c.n_lpairs < 65536 && S.c.n_cons < 65536;
+        const size_t lists_bytes = fits16 ? pack_program(S, true, true, sub, sv) : 0;
+        const uint32_t wsd = workspace_doubles(S.c);
+        if (!fits16 || !sv.packed || lists_bytes + (size_t)wsd * 8 + 2048 > kLdsBytesMax ||
+            s.grid_blob.size() + sub.size() > 0xFFFFFF00ull) {
+            s.grid_blob.clear();
+            s.host_grid_views.clear();
+            return false;
+        }
+        sv.stage_bytes = (uint32_t)lists_bytes;
+        sv.blob_bytes = (uint32_t)s.grid_blob.size();  // for a grid view: byte offset of this slice in the grid blob
+        s.grid_blob.insert(s.grid_blob.end(), sub.begin(), sub.end());
+        s.grid_blob.resize((s.grid_blob.size() + 255) & ~size_t(255));
+        s.host_grid_views.push_back(sv);
+        s.grid_ws_doubles = std::max(s.grid_ws_doubles, wsd);
+        s.grid_stage_bytes = std::max<size_t>(s.grid_stage_bytes, lists_bytes);
+    }
+    return true;
+}
+
 // Symbolic phase + launch-shape decision shared by ezpz_system_create and ezpz_analyze.
 static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t team_size, EzpzSystem& s,
                         Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable) {
@@ -600,18 +632,27 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             while (g < (uint32_t)kGridMaxWgs && (uint64_t)g * 2 * W * 64 <= n_vars) g <<= 1;
             return g;
         };
-        auto build_grid = [&](uint32_t g) -> int {  // 1 built, 0 not balanced at any size, -1 error
-            for (; g > 1; g >>= 1) {
+        auto build_grid = [&](uint32_t g0) -> int {  // > 1: workgroups of the grid team now in P; 0: none works; -1: error
+            // unbalanced -> fewer, larger shares; a share too big for a CU's LDS -> more, smaller ones
+            bool grow = false;
+            for (uint32_t g = g0; g > 1 && g <= (uint32_t)kGridMaxWgs;) {
                 Program Q;
                 BuildError qe;
                 if (!build_program(cs, n_cs, n_vars, Q, qe, g * W)) {
                     be = qe;
                     return -1;
                 }
-                if (Q.c.n_parts == g * W) {
+                if (Q.c.n_parts != g * W) {
+                    if (grow) return 0;
+                    g >>= 1;
+                    continue;
+                }
+                if (pack_grid_slices(s, Q, g, W)) {
                     P = std::move(Q);
                     return (int)g;
                 }
+                grow = true;
+                g <<= 1;
             }
             return 0;
         };
@@ -673,39 +714,6 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return fail();
     }
     v.stage_bytes = (uint32_t)stage_bytes;
-    // ---- grid team: one sub-program per workgroup, every one of them staged like a workgroup team's --------------------------
-    s.grid_blob.clear();
-    s.host_grid_views.clear();
-    s.grid_ws_doubles = 0;
-    s.grid_stage_bytes = 0;
-    if (s.grid_wgs > 1) {
-        const uint32_t W = s.team_size / 64;
-        bool ok = true;
-        std::vector<unsigned char> sub;
-        for (uint32_t g = 0; g < s.grid_wgs && ok; ++g) {
-            const Program S = slice_program(P, g * W, g * W + W);
-            ProgramView sv{};
-            const bool fits16 = S.c.n_vars < 65536 && S.c.n_rows < 65536 && S.c.zj < 65536 && S.c.zlo < 65536 &&
-                                S.c.n_apairs < 65536 && S.c.n_lpairs < 65536 && S.c.n_cons < 65536;
-            const size_t lists_bytes = fits16 ? pack_program(S, true, true, sub, sv) : 0;
-            const uint32_t wsd = workspace_doubles(S.c);
-            if (!fits16 || !sv.packed || lists_bytes + (size_t)wsd * 8 + 2048 > kLdsBytesMax) {
-                ok = false;
-                break;
-            }
-            sv.stage_bytes = (uint32_t)lists_bytes;
-            sv.blob_bytes = (uint32_t)s.grid_blob.size();  // for a grid view: byte offset of this slice in the grid blob
-            s.grid_blob.insert(s.grid_blob.end(), sub.begin(), sub.end());
-            s.grid_blob.resize((s.grid_blob.size() + 255) & ~size_t(255));
-            s.host_grid_views.push_back(sv);
-            s.grid_ws_doubles = std::max(s.grid_ws_doubles, wsd);
-            s.grid_stage_bytes = std::max<size_t>(s.grid_stage_bytes, lists_bytes);
-        }
-        if (!ok || s.grid_blob.size() > 0xFFFFFFF0ull) {  // cannot happen for balanced partitions; be safe
-            be.code = EZPZ_ERR_TOO_LARGE;
-            return fail();
-        }
-    }
     finish_team(s, stage_bytes);
 
     EzpzSystemInfo& info = s.info;

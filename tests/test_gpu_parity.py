@@ -544,6 +544,43 @@ def test_mosaic_of_fixtures_in_workgroup_and_grid_teams(E, copies, team, perp):
         assert_x_close(x[b], want.final_values)
 
 
+@pytest.mark.parametrize("team,ncomp", [(0, 120), (128, 120), (512, 120), (0, 1200), (512, 1200)])
+def test_random_block_systems_are_deterministic_and_match_the_oracle(E, team, ncomp):
+    """Workgroup teams on big systems made of random little components of all 25 kinds (the fuzz generator's, one
+    block of variables each): bitwise the same answer on every run and for every system of a batch (a wavefront that
+    read another's half-written data would show here), error-free, and -- the LM path of such a system hinges on
+    rank-deficient blocks held by lambda only -- the same residual as the oracle where the oracle converges."""
+    rng = np.random.default_rng(4242 + team + ncomp)
+    for trial in range(6 if ncomp < 1000 else 2):
+        recs, guesses, off = [], [], 0
+        for comp in range(int(rng.integers(3 * ncomp // 4, 5 * ncomp // 4))):
+            nv = int(rng.integers(4, 11))
+            for _ in range(int(rng.integers(1, 7))):
+                c = gen.arb_constraint(rng, int(rng.integers(0, O.NUM_KINDS)), hi=nv)
+                c["ids"] = c["ids"] + off
+                recs.append(c)
+            guesses.append(rng.uniform(-6.0, 6.0, nv))
+            off += nv
+        recs, g = O.stack(recs), np.concatenate(guesses)
+        sysobj = E.System(recs, len(g), team_size=team)
+        assert sysobj.info()["team_mode"] in (1, 2)
+        if ncomp >= 1000:
+            assert (sysobj.info()["grid_workgroups"] > 1) == (team == 0)
+        cfg = dict(max_iterations=25)
+        x0 = np.tile(g, (6, 1))
+        x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+        assert np.all(x == x[0]) or np.array_equal(np.isnan(x), np.isnan(np.tile(x[0], (6, 1))))
+        assert len(set(st["iterations"].tolist())) == 1 and len(set(st["n_warnings"].tolist())) == 1
+        for _ in range(2):
+            x2, st2, _ = sysobj.solve_batch(x0, E.Config(**cfg))
+            assert np.array_equal(x2, x, equal_nan=True) and np.array_equal(st2["iterations"], st["iterations"])
+        want = O.solve(recs, g, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 18)
+        assert want.error == 0
+        assert np.array_equal(np.isnan(x[0]), np.isnan(want.final_values))
+        if want.converged and want.final_residual_inf <= 1e-8:
+            assert bool(st["converged"][0]) and float(st["final_residual_inf"][0]) <= 1e-8
+
+
 def test_batch_solve_with_priorities_and_inferred_sides(E):
     """lib.rs:148-263 per system of a batch: sides inferred from each system's own guesses, cumulative priority tiers
     from the original guesses, last fully satisfied tier wins (tests.rs:49-106 semantics, batched)."""
