@@ -315,6 +315,19 @@ def test_large_ladder_grid_team_and_global_workspace(E):
         x2, st2, _ = sysobj.solve_batch(np.tile(x0, (9, 1)))
         assert np.array_equal(x2, np.tile(x, (9, 1)))
     assert (st["iterations"][0], bool(st["converged"][0])) == (want.iterations, want.converged)
+    # weights other than 1 (side array of the packed records) and an unsatisfiable constraint, on the grid team
+    recs = O.stack(ref.constraints).copy()
+    recs["weight"][::3] = 2.5
+    recs["weight"][1::7] = 0.5
+    recs = O.stack(list(recs) + [O.fixed(int(recs["ids"][5][0]), 123.0)])  # contradicts that variable's Fixed
+    sysobj = E.System(recs, ref.num_vars)
+    assert sysobj.info()["grid_workgroups"] > 1
+    x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+    for b in range(3):
+        want = O.solve(recs, x0[b], linsolve=O.LINSOLVE_SPARSE)
+        assert (int(st["iterations"][b]), bool(st["converged"][b])) == (want.iterations, want.converged)
+        assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied and len(want.unsatisfied) >= 1
+        assert_x_close(x[b], want.final_values)
 
 
 def test_grid_team_with_nonlinear_constraints_and_warnings(E):
