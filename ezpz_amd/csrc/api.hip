@@ -627,9 +627,38 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         // cannot be balanced over that many partitions.  Obviously large systems go straight to the grid build; the
         // others are built for one workgroup first and rebuilt only if their exact state turns out not to fit.
         const uint32_t W = team / 64;
+        // (independent pieces of the system, by union-find over the constraints: a grid team needs at least two per
+        // wavefront to balance, and a single connected sketch must not pay for build attempts that cannot succeed)
+        size_t n_pieces = 0;
+        {
+            std::vector<uint32_t> parent(n_vars);
+            for (size_t v = 0; v < n_vars; ++v) parent[v] = (uint32_t)v;
+            auto find = [&](uint32_t a) {
+                while (parent[a] != a) a = parent[a] = parent[parent[a]];
+                return a;
+            };
+            std::vector<char> used(n_vars, 0);
+            for (size_t i = 0; i < n_cs; ++i) {
+                if (cs[i].kind >= EZPZ_NUM_KINDS) continue;
+                const KindInfo& K = kKinds[cs[i].kind];
+                uint32_t first = UINT32_MAX;
+                for (int r = 0; r < K.n_rows; ++r)
+                    for (int e = 0; e < K.n_nz[r]; ++e) {
+                        const uint32_t v = cs[i].ids[K.nz[r][e]];
+                        if (v >= n_vars) continue;  // reported by build_program
+                        used[v] = 1;
+                        if (first == UINT32_MAX)
+                            first = v;
+                        else
+                            parent[find(v)] = find(first);
+                    }
+            }
+            for (size_t v = 0; v < n_vars; ++v) n_pieces += (!used[v] || find((uint32_t)v) == v) ? 1 : 0;
+        }
         auto grid_wgs_for = [&]() {
             uint32_t g = 1;
-            while (g < (uint32_t)kGridMaxWgs && (uint64_t)g * 2 * W * 64 <= n_vars) g <<= 1;
+            while (g < (uint32_t)kGridMaxWgs && (uint64_t)g * 2 * W * 64 <= n_vars && (uint64_t)g * 2 * W * 2 <= n_pieces)
+                g <<= 1;
             return g;
         };
         auto build_grid = [&](uint32_t g0) -> int {  // > 1: workgroups of the grid team now in P; 0: none works; -1: error

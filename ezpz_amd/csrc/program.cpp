@@ -97,13 +97,18 @@ void order_component(const std::vector<uint32_t>& verts, const IVecs& adj, std::
     }
 }
 
-// Number of strictly-lower entries of the Cholesky factor of one component under the elimination order `ord`
+// Strictly-lower entries of the Cholesky factor of one component under the elimination order `ord`, and the height of
+// its elimination tree = the number of levels the level-scheduled factorisation runs one after the other
 // (symbolic elimination with an elimination tree; O(nnz(L))).
-uint64_t component_fill(const std::vector<uint32_t>& ord, const IVecs& adj, std::vector<uint32_t>& local_id,
-                        std::pmr::memory_resource* pool) {
+struct OrderCost {
+    uint64_t fill;
+    uint32_t height;
+};
+OrderCost component_cost(const std::vector<uint32_t>& ord, const IVecs& adj, std::vector<uint32_t>& local_id,
+                         std::pmr::memory_resource* pool) {
     const size_t k = ord.size();
     for (size_t i = 0; i < k; ++i) local_id[ord[i]] = (uint32_t)i;
-    IVec parent(k, NONE, pool), ancestor(k, NONE, pool), flag(k, NONE, pool);
+    IVec parent(k, NONE, pool), flag(k, NONE, pool), depth(k, 0u, pool);
     uint64_t fill = 0;
     for (uint32_t p = 0; p < k; ++p) {
         flag[p] = p;
@@ -121,8 +126,98 @@ uint64_t component_fill(const std::vector<uint32_t>& ord, const IVecs& adj, std:
             }
         }
     }
-    (void)ancestor;
-    return fill;
+    uint32_t height = 0;
+    for (uint32_t j = 0; j < k; ++j) {  // children come before parents
+        if (parent[j] != NONE) depth[parent[j]] = std::max(depth[parent[j]], depth[j] + 1);
+        height = std::max(height, depth[j] + 1);
+    }
+    return OrderCost{fill, height};
+}
+
+// Nested dissection (George's automatic scheme): breadth-first level structure from a pseudo-peripheral vertex, the
+// middle level is the separator, both sides are ordered first (recursively), the separator last.  A polyline or any
+// other band-like sketch gets an elimination tree of height O(band * log n) instead of n: what the level-scheduled
+// factorisation needs, since it pays one synchronisation per level.
+void nested_dissection(const std::vector<uint32_t>& verts, const IVecs& adj, std::vector<uint32_t>& local_id,
+                       std::vector<uint32_t>& out_order, std::pmr::memory_resource* pool) {
+    const uint32_t k = (uint32_t)verts.size();
+    for (uint32_t i = 0; i < k; ++i) local_id[verts[i]] = i;
+    IVec region(k, 0u, pool);  // which open region a vertex belongs to (0 = the whole component)
+    IVec level(k, 0u, pool), queue(pool);
+    std::pmr::vector<char> seen(k, 0, pool);
+    struct Task {
+        uint32_t region;
+        bool emit;     // second visit: `members` is the region's separator and goes out after both sides
+        IVec members;  // first visit: the region's vertices
+    };
+    std::pmr::vector<Task> stack(pool);
+    {
+        Task all{0, false, IVec(pool)};
+        all.members.resize(k);
+        std::iota(all.members.begin(), all.members.end(), 0u);
+        stack.push_back(std::move(all));
+    }
+    uint32_t next_region = 1;
+    auto bfs = [&](uint32_t start, uint32_t reg) {  // level structure of start's connected piece of `reg`, in `queue`
+        queue.clear();
+        queue.push_back(start);
+        level[start] = 0;
+        seen[start] = 1;
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const uint32_t v = queue[h];
+            for (uint32_t wv : adj[verts[v]]) {
+                const uint32_t w = local_id[wv];
+                if (region[w] == reg && !seen[w]) {
+                    seen[w] = 1;
+                    level[w] = level[v] + 1;
+                    queue.push_back(w);
+                }
+            }
+        }
+        for (uint32_t v : queue) seen[v] = 0;
+    };
+    while (!stack.empty()) {
+        Task t = std::move(stack.back());
+        stack.pop_back();
+        if (t.emit) {
+            for (uint32_t v : t.members) out_order.push_back(verts[v]);
+            continue;
+        }
+        for (uint32_t s0 : t.members) {  // every connected piece of this region
+            if (region[s0] != t.region) continue;  // already handed to a leaf / separator / sub-region
+            bfs(s0, t.region);
+            bfs(queue.back(), t.region);  // pseudo-peripheral: restart from the farthest vertex
+            const uint32_t depth = level[queue.back()];
+            if (queue.size() <= 16 || depth < 4) {  // small or compact piece: a leaf, in request order
+                IVec piece(queue.begin(), queue.end(), pool);
+                std::sort(piece.begin(), piece.end());
+                for (uint32_t v : piece) {
+                    out_order.push_back(verts[v]);
+                    region[v] = NONE;
+                }
+                continue;
+            }
+            const uint32_t mid = depth / 2;
+            Task sep{0, true, IVec(pool)}, left{next_region, false, IVec(pool)}, right{next_region + 1, false, IVec(pool)};
+            next_region += 2;
+            for (uint32_t v : queue) {
+                if (level[v] == mid) {
+                    sep.members.push_back(v);
+                    region[v] = NONE;
+                } else if (level[v] < mid) {
+                    left.members.push_back(v);
+                    region[v] = left.region;
+                } else {
+                    right.members.push_back(v);
+                    region[v] = right.region;
+                }
+            }
+            std::sort(sep.members.begin(), sep.members.end());
+            stack.push_back(std::move(sep));  // LIFO: comes out after both sides
+            stack.push_back(std::move(right));
+            stack.push_back(std::move(left));
+        }
+    }
 }
 
 }  // namespace
@@ -268,7 +363,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     std::vector<uint32_t> order;  // position -> var
     order.reserve(n);
     {
-        std::vector<uint32_t> stack, verts, local_id(n, 0), cand;
+        std::vector<uint32_t> stack, verts, local_id(n, 0), cand, nd;
         uint32_t ncomp = 0;
         for (uint32_t s = 0; s < n; ++s) {
             if (comp[s] != NONE) continue;
@@ -292,11 +387,31 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
                     }
             }
             std::sort(verts.begin(), verts.end());
+            // request order, minimum degree, nested dissection: the cheapest by entries of L plus what its levels cost
+            // (a level is one or two synchronisations, worth about 64 entries); ties go to the earlier candidate, so
+            // the request order -- the textbook left-looking Cholesky of the matrix as the caller numbered it -- wins
+            // whenever nothing is gained by leaving it
+            auto score = [&](const std::vector<uint32_t>& o) {
+                const OrderCost c = component_cost(o, adj, local_id, pool);
+                return c.fill + 64ull * c.height;
+            };
+            uint64_t best = score(verts);
+            const std::vector<uint32_t>* pick = &verts;
             cand.clear();
             order_component(verts, adj, local_id, cand, pool);
-            if (cand != verts && component_fill(verts, adj, local_id, pool) <= component_fill(cand, adj, local_id, pool))
-                cand = verts;
-            order.insert(order.end(), cand.begin(), cand.end());
+            if (cand != verts) {
+                const uint64_t sc = score(cand);
+                if (sc < best) {
+                    best = sc;
+                    pick = &cand;
+                }
+            }
+            nd.clear();
+            if (verts.size() > 64) {
+                nested_dissection(verts, adj, local_id, nd, pool);
+                if (nd.size() == verts.size() && score(nd) < best) pick = &nd;
+            }
+            order.insert(order.end(), pick->begin(), pick->end());
             ++ncomp;
         }
         P.c.n_components = ncomp;

@@ -233,6 +233,23 @@ def test_single_large_component_uses_barrier_workgroup(E, team):
     assert_x_close(x, xo)
 
 
+def test_long_polyline_gets_a_shallow_elimination_tree(E):
+    """One connected component with a band-like graph (a polyline): eliminated in request order its elimination tree
+    is a path -- 8000 levels for 4000 points, one or two barriers each.  Nested dissection brings it to ~32 levels
+    (75 ms -> under 1 ms per solve) at 1.6x the entries of L; the answers stay the oracle's."""
+    recs, g = _chain_system(4000)
+    sysobj = E.System(recs, len(g))
+    info = sysobj.info()
+    assert info["n_components"] == 1 and info["team_mode"] == 2
+    assert info["n_levels"] <= 64 and info["nnz_l"] <= 2 * info["nnz_a"]
+    x0 = g[None, :] + gen.keyed_uniform(3, 3, len(g), -0.02, 0.02)
+    x, st, _ = sysobj.solve_batch(x0)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv)
+    assert np.array_equal(st["n_unsatisfied"], nun)
+    assert_x_close(x, xo)
+
+
 @pytest.mark.parametrize("team", [128, 512, 1024])
 def test_partitioned_workgroup_matches_barrier_workgroup(E, team):
     """two_rectangles has two components: the wavefront-partitioned mode must agree with every other mode."""
