@@ -611,6 +611,55 @@ def test_random_block_systems_are_deterministic_and_match_the_oracle(E, team, nc
             assert bool(st["converged"][0]) and float(st["final_residual_inf"][0]) <= 1e-8
 
 
+@pytest.mark.parametrize("npts,team", [(150, 0), (150, 256), (1500, 0)])
+def test_random_connected_sketch_in_barrier_workgroup(E, npts, team):
+    """One connected component of mixed kinds (a random polyline-like sketch: every point tied to its predecessors by
+    one or two random constraints) on the barrier workgroup (LDS and global-memory workspace): deterministic from
+    run to run, and -- it is fully determined by construction -- the oracle's answer."""
+    rng = np.random.default_rng(77 + npts + team)
+    pt = lambda i: (2 * i, 2 * i + 1)
+    cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
+    true = [np.zeros(2)]
+    for i in range(1, npts):
+        # a point is placed by two scalar conditions relative to earlier points, consistent with a hidden true layout
+        p = true[-1] + rng.uniform(0.5, 2.0, 2) * rng.choice([-1.0, 1.0], 2)
+        true.append(p)
+        a = i - 1
+        b = max(0, i - int(rng.integers(2, 4)))
+        choice = int(rng.integers(0, 5))
+        if choice == 0:
+            cons += [O.horizontal_distance(pt(i), pt(a), float(p[0] - true[a][0])),
+                     O.vertical_distance(pt(i), pt(a), float(p[1] - true[a][1]))]
+        elif choice == 1:
+            cons += [O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a])))),
+                     O.distance(pt(i), pt(b), float(np.hypot(*(p - true[b])))) if b != a else
+                     O.horizontal_distance(pt(i), pt(a), float(p[0] - true[a][0]))]
+        elif choice == 2:
+            cons += [O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a])))),
+                     O.vertical_distance(pt(i), pt(a), float(p[1] - true[a][1]))]
+        elif choice == 3:
+            cons += [O.fixed(2 * i, float(p[0])), O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a]))))]
+        else:
+            cons += [O.horizontal_distance(pt(i), pt(b), float(p[0] - true[b][0])),
+                     O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a]))))]
+    recs = O.stack(cons)
+    g = np.concatenate(true) + rng.uniform(-0.05, 0.05, 2 * npts)
+    sysobj = E.System(recs, len(g), team_size=team)
+    info = sysobj.info()
+    assert info["n_components"] == 1 and info["team_mode"] == 2 and info["n_partitions"] == 1
+    x0 = np.tile(g, (5, 1))
+    cfg = dict(max_iterations=60)
+    x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    assert np.all(x == x[0]) and len(set(st["iterations"].tolist())) == 1
+    x2, st2, _ = sysobj.solve_batch(x0, E.Config(**cfg))
+    assert np.array_equal(x2, x) and np.array_equal(st2["iterations"], st["iterations"])
+    want = O.solve(recs, g, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+    assert want.error == 0 and want.converged and not want.unsatisfied
+    assert (int(st["iterations"][0]), bool(st["converged"][0])) == (want.iterations, True)
+    assert not mask.any() and int(st["n_warnings"][0]) == len(want.warnings)
+    assert_x_close(x[0], want.final_values)
+
+
 def test_batch_solve_with_priorities_and_inferred_sides(E):
     """lib.rs:148-263 per system of a batch: sides inferred from each system's own guesses, cumulative priority tiers
     from the original guesses, last fully satisfied tier wins (tests.rs:49-106 semantics, batched)."""
