@@ -515,6 +515,16 @@ def test_random_systems_fuzz_parity(E):
         if determined:
             assert_x_close(got.final_values, want.final_values)
             determined_checked += 1
+            if want.final_residual_inf <= 1e-8 and trial % 3 == 0:
+                # the other team shapes of the sub-wavefront kernel (one lane per system ... one wavefront per
+                # system) on the same system, several systems per wavefront
+                resolved = O.stack([O.set_from_initial_values(c, guesses) for c in cons])
+                for team in (1, 4, 64):
+                    xs, sts, _ = E.System(resolved, nvars, team_size=team).solve_batch(
+                        np.tile(guesses, (9, 1)), E.Config(**cfg))
+                    assert np.all(sts["iterations"] == want.iterations) and np.all(sts["converged"] == 1), (trial, team)
+                    assert np.all(xs == xs[0])
+                    assert_x_close(xs[0], want.final_values)
         checked += 1
         kinds_seen.update(int(c["kind"]) for c in cons)
     assert checked >= 150 and determined_checked >= 20 and len(kinds_seen) == O.NUM_KINDS, (checked, determined_checked, unstable, sorted(kinds_seen))
