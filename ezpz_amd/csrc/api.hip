@@ -907,10 +907,12 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         uint8_t* hmask = h + x_bytes + st_bytes;
         uint64_t* hlog = reinterpret_cast<uint64_t*>(h + x_bytes + st_bytes + mask_bytes);
         if (n) std::memcpy(hx, x0, batch * n * sizeof(double));
+        // on the calling thread's own stream: solve() calls from different threads (on different systems) overlap on
+        // the device instead of queueing behind each other on the null stream
         rc = ezpz_system_solve_batch_device(sys, hx, batch, cfg, hx, hst, unsat_mask ? hmask : nullptr,
-                                            want_log ? hlog : nullptr, warn_cap, nullptr);
+                                            want_log ? hlog : nullptr, warn_cap, hipStreamPerThread);
         if (rc != EZPZ_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
         std::memcpy(status, hst, st_bytes);
         if (n) std::memcpy(x_out, hx, batch * n * sizeof(double));
         if (unsat_mask && C) std::memcpy(unsat_mask, hmask, batch * C);
