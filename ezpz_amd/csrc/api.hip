@@ -213,9 +213,9 @@ bool sub_team_fits(const ProgramCounts& c, uint32_t team) {
     return team <= 64 && (size_t)workspace_doubles(c) * 8 * (64 / team) <= 60 * 1024;
 }
 
-template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN>
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool DENSE = false>
 int launch_kernel(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
-    auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN>;
+    auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN, false, DENSE>;
     if (s.lds_bytes > 48 * 1024 && !s.lds_attr_set) {  // once per system (one kernel build per system)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)s.lds_bytes));
@@ -235,6 +235,11 @@ int launch_variant(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStrea
 
 template <int TEAM>
 int launch_sub(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
+    if constexpr (TEAM == 4) {  // <= 8 variables: dense factor layout, solved in registers (always staged)
+        if (s.counts.dense)
+            return s.linear_only ? launch_kernel<TEAM, MODE_SUB, true, true, true, true>(s, args, grid, stream)
+                                 : launch_kernel<TEAM, MODE_SUB, true, true, false, true>(s, args, grid, stream);
+    }
     return s.prog_in_lds ? launch_variant<TEAM, MODE_SUB, true, true>(s, args, grid, stream)
                          : launch_variant<TEAM, MODE_SUB, true, false>(s, args, grid, stream);
 }
@@ -600,13 +605,22 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     };
     bool want_sub = team_size ? team_size <= 64 : width <= 64;
     if (want_sub) {
-        if (!build_program(cs, n_cs, n_vars, P, be, 1)) return fail();
         uint32_t team = team_size ? pow2_ceil(team_size) : auto_sub_team(cs, n_cs);
+        // Systems of <= 8 variables (the typical sketch fixture) on teams of four lanes solve their normal equations
+        // in registers: a level-by-level list walk costs an 8 x 8 system 27 k cycles per factorisation (~10 LDS hops
+        // per level, 8 levels), the register version ~3 k.
+        const bool allow_dense = n_vars <= 8 && n_vars >= 2 && (team_size == 0 || team == 4);
+        if (!build_program(cs, n_cs, n_vars, P, be, 1, allow_dense)) return fail();
+        const bool dense = P.c.dense != 0;  // granted only when JtJ is mostly full
+        if (dense) team = 4;
         // 64 / team workspaces share a wavefront: keep a wavefront's share of the LDS <= 32 KiB when choosing
         // automatically (>= 4 wavefronts per CU), and inside the hard limit in any case
         if (!team_size)
             while (team < 64 && (size_t)workspace_doubles(P.c) * 8 * (64 / team) > 32 * 1024) team <<= 1;
         while (team < 64 && !sub_team_fits(P.c, team)) team <<= 1;
+        if (dense && team != 4) {  // many constraints on few variables pushed the team up: the list-walk build after all
+            if (!build_program(cs, n_cs, n_vars, P, be, 1, false)) return fail();
+        }
         if (sub_team_fits(P.c, team)) {
             s.mode = MODE_SUB;
             s.team_size = team;

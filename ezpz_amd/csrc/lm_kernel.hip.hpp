@@ -289,6 +289,93 @@ __device__ __forceinline__ double reduce_lanes(double v, Op op) {
     return v;
 }
 
+// ---- dense 8 x 8 linear solve in registers (teams of four lanes on systems of <= 8 variables) -----------------------
+// Value of lane S (0..3) of every quad in all four lanes of the quad: one DPP move per 32-bit half, no LDS round trip.
+__device__ __forceinline__ double quad_bcast(double v, int s) {
+    switch (s & 3) {
+    case 0: return dpp_move<0x00>(v);
+    case 1: return dpp_move<0x55>(v);
+    case 2: return dpp_move<0xAA>(v);
+    default: return dpp_move<0xFF>(v);
+    }
+}
+
+// (A + lambda I) d = b for a system of n <= 8 variables: A = D (diagonal, ws[o_d + r]) and the strictly-lower entries in
+// the dense column layout of build_program (column c starts at slot lvl_sptr[c]); b in ws[o_v].  Lane l of the four
+// holds rows l and l + 4 in registers; pivots and multipliers travel by quad broadcast.  Right-looking Cholesky with
+// the forward substitution folded in, then the backward substitution: every entry receives its updates in ascending
+// column order and is divided last, every substitution sum runs over ascending indices -- operation for operation
+// what the level-scheduled list walk does on the same (full) pattern, without its ~10 LDS hops per level.
+// Returns 1.0 when a pivot of the real system is not positive (LltError::Numeric), d in ws[o_v].
+template <class WS, class LP>
+__device__ __forceinline__ double dense8_solve(const WS& ws, uint32_t o_d, uint32_t o_l, uint32_t o_v, LP lvl_sptr,
+                                               uint32_t n, int lane) {
+    uint32_t cs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cs[c] = (uint32_t)c < n ? (uint32_t)lvl_sptr[c] : 0u;
+    double a[2][8], bv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t r = (uint32_t)lane + 4u * q;
+        const bool in = r < n;
+        bv[q] = in ? ws[o_v + r] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double v = 0.0;
+            if (in && (uint32_t)c < r)
+                v = ws[o_l + cs[c] + (r - c - 1)];
+            else if ((uint32_t)c == r)
+                v = in ? ws[o_d + r] : 1.0;  // rows beyond n: identity, they touch nothing
+            a[q][c] = v;
+        }
+    }
+    double bad = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double pivot = quad_bcast(a[j >> 2][j], j & 3);
+        if ((uint32_t)j < n && !(pivot > 0.0)) bad = 1.0;
+        const double dj = sqrt(pivot);
+        const double yj = quad_bcast(bv[j >> 2], j & 3) / dj;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = lane + 4 * q;
+            if (r > j) {
+                a[q][j] = a[q][j] / dj;
+                bv[q] = bv[q] - a[q][j] * yj;
+            } else if (r == j) {
+                a[q][j] = dj;
+                bv[q] = yj;
+            }
+        }
+#pragma unroll
+        for (int k = j + 1; k < 8; ++k) {
+            const double lkj = quad_bcast(a[k >> 2][j], k & 3);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (lane + 4 * q >= k) a[q][k] = a[q][k] - a[q][j] * lkj;
+        }
+    }
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        double acc = quad_bcast(bv[j >> 2], j & 3);
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) {
+            const double p = a[i >> 2][j] * bv[i >> 2];  // meaningful on the lane that owns row i
+            acc = acc - quad_bcast(p, i & 3);
+        }
+        const double xj = acc / quad_bcast(a[j >> 2][j], j & 3);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (lane + 4 * q == j) bv[q] = xj;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t r = (uint32_t)lane + 4u * q;
+        if (r < n) ws[o_v + r] = bv[q];
+    }
+    return bad;
+}
+
 template <int TEAM, int MODE, bool GRID = false>
 struct Team {
     int lane;     // lane inside the unit that walks a phase (team for SUB, wave for PART, workgroup for WGB)
@@ -445,9 +532,12 @@ struct ConRef<2, PROG> {
 // LIN: every constraint of the topology is of a linear kind (see con_residual); the evaluators are built without
 // the other sixteen kinds.
 // GRID: the build for grid teams (several workgroups per system; MODE_PART with staged lists only).
-template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false>
+// DENSE: tiny systems of sub-wavefront teams whose program was built with the dense factor layout (build_program):
+// Cholesky and the substitutions are plain loops over rows and columns instead of level-by-level list walks.
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false, bool DENSE = false>
 __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), MODE == MODE_SUB ? 4 : 1)
     lm_solve_kernel(const SolveArgs a) {
+    static_assert(!DENSE || (MODE == MODE_SUB && TEAM == 4), "the register-resident dense solve is for teams of four");
     static_assert(!GRID || (MODE == MODE_PART && LDSWS && PLDS), "grid teams are partitioned teams with staged lists");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using namespace dev;
@@ -645,8 +735,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 }
                 tm.phase_sync();
                 EZPZ_STAMP(10);
-                // ---- level-scheduled sparse Cholesky + forward substitution (newton.rs:87-102) --------------------
                 double bad = 0.0;
+                if constexpr (DENSE) {
+                    // ---- <= 8 variables, four lanes: the whole linear solve in registers (dense8_solve) --------------------
+                    bad = dense8_solve(ws, o_d, o_l, o_v, lvl_sptr, n, tm.lane);
+                    tm.phase_sync();
+                    EZPZ_STAMP(11);
+                } else {
+                // ---- level-scheduled sparse Cholesky + forward substitution (newton.rs:87-102) --------------------
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
                     const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
                     const uint32_t s0 = lvl_sptr[lv], s1 = lvl_sptr[lv + 1];
@@ -703,6 +799,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                         ws[o_v + v] = acc / ws[o_d + v];
                     }
                     tm.phase_sync();
+                }
                 }
                 EZPZ_STAMP(12);
                 // ---- ||d||_inf and "did any pivot fail": one rendezvous (newton.rs:96-99, :108) ------------------------------

@@ -223,8 +223,10 @@ void nested_dissection(const std::vector<uint32_t>& verts, const IVecs& adj, std
 }  // namespace
 
 bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& P, BuildError& err,
-                   uint32_t want_parts) {
+                   uint32_t want_parts, bool dense) {
     P = Program();
+    P.c.dense = dense ? 1u : 0u;
+    if (dense) want_parts = 1;
     if (n_cs > 0x7FFFFFF0u || n_vars > 0x7FFFFFF0u) {
         err.code = EZPZ_ERR_TOO_LARGE;
         err.message = "more than 2^31 constraints or variables";
@@ -339,6 +341,12 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
             if (w < v) ++za;
     }
     P.c.za = (uint32_t)za;
+    // The dense layout pays when JtJ is mostly full to begin with (square, parallelogram, circle_tangent: 100 %); a
+    // sketch of mostly Fixed / axis-aligned constraints (tiny: 1 of 6 entries, arc_radius: 11 of 28) keeps its lists.
+    if (dense && (za - n) * 5 < (uint64_t)n * (n - 1) / 2 * 3) {
+        dense = false;
+        P.c.dense = 0;
+    }
     // Elimination order, per connected component: minimum degree, unless the request order already gives a
     // factor that is no denser -- then the variables are eliminated in id order, which makes the factorisation
     // operation-for-operation the textbook left-looking Cholesky of the matrix as the caller numbered it.
@@ -465,6 +473,18 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     std::vector<uint32_t> level(n, 0);
     for (uint32_t j = 0; j < n; ++j)
         if (parent[j] != NONE) level[parent[j]] = std::max(level[parent[j]], level[j] + 1);
+    if (dense) {  // every strictly-lower entry, every column its own level
+        uint64_t zlo = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            rowpat[k].clear();
+            colrows[k].clear();
+            for (uint32_t j = 0; j < k; ++j) rowpat[k].push_back(j);
+            for (uint32_t i = k + 1; i < n; ++i) colrows[k].push_back(i);
+            level[k] = k;
+            zlo += k;
+        }
+        P.c.zlo = (uint32_t)zlo;
+    }
 
     // ---- partitions: balanced unions of components, one per wavefront (longest-processing-time first) -------
     const uint32_t ncomp = P.c.n_components;
@@ -609,7 +629,11 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
     }
 
     // ---- Cholesky pair lists: L(i,j) -= sum_k L(i,k) L(j,k), k < j ---------------------------------------------------
-    {
+    if (dense) {
+        P.lpair_ptr.assign(zlo + 1, 0);
+        P.lpairs.clear();
+        P.c.n_lpairs = 0;
+    } else {
         uint64_t total = 0;
         P.lpair_ptr.assign(zlo + 1, 0);
         // count
@@ -673,9 +697,13 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
         P.fwd_ptr[v + 1] = P.fwd_ptr[v] + (uint32_t)rowpat[pos[v]].size();
         P.bwd_ptr[v + 1] = P.bwd_ptr[v] + (uint32_t)colrows[pos[v]].size();
     }
-    P.fwd_items.assign((size_t)zlo * 2, 0);
-    P.bwd_items.assign((size_t)zlo * 2, 0);
-    for (uint32_t v = 0; v < n; ++v) {
+    if (dense) {  // the kernel does not walk these
+        std::fill(P.fwd_ptr.begin(), P.fwd_ptr.end(), 0u);
+        std::fill(P.bwd_ptr.begin(), P.bwd_ptr.end(), 0u);
+    }
+    P.fwd_items.assign(dense ? 0 : (size_t)zlo * 2, 0);
+    P.bwd_items.assign(dense ? 0 : (size_t)zlo * 2, 0);
+    for (uint32_t v = 0; v < n && !dense; ++v) {
         uint32_t k = pos[v];
         size_t o = (size_t)P.fwd_ptr[v] * 2;
         for (size_t t = 0; t < rowpat[k].size(); ++t) {

@@ -59,6 +59,7 @@ struct ProgramCounts {
     uint32_t n_levels = 0;  // elimination-tree height (max over partitions)
     uint32_t n_components = 0;
     uint32_t n_parts = 1;
+    uint32_t dense = 0;  // dense factor layout (see build_program)
     uint64_t n_apairs = 0, n_lpairs = 0;
 };
 
@@ -96,8 +97,12 @@ int kind_num_ids(uint16_t kind);
 // Builds the program.  `want_parts` > 1 asks for that many balanced partitions (one per wavefront of a
 // workgroup team); if the components cannot be balanced the program comes back with a single partition.
 // Returns false and fills `err` on MissingGuess / bad ids / size limits.
+// `dense` allows the dense factor layout (granted when JtJ is at least 60 % full; see ProgramCounts::dense): tiny
+// systems, one partition: L keeps every strictly-lower entry, column by column in elimination order
+// (slot of column j: lvl_sptr[j] + (i - j - 1)), every column is its own level, and no Cholesky / substitution
+// lists are emitted -- the kernel factorises with plain loops over i, j instead of walking lists level by level.
 bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& out, BuildError& err,
-                   uint32_t want_parts = 1);
+                   uint32_t want_parts = 1, bool dense = false);
 
 // 64-bit topology hash (kinds, tags, ids; not params/weights) for the host-side program cache.
 uint64_t topology_hash(const EzpzConstraint* cs, size_t n_cs, size_t n_vars);
