@@ -190,6 +190,8 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
     if (s.mode == MODE_SUB) {
         const uint32_t team = s.team_size;
         s.lds_ws = true;
+        // 256 lanes unless the workspaces would not fit; measured: smaller workgroups (more resident wavefronts for
+        // big workspaces) are never faster, the kernels are issue-bound
         uint32_t threads = 256;
         while (threads > 64 && prog_bytes + (size_t)(threads / team) * ws_bytes > 64 * 1024) threads >>= 1;
         s.block_threads = std::max(threads, team);

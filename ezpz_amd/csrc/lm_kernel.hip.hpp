@@ -534,8 +534,10 @@ struct ConRef<2, PROG> {
 // GRID: the build for grid teams (several workgroups per system; MODE_PART with staged lists only).
 // DENSE: tiny systems of sub-wavefront teams whose program was built with the dense factor layout (build_program):
 // Cholesky and the substitutions are plain loops over rows and columns instead of level-by-level list walks.
+// Occupancy hints: sub-wavefront teams are compiled for 4 workgroups per CU (128 VGPRs; measured against 3 and 2:
+// +8 % on some topologies, -7 % on others), the register-resident dense solve for 2 (184 VGPRs, no spills: +12 %).
 template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false, bool DENSE = false>
-__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), MODE == MODE_SUB ? 4 : 1)
+__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), MODE == MODE_SUB ? (DENSE ? 2 : 4) : 1)
     lm_solve_kernel(const SolveArgs a) {
     static_assert(!DENSE || (MODE == MODE_SUB && TEAM == 4), "the register-resident dense solve is for teams of four");
     static_assert(!GRID || (MODE == MODE_PART && LDSWS && PLDS), "grid teams are partitioned teams with staged lists");

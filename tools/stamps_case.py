@@ -8,18 +8,19 @@ from oracle import oracle as O, textual as T
 from conftest import read_case
 name = sys.argv[1] if len(sys.argv) > 1 else "square"
 team = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # systems per launch (stamps come from block 0 / lane 0 only)
 ref = T.load(read_case(name))
 recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
 s = E.System(recs, ref.num_vars, team_size=team)
 print(s.info())
 dev = torch.device('cuda', 0)
-x0 = torch.from_numpy(ref.guesses[None, :].copy()).to(dev)
-xo = torch.empty_like(x0); st = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+x0 = torch.from_numpy(np.repeat(ref.guesses[None, :], B, axis=0).copy()).to(dev)
+xo = torch.empty_like(x0); st = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
 buf = torch.zeros(2048, dtype=torch.int64, device=dev)
 L = E.lib(); L.ezpz_debug_set_stamps.argtypes = [C.c_void_p]; L.ezpz_debug_set_stamps(buf.data_ptr())
 stream = torch.cuda.current_stream(dev).cuda_stream
 for _ in range(3):
-    buf.zero_(); s.solve_batch_device(x0.data_ptr(), 1, xo.data_ptr(), st.data_ptr(), 0, stream)
+    buf.zero_(); s.solve_batch_device(x0.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, stream)
 torch.cuda.synchronize()
 b = buf.cpu().numpy().reshape(-1, 2)
 names = {1: "start", 2: "x loaded", 10: "normal eq", 11: "chol+fwd", 12: "bwd", 13: "reduce(bad,dmax)", 14: "x+=d", 20: "R sweep",
