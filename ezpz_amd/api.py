@@ -601,6 +601,9 @@ def solve_batch(reqs, x0: np.ndarray, config: Optional[Config] = None, want_mask
     return x, st, prio, mask
 
 
+TEAM_AUTO_LATENCY = 0xFFFFFFFF  # `team_size`: choose for the latency of one solve instead of batch throughput (ezpz_amd.h)
+
+
 class System:
     """One analysed topology resident on a device: `ezpz_system_create` + batched solves.
 

@@ -110,6 +110,8 @@ struct EzpzSystem {
     void* dev_grid_blob = nullptr;
     DevBuf<ProgramView> grid_views;
     uint32_t prog_lds_doubles = 0;
+    uint32_t lvl_lds_off = 0, lvl_tab_words = 0, lvl_buf_words = 0;  // level staging of the Cholesky lists (finish_team)
+    uint32_t lvl_nlev = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
     size_t lds_bytes = 0;
@@ -187,15 +189,33 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
     s.prog_in_lds = stage_bytes > 0;
     s.prog_lds_doubles = (uint32_t)((stage_bytes + 15) / 16 * 2);
     const size_t prog_bytes = (size_t)s.prog_lds_doubles * 8;
+    // Level staging (lm_kernel.hip.hpp, Cholesky loop): programs read from global memory on one wavefront or one
+    // barrier workgroup per system get LDS for the three level tables and for one level of lists (levels wider than
+    // the buffer are walked from global memory as before).
+    s.lvl_lds_off = s.lvl_tab_words = s.lvl_buf_words = 0;
+    const bool lvl_ok = s.view.lvl_words_max > 0 && !s.prog_in_lds && s.grid_wgs <= 1 &&
+                        ((s.mode == MODE_SUB && s.team_size == 64) || s.mode == MODE_WGB);
+    const uint32_t lvl_tab_words = (5 * (s.lvl_nlev + 1) + 3) & ~3u;
     if (s.mode == MODE_SUB) {
         const uint32_t team = s.team_size;
         s.lds_ws = true;
+        size_t buf_bytes = 0;
+        if (lvl_ok) {  // one buffer per wavefront, at most a quarter of what the workspace takes
+            buf_bytes = std::min<size_t>((size_t)s.view.lvl_words_max * 4, std::max<size_t>(ws_bytes / 4, 2048));
+            buf_bytes &= ~size_t(15);
+        }
         // 256 lanes unless the workspaces would not fit; measured: smaller workgroups (more resident wavefronts for
         // big workspaces) are never faster, the kernels are issue-bound
         uint32_t threads = 256;
-        while (threads > 64 && prog_bytes + (size_t)(threads / team) * ws_bytes > 64 * 1024) threads >>= 1;
+        while (threads > 64 && prog_bytes + (size_t)(threads / team) * (ws_bytes + buf_bytes) > 64 * 1024) threads >>= 1;
         s.block_threads = std::max(threads, team);
         s.lds_bytes = prog_bytes + (size_t)(s.block_threads / team) * ws_bytes + 16;
+        if (lvl_ok && buf_bytes >= 1024) {
+            s.lvl_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);
+            s.lvl_tab_words = lvl_tab_words;
+            s.lvl_buf_words = (uint32_t)(buf_bytes / 4);
+            s.lds_bytes = (size_t)s.lvl_lds_off * 8 + (size_t)lvl_tab_words * 4 + (size_t)(s.block_threads / 64) * buf_bytes;
+        }
     } else {
         s.block_threads = s.team_size;
         if (s.grid_wgs > 1) {  // every workgroup stages its own sub-program's lists
@@ -207,6 +227,19 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
         } else {
             s.lds_ws = prog_bytes + ws_bytes + 1024 <= kLdsBytesMax;
             s.lds_bytes = s.lds_ws ? prog_bytes + ws_bytes + 64 * 8 + 16 : prog_bytes + 80 * 8;
+            if (lvl_ok) {
+                const size_t base = (s.lds_bytes + 15) & ~size_t(15);
+                const size_t room = kLdsBytesMax - 1024 > base + (size_t)lvl_tab_words * 4
+                                        ? kLdsBytesMax - 1024 - base - (size_t)lvl_tab_words * 4 : 0;
+                size_t buf_bytes = std::min<size_t>((size_t)s.view.lvl_words_max * 4, std::min<size_t>(room, 48 * 1024));
+                buf_bytes &= ~size_t(15);
+                if (buf_bytes >= 1024) {
+                    s.lvl_lds_off = (uint32_t)(base / 8);
+                    s.lvl_tab_words = lvl_tab_words;
+                    s.lvl_buf_words = (uint32_t)(buf_bytes / 4);
+                    s.lds_bytes = base + (size_t)lvl_tab_words * 4 + buf_bytes;
+                }
+            }
         }
     }
 }
@@ -431,6 +464,11 @@ static size_t pack_program(const Program& P, bool idx16, bool pack_table, std::v
     v.o_lvl_cptr = put(P.lvl_cptr);
     v.o_lvl_sptr = put(P.lvl_sptr);
     v.o_l_col = put(P.l_col);
+    {
+        std::vector<uint32_t> grp = P.lvl_grp;
+        grp.resize(P.lvl_cptr.size(), 1u | (1u << 8));
+        v.o_lvl_grp = put(grp);
+    }
     v.o_lpair_ptr = put(P.lpair_ptr);
     v.o_lpairs = put(P.lpairs);
     v.o_fwd_ptr = put(P.fwd_ptr);
@@ -488,6 +526,64 @@ static size_t pack_program(const Program& P, bool idx16, bool pack_table, std::v
         v.o_cons = (uint32_t)append(blob, P.cons);
     }
     blob.resize((blob.size() + 15) & ~size_t(15));
+    // Programs read from global memory (32-bit lists) of one partition: the lists one elimination level walks,
+    // gathered into one contiguous block per level with level-relative list bounds, so that a team can bring a whole
+    // level into LDS with one round of independent loads instead of chasing ptr -> items -> values through L2 twice
+    // per level.  Block layout (32-bit words, every array padded to an even count, the block to a multiple of 4):
+    //   [n_fwd, n_pairs] [fwd_ptr - fwd_ptr[c0] : ncols + 1] [fwd_items : 2 n_fwd]
+    //   [lpair_ptr - lpair_ptr[s0] : nslots + 1] [lpairs : 2 n_pairs] [l_col : nslots]
+    v.o_lvl_off = v.o_lvl_stream = v.o_lvl_boff = v.o_lvl_bstream = v.lvl_words_max = 0;
+    if (!idx16 && P.c.n_parts == 1 && !P.c.dense && !P.parts.empty()) {
+        const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev;
+        std::vector<uint32_t> off(nlev + 1), stream;
+        auto pad = [&](size_t to) {
+            while (stream.size() % to) stream.push_back(0);
+        };
+        uint32_t widest = 0;
+        for (uint32_t lv = 0; lv < nlev; ++lv) {
+            const uint32_t c0 = P.lvl_cptr[lvl0 + lv], c1 = P.lvl_cptr[lvl0 + lv + 1];
+            const uint32_t s0 = P.lvl_sptr[lvl0 + lv], s1 = P.lvl_sptr[lvl0 + lv + 1];
+            const uint32_t fq0 = P.fwd_ptr[c0], fq1 = P.fwd_ptr[c1], lq0 = P.lpair_ptr[s0], lq1 = P.lpair_ptr[s1];
+            off[lv] = (uint32_t)stream.size();
+            stream.push_back(fq1 - fq0);
+            stream.push_back(lq1 - lq0);
+            for (uint32_t k = c0; k <= c1; ++k) stream.push_back(P.fwd_ptr[k] - fq0);
+            pad(2);
+            stream.insert(stream.end(), P.fwd_items.begin() + 2 * (size_t)fq0, P.fwd_items.begin() + 2 * (size_t)fq1);
+            for (uint32_t k = s0; k <= s1; ++k) stream.push_back(P.lpair_ptr[k] - lq0);
+            pad(2);
+            stream.insert(stream.end(), P.lpairs.begin() + 2 * (size_t)lq0, P.lpairs.begin() + 2 * (size_t)lq1);
+            stream.insert(stream.end(), P.l_col.begin() + s0, P.l_col.begin() + s1);
+            pad(4);
+            widest = std::max<uint32_t>(widest, (uint32_t)stream.size() - off[lv]);
+        }
+        off[nlev] = (uint32_t)stream.size();
+        std::vector<uint32_t> boff(nlev + 1), bstream;
+        for (uint32_t lv = 0; lv < nlev; ++lv) {
+            const uint32_t c0 = P.lvl_cptr[lvl0 + lv], c1 = P.lvl_cptr[lvl0 + lv + 1];
+            const uint32_t q0 = P.bwd_ptr[c0], q1 = P.bwd_ptr[c1];
+            boff[lv] = (uint32_t)bstream.size();
+            bstream.push_back(q1 - q0);
+            bstream.push_back(0);
+            for (uint32_t k = c0; k <= c1; ++k) bstream.push_back(P.bwd_ptr[k] - q0);
+            while (bstream.size() % 2) bstream.push_back(0);
+            bstream.insert(bstream.end(), P.bwd_items.begin() + 2 * (size_t)q0, P.bwd_items.begin() + 2 * (size_t)q1);
+            while (bstream.size() % 4) bstream.push_back(0);
+            widest = std::max<uint32_t>(widest, (uint32_t)bstream.size() - boff[lv]);
+        }
+        boff[nlev] = (uint32_t)bstream.size();
+        if (stream.size() < (1u << 30) && bstream.size() < (1u << 30)) {
+            v.o_lvl_off = (uint32_t)append(blob, off);
+            blob.resize((blob.size() + 15) & ~size_t(15));
+            v.o_lvl_stream = (uint32_t)append(blob, stream);
+            blob.resize((blob.size() + 15) & ~size_t(15));
+            v.o_lvl_boff = (uint32_t)append(blob, boff);
+            blob.resize((blob.size() + 15) & ~size_t(15));
+            v.o_lvl_bstream = (uint32_t)append(blob, bstream);
+            blob.resize((blob.size() + 15) & ~size_t(15));
+            v.lvl_words_max = widest;
+        }
+    }
     v.blob_bytes = (uint32_t)blob.size();
     v.n_cons = P.c.n_cons;
     v.n_vars = P.c.n_vars;
@@ -596,6 +692,39 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
 }
 
 // Symbolic phase + launch-shape decision shared by ezpz_system_create and ezpz_analyze.
+// Lanes per list, level by level, for the teams that run a level as one phase (one wavefront or one barrier workgroup
+// on a one-partition program): a level lasts as long as its longest list, and the top levels of an elimination tree are
+// a few columns with long lists, so there g lanes share each list.  g minimises passes x (rounds per list + the group's
+// reduction), in units of one chunk's round trip.
+static void choose_level_groups(Program& P, const EzpzSystem& s) {
+    P.lvl_grp.assign(P.lvl_cptr.size(), 1u | (1u << 8));
+    const bool fused = (s.mode == MODE_WGB || (s.mode == MODE_SUB && s.team_size == 64)) && s.grid_wgs <= 1;
+    if (!fused || P.c.n_parts != 1 || P.c.dense || P.parts.empty()) return;
+    const uint32_t lanes = s.team_size, chunk = s.mode == MODE_SUB ? 4u : 2u;
+    const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev;
+    for (uint32_t lv = 0; lv < nlev; ++lv) {
+        const uint32_t c0 = P.lvl_cptr[lvl0 + lv], c1 = P.lvl_cptr[lvl0 + lv + 1];
+        const uint32_t s0 = P.lvl_sptr[lvl0 + lv], s1 = P.lvl_sptr[lvl0 + lv + 1];
+        if (c1 - c0 > lanes) continue;  // wider than the team: the two-phase walk
+        uint32_t need = 0;
+        for (uint32_t c = c0; c < c1; ++c) need = std::max(need, P.fwd_ptr[c + 1] - P.fwd_ptr[c]);
+        for (uint32_t k = s0; k < s1; ++k) need = std::max(need, P.lpair_ptr[k + 1] - P.lpair_ptr[k]);
+        double best = 0.0;
+        uint32_t best_g = 1;
+        for (uint32_t g = 1, lg = 0; g <= 64 && (uint64_t)(c1 - c0) * g <= lanes; g <<= 1, ++lg) {
+            const double passes = std::max<double>(1.0, std::ceil((double)(s1 - s0) * g / lanes));
+            const double rounds = std::ceil((double)need / (g * chunk));
+            const double cost = passes * (rounds + (g > 1 ? 0.3 + 0.25 * lg : 0.0));
+            if (g == 1 || cost < best - 1e-9) best = cost, best_g = g;
+        }
+        // backward substitution: one list per column, so g is bounded by the lanes per column only
+        uint32_t bneed = 0, bg = 1;
+        for (uint32_t c = c0; c < c1; ++c) bneed = std::max(bneed, P.bwd_ptr[c + 1] - P.bwd_ptr[c]);
+        while (bg < 64 && (uint64_t)(c1 - c0) * (bg * 2) <= lanes && bg * chunk < bneed) bg <<= 1;
+        P.lvl_grp[lvl0 + lv] = best_g | (bg << 8);
+    }
+}
+
 static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t team_size, EzpzSystem& s,
                         Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable) {
     BuildError be;
@@ -605,6 +734,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         if (err_variable) *err_variable = be.variable;
         return be.code;
     };
+    const bool for_latency = team_size == EZPZ_TEAM_AUTO_LATENCY;
+    if (for_latency) team_size = 0;
     bool want_sub = team_size ? team_size <= 64 : width <= 64;
     if (want_sub) {
         uint32_t team = team_size ? pow2_ceil(team_size) : auto_sub_team(cs, n_cs);
@@ -725,7 +856,18 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
         s.grid_wgs = G;
         s.mode = P.c.n_parts > 1 ? MODE_PART : MODE_WGB;
+        // one partition: the lanes are not tied to partitions, and the levels' long lists are shared by groups of
+        // lanes (choose_level_groups), so more lanes shorten every level (800 variables: 11.1 / 8.7 / 7.1 ms per 60
+        // iterations on 128 / 256 / 512 lanes)
+        if (!team_size && G == 1 && P.c.n_parts == 1) team = std::min<uint32_t>(512, std::max(team, pow2_ceil(width)));
         s.team_size = team;
+        // One connected component is a chain of elimination levels, each a few dependent memory hops and a divide: a
+        // workgroup's extra lanes mostly wait at its barriers.  For batches one wavefront per system (no barriers, 2-4
+        // systems per CU) gives 2-2.6x the rate at 150-300 variables; one solve alone takes ~25 % longer that way.
+        if (!team_size && !for_latency && G == 1 && P.c.n_parts == 1 && sub_team_fits(P.c, 64)) {
+            s.mode = MODE_SUB;
+            s.team_size = 64;
+        }
     }
     s.counts = P.c;
     s.unit_weights = true;
@@ -739,6 +881,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     s.host_slot_row = P.slot_row;
     s.host_slot_col = P.slot_col;
 
+    choose_level_groups(P, s);
     // ---- pack the blob (pack_program) ----------------------------------------------------------------------------
     const bool small_counts = P.c.n_vars < 65536 && P.c.n_rows < 65536 && P.c.zj < 65536 && P.c.zlo < 65536 &&
                               P.c.n_apairs < 65536 && P.c.n_lpairs < 65536 && P.c.n_cons < 65536;
@@ -759,6 +902,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return fail();
     }
     v.stage_bytes = (uint32_t)stage_bytes;
+    s.lvl_nlev = P.parts.empty() ? 0 : P.parts[0].nlev;
     finish_team(s, stage_bytes);
 
     EzpzSystemInfo& info = s.info;
@@ -890,6 +1034,9 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.batch = batch;
     a.ws_doubles = sys->ws_doubles;
     a.prog_lds_doubles = sys->prog_lds_doubles;
+    a.lvl_lds_off = sys->lvl_lds_off;
+    a.lvl_tab_words = sys->lvl_tab_words;
+    a.lvl_buf_words = sys->lvl_buf_words;
     a.stamps = g_stamps;
     a.unit_weights = sys->unit_weights ? 1u : 0u;
     a.grid_wgs = 1;

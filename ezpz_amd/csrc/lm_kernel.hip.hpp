@@ -41,12 +41,16 @@ struct ProgramView {
     uint32_t o_cons, o_parts;
     uint32_t o_colj_ptr, o_colj_items;
     uint32_t o_apair_ptr, o_apairs;
-    uint32_t o_lvl_cptr, o_var_of, o_lvl_sptr, o_l_col;
+    uint32_t o_lvl_cptr, o_var_of, o_lvl_sptr, o_l_col, o_lvl_grp;
     uint32_t o_lpair_ptr, o_lpairs;
     uint32_t o_fwd_ptr, o_fwd_items;
     uint32_t o_bwd_ptr, o_bwd_items;
     uint32_t o_pos, o_weights, o_patterns;  // side arrays of a packed constraint table
     uint32_t packed;                        // constraint table holds 32-byte PackedCon records
+    // Per-level stream of the Cholesky lists (32-bit programs of one partition; see pack_program): level lv is words
+    // [lvl_off[lv], lvl_off[lv + 1]) of lvl_stream, a block that a team copies to LDS in one go.
+    uint32_t o_lvl_off, o_lvl_stream, lvl_words_max;
+    uint32_t o_lvl_boff, o_lvl_bstream;  // the same for the backward substitution: [n_items, 0] [bwd_ptr rel] [bwd_items]
     uint32_t blob_bytes;
     uint32_t stage_bytes;  // leading bytes of the blob to copy into LDS (index lists, or the whole blob); 0 = none
     uint32_t n_cons, n_vars, n_rows, zj, zlo, n_parts;
@@ -64,11 +68,13 @@ struct Prog {
     const PartDesc* parts;
     const IDX *colj_ptr, *colj_items;
     const IDX *apair_ptr, *apairs;
-    const IDX *lvl_cptr, *lvl_sptr, *l_col;
+    const IDX *lvl_cptr, *lvl_sptr, *l_col, *lvl_grp;
     const uint32_t* var_of;
     const IDX *lpair_ptr, *lpairs;
     const IDX *fwd_ptr, *fwd_items;
     const IDX *bwd_ptr, *bwd_items;
+    const uint32_t *lvl_off, *lvl_stream;  // per-level blocks of the Cholesky lists (32-bit programs of one partition)
+    const uint32_t *lvl_boff, *lvl_bstream;  // ... and of the backward substitution's
 };
 
 // `lists` addresses the index lists (LDS copy or global blob), `tables` the constraint table / partitions.
@@ -91,12 +97,17 @@ __device__ __forceinline__ Prog<IDX> make_prog(const ProgramView& v, const unsig
     p.var_of = reinterpret_cast<const uint32_t*>(lists + v.o_var_of);
     p.lvl_sptr = u(v.o_lvl_sptr);
     p.l_col = u(v.o_l_col);
+    p.lvl_grp = u(v.o_lvl_grp);
     p.lpair_ptr = u(v.o_lpair_ptr);
     p.lpairs = u(v.o_lpairs);
     p.fwd_ptr = u(v.o_fwd_ptr);
     p.fwd_items = u(v.o_fwd_items);
     p.bwd_ptr = u(v.o_bwd_ptr);
     p.bwd_items = u(v.o_bwd_items);
+    p.lvl_off = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_off);
+    p.lvl_stream = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_stream);
+    p.lvl_boff = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_boff);
+    p.lvl_bstream = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_bstream);
     return p;
 }
 
@@ -197,6 +208,9 @@ struct SolveArgs {
     GridScratch* grid_scratch;   // grid teams: one per system in flight
     const ProgramView* grid_views;  // grid teams: the sub-program of each workgroup of a system
     uint32_t grid_wgs;           // workgroups per system (1 = every other team shape)
+    // level staging (see the Cholesky loop): LDS offset (doubles) of the level tables, words reserved for the tables,
+    // words of one level buffer (0 = off)
+    uint32_t lvl_lds_off, lvl_tab_words, lvl_buf_words;
 };
 
 #ifdef EZPZ_STAMPS
@@ -249,6 +263,22 @@ __device__ __forceinline__ void load_pair(const uint32_t* items, uint32_t q, uin
         _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) {                   \
             ok_[k] = q_ + k < (q1);                                                \
             load_pair((items), ok_[k] ? q_ + k : q_, A[k], B[k]);                  \
+        }                                                                          \
+        _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) { LOADVALS; }       \
+        _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) {                   \
+            if (ok_[k]) { FOLD; }                                                  \
+        }                                                                          \
+    }
+
+// The same walk by one lane of a group of `step` lanes that share the list: entries qb, qb + step, qb + 2 step, ...
+// (qb = q0 + the lane's position in its group); the group adds its partial sums afterwards.
+#define EZPZ_FOR_PAIRS_STRIDED(items, qb, q1, step, A, B, LOADVALS, FOLD)          \
+    for (uint32_t q_ = (qb); q_ < (q1); q_ += LIST_CHUNK * (step)) {               \
+        uint32_t A[LIST_CHUNK], B[LIST_CHUNK];                                     \
+        bool ok_[LIST_CHUNK];                                                      \
+        _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) {                   \
+            ok_[k] = q_ + k * (step) < (q1);                                       \
+            load_pair((items), ok_[k] ? q_ + k * (step) : q_, A[k], B[k]);         \
         }                                                                          \
         _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) { LOADVALS; }       \
         _Pragma("unroll") for (int k = 0; k < LIST_CHUNK; ++k) {                   \
@@ -648,9 +678,35 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     const uint32_t con0 = part.con0, con1 = part.con1;
     const idx_t* lvl_cptr = P.lvl_cptr + part.lvl0;
     const idx_t* lvl_sptr = P.lvl_sptr + part.lvl0;
+    const idx_t* lvl_grp = P.lvl_grp + part.lvl0;  // lanes per list, by level (fused levels only)
     const uint32_t nlev = part.nlev;
     const uint32_t call0 = lvl_cptr[0], call1 = lvl_cptr[nlev];  // all of the partition's (internal) variables
     const uint32_t sall0 = lvl_sptr[0], sall1 = lvl_sptr[nlev];  // all of its strictly-lower L slots
+
+    // ---- level staging ---------------------------------------------------------------------------------------------
+    // A program read from global memory costs the Cholesky two dependent L2 round trips (ptr -> items) before the
+    // first value load, twice per elimination level; with ~40 levels of a few columns each that chain is most of a
+    // connected sketch's solve.  One wavefront / one barrier workgroup per system therefore copies each level's lists
+    // (a contiguous block of lvl_stream, see pack_program) into LDS with one round of independent 16-byte loads and
+    // walks them from there; the three level tables are copied once per workgroup.
+    constexpr bool LVL_STAGE = !PLDS && !DENSE && !GRID && (MODE == MODE_WGB || (MODE == MODE_SUB && TEAM == 64));
+    const uint32_t* lvl_tab = nullptr;  // [lvl_cptr | lvl_sptr | lvl_off | lvl_grp | lvl_boff], nlev + 1 words each
+    uint32_t* lvl_buf = nullptr;
+    if constexpr (LVL_STAGE) {
+        if (a.lvl_buf_words) {
+            uint32_t* tab = reinterpret_cast<uint32_t*>(smem + a.lvl_lds_off);
+            for (uint32_t i = tid; i <= nlev; i += blockDim.x) {
+                tab[i] = lvl_cptr[i];
+                tab[nlev + 1 + i] = lvl_sptr[i];
+                tab[2 * (nlev + 1) + i] = P.lvl_off[i];
+                tab[3 * (nlev + 1) + i] = i < nlev ? lvl_grp[i] : 1u;
+                tab[4 * (nlev + 1) + i] = P.lvl_boff[i];
+            }
+            __syncthreads();
+            lvl_tab = tab;
+            lvl_buf = tab + a.lvl_tab_words + (MODE == MODE_SUB ? (uint32_t)(tid >> 6) * a.lvl_buf_words : 0u);
+        }
+    }
 
     // (A variant that kept the first four rounds of constraint records in VGPRs across sweeps and systems was
     // measured slower -- 54 vs 38 us per 2000x2000 system -- and is not kept; records are re-read per sweep.)
@@ -745,16 +801,121 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     EZPZ_STAMP(11);
                 } else {
                 // ---- level-scheduled sparse Cholesky + forward substitution (newton.rs:87-102) --------------------
-                for (uint32_t lv = 0; lv < nlev; ++lv) {
-                    const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
-                    const uint32_t s0 = lvl_sptr[lv], s1 = lvl_sptr[lv + 1];
+                // One level = the columns [c0, c1) and the strictly-lower slots [s0, s1) of L.  `fptr` is indexed by
+                // column and `lptr` / `lcol` by slot (absolute numbers: the staged copies are biased accordingly), the
+                // list bounds they hold are relative to `fitems` / `lpairs`.
+                // Teams that own a whole connected system (one wavefront, or a barrier workgroup) are bound by the chain
+                // of dependent hops per level, so they run a level as ONE phase when it has no more columns than lanes:
+                // the lane of column v takes d_v = sqrt(A_vv - sum l_vk^2) and y_v at once, and every lane of a slot
+                // (i, j) recomputes d_j itself (same terms, same order, same bits) instead of waiting a phase for it.
+                // d_v is stored after the rendezvous: until then A_vv is still being read, and nothing reads d_v before
+                // the backward substitution (which the same lane does for v).
+                constexpr bool FUSE_LEVEL = MODE == MODE_WGB || (MODE == MODE_SUB && TEAM == 64);
+                // The top of an elimination tree is narrow and dense (a separator's columns: 1-10 columns whose lists
+                // hold 20-50 terms), and a level lasts as long as its longest list.  There `g` lanes share every list
+                // (the host picks g per level, choose_level_groups): each takes every g-th term, and the group adds
+                // the partial sums in a fixed DPP / shuffle tree (the same on every run; the rounding differs from the
+                // one-lane order, as it does between any two elimination orders).
+                auto group_sum = [&](double v, uint32_t g) {
+                    switch (g) {
+                    case 2: return reduce_lanes<2>(v, OpSum());
+                    case 4: return reduce_lanes<4>(v, OpSum());
+                    case 8: return reduce_lanes<8>(v, OpSum());
+                    case 16: return reduce_lanes<16>(v, OpSum());
+                    case 32: return reduce_lanes<32>(v, OpSum());
+                    default: return reduce_lanes<64>(v, OpSum());
+                    }
+                };
+                auto chol_level = [&](uint32_t c0, uint32_t c1, uint32_t s0, uint32_t s1, uint32_t g, auto fptr,
+                                      auto fitems, auto lptr, auto lpairs, auto lcol) __attribute__((always_inline)) {
+                    if (FUSE_LEVEL && g > 1) {  // (c1 - c0) * g <= lanes, by construction
+                        const uint32_t lg = (uint32_t)__builtin_ctz(g);
+                        const uint32_t sub = (uint32_t)tm.lane & (g - 1), grp = (uint32_t)tm.lane >> lg;
+                        const uint32_t ngrp = (uint32_t)tm.stride >> lg;
+                        const uint32_t v = c0 + grp;
+                        const bool own = v < c1;
+                        double dv = 0.0;
+                        if (own) {
+                            double sa = 0.0, sy = 0.0;
+                            const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
+                            double va[4], vb[4];
+                            EZPZ_FOR_PAIRS_STRIDED(fitems, q0 + sub, q1, g, sl, vk,
+                                                   (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
+                                                   (sa += va[k] * va[k], sy += va[k] * vb[k]))
+                            sa = group_sum(sa, g);
+                            sy = group_sum(sy, g);
+                            const double acc = ws[o_d + v] - sa;
+                            const double y = ws[o_v + v] - sy;
+                            if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                            dv = sqrt(acc);
+                            if (sub == 0) ws[o_v + v] = y / dv;
+                        }
+                        for (uint32_t s = s0 + grp; s < s1; s += ngrp) {
+                            const uint32_t j = lcol[s];
+                            double sd = 0.0, sp = 0.0;
+                            {
+                                const uint32_t q0 = fptr[j], q1 = fptr[j + 1];
+                                double l[4];
+                                EZPZ_FOR_PAIRS_STRIDED(fitems, q0 + sub, q1, g, sl, vk, (l[k] = ws[o_l + sl[k]]),
+                                                       (sd += l[k] * l[k]))
+                            }
+                            {
+                                const uint32_t q0 = lptr[s], q1 = lptr[s + 1];
+                                double va[4], vb[4];
+                                EZPZ_FOR_PAIRS_STRIDED(lpairs, q0 + sub, q1, g, ia, ib,
+                                                       (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_l + ib[k]]),
+                                                       (sp += va[k] * vb[k]))
+                            }
+                            sd = group_sum(sd, g);
+                            sp = group_sum(sp, g);
+                            if (sub == 0) ws[o_l + s] = (ws[o_l + s] - sp) / sqrt(ws[o_d + j] - sd);
+                        }
+                        tm.phase_sync();
+                        if (own && sub == 0) ws[o_d + v] = dv;
+                        return;
+                    }
+                    if (FUSE_LEVEL && c1 - c0 <= (uint32_t)tm.stride) {
+                        const uint32_t v = c0 + tm.lane;
+                        const bool own = v < c1;
+                        double dv = 0.0;
+                        if (own) {
+                            double acc = ws[o_d + v], y = ws[o_v + v];
+                            const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
+                            double va[4], vb[4];
+                            EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
+                                            (acc -= va[k] * va[k], y -= va[k] * vb[k]))
+                            if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                            dv = sqrt(acc);
+                            ws[o_v + v] = y / dv;
+                        }
+                        for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride) {
+                            const uint32_t j = lcol[s];
+                            double dj = ws[o_d + j];
+                            {
+                                const uint32_t q0 = fptr[j], q1 = fptr[j + 1];
+                                double l[4];
+                                EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (l[k] = ws[o_l + sl[k]]), (dj -= l[k] * l[k]))
+                            }
+                            double acc = ws[o_l + s];
+                            {
+                                const uint32_t q0 = lptr[s], q1 = lptr[s + 1];
+                                double va[4], vb[4];
+                                EZPZ_FOR_PAIRS4(lpairs, q0, q1, ia, ib, (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_l + ib[k]]),
+                                                (acc -= va[k] * vb[k]))
+                            }
+                            ws[o_l + s] = acc / sqrt(dj);
+                        }
+                        tm.phase_sync();
+                        if (own) ws[o_d + v] = dv;
+                        return;
+                    }
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
                         const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_d + v];
                         {
-                            const uint32_t q0 = P.fwd_ptr[v], q1 = P.fwd_ptr[v + 1];
+                            const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
                             double l[4];
-                            EZPZ_FOR_PAIRS4(P.fwd_items, q0, q1, sl, vk, (l[k] = ws[o_l + sl[k]]), (acc -= l[k] * l[k]))
+                            EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (l[k] = ws[o_l + sl[k]]), (acc -= l[k] * l[k]))
                         }
                         if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
                         ws[o_d + v] = sqrt(acc);
@@ -762,45 +923,107 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride) {
                         double acc = ws[o_l + s];
                         {
-                            const uint32_t q0 = P.lpair_ptr[s], q1 = P.lpair_ptr[s + 1];
+                            const uint32_t q0 = lptr[s], q1 = lptr[s + 1];
                             double va[4], vb[4];
-                            EZPZ_FOR_PAIRS4(P.lpairs, q0, q1, ia, ib, (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_l + ib[k]]),
+                            EZPZ_FOR_PAIRS4(lpairs, q0, q1, ia, ib, (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_l + ib[k]]),
                                             (acc -= va[k] * vb[k]))
                         }
                         ws[o_l + s] = acc;
                     }
                     tm.phase_sync();
                     for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride)
-                        ws[o_l + s] = ws[o_l + s] / ws[o_d + P.l_col[s]];
+                        ws[o_l + s] = ws[o_l + s] / ws[o_d + lcol[s]];
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
                         const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_v + v];
                         {
-                            const uint32_t q0 = P.fwd_ptr[v], q1 = P.fwd_ptr[v + 1];
+                            const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
                             double va[4], vb[4];
-                            EZPZ_FOR_PAIRS4(P.fwd_items, q0, q1, sl, vk, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
+                            EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
                                             (acc -= va[k] * vb[k]))
                         }
                         ws[o_v + v] = acc / ws[o_d + v];
                     }
                     tm.phase_sync();
+                };
+                for (uint32_t lv = 0; lv < nlev; ++lv) {
+                    if constexpr (LVL_STAGE) {
+                        if (lvl_buf) {
+                            const uint32_t w0 = lvl_tab[2 * (nlev + 1) + lv], w1 = lvl_tab[2 * (nlev + 1) + lv + 1];
+                            if (w1 - w0 <= a.lvl_buf_words) {
+                                const uint32_t c0 = lvl_tab[lv], c1 = lvl_tab[lv + 1];
+                                const uint32_t s0 = lvl_tab[nlev + 1 + lv], s1 = lvl_tab[nlev + 1 + lv + 1];
+                                const uint4* src = reinterpret_cast<const uint4*>(P.lvl_stream + w0);
+                                uint4* dst = reinterpret_cast<uint4*>(lvl_buf);
+                                for (uint32_t i = tm.lane; i < (w1 - w0) / 4; i += tm.stride) dst[i] = src[i];
+                                tm.phase_sync();
+                                const uint32_t n_fwd = lvl_buf[0], n_pairs = lvl_buf[1];
+                                const uint32_t* fptr = lvl_buf + 2;
+                                const uint32_t* fitems = fptr + ((c1 - c0 + 2) & ~1u);
+                                const uint32_t* lptr = fitems + 2 * n_fwd;
+                                const uint32_t* lpairs = lptr + ((s1 - s0 + 2) & ~1u);
+                                const uint32_t* lcol = lpairs + 2 * n_pairs;
+                                chol_level(c0, c1, s0, s1, lvl_tab[3 * (nlev + 1) + lv] & 0xFFu, fptr - c0, fitems, lptr - s0, lpairs,
+                                           lcol - s0);
+                                continue;
+                            }
+                        }
+                    }
+                    chol_level(lvl_cptr[lv], lvl_cptr[lv + 1], lvl_sptr[lv], lvl_sptr[lv + 1], FUSE_LEVEL ? (lvl_grp[lv] & 0xFFu) : 1u,
+                               P.fwd_ptr, P.fwd_items, P.lpair_ptr, P.lpairs, P.l_col);
                 }
                 EZPZ_STAMP(11);
                 // ---- backward substitution (garbage but harmless if the factorisation failed) ---------------------------
-                for (uint32_t lv = nlev; lv-- > 0;) {
-                    const uint32_t c0 = lvl_cptr[lv], c1 = lvl_cptr[lv + 1];
-                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
-                        const uint32_t v = ci;  // internal variable numbering = schedule order
-                        double acc = ws[o_v + v];
-                        {
-                            const uint32_t q0 = P.bwd_ptr[v], q1 = P.bwd_ptr[v + 1];
+                // Same two devices as the factorisation: the level's lists come from LDS when they were staged, and g
+                // lanes share a column's list where the level has lanes to spare (high byte of lvl_grp).
+                auto bwd_level = [&](uint32_t c0, uint32_t c1, uint32_t g, auto bptr, auto bitems)
+                                     __attribute__((always_inline)) {
+                    if (FUSE_LEVEL && g > 1) {  // (c1 - c0) * g <= lanes, by construction
+                        const uint32_t lg = (uint32_t)__builtin_ctz(g);
+                        const uint32_t sub = (uint32_t)tm.lane & (g - 1), v = c0 + ((uint32_t)tm.lane >> lg);
+                        if (v < c1) {
+                            double sy = 0.0;
+                            const uint32_t q0 = bptr[v], q1 = bptr[v + 1];
                             double va[4], vb[4];
-                            EZPZ_FOR_PAIRS4(P.bwd_items, q0, q1, sl, vi, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vi[k]]),
-                                            (acc -= va[k] * vb[k]))
+                            EZPZ_FOR_PAIRS_STRIDED(bitems, q0 + sub, q1, g, sl, vi,
+                                                   (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vi[k]]), (sy += va[k] * vb[k]))
+                            sy = group_sum(sy, g);
+                            if (sub == 0) ws[o_v + v] = (ws[o_v + v] - sy) / ws[o_d + v];
                         }
-                        ws[o_v + v] = acc / ws[o_d + v];
+                    } else {
+                        for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
+                            const uint32_t v = ci;  // internal variable numbering = schedule order
+                            double acc = ws[o_v + v];
+                            {
+                                const uint32_t q0 = bptr[v], q1 = bptr[v + 1];
+                                double va[4], vb[4];
+                                EZPZ_FOR_PAIRS4(bitems, q0, q1, sl, vi, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vi[k]]),
+                                                (acc -= va[k] * vb[k]))
+                            }
+                            ws[o_v + v] = acc / ws[o_d + v];
+                        }
                     }
                     tm.phase_sync();
+                };
+                for (uint32_t lv = nlev; lv-- > 0;) {
+                    if constexpr (LVL_STAGE) {
+                        if (lvl_buf) {
+                            const uint32_t w0 = lvl_tab[4 * (nlev + 1) + lv], w1 = lvl_tab[4 * (nlev + 1) + lv + 1];
+                            if (w1 - w0 <= a.lvl_buf_words) {
+                                const uint32_t c0 = lvl_tab[lv], c1 = lvl_tab[lv + 1];
+                                const uint4* src = reinterpret_cast<const uint4*>(P.lvl_bstream + w0);
+                                uint4* dst = reinterpret_cast<uint4*>(lvl_buf);
+                                for (uint32_t i = tm.lane; i < (w1 - w0) / 4; i += tm.stride) dst[i] = src[i];
+                                tm.phase_sync();
+                                const uint32_t* bptr = lvl_buf + 2;
+                                const uint32_t* bitems = bptr + ((c1 - c0 + 2) & ~1u);
+                                bwd_level(c0, c1, (lvl_tab[3 * (nlev + 1) + lv] >> 8) & 0xFFu, bptr - c0, bitems);
+                                continue;
+                            }
+                        }
+                    }
+                    bwd_level(lvl_cptr[lv], lvl_cptr[lv + 1], FUSE_LEVEL ? ((lvl_grp[lv] >> 8) & 0xFFu) : 1u, P.bwd_ptr,
+                              P.bwd_items);
                 }
                 }
                 EZPZ_STAMP(12);

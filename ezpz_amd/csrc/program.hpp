@@ -80,6 +80,9 @@ struct Program {
     std::vector<uint32_t> lpair_ptr, lpairs;           // per offdiag slot: (slot_ik, slot_jk)*
     std::vector<uint32_t> fwd_ptr, fwd_items;          // per var j: (slot(j,k), var k)*  -- row of L
     std::vector<uint32_t> bwd_ptr, bwd_items;          // per var j: (slot(i,j), var i)*  -- column of L
+    // per (partition, level): lanes that share one list of the level's Cholesky walks (a power of two; 1 = one lane
+    // per list).  Filled by the launch-shape code (api.hip: choose_level_groups); empty means 1 everywhere.
+    std::vector<uint32_t> lvl_grp;
 };
 
 struct BuildError {

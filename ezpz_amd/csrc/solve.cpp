@@ -30,6 +30,7 @@ struct CacheEntry {
     std::vector<unsigned char> key;
     size_t n_vars;
     int device;
+    bool one_solve;  // built for the latency of one solve (solve()) or for batch throughput (solve_batch())
     std::shared_ptr<EzpzSystem> sys;
 };
 std::mutex g_cache_mu;
@@ -39,8 +40,8 @@ constexpr size_t kCacheMax = 16;
 // The system comes back shared: solve() is callable from many threads at once (like the reference's), and an entry
 // another thread evicts must outlive the solves still running on it.  Systems live on the calling thread's current
 // HIP device.
-int cached_system(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, std::shared_ptr<EzpzSystem>* out, int32_t* ec,
-                  int64_t* ev) {
+int cached_system(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, bool one_solve,
+                  std::shared_ptr<EzpzSystem>* out, int32_t* ec, int64_t* ev) {
     const uint64_t h = topology_hash(cs, n_cs, n_vars);
     const size_t bytes = n_cs * sizeof(EzpzConstraint);
     const int device = ezpz_current_device();
@@ -48,7 +49,8 @@ int cached_system(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, std::sha
     {
         std::lock_guard<std::mutex> lock(g_cache_mu);
         for (auto it = g_cache.begin(); it != g_cache.end(); ++it) {
-            if (it->hash == h && it->n_vars == n_vars && it->device == device && it->key.size() == bytes &&
+            if (it->hash == h && it->n_vars == n_vars && it->device == device && it->one_solve == one_solve &&
+                it->key.size() == bytes &&
                 std::memcmp(it->key.data(), cs, bytes) == 0) {
                 g_cache.splice(g_cache.begin(), g_cache, it);
                 *out = g_cache.front().sys;
@@ -58,13 +60,14 @@ int cached_system(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, std::sha
     }
     // the symbolic phase runs outside the lock; two threads racing on a new topology both build it, one entry wins
     EzpzSystem* raw = nullptr;
-    int rc = ezpz_system_create(cs, n_cs, n_vars, device, 0, &raw, ec, ev);
+    int rc = ezpz_system_create(cs, n_cs, n_vars, device, one_solve ? EZPZ_TEAM_AUTO_LATENCY : 0, &raw, ec, ev);
     if (rc != EZPZ_OK) return rc;
     CacheEntry e;
     e.hash = h;
     e.key.assign(reinterpret_cast<const unsigned char*>(cs), reinterpret_cast<const unsigned char*>(cs) + bytes);
     e.n_vars = n_vars;
     e.device = device;
+    e.one_solve = one_solve;
     e.sys = std::shared_ptr<EzpzSystem>(raw, [](EzpzSystem* p) { ezpz_system_destroy(p); });
     *out = e.sys;
     std::lock_guard<std::mutex> lock(g_cache_mu);
@@ -182,7 +185,7 @@ int solve_inner_impl(const EzpzConstraint* cs, const uint64_t* orig_ids, size_t 
     std::shared_ptr<EzpzSystem> sys_ref;
     int32_t ec = -1;
     int64_t ev = -1;
-    int rc = cached_system(cs, n_cs, n_guesses, &sys_ref, &ec, &ev);
+    int rc = cached_system(cs, n_cs, n_guesses, true, &sys_ref, &ec, &ev);
     EzpzSystem* sys = sys_ref.get();
     if (rc != EZPZ_OK) {
         if (rc == EZPZ_ERR_MISSING_GUESS && !dense) rc = EZPZ_ERR_MATRIX;  // id has a guess but no column
@@ -473,7 +476,7 @@ int ezpz_solve_batch(const EzpzConstraint* reqs_in, size_t n_reqs, size_t n_vars
             std::shared_ptr<EzpzSystem> sys_ref;
             int32_t ec = -1;
             int64_t ev = -1;
-            int rc = cached_system(subset.data(), subset.size(), n_vars, &sys_ref, &ec, &ev);
+            int rc = cached_system(subset.data(), subset.size(), n_vars, batch == 1, &sys_ref, &ec, &ev);
             EzpzSystem* sys = sys_ref.get();
             if (rc != EZPZ_OK) {
                 if (first_tier) {  // lib.rs:239-244: no earlier tier to fall back to

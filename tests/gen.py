@@ -65,3 +65,38 @@ def keyed_uniform(seed, n_systems, n_vars, lo, hi, integer=False):
     if integer:
         return np.floor(lo + u * (hi - lo))
     return lo + u * (hi - lo)
+
+
+def connected_sketch(npts, seed):
+    """One connected, fully determined component of mixed kinds: a random polyline-like sketch in which every point
+    is tied to its predecessors by two scalar conditions consistent with a hidden true layout.  Returns the constraint
+    records and guesses near the true layout."""
+    rng = np.random.default_rng(seed)
+    pt = lambda i: (2 * i, 2 * i + 1)
+    cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
+    true = [np.zeros(2)]
+    for i in range(1, npts):
+        # a point is placed by two scalar conditions relative to earlier points, consistent with a hidden true layout
+        p = true[-1] + rng.uniform(0.5, 2.0, 2) * rng.choice([-1.0, 1.0], 2)
+        true.append(p)
+        a = i - 1
+        b = max(0, i - int(rng.integers(2, 4)))
+        choice = int(rng.integers(0, 5))
+        if choice == 0:
+            cons += [O.horizontal_distance(pt(i), pt(a), float(p[0] - true[a][0])),
+                     O.vertical_distance(pt(i), pt(a), float(p[1] - true[a][1]))]
+        elif choice == 1:
+            cons += [O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a])))),
+                     O.distance(pt(i), pt(b), float(np.hypot(*(p - true[b])))) if b != a else
+                     O.horizontal_distance(pt(i), pt(a), float(p[0] - true[a][0]))]
+        elif choice == 2:
+            cons += [O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a])))),
+                     O.vertical_distance(pt(i), pt(a), float(p[1] - true[a][1]))]
+        elif choice == 3:
+            cons += [O.fixed(2 * i, float(p[0])), O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a]))))]
+        else:
+            cons += [O.horizontal_distance(pt(i), pt(b), float(p[0] - true[b][0])),
+                     O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a]))))]
+    recs = O.stack(cons)
+    g = np.concatenate(true) + rng.uniform(-0.05, 0.05, 2 * npts)
+    return recs, g

@@ -218,13 +218,16 @@ def _chain_system(n_pts):
     return O.stack(cons), np.asarray(guesses)
 
 
-@pytest.mark.parametrize("team", [0, 256, 512])
+@pytest.mark.parametrize("team", [0, "latency", 256, 512])
 def test_single_large_component_uses_barrier_workgroup(E, team):
-    """A system that cannot be partitioned (one connected component) runs with all lanes on one partition."""
+    """A system that cannot be partitioned (one connected component) runs with all lanes on one partition: a barrier
+    workgroup when asked for (or when one solve's latency is what counts, as in solve()), else -- for batches -- one
+    wavefront per system when its state fits."""
     recs, g = _chain_system(120)
-    sysobj = E.System(recs, len(g), team_size=team)
+    sysobj = E.System(recs, len(g), team_size=E.TEAM_AUTO_LATENCY if team == "latency" else team)
     info = sysobj.info()
-    assert info["n_components"] == 1 and info["team_mode"] == 2 and info["n_partitions"] == 1
+    assert info["n_components"] == 1 and info["n_partitions"] == 1
+    assert (info["team_mode"], info["team_size"]) == ((0, 64) if team == 0 else (2, info["team_size"]))
     x0 = g[None, :] + gen.keyed_uniform(5, 6, len(g), -0.05, 0.05)
     x, st, _ = sysobj.solve_batch(x0)
     rc, xo, it, conv, nun = O.solve_batch(recs, x0)
@@ -621,42 +624,16 @@ def test_random_block_systems_are_deterministic_and_match_the_oracle(E, team, nc
             assert bool(st["converged"][0]) and float(st["final_residual_inf"][0]) <= 1e-8
 
 
-@pytest.mark.parametrize("npts,team", [(150, 0), (150, 256), (1500, 0)])
-def test_random_connected_sketch_in_barrier_workgroup(E, npts, team):
+@pytest.mark.parametrize("npts,team,mode", [(150, 0, 0), (150, 256, 2), (400, 0, 2), (1500, 0, 2)])
+def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, team, mode):
     """One connected component of mixed kinds (a random polyline-like sketch: every point tied to its predecessors by
-    one or two random constraints) on the barrier workgroup (LDS and global-memory workspace): deterministic from
-    run to run, and -- it is fully determined by construction -- the oracle's answer."""
-    rng = np.random.default_rng(77 + npts + team)
-    pt = lambda i: (2 * i, 2 * i + 1)
-    cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
-    true = [np.zeros(2)]
-    for i in range(1, npts):
-        # a point is placed by two scalar conditions relative to earlier points, consistent with a hidden true layout
-        p = true[-1] + rng.uniform(0.5, 2.0, 2) * rng.choice([-1.0, 1.0], 2)
-        true.append(p)
-        a = i - 1
-        b = max(0, i - int(rng.integers(2, 4)))
-        choice = int(rng.integers(0, 5))
-        if choice == 0:
-            cons += [O.horizontal_distance(pt(i), pt(a), float(p[0] - true[a][0])),
-                     O.vertical_distance(pt(i), pt(a), float(p[1] - true[a][1]))]
-        elif choice == 1:
-            cons += [O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a])))),
-                     O.distance(pt(i), pt(b), float(np.hypot(*(p - true[b])))) if b != a else
-                     O.horizontal_distance(pt(i), pt(a), float(p[0] - true[a][0]))]
-        elif choice == 2:
-            cons += [O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a])))),
-                     O.vertical_distance(pt(i), pt(a), float(p[1] - true[a][1]))]
-        elif choice == 3:
-            cons += [O.fixed(2 * i, float(p[0])), O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a]))))]
-        else:
-            cons += [O.horizontal_distance(pt(i), pt(b), float(p[0] - true[b][0])),
-                     O.distance(pt(i), pt(a), float(np.hypot(*(p - true[a]))))]
-    recs = O.stack(cons)
-    g = np.concatenate(true) + rng.uniform(-0.05, 0.05, 2 * npts)
+    one or two random constraints) on one wavefront (300 variables), on the barrier workgroup with its workspace in
+    LDS (300, 800) and in global memory (3000): deterministic from run to run, and -- it is fully determined by
+    construction -- the oracle's answer."""
+    recs, g = gen.connected_sketch(npts, 77 + npts + team)
     sysobj = E.System(recs, len(g), team_size=team)
     info = sysobj.info()
-    assert info["n_components"] == 1 and info["team_mode"] == 2 and info["n_partitions"] == 1
+    assert info["n_components"] == 1 and info["team_mode"] == mode and info["n_partitions"] == 1
     x0 = np.tile(g, (5, 1))
     cfg = dict(max_iterations=60)
     x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)

@@ -9,14 +9,19 @@ from conftest import read_case
 name = sys.argv[1] if len(sys.argv) > 1 else "square"
 team = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # systems per launch (stamps come from block 0 / lane 0 only)
-ref = T.load(read_case(name))
-recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
+if name.startswith("sketch:"):  # tests/gen.py:connected_sketch
+    import gen, types
+    recs, g = gen.connected_sketch(int(name[7:]), 1000 + int(name[7:]))
+    ref = types.SimpleNamespace(guesses=g, num_vars=len(g))
+else:
+    ref = T.load(read_case(name))
+    recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
 s = E.System(recs, ref.num_vars, team_size=team)
 print(s.info())
 dev = torch.device('cuda', 0)
 x0 = torch.from_numpy(np.repeat(ref.guesses[None, :], B, axis=0).copy()).to(dev)
 xo = torch.empty_like(x0); st = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
-buf = torch.zeros(2048, dtype=torch.int64, device=dev)
+buf = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
 L = E.lib(); L.ezpz_debug_set_stamps.argtypes = [C.c_void_p]; L.ezpz_debug_set_stamps(buf.data_ptr())
 stream = torch.cuda.current_stream(dev).cuda_stream
 for _ in range(3):
