@@ -36,7 +36,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // Minimum-degree ordering of one connected component of the JtJ graph (exact degrees, explicit
 // elimination graph).  Components in constraint sketches are small; beyond `kMinDegLimit` vertices we
 // keep the natural order instead.
-constexpr size_t kMinDegLimit = 4096;
+constexpr size_t kMinDegLimit = 16384;
 
 // Stable counting sort: perm[i] = the element that comes i-th when ordered by key (< n_keys), ties in `input` order.
 // `input` is the current order (a permutation or identity given as nullptr).
@@ -72,14 +72,27 @@ void order_component(const std::vector<uint32_t>& verts, const IVecs& adj, std::
     }
     std::pmr::vector<char> gone(k, 0, pool);
     IVec merged(pool), nb(pool);
+    // smallest (degree, index) first; entries whose degree is out of date are skipped when they surface
+    typedef std::pair<uint32_t, uint32_t> DegIdx;
+    std::priority_queue<DegIdx, std::vector<DegIdx>, std::greater<DegIdx>> heap;
+    const bool scan = k <= 64;  // the typical sketch component: a linear scan beats the heap
+    if (!scan)
+        for (size_t i = 0; i < k; ++i) heap.push(DegIdx((uint32_t)g[i].size(), (uint32_t)i));
     for (size_t step = 0; step < k; ++step) {
         size_t best = k;
-        size_t best_deg = (size_t)-1;
-        for (size_t i = 0; i < k; ++i) {
-            if (!gone[i] && g[i].size() < best_deg) {
-                best_deg = g[i].size();
-                best = i;
+        if (scan) {
+            size_t best_deg = (size_t)-1;
+            for (size_t i = 0; i < k; ++i) {
+                if (!gone[i] && g[i].size() < best_deg) {
+                    best_deg = g[i].size();
+                    best = i;
+                }
             }
+        }
+        while (best == k) {
+            const DegIdx top = heap.top();
+            heap.pop();
+            if (!gone[top.second] && g[top.second].size() == top.first) best = top.second;
         }
         gone[best] = 1;
         out_order.push_back(verts[best]);
@@ -92,6 +105,7 @@ void order_component(const std::vector<uint32_t>& verts, const IVecs& adj, std::
             gu.clear();
             for (uint32_t w : merged)
                 if (w != u && w != best) gu.push_back(w);
+            if (!scan) heap.push(DegIdx((uint32_t)gu.size(), u));
         }
         g[best].clear();
     }

@@ -647,6 +647,66 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
     assert_x_close(x[0], want.final_values)
 
 
+def _hub_sketch(npts, seed, hub_last):
+    """`npts` points each tied to one hub point (a distance and a horizontal distance): one connected component.  The
+    hub's two variables come last or -- the way a sketch dimensioned from its origin is written -- first; the layout
+    and the guesses are the same either way."""
+    rng = np.random.default_rng(seed)
+    place = (lambda k: npts if k == 0 else k - 1) if hub_last else (lambda k: k)  # logical point (hub = 0) -> slot
+    pt = lambda k: (2 * place(k), 2 * place(k) + 1)
+    true = np.zeros((npts + 1, 2))
+    true[0] = (1.0, -2.0)
+    true[1:] = true[0] + rng.uniform(1.0, 9.0, (npts, 2)) * rng.choice([-1.0, 1.0], (npts, 2))
+    guess = true + rng.uniform(-0.05, 0.05, true.shape)
+    cons = [O.fixed(pt(0)[0], 1.0), O.fixed(pt(0)[1], -2.0)]
+    for k in range(1, npts + 1):
+        cons += [O.distance(pt(k), pt(0), float(np.hypot(*(true[k] - true[0])))),
+                 O.horizontal_distance(pt(k), pt(0), float(true[k][0] - true[0][0]))]
+    g = np.zeros(2 * (npts + 1))
+    for k in range(npts + 1):
+        g[2 * place(k):2 * place(k) + 2] = guess[k]
+    return O.stack(cons), g
+
+
+@pytest.mark.parametrize("team", [0, 256])
+def test_hub_sketch_with_one_level_wider_than_the_team_and_its_staging_buffer(E, team):
+    """3000 points each tied to one hub point: one connected component whose first elimination level holds all 6000
+    leaf columns -- wider than any team (so that level runs as the two-phase walk) and larger than the LDS buffer a
+    level's lists are staged in (so it is walked from global memory) -- followed by the hub's narrow, long-list levels
+    (staged, one phase, lists shared by groups of lanes).  The answer is the oracle's."""
+    recs, g = _hub_sketch(3000, 5150 + team, hub_last=True)
+    sysobj = E.System(recs, len(g), team_size=team)
+    info = sysobj.info()
+    assert info["n_components"] == 1 and info["team_mode"] == 2 and info["n_partitions"] == 1
+    assert info["n_levels"] <= 4 and not info["program_in_lds"]
+    x0 = np.stack([g, g + 0.01])
+    x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+    x2, st2, _ = sysobj.solve_batch(x0)
+    assert np.array_equal(x2, x) and np.array_equal(st2["iterations"], st["iterations"])
+    for b in range(2):
+        want = O.solve(recs, x0[b], linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert want.error == 0 and want.converged and not want.unsatisfied
+        assert (int(st["iterations"][b]), bool(st["converged"][b])) == (want.iterations, True)
+        assert not mask[b].any()
+        assert_x_close(x[b], want.final_values)
+
+
+def test_hub_declared_first_is_eliminated_last(E):
+    """The same sketch with the hub's variables numbered first, as a sketch dimensioned from its origin is written: in
+    request order the hub is eliminated first and L fills in completely (18 M entries, 3.6e10 multiply-adds: `system
+    too large`).  The graph is too compact for nested dissection (everything is two steps from the hub), so this is
+    minimum degree's case -- on 6002 vertices.  Same factor size and the same answer as with the hub numbered last."""
+    recs_f, g_f = _hub_sketch(3000, 5150, hub_last=False)
+    recs_l, g_l = _hub_sketch(3000, 5150, hub_last=True)
+    first, last = E.System(recs_f, len(g_f)), E.System(recs_l, len(g_l))
+    assert first.info()["nnz_l"] == last.info()["nnz_l"] == first.info()["nnz_a"]  # no fill at all
+    xf, stf, _ = first.solve_batch(g_f[None, :])
+    xl, stl, _ = last.solve_batch(g_l[None, :])
+    assert bool(stf["converged"][0]) and int(stf["iterations"][0]) == int(stl["iterations"][0])
+    assert_x_close(xf[0, 2:], xl[0, :-2])   # leaves
+    assert_x_close(xf[0, :2], xl[0, -2:])   # hub
+
+
 def test_batch_solve_with_priorities_and_inferred_sides(E):
     """lib.rs:148-263 per system of a batch: sides inferred from each system's own guesses, cumulative priority tiers
     from the original guesses, last fully satisfied tier wins (tests.rs:49-106 semantics, batched)."""
