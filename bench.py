@@ -227,17 +227,20 @@ def main():
         if world > 1 and backend == "nccl":
             from ezpz_amd.distributed import solve_batch_sharded
 
-            full = torch.cat([x0] * world, dim=0) if rank == 0 else None
-            solve_batch_sharded(system, full, n, device=dev)
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            te = time.perf_counter()
-            reps = max(1, min(args.steps, 10))
-            for _ in range(reps):
+            try:  # an extra: a failure here must not cost the run its headline line
+                full = torch.cat([x0] * world, dim=0) if rank == 0 else None
                 solve_batch_sharded(system, full, n, device=dev)
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            extras["with_rccl_scatter_gather_solves_per_s"] = world * B * reps / (time.perf_counter() - te)
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                te = time.perf_counter()
+                reps = max(1, min(args.steps, 10))
+                for _ in range(reps):
+                    solve_batch_sharded(system, full, n, device=dev)
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                extras["with_rccl_scatter_gather_solves_per_s"] = world * B * reps / (time.perf_counter() - te)
+            except Exception as exc:  # noqa: BLE001
+                extras["with_rccl_scatter_gather_error"] = repr(exc)[:200]
 
     st = np.concatenate([p["status"].cpu().numpy().view(E.STATUS_DTYPE).reshape(-1) for p in parts])
     iters = np.unique(st["iterations"]).tolist()
