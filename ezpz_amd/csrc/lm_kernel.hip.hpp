@@ -913,12 +913,18 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                         const uint32_t v = ci;  // internal variable numbering = schedule order
                         double acc = ws[o_d + v];
                         {
+                            // row v of L is complete (its entries belong to columns of earlier levels), so the forward
+                            // substitution's sum for y_v rides on the same walk: one pass over the list instead of two
                             const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
-                            double l[4];
-                            EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (l[k] = ws[o_l + sl[k]]), (acc -= l[k] * l[k]))
+                            double y = ws[o_v + v];
+                            double va[4], vb[4];
+                            EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
+                                            (acc -= va[k] * va[k], y -= va[k] * vb[k]))
+                            if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                            const double dv = sqrt(acc);
+                            ws[o_d + v] = dv;
+                            ws[o_v + v] = y / dv;
                         }
-                        if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
-                        ws[o_d + v] = sqrt(acc);
                     }
                     for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride) {
                         double acc = ws[o_l + s];
@@ -933,17 +939,6 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     tm.phase_sync();
                     for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride)
                         ws[o_l + s] = ws[o_l + s] / ws[o_d + lcol[s]];
-                    for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
-                        const uint32_t v = ci;  // internal variable numbering = schedule order
-                        double acc = ws[o_v + v];
-                        {
-                            const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
-                            double va[4], vb[4];
-                            EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
-                                            (acc -= va[k] * vb[k]))
-                        }
-                        ws[o_v + v] = acc / ws[o_d + v];
-                    }
                     tm.phase_sync();
                 };
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
