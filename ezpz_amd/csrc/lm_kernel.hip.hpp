@@ -794,6 +794,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 tm.phase_sync();
                 EZPZ_STAMP(10);
                 double bad = 0.0;
+                double dmax = __builtin_nan("");  // fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax)
                 if constexpr (DENSE) {
                     // ---- <= 8 variables, four lanes: the whole linear solve in registers (dense8_solve) --------------------
                     bad = dense8_solve(ws, o_d, o_l, o_v, lvl_sptr, n, tm.lane);
@@ -983,7 +984,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                             EZPZ_FOR_PAIRS_STRIDED(bitems, q0 + sub, q1, g, sl, vi,
                                                    (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vi[k]]), (sy += va[k] * vb[k]))
                             sy = group_sum(sy, g);
-                            if (sub == 0) ws[o_v + v] = (ws[o_v + v] - sy) / ws[o_d + v];
+                            if (sub == 0) {
+                                const double dval = (ws[o_v + v] - sy) / ws[o_d + v];
+                                ws[o_v + v] = dval;
+                                dmax = fmax(dmax, fabs(dval));
+                            }
                         }
                     } else {
                         for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
@@ -995,7 +1000,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                                 EZPZ_FOR_PAIRS4(bitems, q0, q1, sl, vi, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vi[k]]),
                                                 (acc -= va[k] * vb[k]))
                             }
-                            ws[o_v + v] = acc / ws[o_d + v];
+                            const double dval = acc / ws[o_d + v];
+                            ws[o_v + v] = dval;
+                            dmax = fmax(dmax, fabs(dval));
                         }
                     }
                     tm.phase_sync();
@@ -1023,9 +1030,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 }
                 EZPZ_STAMP(12);
                 // ---- ||d||_inf and "did any pivot fail": one rendezvous (newton.rs:96-99, :108) ------------------------------
-                double dmax = __builtin_nan("");  // fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax)
-                for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride)
-                    dmax = fmax(dmax, fabs(ws[o_v + ci]));
+                // (the list-walk builds took max |d_v| while the backward substitution produced d_v)
+                if constexpr (DENSE) {
+                    for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride)
+                        dmax = fmax(dmax, fabs(ws[o_v + ci]));
+                }
                 tm.reduce2(bad, dmax, OpMax(), OpMax());
                 EZPZ_STAMP(13);
                 if (bad > 0.0) {  // numeric failure => lambda *= 10, burn the iteration
