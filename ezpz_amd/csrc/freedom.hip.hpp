@@ -67,6 +67,7 @@ struct Ws {
 };
 
 struct LaneCtx {
+    static constexpr bool kRowMajor = false;  // a private matrix: the layout does not matter
     __device__ __forceinline__ uint32_t id() const { return 0; }
     __device__ __forceinline__ uint32_t count() const { return 1; }
     __device__ __forceinline__ void sync() const {}
@@ -75,6 +76,9 @@ struct LaneCtx {
 };
 
 struct BlockCtx {
+    // lanes work across columns: with rows contiguous a wavefront's accesses to A(i, j..j+63) coalesce (the global
+    // workspace of a large component was read 8 bytes per cache line the other way round)
+    static constexpr bool kRowMajor = true;
     double* red;  // LDS scratch, 16 doubles
     __device__ __forceinline__ uint32_t id() const { return threadIdx.x; }
     __device__ __forceinline__ uint32_t count() const { return blockDim.x; }
@@ -137,26 +141,39 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
     const uint32_t m = cd.m, n = cd.n, mn = m * n;
     const uint32_t oNS = mn, oQ = mn + n * n, oPerm = mn + 2 * n * n, oTau = oPerm + n;
     const uint32_t id = ctx.id(), cnt = ctx.count();
-#define A_(i, j) W((j) * m + (i))
+#define A_(i, j) W(C::kRowMajor ? (i) * n + (j) : (j) * m + (i))
 #define NS_(i, j) W(oNS + (j) * n + (i))
 #define Q_(i, j) W(oQ + (j) * n + (i))
 #define PERM_(j) ((uint32_t)W(oPerm + (j)))
+#define NORM_(j) W(oTau + (j))  // running squared column norms during the QR (tau is only needed afterwards)
     for (uint32_t e = id; e < mn; e += cnt) W(e) = 0.0;
     for (uint32_t j = id; j < n; j += cnt) W(oPerm + j) = (double)j;
     ctx.sync();
-    for (uint32_t it = cd.item0 + id; it < cd.item1; it += cnt) W(items[2 * it + 1]) = jv[items[2 * it]];
+    for (uint32_t it = cd.item0 + id; it < cd.item1; it += cnt) {
+        const uint32_t e = items[2 * it + 1];  // lcol * m + lrow
+        const uint32_t lcol = e / m;
+        A_(e - lcol * m, lcol) = jv[items[2 * it]];
+    }
     ctx.sync();
     // ---- column-pivoted Householder QR (find_dof.rs:35 ColPivQr) ------------------------------------------------------
+    // The squared norm of every remaining column below the current row is what the pivot search needs; it is summed
+    // (rows ascending, exactly as a fresh pass would) while the reflector is applied to the column, so a step reads
+    // the trailing matrix twice instead of three times.
     const uint32_t ndiag = m < n ? m : n;
+    for (uint32_t j = id; j < n; j += cnt) {
+        double s = 0.0;
+        for (uint32_t i = 0; i < m; ++i) {
+            const double a = A_(i, j);
+            s += a * a;
+        }
+        NORM_(j) = s;
+    }
+    ctx.sync();
     for (uint32_t k = 0; k < ndiag; ++k) {
         double bv = -1.0;
         uint32_t bj = k;
         for (uint32_t j = k + id; j < n; j += cnt) {
-            double s = 0.0;
-            for (uint32_t i = k; i < m; ++i) {
-                const double a = A_(i, j);
-                s += a * a;
-            }
+            const double s = NORM_(j);
             if (s > bv) {
                 bv = s;
                 bj = j;
@@ -174,6 +191,7 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
                 const double t = W(oPerm + k);
                 W(oPerm + k) = W(oPerm + bj);
                 W(oPerm + bj) = t;
+                NORM_(bj) = NORM_(k);  // column k's own norm is not needed again
             }
         }
         ctx.sync();
@@ -191,7 +209,13 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
             for (uint32_t i = k + 1; i < m; ++i) dot += A_(i, k) * A_(i, j);
             dot *= tau;
             A_(k, j) -= dot;
-            for (uint32_t i = k + 1; i < m; ++i) A_(i, j) -= dot * A_(i, k);
+            double s = 0.0;
+            for (uint32_t i = k + 1; i < m; ++i) {
+                const double a = A_(i, j) - dot * A_(i, k);
+                A_(i, j) = a;
+                s += a * a;
+            }
+            NORM_(j) = s;
         }
         ctx.sync();
     }
@@ -209,16 +233,20 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
         W(oQ + e) = 0.0;
     }
     ctx.sync();
-    for (uint32_t fc = id; fc < nullity; fc += cnt) {
+    // R11 x = -R12 e_fc, one null vector at a time, the lanes sharing each row's dot product (one lane per vector walked
+    // rank^2 / 2 dependent global loads: a second per vector at 2000 variables)
+    for (uint32_t fc = 0; fc < nullity; ++fc) {
         const uint32_t fv = rank + fc;
-        NS_(PERM_(fv), fc) = 1.0;
+        if (id == 0) NS_(PERM_(fv), fc) = 1.0;
+        ctx.sync();
         for (uint32_t i = rank; i-- > 0;) {
-            double rhs = A_(i, fv);
-            for (uint32_t j = i + 1; j < rank; ++j) rhs += A_(i, j) * NS_(PERM_(j), fc);
-            NS_(PERM_(i), fc) = -rhs / A_(i, i);
+            double dot = 0.0;
+            for (uint32_t j = i + 1 + id; j < rank; j += cnt) dot += A_(i, j) * NS_(PERM_(j), fc);
+            dot = ctx.sum(dot);
+            if (id == 0) NS_(PERM_(i), fc) = -(A_(i, fv) + dot) / A_(i, i);
+            ctx.sync();
         }
     }
-    ctx.sync();
     // ---- thin Q of the basis (find_dof.rs:79) ------------------------------------------------------------------------
     for (uint32_t k = 0; k < nullity; ++k) {
         double s = 0.0;
@@ -276,6 +304,7 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
     atomic_max_nonneg(partmax, local_max);
     ctx.sync();
 #undef A_
+#undef NORM_
 #undef NS_
 #undef Q_
 #undef PERM_
