@@ -1107,12 +1107,35 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                         a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
                 }
             };
+            // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121; solver.rs:359-440) ------------------
+            auto jacobian_of = [&](const CRef& cref, uint32_t ci) {
+                const DevCon& c = cref.get();
+                JacWriter<WsRef<WS_STRIDE>> w;
+                w.jv = ws + o_j;
+                w.jbase = c.jbase;
+                const uint4 loc = cref.jloc(P);
+                w.loc[0] = loc.x;
+                w.loc[1] = loc.y;
+                w.loc[2] = loc.z;
+                w.loc[3] = loc.w;
+                w.weight = c.weight;
+                const bool deg = con_jacobian<LIN>(c, ws + o_x, w);
+                if (deg) {
+                    int idx = atomicAdd(nwarn, 1);
+                    if (a.warn_log && (uint32_t)idx < a.warn_cap)
+                        a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
+                }
+            };
             for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
                 EZPZ_STAMP_DRAIN(40);
                 const CRef cref(P, ci, unit_w);
                 EZPZ_STAMP_DRAIN(41);
                 residual_of(cref, ci);
                 EZPZ_STAMP_DRAIN(42);
+                // linear-only build: its one Jacobian sweep per solve (see below) shares eval()'s pass over the records
+                if constexpr (LIN) {
+                    if (mode == EVAL0) jacobian_of(cref, ci);
+                }
             }
             ++pass;
             tm.phase_sync();
@@ -1128,29 +1151,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     o_rn = t;
                     lambda *= LM_LAMBDA_DECR;
                 }
-                // ---- the one Jacobian sweep (eval() and accepted steps, newton.rs:121; solver.rs:359-440) ------------------
-                auto jacobian_of = [&](const CRef& cref, uint32_t ci) {
-                    const DevCon& c = cref.get();
-                    JacWriter<WsRef<WS_STRIDE>> w;
-                    w.jv = ws + o_j;
-                    w.jbase = c.jbase;
-                    const uint4 loc = cref.jloc(P);
-                    w.loc[0] = loc.x;
-                    w.loc[1] = loc.y;
-                    w.loc[2] = loc.z;
-                    w.loc[3] = loc.w;
-                    w.weight = c.weight;
-                    const bool deg = con_jacobian<LIN>(c, ws + o_x, w);
-                    if (deg) {
-                        int idx = atomicAdd(nwarn, 1);
-                        if (a.warn_log && (uint32_t)idx < a.warn_cap)
-                            a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
-                    }
-                };
                 // The nine linear kinds have constant partials (weight x +-1 or +-0.5) and no degenerate guard: after
                 // eval() the refresh of an accepted step (newton.rs:121) would store the same bits again, so the
-                // linear-only build sweeps the Jacobian once per solve.
-                if (!LIN || mode == EVAL0) {
+                // linear-only build sweeps the Jacobian once per solve -- inside eval()'s residual sweep above.
+                if constexpr (!LIN) {
                     for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
                         const CRef cref(P, ci, unit_w);
                         jacobian_of(cref, ci);
