@@ -968,6 +968,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     chol_level(lvl_cptr[lv], lvl_cptr[lv + 1], lvl_sptr[lv], lvl_sptr[lv + 1], FUSE_LEVEL ? (lvl_grp[lv] & 0xFFu) : 1u,
                                P.fwd_ptr, P.fwd_items, P.lpair_ptr, P.lpairs, P.l_col);
                 }
+                // a one-phase level stores its d_v after its rendezvous: order the last level's before the backward
+                // substitution, whose lane for v may sit in another wavefront (different group sizes)
+                if constexpr (FUSE_LEVEL) tm.phase_sync();
                 EZPZ_STAMP(11);
                 // ---- backward substitution (garbage but harmless if the factorisation failed) ---------------------------
                 // Same two devices as the factorisation: the level's lists come from LDS when they were staged, and g
