@@ -691,6 +691,23 @@ def test_hub_sketch_with_one_level_wider_than_the_team_and_its_staging_buffer(E,
         assert_x_close(x[b], want.final_values)
 
 
+@pytest.mark.parametrize("npts,hub_last", [(40, True), (100, False), (300, True)])
+def test_small_hub_sketch_on_one_wavefront(E, npts, hub_last):
+    """The hub sketch small enough for one wavefront per system (batches): its first level is wider than the 64 lanes
+    (two-phase walk) and, from 100 points, larger than the wavefront's staging buffer (walked from global memory); the
+    hub's levels are one phase with lists shared by up to 64 lanes."""
+    recs, g = _hub_sketch(npts, 77 + npts, hub_last)
+    sysobj = E.System(recs, len(g))
+    info = sysobj.info()
+    assert info["n_components"] == 1 and (info["team_mode"], info["team_size"]) == (0, 64)
+    x0 = g[None, :] + gen.keyed_uniform(41, 64, len(g), -0.05, 0.05)
+    x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv)
+    assert np.array_equal(st["n_unsatisfied"], nun) and not mask.any()
+    assert_x_close(x, xo)
+
+
 def test_hub_declared_first_is_eliminated_last(E):
     """The same sketch with the hub's variables numbered first, as a sketch dimensioned from its origin is written: in
     request order the hub is eliminated first and L fills in completely (18 M entries, 3.6e10 multiply-adds: `system
