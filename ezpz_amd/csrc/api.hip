@@ -132,7 +132,9 @@ struct EzpzSystem {
         DevBuf<FreedomComp> comps;
         DevBuf<uint32_t> lists;  // items | comp_vars | col_ptr | col_slots
         uint32_t o_vars = 0, o_col_ptr = 0, o_col_slots = 0;
-        DevBuf<double> x_int, jv, part, gws;
+        DevBuf<double> x_int, jv, part, gws, step_tau;
+        DevBuf<uint32_t> step_done;
+        FreedomComp comp0{};  // host copy of the first component (the wide QR path runs on one-component systems)
         DevBuf<uint8_t> mask;
         DevBuf<uint32_t> count;
     } freedom;
@@ -1218,6 +1220,7 @@ int build_freedom(EzpzSystem* sys) {
         HIP_TRY(hipMemcpy(F.comps.p, comps.data(), comps.size() * sizeof(FreedomComp), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(F.lists.p, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     F.ncomp = (uint32_t)comps.size();
+    if (!comps.empty()) F.comp0 = comps[0];
     F.ws = std::max<uint32_t>(ws, 1);
     F.max_n = max_n;
     // LANE: a lane per (system, component) with 128 private workspaces in <= 64 KiB of LDS
@@ -1291,6 +1294,51 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
             grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(batch, 1024), (4ull << 30) / per));
             if ((rc = F.gws.ensure((size_t)grid * F.ws)) != EZPZ_OK) return rc;
             a.gws = F.gws.p;
+            if (F.ncomp == 1 && F.comp0.n >= 96) {
+                // One big component: its pivoted QR as a chain of step launches over the whole device (freedom.hip.hpp),
+                // `grid` systems side by side, then the ordinary kernel for rank / null space / participation.
+                if ((rc = F.step_done.ensure(grid)) != EZPZ_OK) return rc;
+                if ((rc = F.step_tau.ensure(grid)) != EZPZ_OK) return rc;
+                HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                const uint32_t m = F.comp0.m, nc = F.comp0.n, ndiag = std::min(m, nc);
+                for (size_t base = 0; base < batch; base += grid) {
+                    const uint32_t nb = (uint32_t)std::min<size_t>(grid, batch - base);
+                    FreedomStepArgs sa{};
+                    sa.gws = F.gws.p;
+                    sa.jv = F.jv.p + base * zj;
+                    sa.items = a.items;
+                    sa.done = F.step_done.p;
+                    sa.tau = F.step_tau.p;
+                    sa.ws = F.ws;
+                    sa.zj = (uint32_t)zj;
+                    sa.m = m;
+                    sa.n = nc;
+                    sa.item0 = F.comp0.item0;
+                    sa.item1 = F.comp0.item1;
+                    const uint32_t bl_mn = (uint32_t)std::min<uint64_t>(((uint64_t)m * nc + 255) / 256, 4096);
+                    const uint32_t bl_it = std::max<uint32_t>(1, std::min<uint32_t>((sa.item1 - sa.item0 + 255) / 256, 1024));
+                    hipLaunchKernelGGL(fr_init_kernel, dim3(bl_mn, nb), dim3(256), 0, stream, sa);
+                    hipLaunchKernelGGL(fr_scatter_kernel, dim3(bl_it, nb), dim3(256), 0, stream, sa);
+                    hipLaunchKernelGGL(fr_norms_kernel, dim3((nc + 255) / 256, nb), dim3(256), 0, stream, sa);
+                    for (uint32_t k = 0; k < ndiag; ++k) {
+                        sa.k = k;
+                        hipLaunchKernelGGL(fr_pivot_kernel, dim3(nb), dim3(256), 0, stream, sa);
+                        if (nc - k - 1 > 0)
+                            hipLaunchKernelGGL(fr_apply_kernel, dim3((nc - k - 1 + 63) / 64, nb), dim3(1024), 0, stream, sa);
+                    }
+                    FreedomArgs fa = a;
+                    fa.jv = a.jv + base * zj;
+                    fa.part = a.part + base * n;
+                    fa.mask = a.mask + base * n;
+                    fa.n_under = a.n_under ? a.n_under + base : nullptr;
+                    fa.batch = nb;
+                    fa.qr_done = 1;
+                    hipLaunchKernelGGL(freedom_kernel<false>, dim3(nb), dim3(F.threads), lds, stream, fa);
+                }
+                HIP_TRY(hipGetLastError());
+                return EZPZ_OK;
+            }
         }
         HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));

@@ -43,6 +43,7 @@ struct FreedomArgs {
     uint32_t n, zj, ncomp;
     uint32_t ws;     // workspace doubles of the largest component
     uint32_t group;  // LANE: systems per workgroup
+    uint32_t qr_done;  // TEAM, global workspace: the pivoted QR is already in the workspace (step kernels below)
 };
 
 constexpr double kFreedomRankTol = 1e-8;  // find_dof.rs:12
@@ -137,7 +138,7 @@ __host__ __device__ inline uint32_t component_ws(uint32_t m, uint32_t n) { retur
 template <class C>
 __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd, const uint32_t* __restrict__ items,
                                   const double* __restrict__ jv, const double tol, const uint32_t* __restrict__ vars,
-                                  double* __restrict__ part, unsigned long long* partmax) {
+                                  double* __restrict__ part, unsigned long long* partmax, const bool qr_done = false) {
     const uint32_t m = cd.m, n = cd.n, mn = m * n;
     const uint32_t oNS = mn, oQ = mn + n * n, oPerm = mn + 2 * n * n, oTau = oPerm + n;
     const uint32_t id = ctx.id(), cnt = ctx.count();
@@ -146,6 +147,8 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
 #define Q_(i, j) W(oQ + (j) * n + (i))
 #define PERM_(j) ((uint32_t)W(oPerm + (j)))
 #define NORM_(j) W(oTau + (j))  // running squared column norms during the QR (tau is only needed afterwards)
+    const uint32_t ndiag = m < n ? m : n;
+    if (!qr_done) {
     for (uint32_t e = id; e < mn; e += cnt) W(e) = 0.0;
     for (uint32_t j = id; j < n; j += cnt) W(oPerm + j) = (double)j;
     ctx.sync();
@@ -159,7 +162,6 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
     // The squared norm of every remaining column below the current row is what the pivot search needs; it is summed
     // (rows ascending, exactly as a fresh pass would) while the reflector is applied to the column, so a step reads
     // the trailing matrix twice instead of three times.
-    const uint32_t ndiag = m < n ? m : n;
     for (uint32_t j = id; j < n; j += cnt) {
         double s = 0.0;
         for (uint32_t i = 0; i < m; ++i) {
@@ -219,6 +221,7 @@ __device__ void freedom_component(const C& ctx, const Ws W, const FreedomComp cd
         }
         ctx.sync();
     }
+    }  // !qr_done
     // ---- rank and null-space basis (find_dof.rs:38-77) --------------------------------------------------------------
     uint32_t rank = 0;
     while (rank < ndiag && fabs(A_(rank, rank)) > tol) ++rank;
@@ -363,7 +366,7 @@ __global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
             for (uint32_t c = 0; c < a.ncomp; ++c) {
                 const FreedomComp cd = a.comps[c];
                 freedom_component(BlockCtx{red}, Ws{w, 1}, cd, a.items, a.jv + base * a.zj, tol, a.comp_vars + cd.var0,
-                                  a.part + base * a.n, &partmax[0]);
+                                  a.part + base * a.n, &partmax[0], a.qr_done != 0);
             }
         }
         __threadfence_block();
@@ -379,6 +382,134 @@ __global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
         if (a.n_under)
             for (uint32_t g = tid; g < nsys; g += nthr) a.n_under[base + g] = under[g];
         __syncthreads();
+    }
+}
+
+// ---- the pivoted QR of ONE large component, spread over the device ------------------------------------------------------
+// A workgroup alone streams the trailing matrix at 12 GB/s (a few wavefronts' worth of loads in flight).  For systems
+// that are one big component the host therefore runs the QR as a chain of small launches per Householder step --
+// fr_pivot (one workgroup per system: pivot search on the running norms, column swap, reflector) and fr_apply (64
+// columns x 16 row chunks per workgroup, all systems of the chunk side by side in grid.y) -- and then the ordinary
+// kernel with `qr_done` for rank, null space and participation.  Same algorithm and pivot rule; the dot products and
+// norms are summed as 16 partial sums, so R differs from the one-workgroup R in the last bits (the participation it
+// leads to does not depend on the basis).  Workspace layout = freedom_component's row-major one.
+struct FreedomStepArgs {
+    double* gws;            // [systems][ws]
+    const double* jv;       // [systems][zj]
+    const uint32_t* items;  // the component's (slot, lcol * m + lrow) pairs
+    uint32_t* done;         // [systems]: nothing left to eliminate (all remaining columns are zero)
+    double* tau;            // [systems]: tau of the current step
+    uint32_t ws, zj, m, n, item0, item1, k;
+};
+
+__global__ void __launch_bounds__(256) fr_init_kernel(const FreedomStepArgs a) {
+    double* W = a.gws + (size_t)blockIdx.y * a.ws;
+    const uint32_t mn = a.m * a.n, oPerm = mn + 2 * a.n * a.n;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < mn; e += gridDim.x * blockDim.x) W[e] = 0.0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n; j += gridDim.x * blockDim.x) W[oPerm + j] = (double)j;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.done[blockIdx.y] = 0;
+}
+__global__ void __launch_bounds__(256) fr_scatter_kernel(const FreedomStepArgs a) {
+    double* W = a.gws + (size_t)blockIdx.y * a.ws;
+    const double* jv = a.jv + (size_t)blockIdx.y * a.zj;
+    for (uint32_t it = a.item0 + blockIdx.x * blockDim.x + threadIdx.x; it < a.item1; it += gridDim.x * blockDim.x) {
+        const uint32_t e = a.items[2 * it + 1], lcol = e / a.m;
+        W[(size_t)(e - lcol * a.m) * a.n + lcol] = jv[a.items[2 * it]];
+    }
+}
+__global__ void __launch_bounds__(256) fr_norms_kernel(const FreedomStepArgs a) {
+    double* W = a.gws + (size_t)blockIdx.y * a.ws;
+    const uint32_t oTau = a.m * a.n + 2 * a.n * a.n + a.n;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n; j += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (uint32_t i = 0; i < a.m; ++i) {
+            const double v = W[(size_t)i * a.n + j];
+            s += v * v;
+        }
+        W[oTau + j] = s;
+    }
+}
+__global__ void __launch_bounds__(256) fr_pivot_kernel(const FreedomStepArgs a) {
+    __shared__ double red[16];
+    if (a.done[blockIdx.x]) return;
+    double* W = a.gws + (size_t)blockIdx.x * a.ws;
+    const uint32_t m = a.m, n = a.n, k = a.k, oPerm = m * n + 2 * n * n, oTau = oPerm + n;
+    const freedom::BlockCtx ctx{red};
+    double bv = -1.0;
+    uint32_t bj = k;
+    for (uint32_t j = k + threadIdx.x; j < n; j += blockDim.x) {
+        const double s = W[oTau + j];
+        if (s > bv) {
+            bv = s;
+            bj = j;
+        }
+    }
+    ctx.argmax(bv, bj);
+    if (!(bv > 0.0)) {  // nothing left (or NaN): the remaining diagonal is exactly zero
+        if (threadIdx.x == 0) a.done[blockIdx.x] = 1;
+        return;
+    }
+    if (bj != k) {
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+            const double t = W[(size_t)i * n + k];
+            W[(size_t)i * n + k] = W[(size_t)i * n + bj];
+            W[(size_t)i * n + bj] = t;
+        }
+        if (threadIdx.x == 0) {
+            const double t = W[oPerm + k];
+            W[oPerm + k] = W[oPerm + bj];
+            W[oPerm + bj] = t;
+            W[oTau + bj] = W[oTau + k];
+        }
+    }
+    __syncthreads();
+    const double norm = sqrt(bv);
+    const double alpha = W[(size_t)k * n + k];
+    const double beta = alpha >= 0.0 ? -norm : norm;
+    const double denom = alpha - beta;
+    __syncthreads();
+    for (uint32_t i = k + 1 + threadIdx.x; i < m; i += blockDim.x) W[(size_t)i * n + k] /= denom;
+    if (threadIdx.x == 0) {
+        W[(size_t)k * n + k] = beta;
+        a.tau[blockIdx.x] = (beta - alpha) / beta;
+    }
+}
+// 64 columns per workgroup, the rows below k in 16 contiguous chunks (one per wavefront).
+__global__ void __launch_bounds__(1024) fr_apply_kernel(const FreedomStepArgs a) {
+    __shared__ double part[16][64];
+    if (a.done[blockIdx.y]) return;
+    double* W = a.gws + (size_t)blockIdx.y * a.ws;
+    const uint32_t m = a.m, n = a.n, k = a.k, oTau = m * n + 2 * n * n + n;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t j = k + 1 + blockIdx.x * 64 + lane;
+    const bool live = j < n;
+    const uint32_t rows = m - (k + 1), per = (rows + 15) / 16;
+    const uint32_t i0 = k + 1 + w * per, i1 = (i0 + per < m) ? i0 + per : m;
+    const double tau = a.tau[blockIdx.y];
+    double dot = 0.0;
+    if (live)
+        for (uint32_t i = i0; i < i1; ++i) dot += W[(size_t)i * n + k] * W[(size_t)i * n + j];
+    part[w][lane] = dot;
+    __syncthreads();
+    dot = live ? W[(size_t)k * n + j] : 0.0;
+    for (uint32_t q = 0; q < 16; ++q) dot += part[q][lane];
+    dot *= tau;
+    __syncthreads();
+    double s = 0.0;
+    if (live) {
+        if (w == 0) W[(size_t)k * n + j] -= dot;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const double v = W[(size_t)i * n + j] - dot * W[(size_t)i * n + k];
+            W[(size_t)i * n + j] = v;
+            s += v * v;
+        }
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && live) {
+        s = 0.0;
+        for (uint32_t q = 0; q < 16; ++q) s += part[q][lane];
+        W[oTau + j] = s;
     }
 }
 

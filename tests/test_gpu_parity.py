@@ -814,6 +814,37 @@ def test_freedom_workgroup_mode_with_global_workspace(E):
     assert np.all(mask[:, -2:].any(axis=1)) and np.all(mask[:, :-2] == 0)  # only the last point is free
 
 
+def test_freedom_of_one_large_component_spread_over_the_device(E):
+    """A 300-variable connected sketch that lost its last three constraints: one component, so its pivoted QR runs as a
+    chain of step launches over the whole device (dot products and norms in 16 partial sums) before the ordinary
+    kernel takes rank, null space and participation; three systems side by side.  Against the oracle's dense QR."""
+    recs, g = gen.connected_sketch(150, 4242)
+    recs = recs[:-3]
+    X = g[None, :] + gen.keyed_uniform(43, 3, len(g), -0.02, 0.02)
+    sysobj = E.System(recs, len(g))
+    x, st, _ = sysobj.solve_batch(X, E.Config(max_iterations=60))
+    _, mask, part = _freedom_vs_oracle(E, recs, len(g), x, atol=1e-8)
+    assert mask.any() and np.all(mask[:, :200] == 0)  # only points near the loose end are free
+    # the same analysis for every system of a batch larger than one launch's worth is consistent
+    mask2, part2 = sysobj.freedom_batch(np.repeat(x[:1], 5, axis=0))
+    assert np.all(mask2 == mask[0]) and np.allclose(part2, part[0], atol=1e-12)
+
+
+def test_freedom_two_large_components_on_one_workgroup(E):
+    """Two 120-variable chains in one system: not a one-component system, so each system's components are factorised in
+    sequence by one workgroup out of the global workspace (rows contiguous, norms summed during the update)."""
+    recs, g = _chain_system(60)
+    recs2 = recs.copy()
+    recs2["ids"] = recs2["ids"] + len(g)
+    both = np.concatenate([recs[:-1], recs2[:-2]])  # each chain loses its last constraint(s)
+    gg = np.concatenate([g, g + 0.3])
+    X = gg[None, :] + gen.keyed_uniform(47, 2, len(gg), -0.03, 0.03)
+    sysobj = E.System(both, len(gg))
+    x, st, _ = sysobj.solve_batch(X)
+    _, mask, _ = _freedom_vs_oracle(E, both, len(gg), x, atol=1e-8)
+    assert mask[:, len(g) - 2:len(g)].any() and mask[:, -2:].any()
+
+
 def test_freedom_random_systems(E):
     """The fuzz generator's systems (all 25 kinds, repeated ids, isolated variables) through the analysis."""
     rng = np.random.default_rng(99)
