@@ -112,6 +112,7 @@ struct EzpzSystem {
     uint32_t prog_lds_doubles = 0;
     uint32_t lvl_lds_off = 0, lvl_tab_words = 0, lvl_buf_words = 0;  // level staging of the Cholesky lists (finish_team)
     uint32_t lvl_nlev = 0;
+    bool lean_lds = false;  // batch-throughput workgroup: keep LDS per workgroup small (no whole-list staging)
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
     size_t lds_bytes = 0;
@@ -234,6 +235,7 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
                 const size_t room = kLdsBytesMax - 1024 > base + (size_t)lvl_tab_words * 4
                                         ? kLdsBytesMax - 1024 - base - (size_t)lvl_tab_words * 4 : 0;
                 size_t buf_bytes = std::min<size_t>((size_t)s.view.lvl_words_max * 4, std::min<size_t>(room, 48 * 1024));
+                if (s.lean_lds) buf_bytes = std::min<size_t>(buf_bytes, std::max<size_t>(ws_bytes / 4, 2048));
                 buf_bytes &= ~size_t(15);
                 if (buf_bytes >= 1024) {
                     s.lvl_lds_off = (uint32_t)(base / 8);
@@ -866,9 +868,18 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         // One connected component is a chain of elimination levels, each a few dependent memory hops and a divide: a
         // workgroup's extra lanes mostly wait at its barriers.  For batches one wavefront per system (no barriers, 2-4
         // systems per CU) gives 2-2.6x the rate at 150-300 variables; one solve alone takes ~25 % longer that way.
-        if (!team_size && !for_latency && G == 1 && P.c.n_parts == 1 && sub_team_fits(P.c, 64)) {
-            s.mode = MODE_SUB;
-            s.team_size = 64;
+        // Larger states (from ~250 variables) do better on a 128-lane workgroup that does NOT stage its lists whole (two
+        // or three workgroups per CU instead of one; levels are staged one at a time).  Measured, one wavefront vs this:
+        // 200 variables 3.06 / 3.02 M solves/s, 250: 1.66 / 1.92, 300: 1.04 / 1.39, 400: 0.56 / 0.76, 500: 0.20 / 0.28.
+        if (!team_size && !for_latency && G == 1 && P.c.n_parts == 1) {
+            const size_t wsb = (size_t)workspace_doubles(P.c) * 8;
+            if (sub_team_fits(P.c, 64) && wsb <= 24 * 1024) {
+                s.mode = MODE_SUB;
+                s.team_size = 64;
+            } else if (wsb <= 56 * 1024) {
+                s.team_size = 128;
+                s.lean_lds = true;
+            }
         }
     }
     s.counts = P.c;
@@ -894,7 +905,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
         if (s.mode == MODE_SUB) {
             if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
-        } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= kLdsBytesMax) {
+        } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= kLdsBytesMax && !s.lean_lds) {
             stage_bytes = lists_bytes;
         }
     }

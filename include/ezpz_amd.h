@@ -168,8 +168,8 @@ const char* ezpz_error_string(int err);
  * directly (Layout::index_of, solver.rs:107-109).  On MissingGuess, err_constraint/err_variable
  * receive the offending position in `cs` and the id.  `team_size` 0 = choose automatically for batch
  * throughput; EZPZ_TEAM_AUTO_LATENCY = choose automatically for the latency of one solve (what ezpz_solve does:
- * a connected sketch of a few hundred variables then runs on a whole workgroup instead of one wavefront, ~25 %
- * sooner per solve at less than half the batch rate). */
+ * a connected sketch of a few hundred variables then runs on a 256-512 lane workgroup with its lists staged in LDS
+ * instead of one wavefront / a lean 128-lane workgroup: ~35 % sooner per solve at less than half the batch rate). */
 #define EZPZ_TEAM_AUTO_LATENCY 0xFFFFFFFFu
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);

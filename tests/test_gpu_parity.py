@@ -624,16 +624,19 @@ def test_random_block_systems_are_deterministic_and_match_the_oracle(E, team, nc
             assert bool(st["converged"][0]) and float(st["final_residual_inf"][0]) <= 1e-8
 
 
-@pytest.mark.parametrize("npts,team,mode", [(150, 0, 0), (150, 256, 2), (400, 0, 2), (1500, 0, 2)])
+@pytest.mark.parametrize("npts,team,mode", [(90, 0, 0), (150, 0, 2), (150, 256, 2), (400, 0, 2), (1500, 0, 2)])
 def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, team, mode):
     """One connected component of mixed kinds (a random polyline-like sketch: every point tied to its predecessors by
-    one or two random constraints) on one wavefront (300 variables), on the barrier workgroup with its workspace in
-    LDS (300, 800) and in global memory (3000): deterministic from run to run, and -- it is fully determined by
-    construction -- the oracle's answer."""
+    one or two random constraints) on one wavefront (180 variables), on a lean 128-lane workgroup whose lists stay in
+    global memory (300), on the barrier workgroup with staged lists (300 on 256 lanes), with its workspace in LDS (800)
+    and in global memory (3000): deterministic from run to run, and -- it is fully determined by construction -- the
+    oracle's answer."""
     recs, g = gen.connected_sketch(npts, 77 + npts + team)
     sysobj = E.System(recs, len(g), team_size=team)
     info = sysobj.info()
     assert info["n_components"] == 1 and info["team_mode"] == mode and info["n_partitions"] == 1
+    if (npts, team) == (150, 0):
+        assert info["team_size"] == 128 and not info["program_in_lds"]
     x0 = np.tile(g, (5, 1))
     cfg = dict(max_iterations=60)
     x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
@@ -691,15 +694,16 @@ def test_hub_sketch_with_one_level_wider_than_the_team_and_its_staging_buffer(E,
         assert_x_close(x[b], want.final_values)
 
 
-@pytest.mark.parametrize("npts,hub_last", [(40, True), (100, False), (300, True)])
-def test_small_hub_sketch_on_one_wavefront(E, npts, hub_last):
-    """The hub sketch small enough for one wavefront per system (batches): its first level is wider than the 64 lanes
-    (two-phase walk) and, from 100 points, larger than the wavefront's staging buffer (walked from global memory); the
-    hub's levels are one phase with lists shared by up to 64 lanes."""
+@pytest.mark.parametrize("npts,hub_last,shape", [(40, True, (0, 64)), (100, False, (0, 64)), (300, True, (2, 128))])
+def test_small_hub_sketch_on_one_wavefront_or_lean_workgroup(E, npts, hub_last, shape):
+    """The hub sketch at the sizes batches run on one wavefront per system (82, 202 variables) or on a lean 128-lane
+    workgroup (602): its first level is wider than the team (two-phase walk) and, from 100 points, larger than the
+    team's staging buffer (walked from global memory); the hub's levels are one phase with lists shared by groups of
+    lanes."""
     recs, g = _hub_sketch(npts, 77 + npts, hub_last)
     sysobj = E.System(recs, len(g))
     info = sysobj.info()
-    assert info["n_components"] == 1 and (info["team_mode"], info["team_size"]) == (0, 64)
+    assert info["n_components"] == 1 and (info["team_mode"], info["team_size"]) == shape
     x0 = g[None, :] + gen.keyed_uniform(41, 64, len(g), -0.05, 0.05)
     x, st, mask = sysobj.solve_batch(x0, want_mask=True)
     rc, xo, it, conv, nun = O.solve_batch(recs, x0, linsolve=O.LINSOLVE_SPARSE)
