@@ -85,6 +85,11 @@ struct PinnedBuf {
 
 constexpr size_t kZeroCopyBytes = 1 << 20;  // calls moving less than this skip DMA and use mapped host memory
 
+// The staging buffer of the zero-copy path belongs to the calling thread (one per device), not to the system: a
+// solve() on a new topology then does not pay a hipHostMalloc (~200 us) for its first launch, and threads never share
+// one.  The thread's solve has synchronised its stream before it returns, so the buffer is free for its next call.
+thread_local PinnedBuf t_pinned[16];
+
 }  // namespace
 
 struct EzpzSystem {
@@ -123,7 +128,6 @@ struct EzpzSystem {
     DevBuf<uint8_t> mask_dev;
     DevBuf<uint64_t> log_dev;
     DevBuf<double> gws_dev;
-    PinnedBuf pinned;
     std::vector<uint32_t> host_var_of, host_row_of, host_slot_row, host_slot_col;  // internal -> caller numbering
     // FreedomAnalysis program (built on first use) and its scratch
     struct Freedom {
@@ -1076,8 +1080,9 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         // Small call (the solve() case): no DMA at all.  The kernel reads the guesses from, and writes the
         // results to, pinned host memory mapped into the device address space; one launch + one stream sync.
         const size_t total = x_bytes + st_bytes + mask_bytes + log_bytes;
-        if ((rc = sys->pinned.ensure(total)) != EZPZ_OK) return rc;
-        unsigned char* h = sys->pinned.p;
+        PinnedBuf& pinned = t_pinned[sys->device & 15];
+        if ((rc = pinned.ensure(total)) != EZPZ_OK) return rc;
+        unsigned char* h = pinned.p;
         double* hx = reinterpret_cast<double*>(h);
         EzpzStatus* hst = reinterpret_cast<EzpzStatus*>(h + x_bytes);
         uint8_t* hmask = h + x_bytes + st_bytes;
