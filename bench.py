@@ -176,7 +176,7 @@ def main():
     if args.extras:
         # (1) host-pointer entry point: H2D + kernel + D2H per call (pageable host memory) -- the PCIe-inclusive rate
         if rank == 0:
-            hb = min(B, 1024)
+            hb = min(B, 65536)  # the same systems per call as `value` (one launch per call)
             system.solve_batch(x0_host[:hb])
             th = time.perf_counter()
             for _ in range(3):

@@ -1106,29 +1106,39 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         }
         return EZPZ_OK;
     }
-    if ((rc = sys->x_dev.ensure(batch * std::max<size_t>(n, 1))) != EZPZ_OK) return rc;
-    if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
-    if (unsat_mask && (rc = sys->mask_dev.ensure(batch * std::max<size_t>(C, 1))) != EZPZ_OK) return rc;
-    if (want_log && (rc = sys->log_dev.ensure(batch * (size_t)warn_cap)) != EZPZ_OK) return rc;
-    if (n) HIP_TRY(hipMemcpy(sys->x_dev.p, x0, batch * n * sizeof(double), hipMemcpyHostToDevice));
-    rc = ezpz_system_solve_batch_device(sys, sys->x_dev.p, batch, cfg, sys->x_dev.p, sys->st_dev.p,
-                                        unsat_mask ? sys->mask_dev.p : nullptr, want_log ? sys->log_dev.p : nullptr,
-                                        warn_cap, nullptr);
-    if (rc != EZPZ_OK) return rc;
-    HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
-    if (n) HIP_TRY(hipMemcpy(x_out, sys->x_dev.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
-    if (unsat_mask && C) HIP_TRY(hipMemcpy(unsat_mask, sys->mask_dev.p, batch * C, hipMemcpyDeviceToHost));
-    if (want_log) {
-        // the log's capacity is sized for the worst case (every constraint warning in every sweep): bring back only
-        // what each system wrote, or everything when that is small anyway
-        if (log_bytes <= (1u << 20)) {
-            HIP_TRY(hipMemcpy(warn_log, sys->log_dev.p, log_bytes, hipMemcpyDeviceToHost));
-        } else {
-            for (size_t b = 0; b < batch; ++b) {
-                const size_t cnt = std::min<size_t>(status[b].n_warnings, warn_cap);
-                if (cnt)
-                    HIP_TRY(hipMemcpy(warn_log + b * warn_cap, sys->log_dev.p + b * warn_cap, cnt * sizeof(uint64_t),
-                                      hipMemcpyDeviceToHost));
+    // Larger calls: DMA in pieces of <= 16 MB of guesses (pageable copies of that size run at ~43 GB/s on this
+    // platform, 64 MB ones at ~20 GB/s), each piece H2D -> solve -> D2H through the same device buffers.  (Two sets of
+    // buffers on two streams with hipMemcpyAsync were measured slower, 1.01 vs 1.39 M solves/s on the 2000x2000
+    // system: copies from and to pageable memory do not overlap, they only add stream bookkeeping.)
+    const size_t row_bytes = std::max<size_t>(n, 1) * sizeof(double);
+    const size_t piece = std::max<size_t>(1, std::min<size_t>(batch, (16u << 20) / row_bytes));
+    if ((rc = sys->x_dev.ensure(piece * std::max<size_t>(n, 1))) != EZPZ_OK) return rc;
+    if ((rc = sys->st_dev.ensure(piece)) != EZPZ_OK) return rc;
+    if (unsat_mask && (rc = sys->mask_dev.ensure(piece * std::max<size_t>(C, 1))) != EZPZ_OK) return rc;
+    if (want_log && (rc = sys->log_dev.ensure(piece * (size_t)warn_cap)) != EZPZ_OK) return rc;
+    for (size_t off = 0; off < batch; off += piece) {
+        const size_t nb = std::min(piece, batch - off);
+        if (n) HIP_TRY(hipMemcpy(sys->x_dev.p, x0 + off * n, nb * n * sizeof(double), hipMemcpyHostToDevice));
+        rc = ezpz_system_solve_batch_device(sys, sys->x_dev.p, nb, cfg, sys->x_dev.p, sys->st_dev.p,
+                                            unsat_mask ? sys->mask_dev.p : nullptr, want_log ? sys->log_dev.p : nullptr,
+                                            warn_cap, nullptr);
+        if (rc != EZPZ_OK) return rc;
+        HIP_TRY(hipMemcpy(status + off, sys->st_dev.p, nb * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
+        if (n) HIP_TRY(hipMemcpy(x_out + off * n, sys->x_dev.p, nb * n * sizeof(double), hipMemcpyDeviceToHost));
+        if (unsat_mask && C) HIP_TRY(hipMemcpy(unsat_mask + off * C, sys->mask_dev.p, nb * C, hipMemcpyDeviceToHost));
+        if (want_log) {
+            // the log's capacity is sized for the worst case (every constraint warning in every sweep): bring back only
+            // what each system wrote, or everything when that is small anyway
+            const size_t bytes = nb * (size_t)warn_cap * sizeof(uint64_t);
+            if (bytes <= (1u << 20)) {
+                HIP_TRY(hipMemcpy(warn_log + off * warn_cap, sys->log_dev.p, bytes, hipMemcpyDeviceToHost));
+            } else {
+                for (size_t b2 = 0; b2 < nb; ++b2) {
+                    const size_t cnt = std::min<size_t>(status[off + b2].n_warnings, warn_cap);
+                    if (cnt)
+                        HIP_TRY(hipMemcpy(warn_log + (off + b2) * warn_cap, sys->log_dev.p + b2 * warn_cap,
+                                          cnt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                }
             }
         }
     }
