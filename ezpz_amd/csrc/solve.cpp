@@ -435,16 +435,20 @@ int ezpz_solve_batch(const EzpzConstraint* reqs_in, size_t n_reqs, size_t n_vars
     {
         std::vector<double> iv(n_vars);
         std::vector<uint8_t> key(undefined.size());
-        for (size_t b = 0; b < batch; ++b) {
-            if (!undefined.empty()) {
+        if (undefined.empty()) {  // one group: every system, in order
+            std::vector<size_t>& all = groups[key];
+            all.resize(batch);
+            for (size_t b = 0; b < batch; ++b) all[b] = b;
+        } else {
+            for (size_t b = 0; b < batch; ++b) {
                 std::memcpy(iv.data(), x0 + b * n_vars, n_vars * sizeof(double));
                 for (size_t u = 0; u < undefined.size(); ++u) {
                     EzpzConstraint c = reqs_in[undefined[u]];
                     set_from_initial_values(c, iv);
                     key[u] = c.tag;
                 }
+                groups[key].push_back(b);
             }
-            groups[key].push_back(b);
         }
     }
     std::vector<uint32_t> prios;
@@ -487,6 +491,34 @@ int ezpz_solve_batch(const EzpzConstraint* reqs_in, size_t n_reqs, size_t n_vars
                 break;  // every system of the group keeps its previous tier
             }
             const size_t na = active.size(), ns = subset.size();
+            if (first_tier && na == batch) {
+                // The whole batch in one group, first tier (the common call: no side to infer, one priority): the systems
+                // are 0..batch-1 in order and every result is kept (lib.rs:232-234 only drops an unsatisfied *later*
+                // tier), so the solve reads the caller's guesses and writes the caller's outputs -- no gather, no scatter.
+                const bool direct_mask = unsat_mask && ns == n_reqs;  // subset_ids is the identity
+                if (unsat_mask && !direct_mask) maskres.assign(na * std::max<size_t>(ns, 1), 0);
+                rc = ezpz_system_solve_batch(sys, x0, na, cfg, x_out, status,
+                                             unsat_mask ? (direct_mask ? unsat_mask : maskres.data()) : nullptr, nullptr, 0);
+                if (rc != EZPZ_OK) return rc;
+                if (priority_solved)
+                    for (size_t b = 0; b < batch; ++b) priority_solved[b] = lowest;
+                if (unsat_mask && !direct_mask) {
+                    std::memset(unsat_mask, 0, batch * n_reqs);
+                    for (size_t b = 0; b < batch; ++b)
+                        for (size_t k = 0; k < ns; ++k) unsat_mask[b * n_reqs + subset_ids[k]] = maskres[b * ns + k];
+                }
+                std::fill(have_res.begin(), have_res.end(), 1);
+                if (prios.size() > 1) {
+                    std::vector<size_t> still;
+                    for (size_t b = 0; b < batch; ++b)
+                        if (status[b].n_unsatisfied == 0) still.push_back(b);
+                    active.swap(still);
+                } else {
+                    active.clear();
+                }
+                first_tier = false;
+                continue;
+            }
             xin.resize(na * std::max<size_t>(n_vars, 1));
             xres.resize(xin.size());
             stres.resize(na);
