@@ -319,6 +319,26 @@ __device__ __forceinline__ double reduce_lanes(double v, Op op) {
     return v;
 }
 
+// Reduction of a whole wavefront into its LAST lane without the LDS crossbar: rows of 16 as above, then the two
+// wave-level DPP broadcasts of GFX9 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lanes the
+// row mask leaves out keep the operator's identity, so one unconditional op() per step serves every lane.  Same
+// pairing as the xor shuffles ((r0 + r1) + (r2 + r3)), so the same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_rows(double v, double keep) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned long long o = __builtin_bit_cast(unsigned long long, keep);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <class Op>
+__device__ __forceinline__ double reduce_wave_to_last_lane(double v, Op op) {
+    v = reduce_lanes<16>(v, op);
+    v = op(v, dpp_move_rows<0x142, 0xA>(v, op.identity()));  // row_bcast:15
+    v = op(v, dpp_move_rows<0x143, 0xC>(v, op.identity()));  // row_bcast:31
+    return v;
+}
+
 // ---- dense 8 x 8 linear solve in registers (teams of four lanes on systems of <= 8 variables) -----------------------
 // Value of lane S (0..3) of every quad in all four lanes of the quad: one DPP move per 32-bit half, no LDS round trip.
 __device__ __forceinline__ double quad_bcast(double v, int s) {
@@ -445,13 +465,13 @@ struct Team {
             a = reduce_lanes<TEAM>(a, opa);
             b = reduce_lanes<TEAM>(b, opb);
         } else {
-            a = reduce_lanes<64>(a, opa);
-            b = reduce_lanes<64>(b, opb);
+            a = reduce_wave_to_last_lane(a, opa);
+            b = reduce_wave_to_last_lane(b, opb);
             double* buf = red + (red_flip ? 32 : 0);
             red_flip ^= 1;
             const int wave = threadIdx.x >> 6;
             const int nwaves = (blockDim.x + 63) >> 6;
-            if ((threadIdx.x & 63) == 0) {
+            if ((threadIdx.x & 63) == 63) {
                 buf[wave] = a;
                 buf[16 + wave] = b;
             }
