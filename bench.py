@@ -42,9 +42,12 @@ def make_workload(name: str):
     from oracle import textual as T
 
     if name.startswith("massive"):
-        lines = int(name[len("massive"):] or 500)
-        cs = T.load(T.gen_big_problem(lines))
-        return f"massive_parallel_system gen_big_problem.py {lines} ({4 * lines} rows x {4 * lines} vars)", cs.constraints, cs.guesses, 0.25, 2
+        over = name.endswith("o")  # gen_big_problem.py <lines> true: one distance per line on top (5 rows per line, non-linear)
+        lines = int(name[len("massive"):].rstrip("o") or 500)
+        cs = T.load(T.gen_big_problem(lines, over))
+        rows = (5 if over else 4) * lines
+        return (f"massive_parallel_system gen_big_problem.py {lines}{' true' if over else ''} ({rows} rows x {4 * lines} vars)",
+                cs.constraints, cs.guesses, 0.25, None if over else 2)
     path = os.path.join(ROOT, "tests", "golden", "test_cases", name, "problem.md")
     cs = T.load(open(path).read())
     recs = cs.constraints.copy()
@@ -84,7 +87,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="systems per launch per GPU")
-    ap.add_argument("--workload", default="massive500", help="massive<lines> or a test_cases/ directory name")
+    ap.add_argument("--workload", default="massive500", help="massive<lines>[o] (o = over-constrained variant) or a test_cases/ directory name")
     ap.add_argument("--team", type=int, default=0, help="override lanes per system (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--check", type=int, default=1, help="verify the results of the last step against the oracle")
