@@ -7,7 +7,7 @@ import ezpz_amd as E
 from oracle import oracle as O
 import gen
 bad = 0; tot = 0
-for seed in range(60):
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     npts = [20, 33, 48, 70, 100, 140, 200, 320][seed % 8]
     recs, g = gen.connected_sketch(npts, 9000 + seed)
     for team in (0, E.TEAM_AUTO_LATENCY, 128):
