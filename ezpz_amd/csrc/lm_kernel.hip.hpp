@@ -732,6 +732,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     // measured slower -- 54 vs 38 us per 2000x2000 system -- and is not kept; records are re-read per sweep.)
     const uint64_t n_teams = (uint64_t)(gridDim.x / grid_wgs) * teams_per_block;
     uint32_t sys_parity = 0;  // grid teams: which of the slot's two warning counters this system uses
+    double x_pre[4] = {0.0, 0.0, 0.0, 0.0};  // partitioned teams: the next system's first values per lane, fetched ahead
+    bool x_have = false;
     for (uint64_t sys = (uint64_t)grid_slot * teams_per_block + team_in_block; sys < a.batch;
          sys += n_teams, sys_parity ^= 1u) {
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
@@ -742,8 +744,25 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         const double* x0 = a.x0 + sys * n_row;
         if constexpr (MODE == MODE_PART) {
             // each wavefront loads (and later stores) its own partition's variables only: a wavefront that is already
-            // on the next system never touches values another one has not stored yet
-            for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) ws[o_x + ci] = x0[P.var_of[ci]];
+            // on the next system never touches values another one has not stored yet.  The first four values per lane
+            // were fetched while the previous system was being solved (the HBM round trip of this load was 5 % of a
+            // 2000 x 2000 solve, on the critical path of whichever wavefront finished last).
+            constexpr uint32_t XPRE = 4;
+#pragma unroll
+            for (uint32_t j = 0; j < XPRE; ++j) {
+                const uint32_t ci = call0 + tm.lane + j * 64;
+                if (ci < call1) ws[o_x + ci] = x_have ? x_pre[j] : x0[P.var_of[ci]];
+            }
+            for (uint32_t ci = call0 + tm.lane + XPRE * 64; ci < call1; ci += tm.stride) ws[o_x + ci] = x0[P.var_of[ci]];
+            x_have = sys + n_teams < a.batch;
+            if (x_have) {
+                const double* x1 = a.x0 + (sys + n_teams) * n_row;
+#pragma unroll
+                for (uint32_t j = 0; j < XPRE; ++j) {
+                    const uint32_t ci = call0 + tm.lane + j * 64;
+                    x_pre[j] = ci < call1 ? x1[P.var_of[ci]] : 0.0;
+                }
+            }
         } else {
             for (uint32_t i = tlane; i < n; i += tsize) ws[o_x + i] = x0[P.var_of[i]];
         }
