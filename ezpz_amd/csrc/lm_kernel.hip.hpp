@@ -734,6 +734,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     uint32_t sys_parity = 0;  // grid teams: which of the slot's two warning counters this system uses
     double x_pre[4] = {0.0, 0.0, 0.0, 0.0};  // partitioned teams: the next system's first values per lane, fetched ahead
     bool x_have = false;
+    uint32_t x_id[4] = {0, 0, 0, 0};  // ... and the caller's ids of this lane's first four variables (the same for every system)
+    if constexpr (MODE == MODE_PART) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t ci = call0 + tm.lane + j * 64;
+            x_id[j] = ci < call1 ? P.var_of[ci] : 0u;
+        }
+    }
     for (uint64_t sys = (uint64_t)grid_slot * teams_per_block + team_in_block; sys < a.batch;
          sys += n_teams, sys_parity ^= 1u) {
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
@@ -751,7 +759,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
 #pragma unroll
             for (uint32_t j = 0; j < XPRE; ++j) {
                 const uint32_t ci = call0 + tm.lane + j * 64;
-                if (ci < call1) ws[o_x + ci] = x_have ? x_pre[j] : x0[P.var_of[ci]];
+                if (ci < call1) ws[o_x + ci] = x_have ? x_pre[j] : x0[x_id[j]];
             }
             for (uint32_t ci = call0 + tm.lane + XPRE * 64; ci < call1; ci += tm.stride) ws[o_x + ci] = x0[P.var_of[ci]];
             x_have = sys + n_teams < a.batch;
@@ -760,7 +768,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
 #pragma unroll
                 for (uint32_t j = 0; j < XPRE; ++j) {
                     const uint32_t ci = call0 + tm.lane + j * 64;
-                    x_pre[j] = ci < call1 ? x1[P.var_of[ci]] : 0.0;
+                    x_pre[j] = ci < call1 ? x1[x_id[j]] : 0.0;
                 }
             }
         } else {
@@ -1242,7 +1250,12 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         EZPZ_STAMP(31);
         double* xo = a.x_out + sys * n_row;
         if constexpr (OWN_STORE) {
-            for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) xo[P.var_of[ci]] = ws[o_x + ci];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t ci = call0 + tm.lane + j * 64;
+                if (ci < call1) xo[x_id[j]] = ws[o_x + ci];
+            }
+            for (uint32_t ci = call0 + tm.lane + 4 * 64; ci < call1; ci += tm.stride) xo[P.var_of[ci]] = ws[o_x + ci];
         } else {
             for (uint32_t i = tlane; i < n; i += tsize) xo[P.var_of[i]] = ws[o_x + i];
         }
