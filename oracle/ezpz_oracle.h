@@ -6,8 +6,8 @@
  * cpu_baseline leg may load this library; the product (ezpz_amd/) never does.
  *
  * Parity status: PINNED against the reference's own known-answer tests
- * (tests/golden/reference_pins.json, transcribed from ezpz/src/tests.rs with
- * file:line) -- the reference itself is Rust and cannot be built in this image
+ * (tests/cases.py, transcribed from ezpz/src/tests.rs with file:line and run
+ * on this library by tests/test_oracle_pins.py) -- the reference itself is Rust and cannot be built in this image
  * (no cargo/rustc; faer 0.24.0 / libm 0.2.16 are un-vendored crates.io deps).
  * faer's sparse LLT is restated here as a textbook up-looking sparse Cholesky
  * (and a dense Cholesky); equality with faer is up to rounding only.

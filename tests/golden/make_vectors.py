@@ -30,7 +30,7 @@ def main():
         variants += [cs.guesses + jit[k] for k in range(3)]
         recs = []
         for g in variants:
-            o = O.solve(cs.constraints, g)
+            o = O.solve(cs.constraints, g, analysis=True)
             # Conditioning of the answer itself: how far the oracle's own result moves when the inputs are
             # perturbed by one ulp.  Under-determined systems are regularised only by lambda ~ 1e-9..1e-10, so
             # rounding noise in the null space is amplified by ~1/lambda and 1e-6 agreement is not defined there.
@@ -43,6 +43,9 @@ def main():
                                                   / np.maximum(1.0, np.abs(o.final_values)))))
             recs.append({
                 "ulp_sensitivity": sens,
+                # FreedomAnalysis of the oracle (find_dof.rs): the variables no constraint determines.  Only these
+                # may use the widened tolerance in the GPU parity test; every other coordinate is held to 1e-6.
+                "underconstrained": o.underconstrained,
                 "guesses": [float(v) for v in g],
                 "final_values": [float(v) for v in o.final_values],
                 "iterations": o.iterations,

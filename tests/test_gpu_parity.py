@@ -95,11 +95,19 @@ def test_golden_vectors(E):
             assert got.converged == rec["converged"], case
             assert got.unsatisfied == rec["unsatisfied"], case
             assert len(got.warnings) == rec["n_warnings"], case
-            # 1e-6 relative, widened only where the oracle's own answer moves by more than that under a one-ulp
-            # input perturbation (under-determined fixtures; see make_vectors.py), never beyond the reference's
-            # own test tolerance of 1e-4.
-            tol = min(1e-4, max(REL, 20.0 * rec["ulp_sensitivity"]))
-            assert_x_close(got.final_values, rec["final_values"], tol)
+            # Every coordinate the constraints determine is held to 1e-6 relative (north_star).  Only the variables the
+            # oracle's FreedomAnalysis flags as underconstrained (find_dof.rs; recorded per vector by make_vectors.py)
+            # may use a wider bar: they are held in place by lambda ~ 1e-9..1e-10 alone, the oracle's own answer moves
+            # by `ulp_sensitivity` there under a one-ulp input perturbation, and the bar is 20x that -- never beyond
+            # the reference's own test tolerance of 1e-4.
+            want = np.asarray(rec["final_values"])
+            free = np.zeros(len(want), dtype=bool)
+            free[rec["underconstrained"]] = True
+            gotv = np.asarray(got.final_values)
+            if np.any(~free):
+                assert_x_close(gotv[~free], want[~free], REL)
+            if np.any(free):
+                assert_x_close(gotv[free], want[free], min(1e-4, max(REL, 20.0 * rec["ulp_sensitivity"])))
             assert abs(got.final_residual_inf - rec["final_residual_inf"]) <= 1e-9, case
 
 
