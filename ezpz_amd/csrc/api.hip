@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -27,8 +28,32 @@ using namespace ezpz;
 
 namespace {
 
-constexpr size_t kLdsBytesMax = 160 * 1024;  // MI355X: 160 KiB LDS per CU
-constexpr int kNumCUs = 256;
+// What the launch shapes are sized for.  Queried from the device the system is created on (a partitioned MI355X --
+// CPX / DPX -- or a CU-masked process sees fewer CUs than the full chip's 256); the host-only analysis
+// (ezpz_analyze, no device) assumes the full MI355X.
+struct DeviceLimits {
+    int cus = 256;                  // compute units
+    size_t lds_bytes = 160 * 1024;  // LDS one workgroup may allocate (MI355X: 160 KiB per CU)
+};
+const DeviceLimits& device_limits(int device) {
+    static const DeviceLimits full_chip;
+    static std::mutex mu;
+    static DeviceLimits cache[16];
+    static bool have[16] = {};
+    if (device < 0 || device >= 16) return full_chip;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!have[device]) {
+        DeviceLimits d;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) d.cus = v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
+            d.lds_bytes = (size_t)v;
+        (void)hipGetLastError();
+        cache[device] = d;
+        have[device] = true;
+    }
+    return cache[device];
+}
 
 #define HIP_TRY(expr)                                  \
     do {                                               \
@@ -93,7 +118,8 @@ thread_local PinnedBuf t_pinned[16];
 }  // namespace
 
 struct EzpzSystem {
-    int device = 0;
+    int device = -1;      // -1: host-only analysis
+    DeviceLimits lim;     // of `device`
     ProgramCounts counts;
     EzpzSystemInfo info{};
     void* dev_program = nullptr;  // single allocation holding every list
@@ -110,7 +136,6 @@ struct EzpzSystem {
     std::vector<unsigned char> grid_blob;       // the workgroups' sub-programs, one after the other
     std::vector<ProgramView> host_grid_views;   // per workgroup; blob_bytes = offset of its slice in grid_blob
     size_t grid_stage_bytes = 0;
-    bool lds_attr_set = false;   // hipFuncAttributeMaxDynamicSharedMemorySize raised for this system's kernel build
     uint64_t grid_capacity = 0;  // workgroups of the grid build the device holds at once (0 = not asked yet)
     void* dev_grid_blob = nullptr;
     DevBuf<ProgramView> grid_views;
@@ -232,12 +257,12 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
             s.prog_lds_doubles = (uint32_t)((s.grid_stage_bytes + 15) / 16 * 2);
             s.lds_bytes = (size_t)s.prog_lds_doubles * 8 + (size_t)s.ws_doubles * 8 + 64 * 8 + 16;
         } else {
-            s.lds_ws = prog_bytes + ws_bytes + 1024 <= kLdsBytesMax;
+            s.lds_ws = prog_bytes + ws_bytes + 1024 <= s.lim.lds_bytes;
             s.lds_bytes = s.lds_ws ? prog_bytes + ws_bytes + 64 * 8 + 16 : prog_bytes + 80 * 8;
             if (lvl_ok) {
                 const size_t base = (s.lds_bytes + 15) & ~size_t(15);
-                const size_t room = kLdsBytesMax - 1024 > base + (size_t)lvl_tab_words * 4
-                                        ? kLdsBytesMax - 1024 - base - (size_t)lvl_tab_words * 4 : 0;
+                const size_t room = s.lim.lds_bytes - 1024 > base + (size_t)lvl_tab_words * 4
+                                        ? s.lim.lds_bytes - 1024 - base - (size_t)lvl_tab_words * 4 : 0;
                 size_t buf_bytes = std::min<size_t>((size_t)s.view.lvl_words_max * 4, std::min<size_t>(room, 48 * 1024));
                 if (s.lean_lds) buf_bytes = std::min<size_t>(buf_bytes, std::max<size_t>(ws_bytes / 4, 2048));
                 buf_bytes &= ~size_t(15);
@@ -259,10 +284,14 @@ bool sub_team_fits(const ProgramCounts& c, uint32_t team) {
 template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool DENSE = false>
 int launch_kernel(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
     auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN, false, DENSE>;
-    if (s.lds_bytes > 48 * 1024 && !s.lds_attr_set) {  // once per system (one kernel build per system)
+    // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to the system: raised once per kernel
+    // build and device, to everything the device allows, so that systems of different sizes sharing a build never
+    // lower each other's limit
+    static std::atomic<bool> raised[16];
+    if (s.lds_bytes > 48 * 1024 && !raised[s.device & 15].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)s.lds_bytes));
-        s.lds_attr_set = true;
+                                    (int)s.lim.lds_bytes));
+        raised[s.device & 15].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(s.block_threads), s.lds_bytes, stream, args);
     HIP_TRY(hipGetLastError());
@@ -298,10 +327,10 @@ int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (s.grid_capacity == 0) {  // once per system: these two runtime calls cost more than the solve
         if (s.lds_bytes > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lim.lds_bytes));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)s.block_threads, s.lds_bytes));
-        s.grid_capacity = (uint64_t)kNumCUs * (uint64_t)std::max(per_cu, 1);
+        s.grid_capacity = (uint64_t)s.lim.cus * (uint64_t)std::max(per_cu, 1);
     }
     const uint64_t capacity = s.grid_capacity;
     if (capacity < s.grid_wgs) return EZPZ_ERR_TOO_LARGE;
@@ -353,7 +382,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (s.mode == MODE_SUB) {
         const uint32_t tpb = s.block_threads / s.team_size;
         uint64_t blocks = (args.batch + tpb - 1) / tpb;
-        grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)kNumCUs * 32);
+        grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)s.lim.cus * 32);
         switch (s.team_size) {
         case 1: return launch_sub<1>(s, args, grid, stream);
         case 2: return launch_sub<2>(s, args, grid, stream);
@@ -365,9 +394,9 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         }
     }
     if (s.grid_wgs > 1) return launch_grid_team(s, args, stream);
-    const uint32_t per_cu = s.lds_ws ? (uint32_t)std::max<size_t>(1, kLdsBytesMax / std::max<size_t>(s.lds_bytes, 1))
+    const uint32_t per_cu = s.lds_ws ? (uint32_t)std::max<size_t>(1, s.lim.lds_bytes / std::max<size_t>(s.lds_bytes, 1))
                                      : 2048u / s.block_threads;
-    grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)kNumCUs * std::min<uint32_t>(per_cu, 8) * 2);
+    grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)s.lim.cus * std::min<uint32_t>(per_cu, 8) * 2);
     if (!s.lds_ws) {
         int rc = s.gws_dev.ensure((size_t)grid * s.ws_doubles);
         if (rc != EZPZ_OK) return rc;
@@ -682,7 +711,7 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
                             S.c.n_apairs < 65536 && S.c.n_lpairs < 65536 && S.c.n_cons < 65536;
         const size_t lists_bytes = fits16 ? pack_program(S, true, true, sub, sv) : 0;
         const uint32_t wsd = workspace_doubles(S.c);
-        if (!fits16 || !sv.packed || lists_bytes + (size_t)wsd * 8 + 2048 > kLdsBytesMax ||
+        if (!fits16 || !sv.packed || lists_bytes + (size_t)wsd * 8 + 2048 > s.lim.lds_bytes ||
             s.grid_blob.size() + sub.size() > 0xFFFFFF00ull) {
             s.grid_blob.clear();
             s.host_grid_views.clear();
@@ -812,7 +841,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
         auto grid_wgs_for = [&]() {
             uint32_t g = 1;
-            while (g < (uint32_t)kGridMaxWgs && (uint64_t)g * 2 * W * 64 <= n_vars && (uint64_t)g * 2 * W * 2 <= n_pieces)
+            // every workgroup of a grid team must be resident at once: never more of them than the device has CUs
+            while (g < (uint32_t)kGridMaxWgs && g * 2 <= (uint32_t)s.lim.cus && (uint64_t)g * 2 * W * 64 <= n_vars &&
+                   (uint64_t)g * 2 * W * 2 <= n_pieces)
                 g <<= 1;
             return g;
         };
@@ -842,7 +873,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         };
         uint32_t G = 1;
         bool have_program = false;
-        if (!team_size && (3 * n_vars + 2 * n_cs) * 8 > kLdsBytesMax) {
+        if (!team_size && (3 * n_vars + 2 * n_cs) * 8 > s.lim.lds_bytes) {
             const int r = build_grid(grid_wgs_for());
             if (r < 0) return fail();
             if (r > 1) {
@@ -852,7 +883,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
         if (!have_program) {
             if (!build_program(cs, n_cs, n_vars, P, be, W)) return fail();
-            if (!team_size && (size_t)workspace_doubles(P.c) * 8 + 4096 > kLdsBytesMax && grid_wgs_for() > 1) {
+            if (!team_size && (size_t)workspace_doubles(P.c) * 8 + 4096 > s.lim.lds_bytes && grid_wgs_for() > 1) {
                 Program one = std::move(P);
                 const int r = build_grid(grid_wgs_for());
                 if (r < 0) return fail();
@@ -909,7 +940,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
         if (s.mode == MODE_SUB) {
             if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
-        } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= kLdsBytesMax && !s.lean_lds) {
+        } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= s.lim.lds_bytes && !s.lean_lds) {
             stage_bytes = lists_bytes;
         }
     }
@@ -950,11 +981,17 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
     std::unique_ptr<EzpzSystem> s(new EzpzSystem());
     Program P;
     std::vector<unsigned char> blob;
+    // launch shapes are sized for the device the system will live on; request errors (MissingGuess ...) are reported
+    // before the absence of a device, like the reference reports them before any numeric work
+    const bool have_device = device >= 0 && ezpz_device_count() > device;
+    if (have_device) {
+        s->device = device;
+        s->lim = device_limits(device);
+    }
     int rc = analyze_into(cs, n_cs, n_vars, team_size, *s, P, blob, err_constraint, err_variable);
     if (rc != EZPZ_OK) return rc;
-    if (ezpz_device_count() <= device || device < 0) return EZPZ_ERR_NO_DEVICE;
+    if (!have_device) return EZPZ_ERR_NO_DEVICE;
     HIP_TRY(hipSetDevice(device));
-    s->device = device;
     HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
     HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
     s->view.base = static_cast<const unsigned char*>(s->dev_program);
@@ -1095,6 +1132,9 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         if (rc != EZPZ_OK) return rc;
         HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
         std::memcpy(status, hst, st_bytes);
+        if (sys->grid_wgs > 1)
+            for (size_t b2 = 0; b2 < batch; ++b2)
+                if (status[b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
         if (n) std::memcpy(x_out, hx, batch * n * sizeof(double));
         if (unsat_mask && C) std::memcpy(unsat_mask, hmask, batch * C);
         if (want_log) {
@@ -1124,6 +1164,9 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                                             warn_cap, nullptr);
         if (rc != EZPZ_OK) return rc;
         HIP_TRY(hipMemcpy(status + off, sys->st_dev.p, nb * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
+        if (sys->grid_wgs > 1)
+            for (size_t b2 = 0; b2 < nb; ++b2)
+                if (status[off + b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
         if (n) HIP_TRY(hipMemcpy(x_out + off * n, sys->x_dev.p, nb * n * sizeof(double), hipMemcpyDeviceToHost));
         if (unsat_mask && C) HIP_TRY(hipMemcpy(unsat_mask + off * C, sys->mask_dev.p, nb * C, hipMemcpyDeviceToHost));
         if (want_log) {

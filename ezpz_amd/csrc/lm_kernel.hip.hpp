@@ -164,7 +164,8 @@ constexpr int kGridMaxWgs = 256;
 typedef unsigned int gridchunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, seq, 0)
 struct GridScratch {
     int nwarn[2];                           // Degenerate-warning counters, by parity of the system's index in this slot
-    int pad[14];
+    int dead;                               // a rendezvous timed out (some workgroup of the team never became resident)
+    int pad[13];
     gridchunk_t arr[2][2][kGridMaxWgs];     // [parity of the sequence number][value][workgroup]: partials
     gridchunk_t out[2][kGridMaxWgs][4];     // [parity][workgroup]: (a, seq), (b, seq) in one 64-byte line
 };
@@ -178,12 +179,21 @@ __device__ __forceinline__ void grid_store(gridchunk_t* p, double v, unsigned in
     c.w = 0;
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(c) : "memory");
 }
-// Spins until the chunk carries `seq`, returns its value.
-__device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int seq) {
+// Spins until the chunk carries `seq`, returns its value.  The spin is bounded (~1 s): if a workgroup of the team is
+// not resident (a device with fewer free CUs than the launch was sized for, e.g. another process's grid teams on the
+// same device) the waiters give up, flag the slot dead and return NaN instead of hanging the GPU; the solve's status
+// then carries EZPZ_ITERATIONS_TEAM_TIMEOUT.
+constexpr unsigned int kGridSpinLimit = 1u << 21;
+__device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int seq, int* dead) {
     gridchunk_t c;
-    for (;;) {
+    for (unsigned int spins = 0;; ++spins) {
         asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(c) : "v"(p) : "memory");
         if (c.z == seq) break;
+        if ((spins & 1023u) == 1023u &&
+            (spins >= kGridSpinLimit || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return __builtin_nan("");
+        }
         __builtin_amdgcn_s_sleep(1);
     }
     return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
@@ -496,8 +506,8 @@ struct Team {
                         a = opa.identity();
                         b = opb.identity();
                         if (threadIdx.x < grid_wgs) {
-                            a = grid_wait(&grid->arr[par][0][threadIdx.x], seq);
-                            b = grid_wait(&grid->arr[par][1][threadIdx.x], seq);
+                            a = grid_wait(&grid->arr[par][0][threadIdx.x], seq, &grid->dead);
+                            b = grid_wait(&grid->arr[par][1][threadIdx.x], seq, &grid->dead);
                         }
                         a = reduce_lanes<64>(a, opa);
                         b = reduce_lanes<64>(b, opb);
@@ -517,7 +527,7 @@ struct Team {
                             grid_store(&grid->out[par][threadIdx.x][1], b, seq);
                         }
                     } else {
-                        if (threadIdx.x < 2) buf2[16 * threadIdx.x] = grid_wait(&grid->out[par][grid_wg][threadIdx.x], seq);
+                        if (threadIdx.x < 2) buf2[16 * threadIdx.x] = grid_wait(&grid->out[par][grid_wg][threadIdx.x], seq, &grid->dead);
                         __syncthreads();
                         a = buf2[0];
                         b = buf2[16];
@@ -1106,7 +1116,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 // every weight is 1 and r was evaluated at this x: r already holds the unweighted residuals, so the
                 // unsatisfied check reads it instead of re-evaluating every constraint -- and when even the largest
                 // |r| is below EPSILON (every converged solve) no constraint can be unsatisfied (lib.rs:358-370)
-                if (largest < EPS) {
+                // (fmax drops NaN residuals from `largest`, but is_satisfied's `abs() < EPSILON` is false for them: a NaN
+                // residual makes the sum of squares NaN, and then every constraint takes the per-row test below)
+                if (largest < EPS && !isnan(residual_sq)) {
                     all_satisfied = true;
                     if (a.unsat_mask && grid_wg == 0)
                         for (uint32_t i = tlane; i < a.p.n_cons; i += tsize) a.unsat_mask[sys * a.p.n_cons + i] = 0;
@@ -1268,6 +1280,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                                       : (uint32_t)*nwarn;
             st.final_residual_inf = (m > 0) ? largest : 0.0;
             st.final_lambda = lambda;
+            if (grid_team && __hip_atomic_load(&tm.grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                st.iterations = EZPZ_ITERATIONS_TEAM_TIMEOUT;
+                st.converged = 0;
+            }
             a.status[sys] = st;
             // grid teams: this counter serves the slot's system after next; every workgroup passes a grid reduction
             // of the next system (which this thread joins only after the store) before it can get there

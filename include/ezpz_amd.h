@@ -110,6 +110,7 @@ typedef struct EzpzWarning {
 
 /* Per-system result of the device LM loop: SuccessfulSolve (solver/newton.rs:18-24) plus what
  * solve_inner derives (lib.rs:305-327).  32 bytes. */
+#define EZPZ_ITERATIONS_TEAM_TIMEOUT 0xFFFFFFFFu /* EzpzStatus.iterations: see ezpz_system_solve_batch_device */
 typedef struct EzpzStatus {
     uint32_t iterations;
     uint32_t converged;
@@ -197,7 +198,11 @@ int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t
  * The _device form takes device pointers and only enqueues on `stream` (a hipStream_t; NULL = default);
  * the host form copies in, runs, copies out and synchronises.  Launches on one EzpzSystem must not overlap in time
  * when the system uses per-system device scratch (a global workspace or a grid team, see EzpzSystemInfo): enqueue
- * them on one stream, or create one EzpzSystem per stream. */
+ * them on one stream, or create one EzpzSystem per stream.
+ * Grid teams (EzpzSystemInfo.grid_workgroups > 1) need all their workgroups resident at once; launches are sized to
+ * the device's CU count, and should a rendezvous still time out (~1 s: another process occupying the device) the
+ * affected systems report iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT, converged == 0 instead of hanging; the host
+ * form returns EZPZ_ERR_HIP in that case and the EzpzSystem must be destroyed. */
 int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
                                    double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
                                    uint64_t* warn_log_dev, uint32_t warn_cap, void* stream);
