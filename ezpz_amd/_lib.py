@@ -54,6 +54,7 @@ EXPORTS = [
     "ezpz_solve_analysis",
     "ezpz_system_freedom_batch",
     "ezpz_system_freedom_batch_device",
+    "ezpz_resolve_sides",
 ]
 
 _lib = None
@@ -92,6 +93,8 @@ def lib():
     L.ezpz_system_freedom_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.ezpz_current_device.restype = C.c_int
     L.ezpz_current_device.argtypes = []
+    L.ezpz_resolve_sides.restype = C.c_int
+    L.ezpz_resolve_sides.argtypes = [vp, sz, vp, sz]
     L.ezpz_cache_clear.restype = None
     L.ezpz_cache_clear.argtypes = []
     L.ezpz_analyze.restype = C.c_int

@@ -601,6 +601,18 @@ def solve_batch(reqs, x0: np.ndarray, config: Optional[Config] = None, want_mask
     return x, st, prio, mask
 
 
+def resolve_sides(records, values) -> np.ndarray:
+    """`Constraint::set_from_initial_values` (constraints.rs:146-193) over a request list: a copy of `records` in which
+    every undefined LineSide / CircleSide is the one `values` (by id) imply.  `System` takes side-resolved records."""
+    recs = stack_records(records).copy()
+    vals = np.ascontiguousarray(values, dtype=np.float64)
+    rc = lib().ezpz_resolve_sides(recs.ctypes.data if len(recs) else None, len(recs),
+                                  vals.ctypes.data if len(vals) else None, len(vals))
+    if rc != 0:
+        raise NonLinearSystemError(rc)
+    return recs
+
+
 TEAM_AUTO_LATENCY = 0xFFFFFFFF  # `team_size`: choose for the latency of one solve instead of batch throughput (ezpz_amd.h)
 
 

@@ -133,6 +133,21 @@ void ezpz_cache_clear(void) {
     g_cache.clear();
 }
 
+int ezpz_resolve_sides(EzpzConstraint* cs, size_t n_cs, const double* values, size_t n_vars) {
+    if ((n_cs && !cs) || (n_vars && !values)) return EZPZ_ERR_INVALID_ARGUMENT;
+    const std::vector<double> iv(values, values + n_vars);
+    for (size_t i = 0; i < n_cs; ++i) {
+        EzpzConstraint& c = cs[i];
+        const bool undefined_side = (c.kind == EZPZ_LINE_TANGENT_TO_CIRCLE || c.kind == EZPZ_CIRCLE_TANGENT_TO_CIRCLE) &&
+                                    c.tag == EZPZ_SIDE_UNDEFINED;
+        if (!undefined_side) continue;
+        for (int k = 0; k < kind_num_ids(c.kind); ++k)
+            if (c.ids[k] >= n_vars) return EZPZ_ERR_MISSING_GUESS;
+        set_from_initial_values(c, iv);
+    }
+    return EZPZ_OK;
+}
+
 }  // extern "C"
 
 namespace {

@@ -134,3 +134,20 @@ class Problem:
 
     def to_constraint_system(self) -> ConstraintSystem:
         return self._system
+
+
+def gen_big_problem(total_lines: int, overconstrain: bool = False) -> str:
+    """The synthetic parallel-line problem of BASELINE configs[1] / [3]: the text
+    test_cases/massive_parallel_system/gen_big_problem.py:16-35 prints for `total_lines` (and `true` for the
+    over-constrained variant): per line two points, `vertical`, x of the first fixed to the line number, y fixed to 0
+    and 4 (plus `distance(.., 4)` when over-constrained); guesses p_k roughly (k, k)."""
+    out = ["# constraints"]
+    for line in range(total_lines):
+        a, b = 2 * line, 2 * line + 1
+        out += [f"point p{a}", f"point p{b}", f"vertical(p{a}, p{b})", f"p{a}.x={line}", f"p{a}.y=0", f"p{b}.y=4"]
+        if overconstrain:
+            out.append(f"distance(p{a}, p{b}, 4)")
+    out += ["", "# guesses"]
+    for k in range(2 * total_lines):
+        out.append(f"p{k} roughly ({k},{k})")
+    return "\n".join(out) + "\n"

@@ -252,6 +252,12 @@ int ezpz_solve_batch(const EzpzConstraint* reqs, size_t n_reqs, size_t n_vars, c
                      const EzpzConfig* cfg, double* x_out, EzpzStatus* status, uint32_t* priority_solved,
                      uint8_t* unsat_mask, int32_t* err_constraint, int64_t* err_variable);
 
+/* Constraint::set_from_initial_values (ezpz/src/constraints.rs:146-193) over a request list, in place: every
+ * LineTangentToCircle / CircleTangentToCircle whose side is EZPZ_SIDE_UNDEFINED gets the side the values imply
+ * (values by id, id == index).  ezpz_solve / ezpz_solve_batch do this themselves; callers of the handle API
+ * (ezpz_system_create takes side-resolved tiers) use this first. */
+int ezpz_resolve_sides(EzpzConstraint* cs, size_t n_cs, const double* values, size_t n_vars);
+
 /* ezpz_solve / ezpz_solve_inner keep a small cache of analysed topologies keyed by the request bytes, so that
  * repeated solves of one problem (ezpz-cli's 100-run loop, main.rs:96-98) skip the symbolic phase.  This drops
  * it (used to time cold solves). */
