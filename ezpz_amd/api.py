@@ -613,6 +613,7 @@ def resolve_sides(records, values) -> np.ndarray:
     return recs
 
 
+TEAM_AUTO_LISTS = 0xFFFFFFFE  # `team_size`: automatic, list-walk shapes only (never component-resident)
 TEAM_AUTO_LATENCY = 0xFFFFFFFF  # `team_size`: choose for the latency of one solve instead of batch throughput (ezpz_amd.h)
 
 

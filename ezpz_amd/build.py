@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libezpz_amd.so")
-SOURCES = ["api.hip", "solve.cpp", "program.cpp", "textual.cpp"]
+SOURCES = ["api.hip", "comp.hip", "comp_program.cpp", "solve.cpp", "program.cpp", "textual.cpp"]
 HEADERS = ["program.hpp", "kinds.hpp", "constraint_eval.hip.hpp", "lm_kernel.hip.hpp", "freedom.hip.hpp", "wave_ops.hip.hpp",
            "comp_kernel.hip.hpp", "comp_program.hpp", "system.hpp", "../../include/ezpz_amd.h"]
 # -ffp-contract=off: the reference (Rust) never fuses a*b+c; see constraint_eval.hip.hpp.

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -19,6 +20,7 @@
 #include <vector>
 
 #include "../../include/ezpz_amd.h"
+#include "comp_program.hpp"
 #include "freedom.hip.hpp"
 #include "kinds.hpp"
 #include "lm_kernel.hip.hpp"
@@ -130,6 +132,10 @@ struct EzpzSystem {
     bool prog_in_lds = false;
     bool unit_weights = true;
     bool linear_only = false;  // every constraint is of a linear kind: the evaluators are built without the others
+    // component-resident launch shape (comp_program.hpp): the plan and its device copy; when present, solves run on
+    // comp_solve_kernel and the list-walk program above serves only evaluation / FreedomAnalysis
+    std::unique_ptr<CompPlan> comp;
+    uint32_t* dev_comp = nullptr;
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
     DevBuf<GridScratch> grid_scratch;
@@ -171,6 +177,7 @@ struct EzpzSystem {
     ~EzpzSystem() {
         if (dev_program) (void)hipFree(dev_program);
         if (dev_grid_blob) (void)hipFree(dev_grid_blob);
+        if (dev_comp) (void)hipFree(dev_comp);
     }
 };
 
@@ -378,6 +385,21 @@ int launch_grid_team(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
 
 int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
+    if (s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
+        CompLaunch L{};
+        L.x0 = args.x0;
+        L.x_out = args.x_out;
+        L.status = args.status;
+        L.unsat_mask = args.unsat_mask;
+        L.warn_log = args.warn_log;
+        L.warn_cap = args.warn_cap;
+        L.batch = args.batch;
+        L.max_iterations = args.max_iterations;
+        L.residual_tolerance = args.residual_tolerance;
+        L.step_tolerance = args.step_tolerance;
+        L.initial_lambda = args.initial_lambda;
+        return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
+    }
     uint32_t grid;
     if (s.mode == MODE_SUB) {
         const uint32_t tpb = s.block_threads / s.team_size;
@@ -772,7 +794,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return be.code;
     };
     const bool for_latency = team_size == EZPZ_TEAM_AUTO_LATENCY;
-    if (for_latency) team_size = 0;
+    const bool auto_shape = team_size == 0 || for_latency;
+    if (for_latency || team_size == EZPZ_TEAM_AUTO_LISTS) team_size = 0;
     bool want_sub = team_size ? team_size <= 64 : width <= 64;
     if (want_sub) {
         uint32_t team = team_size ? pow2_ceil(team_size) : auto_sub_team(cs, n_cs);
@@ -971,6 +994,32 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     info.n_partitions = P.c.n_parts;
     info.program_in_lds = s.prog_in_lds ? 1 : 0;
     info.grid_workgroups = s.grid_wgs;
+
+    // ---- component-resident launch shape ------------------------------------------------------------------------------
+    // Systems of many small independent components (>= 128 of them, in a few isomorphism classes, state within the LDS)
+    // run one lane per component instead of walking per-system lists; chosen automatically only (an explicit team size
+    // asks for one of the list-walk shapes; EZPZ_COMP=0 in the environment turns the shape off for A/B runs).
+    s.comp.reset();
+    static const bool comp_enabled = [] {
+        const char* e = std::getenv("EZPZ_COMP");
+        return !(e && e[0] == '0');
+    }();
+    if (auto_shape && comp_enabled) {
+        std::unique_ptr<CompPlan> plan(new CompPlan());
+        CompLimits cl;
+        cl.lds_bytes = s.lim.lds_bytes;
+        if (comp_plan_build(cs, n_cs, n_vars, cl, *plan)) {
+            info.team_mode = 3;
+            info.team_size = plan->n_waves * 64;
+            info.n_partitions = plan->n_chunks;
+            info.workspace_bytes = plan->lds_bytes;
+            info.workspace_in_lds = 1;
+            info.program_in_lds = 0;
+            info.program_bytes += plan->blob.size() * 4;
+            info.grid_workgroups = 1;
+            s.comp = std::move(plan);
+        }
+    }
     return EZPZ_OK;
 }
 
@@ -995,6 +1044,10 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
     HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
     HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
     s->view.base = static_cast<const unsigned char*>(s->dev_program);
+    if (s->comp) {
+        HIP_TRY(hipMalloc((void**)&s->dev_comp, s->comp->blob.size() * 4));
+        HIP_TRY(hipMemcpy(s->dev_comp, s->comp->blob.data(), s->comp->blob.size() * 4, hipMemcpyHostToDevice));
+    }
     *out = s.release();
     return EZPZ_OK;
 }

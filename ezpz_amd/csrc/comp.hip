@@ -1,0 +1,66 @@
+// Launch of the component-resident LM kernel (comp_kernel.hip.hpp) -- its own translation unit so that the two kernel
+// builds compile beside the list-walk kernels of api.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+
+#include "comp_kernel.hip.hpp"
+
+namespace ezpz {
+
+namespace {
+
+template <bool LIN>
+int launch_build(const CompPlan& plan, const CompArgs& args, int device, int cus, size_t lds_limit, hipStream_t stream) {
+    auto kernel = comp_solve_kernel<LIN>;
+    static std::atomic<bool> raised[16];  // per kernel build and device (see launch_kernel in api.hip)
+    if (plan.lds_bytes > 48 * 1024 && !raised[device & 15].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_limit) != hipSuccess) {
+            (void)hipGetLastError();
+            return EZPZ_ERR_HIP;
+        }
+        raised[device & 15].store(true, std::memory_order_release);
+    }
+    const uint32_t threads = plan.n_waves * 64;
+    // persistent workgroups: as many as the device holds at once (LDS and the 2048 lanes of a CU), each walks the batch
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(lds_limit / std::max<uint32_t>(plan.lds_bytes, 1), 2048 / threads));  // (a CU holds 2048 lanes)
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)cus * per_cu);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), plan.lds_bytes, stream, args);
+    if (hipGetLastError() != hipSuccess) return EZPZ_ERR_HIP;
+    return EZPZ_OK;
+}
+
+}  // namespace
+
+int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& L, int device, int cus, size_t lds_limit,
+                void* stream) {
+    if (L.batch == 0) return EZPZ_OK;
+    CompArgs a{};
+    a.prog = dev_blob;
+    a.o_waves = plan.o_waves;
+    a.o_chunks = plan.o_chunks;
+    a.n_row = plan.n_vars;
+    a.n_cons = plan.n_cons;
+    a.n_rows_total = plan.n_rows;
+    a.x0 = L.x0;
+    a.x_out = L.x_out;
+    a.status = L.status;
+    a.unsat_mask = L.unsat_mask;
+    a.warn_log = L.warn_cap ? L.warn_log : nullptr;
+    a.warn_cap = L.warn_cap;
+    a.batch = L.batch;
+    a.max_iterations = L.max_iterations;
+    a.unit_weights = plan.unit_weights ? 1u : 0u;
+    a.residual_tolerance = L.residual_tolerance;
+    a.step_tolerance = L.step_tolerance;
+    a.initial_lambda = L.initial_lambda;
+    a.scratch_row0 = plan.rows_persistent;
+    a.scratch_rows = plan.scratch_rows;
+    a.red_row0 = plan.rows_persistent + plan.n_waves * plan.scratch_rows;
+    return plan.linear ? launch_build<true>(plan, a, device, cus, lds_limit, static_cast<hipStream_t>(stream))
+                       : launch_build<false>(plan, a, device, cus, lds_limit, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace ezpz

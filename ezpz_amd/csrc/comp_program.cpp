@@ -1,0 +1,467 @@
+// Component plan (see comp_program.hpp).  Plain C++17, no device code.
+#include "comp_program.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "kinds.hpp"
+#include "program.hpp"
+
+namespace ezpz {
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+// What is worth a component plan, and what its 16-bit fields hold.
+constexpr size_t kMinInstances = 128;     // fewer components than two wavefronts' lanes: the other launch shapes serve
+constexpr size_t kMaxClasses = 32;
+constexpr size_t kMaxClassVars = 24, kMaxClassCons = 48;  // (the warning mask of a chunk is one 64-bit word per lane)
+
+struct Component {
+    std::vector<uint32_t> verts;  // caller's variable ids, ascending
+    std::vector<uint32_t> cons;   // caller's constraint positions, ascending
+};
+
+struct ClassLayout {  // what every chunk of a class shares (copied into its CompChunk)
+    uint32_t nv = 0, m = 0, zj = 0, ncons = 0, n_ops = 0, ops_off = 0, cons_off = 0;
+    uint32_t rows_p = 0, o_d = 0, o_r0 = 0, o_r1 = 0, o_j = 0, o_wm = 0, s_l = 0;
+    uint32_t ninst_pad = 0, ids_off = 0, par_off = 0, pos_off = 0;
+};
+
+struct Class {
+    ClassLayout H;
+    uint32_t rep = 0;                 // representative component
+    std::vector<uint32_t> instances;  // components of this class, in order of their first variable
+    Program Q;                        // symbolic phase of the representative, class-internal numbering
+    bool linear = true;
+    bool consts_f32 = true;
+    std::vector<double> jconst;       // linear classes: the (constant) Jacobian value of every slot
+    uint32_t cost = 1;
+};
+
+// Partial derivatives of the nine linear kinds in emission order (constraint_eval.hip.hpp con_jacobian; reference
+// ezpz/src/constraints.rs:1252-1357,:1456-1512,:1599-1642).
+int linear_partials(uint32_t kind, double pd[8]) {
+    switch (kind) {
+    case EZPZ_VERTICAL_DISTANCE:
+    case EZPZ_HORIZONTAL_DISTANCE:
+    case EZPZ_VERTICAL:
+    case EZPZ_HORIZONTAL:
+    case EZPZ_SCALAR_EQUAL:
+        pd[0] = 1.0, pd[1] = -1.0;
+        return 2;
+    case EZPZ_FIXED:
+    case EZPZ_CIRCLE_RADIUS:
+        pd[0] = 1.0;
+        return 1;
+    case EZPZ_POINTS_COINCIDENT:
+        pd[0] = 1.0, pd[1] = -1.0, pd[2] = 1.0, pd[3] = -1.0;
+        return 4;
+    case EZPZ_MIDPOINT:
+        pd[0] = 1.0, pd[1] = -0.5, pd[2] = -0.5, pd[3] = 1.0, pd[4] = -0.5, pd[5] = -0.5;
+        return 6;
+    default:
+        return 0;
+    }
+}
+
+bool f32_exact(double v) { return (double)(float)v == v; }
+
+uint32_t f32_bits(double v) {
+    const float f = (float)v;
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+void push_double(std::vector<uint32_t>& w, double v) {
+    uint64_t u;
+    std::memcpy(&u, &v, 8);
+    w.push_back((uint32_t)u);
+    w.push_back((uint32_t)(u >> 32));
+}
+
+void align4(std::vector<uint32_t>& w) {
+    while (w.size() % 4) w.push_back(0);
+}
+
+// One operation = one or more 8-word records.  `items` holds `words_per_item` words per item; `head` (0 or 2 words) goes
+// into w2:w3 of the first record (the linear build's constants), shrinking that build's item room to w4..w7.
+void emit_op(std::vector<uint32_t>& out, uint32_t opcode, uint32_t a, uint32_t b, const std::vector<uint32_t>& items,
+             uint32_t words_per_item, uint32_t items_per_rec, uint32_t item_word0, const uint32_t* head) {
+    const size_t n = items.size() / words_per_item;
+    size_t done = 0;
+    bool first = true;
+    do {
+        const size_t take = std::min<size_t>(items_per_rec, n - done);
+        const bool last = done + take == n;
+        uint32_t rec[kCompRecWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+        rec[0] = opcode | ((uint32_t)take << 8) | (first ? kCompFirst : 0u) | (last ? kCompLast : 0u);
+        rec[1] = a | (b << 16);
+        if (head) rec[2] = head[0], rec[3] = head[1];
+        for (size_t k = 0; k < take * words_per_item; ++k) rec[item_word0 + k] = items[done * words_per_item + k];
+        out.insert(out.end(), rec, rec + kCompRecWords);
+        done += take;
+        first = false;
+    } while (done < n);
+}
+
+}  // namespace
+
+// EZPZ_COMP_DEBUG=1 in the environment: say on stderr why a system did not get a component plan.
+#define COMP_REJECT(...)                                                            \
+    do {                                                                            \
+        static const bool dbg_ = std::getenv("EZPZ_COMP_DEBUG") != nullptr;        \
+        if (dbg_) std::fprintf(stderr, "[ezpz comp] no plan: " __VA_ARGS__), std::fputc('\n', stderr); \
+        return false;                                                               \
+    } while (0)
+
+bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const CompLimits& lim, CompPlan& plan) {
+    plan = CompPlan();
+    if (n_cs == 0 || n_vars < kMinInstances || n_cs > 0x3FFFFFFFu || n_vars > 0x3FFFFFFFu) return false;
+    const uint32_t n = (uint32_t)n_vars, C = (uint32_t)n_cs;
+
+    // ---- connected components: every variable of every row of a constraint belongs to one component ---------------------
+    std::vector<uint32_t> parent(n);
+    std::iota(parent.begin(), parent.end(), 0u);
+    auto find = [&](uint32_t a) {
+        while (parent[a] != a) a = parent[a] = parent[parent[a]];
+        return a;
+    };
+    uint64_t m_total = 0;
+    for (uint32_t i = 0; i < C; ++i) {
+        if (cs[i].kind >= EZPZ_NUM_KINDS) return false;
+        const KindInfo& K = kKinds[cs[i].kind];
+        uint32_t first = NONE;
+        for (int r = 0; r < K.n_rows; ++r)
+            for (int e = 0; e < K.n_nz[r]; ++e) {
+                const uint32_t v = cs[i].ids[K.nz[r][e]];
+                if (v >= n) return false;  // MissingGuess: reported by the ordinary symbolic phase
+                if (first == NONE)
+                    first = v;
+                else {
+                    const uint32_t ra = find(v), rb = find(first);
+                    if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+                }
+            }
+        m_total += K.n_rows;
+    }
+    std::vector<uint32_t> comp_of(n, NONE);
+    std::vector<Component> comps;
+    for (uint32_t v = 0; v < n; ++v) {  // roots are the smallest member: components come out in order of first variable
+        const uint32_t r = find(v);
+        if (comp_of[r] == NONE) {
+            comp_of[r] = (uint32_t)comps.size();
+            comps.emplace_back();
+        }
+        comp_of[v] = comp_of[r];
+        comps[comp_of[v]].verts.push_back(v);
+    }
+    if (comps.size() < kMinInstances) COMP_REJECT("%zu components", comps.size());
+    for (uint32_t i = 0; i < C; ++i) comps[comp_of[cs[i].ids[kKinds[cs[i].kind].nz[0][0]]]].cons.push_back(i);
+    for (const Component& c : comps)
+        if (c.verts.size() > kMaxClassVars || c.cons.size() > kMaxClassCons)
+            COMP_REJECT("a component of %zu variables, %zu constraints", c.verts.size(), c.cons.size());
+
+    // ---- classes: components with the same kinds, tags, weights and local variable pattern ---------------------------------
+    plan.unit_weights = true;
+    for (uint32_t i = 0; i < C; ++i)
+        if (cs[i].weight != 1.0) plan.unit_weights = false;
+    std::map<std::vector<uint32_t>, uint32_t> class_of_sig;
+    std::vector<Class> classes;
+    std::vector<uint32_t> sig;
+    auto local_con = [&](const Component& comp, uint32_t ci, EzpzConstraint& out) {
+        out = cs[ci];
+        const KindInfo& K = kKinds[out.kind];
+        bool used[8] = {false, false, false, false, false, false, false, false};
+        for (int r = 0; r < K.n_rows; ++r)
+            for (int e = 0; e < K.n_nz[r]; ++e) used[K.nz[r][e]] = true;
+        for (int k = 0; k < 8; ++k) {
+            if (k < K.n_ids && used[k])
+                out.ids[k] = (uint32_t)(std::lower_bound(comp.verts.begin(), comp.verts.end(), out.ids[k]) - comp.verts.begin());
+            else
+                out.ids[k] = 0;  // ids a kind never dereferences
+        }
+        out.priority = 0;
+        out.flags = 0;
+    };
+    for (uint32_t ic = 0; ic < comps.size(); ++ic) {
+        const Component& comp = comps[ic];
+        sig.clear();
+        sig.push_back((uint32_t)comp.verts.size());
+        sig.push_back((uint32_t)comp.cons.size());
+        for (uint32_t ci : comp.cons) {
+            EzpzConstraint lc;
+            local_con(comp, ci, lc);
+            uint64_t wbits;
+            std::memcpy(&wbits, &lc.weight, 8);
+            sig.push_back(lc.kind | ((uint32_t)lc.tag << 16));
+            sig.push_back((uint32_t)wbits);
+            sig.push_back((uint32_t)(wbits >> 32));
+            for (int k = 0; k < 8; ++k) sig.push_back(lc.ids[k]);
+        }
+        auto it = class_of_sig.find(sig);
+        if (it == class_of_sig.end()) {
+            if (classes.size() >= kMaxClasses) COMP_REJECT("more than %zu classes", kMaxClasses);
+            it = class_of_sig.emplace(sig, (uint32_t)classes.size()).first;
+            classes.emplace_back();
+            classes.back().rep = ic;
+        }
+        classes[it->second].instances.push_back(ic);
+    }
+
+    // ---- per class: the symbolic phase of the representative, then its records -----------------------------------------------
+    bool all_linear = true;
+    for (Class& cl : classes) {
+        const Component& rep = comps[cl.rep];
+        std::vector<EzpzConstraint> local(rep.cons.size());
+        for (size_t k = 0; k < rep.cons.size(); ++k) local_con(rep, rep.cons[k], local[k]);
+        BuildError be;
+        if (!build_program(local.data(), local.size(), rep.verts.size(), cl.Q, be, 1, false)) return false;
+        const Program& Q = cl.Q;
+        if (Q.c.n_parts != 1 || Q.c.zj >= 0xFFFF || Q.c.zlo >= 0xFFFF || Q.c.n_rows >= 0xFFFF) return false;
+        for (const DevCon& d : Q.cons) cl.linear = cl.linear && kind_is_linear(d.kind);
+        if (cl.linear) {  // constant Jacobian: slot values exactly as con_jacobian's writer stores them
+            cl.jconst.assign(Q.c.zj, 0.0);
+            for (const DevCon& d : Q.cons) {
+                double pd[8];
+                const int np = linear_partials(d.kind, pd);
+                for (int e = 0; e < np; ++e) {
+                    const uint32_t code = d.jloc[e];
+                    const uint32_t slot = d.jbase + (code & 0x7Fu);
+                    const double w = d.weight * pd[e];
+                    if (code & 0x80u)
+                        cl.jconst[slot] = cl.jconst[slot] + w;
+                    else
+                        cl.jconst[slot] = w;
+                }
+            }
+            for (double v : cl.jconst) cl.consts_f32 = cl.consts_f32 && f32_exact(v);
+        }
+        all_linear = all_linear && cl.linear && cl.consts_f32;
+        uint32_t cost = 8;
+        for (const DevCon& d : Q.cons) cost += kind_is_linear(d.kind) ? 12 : 60;
+        cost += 40 * Q.c.n_vars + 14 * Q.c.zlo + 4 * (uint32_t)(Q.colj_items.size() / 2 + Q.apairs.size() / 2 + Q.lpairs.size() / 2 +
+                                                                Q.fwd_items.size() / 2 + Q.bwd_items.size() / 2);
+        cl.cost = cost;
+    }
+    plan.linear = all_linear;
+    const bool LIN = plan.linear;
+
+    std::vector<uint32_t>& blob = plan.blob;
+    blob.clear();
+    uint32_t scratch_rows = 1;
+    for (size_t k = 0; k < classes.size(); ++k) {
+        Class& cl = classes[k];
+        const Program& Q = cl.Q;
+        const uint32_t nv = Q.c.n_vars, m = Q.c.n_rows, zj = Q.c.zj, zlo = Q.c.zlo, ncons = Q.c.n_cons;
+        ClassLayout& H = cl.H;
+        H.nv = nv, H.m = m, H.zj = zj, H.ncons = ncons;
+        H.o_d = nv;
+        H.o_r0 = 2 * nv;
+        H.o_r1 = 2 * nv + m;
+        H.o_j = 2 * nv + 2 * m;
+        H.o_wm = H.o_j + (LIN ? 0 : zj);
+        H.rows_p = H.o_wm + (LIN ? 0 : 1);
+        H.s_l = nv;
+        scratch_rows = std::max(scratch_rows, nv + zlo);
+        const uint32_t ninst = (uint32_t)cl.instances.size();
+        H.ninst_pad = (ninst + 63) & ~63u;
+
+        // ---- operation stream of the linear solve, in execution order ----
+        std::vector<uint32_t> ops, items;
+        for (uint32_t v = 0; v < nv; ++v) {
+            items.clear();
+            if (LIN) {
+                double acc = 0.0;
+                for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
+                    const double jv = cl.jconst[Q.colj_items[2 * q]];
+                    acc += jv * jv;
+                    items.push_back(Q.colj_items[2 * q + 1]);
+                    items.push_back(f32_bits(jv));
+                }
+                std::vector<uint32_t> head;
+                push_double(head, acc);
+                emit_op(ops, COMP_DIAG, v, 0, items, 2, kCompItemsLin, 4, head.data());
+            } else {
+                for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q)
+                    items.push_back(Q.colj_items[2 * q] | (Q.colj_items[2 * q + 1] << 16));
+                emit_op(ops, COMP_DIAG, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+            }
+        }
+        for (uint32_t s = 0; s < zlo; ++s) {
+            items.clear();
+            if (LIN) {
+                double acc = 0.0;
+                for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
+                    acc += cl.jconst[Q.apairs[2 * q]] * cl.jconst[Q.apairs[2 * q + 1]];
+                std::vector<uint32_t> head;
+                push_double(head, acc);
+                emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 4, head.data());
+            } else {
+                for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
+                    items.push_back(Q.apairs[2 * q] | (Q.apairs[2 * q + 1] << 16));
+                emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 2, nullptr);
+            }
+        }
+        const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
+        for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+            const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
+            for (uint32_t v = c0; v < c1; ++v) {
+                items.clear();
+                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
+                    items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
+                emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+            }
+            for (uint32_t s = s0; s < s1; ++s) {
+                items.clear();
+                for (uint32_t q = Q.lpair_ptr[s]; q < Q.lpair_ptr[s + 1]; ++q)
+                    items.push_back(Q.lpairs[2 * q] | (Q.lpairs[2 * q + 1] << 16));
+                emit_op(ops, COMP_SLOT, s, Q.l_col[s], items, 1, kCompItemsGen, 2, nullptr);
+            }
+        }
+        for (uint32_t lv = part.nlev; lv-- > 0;) {
+            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+            for (uint32_t v = c0; v < c1; ++v) {
+                items.clear();
+                for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
+                    items.push_back(Q.bwd_items[2 * q] | (Q.bwd_items[2 * q + 1] << 16));
+                emit_op(ops, COMP_BWD, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+            }
+        }
+        H.n_ops = (uint32_t)(ops.size() / kCompRecWords);
+
+        // ---- lay the class out in the blob: operation stream (+ one pad record), constraint records, tables ----
+        align4(blob);
+        H.ops_off = (uint32_t)blob.size();
+        blob.insert(blob.end(), ops.begin(), ops.end());
+        blob.resize(blob.size() + kCompRecWords, 0);  // the interpreter reads one record ahead
+        H.cons_off = (uint32_t)blob.size();
+        for (uint32_t ci = 0; ci < ncons; ++ci) {
+            const DevCon& d = Q.cons[ci];
+            uint32_t rec[kCompConWords] = {};
+            rec[0] = d.kind | ((uint32_t)d.tag << 8) | ((uint32_t)d.nrows << 16) | ((uint32_t)d.nslots << 24);
+            rec[1] = d.row0 | (d.jbase << 16);
+            for (int e = 0; e < 4; ++e) rec[2 + e] = d.ids[2 * e] | (d.ids[2 * e + 1] << 16);
+            std::memcpy(&rec[6], d.jloc, 16);
+            std::memcpy(&rec[10], &d.weight, 8);
+            rec[12] = ci;
+            blob.insert(blob.end(), rec, rec + kCompConWords);
+        }
+        blob.resize(blob.size() + kCompConWords, 0);  // read-ahead pad
+        align4(blob);
+        H.ids_off = (uint32_t)blob.size();
+        blob.resize(blob.size() + (size_t)nv * H.ninst_pad, 0);
+        for (uint32_t kv = 0; kv < nv; ++kv)
+            for (uint32_t i = 0; i < ninst; ++i)
+                blob[H.ids_off + (size_t)kv * H.ninst_pad + i] = comps[cl.instances[i]].verts[Q.var_of[kv]];
+        align4(blob);
+        H.par_off = (uint32_t)blob.size();
+        blob.resize(blob.size() + (size_t)2 * ncons * H.ninst_pad, 0);
+        for (uint32_t ci = 0; ci < ncons; ++ci)
+            for (uint32_t i = 0; i < ninst; ++i) {
+                const double p = cs[comps[cl.instances[i]].cons[Q.cons[ci].pos]].param;
+                std::memcpy(&blob[H.par_off + 2 * ((size_t)ci * H.ninst_pad + i)], &p, 8);
+            }
+        align4(blob);
+        H.pos_off = (uint32_t)blob.size();
+        blob.resize(blob.size() + (size_t)ncons * H.ninst_pad, 0);
+        for (uint32_t ci = 0; ci < ncons; ++ci)
+            for (uint32_t i = 0; i < ninst; ++i)
+                blob[H.pos_off + (size_t)ci * H.ninst_pad + i] = comps[cl.instances[i]].cons[Q.cons[ci].pos];
+        if (blob.size() > (64u << 20)) return false;
+
+        plan.zj += (uint64_t)zj * ninst;
+        plan.za += (uint64_t)Q.c.za * ninst;
+        plan.zl += (uint64_t)(zlo + nv) * ninst;
+        plan.max_levels = std::max(plan.max_levels, Q.c.n_levels);
+    }
+
+    // ---- chunks of <= 64 instances, dealt to the wavefronts (longest processing time first) --------------------------------------
+    struct ChunkTmp {
+        uint32_t cls, inst0, count, cost, rows;
+    };
+    std::vector<ChunkTmp> chunks;
+    for (size_t k = 0; k < classes.size(); ++k) {
+        const uint32_t ninst = (uint32_t)classes[k].instances.size();
+        for (uint32_t i0 = 0; i0 < ninst; i0 += 64)
+            chunks.push_back(ChunkTmp{(uint32_t)k, i0, std::min<uint32_t>(64, ninst - i0), classes[k].cost, classes[k].H.rows_p});
+    }
+    uint64_t rows_persistent = 0;
+    for (const ChunkTmp& c : chunks) rows_persistent += c.rows;
+    // Wavefronts per workgroup (= per system): more of them shorten a solve, but every one pays the reductions of
+    // the LM control, and a CU holds 160 KiB of LDS: take the count that puts the most wavefronts on a CU (several
+    // workgroups side by side when the state allows it), the smaller workgroup on a tie.
+    const uint32_t max_waves = LIN ? lim.max_waves_linear : lim.max_waves_general;
+    const size_t fixed_bytes = 3 * 4 * 16 * 8 + 64;  // reduction scratch + flags + warning counters
+    auto bytes_for = [&](uint32_t w) { return (rows_persistent + (uint64_t)w * scratch_rows) * 512 + fixed_bytes; };
+    uint32_t W = 0;
+    uint64_t best_waves = 0;
+    for (uint32_t w = 1; w <= max_waves; w <<= 1) {
+        if (w > chunks.size() && w > 1) break;
+        const uint64_t bytes = bytes_for(w);
+        if (bytes > lim.lds_bytes) continue;
+        const uint64_t per_cu = std::min<uint64_t>(lim.lds_bytes / bytes, 32 / w);
+        const uint64_t waves = std::min<uint64_t>(per_cu * w, 16);  // beyond 4 per SIMD nothing is gained
+        if (waves > best_waves) best_waves = waves, W = w;
+    }
+    if (W == 0)
+        COMP_REJECT("%llu rows of state + %u scratch rows do not fit the LDS", (unsigned long long)rows_persistent, scratch_rows);
+    std::vector<uint32_t> order(chunks.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return chunks[a].cost > chunks[b].cost; });
+    std::vector<uint64_t> load(W, 0);
+    std::vector<std::vector<uint32_t>> of_wave(W);
+    for (uint32_t c : order) {
+        const uint32_t w = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[w] += chunks[c].cost;
+        of_wave[w].push_back(c);
+    }
+    align4(blob);
+    plan.o_waves = (uint32_t)blob.size();
+    blob.resize(blob.size() + W + 1, 0);
+    while (blob.size() % 32) blob.push_back(0);
+    plan.o_chunks = (uint32_t)blob.size();
+    uint32_t row = 0, nch = 0;
+    for (uint32_t w = 0; w < W; ++w) {
+        std::sort(of_wave[w].begin(), of_wave[w].end());  // class-major, instances ascending
+        blob[plan.o_waves + w] = nch;
+        for (uint32_t c : of_wave[w]) {
+            const ClassLayout& H = classes[chunks[c].cls].H;
+            CompChunk ch{};
+            ch.count = chunks[c].count;
+            ch.nv = H.nv, ch.m = H.m, ch.ncons = H.ncons;
+            ch.n_ops = H.n_ops, ch.ops_off = H.ops_off, ch.cons_off = H.cons_off;
+            ch.row0 = row;
+            ch.o_d = H.o_d, ch.o_r0 = H.o_r0, ch.o_r1 = H.o_r1, ch.o_j = H.o_j, ch.o_wm = H.o_wm, ch.s_l = H.s_l;
+            ch.stride = H.ninst_pad;
+            ch.ids_off = H.ids_off + chunks[c].inst0;
+            ch.par_off = H.par_off + 2 * chunks[c].inst0;
+            ch.pos_off = H.pos_off + chunks[c].inst0;
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&ch);
+            blob.insert(blob.end(), p, p + sizeof(CompChunk) / 4);
+            row += chunks[c].rows;
+            ++nch;
+        }
+    }
+    blob[plan.o_waves + W] = nch;
+    blob.resize(blob.size() + 16, 0);
+    plan.n_waves = W;
+    plan.n_chunks = nch;
+    plan.n_classes = (uint32_t)classes.size();
+    plan.n_instances = (uint32_t)comps.size();
+    plan.rows_persistent = (uint32_t)rows_persistent;
+    plan.scratch_rows = scratch_rows;
+    plan.lds_bytes = (uint32_t)bytes_for(W);
+    plan.n_vars = n;
+    plan.n_cons = C;
+    plan.n_rows = (uint32_t)m_total;
+    return true;
+}
+
+}  // namespace ezpz

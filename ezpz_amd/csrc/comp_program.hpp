@@ -1,0 +1,109 @@
+// Component-resident solve: the host side.
+//
+// A constraint system made of many small independent pieces -- the 2000 x 2000 massive_parallel_system is 1500 of them
+// (500 x {Vertical, Fixed} on two variables, 1000 x {Fixed} on one) -- needs no per-system index lists at all: its
+// connected components fall into a handful of isomorphism CLASSES (same kinds, tags, weights and local variable
+// pattern; only the caller's variable ids and the constraint parameters differ).  The component plan therefore holds
+//   * one tiny program per class: its constraint records and the straight-line operation stream of its linear solve
+//     (normal equations, Cholesky, substitutions), derived from the ordinary symbolic phase (build_program) run on
+//     one representative component -- same elimination order, same operation order as the list-walk kernels;
+//   * per class, structure-of-arrays tables over its instances: caller's variable ids, constraint parameters,
+//     caller's constraint positions;
+//   * chunks of up to 64 instances of one class (one per lane of a wavefront) dealt to the wavefronts of a workgroup.
+// The kernel (comp_kernel.hip.hpp) runs one lane per component instance; every wavefront executes one class program
+// at a time, so the program is read through the scalar unit and all control flow is uniform.
+// Replaces, for such systems, the same reference code as lm_kernel.hip.hpp (ezpz/src/solver/newton.rs:29-145,
+// solver.rs:192-440).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/ezpz_amd.h"
+
+namespace ezpz {
+
+// Operation stream of a class: records of 8 words.
+//   w0 = opcode | n_items << 8 | flags << 16     (flags: 1 = first record of the operation, 2 = last)
+//   w1 = a | b << 16                              (operands, rows of the chunk's state)
+//   w2.. items
+// General build (Jacobian values in LDS): one word per item, two 16-bit row numbers; up to 6 items per record.
+// (b, y and the step d share the rows at o_d; the diagonal and, once it is dead, the tentative x share scratch row 0..)
+//   DIAG  a = variable v          items (Jacobian slot, residual row):  A_vv = sum j^2 + lambda, b_v = sum j * -r
+//   OFF   a = L slot s            items (slot, slot):                   A_s = sum j_a * j_b
+//   COL   a = variable v          items (L slot of (v,k), variable k):  d_v = sqrt(A_vv - sum l^2), y_v = (b_v - sum l y_k) / d_v
+//   SLOT  a = L slot s, b = col j items (L slot (i,k), L slot (j,k)):   l_s = (A_s - sum l l) / d_j
+//   BWD   a = variable v          items (L slot of (i,v), variable i):  dx_v = (y_v - sum l dx_i) / d_v
+// Linear build (every kind linear, Jacobian entries are class constants): DIAG carries sum j^2 in w2:w3 and up to two
+// items (row, j as f32) in w4..w7; OFF carries its constant in w2:w3.
+enum CompOpcode : uint32_t { COMP_DIAG = 1, COMP_OFF = 2, COMP_COL = 3, COMP_SLOT = 4, COMP_BWD = 5 };
+constexpr uint32_t kCompRecWords = 8;
+constexpr uint32_t kCompItemsGen = 6, kCompItemsLin = 2;
+constexpr uint32_t kCompFirst = 1u << 16, kCompLast = 2u << 16;
+
+// Constraint record of a class: 16 words.
+//   w0 kind | tag << 8 | nrows << 16 | nslots << 24      w1 row0 | jbase << 16
+//   w2..w5 ids[8] (16-bit, class-internal variable numbers)   w6..w9 jloc[16]   w10:w11 weight   w12 index in the class
+constexpr uint32_t kCompConWords = 16;
+
+// Chunk descriptor: one wavefront's worth of instances (<= 64, one per lane) of one class, with everything the
+// kernel needs to run the class program on them.  32 words, read through the scalar unit once per pass.
+struct CompChunk {
+    uint32_t count;                 // lanes in use
+    uint32_t nv, m, ncons;          // variables, residual rows, constraints of the class
+    uint32_t n_ops, ops_off;        // operation stream (records, word offset into the blob)
+    uint32_t cons_off;              // constraint records (word offset)
+    uint32_t row0;                  // first LDS row (of 64 doubles) of the chunk's persistent state: x at 0,
+    uint32_t o_d, o_r0, o_r1, o_j, o_wm;  // ... step d (b -> y -> d during a solve), residuals (two copies), Jacobian, warning mask
+    uint32_t s_l;                   // the wavefront's scratch rows: diagonal (later the tentative x) at 0, L here
+    uint32_t stride;                // instances of the class, padded to a multiple of 64: row stride of its tables
+    uint32_t ids_off;               // u32 [nv][stride]     caller's variable id      (word offsets, first instance
+    uint32_t par_off;               // f64 [ncons][stride]  constraint parameter       of the chunk folded in)
+    uint32_t pos_off;               // u32 [ncons][stride]  caller's constraint position
+    uint32_t pad[14];
+};
+static_assert(sizeof(CompChunk) == 32 * 4, "CompChunk layout");
+
+struct CompPlan {
+    std::vector<uint32_t> blob;   // everything the kernel reads, as 32-bit words
+    uint32_t o_waves = 0;         // [n_waves + 1] first chunk of every wavefront
+    uint32_t o_chunks = 0;        // CompChunk[n_chunks], wavefront-major
+    uint32_t n_waves = 0, n_chunks = 0, n_classes = 0, n_instances = 0;
+    bool linear = false;          // every class linear with f32-exact Jacobian constants: the linear build of the kernel
+    bool unit_weights = true;
+    uint32_t rows_persistent = 0, scratch_rows = 0;  // LDS rows: all chunks' state; per wavefront scratch
+    uint32_t lds_bytes = 0;
+    uint32_t n_vars = 0, n_cons = 0, n_rows = 0;
+    uint32_t max_levels = 0;
+    uint64_t zj = 0, za = 0, zl = 0;  // totals over all components (EzpzSystemInfo)
+};
+
+struct CompLimits {
+    size_t lds_bytes = 160 * 1024;
+    uint32_t max_waves_linear = 8, max_waves_general = 8;
+};
+
+// True when the system is worth running component-resident (many small components in few classes, state fits the
+// LDS); `plan` is then complete.  False leaves the caller with its other launch shapes.  Request errors (bad ids ...)
+// are not diagnosed here: the caller has validated the request.
+bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const CompLimits& lim, CompPlan& plan);
+
+}  // namespace ezpz
+
+namespace ezpz {
+
+// One batch launch of the component-resident kernel (comp.hip).  Device pointers; `stream` is a hipStream_t.
+struct CompLaunch {
+    const double* x0;
+    double* x_out;
+    EzpzStatus* status;
+    uint8_t* unsat_mask;
+    uint64_t* warn_log;
+    uint32_t warn_cap;
+    uint64_t batch;
+    uint32_t max_iterations;
+    double residual_tolerance, step_tolerance, initial_lambda;
+};
+int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus,
+                size_t lds_limit, void* stream);
+
+}  // namespace ezpz

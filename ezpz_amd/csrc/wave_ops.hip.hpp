@@ -1,0 +1,66 @@
+// Wavefront-level building blocks shared by the LM kernels (lm_kernel.hip.hpp, comp_kernel.hip.hpp): the LM damping
+// constants, the two reduction operators of the LM control (sum of squares, NaN-ignoring maximum) and cross-lane
+// reductions on DPP moves (no LDS crossbar traffic) for gfx950's 64-wide wavefronts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ezpz {
+namespace dev {
+
+constexpr double LM_LAMBDA_INCR = 10.0;  // newton.rs:15
+constexpr double LM_LAMBDA_DECR = 0.1;   // newton.rs:16
+
+struct OpSum {
+    __device__ __forceinline__ double operator()(double a, double b) const { return a + b; }
+    __device__ __forceinline__ double identity() const { return 0.0; }
+};
+struct OpMax {  // libm::fmax (NaN-ignoring), newton.rs:53,:108
+    __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); }
+    __device__ __forceinline__ double identity() const { return __builtin_nan(""); }  // dropped by fmax
+};
+
+// Cross-lane moves inside a row of 16 lanes without touching the LDS crossbar (DPP modifiers on v_mov):
+// quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror.  After the four steps every lane of a row holds
+// the row's reduction (the two mirror steps work because all lanes of a quad / half-row already agree).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    // bound_ctrl: every lane of these permutations has a valid source, and with it the compiler need not
+    // materialise the `old` operand (one v_mov less per 32-bit half)
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int WIDTH, class Op>
+__device__ __forceinline__ double reduce_lanes(double v, Op op) {
+    if constexpr (WIDTH >= 2) v = op(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
+    if constexpr (WIDTH >= 4) v = op(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]
+    if constexpr (WIDTH >= 8) v = op(v, dpp_move<0x141>(v));  // row_half_mirror
+    if constexpr (WIDTH >= 16) v = op(v, dpp_move<0x140>(v)); // row_mirror
+    if constexpr (WIDTH >= 32) v = op(v, __shfl_xor(v, 16, 64));
+    if constexpr (WIDTH >= 64) v = op(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// Reduction of a whole wavefront into its LAST lane without the LDS crossbar: rows of 16 as above, then the two
+// wave-level DPP broadcasts of GFX9 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lanes the
+// row mask leaves out keep the operator's identity, so one unconditional op() per step serves every lane.  Same
+// pairing as the xor shuffles ((r0 + r1) + (r2 + r3)), so the same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_rows(double v, double keep) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned long long o = __builtin_bit_cast(unsigned long long, keep);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <class Op>
+__device__ __forceinline__ double reduce_wave_to_last_lane(double v, Op op) {
+    v = reduce_lanes<16>(v, op);
+    v = op(v, dpp_move_rows<0x142, 0xA>(v, op.identity()));  // row_bcast:15
+    v = op(v, dpp_move_rows<0x143, 0xC>(v, op.identity()));  // row_bcast:31
+    return v;
+}
+
+}  // namespace dev
+}  // namespace ezpz

@@ -148,7 +148,9 @@ typedef struct EzpzSystemInfo {
     uint64_t workspace_bytes; /* per-system LDS / global workspace */
     uint32_t team_size;     /* lanes cooperating on one system */
     uint32_t workspace_in_lds;
-    uint32_t team_mode;     /* 0 sub-wavefront teams, 1 wavefront-partitioned workgroup, 2 barrier workgroup */
+    uint32_t team_mode;     /* 0 sub-wavefront teams, 1 wavefront-partitioned workgroup, 2 barrier workgroup,
+                             * 3 component-resident (one lane per connected component; n_partitions = chunks of <= 64
+                             * components of one isomorphism class) */
     uint32_t n_partitions;  /* partitions (balanced unions of components), one per wavefront in mode 1 */
     uint32_t program_in_lds;
     uint32_t grid_workgroups; /* workgroups that share one system (grid team: one large system on many CUs), else 1 */
@@ -172,6 +174,8 @@ const char* ezpz_error_string(int err);
  * a connected sketch of a few hundred variables then runs on a 256-512 lane workgroup with its lists staged in LDS
  * instead of one wavefront / a lean 128-lane workgroup: ~35 % sooner per solve at less than half the batch rate). */
 #define EZPZ_TEAM_AUTO_LATENCY 0xFFFFFFFFu
+/* automatic choice among the list-walk shapes only (team_mode 0-2): never the component-resident shape (A/B runs) */
+#define EZPZ_TEAM_AUTO_LISTS 0xFFFFFFFEu
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);
 void ezpz_system_destroy(EzpzSystem* sys);

@@ -1,0 +1,209 @@
+"""GPU parity tests (-m gpu) of the component-resident launch shape (comp_kernel.hip.hpp: one lane per connected
+component, class programs read through the scalar unit), through the C ABI, against the CPU oracle and against the
+list-walk kernels.  Same tolerances as test_gpu_parity.py; block systems are additionally bitwise equal to the oracle
+(every component is factorised in the same order with the same operations)."""
+import numpy as np
+import pytest
+
+import gen
+from conftest import read_case
+from oracle import oracle as O
+from oracle import textual as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import ezpz_amd
+
+    if ezpz_amd.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device: the product path has no CPU fallback")
+    return ezpz_amd
+
+
+def assert_x_close(got, want, rel=1e-6):
+    got, want = np.asarray(got), np.asarray(want)
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and (not np.any(~np.isnan(err)) or np.nanmax(err) <= rel), float(np.nanmax(err))
+
+
+def replicate(constraints, guesses, copies, seed=0, jitter=0.0):
+    """`copies` independent replicas of a system (variable ids shifted): a block system of isomorphic components."""
+    n = len(guesses)
+    rng = np.random.default_rng(seed)
+    recs, gs = [], []
+    for r in range(copies):
+        for c in constraints:
+            c = c.copy()
+            c["ids"] = c["ids"] + r * n
+            recs.append(c)
+        gs.append(np.asarray(guesses) + (rng.uniform(-jitter, jitter, n) if jitter else 0.0))
+    return O.stack(recs), np.concatenate(gs)
+
+
+def solve_both(E, recs, x0, cfg=None, linsolve=O.LINSOLVE_SPARSE, expect_mode=3):
+    """Component-resident solve of a batch + the oracle per system; checks everything the status carries."""
+    cfg = cfg or {}
+    n = x0.shape[1]
+    sysobj = E.System(recs, n)
+    info = sysobj.info()
+    assert info["team_mode"] == expect_mode, info
+    x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=linsolve)
+    assert rc == 0
+    assert np.array_equal(st["iterations"], it), (st["iterations"][:8], it[:8])
+    assert np.array_equal(st["converged"], conv)
+    assert np.array_equal(st["n_unsatisfied"], nun)
+    assert np.array_equal(mask.sum(axis=1), nun)
+    return sysobj, x, st, mask, xo
+
+
+def test_massive_parallel_system_is_component_resident_and_bitwise(E):
+    """BASELINE configs[1]: 2000 x 2000 = 1500 components in 2 classes; bitwise equal to the oracle and to the
+    wavefront-partitioned list-walk kernel, 2 iterations (README.md:36-38)."""
+    ref = T.load(T.gen_big_problem(500))
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(11, 40, ref.num_vars, -0.25, 0.25)
+    x0[0] = ref.guesses
+    sysobj, x, st, mask, xo = solve_both(E, ref.constraints, x0)
+    info = sysobj.info()
+    assert (info["n_components"], info["n_partitions"], info["team_size"]) == (1500, 24, 512)
+    assert (info["nnz_j"], info["nnz_a"], info["nnz_l"], info["n_levels"]) == (2500, 2500, 2500, 2)
+    assert np.array_equal(x, xo)
+    assert np.all(st["iterations"] == 2) and np.all(st["n_unsatisfied"] == 0) and np.all(st["final_residual_inf"] <= 1e-9)
+    walk = E.System(ref.constraints, ref.num_vars, team_size=512)
+    assert walk.info()["team_mode"] == 1
+    xw, stw, _ = walk.solve_batch(x0)
+    assert np.array_equal(x, xw)
+    for f in ("iterations", "converged", "n_unsatisfied", "n_warnings", "final_residual_inf", "final_lambda"):
+        assert np.array_equal(st[f], stw[f]), f
+    # one call of the reference's solve() lands on the same shape
+    got = E.solve_records(ref.constraints, ref.guesses)
+    assert (got.error, got.iterations, got.converged, got.unsatisfied) == (0, 2, True, [])
+    assert np.array_equal(got.final_values, xo[0])
+
+
+@pytest.mark.parametrize("lines", [43, 64, 130, 600])
+def test_ragged_chunk_sizes_and_free_variables(E, lines):
+    """Instance counts that are not multiples of 64 (partial chunks) and variables no constraint mentions (components of
+    their own with no constraint: the reference's step for them is exactly zero)."""
+    ref = T.load(T.gen_big_problem(lines))
+    n = ref.num_vars
+    x0 = np.concatenate([ref.guesses[None, :] + gen.keyed_uniform(5, 7, n, -0.25, 0.25), np.arange(35.0).reshape(7, 5) - 17.0], axis=1)
+    x0[3, n + 2] = -0.0
+    sysobj, x, st, mask, xo = solve_both(E, ref.constraints, x0)
+    assert sysobj.info()["n_components"] == 3 * lines + 5
+    assert np.array_equal(x, xo) and np.array_equal(np.signbit(x), np.signbit(xo))
+    assert np.all(st["iterations"] == 2)
+
+
+def test_overconstrained_lines_general_build(E):
+    """gen_big_problem.py <lines> true: one non-linear `distance` per line on top -- 4-variable components of one class
+    on the general (all kinds) build, Jacobian values in LDS, 3-4 iterations."""
+    ref = T.load(T.gen_big_problem(300, True))
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(23, 12, ref.num_vars, -0.25, 0.25)
+    sysobj, x, st, mask, xo = solve_both(E, ref.constraints, x0)
+    assert sysobj.info()["n_components"] == 300
+    assert_x_close(x, xo)
+    assert np.all(st["n_unsatisfied"] == 0) and np.all(st["iterations"] >= 3)
+    walk = E.System(ref.constraints, ref.num_vars, team_size=256)
+    xw, stw, _ = walk.solve_batch(x0)
+    assert np.array_equal(x, xw) and np.array_equal(st["iterations"], stw["iterations"])
+
+
+@pytest.mark.parametrize("case,copies", [("square", 150), ("two_rectangles", 130), ("circle_tangent", 200), ("arc_radius", 140),
+                                         ("chamfer_square", 128), ("perpendicular", 129), ("symmetric", 131)])
+def test_replicated_fixtures_match_the_oracle_per_system(E, case, copies):
+    """Block systems made of one reference fixture replicated: dense little components (square: 8 variables, lists
+    longer than one record), circles, arcs, rejected steps (perpendicular).  LM accepts or rejects a step for the whole
+    system, so a system of jittered replicas is its own test of the shared control."""
+    ref = T.load(read_case(case))
+    base = [O.set_from_initial_values(c, ref.guesses) for c in ref.constraints]
+    recs, g = replicate(base, ref.guesses, copies, seed=7, jitter=0.02)
+    x0 = np.stack([g, g + 0.004, g - 0.003])
+    cfg = dict(max_iterations=120)
+    sysobj, x, st, mask, xo = solve_both(E, recs, x0, cfg)
+    assert_x_close(x, xo)
+    for b in range(x0.shape[0]):
+        want = O.solve(recs, x0[b], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied
+        assert int(st["n_warnings"][b]) == len(want.warnings)
+        assert abs(float(st["final_residual_inf"][b]) - want.final_residual_inf) <= 1e-9 * max(1.0, want.final_residual_inf)
+    # run-to-run determinism, and the same bits for every system of a batch of identical inputs
+    x2, st2, _ = sysobj.solve_batch(np.tile(x0[:1], (9, 1)), E.Config(**cfg))
+    assert np.all(x2 == x[0]) and np.all(st2["iterations"] == st["iterations"][0])
+
+
+def test_weights_and_unsatisfiable_components(E):
+    """Non-unit weights (class constants of the linear build when exactly representable, else the general build) and
+    components that cannot be satisfied: the unsatisfied mask and counts, with r re-evaluated unweighted."""
+    for wts, mode_linear in (((1.0, 1.0), True), ((2.5, 0.5), True), ((1.0 / 3.0, 7.1), False)):
+        recs = []
+        for k in range(160):
+            a, b = 2 * k, 2 * k + 1
+            recs.append(O.fixed(a, float(k), weight=wts[0]))
+            recs.append(O.fixed(a, float(k) + (0.5 if k % 7 == 0 else 0.0), weight=wts[1]))  # conflicting on every 7th
+            recs.append(O.scalar_equal(a, b))
+            recs.append(O.fixed(b, float(k) + (2.0 if k % 5 == 0 else 0.0)))  # conflicting on every 5th
+        recs = O.stack(recs)
+        x0 = gen.keyed_uniform(3, 6, 320, -3.0, 3.0)
+        sysobj, x, st, mask, xo = solve_both(E, recs, x0)
+        assert np.all(st["n_unsatisfied"] > 0)
+        rc, xo, it, conv, nun = O.solve_batch(recs, x0, linsolve=O.LINSOLVE_SPARSE)
+        assert_x_close(x, xo, 1e-9)
+        want = O.solve(recs, x0[0], linsolve=O.LINSOLVE_SPARSE)
+        assert np.nonzero(mask[0])[0].tolist() == want.unsatisfied
+
+
+def test_degenerate_warnings_and_failed_pivots(E):
+    """Degenerate evaluations (coincident points under `distance`): one warning per evaluation that officially happened,
+    in the reference's order, including the sweeps of rejected steps and none for the speculative sweep of an iteration
+    whose factorisation failed (newton.rs:93-99); NaN guesses in one component stall the whole system like the
+    reference's global LM control does."""
+    recs, guesses = [], []
+    for k in range(140):
+        o = 4 * k
+        recs.append(O.distance((o, o + 1), (o + 2, o + 3), 1.0 + 0.01 * k))
+        recs.append(O.fixed(o, float(k)))
+        recs.append(O.fixed(o + 1, 0.0))
+        recs.append(O.horizontal((o, o + 1), (o + 2, o + 3)))
+        guesses += [float(k), 0.0, float(k) + (0.0 if k % 9 == 0 else 0.7), 0.0 if k % 9 == 0 else 0.2]
+    recs = O.stack(recs)
+    g = np.asarray(guesses)
+    for cfg, gg in ((dict(), g), (dict(initial_lambda=1e-30), g), (dict(max_iterations=7), np.where(np.arange(len(g)) == 6, np.nan, g))):
+        got = E.solve_records(recs, gg, E.Config(**cfg), warn_cap=1 << 16)
+        want = O.solve(recs, gg, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert (got.error, got.iterations, got.converged, got.unsatisfied) == (want.error, want.iterations, want.converged, want.unsatisfied)
+        assert got.warnings == want.warnings and len(want.warnings) > 0
+        assert np.array_equal(np.isnan(got.final_values), np.isnan(want.final_values))
+        assert_x_close(got.final_values, want.final_values)
+
+
+def test_iteration_limits_and_tolerances(E):
+    ref = T.load(T.gen_big_problem(200))
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(2, 3, ref.num_vars, -0.25, 0.25)
+    for cfg in (dict(max_iterations=0), dict(max_iterations=1), dict(residual_tolerance=1e3), dict(step_tolerance=1e3),
+                dict(initial_lambda=1.0, max_iterations=6)):
+        sysobj, x, st, mask, xo = solve_both(E, ref.constraints, x0, cfg)
+        assert np.array_equal(x, xo), cfg
+
+
+def test_mixed_classes_with_nonlinear_members(E):
+    """A block system with several classes at once (linear and non-linear components, different sizes)."""
+    parts = []
+    for name, copies in (("tiny", 50), ("circle_tangent", 40), ("midpoint", 45), ("nonsquare", 33)):
+        ref = T.load(read_case(name))
+        base = [O.set_from_initial_values(c, ref.guesses) for c in ref.constraints]
+        parts.append(replicate(base, ref.guesses, copies, seed=len(name), jitter=0.01))
+    recs, gs, off = [], [], 0
+    for r, g in parts:
+        r = r.copy()
+        r["ids"] = r["ids"] + off
+        recs.append(r)
+        gs.append(g)
+        off += len(g)
+    recs, g = np.concatenate(recs), np.concatenate(gs)
+    x0 = np.stack([g, g + 0.002])
+    sysobj, x, st, mask, xo = solve_both(E, recs, x0, dict(max_iterations=60))
+    assert_x_close(x, xo)
+    assert np.all(st["n_unsatisfied"] == 0)

@@ -211,7 +211,12 @@ def test_massive_parallel_system_batch(E):
     assert np.all(st["final_residual_inf"] <= 1e-9)
     info = sysobj.info()
     assert (info["nnz_j"], info["nnz_a"], info["nnz_l"], info["n_levels"]) == (2500, 2500, 2500, 2)
+    assert info["team_mode"] == 3  # component-resident; the list-walk shapes on this system: test_gpu_components.py
+    walk = E.System(ref.constraints, ref.num_vars, team_size=E.TEAM_AUTO_LISTS)
+    info = walk.info()
     assert info["team_mode"] == 1 and info["n_partitions"] == info["team_size"] // 64  # wavefront-partitioned
+    xw, stw, _ = walk.solve_batch(x0)
+    assert np.array_equal(xw, x) and np.array_equal(stw["iterations"], st["iterations"])
 
 
 def _chain_system(n_pts):
@@ -571,7 +576,9 @@ def test_mosaic_of_fixtures_in_workgroup_and_grid_teams(E, copies, team, perp):
     records with several partial-slot patterns, the staged-lists and global-workspace variants, and a grid team."""
     recs, g = _fixture_mosaic(copies, seed=copies, with_perpendicular=perp)
     assert len(set(int(k) for k in recs["kind"])) >= 11
-    sysobj = E.System(recs, len(g), team_size=team)
+    # (a dozen classes of components: too many rows of state for the component-resident shape, whose multi-class case
+    # is test_gpu_components.py::test_mixed_classes_with_nonlinear_members)
+    sysobj = E.System(recs, len(g), team_size=team or E.TEAM_AUTO_LISTS)
     info = sysobj.info()
     assert info["team_mode"] in (1, 2)
     if copies == 40:
@@ -613,7 +620,7 @@ def test_random_block_systems_are_deterministic_and_match_the_oracle(E, team, nc
             guesses.append(rng.uniform(-6.0, 6.0, nv))
             off += nv
         recs, g = O.stack(recs), np.concatenate(guesses)
-        sysobj = E.System(recs, len(g), team_size=team)
+        sysobj = E.System(recs, len(g), team_size=team or E.TEAM_AUTO_LISTS)
         assert sysobj.info()["team_mode"] in (1, 2)
         if ncomp >= 1000:
             assert (sysobj.info()["grid_workgroups"] > 1) == (team == 0)
