@@ -56,7 +56,7 @@ PMC_SETS = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
 ]
-SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel")
+SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel", "ezpz_jit_solve")
 
 
 def algorithmic_bytes(info: dict, k: int) -> int:
@@ -120,6 +120,7 @@ def parse_args(argv=None):
     ap.add_argument("--check", type=int, default=1, help="verify the results of the last step against the oracle")
     ap.add_argument("--extras", type=int, default=1, help="also report the host-to-host rate, single-solve latency (and, "
                     "for N>1, the rate with the RCCL scatter/gather of the batch) -- never part of `value`")
+    ap.add_argument("--specialize", type=int, default=1, help="use the run-time compiled class-specialised kernel where the topology has one")
     ap.add_argument("--pmc", type=int, default=1, help="N=1: collect the roofline's PMC counters with rocprofv3 child passes of this script")
     return ap.parse_args(argv)
 
@@ -194,7 +195,7 @@ def collect_pmc(args) -> dict:
     outdir = tempfile.mkdtemp(prefix="bench_pmc_", dir=base)
     env = dict(os.environ, TMPDIR="/tmp")
     child = ["python3", os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch), "--team", str(args.team),
-             "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--check", "0", "--extras", "0", "--pmc", "0"]
+             "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--check", "0", "--extras", "0", "--pmc", "0", "--specialize", str(args.specialize)]
     counters, errors = {}, []
     for i, cset in enumerate(PMC_SETS):
         d = os.path.join(outdir, f"set{i}")
@@ -309,12 +310,15 @@ def main():
         n_k = len(guesses_k)
         B_k = args.batch // len(names) + (1 if k < args.batch % len(names) else 0)
         system_k = E.System(records_k, n_k, device=device_index, team_size=args.team)
+        # component-resident systems: the class-specialised kernel (run-time compiled once per topology, outside the
+        # timed region like the symbolic phase; batch calls would start it themselves in the background)
+        spec_k = system_k.specialize(wait=True) == 2 if args.specialize else False
         # synthetic inputs: replicas of the system with keyed-PRNG jitter on the guesses, resident in HBM
         x0_host_k = guesses_k[None, :] + gen.keyed_uniform(0x657A707A + rank + 101 * k, B_k, n_k, -jitter_k, jitter_k)
         x0_host_k[0] = guesses_k
         x0_k = torch.from_numpy(x0_host_k).to(dev)
         parts.append(dict(desc=desc_k, records=records_k, guesses=guesses_k, jitter=jitter_k, expect=expect_k, n=n_k,
-                          B=B_k, system=system_k, info=system_k.info(), x0_host=x0_host_k, x0=x0_k,
+                          B=B_k, system=system_k, info=system_k.info(), specialized=spec_k, x0_host=x0_host_k, x0=x0_k,
                           x_out=torch.empty_like(x0_k), status=torch.zeros((B_k, 32), dtype=torch.uint8, device=dev)))
     # the single-topology names used below refer to the first (usually only) part
     p0 = parts[0]
@@ -504,6 +508,7 @@ def main():
                 "rows": info["n_rows"], "vars": info["n_vars"], "constraints": info["n_constraints"],
                 "nnz_j": info["nnz_j"], "nnz_a": info["nnz_a"], "nnz_l": info["nnz_l"], "levels": info["n_levels"],
                 "team_size": info["team_size"], "team_mode": info["team_mode"], "workspace_in_lds": bool(info["workspace_in_lds"]),
+                "class_specialised_kernel": [bool(p["specialized"]) for p in parts] if len(parts) > 1 else bool(p0["specialized"]),
                 "parallelism": f"batch-sharded x{world}, no collective on the data path",
                 "inputs": "resident in HBM; guesses = file guesses + keyed U(-%.2f,%.2f)" % (jitter, jitter),
             },

@@ -55,6 +55,8 @@ EXPORTS = [
     "ezpz_system_freedom_batch",
     "ezpz_system_freedom_batch_device",
     "ezpz_resolve_sides",
+    "ezpz_system_specialize",
+    "ezpz_specialized_source",
 ]
 
 _lib = None
@@ -93,6 +95,10 @@ def lib():
     L.ezpz_system_freedom_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.ezpz_current_device.restype = C.c_int
     L.ezpz_current_device.argtypes = []
+    L.ezpz_system_specialize.restype = C.c_int
+    L.ezpz_system_specialize.argtypes = [vp, C.c_int]
+    L.ezpz_specialized_source.restype = C.c_long
+    L.ezpz_specialized_source.argtypes = [vp, sz, sz, C.c_int, C.c_char_p, sz]
     L.ezpz_resolve_sides.restype = C.c_int
     L.ezpz_resolve_sides.argtypes = [vp, sz, vp, sz]
     L.ezpz_cache_clear.restype = None

@@ -601,6 +601,18 @@ def solve_batch(reqs, x0: np.ndarray, config: Optional[Config] = None, want_mask
     return x, st, prio, mask
 
 
+def specialized_source(records, n_vars: int, compile: bool = False) -> str:
+    """`ezpz_specialized_source`: the generated source of the request's class-specialised kernel ('' = none); with
+    compile=True it is also compiled for gfx950 (hiprtc; no device needed) and a failure raises with the log."""
+    recs = stack_records(records)
+    buf = C.create_string_buffer(1 << 22)
+    rc = lib().ezpz_specialized_source(recs.ctypes.data if len(recs) else None, len(recs), int(n_vars), 1 if compile else 0,
+                                       buf, len(buf))
+    if rc < 0:
+        raise RuntimeError("run-time compilation failed:\n" + buf.value.decode(errors="replace")[-4000:])
+    return buf.value.decode() if rc > 0 else ""
+
+
 def resolve_sides(records, values) -> np.ndarray:
     """`Constraint::set_from_initial_values` (constraints.rs:146-193) over a request list: a copy of `records` in which
     every undefined LineSide / CircleSide is the one `values` (by id) imply.  `System` takes side-resolved records."""
@@ -642,10 +654,36 @@ class System:
             lib().ezpz_system_destroy(h)
             self._h = None
 
+    def specialize(self, wait: bool = True) -> int:
+        """`ezpz_system_specialize`: 2 = the class-specialised kernel is ready, 1 = compiling, 0 = none for this system."""
+        rc = lib().ezpz_system_specialize(self._h, 1 if wait else 0)
+        if rc < 0:
+            raise NonLinearSystemError(rc)
+        return rc
+
     def info(self) -> dict:
         i = CSystemInfo()
         lib().ezpz_system_info(self._h, C.byref(i))
         return {f: getattr(i, f) for f, _ in CSystemInfo._fields_}
+
+    def solve_batch_logged(self, x0: np.ndarray, config: Optional[Config] = None, warn_cap: int = 1024):
+        """solve_batch plus the Degenerate warnings of every system: a list per system of (pass, constraint position)
+        in the reference's chronological order (the kernel's log entries sorted), truncated to warn_cap."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, max(self.n_vars, 1))
+        batch = x0.shape[0]
+        cfg = (config or Config())._c()
+        x = np.empty_like(x0)
+        st = np.zeros(batch, dtype=STATUS_DTYPE)
+        log = np.zeros((batch, warn_cap), dtype=np.uint64)
+        rc = lib().ezpz_system_solve_batch(self._h, x0.ctypes.data, batch, C.byref(cfg), x.ctypes.data, st.ctypes.data,
+                                           None, log.ctypes.data, warn_cap)
+        if rc != 0:
+            raise NonLinearSystemError(rc)
+        logs = []
+        for b in range(batch):
+            e = np.sort(log[b, : min(int(st["n_warnings"][b]), warn_cap)])
+            logs.append([(int(v >> np.uint64(32)), int(v & np.uint64(0xFFFFFFFF))) for v in e])
+        return x, st, logs
 
     def solve_batch(self, x0: np.ndarray, config: Optional[Config] = None, want_mask: bool = False):
         """Host arrays in/out.  x0 [batch, n_vars] -> (x [batch, n_vars], status (STATUS_DTYPE), mask or None)."""

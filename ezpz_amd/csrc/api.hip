@@ -136,6 +136,7 @@ struct EzpzSystem {
     // comp_solve_kernel and the list-walk program above serves only evaluation / FreedomAnalysis
     std::unique_ptr<CompPlan> comp;
     uint32_t* dev_comp = nullptr;
+    CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
     DevBuf<GridScratch> grid_scratch;
@@ -178,6 +179,7 @@ struct EzpzSystem {
         if (dev_program) (void)hipFree(dev_program);
         if (dev_grid_blob) (void)hipFree(dev_grid_blob);
         if (dev_comp) (void)hipFree(dev_comp);
+        comp_jit_destroy(jit);
     }
 };
 
@@ -398,6 +400,16 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         L.residual_tolerance = args.residual_tolerance;
         L.step_tolerance = args.step_tolerance;
         L.initial_lambda = args.initial_lambda;
+        // the class-specialised kernel once it is compiled; large batches start its compilation (background thread)
+        if (s.jit) {
+            static const bool sync = [] {
+                const char* e = std::getenv("EZPZ_JIT");
+                return e && std::strcmp(e, "sync") == 0;
+            }();
+            int st = comp_jit_state(s.jit);
+            if (st == 0 && (args.batch >= 1024 || sync)) st = comp_jit_request(s.jit, sync);
+            if (st == 2 && comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+        }
         return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
     }
     uint32_t grid;
@@ -1023,6 +1035,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     return EZPZ_OK;
 }
 
+
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable) {
     if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
@@ -1047,6 +1060,7 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
     if (s->comp) {
         HIP_TRY(hipMalloc((void**)&s->dev_comp, s->comp->blob.size() * 4));
         HIP_TRY(hipMemcpy(s->dev_comp, s->comp->blob.data(), s->comp->blob.size() * 4, hipMemcpyHostToDevice));
+        s->jit = comp_jit_create(*s->comp);
     }
     *out = s.release();
     return EZPZ_OK;
@@ -1244,6 +1258,35 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
 }  // extern "C"
 
 extern "C" {
+
+int ezpz_system_specialize(EzpzSystem* sys, int wait) {
+    if (!sys) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (!sys->jit) return 0;
+    const int st = comp_jit_request(sys->jit, wait != 0);
+    return st < 0 ? EZPZ_ERR_HIP : st;
+}
+
+long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int compile, char* buf, size_t cap) {
+    CompPlan plan;
+    CompLimits cl;
+    if (!comp_plan_build(cs, n_cs, n_vars, cl, plan) || plan.jit_source.empty()) return 0;
+    std::string text = plan.jit_source;
+    long rc = (long)text.size();
+    if (compile) {
+        std::vector<char> code;
+        std::string log;
+        if (comp_jit_compile(plan.jit_source, code, log) != EZPZ_OK) {
+            text = log;
+            rc = EZPZ_ERR_HIP;
+        }
+    }
+    if (buf && cap) {
+        const size_t k = std::min(cap - 1, text.size());
+        std::memcpy(buf, text.data(), k);
+        buf[k] = 0;
+    }
+    return rc;
+}
 
 #ifdef EZPZ_STAMPS
 void ezpz_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = dev_buf; }

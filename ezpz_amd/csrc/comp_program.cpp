@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <string>
 
 #include "kinds.hpp"
 #include "program.hpp"
@@ -108,6 +109,122 @@ void emit_op(std::vector<uint32_t>& out, uint32_t opcode, uint32_t a, uint32_t b
         done += take;
         first = false;
     } while (done < n);
+}
+
+// ---- source text of the class-specialised kernel (see jit_kernel.hip.hpp) ---------------------------------------------------------
+// Every statement below is one operation of the class program, in the interpreter's order (comp_kernel.hip.hpp), with
+// literal indices; doubles are written as hexadecimal floating literals (exact).
+std::string hexf(double v) {
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%a", v);
+    return std::string("(") + buf + ")";
+}
+
+void emit_class(std::string& o, size_t k, const Class& cl) {
+    const Program& Q = cl.Q;
+    const uint32_t nv = Q.c.n_vars, m = Q.c.n_rows, zj = Q.c.zj, zlo = Q.c.zlo, nc = Q.c.n_cons;
+    const bool lin = cl.linear;
+    auto S = [](uint32_t v) { return std::to_string(v); };
+    auto con_expr = [&](const DevCon& d, uint32_t ci) {
+        std::string e = "ezpz::jit::mkcon(" + S(d.kind) + ", " + S(d.tag) + ", " + S(d.nrows);
+        for (int i = 0; i < 8; ++i) e += ", " + S(d.ids[i]);
+        e += ", " + hexf(d.weight) + ", par[" + S(ci) + "])";
+        return e;
+    };
+    o += "struct Cls" + S((uint32_t)k) + " {\n";
+    o += "    static constexpr int NV = " + S(nv) + ", M = " + S(m) + ", NC = " + S(nc) + ", ZJS = " + S(lin ? 0 : zj) +
+         ", STRIDE = " + S(cl.H.ninst_pad) + ";\n";
+    o += std::string("    static constexpr bool LINEAR = ") + (lin ? "true" : "false") + ";\n";
+    const std::string xs = "const double (&x)[" + S(nv) + "], const double (&par)[" + S(std::max(nc, 1u)) + "]";
+    // residual sweep (solver.rs:318-356): r = weight * residual, sum of squares, maximum, degenerate mask
+    o += "    static __device__ __forceinline__ void residuals(" + xs + ", double (&r)[" + S(std::max(m, 1u)) +
+         "], bool active, double& sq, double& mx, unsigned long long& wm) {\n";
+    for (uint32_t ci = 0; ci < nc; ++ci) {
+        const DevCon& d = Q.cons[ci];
+        o += "        { const DevCon c = " + con_expr(d, ci) + "; double r0, r1; const bool deg = ezpz::dev::con_residual<LINEAR>(c, x, r0, r1);\n";
+        o += "          const double w0 = c.weight * r0; r[" + S(d.row0) + "] = w0; if (active) { sq += w0 * w0; mx = fmax(mx, fabs(w0)); }\n";
+        if (d.nrows > 1)
+            o += "          const double w1 = c.weight * r1; r[" + S(d.row0 + 1) + "] = w1; if (active) { sq += w1 * w1; mx = fmax(mx, fabs(w1)); }\n";
+        o += "          if (!LINEAR && deg) wm |= 1ull << " + S(ci) + "; (void)r1; }\n";
+    }
+    o += "        (void)x; (void)par; (void)r; (void)active; (void)sq; (void)mx; (void)wm;\n    }\n";
+    // Jacobian sweep (solver.rs:359-440)
+    o += "    static __device__ __forceinline__ void jacobian(" + xs + ", double (&J)[" + S(lin ? 1u : std::max(zj, 1u)) +
+         "], unsigned long long& wm) {\n";
+    if (!lin)
+        for (uint32_t ci = 0; ci < nc; ++ci) {
+            const DevCon& d = Q.cons[ci];
+            uint32_t loc[4];
+            std::memcpy(loc, d.jloc, 16);
+            o += "        { const DevCon c = " + con_expr(d, ci) + "; ezpz::dev::JacWriter<double*> w; w.jv = J; w.jbase = " + S(d.jbase) +
+                 "; w.loc[0] = " + S(loc[0]) + "u; w.loc[1] = " + S(loc[1]) + "u; w.loc[2] = " + S(loc[2]) + "u; w.loc[3] = " + S(loc[3]) +
+                 "u; w.weight = c.weight;\n";
+            o += "          if (ezpz::dev::con_jacobian<false>(c, x, w)) wm |= 1ull << " + S(ci) + "; }\n";
+        }
+    o += "        (void)x; (void)par; (void)J; (void)wm;\n    }\n";
+    // the linear solve (newton.rs:73-102)
+    o += "    static __device__ __forceinline__ bool solve(const double (&J)[" + S(lin ? 1u : std::max(zj, 1u)) + "], const double (&r)[" +
+         S(std::max(m, 1u)) + "], double lambda, double (&d)[" + S(nv) + "], double& dmax) {\n        bool bad = false;\n";
+    auto jv = [&](uint32_t slot) { return lin ? hexf(cl.jconst[slot]) : "J[" + S(slot) + "]"; };
+    for (uint32_t v = 0; v < nv; ++v) {
+        o += "        double D" + S(v) + " = 0.0, V" + S(v) + " = 0.0;\n";
+        for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
+            const std::string j = jv(Q.colj_items[2 * q]);
+            o += "        D" + S(v) + " += " + j + " * " + j + "; V" + S(v) + " += " + j + " * -r[" + S(Q.colj_items[2 * q + 1]) + "];\n";
+        }
+        o += "        D" + S(v) + " = D" + S(v) + " + lambda;\n";
+    }
+    for (uint32_t s2 = 0; s2 < zlo; ++s2) {
+        o += "        double L" + S(s2) + " = 0.0;\n";
+        for (uint32_t q = Q.apair_ptr[s2]; q < Q.apair_ptr[s2 + 1]; ++q)
+            o += "        L" + S(s2) + " += " + jv(Q.apairs[2 * q]) + " * " + jv(Q.apairs[2 * q + 1]) + ";\n";
+    }
+    const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
+    for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+        const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
+        for (uint32_t v = c0; v < c1; ++v) {
+            for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q) {
+                const std::string l = "L" + S(Q.fwd_items[2 * q]);
+                o += "        D" + S(v) + " -= " + l + " * " + l + "; V" + S(v) + " -= " + l + " * V" + S(Q.fwd_items[2 * q + 1]) + ";\n";
+            }
+            o += "        if (!(D" + S(v) + " > 0.0)) bad = true;\n";
+            o += "        D" + S(v) + " = sqrt(D" + S(v) + "); V" + S(v) + " = V" + S(v) + " / D" + S(v) + ";\n";
+        }
+        for (uint32_t s2 = s0; s2 < s1; ++s2) {
+            for (uint32_t q = Q.lpair_ptr[s2]; q < Q.lpair_ptr[s2 + 1]; ++q)
+                o += "        L" + S(s2) + " -= L" + S(Q.lpairs[2 * q]) + " * L" + S(Q.lpairs[2 * q + 1]) + ";\n";
+            o += "        L" + S(s2) + " = L" + S(s2) + " / D" + S(Q.l_col[s2]) + ";\n";
+        }
+    }
+    for (uint32_t lv = part.nlev; lv-- > 0;) {
+        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+        for (uint32_t v = c0; v < c1; ++v) {
+            for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
+                o += "        V" + S(v) + " -= L" + S(Q.bwd_items[2 * q]) + " * V" + S(Q.bwd_items[2 * q + 1]) + ";\n";
+            o += "        V" + S(v) + " = V" + S(v) + " / D" + S(v) + "; d[" + S(v) + "] = V" + S(v) + "; dmax = fmax(dmax, fabs(V" + S(v) + "));\n";
+        }
+    }
+    o += "        (void)J; (void)r;\n        return bad;\n    }\n";
+    // unsatisfied check (lib.rs:305-327, :358-370)
+    o += "    static __device__ __forceinline__ void unsatisfied(" + xs + ", bool active, double& unsat, uint8_t* mask, const uint32_t* pos) {\n";
+    for (uint32_t ci = 0; ci < nc; ++ci) {
+        const DevCon& d = Q.cons[ci];
+        o += "        { const DevCon c = " + con_expr(d, ci) + "; double r0, r1; ezpz::dev::con_residual<LINEAR>(c, x, r0, r1);\n";
+        o += std::string("          bool sat = fabs(r0) < ezpz::dev::EPS;") + (d.nrows > 1 ? " sat = sat && (fabs(r1) < ezpz::dev::EPS);" : "") + "\n";
+        o += "          if (active) { if (!sat) unsat += 1.0; if (mask) mask[pos[(size_t)" + S(ci) + " * STRIDE]] = sat ? 0 : 1; } (void)r1; }\n";
+    }
+    o += "        (void)x; (void)par; (void)active; (void)unsat; (void)mask; (void)pos;\n    }\n";
+    o += "    static __device__ __forceinline__ void unsatisfied_from_r(const double (&r)[" + S(std::max(m, 1u)) +
+         "], bool active, double& unsat, uint8_t* mask, const uint32_t* pos) {\n";
+    for (uint32_t ci = 0; ci < nc; ++ci) {
+        const DevCon& d = Q.cons[ci];
+        o += "        { bool sat = fabs(r[" + S(d.row0) + "]) < ezpz::dev::EPS;" +
+             (d.nrows > 1 ? " sat = sat && (fabs(r[" + S(d.row0 + 1) + "]) < ezpz::dev::EPS);" : "") + "\n";
+        o += "          if (active) { if (!sat) unsat += 1.0; if (mask) mask[pos[(size_t)" + S(ci) + " * STRIDE]] = sat ? 0 : 1; } }\n";
+    }
+    o += "        (void)r; (void)active; (void)unsat; (void)mask; (void)pos;\n    }\n";
+    o += "};\n\n";
 }
 
 }  // namespace
@@ -461,6 +578,70 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
     plan.n_vars = n;
     plan.n_cons = C;
     plan.n_rows = (uint32_t)m_total;
+
+    // ---- the same plan as source text for the class-specialised kernel --------------------------------------------------------------
+    // A wavefront gets ceil(chunks of class k / T) slots of every class k -- the same sequence for every wavefront, so
+    // one body of code serves them all; a slot beyond a class's last chunk runs with no active lane.  T = the fewest
+    // wavefronts per system (every one pays the LM control's reductions) whose slots still fit the register file.
+    {
+        std::vector<uint32_t> nchunk(classes.size());
+        for (size_t k = 0; k < classes.size(); ++k) nchunk[k] = ((uint32_t)classes[k].instances.size() + 63) / 64;
+        auto vgprs = [&](uint32_t T) {
+            uint64_t v = 0;
+            for (size_t k = 0; k < classes.size(); ++k) {
+                const ClassLayout& H = classes[k].H;
+                const uint64_t per = 2ull * (2 * H.nv + 2 * H.m + (classes[k].linear ? 0 : H.zj) + H.ncons) + H.nv + 4;
+                v += per * ((nchunk[k] + T - 1) / T);
+            }
+            return v;
+        };
+        uint32_t T = 0;
+        static const char* env_t = std::getenv("EZPZ_JIT_WAVES");
+        if (env_t && std::atoi(env_t) > 0) {
+            T = (uint32_t)std::atoi(env_t);
+        } else {
+            for (uint32_t t = 1; t <= 8 && !T; t <<= 1)
+                if (vgprs(t) <= 128) T = t;
+            if (!T) T = 8;  // big classes: one slot per class and wavefront, at whatever occupancy the registers leave
+        }
+        if (T && T <= 16 && vgprs(T) <= 360) {
+            std::string& o = plan.jit_source;
+            o = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
+            for (size_t k = 0; k < classes.size(); ++k) emit_class(o, k, classes[k]);
+            std::string seq;
+            uint32_t nslots = 0;
+            std::vector<std::pair<uint32_t, uint32_t>> slot_of;  // (class, round)
+            for (size_t k = 0; k < classes.size(); ++k)
+                for (uint32_t j = 0; j < (nchunk[k] + T - 1) / T; ++j) {
+                    seq += (nslots ? ", Cls" : "Cls") + std::to_string(k);
+                    slot_of.emplace_back((uint32_t)k, j);
+                    ++nslots;
+                }
+            bool any_nonlinear = false;
+            for (const Class& cl : classes) any_nonlinear = any_nonlinear || !cl.linear;
+            o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ") ezpz_jit_solve(const ezpz::jit::JitArgs a) {\n";
+            o += "    __shared__ double smem[112];\n";
+            o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
+                 (plan.unit_weights ? "true" : "false") + ">(a, smem);\n}\n";
+            align4(blob);
+            plan.o_jit_slots = (uint32_t)blob.size();
+            for (uint32_t w = 0; w < T; ++w)
+                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                    const ClassLayout& H = classes[slot_of[sl].first].H;
+                    const uint32_t chunk = slot_of[sl].second * T + w;  // chunk index inside the class
+                    const uint32_t ninst = (uint32_t)classes[slot_of[sl].first].instances.size();
+                    const uint32_t inst0 = std::min(chunk * 64, H.ninst_pad ? H.ninst_pad - 64 : 0u);
+                    const uint32_t count = chunk * 64 < ninst ? std::min<uint32_t>(64, ninst - chunk * 64) : 0u;
+                    blob.push_back(H.ids_off + inst0);
+                    blob.push_back(H.par_off + 2 * inst0);
+                    blob.push_back(H.pos_off + inst0);
+                    blob.push_back(count);
+                }
+            blob.resize(blob.size() + 16, 0);
+            plan.jit_waves = T;
+            plan.jit_slots = nslots;
+        }
+    }
     return true;
 }
 

@@ -16,6 +16,7 @@
 // solver.rs:192-440).
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "../../include/ezpz_amd.h"
@@ -75,6 +76,11 @@ struct CompPlan {
     uint32_t n_vars = 0, n_cons = 0, n_rows = 0;
     uint32_t max_levels = 0;
     uint64_t zj = 0, za = 0, zl = 0;  // totals over all components (EzpzSystemInfo)
+    // The same plan as source text for the class-specialised kernel (jit_kernel.hip.hpp + jit.cpp): one struct per
+    // class, the slot sequence of a wavefront and the kernel entry point; `jit_waves` wavefronts per system, each with
+    // `jit_slots` slots; blob[o_jit_slots ...] = [wave][slot] {ids_off, par_off, pos_off, count}.  Empty = none.
+    std::string jit_source;
+    uint32_t jit_waves = 0, jit_slots = 0, o_jit_slots = 0;
 };
 
 struct CompLimits {
@@ -105,5 +111,21 @@ struct CompLaunch {
 };
 int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus,
                 size_t lds_limit, void* stream);
+
+}  // namespace ezpz
+
+namespace ezpz {
+
+// The class-specialised kernel of a plan (jit.cpp): run-time compiled (hiprtc) on a background thread.
+// comp_jit_create returns nullptr when the plan carries no source or EZPZ_JIT=0.  comp_jit_request starts the
+// compilation if it has not started (and waits for it if asked); returns 0 idle, 1 compiling, 2 ready, -1 failed.
+struct CompJit;
+CompJit* comp_jit_create(const CompPlan& plan);
+void comp_jit_destroy(CompJit* jit);
+int comp_jit_request(CompJit* jit, bool wait);
+int comp_jit_state(const CompJit* jit);
+const char* comp_jit_log(const CompJit* jit);
+int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int cus, void* stream);
+int comp_jit_compile(const std::string& source, std::vector<char>& code, std::string& log);
 
 }  // namespace ezpz

@@ -12,9 +12,11 @@
 // Built with -ffp-contract=off: the Rust reference never fuses a*b+c, and the LM accept/reject and
 // convergence tests compare sums of these values.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
-#include "program.hpp"
+#include "dev_types.hpp"
 
 namespace ezpz {
 namespace dev {

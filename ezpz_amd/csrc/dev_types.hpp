@@ -1,0 +1,47 @@
+// Plain-data records shared by the host symbolic phase and the device kernels.  No standard-library dependency: this
+// header is also compiled at run time (hiprtc, see jit.cpp) as part of the class-specialised kernels.
+#pragma once
+#ifdef __HIPCC_RTC__
+#include "ezpz_amd.h"
+#else
+#include <cstdint>
+
+#include "../../include/ezpz_amd.h"
+#endif
+
+namespace ezpz {
+
+// One constraint as the kernel sees it.  80 bytes.
+struct alignas(16) DevCon {
+    uint32_t ids[8];
+    double param;
+    double weight;
+    uint32_t row0;   // first residual row (rows are numbered in request order, solver.rs:226-253)
+    uint32_t jbase;  // first Jacobian slot owned by this constraint
+    uint32_t pos;    // position in the caller's constraint list (for unsat mask / warnings)
+    uint8_t kind, tag, nrows, nslots;
+    uint8_t jloc[16];  // per emitted partial: slot offset from jbase; bit 7 = accumulate into an earlier entry's slot
+};
+static_assert(sizeof(DevCon) == 80, "DevCon layout");
+
+// The same constraint in 32 bytes, for programs whose every count fits 16 bits and whose constraint table is read
+// from global memory / L2 by workgroup teams: the table is re-read by every residual and Jacobian sweep of every
+// system, and its bytes (not HBM's) are what the massive_parallel_system launch is bound by.  weight, pos and the
+// jloc pattern live in side arrays (weights are read only when some weight != 1, pos only when a mask or a warning
+// is written, the handful of distinct jloc patterns sit in LDS).
+struct alignas(16) PackedCon {
+    uint16_t ids[8];
+    double param;
+    uint16_t row0, jbase;
+    uint8_t kind, tag, nrows, pattern;
+};
+static_assert(sizeof(PackedCon) == 32, "PackedCon layout");
+
+// A partition of the system: a union of connected components that one wavefront can own end to end
+// (its constraints, variables, Jacobian slots and Cholesky columns are disjoint from every other partition's).
+struct PartDesc {
+    uint32_t con0, con1;  // constraint range (table is sorted by partition, then kind)
+    uint32_t lvl0, nlev;  // this partition's slice of lvl_cptr / lvl_sptr (nlev + 1 entries each)
+};
+
+}  // namespace ezpz

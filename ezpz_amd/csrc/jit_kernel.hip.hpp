@@ -1,0 +1,349 @@
+// Class-specialised component-resident LM kernel: the skeleton.
+//
+// comp_kernel.hip.hpp interprets a class program record by record; for batches large enough to pay for a run-time
+// compilation (hiprtc, jit.cpp) the same plan is compiled into straight-line code instead.  The host emits, per
+// isomorphism class of components, a small struct (NV, M, ..., and three functions: residuals, jacobian, solve) whose
+// bodies are the class program with every index a literal -- the same operations in the same order as the interpreter
+// and the list-walk kernels, so results stay bit-identical -- and one line naming the sequence of classes a wavefront
+// handles.  This header, compiled together with that text, is everything else: it is hand-written and fixed.
+//
+// What the specialisation buys on gfx950: a lane keeps the whole state of its components (x, d, r, r_next, Jacobian
+// values, constraint parameters, the caller's variable ids) in VGPRs -- arrays indexed by literals only -- so there is
+// no LDS traffic and no address arithmetic at all, the scalar unit no longer decodes records, and with no LDS
+// footprint several workgroups share a CU.  LDS holds only the reduction scratch of the LM control
+// (newton.rs:50-60,:96-139): one rendezvous per LM iteration, exactly as in comp_kernel.hip.hpp.
+// Replaces the same reference code as comp_kernel.hip.hpp (ezpz/src/solver/newton.rs:29-145, solver.rs:318-440,
+// lib.rs:305-327).
+#pragma once
+#include "constraint_eval.hip.hpp"
+#include "wave_ops.hip.hpp"
+
+namespace ezpz {
+namespace jit {
+
+struct JitArgs {
+    const uint32_t* blob;  // the component plan's blob (per-class tables of ids / parameters / positions)
+    uint32_t o_slots;      // word offset of the slot table: [wave][slot] {ids_off, par_off, pos_off, count}
+    uint32_t n_row;        // values per system in x0 / x_out
+    uint32_t n_cons;       // constraints per system (unsat mask row)
+    uint32_t n_rows_total;
+    const double* x0;
+    double* x_out;
+    EzpzStatus* status;
+    uint8_t* unsat_mask;  // optional
+    uint64_t* warn_log;   // optional
+    uint32_t warn_cap;
+    uint32_t max_iterations;
+    uint64_t batch;
+    double residual_tolerance, step_tolerance, initial_lambda;
+};
+static_assert(sizeof(JitArgs) == 104, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
+
+// One component per lane of one class: everything in registers (every index below is a literal after inlining).
+template <class C>
+struct Slot {
+    double x[C::NV], d[C::NV];
+    double r[C::M > 0 ? C::M : 1], rn[C::M > 0 ? C::M : 1];
+    double J[C::ZJS > 0 ? C::ZJS : 1];    // Jacobian values (classes with a non-linear member; constant otherwise)
+    double par[C::NC > 0 ? C::NC : 1];    // constraint parameters of this lane's instance
+    uint32_t ids[C::NV];                  // the caller's ids of its variables
+    const uint32_t* pos;                  // the caller's positions of its constraints: pos[ci * STRIDE]
+    unsigned long long wmask;             // degenerate evaluations of the speculative residual sweep
+    bool active;
+};
+
+template <class P>
+struct class_of;
+template <class C>
+struct class_of<C*> {
+    typedef C type;
+};
+
+// The sequence of slots a wavefront owns, as a compile-time list.
+template <class... Cs>
+struct Slots;
+template <>
+struct Slots<> {
+    static constexpr int N = 0;
+    template <class F>
+    __device__ __forceinline__ void each(F&&, int = 0) {}
+};
+template <class C, class... Rest>
+struct Slots<C, Rest...> {
+    static constexpr int N = 1 + sizeof...(Rest);
+    Slot<C> head;
+    Slots<Rest...> tail;
+    template <class F>
+    __device__ __forceinline__ void each(F&& f, int index = 0) {
+        f(head, static_cast<C*>(nullptr), index);
+        tail.each(f, index + 1);
+    }
+};
+
+__device__ __forceinline__ double uniform(double v) {  // a value every lane holds -> scalar registers
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)u);
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Workgroup reductions with one barrier (the same scheme as CompRed in comp_kernel.hip.hpp).
+struct Red {
+    double* buf;  // 2 x 3 x 16 doubles
+    int* flags;   // 3 words
+    int flip, turn;
+    __device__ __forceinline__ void sum_max(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
+        using namespace ezpz::dev;
+        s0 = reduce_wave_to_last_lane(s0, OpSum());
+        m1 = reduce_wave_to_last_lane(m1, OpMax());
+        if (nwaves == 1) {  // one wavefront per system: no LDS, no barrier
+            s0 = uniform(__shfl(s0, 63, 64));
+            m1 = uniform(__shfl(m1, 63, 64));
+            return;
+        }
+        double* b = buf + (flip ? 48 : 0);
+        flip ^= 1;
+        if (lane == 63) {
+            b[wave] = s0;
+            b[16 + wave] = m1;
+        }
+        __syncthreads();
+        const bool in = (uint32_t)lane < nwaves;
+        const int l = lane & 15;
+        s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
+        m1 = uniform(reduce_lanes<16>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
+    }
+    __device__ __forceinline__ bool step(double& s0, double& m1, double& m2, bool flag, int lane, uint32_t wave, uint32_t nwaves) {
+        using namespace ezpz::dev;
+        s0 = reduce_wave_to_last_lane(s0, OpSum());
+        m1 = reduce_wave_to_last_lane(m1, OpMax());
+        m2 = reduce_wave_to_last_lane(m2, OpMax());
+        const bool any = __ballot(flag) != 0;
+        if (nwaves == 1) {
+            s0 = uniform(__shfl(s0, 63, 64));
+            m1 = uniform(__shfl(m1, 63, 64));
+            m2 = uniform(__shfl(m2, 63, 64));
+            return any;
+        }
+        double* b = buf + (flip ? 48 : 0);
+        flip ^= 1;
+        int* f = flags + turn;
+        const int next = turn == 2 ? 0 : turn + 1;
+        if (lane == 63) {
+            b[wave] = s0;
+            b[16 + wave] = m1;
+            b[32 + wave] = m2;
+            if (any) atomicOr(f, 1);
+            if (wave == 0) flags[next] = 0;  // last read two reductions ago, next set after this barrier
+        }
+        turn = next;
+        __syncthreads();
+        const bool in = (uint32_t)lane < nwaves;
+        const int l = lane & 15;
+        s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
+        m1 = uniform(reduce_lanes<16>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
+        m2 = uniform(reduce_lanes<16>(in ? b[32 + l] : __builtin_nan(""), OpMax()));
+        return __builtin_amdgcn_readfirstlane(*f) != 0;
+    }
+};
+
+// A DevCon with literal fields for the evaluators (the compiler folds the kind switch and indexes x by constants).
+__device__ __forceinline__ DevCon mkcon(uint32_t kind, uint32_t tag, uint32_t nrows, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3,
+                                        uint32_t i4, uint32_t i5, uint32_t i6, uint32_t i7, double weight, double param) {
+    DevCon c;
+    c.ids[0] = i0, c.ids[1] = i1, c.ids[2] = i2, c.ids[3] = i3, c.ids[4] = i4, c.ids[5] = i5, c.ids[6] = i6, c.ids[7] = i7;
+    c.param = param;
+    c.weight = weight;
+    c.row0 = 0, c.jbase = 0, c.pos = 0;
+    c.kind = (uint8_t)kind, c.tag = (uint8_t)tag, c.nrows = (uint8_t)nrows, c.nslots = 0;
+    return c;
+}
+
+// SEQ: Slots<...> of one wavefront; NWAVES wavefronts share a system; UNIT_W: every weight is 1.
+template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W>
+__device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
+    using namespace ezpz::dev;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    Red red;
+    red.buf = smem;
+    red.flags = reinterpret_cast<int*>(smem + 96);
+    red.flip = 0;
+    red.turn = 0;
+    int* nwarn2 = red.flags + 4;
+    if (tid < 8) red.flags[tid] = 0;
+    if (NWAVES > 1) __syncthreads();
+
+    // ---- this wavefront's slots: what never changes from system to system lives in registers for the whole launch ----
+    SEQ seq;
+    seq.each([&](auto& s, auto* cls, int index) {
+        using C = typename class_of<decltype(cls)>::type;
+        const uint32_t* t = a.blob + a.o_slots + 4 * ((size_t)wave * SEQ::N + index);
+        const uint32_t ids_off = t[0], par_off = t[1], pos_off = t[2], count = t[3];
+        s.active = (uint32_t)lane < count;
+#pragma unroll
+        for (int k = 0; k < C::NV; ++k) s.ids[k] = a.blob[ids_off + (size_t)k * C::STRIDE + lane];
+        const double* par = reinterpret_cast<const double*>(a.blob + par_off) + lane;
+#pragma unroll
+        for (int k = 0; k < C::NC; ++k) s.par[k] = par[(size_t)k * C::STRIDE];
+        s.pos = a.blob + pos_off + lane;
+        s.wmask = 0;
+    });
+
+    uint32_t parity = 0;
+    for (uint64_t sys = blockIdx.x; sys < a.batch; sys += gridDim.x, parity ^= 1u) {
+        const double* x0 = a.x0 + sys * a.n_row;
+        int* nwarn = nwarn2 + parity;
+        auto log_warning = [&](uint32_t pass, uint32_t pos) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
+            const int idx = atomicAdd(nwarn, 1);
+            if (a.warn_log && (uint32_t)idx < a.warn_cap) a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | pos;
+        };
+        auto log_mask = [&](auto& s, auto* cls, unsigned long long m, uint32_t pass) {
+            using C = typename class_of<decltype(cls)>::type;
+            if (!s.active) m = 0;
+            while (m) {
+                const int ci = __builtin_ctzll(m);
+                m &= m - 1;
+                log_warning(pass, s.pos[(size_t)ci * C::STRIDE]);
+            }
+        };
+
+        // ---- load the initial values; eval() (newton.rs:45, :232-236) ------------------------------------------------------------
+        double sq = 0.0, mx = __builtin_nan("");
+        seq.each([&](auto& s, auto* cls, int) {
+            using C = typename class_of<decltype(cls)>::type;
+#pragma unroll
+            for (int k = 0; k < C::NV; ++k) s.x[k] = x0[s.ids[k]];
+            unsigned long long wm = 0;
+            C::residuals(s.x, s.par, s.r, s.active, sq, mx, wm);
+            if constexpr (!C::LINEAR) {
+                log_mask(s, cls, wm, 0);
+                wm = 0;
+                C::jacobian(s.x, s.par, s.J, wm);
+                log_mask(s, cls, wm, 1);
+            }
+        });
+        red.sum_max(sq, mx, lane, wave, NWAVES);
+        double residual_sq = sq, largest = mx;
+        uint32_t pass = 2;
+        double lambda = a.initial_lambda;
+        uint32_t it = 0, iterations = a.max_iterations, converged = 0;
+        bool r_is_at_x = true;
+
+        // ---- the LM loop (newton.rs:47-139) ------------------------------------------------------------------------------------------
+        for (;;) {
+            if (it >= a.max_iterations) break;            // newton.rs:141-144
+            if (largest <= a.residual_tolerance) {        // newton.rs:50-60
+                iterations = it;
+                converged = 1;
+                break;
+            }
+            bool lane_bad = false;
+            double dmax = __builtin_nan("");
+            sq = 0.0;
+            mx = __builtin_nan("");
+            seq.each([&](auto& s, auto* cls, int) {
+                using C = typename class_of<decltype(cls)>::type;
+                // normal equations, Cholesky, substitutions of this lane's component (newton.rs:73-102)
+                double cd = __builtin_nan("");
+                const bool cb = C::solve(s.J, s.r, lambda, s.d, cd);
+                if (s.active) {
+                    lane_bad = lane_bad || cb;
+                    dmax = fmax(dmax, cd);
+                }
+                // residual at the tentative values (newton.rs:111-116), speculative: x moves only after the rendezvous
+                double xt[C::NV];
+#pragma unroll
+                for (int k = 0; k < C::NV; ++k) xt[k] = s.x[k] + s.d[k];
+                s.wmask = 0;
+                C::residuals(xt, s.par, s.rn, s.active, sq, mx, s.wmask);
+            });
+            const bool bad = red.step(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
+            if (bad) {  // numeric failure anywhere in the system => lambda *= 10, burn the iteration, x untouched
+                lambda *= LM_LAMBDA_INCR;
+                ++it;
+                continue;
+            }
+            const double step_inf_norm = (a.n_row > 0) ? dmax : 0.0;
+            const bool accept = sq < residual_sq;  // strict, newton.rs:118
+            const uint32_t pass_res = pass++;
+            const uint32_t pass_jac = pass;
+            if (accept) ++pass;
+            seq.each([&](auto& s, auto* cls, int) {
+                using C = typename class_of<decltype(cls)>::type;
+                if constexpr (!C::LINEAR) log_mask(s, cls, s.wmask, pass_res);
+                if (accept) {
+#pragma unroll
+                    for (int k = 0; k < C::NV; ++k) s.x[k] = s.x[k] + s.d[k];
+#pragma unroll
+                    for (int k = 0; k < C::M; ++k) s.r[k] = s.rn[k];
+                    if constexpr (!C::LINEAR) {
+                        unsigned long long wm = 0;
+                        C::jacobian(s.x, s.par, s.J, wm);
+                        log_mask(s, cls, wm, pass_jac);
+                    }
+                } else {  // reject: x += d, x -= d like the reference (newton.rs:111-114,:124-131), not a copy
+#pragma unroll
+                    for (int k = 0; k < C::NV; ++k) s.x[k] = (s.x[k] + s.d[k]) - s.d[k];
+                }
+            });
+            if (accept) {
+                lambda *= LM_LAMBDA_DECR;
+                residual_sq = sq;
+                largest = mx;
+                r_is_at_x = true;
+            } else {
+                r_is_at_x = false;  // x is now (x + d) - d, which may differ from the x of r in the last bit
+                lambda *= LM_LAMBDA_INCR;
+            }
+            if (step_inf_norm <= a.step_tolerance) {  // newton.rs:134-139
+                iterations = it;
+                converged = 1;
+                break;
+            }
+            ++it;
+        }
+
+        // ---- unsatisfied check (lib.rs:305-327, :358-370) and write-back -----------------------------------------------------------------
+        const bool use_r = r_is_at_x && UNIT_W;
+        const bool all_satisfied = use_r && largest < EPS && !isnan(residual_sq);
+        double unsat_cnt = 0.0;
+        double* xo = a.x_out + sys * a.n_row;
+        uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
+        seq.each([&](auto& s, auto* cls, int) {
+            using C = typename class_of<decltype(cls)>::type;
+            if (all_satisfied) {
+                if (mask && s.active)
+#pragma unroll
+                    for (int ci = 0; ci < C::NC; ++ci) mask[s.pos[(size_t)ci * C::STRIDE]] = 0;
+            } else if (use_r) {
+                C::unsatisfied_from_r(s.r, s.active, unsat_cnt, mask, s.pos);
+            } else {
+                C::unsatisfied(s.x, s.par, s.active, unsat_cnt, mask, s.pos);
+            }
+            if (s.active) {
+#pragma unroll
+                for (int k = 0; k < C::NV; ++k) xo[s.ids[k]] = s.x[k];
+            }
+        });
+        if (!all_satisfied || ANY_NONLINEAR) {
+            double none = __builtin_nan("");
+            red.sum_max(unsat_cnt, none, lane, wave, NWAVES);
+        }
+        if (tid == 0) {
+            EzpzStatus st;
+            st.iterations = iterations;
+            st.converged = converged;
+            st.n_unsatisfied = (uint32_t)unsat_cnt;
+            st.n_warnings = ANY_NONLINEAR ? (uint32_t)*nwarn : 0u;
+            st.final_residual_inf = (a.n_rows_total > 0) ? largest : 0.0;
+            st.final_lambda = lambda;
+            a.status[sys] = st;
+            if (ANY_NONLINEAR) *nwarn = 0;  // serves the workgroup's system after next (see comp_kernel.hip.hpp)
+        }
+    }
+}
+
+}  // namespace jit
+}  // namespace ezpz

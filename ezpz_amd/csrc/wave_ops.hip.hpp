@@ -2,7 +2,9 @@
 // constants, the two reduction operators of the LM control (sum of squares, NaN-ignoring maximum) and cross-lane
 // reductions on DPP moves (no LDS crossbar traffic) for gfx950's 64-wide wavefronts.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace ezpz {
 namespace dev {

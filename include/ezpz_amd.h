@@ -16,8 +16,18 @@
 #ifndef EZPZ_AMD_H
 #define EZPZ_AMD_H
 
+#ifndef __HIPCC_RTC__
 #include <stddef.h>
 #include <stdint.h>
+#else /* run-time compilation of the device kernels (hiprtc has no system headers) */
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+typedef int int32_t;
+typedef long long int64_t;
+typedef unsigned long long uintptr_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -261,6 +271,19 @@ int ezpz_solve_batch(const EzpzConstraint* reqs, size_t n_reqs, size_t n_vars, c
  * (values by id, id == index).  ezpz_solve / ezpz_solve_batch do this themselves; callers of the handle API
  * (ezpz_system_create takes side-resolved tiers) use this first. */
 int ezpz_resolve_sides(EzpzConstraint* cs, size_t n_cs, const double* values, size_t n_vars);
+
+/* ---- class-specialised kernels ------------------------------------------------------------------------------------
+ * Systems that run component-resident (EzpzSystemInfo.team_mode 3) can have their kernel compiled at run time
+ * (hiprtc) into straight-line code for exactly their classes of components: same operations in the same order,
+ * state in registers instead of LDS.  Batch calls of >= 1024 systems start that compilation on a background thread
+ * and switch to the specialised kernel once it is ready (results are bit-identical either way); EZPZ_JIT=0 in the
+ * environment turns it off.  ezpz_system_specialize starts it explicitly and, with wait != 0, returns when it is
+ * done: 2 = ready, 1 = still compiling, 0 = this system has no specialised form, negative = compilation failed.
+ * ezpz_specialized_source (no device needed) writes the generated source of a request into buf (NUL-terminated,
+ * truncated to cap) and returns its length, 0 when the request gets no component plan; with compile != 0 it also
+ * compiles it for gfx950 and returns a negative error with the compiler's log in buf on failure. */
+int ezpz_system_specialize(EzpzSystem* sys, int wait);
+long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int compile, char* buf, size_t cap);
 
 /* ezpz_solve / ezpz_solve_inner keep a small cache of analysed topologies keyed by the request bytes, so that
  * repeated solves of one problem (ezpz-cli's 100-run loop, main.rs:96-98) skip the symbolic phase.  This drops

@@ -156,3 +156,28 @@ def test_product_never_imports_the_oracle():
         if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
             src = open(path).read()
             assert "oracle" not in src.lower() or path.endswith("kinds.hpp"), path
+
+
+def test_specialized_kernel_source_compiles_without_a_device():
+    """The class-specialised kernel of a component plan: generated source + the embedded device headers compile for
+    gfx950 with hiprtc here (no GPU needed); requests without a component plan have none."""
+    import ezpz_amd as E
+    from oracle import oracle as O
+    from oracle import textual as T
+
+    ref = T.load(T.gen_big_problem(200))
+    src = E.specialized_source(ref.constraints, ref.num_vars, compile=True)
+    assert "struct Cls0" in src and "struct Cls1" in src and "ezpz_jit_solve" in src
+    # a non-linear class (distance per line) and an arc fixture replicated: the general evaluators compile too
+    ref = T.load(T.gen_big_problem(150, True))
+    assert "con_jacobian" in E.specialized_source(ref.constraints, ref.num_vars, compile=True)
+    ref = T.load(open(os.path.join(GOLDEN, "test_cases", "arc_length", "problem.md")).read())
+    recs = []
+    for r in range(130):
+        for c in ref.constraints:
+            c = O.set_from_initial_values(c, ref.guesses).copy()
+            c["ids"] = c["ids"] + r * ref.num_vars
+            recs.append(c)
+    assert E.specialized_source(O.stack(recs), 130 * ref.num_vars, compile=True)
+    ref = T.load(open(os.path.join(GOLDEN, "test_cases", "square", "problem.md")).read())
+    assert E.specialized_source(ref.constraints, ref.num_vars) == ""

@@ -56,6 +56,16 @@ def solve_both(E, recs, x0, cfg=None, linsolve=O.LINSOLVE_SPARSE, expect_mode=3)
     assert np.array_equal(st["converged"], conv)
     assert np.array_equal(st["n_unsatisfied"], nun)
     assert np.array_equal(mask.sum(axis=1), nun)
+    # the class-specialised kernel (run-time compiled straight-line code, state in registers): same bits as the
+    # interpreter in every output, including the warning log
+    xl, stl, logs = sysobj.solve_batch_logged(x0, E.Config(**cfg), warn_cap=256)
+    assert sysobj.specialize(wait=True) == 2
+    x2, st2, mask2 = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    assert np.array_equal(x2, x, equal_nan=True) and np.array_equal(mask2, mask)
+    for f in st.dtype.names:
+        assert np.array_equal(st2[f], st[f], equal_nan=True), f
+    x3, st3, logs3 = sysobj.solve_batch_logged(x0, E.Config(**cfg), warn_cap=256)
+    assert np.array_equal(x3, xl, equal_nan=True) and logs3 == logs
     return sysobj, x, st, mask, xo
 
 
@@ -177,6 +187,9 @@ def test_degenerate_warnings_and_failed_pivots(E):
         assert got.warnings == want.warnings and len(want.warnings) > 0
         assert np.array_equal(np.isnan(got.final_values), np.isnan(want.final_values))
         assert_x_close(got.final_values, want.final_values)
+        # the same through the interpreter and the specialised kernel (solve_both compares their logs entry by entry)
+        sysobj, x, st, mask, xo = solve_both(E, recs, np.stack([gg, gg]), cfg)
+        assert int(st["n_warnings"][0]) == len(want.warnings)
 
 
 def test_iteration_limits_and_tolerances(E):
