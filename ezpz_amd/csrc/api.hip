@@ -137,6 +137,7 @@ struct EzpzSystem {
     std::unique_ptr<CompPlan> comp;
     uint32_t* dev_comp = nullptr;
     CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
+    std::unique_ptr<LanePlan> lane;  // small systems: one lane per system, run-time compiled (jit stands for it then)
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
     DevBuf<GridScratch> grid_scratch;
@@ -385,30 +386,45 @@ int launch_grid_team(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     return s.linear_only ? launch_grid_kernel<true>(s, args, stream) : launch_grid_kernel<false>(s, args, stream);
 }
 
+CompLaunch comp_launch_args(const SolveArgs& args) {
+    CompLaunch L{};
+    L.x0 = args.x0;
+    L.x_out = args.x_out;
+    L.status = args.status;
+    L.unsat_mask = args.unsat_mask;
+    L.warn_log = args.warn_log;
+    L.warn_cap = args.warn_cap;
+    L.batch = args.batch;
+    L.max_iterations = args.max_iterations;
+    L.residual_tolerance = args.residual_tolerance;
+    L.step_tolerance = args.step_tolerance;
+    L.initial_lambda = args.initial_lambda;
+    return L;
+}
+
+bool jit_sync() {
+    static const bool sync = [] {
+        const char* e = std::getenv("EZPZ_JIT");
+        return e && std::strcmp(e, "sync") == 0;
+    }();
+    return sync;
+}
+
 int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
+    if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
+        int st = comp_jit_state(s.jit);
+        if (st == 0 && (args.batch >= 4096 || jit_sync())) st = comp_jit_request(s.jit, jit_sync());
+        if (st == 2 && lane_jit_launch(s.jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+    }
     if (s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
-        CompLaunch L{};
-        L.x0 = args.x0;
-        L.x_out = args.x_out;
-        L.status = args.status;
-        L.unsat_mask = args.unsat_mask;
-        L.warn_log = args.warn_log;
-        L.warn_cap = args.warn_cap;
-        L.batch = args.batch;
-        L.max_iterations = args.max_iterations;
-        L.residual_tolerance = args.residual_tolerance;
-        L.step_tolerance = args.step_tolerance;
-        L.initial_lambda = args.initial_lambda;
+        const CompLaunch L = comp_launch_args(args);
         // the class-specialised kernel once it is compiled; large batches start its compilation (background thread)
         if (s.jit) {
-            static const bool sync = [] {
-                const char* e = std::getenv("EZPZ_JIT");
-                return e && std::strcmp(e, "sync") == 0;
-            }();
+            const bool sync = jit_sync();
             int st = comp_jit_state(s.jit);
             if (st == 0 && (args.batch >= 1024 || sync)) st = comp_jit_request(s.jit, sync);
-            if (st == 2 && comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+            if (st == 2 && comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
         }
         return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
     }
@@ -1032,9 +1048,14 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             s.comp = std::move(plan);
         }
     }
+    // ---- one lane per system: small systems that are not block systems (sub-wavefront teams otherwise) -----------------------
+    s.lane.reset();
+    if (auto_shape && comp_enabled && !s.comp && s.mode == MODE_SUB) {
+        std::unique_ptr<LanePlan> lp(new LanePlan());
+        if (lane_plan_build(cs, n_cs, n_vars, *lp)) s.lane = std::move(lp);
+    }
     return EZPZ_OK;
 }
-
 
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable) {
@@ -1061,6 +1082,8 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
         HIP_TRY(hipMalloc((void**)&s->dev_comp, s->comp->blob.size() * 4));
         HIP_TRY(hipMemcpy(s->dev_comp, s->comp->blob.data(), s->comp->blob.size() * 4, hipMemcpyHostToDevice));
         s->jit = comp_jit_create(*s->comp);
+    } else if (s->lane) {
+        s->jit = comp_jit_create_source(s->lane->jit_source, "ezpz_jit_lane");
     }
     *out = s.release();
     return EZPZ_OK;
@@ -1269,13 +1292,19 @@ int ezpz_system_specialize(EzpzSystem* sys, int wait) {
 long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int compile, char* buf, size_t cap) {
     CompPlan plan;
     CompLimits cl;
-    if (!comp_plan_build(cs, n_cs, n_vars, cl, plan) || plan.jit_source.empty()) return 0;
-    std::string text = plan.jit_source;
+    LanePlan lane;
+    std::string text;
+    if (comp_plan_build(cs, n_cs, n_vars, cl, plan))
+        text = plan.jit_source;
+    else if (lane_plan_build(cs, n_cs, n_vars, lane))
+        text = lane.jit_source;
+    if (text.empty()) return 0;
+    const std::string source = text;
     long rc = (long)text.size();
     if (compile) {
         std::vector<char> code;
         std::string log;
-        if (comp_jit_compile(plan.jit_source, code, log) != EZPZ_OK) {
+        if (comp_jit_compile(source, code, log) != EZPZ_OK) {
             text = log;
             rc = EZPZ_ERR_HIP;
         }

@@ -120,7 +120,9 @@ std::string hexf(double v) {
     return std::string("(") + buf + ")";
 }
 
-void emit_class(std::string& o, size_t k, const Class& cl) {
+// `lane`: the class is a whole system solved by one lane (jit_kernel.hip.hpp, lane_kernel): constraint parameters and
+// the caller's constraint positions are literals, and load / store / pos_of map the caller's numbering.
+void emit_class(std::string& o, size_t k, const Class& cl, bool lane = false, const EzpzConstraint* cs = nullptr) {
     const Program& Q = cl.Q;
     const uint32_t nv = Q.c.n_vars, m = Q.c.n_rows, zj = Q.c.zj, zlo = Q.c.zlo, nc = Q.c.n_cons;
     const bool lin = cl.linear;
@@ -128,7 +130,7 @@ void emit_class(std::string& o, size_t k, const Class& cl) {
     auto con_expr = [&](const DevCon& d, uint32_t ci) {
         std::string e = "ezpz::jit::mkcon(" + S(d.kind) + ", " + S(d.tag) + ", " + S(d.nrows);
         for (int i = 0; i < 8; ++i) e += ", " + S(d.ids[i]);
-        e += ", " + hexf(d.weight) + ", par[" + S(ci) + "])";
+        e += ", " + hexf(d.weight) + ", " + (lane ? hexf(cs[d.pos].param) : "par[" + S(ci) + "]") + ")";
         return e;
     };
     o += "struct Cls" + S((uint32_t)k) + " {\n";
@@ -139,7 +141,12 @@ void emit_class(std::string& o, size_t k, const Class& cl) {
     // residual sweep (solver.rs:318-356): r = weight * residual, sum of squares, maximum, degenerate mask
     o += "    static __device__ __forceinline__ void residuals(" + xs + ", double (&r)[" + S(std::max(m, 1u)) +
          "], bool active, double& sq, double& mx, unsigned long long& wm) {\n";
-    for (uint32_t ci = 0; ci < nc; ++ci) {
+    // (one lane per system: in request order, so that the sum of squares is formed exactly like the reference's
+    // sequential sum over the rows -- the accept test `sum < previous` of a stalled solve hinges on its last bit)
+    std::vector<uint32_t> sweep(nc);
+    std::iota(sweep.begin(), sweep.end(), 0u);
+    if (lane) std::sort(sweep.begin(), sweep.end(), [&](uint32_t a, uint32_t b) { return Q.cons[a].pos < Q.cons[b].pos; });
+    for (uint32_t ci : sweep) {
         const DevCon& d = Q.cons[ci];
         o += "        { const DevCon c = " + con_expr(d, ci) + "; double r0, r1; const bool deg = ezpz::dev::con_residual<LINEAR>(c, x, r0, r1);\n";
         o += "          const double w0 = c.weight * r0; r[" + S(d.row0) + "] = w0; if (active) { sq += w0 * w0; mx = fmax(mx, fabs(w0)); }\n";
@@ -212,7 +219,7 @@ void emit_class(std::string& o, size_t k, const Class& cl) {
         const DevCon& d = Q.cons[ci];
         o += "        { const DevCon c = " + con_expr(d, ci) + "; double r0, r1; ezpz::dev::con_residual<LINEAR>(c, x, r0, r1);\n";
         o += std::string("          bool sat = fabs(r0) < ezpz::dev::EPS;") + (d.nrows > 1 ? " sat = sat && (fabs(r1) < ezpz::dev::EPS);" : "") + "\n";
-        o += "          if (active) { if (!sat) unsat += 1.0; if (mask) mask[pos[(size_t)" + S(ci) + " * STRIDE]] = sat ? 0 : 1; } (void)r1; }\n";
+        o += "          if (active) { if (!sat) unsat += 1.0; if (mask) mask[" + (lane ? S(d.pos) : "pos[(size_t)" + S(ci) + " * STRIDE]") + "] = sat ? 0 : 1; } (void)r1; }\n";
     }
     o += "        (void)x; (void)par; (void)active; (void)unsat; (void)mask; (void)pos;\n    }\n";
     o += "    static __device__ __forceinline__ void unsatisfied_from_r(const double (&r)[" + S(std::max(m, 1u)) +
@@ -221,9 +228,18 @@ void emit_class(std::string& o, size_t k, const Class& cl) {
         const DevCon& d = Q.cons[ci];
         o += "        { bool sat = fabs(r[" + S(d.row0) + "]) < ezpz::dev::EPS;" +
              (d.nrows > 1 ? " sat = sat && (fabs(r[" + S(d.row0 + 1) + "]) < ezpz::dev::EPS);" : "") + "\n";
-        o += "          if (active) { if (!sat) unsat += 1.0; if (mask) mask[pos[(size_t)" + S(ci) + " * STRIDE]] = sat ? 0 : 1; } }\n";
+        o += "          if (active) { if (!sat) unsat += 1.0; if (mask) mask[" + (lane ? S(d.pos) : "pos[(size_t)" + S(ci) + " * STRIDE]") + "] = sat ? 0 : 1; } }\n";
     }
     o += "        (void)r; (void)active; (void)unsat; (void)mask; (void)pos;\n    }\n";
+    if (lane) {  // the caller's numbering: variables (row of x0 / x_out) and constraint positions
+        o += "    static __device__ __forceinline__ void load(const double* row, double (&x)[" + S(nv) + "]) {\n       ";
+        for (uint32_t v = 0; v < nv; ++v) o += " x[" + S(v) + "] = row[" + S(Q.var_of[v]) + "];";
+        o += "\n    }\n    static __device__ __forceinline__ void store(double* row, const double (&x)[" + S(nv) + "]) {\n       ";
+        for (uint32_t v = 0; v < nv; ++v) o += " row[" + S(Q.var_of[v]) + "] = x[" + S(v) + "];";
+        o += "\n    }\n    static __device__ __forceinline__ uint32_t pos_of(int ci) {\n        switch (ci) {\n";
+        for (uint32_t ci = 0; ci < nc; ++ci) o += "        case " + S(ci) + ": return " + S(Q.cons[ci].pos) + ";\n";
+        o += "        default: return 0;\n        }\n    }\n";
+    }
     o += "};\n\n";
 }
 
@@ -642,6 +658,49 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             plan.jit_slots = nslots;
         }
     }
+    return true;
+}
+
+// ---- one lane per system (jit_kernel.hip.hpp, lane_kernel) --------------------------------------------------------------------------
+bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LanePlan& plan) {
+    plan = LanePlan();
+    // what a lane can hold in registers: x, the accepted x, r, r_next, d, the Jacobian values of one iteration, L
+    if (n_cs == 0 || n_vars == 0 || n_vars > 20 || n_cs > 40) return false;
+    Class cl;
+    BuildError be;
+    if (!build_program(cs, n_cs, n_vars, cl.Q, be, 1, false)) return false;
+    const Program& Q = cl.Q;
+    if (Q.c.zj + Q.c.zlo > 220 || Q.c.n_rows > 48) return false;
+    plan.unit_weights = true;
+    for (const DevCon& d : Q.cons) {
+        cl.linear = cl.linear && kind_is_linear(d.kind);
+        if (d.weight != 1.0) plan.unit_weights = false;
+    }
+    if (cl.linear) {
+        cl.jconst.assign(Q.c.zj, 0.0);
+        for (const DevCon& d : Q.cons) {
+            double pd[8];
+            const int np = linear_partials(d.kind, pd);
+            for (int e = 0; e < np; ++e) {
+                const uint32_t code = d.jloc[e];
+                const uint32_t slot = d.jbase + (code & 0x7Fu);
+                const double w = d.weight * pd[e];
+                if (code & 0x80u)
+                    cl.jconst[slot] = cl.jconst[slot] + w;
+                else
+                    cl.jconst[slot] = w;
+            }
+        }
+    }
+    cl.H.ninst_pad = 1;
+    std::string& o = plan.jit_source;
+    o = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
+    emit_class(o, 0, cl, true, cs);
+    o += "extern \"C\" __global__ void __launch_bounds__(256) ezpz_jit_lane(const ezpz::jit::LaneArgs a) {\n";
+    o += std::string("    ezpz::jit::lane_kernel<Cls0, ") + (plan.unit_weights ? "true" : "false") + ">(a);\n}\n";
+    plan.n_vars = (uint32_t)n_vars;
+    plan.n_cons = (uint32_t)n_cs;
+    plan.n_rows = Q.c.n_rows;
     return true;
 }
 

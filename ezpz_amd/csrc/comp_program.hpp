@@ -116,16 +116,27 @@ int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch
 
 namespace ezpz {
 
+// One lane per system (jit_kernel.hip.hpp, lane_kernel): batches of one small system (<= 20 variables) as run-time
+// compiled straight-line code, every lane running the whole LM loop of its own system.
+struct LanePlan {
+    std::string jit_source;
+    uint32_t n_vars = 0, n_cons = 0, n_rows = 0;
+    bool unit_weights = true;
+};
+bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LanePlan& plan);
+
 // The class-specialised kernel of a plan (jit.cpp): run-time compiled (hiprtc) on a background thread.
 // comp_jit_create returns nullptr when the plan carries no source or EZPZ_JIT=0.  comp_jit_request starts the
 // compilation if it has not started (and waits for it if asked); returns 0 idle, 1 compiling, 2 ready, -1 failed.
 struct CompJit;
 CompJit* comp_jit_create(const CompPlan& plan);
+CompJit* comp_jit_create_source(const std::string& source, const char* entry);
+int lane_jit_launch(CompJit* jit, const LanePlan& plan, const CompLaunch& launch, int device, int cus, void* stream);
 void comp_jit_destroy(CompJit* jit);
 int comp_jit_request(CompJit* jit, bool wait);
 int comp_jit_state(const CompJit* jit);
 const char* comp_jit_log(const CompJit* jit);
-int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int cus, void* stream);
+int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus, void* stream);
 int comp_jit_compile(const std::string& source, std::vector<char>& code, std::string& log);
 
 }  // namespace ezpz

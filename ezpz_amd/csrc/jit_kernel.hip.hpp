@@ -345,5 +345,165 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     }
 }
 
+// ---- one LANE per system ------------------------------------------------------------------------------------------------------
+// Batches of one small system (a sketch fixture: <= ~24 variables, one or a few components) need no cross-lane traffic at
+// all: every lane runs the whole LM loop of newton.rs:29-145 on its own system with its own lambda / accept / iteration
+// count, state in registers, and picks the next system of the batch when it is done (persistent lanes: a wavefront's
+// lanes are at different iterations of different systems, none waits for the slowest).  Sums run in row order on one
+// lane -- the reference's own order.  The class struct is the same straight-line code as above with the constraint
+// parameters as literals (every system of the batch shares them); C::load / C::store map the caller's variable order.
+// The Jacobian is not kept between iterations: it is re-evaluated at `xj`, the values of the last accepted step (where
+// the reference refreshed it, newton.rs:121) -- the same bits, fewer live registers; its Degenerate warnings are logged
+// the first time only, like the reference's one refresh.
+struct LaneArgs {
+    const double* x0;
+    double* x_out;
+    EzpzStatus* status;
+    uint8_t* unsat_mask;  // optional
+    uint64_t* warn_log;   // optional
+    uint32_t warn_cap, max_iterations;
+    uint32_t n_row, n_cons;
+    uint64_t batch;
+    double residual_tolerance, step_tolerance, initial_lambda;
+};
+static_assert(sizeof(LaneArgs) == 88, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
+
+template <class C, bool UNIT_W>
+__device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
+    using namespace ezpz::dev;
+    constexpr int NV = C::NV, M = C::M > 0 ? C::M : 1, ZJ = C::ZJS > 0 ? C::ZJS : 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t next = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool have = false;
+    uint64_t sys = 0;
+    double x[NV], xj[NV], r[M];
+    const double par[C::NC > 0 ? C::NC : 1] = {};  // unused: parameters are literals in the class code
+    double residual_sq = 0.0, largest = 0.0, lambda = 0.0;
+    uint32_t it = 0, pass = 0, pass_jac = 0, nwarn = 0;
+    bool r_is_at_x = true, fresh = false;
+    for (;;) {
+        auto log_mask = [&](unsigned long long m, uint32_t p) {  // Warning::Degenerate, in evaluation order (solver.rs:340-346)
+            while (m) {
+                const int ci = __builtin_ctzll(m);
+                m &= m - 1;
+                if (a.warn_log && nwarn < a.warn_cap) a.warn_log[sys * a.warn_cap + nwarn] = ((uint64_t)p << 32) | C::pos_of(ci);
+                ++nwarn;
+            }
+        };
+        if (!have && next < a.batch) {  // ---- the next system of the batch: eval() (newton.rs:45, :232-236) ----
+            sys = next;
+            next += stride;
+            have = true;
+            C::load(a.x0 + sys * a.n_row, x);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) xj[k] = x[k];
+            nwarn = 0;
+            double sq = 0.0, mx = __builtin_nan("");
+            unsigned long long wm = 0;
+            C::residuals(x, par, r, true, sq, mx, wm);
+            log_mask(wm, 0);
+            residual_sq = sq;
+            largest = mx;
+            lambda = a.initial_lambda;
+            it = 0;
+            pass = 2;
+            pass_jac = 1;
+            fresh = true;  // the Jacobian of eval() is evaluated (and its warnings logged) by the first iteration, or at the end
+            r_is_at_x = true;
+        }
+        if (!__any(have)) break;
+        if (!have) continue;
+        bool finish = false;
+        uint32_t iterations = a.max_iterations, converged = 0;
+        if (it >= a.max_iterations) {  // newton.rs:141-144
+            finish = true;
+        } else if (largest <= a.residual_tolerance) {  // newton.rs:50-60
+            iterations = it;
+            converged = 1;
+            finish = true;
+        } else {
+            double J[ZJ];
+            if constexpr (!C::LINEAR) {
+                unsigned long long wm = 0;
+                C::jacobian(xj, par, J, wm);
+                if (fresh) log_mask(wm, pass_jac);
+                fresh = false;
+            }
+            double d[NV], dmax = __builtin_nan("");
+            const bool bad = C::solve(J, r, lambda, d, dmax);
+            if (bad) {  // LltError::Numeric: lambda *= 10, burn the iteration (newton.rs:93-99)
+                lambda *= LM_LAMBDA_INCR;
+                ++it;
+            } else {
+                double xt[NV], rn[M];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) xt[k] = x[k] + d[k];  // newton.rs:111-114
+                double sq = 0.0, mx = __builtin_nan("");
+                unsigned long long wm = 0;
+                C::residuals(xt, par, rn, true, sq, mx, wm);
+                log_mask(wm, pass++);
+                if (sq < residual_sq) {  // strict, newton.rs:118
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) x[k] = xt[k], xj[k] = xt[k];
+#pragma unroll
+                    for (int k = 0; k < M; ++k) r[k] = rn[k];
+                    lambda *= LM_LAMBDA_DECR;
+                    residual_sq = sq;
+                    largest = mx;
+                    r_is_at_x = true;
+                    fresh = !C::LINEAR;  // newton.rs:121: refresh_jacobian (evaluated lazily, see above)
+                    pass_jac = pass++;
+                } else {  // reject: x += d, x -= d like the reference (newton.rs:124-131), not a copy
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) x[k] = xt[k] - d[k];
+                    lambda *= LM_LAMBDA_INCR;
+                    r_is_at_x = false;
+                }
+                if (dmax <= a.step_tolerance) {  // newton.rs:134-139
+                    iterations = it;
+                    converged = 1;
+                    finish = true;
+                } else {
+                    ++it;
+                }
+            }
+        }
+        if (finish) {
+            if constexpr (!C::LINEAR) {
+                if (fresh) {  // the refresh of the last accepted step (or of eval()) still owes its warnings
+                    double J[ZJ];
+                    unsigned long long wm = 0;
+                    C::jacobian(xj, par, J, wm);
+                    log_mask(wm, pass_jac);
+                    fresh = false;
+                }
+            }
+            // unsatisfied check (lib.rs:305-327, :358-370)
+            double unsat = 0.0;
+            uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
+            const bool use_r = r_is_at_x && UNIT_W;
+            if (use_r && largest < EPS && !isnan(residual_sq)) {
+                if (mask)
+#pragma unroll
+                    for (int ci = 0; ci < C::NC; ++ci) mask[C::pos_of(ci)] = 0;
+            } else if (use_r) {
+                C::unsatisfied_from_r(r, true, unsat, mask, nullptr);
+            } else {
+                C::unsatisfied(x, par, true, unsat, mask, nullptr);
+            }
+            C::store(a.x_out + sys * a.n_row, x);
+            EzpzStatus st;
+            st.iterations = iterations;
+            st.converged = converged;
+            st.n_unsatisfied = (uint32_t)unsat;
+            st.n_warnings = nwarn;
+            st.final_residual_inf = (C::M > 0) ? largest : 0.0;
+            st.final_lambda = lambda;
+            a.status[sys] = st;
+            have = false;
+        }
+    }
+}
+
 }  // namespace jit
 }  // namespace ezpz

@@ -179,5 +179,14 @@ def test_specialized_kernel_source_compiles_without_a_device():
             c["ids"] = c["ids"] + r * ref.num_vars
             recs.append(c)
     assert E.specialized_source(O.stack(recs), 130 * ref.num_vars, compile=True)
-    ref = T.load(open(os.path.join(GOLDEN, "test_cases", "square", "problem.md")).read())
-    assert E.specialized_source(ref.constraints, ref.num_vars) == ""
+    # small systems: one lane per system, parameters as literals
+    for case in ("square", "two_rectangles", "circle_tangent", "arc_radius", "parallelogram", "tiny"):
+        ref = T.load(open(os.path.join(GOLDEN, "test_cases", case, "problem.md")).read())
+        recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
+        src = E.specialized_source(recs, ref.num_vars, compile=True)
+        assert "ezpz_jit_lane" in src and "lane_kernel" in src, case
+    # too large for either form: a connected sketch of 60 variables
+    import gen
+
+    recs, g = gen.connected_sketch(30, 1)
+    assert E.specialized_source(recs, len(g)) == ""

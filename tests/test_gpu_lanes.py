@@ -1,0 +1,153 @@
+"""GPU parity tests (-m gpu) of the lane-per-system specialised kernel (jit_kernel.hip.hpp: lane_kernel): batches of one
+small system as run-time compiled straight-line code, every lane running the LM loop of its own system.  Through the C
+ABI, against the CPU oracle, the committed golden vectors and the sub-wavefront list-walk kernels."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gen
+from conftest import GOLDEN, read_case
+from oracle import oracle as O
+from oracle import textual as T
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def E():
+    import ezpz_amd
+
+    if ezpz_amd.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device: the product path has no CPU fallback")
+    return ezpz_amd
+
+
+def assert_x_close(got, want, rel=REL):
+    got, want = np.asarray(got), np.asarray(want)
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and (not np.any(~np.isnan(err)) or np.nanmax(err) <= rel), float(np.nanmax(err))
+
+
+def lanes(E, recs, n):
+    sysobj = E.System(recs, n)
+    assert sysobj.info()["team_mode"] == 0
+    assert sysobj.specialize(wait=True) == 2
+    return sysobj
+
+
+def test_golden_vectors_on_the_lane_kernel(E):
+    """Every committed vector (28 fixtures x 4 guess variants) as one batch per fixture: iterations, flags, unsatisfied
+    mask, warning count and log order, residual norm; determined coordinates at 1e-6, the variables the oracle's
+    FreedomAnalysis flags as underconstrained at 20x the oracle's own one-ulp sensitivity (never beyond 1e-4)."""
+    vectors = json.load(open(os.path.join(GOLDEN, "oracle_vectors.json")))
+    done = 0
+    for case, recs in vectors.items():
+        ref = T.load(open(os.path.join(GOLDEN, "test_cases", case)).read())
+        by_sides = {}
+        for rec in recs:  # side inference happens above the handle API: group the variants by the sides they infer
+            resolved = O.stack([O.set_from_initial_values(c, np.asarray(rec["guesses"])) for c in ref.constraints])
+            by_sides.setdefault(resolved.tobytes(), (resolved, []))[1].append(rec)
+        for resolved, group in by_sides.values():
+            if E.specialized_source(resolved, ref.num_vars) == "":
+                continue
+            sysobj = lanes(E, resolved, ref.num_vars)
+            x0 = np.asarray([rec["guesses"] for rec in group])
+            x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+            _, _, logs = sysobj.solve_batch_logged(x0, warn_cap=4096)
+            for b, rec in enumerate(group):
+                assert int(st["iterations"][b]) == rec["iterations"], (case, b)
+                assert bool(st["converged"][b]) == rec["converged"], case
+                assert np.nonzero(mask[b])[0].tolist() == rec["unsatisfied"], case
+                assert int(st["n_warnings"][b]) == rec["n_warnings"], case
+                assert logs[b] == sorted(logs[b]), case  # written in the reference's order already
+                want = np.asarray(rec["final_values"])
+                free = np.zeros(len(want), dtype=bool)
+                free[rec["underconstrained"]] = True
+                if np.any(~free):
+                    assert_x_close(x[b][~free], want[~free], REL)
+                if np.any(free):
+                    assert_x_close(x[b][free], want[free], min(1e-4, max(REL, 20.0 * rec["ulp_sensitivity"])))
+                assert abs(float(st["final_residual_inf"][b]) - rec["final_residual_inf"]) <= 1e-9, case
+                done += 1
+    assert done >= 100
+
+
+@pytest.mark.parametrize("case", ["square", "two_rectangles", "circle_tangent", "arc_radius", "chamfer_square", "perpendicular",
+                                  "symmetric", "tiny", "nonsquare", "arc_length"])
+def test_jittered_batches_match_the_oracle_and_the_list_walk_kernel(E, case):
+    ref = T.load(read_case(case))
+    recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
+    B = 5000
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(99, B, ref.num_vars, -0.1, 0.1)
+    x0[0] = ref.guesses
+    cfg = dict(max_iterations=60)
+    walk = E.System(recs, ref.num_vars, team_size=E.TEAM_AUTO_LISTS)
+    xw, stw, maskw = walk.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    sysobj = lanes(E, recs, ref.num_vars)
+    x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg))
+    assert rc == 0
+    assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv) and np.array_equal(st["n_unsatisfied"], nun)
+    assert np.array_equal(mask, maskw) and np.array_equal(st["n_warnings"], stw["n_warnings"])
+    free = sysobj.freedom_batch(x[:64])[0].astype(bool).any(axis=0)
+    assert_x_close(x[:, ~free], xo[:, ~free])
+    assert_x_close(x[:, free], xo[:, free], 2e-4)
+    assert np.max(np.abs(st["final_residual_inf"] - stw["final_residual_inf"])) <= 1e-9
+    # ragged batch sizes: fewer systems than lanes, not a multiple of the wavefront
+    for b in (1, 3, 65, 257):
+        xs, sts, _ = sysobj.solve_batch(x0[:b], E.Config(**cfg))
+        assert np.array_equal(xs, x[:b]) and np.array_equal(sts["iterations"], st["iterations"][:b])
+
+
+def test_square_random_integer_guesses_full_size(E):
+    """BASELINE configs[2]: 65 536 x square with the reference's own proptest distribution (proptests.rs:294-329): every
+    system against the oracle (3 ... 21 iterations; lanes of a wavefront finish at different times and pick up new
+    systems), geometry a 4 x 4 square."""
+    ref = T.load(read_case("square"))
+    B = 65536
+    x0 = gen.keyed_uniform(0x657A707A, B, 8, -10000, 10000, integer=True)
+    sysobj = lanes(E, ref.constraints, ref.num_vars)
+    x, st, _ = sysobj.solve_batch(x0)
+    assert np.all(st["n_unsatisfied"] == 0) and np.all(st["converged"] == 1)
+    a, b, c, d = x[:, 0:2], x[:, 2:4], x[:, 4:6], x[:, 6:8]
+    assert np.all(np.abs(a) < 1e-4) and np.all(np.abs(c - 4.0) < 1e-4)
+    assert np.all(np.abs(b - np.array([4.0, 0.0])) < 1e-4) and np.all(np.abs(d - np.array([0.0, 4.0])) < 1e-4)
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0)
+    assert np.array_equal(st["iterations"], it) and len(np.unique(it)) > 10
+    assert_x_close(x, xo)
+
+
+def test_weights_warnings_and_failed_pivots_per_lane(E):
+    """Per-lane LM control: non-unit weights, degenerate evaluations (warnings in the reference's order, none for the
+    sweep of a failed factorisation), NaN guesses in some systems of the batch only.  The system is consistent: a solve
+    that stalls at a least-squares minimum takes or rejects its last steps on the last bit of the residual sum, where
+    device and host libm differ, so exact warning counts are only defined for solves that converge."""
+    recs = O.stack([O.distance((0, 1), (2, 3), 3.0), O.fixed(0, 0.0, weight=2.5), O.fixed(1, 0.0), O.horizontal((0, 1), (2, 3)),
+                    O.fixed(2, 3.0, weight=0.5), O.points_at_angle((0, 1), (2, 3), (4, 5), ("deg", 90.0)), O.fixed(5, 2.0)])
+    n = 6
+    x0 = gen.keyed_uniform(5, 3000, n, -2.0, 2.0)
+    x0[:, 2] += 3.0
+    x0[::7, 2:4] = x0[::7, 0:2]  # coincident points: Degenerate warnings
+    x0[5::11, 4] = np.nan
+    checked_warnings = 0
+    for cfg in (dict(), dict(initial_lambda=1e-30, max_iterations=12)):
+        sysobj = lanes(E, recs, n)
+        x, st, logs = sysobj.solve_batch_logged(x0, E.Config(**cfg), warn_cap=512)
+        _, _, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+        for b in list(range(0, 3000, 97)) + list(range(0, 60)):
+            want = O.solve(recs, x0[b], O.Config(**cfg), warn_cap=4096)
+            assert np.array_equal(np.isnan(x[b]), np.isnan(want.final_values)), b
+            assert bool(st["converged"][b]) == want.converged, b
+            if not want.converged and not np.any(np.isnan(x0[b])):
+                continue
+            assert int(st["iterations"][b]) == want.iterations, b
+            assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied, b
+            assert int(st["n_warnings"][b]) == len(want.warnings), b
+            assert float(st["final_lambda"][b]) == want.final_lambda, b
+            assert [p for _, p in logs[b]] == [w[0] for w in want.warnings][: len(logs[b])], b
+            checked_warnings += len(want.warnings)
+            assert_x_close(x[b], want.final_values, 1e-6)
+    assert checked_warnings > 50
