@@ -56,6 +56,8 @@ EXPORTS = [
     "ezpz_system_freedom_batch_device",
     "ezpz_resolve_sides",
     "ezpz_system_specialize",
+    "ezpz_host_register",
+    "ezpz_host_unregister",
     "ezpz_specialized_source",
 ]
 
@@ -95,6 +97,10 @@ def lib():
     L.ezpz_system_freedom_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.ezpz_current_device.restype = C.c_int
     L.ezpz_current_device.argtypes = []
+    L.ezpz_host_register.restype = C.c_int
+    L.ezpz_host_register.argtypes = [vp, sz]
+    L.ezpz_host_unregister.restype = C.c_int
+    L.ezpz_host_unregister.argtypes = [vp]
     L.ezpz_system_specialize.restype = C.c_int
     L.ezpz_system_specialize.argtypes = [vp, C.c_int]
     L.ezpz_specialized_source.restype = C.c_long

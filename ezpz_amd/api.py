@@ -613,6 +613,19 @@ def specialized_source(records, n_vars: int, compile: bool = False) -> str:
     return buf.value.decode() if rc > 0 else ""
 
 
+def host_register(array: np.ndarray) -> None:
+    """`ezpz_host_register`: page-locks a (contiguous) array the caller will pass to batch calls again and again."""
+    rc = lib().ezpz_host_register(array.ctypes.data, array.nbytes)
+    if rc != 0:
+        raise NonLinearSystemError(rc)
+
+
+def host_unregister(array: np.ndarray) -> None:
+    rc = lib().ezpz_host_unregister(array.ctypes.data)
+    if rc != 0:
+        raise NonLinearSystemError(rc)
+
+
 def resolve_sides(records, values) -> np.ndarray:
     """`Constraint::set_from_initial_values` (constraints.rs:146-193) over a request list: a copy of `records` in which
     every undefined LineSide / CircleSide is the one `values` (by id) imply.  `System` takes side-resolved records."""

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -110,6 +111,20 @@ struct PinnedBuf {
     }
 };
 
+// Host ranges the caller has registered (ezpz_host_register): page-locked, so batch calls can DMA straight from / to
+// them with asynchronous copies that overlap the kernels.
+std::mutex g_host_mu;
+std::map<uintptr_t, size_t> g_host_ranges;  // start -> bytes
+bool host_range_registered(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    auto it = g_host_ranges.upper_bound(a);
+    if (it == g_host_ranges.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+}
+
 constexpr size_t kZeroCopyBytes = 1 << 20;  // calls moving less than this skip DMA and use mapped host memory
 
 // The staging buffer of the zero-copy path belongs to the calling thread (one per device), not to the system: a
@@ -138,6 +153,7 @@ struct EzpzSystem {
     uint32_t* dev_comp = nullptr;
     CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
     std::unique_ptr<LanePlan> lane;  // small systems: one lane per system, run-time compiled (jit stands for it then)
+    std::atomic<uint32_t> launches{0};  // a topology solved again and again (an interactive sketch) earns its specialised kernel
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
     DevBuf<GridScratch> grid_scratch;
@@ -161,6 +177,17 @@ struct EzpzSystem {
     DevBuf<uint8_t> mask_dev;
     DevBuf<uint64_t> log_dev;
     DevBuf<double> gws_dev;
+    // the three slots of the pipelined host-to-host path (registered caller buffers): device buffers, a pinned status
+    // staging buffer, a stream and an event each
+    struct Slot {
+        DevBuf<double> x;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        ~Slot() {
+            if (stream) (void)hipStreamDestroy(stream);
+            if (done) (void)hipEventDestroy(done);
+        }
+    } slots[3];
     std::vector<uint32_t> host_var_of, host_row_of, host_slot_row, host_slot_col;  // internal -> caller numbering
     // FreedomAnalysis program (built on first use) and its scratch
     struct Freedom {
@@ -414,7 +441,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
     if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
-        if (st == 0 && (args.batch >= 4096 || jit_sync())) st = comp_jit_request(s.jit, jit_sync());
+        if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 16)) st = comp_jit_request(s.jit, jit_sync());
         if (st == 2 && lane_jit_launch(s.jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
     }
     if (s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
@@ -423,7 +450,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         if (s.jit) {
             const bool sync = jit_sync();
             int st = comp_jit_state(s.jit);
-            if (st == 0 && (args.batch >= 1024 || sync)) st = comp_jit_request(s.jit, sync);
+            if (st == 0 && (args.batch >= 1024 || sync || s.launches.fetch_add(1) >= 16)) st = comp_jit_request(s.jit, sync);
             if (st == 2 && comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
         }
         return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
@@ -1220,7 +1247,19 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         rc = ezpz_system_solve_batch_device(sys, hx, batch, cfg, hx, hst, unsat_mask ? hmask : nullptr,
                                             want_log ? hlog : nullptr, warn_cap, hipStreamPerThread);
         if (rc != EZPZ_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+        // a solve() call is over in tens of microseconds: poll the stream for a while before blocking on it (the
+        // blocking wait sleeps on an interrupt and comes back ~10 us late)
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t q;
+            while ((q = hipStreamQuery(hipStreamPerThread)) == hipErrorNotReady) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+            }
+            if (q != hipSuccess) {
+                (void)hipGetLastError();
+                HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+            }
+        }
         std::memcpy(status, hst, st_bytes);
         if (sys->grid_wgs > 1)
             for (size_t b2 = 0; b2 < batch; ++b2)
@@ -1234,6 +1273,48 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                 std::memcpy(warn_log + b * warn_cap, hlog + b * warn_cap, cnt * sizeof(uint64_t));
             }
         }
+        return EZPZ_OK;
+    }
+    // Registered (page-locked) caller buffers: the batch streams through three slots -- H2D of piece k+1, the kernel
+    // of piece k and D2H of piece k-1 overlap, each slot on its own stream with its own device buffers.  On the
+    // MI355X boxes measured (tools/pcie_bw.py) the host link moves 56 GB/s one way but only 28-45 GB/s each way when
+    // both directions run at once, so this buys ~5 % over the pageable path, not the 2x of a full-duplex link.  Only for launch shapes that keep no per-system
+    // device scratch (kernels of one EzpzSystem may then overlap) and calls without mask / warning log.
+    const bool scratch_free = sys->comp || sys->lane || (sys->lds_ws && sys->grid_wgs == 1);
+    if (n && scratch_free && !unsat_mask && !want_log && host_range_registered(x0, x_bytes) &&
+        host_range_registered(x_out, x_bytes)) {
+        const size_t row = n * sizeof(double);
+        // pieces of ~2 MB (measured 2 / 4 / 8 / 16 MB: 1.67 / 1.63 / 1.63 / 1.59 M solves/s on the 2000 x 2000 system), at
+        // least 6 of them when the batch allows it (EZPZ_H2H_PIECE_MB overrides, for measurements)
+        static const size_t piece_bytes = [] {
+            const char* e = std::getenv("EZPZ_H2H_PIECE_MB");
+            return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 2) << 20;
+        }();
+        const size_t piece = std::max<size_t>(1, std::min<size_t>(piece_bytes / row, (batch + 5) / 6));
+        // the statuses of the whole call collect in one device buffer and come back in one copy at the end
+        if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
+        size_t k = 0;
+        for (size_t off = 0; off < batch; off += piece, ++k) {
+            EzpzSystem::Slot& sl = sys->slots[k % 3];
+            const size_t nb = std::min(piece, batch - off);
+            if (!sl.stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            }
+            if (sl.x.cap < piece * n) {  // (re)allocation frees the old buffer: nothing may still be using it
+                HIP_TRY(hipStreamSynchronize(sl.stream));
+                if ((rc = sl.x.ensure(piece * n)) != EZPZ_OK) return rc;
+            }
+            // a slot's stream runs its pieces in order, so its device buffer is free again when the copy-out of the
+            // previous piece has been issued ahead of this copy-in on the same stream
+            HIP_TRY(hipMemcpyAsync(sl.x.p, x0 + off * n, nb * row, hipMemcpyHostToDevice, sl.stream));
+            rc = ezpz_system_solve_batch_device(sys, sl.x.p, nb, cfg, sl.x.p, sys->st_dev.p + off, nullptr, nullptr, 0, sl.stream);
+            if (rc != EZPZ_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(x_out + off * n, sl.x.p, nb * row, hipMemcpyDeviceToHost, sl.stream));
+        }
+        for (auto& sl : sys->slots)
+            if (sl.stream) HIP_TRY(hipStreamSynchronize(sl.stream));
+        HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
         return EZPZ_OK;
     }
     // Larger calls: DMA in pieces of <= 16 MB of guesses (pageable copies of that size run at ~43 GB/s on this
@@ -1281,6 +1362,32 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
 }  // extern "C"
 
 extern "C" {
+
+int ezpz_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (ezpz_device_count() < 1) return EZPZ_ERR_NO_DEVICE;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return EZPZ_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    g_host_ranges[reinterpret_cast<uintptr_t>(p)] = bytes;
+    return EZPZ_OK;
+}
+
+int ezpz_host_unregister(void* p) {
+    {
+        std::lock_guard<std::mutex> lock(g_host_mu);
+        auto it = g_host_ranges.find(reinterpret_cast<uintptr_t>(p));
+        if (it == g_host_ranges.end()) return EZPZ_ERR_INVALID_ARGUMENT;
+        g_host_ranges.erase(it);
+    }
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return EZPZ_ERR_HIP;
+    }
+    return EZPZ_OK;
+}
 
 int ezpz_system_specialize(EzpzSystem* sys, int wait) {
     if (!sys) return EZPZ_ERR_INVALID_ARGUMENT;

@@ -217,6 +217,13 @@ int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t
  * the device's CU count, and should a rendezvous still time out (~1 s: another process occupying the device) the
  * affected systems report iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT, converged == 0 instead of hanging; the host
  * form returns EZPZ_ERR_HIP in that case and the EzpzSystem must be destroyed. */
+/* Host buffers a caller reuses across batch calls can be page-locked once (hipHostRegister underneath): when both x0
+ * and x_out of an ezpz_system_solve_batch call lie inside registered ranges (and no mask / warning log is asked for) the
+ * call streams the batch through three device slots, so that the PCIe copy in, the kernels and the copy out overlap.
+ * The caller must unregister a range before freeing it. */
+int ezpz_host_register(void* p, size_t bytes);
+int ezpz_host_unregister(void* p);
+
 int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
                                    double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
                                    uint64_t* warn_log_dev, uint32_t warn_cap, void* stream);
@@ -276,7 +283,9 @@ int ezpz_resolve_sides(EzpzConstraint* cs, size_t n_cs, const double* values, si
  * Systems that run component-resident (EzpzSystemInfo.team_mode 3) can have their kernel compiled at run time
  * (hiprtc) into straight-line code for exactly their classes of components: same operations in the same order,
  * state in registers instead of LDS.  Batch calls of >= 1024 systems start that compilation on a background thread
- * and switch to the specialised kernel once it is ready (results are bit-identical either way); EZPZ_JIT=0 in the
+ * (so do topologies solved more than 16 times, one call after the other: an interactive sketch) and switch to the
+ * specialised kernel once it is ready (results are bit-identical either way for component-resident systems; the
+ * lane-per-system form sums residuals in request order, i.e. agrees to rounding); EZPZ_JIT=0 in the
  * environment turns it off.  ezpz_system_specialize starts it explicitly and, with wait != 0, returns when it is
  * done: 2 = ready, 1 = still compiling, 0 = this system has no specialised form, negative = compilation failed.
  * ezpz_specialized_source (no device needed) writes the generated source of a request into buf (NUL-terminated,

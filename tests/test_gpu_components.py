@@ -220,3 +220,33 @@ def test_mixed_classes_with_nonlinear_members(E):
     sysobj, x, st, mask, xo = solve_both(E, recs, x0, dict(max_iterations=60))
     assert_x_close(x, xo)
     assert np.all(st["n_unsatisfied"] == 0)
+
+
+def test_registered_host_buffers_pipeline_gives_the_same_results(E):
+    """ezpz_host_register: batch calls from / to page-locked caller buffers stream through three device slots (copies
+    and kernels overlap); results are those of the ordinary host path, bit for bit, for every launch shape that uses it."""
+    ref = T.load(T.gen_big_problem(500))
+    x0 = np.ascontiguousarray(ref.guesses[None, :] + gen.keyed_uniform(41, 3000, ref.num_vars, -0.25, 0.25))
+    sq = T.load(read_case("square"))
+    xs = np.ascontiguousarray(gen.keyed_uniform(42, 200000, 8, -100, 100, integer=True))
+    for recs, n, xin in ((ref.constraints, ref.num_vars, x0), (sq.constraints, 8, xs)):
+        sysobj = E.System(recs, n)
+        want_x, want_st, _ = sysobj.solve_batch(xin)
+        E.host_register(xin)
+        out = np.empty_like(xin)
+        E.host_register(out)
+        try:
+            import ctypes as C
+
+            st = np.zeros(len(xin), dtype=E.STATUS_DTYPE)
+            cfg = E.Config()._c()
+            for _ in range(2):
+                rc = E.lib().ezpz_system_solve_batch(sysobj._h, xin.ctypes.data, len(xin), C.byref(cfg), out.ctypes.data,
+                                                     st.ctypes.data, None, None, 0)
+                assert rc == 0
+                assert np.array_equal(out, want_x)
+                for f in st.dtype.names:
+                    assert np.array_equal(st[f], want_st[f]), f
+        finally:
+            E.host_unregister(xin)
+            E.host_unregister(out)
