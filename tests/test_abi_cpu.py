@@ -190,3 +190,62 @@ def test_specialized_kernel_source_compiles_without_a_device():
 
     recs, g = gen.connected_sketch(30, 1)
     assert E.specialized_source(recs, len(g)) == ""
+
+
+def test_header_compiles_and_links_as_c11(tmp_path):
+    """include/ezpz_amd.h is a C header: a strict C11 program (gcc, not hipcc) builds against it, links the shared
+    library and calls ezpz_analyze (host-only) and ezpz_solve (needs a device: EZPZ_ERR_NO_DEVICE here, 0 on a GPU box)."""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "ezpz_amd.h"
+
+int main(void) {
+    /* test_cases/tiny: p = (0,0), q = (0,0) as four Fixed constraints; guesses (3,4), (5,6) */
+    EzpzConstraint cs[4];
+    memset(cs, 0, sizeof cs);
+    for (int i = 0; i < 4; ++i) {
+        cs[i].kind = EZPZ_FIXED;
+        cs[i].ids[0] = (uint32_t)i;
+        cs[i].param = 0.0;
+        cs[i].weight = 1.0;
+    }
+    const uint32_t ids[4] = {0, 1, 2, 3};
+    const double guesses[4] = {3.0, 4.0, 5.0, 6.0};
+    EzpzSystemInfo info;
+    int32_t ec = -1;
+    int64_t ev = -1;
+    int rc = ezpz_analyze(cs, 4, 4, &info, &ec, &ev);
+    if (rc != EZPZ_OK || info.n_rows != 4 || info.n_vars != 4 || info.nnz_j != 4) return 10;
+    cs[3].ids[0] = 9; /* MissingGuess: constraint 3 references variable 9 */
+    rc = ezpz_analyze(cs, 4, 4, &info, &ec, &ev);
+    if (rc != EZPZ_ERR_MISSING_GUESS || ec != 3 || ev != 9) return 11;
+    cs[3].ids[0] = 3;
+    EzpzConfig cfg;
+    ezpz_default_config(&cfg);
+    if (cfg.max_iterations != 35) return 12;
+    double x[4];
+    uint64_t unsat[4];
+    EzpzWarning warn[8];
+    EzpzOutcome out;
+    rc = ezpz_solve(cs, 4, ids, guesses, 4, &cfg, x, unsat, warn, 8, &out);
+    printf("solve rc=%d (%s) iterations=%llu\n", rc, ezpz_error_string(rc), (unsigned long long)out.iterations);
+    if (rc == EZPZ_OK) {
+        for (int i = 0; i < 4; ++i)
+            if (x[i] > 1e-6 || x[i] < -1e-6) return 13;
+        return out.n_unsatisfied == 0 ? 0 : 14;
+    }
+    return rc == EZPZ_ERR_NO_DEVICE && ezpz_device_count() == 0 ? 0 : 15;
+}
+''')
+    libdir = os.path.join(ROOT, "ezpz_amd")
+    E.lib()  # built
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lezpz_amd", "-Wl,-rpath," + libdir])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "solve rc=" in r.stdout

@@ -1,0 +1,73 @@
+"""GPU tests (-m gpu) at BASELINE.json's full sizes for configs[3] and configs[4]: size-independent properties over
+the whole batch plus a sample of systems against the CPU oracle (the full batches would take the oracle minutes)."""
+import numpy as np
+import pytest
+
+import gen
+from conftest import read_case
+from oracle import oracle as O
+from oracle import textual as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import ezpz_amd
+
+    if ezpz_amd.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device: the product path has no CPU fallback")
+    return ezpz_amd
+
+
+def test_200k_variable_ladder_full_size(E):
+    """BASELINE configs[3]: gen_big_problem.py 50000 -- one sparse system of 200 000 variables / rows (150 000
+    components), on a grid team.  Every solve takes the reference's 2 iterations (README.md:36-38), ends with
+    max |r| <= 1e-9 and the exact geometry; 16 jittered systems bitwise against the oracle."""
+    cs = E.textual.Problem.from_str(E.textual.gen_big_problem(50000)).to_constraint_system()
+    n = cs.num_vars
+    assert n == 200000 and len(cs.records) == 200000
+    sysobj = E.System(cs.records, n)
+    info = sysobj.info()
+    assert info["grid_workgroups"] > 1 and (info["n_rows"], info["nnz_j"], info["nnz_l"]) == (200000, 250000, 250000)
+    B = 16
+    x0 = cs.guesses[None, :] + gen.keyed_uniform(0x657A707A, B, n, -0.25, 0.25)
+    x0[0] = cs.guesses
+    x, st, _ = sysobj.solve_batch(x0)
+    assert np.all(st["iterations"] == 2) and np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0)
+    assert np.all(st["final_residual_inf"] <= 1e-9)
+    lines = np.arange(50000, dtype=np.float64)
+    # line l: p_2l = (l, 0), p_2l+1 = (l, 4)
+    assert np.max(np.abs(x[:, 0::4] - lines)) <= 1e-9 and np.max(np.abs(x[:, 2::4] - lines)) <= 1e-9
+    assert np.max(np.abs(x[:, 1::4])) <= 1e-9 and np.max(np.abs(x[:, 3::4] - 4.0)) <= 1e-9
+    rc, xo, it, conv, nun = O.solve_batch(cs.records, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0 and np.array_equal(it, st["iterations"]) and np.array_equal(x, xo)
+
+
+def test_one_million_mixed_systems_full_size(E):
+    """BASELINE configs[4] on one GPU: system i uses [circle_tangent, parallelogram, arc_radius][i mod 3], guesses =
+    file guesses + U(-0.1, 0.1) from the keyed PRNG.  Every system converges with every constraint satisfied; 16 systems
+    per topology (48 in all) against the oracle: iteration counts equal, determined coordinates at 1e-6."""
+    total = 1_000_000
+    for k, name in enumerate(["circle_tangent", "parallelogram", "arc_radius"]):
+        ref = T.load(read_case(name))
+        recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
+        B = total // 3 + (1 if k < total % 3 else 0)
+        x0 = ref.guesses[None, :] + gen.keyed_uniform(0x657A707A + 101 * k, B, ref.num_vars, -0.1, 0.1)
+        sysobj = E.System(recs, ref.num_vars)
+        x, st, _ = sysobj.solve_batch(x0)
+        assert np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0), name
+        assert np.all(st["final_residual_inf"] <= 1e-8)
+        sample = np.arange(0, B, B // 16)[:16]
+        rc, xo, it, conv, nun = O.solve_batch(recs, x0[sample])
+        assert rc == 0 and np.array_equal(st["iterations"][sample], it), name
+        free = sysobj.freedom_batch(x[sample])[0].astype(bool)
+        rel = np.abs(x[sample] - xo) / np.maximum(1.0, np.abs(xo))
+        assert np.max(np.where(free, 0.0, rel)) <= 1e-6, name
+        assert np.max(np.where(free, rel, 0.0)) <= 2e-4, name  # held by lambda only (tests.rs:630-637)
+        # the specialised lane kernel gives the same answers
+        if sysobj.specialize(wait=True) == 2:
+            x2, st2, _ = sysobj.solve_batch(x0)
+            assert np.array_equal(st2["iterations"], st["iterations"]) and np.all(st2["n_unsatisfied"] == 0), name
+            rel2 = np.abs(x2[sample] - xo) / np.maximum(1.0, np.abs(xo))
+            assert np.max(np.where(free, 0.0, rel2)) <= 1e-6, name
