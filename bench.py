@@ -248,10 +248,12 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels):
                           "kernel_cycles": cycles}
     bound = max(roofs, key=lambda k: roofs[k]["frac"])
     top = roofs[bound]
+    assert all(r["frac"] <= 1.0 + 1e-9 for r in roofs.values()), roofs  # every roof is a bound
     algo = solves_per_launch_iters / t / 1e9
     return {
         "bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
         "traffic": traffic,
+        "roofs_measured": sorted(roofs),  # without PMC counters (--pmc 0, N>1) only the HBM roof is known
         "traffic_source": ("rocprofv3 --pmc child passes of this run (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per launch)"
                            if traffic is not None else pmc.get("error") or pmc.get("errors") or "not collected (--pmc 0 or N>1)"),
         "roofs": roofs,

@@ -441,7 +441,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
     if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
-        if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 16)) st = comp_jit_request(s.jit, jit_sync());
+        if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, jit_sync());
         if (st == 2 && lane_jit_launch(s.jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
     }
     if (s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
@@ -450,7 +450,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         if (s.jit) {
             const bool sync = jit_sync();
             int st = comp_jit_state(s.jit);
-            if (st == 0 && (args.batch >= 1024 || sync || s.launches.fetch_add(1) >= 16)) st = comp_jit_request(s.jit, sync);
+            if (st == 0 && (args.batch >= 1024 || sync || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, sync);
             if (st == 2 && comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
         }
         return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);

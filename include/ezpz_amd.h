@@ -283,7 +283,7 @@ int ezpz_resolve_sides(EzpzConstraint* cs, size_t n_cs, const double* values, si
  * Systems that run component-resident (EzpzSystemInfo.team_mode 3) can have their kernel compiled at run time
  * (hiprtc) into straight-line code for exactly their classes of components: same operations in the same order,
  * state in registers instead of LDS.  Batch calls of >= 1024 systems start that compilation on a background thread
- * (so do topologies solved more than 16 times, one call after the other: an interactive sketch) and switch to the
+ * (so do topologies solved more than 256 times, one call after the other: an interactive sketch) and switch to the
  * specialised kernel once it is ready (results are bit-identical either way for component-resident systems; the
  * lane-per-system form sums residuals in request order, i.e. agrees to rounding); EZPZ_JIT=0 in the
  * environment turns it off.  ezpz_system_specialize starts it explicitly and, with wait != 0, returns when it is
