@@ -152,6 +152,7 @@ struct EzpzSystem {
     std::unique_ptr<CompPlan> comp;
     uint32_t* dev_comp = nullptr;
     CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
+    DevBuf<unsigned char> jit_scratch;  // ... and, when it spreads a system over several workgroups, their reduction scratch
     std::unique_ptr<LanePlan> lane;  // small systems: one lane per system, run-time compiled (jit stands for it then)
     std::atomic<uint32_t> launches{0};  // a topology solved again and again (an interactive sketch) earns its specialised kernel
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
@@ -413,6 +414,31 @@ int launch_grid_team(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     return s.linear_only ? launch_grid_kernel<true>(s, args, stream) : launch_grid_kernel<false>(s, args, stream);
 }
 
+// The class-specialised kernel of a system spread over several workgroups (CompPlan::jit_wgs > 1): as many systems in
+// flight as the device holds whole teams of; every workgroup of the launch must be resident (they wait for each other),
+// so launches of this kind are chained like the list-walk grid teams' (launch_grid_kernel).
+int launch_jit_grid(EzpzSystem& s, const CompLaunch& L, hipStream_t stream) {
+    const uint32_t G = s.comp->jit_wgs;
+    const uint64_t capacity = comp_jit_capacity(s.jit, *s.comp, s.device, s.lim.cus);
+    if (capacity < G) return EZPZ_ERR_TOO_LARGE;
+    const uint32_t slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(L.batch, capacity / G));
+    if (s.jit_scratch.cap < (size_t)slots * kJitGridScratchBytes) {
+        int rc = s.jit_scratch.ensure((size_t)slots * kJitGridScratchBytes);
+        if (rc != EZPZ_OK) return rc;
+        HIP_TRY(hipMemsetAsync(s.jit_scratch.p, 0, s.jit_scratch.cap, stream));
+    }
+    std::lock_guard<std::mutex> lock(g_grid_mu);
+    hipEvent_t& ev = g_grid_event[s.device & 15];
+    if (!ev)
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else
+        HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+    int rc = comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream, s.jit_scratch.p, slots);
+    if (rc != EZPZ_OK) return rc;
+    HIP_TRY(hipEventRecord(ev, stream));
+    return EZPZ_OK;
+}
+
 CompLaunch comp_launch_args(const SolveArgs& args) {
     CompLaunch L{};
     L.x0 = args.x0;
@@ -450,10 +476,19 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         if (s.jit) {
             const bool sync = jit_sync();
             int st = comp_jit_state(s.jit);
-            if (st == 0 && (args.batch >= 1024 || sync || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, sync);
-            if (st == 2 && comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+            const bool big = args.batch >= 1024 || args.batch * (uint64_t)s.counts.n_vars >= (1ull << 21);
+            if (st == 0 && (big || sync || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, sync);
+            if (st == 2) {
+                if (s.comp->jit_wgs <= 1) {
+                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+                } else if (launch_jit_grid(s, L, stream) == EZPZ_OK) {
+                    return EZPZ_OK;
+                }
+            }
         }
-        return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
+        if (s.comp->interpretable) return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
+        // (a system too large for the interpreter's LDS state: the list-walk grid team below until the specialised
+        // kernel is ready)
     }
     uint32_t grid;
     if (s.mode == MODE_SUB) {
@@ -1063,7 +1098,13 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         std::unique_ptr<CompPlan> plan(new CompPlan());
         CompLimits cl;
         cl.lds_bytes = s.lim.lds_bytes;
-        if (comp_plan_build(cs, n_cs, n_vars, cl, *plan)) {
+        const bool planned = comp_plan_build(cs, n_cs, n_vars, cl, *plan);
+        if (planned && !plan->interpretable) {
+            // too much state for the interpreter: the list-walk shape chosen above serves until (and unless) the
+            // specialised multi-workgroup kernel is compiled
+            info.program_bytes += plan->blob.size() * 4;
+            s.comp = std::move(plan);
+        } else if (planned) {
             info.team_mode = 3;
             info.team_size = plan->n_waves * 64;
             info.n_partitions = plan->n_chunks;

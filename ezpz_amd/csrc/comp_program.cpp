@@ -543,9 +543,11 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
         const uint64_t waves = std::min<uint64_t>(per_cu * w, 16);  // beyond 4 per SIMD nothing is gained
         if (waves > best_waves) best_waves = waves, W = w;
     }
-    if (W == 0)
-        COMP_REJECT("%llu rows of state + %u scratch rows do not fit the LDS", (unsigned long long)rows_persistent, scratch_rows);
-    std::vector<uint32_t> order(chunks.size());
+    // State that does not fit one CU's LDS (one large system: the 200 000-variable ladder): no interpreter, but the
+    // class-specialised kernel keeps its state in registers and spreads the system over several workgroups (below).
+    plan.interpretable = W != 0;
+    if (!plan.interpretable) W = 1;
+    std::vector<uint32_t> order(plan.interpretable ? chunks.size() : 0);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return chunks[a].cost > chunks[b].cost; });
     std::vector<uint64_t> load(W, 0);
@@ -590,7 +592,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
     plan.n_instances = (uint32_t)comps.size();
     plan.rows_persistent = (uint32_t)rows_persistent;
     plan.scratch_rows = scratch_rows;
-    plan.lds_bytes = (uint32_t)bytes_for(W);
+    plan.lds_bytes = plan.interpretable ? (uint32_t)bytes_for(W) : 0u;
     plan.n_vars = n;
     plan.n_cons = C;
     plan.n_rows = (uint32_t)m_total;
@@ -611,24 +613,52 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             }
             return v;
         };
-        uint32_t T = 0;
+        auto per_slot = [&](size_t k) {
+            const ClassLayout& H = classes[k].H;
+            return 2ull * (2 * H.nv + 2 * H.m + (classes[k].linear ? 0 : H.zj) + H.ncons) + H.nv + 4;
+        };
+        uint32_t T = 0, G = 1;
+        std::vector<uint32_t> slots_k(classes.size(), 0);  // slots of class k per wavefront
         static const char* env_t = std::getenv("EZPZ_JIT_WAVES");
-        if (env_t && std::atoi(env_t) > 0) {
+        if (env_t && std::atoi(env_t) > 0 && plan.interpretable) {
             T = (uint32_t)std::atoi(env_t);
         } else {
             for (uint32_t t = 1; t <= 8 && !T; t <<= 1)
                 if (vgprs(t) <= 128) T = t;
-            if (!T) T = 8;  // big classes: one slot per class and wavefront, at whatever occupancy the registers leave
         }
-        if (T && T <= 16 && vgprs(T) <= 360) {
+        if (T) {
+            for (size_t k = 0; k < classes.size(); ++k) slots_k[k] = (nchunk[k] + T - 1) / T;
+        } else {
+            // One workgroup cannot hold the system: G workgroups of 4 wavefronts share it (grid reductions, see
+            // jit_kernel.hip.hpp).  A wavefront takes slots of every class in proportion to the class's chunks, ~112
+            // VGPRs of state in all.
+            static const char* env_g = std::getenv("EZPZ_JIT_GRID_WAVES");
+            T = env_g && std::atoi(env_g) > 0 ? (uint32_t)std::atoi(env_g) : 4;
+            uint64_t weight = 0;
+            for (size_t k = 0; k < classes.size(); ++k) weight += (uint64_t)nchunk[k] * per_slot(k);
+            uint32_t waves = 0;
+            for (size_t k = 0; k < classes.size(); ++k) {
+                slots_k[k] = std::max<uint32_t>(1, (uint32_t)((double)nchunk[k] * 112.0 / (double)weight + 0.5));
+                waves = std::max(waves, (nchunk[k] + slots_k[k] - 1) / slots_k[k]);
+            }
+            G = (waves + T - 1) / T;
+            if (G <= 1) {  // few chunks of many big classes: one workgroup after all, one slot per class and wavefront
+                G = 1;
+                T = 8;
+                for (size_t k = 0; k < classes.size(); ++k) slots_k[k] = (nchunk[k] + T - 1) / T;
+            }
+        }
+        uint64_t vg = 0;
+        for (size_t k = 0; k < classes.size(); ++k) vg += per_slot(k) * slots_k[k];
+        if (T && T <= 16 && vg <= 360 && G <= 256 && (plan.interpretable || G > 1)) {
             std::string& o = plan.jit_source;
             o = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
             for (size_t k = 0; k < classes.size(); ++k) emit_class(o, k, classes[k]);
             std::string seq;
             uint32_t nslots = 0;
-            std::vector<std::pair<uint32_t, uint32_t>> slot_of;  // (class, round)
+            std::vector<std::pair<uint32_t, uint32_t>> slot_of;  // (class, index among the wavefront's slots of that class)
             for (size_t k = 0; k < classes.size(); ++k)
-                for (uint32_t j = 0; j < (nchunk[k] + T - 1) / T; ++j) {
+                for (uint32_t j = 0; j < slots_k[k]; ++j) {
                     seq += (nslots ? ", Cls" : "Cls") + std::to_string(k);
                     slot_of.emplace_back((uint32_t)k, j);
                     ++nslots;
@@ -641,13 +671,14 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                  (plan.unit_weights ? "true" : "false") + ">(a, smem);\n}\n";
             align4(blob);
             plan.o_jit_slots = (uint32_t)blob.size();
-            for (uint32_t w = 0; w < T; ++w)
+            for (uint32_t w = 0; w < G * T; ++w)  // wavefront w of the system (workgroup w / T) owns consecutive chunks
                 for (uint32_t sl = 0; sl < nslots; ++sl) {
-                    const ClassLayout& H = classes[slot_of[sl].first].H;
-                    const uint32_t chunk = slot_of[sl].second * T + w;  // chunk index inside the class
-                    const uint32_t ninst = (uint32_t)classes[slot_of[sl].first].instances.size();
+                    const uint32_t k = slot_of[sl].first;
+                    const ClassLayout& H = classes[k].H;
+                    const uint32_t chunk = w * slots_k[k] + slot_of[sl].second;  // chunk index inside the class
+                    const uint32_t ninst = (uint32_t)classes[k].instances.size();
                     const uint32_t inst0 = std::min(chunk * 64, H.ninst_pad ? H.ninst_pad - 64 : 0u);
-                    const uint32_t count = chunk * 64 < ninst ? std::min<uint32_t>(64, ninst - chunk * 64) : 0u;
+                    const uint32_t count = (uint64_t)chunk * 64 < ninst ? std::min<uint32_t>(64, ninst - chunk * 64) : 0u;
                     blob.push_back(H.ids_off + inst0);
                     blob.push_back(H.par_off + 2 * inst0);
                     blob.push_back(H.pos_off + inst0);
@@ -656,8 +687,12 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             blob.resize(blob.size() + 16, 0);
             plan.jit_waves = T;
             plan.jit_slots = nslots;
+            plan.jit_wgs = G;
         }
     }
+    if (!plan.interpretable && plan.jit_source.empty())
+        COMP_REJECT("%llu rows of state do not fit the LDS and the system has no multi-workgroup specialised form",
+                    (unsigned long long)rows_persistent);
     return true;
 }
 

@@ -81,7 +81,11 @@ struct CompPlan {
     // `jit_slots` slots; blob[o_jit_slots ...] = [wave][slot] {ids_off, par_off, pos_off, count}.  Empty = none.
     std::string jit_source;
     uint32_t jit_waves = 0, jit_slots = 0, o_jit_slots = 0;
+    uint32_t jit_wgs = 1;        // workgroups that share one system in the specialised kernel (grid reductions when > 1)
+    bool interpretable = true;   // the state fits one CU's LDS: comp_solve_kernel can run the plan (else specialised only)
 };
+
+constexpr size_t kJitGridScratchBytes = 65600;  // sizeof(ezpz::jit::GridScratch), one per system in flight
 
 struct CompLimits {
     size_t lds_bytes = 160 * 1024;
@@ -136,7 +140,10 @@ void comp_jit_destroy(CompJit* jit);
 int comp_jit_request(CompJit* jit, bool wait);
 int comp_jit_state(const CompJit* jit);
 const char* comp_jit_log(const CompJit* jit);
-int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus, void* stream);
+int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus, void* stream,
+                    void* grid_scratch = nullptr, uint32_t grid_slots = 0);
+// workgroups of the specialised kernel the device holds at once (loads the code object on first use); 0 on failure
+uint64_t comp_jit_capacity(CompJit* jit, const CompPlan& plan, int device, int cus);
 int comp_jit_compile(const std::string& source, std::vector<char>& code, std::string& log);
 
 }  // namespace ezpz

@@ -36,8 +36,86 @@ struct JitArgs {
     uint32_t max_iterations;
     uint64_t batch;
     double residual_tolerance, step_tolerance, initial_lambda;
+    struct GridScratch* grid;  // systems too large for one workgroup: one scratch per system in flight (else null)
+    uint32_t grid_wgs;         // workgroups that share a system (1 = the ordinary case)
+    uint32_t pad;
 };
-static_assert(sizeof(JitArgs) == 104, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
+static_assert(sizeof(JitArgs) == 120, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
+
+// One system on several workgroups ("grid team", as in lm_kernel.hip.hpp): every workgroup owns its wavefronts' slots;
+// the reductions of the LM control cross workgroups through this per-system scratch.  Every workgroup publishes its
+// partials; workgroup 0 alone polls them, folds them in a fixed tree and writes the results to one 64-byte line per
+// workgroup; every other workgroup polls only its own line.  A value travels as a 16-byte (value, sequence number)
+// chunk moved by one device-coherent (sc0 sc1) 128-bit access, so it validates itself: no atomics, no fences.  All
+// workgroups of a launch must be resident at once (the host sizes the launch; the spin is bounded all the same).
+constexpr int kGridMaxWgs = 256;
+typedef unsigned int gridchunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, seq, 0)
+struct GridScratch {
+    int nwarn[2];  // Degenerate-warning counters, by parity of the system's turn in this slot
+    int dead;      // a rendezvous timed out
+    int pad[13];
+    gridchunk_t arr[2][4][kGridMaxWgs];  // [parity of the sequence number][value][workgroup]: partials
+    gridchunk_t out[2][kGridMaxWgs][4];  // [parity][workgroup]: the four results in one 64-byte line
+};
+static_assert(sizeof(GridScratch) == 65600, "GridScratch is sized on the host (comp_program.hpp: kJitGridScratchBytes)");
+
+__device__ __forceinline__ void grid_store(gridchunk_t* p, double v, unsigned int seq) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    gridchunk_t c;
+    c.x = (unsigned int)u;
+    c.y = (unsigned int)(u >> 32);
+    c.z = seq;
+    c.w = 0;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(c) : "memory");
+}
+__device__ __forceinline__ gridchunk_t grid_peek(const gridchunk_t* p) {
+    gridchunk_t c;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(c) : "v"(p) : "memory");
+    return c;
+}
+__device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int seq, int* dead) {
+    gridchunk_t c;
+    for (unsigned int spins = 0;; ++spins) {
+        c = grid_peek(p);
+        if (c.z == seq) break;
+        if ((spins & 1023u) == 1023u &&
+            (spins >= (1u << 21) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return __builtin_nan("");
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
+}
+// Four chunks at once (the four partials of one workgroup): the four loads are in flight together, one round trip to
+// the memory side instead of four.
+__device__ __forceinline__ void grid_wait4(const gridchunk_t* p0, const gridchunk_t* p1, const gridchunk_t* p2, const gridchunk_t* p3,
+                                           unsigned int seq, int* dead, double (&v)[4]) {
+    gridchunk_t c0, c1, c2, c3;
+    for (unsigned int spins = 0;; ++spins) {
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+            "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+            "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+            "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+            : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+            : "memory");
+        if (c0.z == seq && c1.z == seq && c2.z == seq && c3.z == seq) break;
+        if ((spins & 1023u) == 1023u &&
+            (spins >= (1u << 21) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[0] = v[1] = v[2] = v[3] = __builtin_nan("");
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    v[0] = __builtin_bit_cast(double, ((unsigned long long)c0.y << 32) | c0.x);
+    v[1] = __builtin_bit_cast(double, ((unsigned long long)c1.y << 32) | c1.x);
+    v[2] = __builtin_bit_cast(double, ((unsigned long long)c2.y << 32) | c2.x);
+    v[3] = __builtin_bit_cast(double, ((unsigned long long)c3.y << 32) | c3.x);
+}
 
 // One component per lane of one class: everything in registers (every index below is a literal after inlining).
 template <class C>
@@ -92,6 +170,63 @@ struct Red {
     double* buf;  // 2 x 3 x 16 doubles
     int* flags;   // 3 words
     int flip, turn;
+    GridScratch* grid;  // null: the workgroup owns its system alone
+    uint32_t grid_wgs, grid_wg;
+    unsigned int grid_seq;
+    // (sum, max, max, max) over the workgroups of a system; every thread passes the workgroup's values, every thread
+    // gets the system's
+    __device__ __forceinline__ void across_workgroups(double& s0, double& m1, double& m2, double& m3, int lane, uint32_t wave, uint32_t nwaves) {
+        using namespace ezpz::dev;
+        const int tid = threadIdx.x;
+        const unsigned int seq = ++grid_seq;
+        const unsigned int par = seq & 1u;
+        // (a workgroup publishes sequence number s+1 only after it has consumed the result of s, and workgroup 0 writes
+        // the result of s+2 only after every arrival for s+2: parities never collide)
+        if (tid < 4) grid_store(&grid->arr[par][tid][grid_wg], tid == 0 ? s0 : tid == 1 ? m1 : tid == 2 ? m2 : m3, seq);
+        double* b = buf + (flip ? 48 : 0);
+        flip ^= 1;
+        if (grid_wg == 0) {
+            double a0 = 0.0, a1 = __builtin_nan(""), a2 = a1, a3 = a1;
+            for (uint32_t g = tid; g < grid_wgs; g += blockDim.x) {
+                double v[4];
+                grid_wait4(&grid->arr[par][0][g], &grid->arr[par][1][g], &grid->arr[par][2][g], &grid->arr[par][3][g], seq, &grid->dead, v);
+                a0 = a0 + v[0];
+                a1 = fmax(a1, v[1]);
+                a2 = fmax(a2, v[2]);
+                a3 = fmax(a3, v[3]);
+            }
+            a0 = reduce_wave_to_last_lane(a0, OpSum());
+            a1 = reduce_wave_to_last_lane(a1, OpMax());
+            a2 = reduce_wave_to_last_lane(a2, OpMax());
+            a3 = reduce_wave_to_last_lane(a3, OpMax());
+            if (lane == 63) {
+                b[wave] = a0;
+                b[12 + wave] = a1;
+                b[24 + wave] = a2;
+                b[36 + wave] = a3;
+            }
+            __syncthreads();
+            const bool in = (uint32_t)lane < nwaves;
+            const int l = lane & 15;
+            s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
+            m1 = uniform(reduce_lanes<16>(in ? b[12 + l] : __builtin_nan(""), OpMax()));
+            m2 = uniform(reduce_lanes<16>(in ? b[24 + l] : __builtin_nan(""), OpMax()));
+            m3 = uniform(reduce_lanes<16>(in ? b[36 + l] : __builtin_nan(""), OpMax()));
+            for (uint32_t g = 1 + tid; g < grid_wgs; g += blockDim.x) {  // one line per workgroup
+                grid_store(&grid->out[par][g][0], s0, seq);
+                grid_store(&grid->out[par][g][1], m1, seq);
+                grid_store(&grid->out[par][g][2], m2, seq);
+                grid_store(&grid->out[par][g][3], m3, seq);
+            }
+        } else {
+            if (tid < 4) b[tid] = grid_wait(&grid->out[par][grid_wg][tid], seq, &grid->dead);
+            __syncthreads();
+            s0 = uniform(b[0]);
+            m1 = uniform(b[1]);
+            m2 = uniform(b[2]);
+            m3 = uniform(b[3]);
+        }
+    }
     __device__ __forceinline__ void sum_max(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
         s0 = reduce_wave_to_last_lane(s0, OpSum());
@@ -112,6 +247,10 @@ struct Red {
         const int l = lane & 15;
         s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
         m1 = uniform(reduce_lanes<16>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
+        if (grid) {
+            double m2 = __builtin_nan(""), m3 = __builtin_nan("");
+            across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
+        }
     }
     __device__ __forceinline__ bool step(double& s0, double& m1, double& m2, bool flag, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
@@ -143,7 +282,13 @@ struct Red {
         s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
         m1 = uniform(reduce_lanes<16>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
         m2 = uniform(reduce_lanes<16>(in ? b[32 + l] : __builtin_nan(""), OpMax()));
-        return __builtin_amdgcn_readfirstlane(*f) != 0;
+        bool failed = __builtin_amdgcn_readfirstlane(*f) != 0;
+        if (grid) {
+            double m3 = failed ? 1.0 : __builtin_nan("");
+            across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
+            failed = m3 > 0.0;
+        }
+        return failed;
     }
 };
 
@@ -174,12 +319,24 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     int* nwarn2 = red.flags + 4;
     if (tid < 8) red.flags[tid] = 0;
     if (NWAVES > 1) __syncthreads();
+    // a system on several workgroups (NWAVES > 1 then): workgroup g of the G that share it, slot = which system in flight
+    const uint32_t grid_wgs = a.grid ? a.grid_wgs : 1u;
+    const uint32_t grid_wg = blockIdx.x % grid_wgs, grid_slot = blockIdx.x / grid_wgs, n_slots = gridDim.x / grid_wgs;
+    red.grid = a.grid ? a.grid + grid_slot : nullptr;
+    red.grid_wgs = grid_wgs;
+    red.grid_wg = grid_wg;
+    red.grid_seq = 0;
+    if (red.grid) {  // continue the slot's sequence numbers where the previous launch left them (this workgroup's own)
+        const gridchunk_t c0 = grid_peek(&red.grid->arr[0][0][grid_wg]), c1 = grid_peek(&red.grid->arr[1][0][grid_wg]);
+        red.grid_seq = c0.z > c1.z ? c0.z : c1.z;
+    }
+    const uint32_t wave_global = grid_wg * NWAVES + wave;
 
     // ---- this wavefront's slots: what never changes from system to system lives in registers for the whole launch ----
     SEQ seq;
     seq.each([&](auto& s, auto* cls, int index) {
         using C = typename class_of<decltype(cls)>::type;
-        const uint32_t* t = a.blob + a.o_slots + 4 * ((size_t)wave * SEQ::N + index);
+        const uint32_t* t = a.blob + a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index);
         const uint32_t ids_off = t[0], par_off = t[1], pos_off = t[2], count = t[3];
         s.active = (uint32_t)lane < count;
 #pragma unroll
@@ -192,9 +349,10 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     });
 
     uint32_t parity = 0;
-    for (uint64_t sys = blockIdx.x; sys < a.batch; sys += gridDim.x, parity ^= 1u) {
+    for (uint64_t sys = grid_slot; sys < a.batch; sys += n_slots, parity ^= 1u) {
         const double* x0 = a.x0 + sys * a.n_row;
-        int* nwarn = nwarn2 + parity;
+        // (several workgroups: the counter is the scratch's, zeroed by workgroup 0 two systems ago)
+        int* nwarn = red.grid ? &red.grid->nwarn[parity] : nwarn2 + parity;
         auto log_warning = [&](uint32_t pass, uint32_t pos) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
             const int idx = atomicAdd(nwarn, 1);
             if (a.warn_log && (uint32_t)idx < a.warn_cap) a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | pos;
@@ -331,16 +489,22 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             double none = __builtin_nan("");
             red.sum_max(unsat_cnt, none, lane, wave, NWAVES);
         }
-        if (tid == 0) {
+        if (tid == 0 && grid_wg == 0) {
             EzpzStatus st;
             st.iterations = iterations;
             st.converged = converged;
             st.n_unsatisfied = (uint32_t)unsat_cnt;
-            st.n_warnings = ANY_NONLINEAR ? (uint32_t)*nwarn : 0u;
+            st.n_warnings = ANY_NONLINEAR ? (uint32_t)__hip_atomic_load(nwarn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             st.final_residual_inf = (a.n_rows_total > 0) ? largest : 0.0;
             st.final_lambda = lambda;
+            if (red.grid && __hip_atomic_load(&red.grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                st.iterations = EZPZ_ITERATIONS_TEAM_TIMEOUT;
+                st.converged = 0;
+            }
             a.status[sys] = st;
-            if (ANY_NONLINEAR) *nwarn = 0;  // serves the workgroup's system after next (see comp_kernel.hip.hpp)
+            // serves the system after next of this workgroup / slot (every wavefront passes a rendezvous of the next
+            // system, which this thread joins only after the store, before it can touch the counter again)
+            if (ANY_NONLINEAR) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -250,3 +250,30 @@ def test_registered_host_buffers_pipeline_gives_the_same_results(E):
         finally:
             E.host_unregister(xin)
             E.host_unregister(out)
+
+
+@pytest.mark.parametrize("lines,over", [(12000, False), (12000, True), (3000, True)])
+def test_specialised_kernel_on_several_workgroups(E, lines, over):
+    """Systems whose state exceeds one CU's LDS have no interpreter form; their specialised kernel shares a system among
+    workgroups (self-validating 16-byte chunks for the reductions of the LM control).  Against the list-walk grid team
+    and the oracle: linear ladder bitwise; the over-constrained variant (a non-linear `distance` per line, 3-4
+    iterations, general evaluators) bitwise against the list-walk kernel, 1e-6 against the oracle."""
+    ref = T.load(T.gen_big_problem(lines, over))
+    n = ref.num_vars
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(77, 5, n, -0.25, 0.25)
+    x0[0] = ref.guesses
+    sysobj = E.System(ref.constraints, n)
+    xw, stw, maskw = sysobj.solve_batch(x0, want_mask=True)   # list-walk (grid team or one workgroup)
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0 and np.array_equal(stw["iterations"], it)
+    spec = sysobj.specialize(wait=True)
+    assert spec == 2
+    for _ in range(3):
+        x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+        assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv) and np.array_equal(st["n_unsatisfied"], nun)
+        assert np.array_equal(mask, maskw)
+        assert np.array_equal(x, xw)
+        assert_x_close(x, xo)
+        if not over:
+            assert np.array_equal(x, xo)
+        assert np.array_equal(st["final_lambda"], stw["final_lambda"]) and np.array_equal(st["n_warnings"], stw["n_warnings"])

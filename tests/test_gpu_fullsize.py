@@ -42,6 +42,16 @@ def test_200k_variable_ladder_full_size(E):
     assert np.max(np.abs(x[:, 1::4])) <= 1e-9 and np.max(np.abs(x[:, 3::4] - 4.0)) <= 1e-9
     rc, xo, it, conv, nun = O.solve_batch(cs.records, x0, linsolve=O.LINSOLVE_SPARSE)
     assert rc == 0 and np.array_equal(it, st["iterations"]) and np.array_equal(x, xo)
+    # the class-specialised kernel spreads the system over ~100 workgroups of 4 wavefronts (grid reductions of the LM
+    # control across them): the same bits, statuses included
+    assert sysobj.specialize(wait=True) == 2
+    for _ in range(2):
+        x2, st2, mask2 = sysobj.solve_batch(x0, want_mask=True)
+        assert np.array_equal(x2, xo) and not mask2.any()
+        for f in st.dtype.names:
+            assert np.array_equal(st2[f], st[f]), f
+    x1, st1, _ = sysobj.solve_batch(x0[3:4])  # one system alone
+    assert np.array_equal(x1[0], xo[3])
 
 
 def test_one_million_mixed_systems_full_size(E):
