@@ -1,4 +1,5 @@
-"""Diagnostic: in-kernel s_memtime stamps of block 0 / lane 0 for one launch (needs libezpz_amd_stamps.so)."""
+"""Diagnostic: in-kernel s_memtime stamps of block 0 / lane 0 for one launch of the list-walk kernel.  Needs the stamped build:
+python -c "import ezpz_amd.build as b; b.build(extra_flags=['-DEZPZ_STAMPS'], lib_path=b.LIB.replace('.so', '_stamps.so'))" """
 import ctypes as C, os, sys
 os.environ["EZPZ_AMD_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ezpz_amd", "libezpz_amd_stamps.so")
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -8,7 +9,7 @@ from oracle import textual as T
 lines = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 cs = T.load(T.gen_big_problem(lines)); n = cs.num_vars
-s = E.System(cs.constraints, n)
+s = E.System(cs.constraints, n, team_size=E.TEAM_AUTO_LISTS)
 dev = torch.device('cuda', 0)
 x0 = torch.from_numpy(cs.guesses[None, :] + gen.keyed_uniform(1, B, n, -0.25, 0.25)).to(dev)
 xo = torch.empty_like(x0); st = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
