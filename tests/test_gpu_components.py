@@ -277,3 +277,39 @@ def test_specialised_kernel_on_several_workgroups(E, lines, over):
         if not over:
             assert np.array_equal(x, xo)
         assert np.array_equal(st["final_lambda"], stw["final_lambda"]) and np.array_equal(st["n_warnings"], stw["n_warnings"])
+
+
+def test_random_classes_interpreter_and_specialised_kernel_agree_bitwise(E):
+    """Random little systems of all 25 kinds (the fuzz generator's), each replicated 130 times with jittered guesses into
+    a block system: the component interpreter and the run-time compiled kernel give the same bits in every output
+    (solve_both), and the oracle's answer where it is determined."""
+    rng = np.random.default_rng(4321)
+    kinds_seen = set()
+    for trial in range(14):
+        nv = int(rng.integers(3, 9))
+        cons = []
+        for _ in range(int(rng.integers(1, 6))):
+            c = gen.arb_constraint(rng, int(rng.integers(0, O.NUM_KINDS)), hi=nv)
+            c["weight"] = float(rng.choice([1.0, 1.0, 2.5]))
+            cons.append(c)
+        kinds_seen.update(int(c["kind"]) for c in cons)
+        base = rng.uniform(-6.0, 6.0, nv)
+        recs, g = replicate(cons, base, 130, seed=trial, jitter=0.05)
+        x0 = np.stack([g, g + 0.01])
+        sysobj = E.System(recs, len(g))
+        if sysobj.info()["team_mode"] != 3:
+            continue
+        cfg = dict(max_iterations=12)
+        x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+        xl, stl, logs = sysobj.solve_batch_logged(x0, E.Config(**cfg), warn_cap=16384)
+        assert int(stl["n_warnings"].max()) <= 16384  # (a truncated log keeps whichever entries arrived first)
+        assert sysobj.specialize(wait=True) == 2
+        x2, st2, mask2 = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+        x3, st3, logs3 = sysobj.solve_batch_logged(x0, E.Config(**cfg), warn_cap=16384)
+        assert np.array_equal(x2, x, equal_nan=True) and np.array_equal(mask2, mask) and logs3 == logs, trial
+        for f in st.dtype.names:
+            assert np.array_equal(st2[f], st[f], equal_nan=True), (trial, f)
+        want = O.solve(recs, x0[0], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert want.error == 0 and np.array_equal(np.isnan(x[0]), np.isnan(want.final_values)), trial
+        assert int(st["n_warnings"][0]) == len(want.warnings) or not want.converged, trial
+    assert len(kinds_seen) >= 20

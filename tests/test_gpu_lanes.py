@@ -151,3 +151,58 @@ def test_weights_warnings_and_failed_pivots_per_lane(E):
             checked_warnings += len(want.warnings)
             assert_x_close(x[b], want.final_values, 1e-6)
     assert checked_warnings > 50
+
+
+def test_random_systems_of_all_kinds_on_the_lane_kernel(E):
+    """The reference's fuzz target as a comparison, on run-time compiled lane kernels: 48 random systems of all 25 kinds
+    (repeated ids, random weights), 24 random guess vectors each, against the oracle.  Always: error-free, NaN patterns,
+    `converged`, the unsatisfied mask; where the oracle's own answer is stable under a one-ulp perturbation of the
+    guesses: iteration counts of solves that end on the residual test, warnings, coordinates where rank J = n."""
+    rng = np.random.default_rng(777)
+    kinds_seen, compared, exact = set(), 0, 0
+    for trial in range(48):
+        nvars = int(rng.integers(4, 13))
+        cons = []
+        for _ in range(int(rng.integers(1, 9))):
+            c = gen.arb_constraint(rng, int(rng.integers(0, O.NUM_KINDS)), hi=nvars)
+            c["weight"] = float(rng.choice([1.0, 1.0, 1.0, 0.25, 3.0]))
+            cons.append(c)
+        recs = O.stack(cons)
+        kinds_seen.update(int(k) for k in recs["kind"])
+        cfg = dict(max_iterations=int(rng.choice([35, 35, 10, 60])))
+        x0 = rng.uniform(-8.0, 8.0, (24, nvars))
+        sysobj = lanes(E, recs, nvars)
+        x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+        for b in range(len(x0)):
+            want = O.solve(recs, x0[b], O.Config(**cfg), warn_cap=1 << 14)
+            assert want.error == 0
+            assert np.array_equal(np.isnan(x[b]), np.isnan(want.final_values)), (trial, b)
+            again = O.solve(recs, x0[b] * (1.0 + rng.uniform(-1.0, 1.0, nvars) * 2.0 ** -52), O.Config(**cfg))
+            scale = np.maximum(1.0, np.abs(want.final_values))
+            stable = (np.all(np.isfinite(want.final_values)) and again.iterations == want.iterations and again.converged == want.converged
+                      and again.unsatisfied == want.unsatisfied and np.max(np.abs(again.final_values - want.final_values) / scale) < 1e-9)
+            if not stable:
+                continue
+            compared += 1
+            assert bool(st["converged"][b]) == want.converged, (trial, b)
+            assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied, (trial, b)
+            if want.final_residual_inf <= 1e-8:
+                assert int(st["iterations"][b]) == want.iterations, (trial, b)
+                assert int(st["n_warnings"][b]) == len(want.warnings), (trial, b)
+                assert abs(float(st["final_residual_inf"][b]) - want.final_residual_inf) <= 1e-9
+                exact += 1
+            else:
+                assert abs(int(st["iterations"][b]) - want.iterations) <= 2, (trial, b)
+            J = np.zeros((sum(O.residual_dim(c) for c in cons), nvars))
+            row = 0
+            for c in cons:
+                rows, _ = O.jacobian_rows(c, want.final_values)
+                for r in rows:
+                    for i, pd in r:
+                        J[row, i] += c["weight"] * pd
+                    row += 1
+            if J.size and np.all(np.isfinite(J)):
+                sv = np.linalg.svd(J, compute_uv=False)
+                if len(sv) >= nvars and sv[nvars - 1] > 1e-7 * max(sv[0], 1e-300):
+                    assert_x_close(x[b], want.final_values)
+    assert compared >= 400 and exact >= 40 and len(kinds_seen) == O.NUM_KINDS, (compared, exact, sorted(kinds_seen))
