@@ -665,7 +665,12 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                 }
             bool any_nonlinear = false;
             for (const Class& cl : classes) any_nonlinear = any_nonlinear || !cl.linear;
-            o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ") ezpz_jit_solve(const ezpz::jit::JitArgs a) {\n";
+            static const char* env_mw = std::getenv("EZPZ_JIT_MINWAVES");  // occupancy hint (waves per SIMD), for measurements
+            // (the slots' state + ~40 working registers: with the matching occupancy as a hint the compiler spends the
+            // whole register budget of that occupancy on scheduling -- 2000 x 2000: 66.9 -> 74.2 M solves/s at 3)
+            const int min_waves = env_mw ? std::atoi(env_mw) : (vg + 40 <= 168 ? 3 : vg + 40 <= 256 ? 2 : 0);
+            const std::string bounds = std::to_string(T * 64) + (min_waves > 0 ? ", " + std::to_string(min_waves) : "");
+            o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve(const ezpz::jit::JitArgs a) {\n";
             o += "    __shared__ double smem[112];\n";
             o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
                  (plan.unit_weights ? "true" : "false") + ">(a, smem);\n}\n";
@@ -731,7 +736,8 @@ bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LaneP
     std::string& o = plan.jit_source;
     o = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
     emit_class(o, 0, cl, true, cs);
-    o += "extern \"C\" __global__ void __launch_bounds__(256) ezpz_jit_lane(const ezpz::jit::LaneArgs a) {\n";
+    static const char* env_lb = std::getenv("EZPZ_JIT_LANE_BOUNDS");  // e.g. "256, 2" -- for measurements
+    o += std::string("extern \"C\" __global__ void __launch_bounds__(") + (env_lb ? env_lb : "256") + ") ezpz_jit_lane(const ezpz::jit::LaneArgs a) {\n";
     o += std::string("    ezpz::jit::lane_kernel<Cls0, ") + (plan.unit_weights ? "true" : "false") + ">(a);\n}\n";
     plan.n_vars = (uint32_t)n_vars;
     plan.n_cons = (uint32_t)n_cs;
