@@ -56,7 +56,7 @@ PMC_SETS = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
 ]
-SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel", "ezpz_jit_solve")
+SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel", "ezpz_jit_solve", "ezpz_jit_lane")
 
 
 def algorithmic_bytes(info: dict, k: int) -> int:

@@ -1331,7 +1331,8 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
             const char* e = std::getenv("EZPZ_H2H_PIECE_MB");
             return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 2) << 20;
         }();
-        const size_t piece = std::max<size_t>(1, std::min<size_t>(piece_bytes / row, (batch + 5) / 6));
+        // (big systems: a launch needs several of them to fill the device, whatever their size in bytes)
+        const size_t piece = std::max<size_t>(std::min<size_t>(batch, 8), std::min<size_t>(piece_bytes / row, (batch + 5) / 6));
         // the statuses of the whole call collect in one device buffer and come back in one copy at the end
         if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
         size_t k = 0;

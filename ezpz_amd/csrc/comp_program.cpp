@@ -623,8 +623,11 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
         if (env_t && std::atoi(env_t) > 0 && plan.interpretable) {
             T = (uint32_t)std::atoi(env_t);
         } else {
+            // measured (2000 x 2000 / 2400 x 2400 / 800 x 800, M solves/s): the fewest wavefronts whose slots take up to
+            // ~176 VGPRs win -- T = 2 / 4 / 8 on 2000 x 2000 (224 / 112 / 56 VGPRs of state): 58 / 68 / 57; T = 4 / 8 on
+            // 2400 x 2400 (153 / 97): 53 / 36; T = 2 / 4 / 8 on 800 x 800 (112 / 56 / 41): 153 / 120 / 72
             for (uint32_t t = 1; t <= 8 && !T; t <<= 1)
-                if (vgprs(t) <= 128) T = t;
+                if (vgprs(t) <= 176) T = t;
         }
         if (T) {
             for (size_t k = 0; k < classes.size(); ++k) slots_k[k] = (nchunk[k] + T - 1) / T;
@@ -667,8 +670,9 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             for (const Class& cl : classes) any_nonlinear = any_nonlinear || !cl.linear;
             static const char* env_mw = std::getenv("EZPZ_JIT_MINWAVES");  // occupancy hint (waves per SIMD), for measurements
             // (the slots' state + ~40 working registers: with the matching occupancy as a hint the compiler spends the
-            // whole register budget of that occupancy on scheduling -- 2000 x 2000: 66.9 -> 74.2 M solves/s at 3)
-            const int min_waves = env_mw ? std::atoi(env_mw) : (vg + 40 <= 168 ? 3 : vg + 40 <= 256 ? 2 : 0);
+            // whole register budget of that occupancy on scheduling -- 2000 x 2000: 66.9 -> 74.2 M solves/s at 3; a hint
+            // the state does not fit costs spills: 2400 x 2400 at 3 instead of 2: 53 -> 43)
+            const int min_waves = env_mw ? std::atoi(env_mw) : (int)std::min<uint64_t>(4, std::max<uint64_t>(1, 512 / (vg + 50)));
             const std::string bounds = std::to_string(T * 64) + (min_waves > 0 ? ", " + std::to_string(min_waves) : "");
             o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve(const ezpz::jit::JitArgs a) {\n";
             o += "    __shared__ double smem[112];\n";
