@@ -154,6 +154,12 @@ struct EzpzSystem {
     CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
     DevBuf<unsigned char> jit_scratch;  // ... and, when it spreads a system over several workgroups, their reduction scratch
     std::unique_ptr<LanePlan> lane;  // small systems: one lane per system, run-time compiled (jit stands for it then)
+    // connected sketches in large batches: one lane per system, uniform program, state in global memory (batch_kernel.hip.hpp)
+    std::unique_ptr<BatchPlan> lanes;
+    uint32_t* dev_lanes = nullptr;
+    DevBuf<double> lanes_ws;
+    uint64_t lanes_ws_waves = 0;
+    uint64_t lanes_min = ~0ull;  // systems per call from which `lanes` serves the call
     std::atomic<uint32_t> launches{0};  // a topology solved again and again (an interactive sketch) earns its specialised kernel
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
@@ -208,6 +214,7 @@ struct EzpzSystem {
         if (dev_program) (void)hipFree(dev_program);
         if (dev_grid_blob) (void)hipFree(dev_grid_blob);
         if (dev_comp) (void)hipFree(dev_comp);
+        if (dev_lanes) (void)hipFree(dev_lanes);
         comp_jit_destroy(jit);
     }
 };
@@ -439,6 +446,7 @@ int launch_jit_grid(EzpzSystem& s, const CompLaunch& L, hipStream_t stream) {
     return EZPZ_OK;
 }
 
+
 CompLaunch comp_launch_args(const SolveArgs& args) {
     CompLaunch L{};
     L.x0 = args.x0;
@@ -465,6 +473,18 @@ bool jit_sync() {
 
 int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
+    if (s.lanes && args.batch >= s.lanes_min) {  // a device-filling batch of one connected sketch: lanes across the batch
+        if (s.lanes_ws_waves == 0) {
+            // one workspace per wavefront the device holds (capped at 24 GiB of the 288: fewer wavefronts then)
+            uint64_t waves = batch_launch_waves(s.lim.cus);
+            const uint64_t per = (uint64_t)s.lanes->rows * 512;
+            while (waves > 4 && waves * per > (24ull << 30)) waves /= 2;
+            if (s.lanes_ws.ensure((size_t)(waves * per / 8)) == EZPZ_OK) s.lanes_ws_waves = waves;
+        }
+        if (s.lanes_ws_waves &&
+            batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream) == EZPZ_OK)
+            return EZPZ_OK;
+    }
     if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
         if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, jit_sync());
@@ -884,8 +904,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return be.code;
     };
     const bool for_latency = team_size == EZPZ_TEAM_AUTO_LATENCY;
-    const bool auto_shape = team_size == 0 || for_latency;
-    if (for_latency || team_size == EZPZ_TEAM_AUTO_LISTS) team_size = 0;
+    const bool batch_lanes = team_size == EZPZ_TEAM_BATCH_LANES;
+    const bool auto_shape = team_size == 0 || for_latency || batch_lanes;
+    if (for_latency || batch_lanes || team_size == EZPZ_TEAM_AUTO_LISTS) team_size = 0;
     bool want_sub = team_size ? team_size <= 64 : width <= 64;
     if (want_sub) {
         uint32_t team = team_size ? pow2_ceil(team_size) : auto_sub_team(cs, n_cs);
@@ -1122,6 +1143,19 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         std::unique_ptr<LanePlan> lp(new LanePlan());
         if (lane_plan_build(cs, n_cs, n_vars, *lp)) s.lane = std::move(lp);
     }
+    // ---- lanes across the batch: one connected sketch too large for a lane's registers.  A lane walks its system alone, every
+    //      operand a trip to L2 / HBM, so the shape pays once the batch gives every SIMD a wavefront (64 x 4 x CUs systems:
+    //      65 536 on the MI355X, measured break-even 56 k, profiles/r02_sketch_scaling.txt); smaller batches keep the teams.
+    s.lanes.reset();
+    s.lanes_min = batch_lanes ? 1 : 64ull * 4 * (s.lim.cus ? s.lim.cus : 256);
+    static const bool lanes_enabled = [] {
+        const char* e = std::getenv("EZPZ_LANES");
+        return !(e && e[0] == '0');
+    }();
+    if (auto_shape && lanes_enabled && !s.comp && !s.lane && s.grid_wgs == 1 && P.c.n_parts == 1 && n_vars > 20) {
+        std::unique_ptr<BatchPlan> bp(new BatchPlan());
+        if (batch_plan_build(cs, n_cs, n_vars, *bp)) s.lanes = std::move(bp);
+    }
     return EZPZ_OK;
 }
 
@@ -1152,6 +1186,10 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
         s->jit = comp_jit_create(*s->comp);
     } else if (s->lane) {
         s->jit = comp_jit_create_source(s->lane->jit_source, "ezpz_jit_lane");
+    }
+    if (s->lanes) {
+        HIP_TRY(hipMalloc((void**)&s->dev_lanes, s->lanes->blob.size() * 4));
+        HIP_TRY(hipMemcpy(s->dev_lanes, s->lanes->blob.data(), s->lanes->blob.size() * 4, hipMemcpyHostToDevice));
     }
     *out = s.release();
     return EZPZ_OK;

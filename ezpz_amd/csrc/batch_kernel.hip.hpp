@@ -1,0 +1,328 @@
+// Lanes across the batch: one LANE per system, for batches of one connected sketch too large for a lane's registers.
+//
+// The list-walk kernels (lm_kernel.hip.hpp) give a connected sketch of 50-5000 variables a wavefront or a workgroup and
+// schedule its sparse Cholesky level by level: most lanes wait most of the time (a level is a few columns), which is
+// the right trade for the latency of ONE solve and the wrong one for a batch.  Every system of a batch shares the
+// topology, so here the 64 lanes of a wavefront are 64 systems running the SAME program -- the class program of
+// comp_program.cpp built for the whole system (constraint records with their parameters, the operation stream of the
+// linear solve) read through the scalar unit, every branch on it a scalar branch -- each lane strictly sequentially
+// on its own system.  No lane ever waits for another: no barriers, no reductions, no LDS.  The state of a wavefront's
+// 64 systems lives in global memory as rows of 64 doubles (row r, lane l = word 64 r + l): every access is one
+// coalesced 512-byte line, served by L2 / the Infinity Cache / HBM -- this kernel trades the on-chip residency of the
+// list-walk kernels for full lanes, and is bound by that traffic.
+// Every lane runs the whole LM loop of newton.rs:29-145 with its own lambda / accept / iteration count (masked
+// bookkeeping; all lanes execute the same record streams); lanes whose system is done wait for a refill, which the
+// wavefront does when a third of its lanes are idle (a refill costs everyone an evaluation sweep).
+// Sums run in request order on one lane (the reference's own order); elimination order and operation order are those
+// of the symbolic phase, as everywhere.  Replaces the same reference code as lm_kernel.hip.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "comp_kernel.hip.hpp"
+
+namespace ezpz {
+
+struct BatchArgs {
+    const uint32_t* prog;  // the plan's blob
+    uint32_t nv, m, zj, zlo, ncons, n_ops, ops_off, cons_off, var_off;
+    uint32_t o_d, o_r, o_rn, o_j, o_dg, o_l, rows;  // rows of a wavefront's workspace: x at 0, b -> y -> d, r, r_next, J, diagonal / tentative x, L
+    uint32_t n_cons;                                // unsat mask row
+    const double* x0;
+    double* x_out;
+    EzpzStatus* status;
+    uint8_t* unsat_mask;  // optional
+    uint64_t* warn_log;   // optional
+    uint32_t warn_cap, max_iterations, unit_weights, pad;
+    uint64_t batch;
+    double residual_tolerance, step_tolerance, initial_lambda;
+    double* ws;  // workspaces: one per wavefront of the launch, `rows` x 64 doubles each
+};
+
+__global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
+    using namespace dev;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const comp_cptr prog = (comp_cptr)(uintptr_t)a.prog;
+    const RowRef P{a.ws + wave_global * (uint64_t)a.rows * 64 + lane};
+    const RowRef V = P + a.o_d, R = P + a.o_r, RN = P + a.o_rn, J = P + a.o_j, S = P + a.o_dg, L = P + a.o_l;
+
+    uint64_t next = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool have = false, fresh = false, r_is_at_x = true;
+    uint64_t sys = 0;
+    double residual_sq = 0.0, largest = 0.0, lambda = 0.0;
+    uint32_t it = 0, pass = 0, pass_jac = 0, nwarn = 0;
+
+    auto log_warning = [&](uint32_t p, uint32_t pos) {  // Warning::Degenerate, in evaluation order (solver.rs:340-346)
+        if (a.warn_log && nwarn < a.warn_cap) a.warn_log[sys * a.warn_cap + nwarn] = ((uint64_t)p << 32) | pos;
+        ++nwarn;
+    };
+    // One sweep over the constraint records (request order).  MODE 0: residuals of `xs` into rows `dst` for the lanes in
+    // `store`, sum of squares / maximum per lane, degenerate evaluations logged with pass `p` for the lanes in `log`;
+    // MODE 2: the unsatisfied check on the unweighted values (lib.rs:305-327) for the lanes in `store`.
+    auto residual_sweep = [&](const RowRef& xs, const RowRef& dst, bool store, bool log, uint32_t p, int MODE, double& sq, double& mx,
+                              double& unsat) {
+        for (uint32_t ci = 0; ci < a.ncons; ++ci) {
+            const CompRec8 ra = comp_load8(prog + a.cons_off + ci * kCompConWords);
+            const CompRec8 rb = comp_load8(prog + a.cons_off + ci * kCompConWords + 8);
+            const DevCon c = comp_make_con(ra, rb, __hiloint2double((int)rb.w[6], (int)rb.w[5]));
+            const uint32_t pos = rb.w[7];
+            double r0, r1;
+            const bool deg = con_residual<false>(c, xs, r0, r1);
+            if (MODE == 2) {
+                bool sat = fabs(r0) < EPS;
+                if (c.nrows > 1) sat = sat && (fabs(r1) < EPS);
+                if (store) {
+                    if (!sat) unsat += 1.0;
+                    if (a.unsat_mask) a.unsat_mask[sys * a.n_cons + pos] = sat ? 0 : 1;
+                }
+                continue;
+            }
+            const double w0 = c.weight * r0;  // solver.rs:353
+            if (store) dst[c.row0] = w0;
+            sq += w0 * w0;
+            mx = fmax(mx, fabs(w0));
+            if (c.nrows > 1) {
+                const double w1 = c.weight * r1;
+                if (store) dst[c.row0 + 1] = w1;
+                sq += w1 * w1;
+                mx = fmax(mx, fabs(w1));
+            }
+            if (deg && log) log_warning(p, pos);
+        }
+    };
+    // Jacobian sweep at the accepted values (eval() and accepted steps, newton.rs:121; solver.rs:359-440) for the lanes
+    // in `mask`: their J rows, their warnings.
+    auto jacobian_sweep = [&](bool mask) {
+        for (uint32_t ci = 0; ci < a.ncons; ++ci) {
+            const CompRec8 ra = comp_load8(prog + a.cons_off + ci * kCompConWords);
+            const CompRec8 rb = comp_load8(prog + a.cons_off + ci * kCompConWords + 8);
+            const DevCon c = comp_make_con(ra, rb, __hiloint2double((int)rb.w[6], (int)rb.w[5]));
+            if (mask) {
+                JacWriter<RowRef> w;
+                w.jv = J;
+                w.jbase = c.jbase;
+                w.loc[0] = ra.w[6];
+                w.loc[1] = ra.w[7];
+                w.loc[2] = rb.w[0];
+                w.loc[3] = rb.w[1];
+                w.weight = c.weight;
+                if (con_jacobian<false>(c, P, w)) log_warning(pass_jac, rb.w[7]);
+            }
+        }
+    };
+
+    for (;;) {
+        // ---- refill: idle lanes take the next systems of the batch; eval() for them (newton.rs:45, :232-236) -------------
+        const bool want = !have && next < a.batch;
+        const unsigned long long wanting = __ballot(want), busy = __ballot(have);
+        if (wanting && (!busy || __popcll(wanting) >= 22)) {
+            if (want) {
+                sys = next;
+                next += stride;
+                const double* row = a.x0 + sys * a.nv;
+                for (uint32_t k = 0; k < a.nv; ++k) P[k] = row[prog[a.var_off + k]];
+                nwarn = 0;
+            }
+            double sq = 0.0, mx = __builtin_nan(""), none = 0.0;
+            residual_sweep(P, R, want, want, 0, 0, sq, mx, none);
+            if (want) {
+                have = true;
+                residual_sq = sq;
+                largest = mx;
+                lambda = a.initial_lambda;
+                it = 0;
+                pass = 2;
+                pass_jac = 1;
+                fresh = true;
+                r_is_at_x = true;
+            }
+        }
+        if (!__any(have)) break;
+
+        // ---- one LM iteration for every lane that has a system (newton.rs:47-139) -----------------------------------------------
+        bool finish = false;
+        uint32_t iterations = a.max_iterations, converged = 0;
+        if (have) {
+            if (it >= a.max_iterations) {  // newton.rs:141-144
+                finish = true;
+            } else if (largest <= a.residual_tolerance) {  // newton.rs:50-60
+                iterations = it;
+                converged = 1;
+                finish = true;
+            }
+        }
+        const bool active = have && !finish;
+        if (__any(active)) {
+            if (__any(active && fresh)) jacobian_sweep(active && fresh);
+            if (active) fresh = false;
+            // -- normal equations, Cholesky, substitutions (newton.rs:73-102): the operation stream, every lane on its own system.
+            //    The operands of a record's items are all requested before the first is used: one trip to L2 / HBM per
+            //    record instead of one per item; the terms are still folded in list order.
+#define LOAD_ITEMS(A, B)                                                              \
+    _Pragma("unroll") for (uint32_t k = 0; k < kCompItemsGen; ++k) {                  \
+        va[k] = vb[k] = 0.0;                                                          \
+        if (k < ni) va[k] = A[rec.w[2 + k] & 0xFFFFu], vb[k] = B[rec.w[2 + k] >> 16]; \
+    }
+            double acc = 0.0, y = 0.0, dmax = __builtin_nan("");
+            bool bad = false;
+            CompRec8 rec = comp_load8(prog + a.ops_off);
+            for (uint32_t io = 0; io < a.n_ops; ++io) {
+                const CompRec8 nxt = comp_load8(prog + a.ops_off + (io + 1) * kCompRecWords);
+                const uint32_t op = rec.w[0] & 0xFFu, ni = (rec.w[0] >> 8) & 0xFFu;
+                const bool first = (rec.w[0] & kCompFirst) != 0, last = (rec.w[0] & kCompLast) != 0;
+                const uint32_t oa = rec.w[1] & 0xFFFFu, ob = rec.w[1] >> 16;
+                double va[kCompItemsGen], vb[kCompItemsGen];
+                switch (op) {
+                case COMP_DIAG:
+                    if (first) acc = 0.0, y = 0.0;
+                    LOAD_ITEMS(J, R)
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k < ni) {
+                            acc += va[k] * va[k];
+                            y += va[k] * -vb[k];
+                        }
+                    if (last) {
+                        S[oa] = acc + lambda;  // newton.rs:77-84
+                        V[oa] = y;
+                    }
+                    break;
+                case COMP_OFF:
+                    if (first) acc = 0.0;
+                    LOAD_ITEMS(J, J)
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k < ni) acc += va[k] * vb[k];
+                    if (last) L[oa] = acc;
+                    break;
+                case COMP_COL:
+                    if (first) {
+                        acc = S[oa];
+                        y = V[oa];
+                    }
+                    LOAD_ITEMS(L, V)
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k < ni) {
+                            acc -= va[k] * va[k];
+                            y -= va[k] * vb[k];
+                        }
+                    if (last) {
+                        if (!(acc > 0.0)) bad = true;  // LltError::Numeric: non-positive pivot (newton.rs:93-99)
+                        const double dv = sqrt(acc);
+                        S[oa] = dv;
+                        V[oa] = y / dv;
+                    }
+                    break;
+                case COMP_SLOT:
+                    if (first) acc = L[oa];
+                    LOAD_ITEMS(L, L)
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k < ni) acc -= va[k] * vb[k];
+                    if (last) L[oa] = acc / S[ob];
+                    break;
+                case COMP_BWD:
+                    if (first) acc = V[oa];
+                    LOAD_ITEMS(L, V)
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k < ni) acc -= va[k] * vb[k];
+                    if (last) {
+                        const double dval = acc / S[oa];
+                        V[oa] = dval;
+                        dmax = fmax(dmax, fabs(dval));
+                        S[oa] = P[oa] + dval;  // the tentative x (newton.rs:111-114); the diagonal entry is dead now
+                    }
+                    break;
+                default: break;
+                }
+                rec = nxt;
+            }
+#undef LOAD_ITEMS
+            // -- residual at the tentative values (newton.rs:115-116); a lane whose factorisation failed skips it like the
+            //    reference's `continue` (no warnings, no step)
+            const bool stepping = active && !bad;
+            double sq = 0.0, mx = __builtin_nan(""), none = 0.0;
+            residual_sweep(S, RN, stepping, stepping, pass, 0, sq, mx, none);
+            if (active && bad) {
+                lambda *= LM_LAMBDA_INCR;
+                ++it;
+            }
+            const bool accept = stepping && sq < residual_sq;  // strict, newton.rs:118
+            if (stepping) {
+                ++pass;
+                // accept: x = x + d; reject: x += d, x -= d like the reference (newton.rs:111-114,:124-131), not a copy
+                for (uint32_t k = 0; k < a.nv; ++k) {
+                    const double xt = S[k];
+                    P[k] = accept ? xt : xt - V[k];
+                }
+                if (accept) {
+                    for (uint32_t k = 0; k < a.m; ++k) R[k] = RN[k];
+                    lambda *= LM_LAMBDA_DECR;
+                    residual_sq = sq;
+                    largest = mx;
+                    r_is_at_x = true;
+                    fresh = true;  // newton.rs:121: refresh_jacobian, evaluated at the top of the next iteration (or at the end)
+                    pass_jac = pass++;
+                } else {
+                    lambda *= LM_LAMBDA_INCR;
+                    r_is_at_x = false;
+                }
+                if (dmax <= a.step_tolerance) {  // newton.rs:134-139
+                    iterations = it;
+                    converged = 1;
+                    finish = true;
+                } else {
+                    ++it;
+                }
+            }
+        }
+
+        // ---- systems that are done: the refresh their last accepted step still owes its warnings, the unsatisfied check
+        //      (lib.rs:305-327, :358-370), write-back ---------------------------------------------------------------------------------
+        if (__any(finish)) {
+            if (__any(finish && fresh)) jacobian_sweep(finish && fresh);
+            const bool use_r = r_is_at_x && a.unit_weights != 0;
+            const bool all_sat = use_r && largest < EPS && !isnan(residual_sq);
+            double unsat = 0.0;
+            if (__any(finish && !all_sat && !use_r)) {
+                double s_ = 0.0, m_ = 0.0;
+                residual_sweep(P, R, finish && !use_r, false, 0, 2, s_, m_, unsat);
+            }
+            if (__any(finish && (all_sat || use_r))) {
+                for (uint32_t ci = 0; ci < a.ncons; ++ci) {
+                    const uint32_t w0 = prog[a.cons_off + ci * kCompConWords], w1 = prog[a.cons_off + ci * kCompConWords + 1];
+                    const uint32_t pos = prog[a.cons_off + ci * kCompConWords + 15];
+                    const uint32_t row = w1 & 0xFFFFu;
+                    if (finish && use_r) {
+                        bool sat = all_sat;
+                        if (!all_sat) {
+                            sat = fabs(R[row]) < EPS;
+                            if (((w0 >> 16) & 0xFFu) > 1) sat = sat && (fabs(R[row + 1]) < EPS);
+                            if (!sat) unsat += 1.0;
+                        }
+                        if (a.unsat_mask) a.unsat_mask[sys * a.n_cons + pos] = sat ? 0 : 1;
+                    }
+                }
+            }
+            if (finish) {
+                double* row = a.x_out + sys * a.nv;
+                for (uint32_t k = 0; k < a.nv; ++k) row[prog[a.var_off + k]] = P[k];
+                EzpzStatus st;
+                st.iterations = iterations;
+                st.converged = converged;
+                st.n_unsatisfied = (uint32_t)unsat;
+                st.n_warnings = nwarn;
+                st.final_residual_inf = (a.m > 0) ? largest : 0.0;
+                st.final_lambda = lambda;
+                a.status[sys] = st;
+                have = false;
+                fresh = false;
+            }
+        }
+    }
+}
+
+}  // namespace ezpz

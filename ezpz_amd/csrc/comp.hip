@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 
+#include "batch_kernel.hip.hpp"
 #include "comp_kernel.hip.hpp"
 
 namespace ezpz {
@@ -61,6 +62,45 @@ int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch
     a.red_row0 = plan.rows_persistent + plan.n_waves * plan.scratch_rows;
     return plan.linear ? launch_build<true>(plan, a, device, cus, lds_limit, static_cast<hipStream_t>(stream))
                        : launch_build<false>(plan, a, device, cus, lds_limit, static_cast<hipStream_t>(stream));
+}
+
+uint64_t batch_launch_waves(int cus) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_lane_kernel, 256, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    return (uint64_t)cus * (uint64_t)per_cu * 4;
+}
+
+int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons, const CompLaunch& L,
+                 void* stream) {
+    if (L.batch == 0) return EZPZ_OK;
+    BatchArgs a{};
+    a.prog = dev_blob;
+    a.nv = plan.nv, a.m = plan.m, a.zj = plan.zj, a.zlo = plan.zlo, a.ncons = plan.ncons;
+    a.n_ops = plan.n_ops, a.ops_off = plan.ops_off, a.cons_off = plan.cons_off, a.var_off = plan.var_off;
+    a.o_d = plan.o_d, a.o_r = plan.o_r, a.o_rn = plan.o_rn, a.o_j = plan.o_j, a.o_dg = plan.o_dg, a.o_l = plan.o_l, a.rows = plan.rows;
+    a.n_cons = n_cons;
+    a.x0 = L.x0;
+    a.x_out = L.x_out;
+    a.status = L.status;
+    a.unsat_mask = L.unsat_mask;
+    a.warn_log = L.warn_cap ? L.warn_log : nullptr;
+    a.warn_cap = L.warn_cap;
+    a.max_iterations = L.max_iterations;
+    a.unit_weights = plan.unit_weights ? 1u : 0u;
+    a.batch = L.batch;
+    a.residual_tolerance = L.residual_tolerance;
+    a.step_tolerance = L.step_tolerance;
+    a.initial_lambda = L.initial_lambda;
+    a.ws = dev_ws;
+    // persistent lanes: as many wavefronts as have a workspace (and systems to solve)
+    const uint64_t blocks = std::min<uint64_t>((L.batch + 255) / 256, ws_waves / 4);
+    if (blocks == 0) return EZPZ_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(batch_lane_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (hipGetLastError() != hipSuccess) return EZPZ_ERR_HIP;
+    return EZPZ_OK;
 }
 
 }  // namespace ezpz

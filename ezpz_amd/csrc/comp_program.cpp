@@ -111,6 +111,103 @@ void emit_op(std::vector<uint32_t>& out, uint32_t opcode, uint32_t a, uint32_t b
     } while (done < n);
 }
 
+// The class program in the blob: the operation stream of the linear solve in execution order (+ one read-ahead pad
+// record) and the constraint records (+ pad).  `params`: requests whose parameters go into the records as literals
+// (w13:w14; a class that is a whole system shared by every lane) -- null: parameters come from per-instance tables.
+void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const EzpzConstraint* params, bool request_order = false) {
+    const Program& Q = cl.Q;
+    ClassLayout& H = cl.H;
+    const uint32_t nv = Q.c.n_vars, zlo = Q.c.zlo, ncons = Q.c.n_cons;
+    // ---- operation stream of the linear solve, in execution order ----
+    std::vector<uint32_t> ops, items;
+    for (uint32_t v = 0; v < nv; ++v) {
+        items.clear();
+        if (LIN) {
+            double acc = 0.0;
+            for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
+                const double jv = cl.jconst[Q.colj_items[2 * q]];
+                acc += jv * jv;
+                items.push_back(Q.colj_items[2 * q + 1]);
+                items.push_back(f32_bits(jv));
+            }
+            std::vector<uint32_t> head;
+            push_double(head, acc);
+            emit_op(ops, COMP_DIAG, v, 0, items, 2, kCompItemsLin, 4, head.data());
+        } else {
+            for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q)
+                items.push_back(Q.colj_items[2 * q] | (Q.colj_items[2 * q + 1] << 16));
+            emit_op(ops, COMP_DIAG, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+        }
+    }
+    for (uint32_t s = 0; s < zlo; ++s) {
+        items.clear();
+        if (LIN) {
+            double acc = 0.0;
+            for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
+                acc += cl.jconst[Q.apairs[2 * q]] * cl.jconst[Q.apairs[2 * q + 1]];
+            std::vector<uint32_t> head;
+            push_double(head, acc);
+            emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 4, head.data());
+        } else {
+            for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
+                items.push_back(Q.apairs[2 * q] | (Q.apairs[2 * q + 1] << 16));
+            emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 2, nullptr);
+        }
+    }
+    const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
+    for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+        const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
+        for (uint32_t v = c0; v < c1; ++v) {
+            items.clear();
+            for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
+                items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
+            emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+        }
+        for (uint32_t s = s0; s < s1; ++s) {
+            items.clear();
+            for (uint32_t q = Q.lpair_ptr[s]; q < Q.lpair_ptr[s + 1]; ++q)
+                items.push_back(Q.lpairs[2 * q] | (Q.lpairs[2 * q + 1] << 16));
+            emit_op(ops, COMP_SLOT, s, Q.l_col[s], items, 1, kCompItemsGen, 2, nullptr);
+        }
+    }
+    for (uint32_t lv = part.nlev; lv-- > 0;) {
+        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+        for (uint32_t v = c0; v < c1; ++v) {
+            items.clear();
+            for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
+                items.push_back(Q.bwd_items[2 * q] | (Q.bwd_items[2 * q + 1] << 16));
+            emit_op(ops, COMP_BWD, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+        }
+    }
+    H.n_ops = (uint32_t)(ops.size() / kCompRecWords);
+
+    // ---- lay the class out in the blob: operation stream (+ one pad record), constraint records, tables ----
+    align4(blob);
+    H.ops_off = (uint32_t)blob.size();
+    blob.insert(blob.end(), ops.begin(), ops.end());
+    blob.resize(blob.size() + kCompRecWords, 0);  // the interpreter reads one record ahead
+    H.cons_off = (uint32_t)blob.size();
+    std::vector<uint32_t> rec_order(ncons);
+    std::iota(rec_order.begin(), rec_order.end(), 0u);
+    if (request_order)  // (one lane per system: sums of squares formed like the reference's sequential sum over the rows)
+        std::sort(rec_order.begin(), rec_order.end(), [&](uint32_t x, uint32_t y) { return Q.cons[x].pos < Q.cons[y].pos; });
+    for (uint32_t ci : rec_order) {
+        const DevCon& d = Q.cons[ci];
+        uint32_t rec[kCompConWords] = {};
+        rec[0] = d.kind | ((uint32_t)d.tag << 8) | ((uint32_t)d.nrows << 16) | ((uint32_t)d.nslots << 24);
+        rec[1] = d.row0 | (d.jbase << 16);
+        for (int e = 0; e < 4; ++e) rec[2 + e] = d.ids[2 * e] | (d.ids[2 * e + 1] << 16);
+        std::memcpy(&rec[6], d.jloc, 16);
+        std::memcpy(&rec[10], &d.weight, 8);
+        rec[12] = ci;
+        if (params) std::memcpy(&rec[13], &params[d.pos].param, 8);
+        rec[15] = d.pos;
+        blob.insert(blob.end(), rec, rec + kCompConWords);
+    }
+    blob.resize(blob.size() + kCompConWords, 0);  // read-ahead pad
+}
+
 // ---- source text of the class-specialised kernel (see jit_kernel.hip.hpp) ---------------------------------------------------------
 // Every statement below is one operation of the class program, in the interpreter's order (comp_kernel.hip.hpp), with
 // literal indices; doubles are written as hexadecimal floating literals (exact).
@@ -405,88 +502,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
         const uint32_t ninst = (uint32_t)cl.instances.size();
         H.ninst_pad = (ninst + 63) & ~63u;
 
-        // ---- operation stream of the linear solve, in execution order ----
-        std::vector<uint32_t> ops, items;
-        for (uint32_t v = 0; v < nv; ++v) {
-            items.clear();
-            if (LIN) {
-                double acc = 0.0;
-                for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
-                    const double jv = cl.jconst[Q.colj_items[2 * q]];
-                    acc += jv * jv;
-                    items.push_back(Q.colj_items[2 * q + 1]);
-                    items.push_back(f32_bits(jv));
-                }
-                std::vector<uint32_t> head;
-                push_double(head, acc);
-                emit_op(ops, COMP_DIAG, v, 0, items, 2, kCompItemsLin, 4, head.data());
-            } else {
-                for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q)
-                    items.push_back(Q.colj_items[2 * q] | (Q.colj_items[2 * q + 1] << 16));
-                emit_op(ops, COMP_DIAG, v, 0, items, 1, kCompItemsGen, 2, nullptr);
-            }
-        }
-        for (uint32_t s = 0; s < zlo; ++s) {
-            items.clear();
-            if (LIN) {
-                double acc = 0.0;
-                for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
-                    acc += cl.jconst[Q.apairs[2 * q]] * cl.jconst[Q.apairs[2 * q + 1]];
-                std::vector<uint32_t> head;
-                push_double(head, acc);
-                emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 4, head.data());
-            } else {
-                for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
-                    items.push_back(Q.apairs[2 * q] | (Q.apairs[2 * q + 1] << 16));
-                emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 2, nullptr);
-            }
-        }
-        const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
-        for (uint32_t lv = 0; lv < part.nlev; ++lv) {
-            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
-            const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
-            for (uint32_t v = c0; v < c1; ++v) {
-                items.clear();
-                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
-                    items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
-                emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr);
-            }
-            for (uint32_t s = s0; s < s1; ++s) {
-                items.clear();
-                for (uint32_t q = Q.lpair_ptr[s]; q < Q.lpair_ptr[s + 1]; ++q)
-                    items.push_back(Q.lpairs[2 * q] | (Q.lpairs[2 * q + 1] << 16));
-                emit_op(ops, COMP_SLOT, s, Q.l_col[s], items, 1, kCompItemsGen, 2, nullptr);
-            }
-        }
-        for (uint32_t lv = part.nlev; lv-- > 0;) {
-            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
-            for (uint32_t v = c0; v < c1; ++v) {
-                items.clear();
-                for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
-                    items.push_back(Q.bwd_items[2 * q] | (Q.bwd_items[2 * q + 1] << 16));
-                emit_op(ops, COMP_BWD, v, 0, items, 1, kCompItemsGen, 2, nullptr);
-            }
-        }
-        H.n_ops = (uint32_t)(ops.size() / kCompRecWords);
-
-        // ---- lay the class out in the blob: operation stream (+ one pad record), constraint records, tables ----
-        align4(blob);
-        H.ops_off = (uint32_t)blob.size();
-        blob.insert(blob.end(), ops.begin(), ops.end());
-        blob.resize(blob.size() + kCompRecWords, 0);  // the interpreter reads one record ahead
-        H.cons_off = (uint32_t)blob.size();
-        for (uint32_t ci = 0; ci < ncons; ++ci) {
-            const DevCon& d = Q.cons[ci];
-            uint32_t rec[kCompConWords] = {};
-            rec[0] = d.kind | ((uint32_t)d.tag << 8) | ((uint32_t)d.nrows << 16) | ((uint32_t)d.nslots << 24);
-            rec[1] = d.row0 | (d.jbase << 16);
-            for (int e = 0; e < 4; ++e) rec[2 + e] = d.ids[2 * e] | (d.ids[2 * e + 1] << 16);
-            std::memcpy(&rec[6], d.jloc, 16);
-            std::memcpy(&rec[10], &d.weight, 8);
-            rec[12] = ci;
-            blob.insert(blob.end(), rec, rec + kCompConWords);
-        }
-        blob.resize(blob.size() + kCompConWords, 0);  // read-ahead pad
+        emit_class_program(blob, cl, LIN, nullptr);
         align4(blob);
         H.ids_off = (uint32_t)blob.size();
         blob.resize(blob.size() + (size_t)nv * H.ninst_pad, 0);
@@ -746,6 +762,36 @@ bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LaneP
     plan.n_vars = (uint32_t)n_vars;
     plan.n_cons = (uint32_t)n_cs;
     plan.n_rows = Q.c.n_rows;
+    return true;
+}
+
+// ---- lanes across the batch (batch_kernel.hip.hpp) ------------------------------------------------------------------------------------
+bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, BatchPlan& plan) {
+    plan = BatchPlan();
+    if (n_cs == 0 || n_vars == 0 || n_vars > 60000 || n_cs > 60000) return false;
+    Class cl;
+    BuildError be;
+    if (!build_program(cs, n_cs, n_vars, cl.Q, be, 1, false)) return false;
+    const Program& Q = cl.Q;
+    if (Q.c.n_parts != 1 || Q.c.zj >= 0xFFFF || Q.c.zlo >= 0xFFFF || Q.c.n_rows >= 0xFFFF) return false;
+    plan.unit_weights = true;
+    for (const DevCon& d : Q.cons)
+        if (d.weight != 1.0) plan.unit_weights = false;
+    cl.linear = false;  // the general records: Jacobian values are stored (no constant folding here)
+    emit_class_program(plan.blob, cl, false, cs, true);
+    align4(plan.blob);
+    plan.var_off = (uint32_t)plan.blob.size();
+    plan.blob.insert(plan.blob.end(), Q.var_of.begin(), Q.var_of.end());
+    plan.blob.resize(plan.blob.size() + 16, 0);
+    plan.nv = Q.c.n_vars, plan.m = Q.c.n_rows, plan.zj = Q.c.zj, plan.zlo = Q.c.zlo, plan.ncons = Q.c.n_cons;
+    plan.n_ops = cl.H.n_ops, plan.ops_off = cl.H.ops_off, plan.cons_off = cl.H.cons_off;
+    plan.o_d = plan.nv;
+    plan.o_r = 2 * plan.nv;
+    plan.o_rn = plan.o_r + plan.m;
+    plan.o_j = plan.o_rn + plan.m;
+    plan.o_dg = plan.o_j + plan.zj;
+    plan.o_l = plan.o_dg + plan.nv;
+    plan.rows = plan.o_l + plan.zlo;
     return true;
 }
 

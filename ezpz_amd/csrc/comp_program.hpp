@@ -129,6 +129,20 @@ struct LanePlan {
 };
 bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LanePlan& plan);
 
+// Lanes across the batch (batch_kernel.hip.hpp): one lane per system for batches of one connected sketch -- the class
+// program of the whole system (parameters in the constraint records, records in request order) + the workspace layout.
+struct BatchPlan {
+    std::vector<uint32_t> blob;
+    uint32_t nv = 0, m = 0, zj = 0, zlo = 0, ncons = 0, n_ops = 0, ops_off = 0, cons_off = 0, var_off = 0;
+    uint32_t o_d = 0, o_r = 0, o_rn = 0, o_j = 0, o_dg = 0, o_l = 0, rows = 0;  // workspace rows of 64 doubles per wavefront
+    bool unit_weights = true;
+};
+bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, BatchPlan& plan);
+// wavefronts of the kernel the device holds at once (their workspaces are what the caller allocates)
+uint64_t batch_launch_waves(int cus);
+int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons,
+                 const CompLaunch& launch, void* stream);
+
 // The class-specialised kernel of a plan (jit.cpp): run-time compiled (hiprtc) on a background thread.
 // comp_jit_create returns nullptr when the plan carries no source or EZPZ_JIT=0.  comp_jit_request starts the
 // compilation if it has not started (and waits for it if asked); returns 0 idle, 1 compiling, 2 ready, -1 failed.

@@ -206,3 +206,40 @@ def test_random_systems_of_all_kinds_on_the_lane_kernel(E):
                 if len(sv) >= nvars and sv[nvars - 1] > 1e-7 * max(sv[0], 1e-300):
                     assert_x_close(x[b], want.final_values)
     assert compared >= 400 and exact >= 40 and len(kinds_seen) == O.NUM_KINDS, (compared, exact, sorted(kinds_seen))
+
+
+@pytest.mark.parametrize("npts,seed", [(12, 5), (30, 1), (75, 2), (150, 3)])
+def test_connected_sketches_lanes_across_the_batch(E, npts, seed):
+    """Device-filling batches (>= 64 x 4 x CUs systems; here forced with TEAM_BATCH_LANES) of one connected sketch of
+    mixed kinds (tests/gen.py:connected_sketch: too large for a lane's registers) run one lane per system on the
+    uniform-program kernel with its state in global memory (batch_kernel.hip.hpp): every system against the oracle
+    (iteration counts, flags, unsatisfied masks, warnings, coordinates at 1e-6) and against the per-system list-walk
+    teams that serve smaller batches."""
+    recs, g = gen.connected_sketch(npts, 1000 + seed)
+    n = len(g)
+    B = 2500
+    x0 = g[None, :] + gen.keyed_uniform(17 + seed, B, n, -0.03, 0.03)
+    x0[0] = g
+    cfg = dict(max_iterations=40)
+    sysobj = E.System(recs, n, team_size=E.TEAM_BATCH_LANES)
+    xs, sts, masks = E.System(recs, n).solve_batch(x0[:300], E.Config(**cfg), want_mask=True)  # the list-walk teams
+    x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)                      # lanes across the batch
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0
+    assert np.array_equal(st["converged"], conv) and np.array_equal(st["n_unsatisfied"], nun) and np.array_equal(mask.sum(axis=1), nun)
+    # (a stop test decided in the last bits -- the elimination orders differ -- moves a system's count by one, and its
+    # coordinates along the sketch's soft direction with it: 1 system of 2500 at 30 points; DESIGN.md section 4)
+    same = st["iterations"] == it
+    assert same.mean() >= 0.995 and np.max(np.abs(st["iterations"].astype(int) - it)) <= 3
+    assert_x_close(x[same], xo[same])
+    assert np.array_equal(st["iterations"][:300], sts["iterations"]) and np.array_equal(mask[:300], masks)
+    assert_x_close(x[:300], xs, 1e-9)
+    # warnings and weights travel per lane: a degenerate start (two coincident points under `distance`) for some systems
+    xd = x0[:2100].copy()
+    xd[::5, 2:4] = xd[::5, 0:2]
+    x2, st2, logs = sysobj.solve_batch_logged(xd, E.Config(**cfg), warn_cap=256)
+    for b in (0, 5, 10, 1001, 2095):
+        want = O.solve(recs, xd[b], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=4096)
+        assert (int(st2["iterations"][b]), bool(st2["converged"][b]), int(st2["n_warnings"][b])) == (want.iterations, want.converged, len(want.warnings)), b
+        assert [p for _, p in logs[b]] == [w[0] for w in want.warnings][: len(logs[b])], b
+        assert_x_close(x2[b], want.final_values)

@@ -23,7 +23,7 @@ for npts in sizes:
         for _ in range(reps): s.solve_batch_device(x0.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, stream, cfg)
         torch.cuda.synchronize(); return (time.perf_counter() - t) / reps, xo, st
     t1, xo, st = run(1, 20)
-    B = max(256, min(65536, (1 << 26) // (8 * len(g))))
+    B = int(__import__("os").environ.get("BATCH", 0)) or max(256, min(65536, (1 << 26) // (8 * len(g))))
     tB, _, _ = run(B, 5)
     t = time.perf_counter(); want = O.solve(recs, g, O.Config(max_iterations=60), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16); t_cpu = time.perf_counter() - t
     x = xo[0].cpu().numpy()
