@@ -227,7 +227,7 @@ struct SolveArgs {
 #ifdef EZPZ_STAMPS
 #define EZPZ_STAMP(id)                                                                     \
     do {                                                                                   \
-        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 250) {            \
+        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 1000) {            \
             a.stamps[2 * stamp_n] = (id);                                                  \
             a.stamps[2 * stamp_n + 1] = __builtin_readcyclecounter();                      \
             ++stamp_n;                                                                     \
@@ -248,6 +248,11 @@ struct SolveArgs {
 #endif
 
 namespace dev {
+
+// A value every lane of the wavefront holds alike (level bounds, lanes per list: properties of the program, and every
+// team of a wavefront runs the same program), moved to a scalar register: branches and loop bounds on it are scalar,
+// and a `switch` on it is one jump instead of a walk through every case under an execution mask.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // One load for an (a, b) index pair of a list.
 __device__ __forceinline__ void load_pair(const uint16_t* items, uint32_t q, uint32_t& a, uint32_t& b) {
@@ -653,13 +658,13 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
 
     // ---- this unit's partition --------------------------------------------------------------------------------------
     const PartDesc part = P.parts[(MODE == MODE_PART) ? (uint32_t)(tid >> 6) : 0u];
-    const uint32_t con0 = part.con0, con1 = part.con1;
+    const uint32_t con0 = uni(part.con0), con1 = uni(part.con1);
     const idx_t* lvl_cptr = P.lvl_cptr + part.lvl0;
     const idx_t* lvl_sptr = P.lvl_sptr + part.lvl0;
     const idx_t* lvl_grp = P.lvl_grp + part.lvl0;  // lanes per list, by level (fused levels only)
-    const uint32_t nlev = part.nlev;
-    const uint32_t call0 = lvl_cptr[0], call1 = lvl_cptr[nlev];  // all of the partition's (internal) variables
-    const uint32_t sall0 = lvl_sptr[0], sall1 = lvl_sptr[nlev];  // all of its strictly-lower L slots
+    const uint32_t nlev = uni(part.nlev);
+    const uint32_t call0 = uni(lvl_cptr[0]), call1 = uni(lvl_cptr[nlev]);  // all of the partition's (internal) variables
+    const uint32_t sall0 = uni(lvl_sptr[0]), sall1 = uni(lvl_sptr[nlev]);  // all of its strictly-lower L slots
 
     // ---- level staging ---------------------------------------------------------------------------------------------
     // A program read from global memory costs the Cholesky two dependent L2 round trips (ptr -> items) before the
@@ -832,87 +837,112 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     default: return reduce_lanes<64>(v, OpSum());
                     }
                 };
+                // two sums of the same group in one basic block: the two chains of cross-lane moves interleave
+                auto group_sum2 = [&](double& u, double& w, uint32_t g) {
+                    switch (g) {
+                    case 2: u = reduce_lanes<2>(u, OpSum()), w = reduce_lanes<2>(w, OpSum()); break;
+                    case 4: u = reduce_lanes<4>(u, OpSum()), w = reduce_lanes<4>(w, OpSum()); break;
+                    case 8: u = reduce_lanes<8>(u, OpSum()), w = reduce_lanes<8>(w, OpSum()); break;
+                    case 16: u = reduce_lanes<16>(u, OpSum()), w = reduce_lanes<16>(w, OpSum()); break;
+                    case 32: u = reduce_lanes<32>(u, OpSum()), w = reduce_lanes<32>(w, OpSum()); break;
+                    default: u = reduce_lanes<64>(u, OpSum()), w = reduce_lanes<64>(w, OpSum()); break;
+                    }
+                };
                 auto chol_level = [&](uint32_t c0, uint32_t c1, uint32_t s0, uint32_t s1, uint32_t g, auto fptr,
                                       auto fitems, auto lptr, auto lpairs, auto lcol) __attribute__((always_inline)) {
+                    // One phase per level: its columns and its slots are work items of ONE walk.  Item (i, j) -- a slot, or
+                    // a column's forward substitution with i = "y" -- is (target - sum of pairs) / sqrt(A_jj - sum l_jk^2):
+                    // a column's pairs are (l_vk, y_k) on the list that also gives its diagonal, a slot's are the
+                    // (l_ik, l_jk) of its own list.  Columns and slots used to run one after the other on the same
+                    // lanes (two chains of hops, sqrt and divide per level: ~4 k cycles a level on a 300-variable sketch);
+                    // as one walk a level is one chain.
+                    // (Issuing the first round of both lists' hops together -- four round trips instead of seven -- was
+                    // measured and not kept: 602 k vs 560 k cycles of factorisation per 300-variable solve; a level is
+                    // bound by the ~400 instructions a wavefront issues for it, not by the hops.)
                     if (FUSE_LEVEL && g > 1) {  // (c1 - c0) * g <= lanes, by construction
                         const uint32_t lg = (uint32_t)__builtin_ctz(g);
                         const uint32_t sub = (uint32_t)tm.lane & (g - 1), grp = (uint32_t)tm.lane >> lg;
                         const uint32_t ngrp = (uint32_t)tm.stride >> lg;
-                        const uint32_t v = c0 + grp;
-                        const bool own = v < c1;
+                        const uint32_t ncol = c1 - c0, nitem = ncol + (s1 - s0);
                         double dv = 0.0;
-                        if (own) {
-                            double sa = 0.0, sy = 0.0;
-                            const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
-                            double va[4], vb[4];
-                            EZPZ_FOR_PAIRS_STRIDED(fitems, q0 + sub, q1, g, sl, vk,
-                                                   (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
-                                                   (sa += va[k] * va[k], sy += va[k] * vb[k]))
-                            sa = group_sum(sa, g);
-                            sy = group_sum(sy, g);
-                            const double acc = ws[o_d + v] - sa;
-                            const double y = ws[o_v + v] - sy;
-                            if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
-                            dv = sqrt(acc);
-                            if (sub == 0) ws[o_v + v] = y / dv;
-                        }
-                        for (uint32_t s = s0 + grp; s < s1; s += ngrp) {
-                            const uint32_t j = lcol[s];
+                        for (uint32_t t = grp; t < nitem; t += ngrp) {
+                            const bool iscol = t < ncol;
+                            const uint32_t sl_ = s0 + (t - ncol);
+                            uint32_t j = c0 + t;
+                            if (!iscol) j = lcol[sl_];
                             double sd = 0.0, sp = 0.0;
                             {
                                 const uint32_t q0 = fptr[j], q1 = fptr[j + 1];
-                                double l[4];
-                                EZPZ_FOR_PAIRS_STRIDED(fitems, q0 + sub, q1, g, sl, vk, (l[k] = ws[o_l + sl[k]]),
-                                                       (sd += l[k] * l[k]))
+                                double l[4], yk[4];
+                                EZPZ_FOR_PAIRS_STRIDED(fitems, q0 + sub, q1, g, sl, vk,
+                                                       (l[k] = ws[o_l + sl[k]], yk[k] = iscol ? ws[o_v + vk[k]] : 0.0),
+                                                       (sd += l[k] * l[k], sp += iscol ? l[k] * yk[k] : 0.0))
                             }
-                            {
-                                const uint32_t q0 = lptr[s], q1 = lptr[s + 1];
+                            if (!iscol) {
+                                const uint32_t q0 = lptr[sl_], q1 = lptr[sl_ + 1];
                                 double va[4], vb[4];
                                 EZPZ_FOR_PAIRS_STRIDED(lpairs, q0 + sub, q1, g, ia, ib,
                                                        (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_l + ib[k]]),
                                                        (sp += va[k] * vb[k]))
                             }
-                            sd = group_sum(sd, g);
-                            sp = group_sum(sp, g);
-                            if (sub == 0) ws[o_l + s] = (ws[o_l + s] - sp) / sqrt(ws[o_d + j] - sd);
+                            const double target = ws[iscol ? o_v + j : o_l + sl_];
+                            const double diag = ws[o_d + j];
+                            group_sum2(sd, sp, g);
+                            const double acc = diag - sd;
+                            const double dj = sqrt(acc);
+                            const double res = (target - sp) / dj;
+                            if (iscol) {
+                                if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                                dv = dj;
+                            }
+                            if (sub == 0) {
+                                if (iscol)
+                                    ws[o_v + j] = res;
+                                else
+                                    ws[o_l + sl_] = res;
+                            }
                         }
+                        // d_v goes out after the rendezvous: until then A_vv is still being read
                         tm.phase_sync();
-                        if (own && sub == 0) ws[o_d + v] = dv;
+                        if (grp < ncol && sub == 0) ws[o_d + c0 + grp] = dv;
                         return;
                     }
                     if (FUSE_LEVEL && c1 - c0 <= (uint32_t)tm.stride) {
-                        const uint32_t v = c0 + tm.lane;
-                        const bool own = v < c1;
+                        // one lane per item, every term subtracted from the entry in list order: bit for bit the
+                        // textbook left-looking order
+                        const uint32_t ncol = c1 - c0, nitem = ncol + (s1 - s0);
                         double dv = 0.0;
-                        if (own) {
-                            double acc = ws[o_d + v], y = ws[o_v + v];
-                            const uint32_t q0 = fptr[v], q1 = fptr[v + 1];
-                            double va[4], vb[4];
-                            EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (va[k] = ws[o_l + sl[k]], vb[k] = ws[o_v + vk[k]]),
-                                            (acc -= va[k] * va[k], y -= va[k] * vb[k]))
-                            if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
-                            dv = sqrt(acc);
-                            ws[o_v + v] = y / dv;
-                        }
-                        for (uint32_t s = s0 + tm.lane; s < s1; s += tm.stride) {
-                            const uint32_t j = lcol[s];
+                        for (uint32_t t = tm.lane; t < nitem; t += tm.stride) {
+                            const bool iscol = t < ncol;
+                            const uint32_t sl_ = s0 + (t - ncol);
+                            uint32_t j = c0 + t;
+                            if (!iscol) j = lcol[sl_];
                             double dj = ws[o_d + j];
+                            double acc = ws[iscol ? o_v + j : o_l + sl_];
                             {
                                 const uint32_t q0 = fptr[j], q1 = fptr[j + 1];
-                                double l[4];
-                                EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (l[k] = ws[o_l + sl[k]]), (dj -= l[k] * l[k]))
+                                double l[4], yk[4];
+                                EZPZ_FOR_PAIRS4(fitems, q0, q1, sl, vk, (l[k] = ws[o_l + sl[k]], yk[k] = iscol ? ws[o_v + vk[k]] : 0.0),
+                                                (dj -= l[k] * l[k], acc -= iscol ? l[k] * yk[k] : 0.0))
                             }
-                            double acc = ws[o_l + s];
-                            {
-                                const uint32_t q0 = lptr[s], q1 = lptr[s + 1];
+                            if (!iscol) {
+                                const uint32_t q0 = lptr[sl_], q1 = lptr[sl_ + 1];
                                 double va[4], vb[4];
                                 EZPZ_FOR_PAIRS4(lpairs, q0, q1, ia, ib, (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_l + ib[k]]),
                                                 (acc -= va[k] * vb[k]))
                             }
-                            ws[o_l + s] = acc / sqrt(dj);
+                            const double root = sqrt(dj);
+                            const double res = acc / root;
+                            if (iscol) {
+                                if (!(dj > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                                dv = root;
+                                ws[o_v + j] = res;
+                            } else {
+                                ws[o_l + sl_] = res;
+                            }
                         }
                         tm.phase_sync();
-                        if (own) ws[o_d + v] = dv;
+                        if ((uint32_t)tm.lane < ncol) ws[o_d + c0 + tm.lane] = dv;
                         return;
                     }
                     for (uint32_t ci = c0 + tm.lane; ci < c1; ci += tm.stride) {
@@ -950,28 +980,30 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
                     if constexpr (LVL_STAGE) {
                         if (lvl_buf) {
-                            const uint32_t w0 = lvl_tab[2 * (nlev + 1) + lv], w1 = lvl_tab[2 * (nlev + 1) + lv + 1];
+                            const uint32_t w0 = uni(lvl_tab[2 * (nlev + 1) + lv]), w1 = uni(lvl_tab[2 * (nlev + 1) + lv + 1]);
                             if (w1 - w0 <= a.lvl_buf_words) {
-                                const uint32_t c0 = lvl_tab[lv], c1 = lvl_tab[lv + 1];
-                                const uint32_t s0 = lvl_tab[nlev + 1 + lv], s1 = lvl_tab[nlev + 1 + lv + 1];
+                                const uint32_t c0 = uni(lvl_tab[lv]), c1 = uni(lvl_tab[lv + 1]);
+                                const uint32_t s0 = uni(lvl_tab[nlev + 1 + lv]), s1 = uni(lvl_tab[nlev + 1 + lv + 1]);
                                 const uint4* src = reinterpret_cast<const uint4*>(P.lvl_stream + w0);
                                 uint4* dst = reinterpret_cast<uint4*>(lvl_buf);
                                 for (uint32_t i = tm.lane; i < (w1 - w0) / 4; i += tm.stride) dst[i] = src[i];
                                 tm.phase_sync();
-                                const uint32_t n_fwd = lvl_buf[0], n_pairs = lvl_buf[1];
+                                const uint32_t n_fwd = uni(lvl_buf[0]), n_pairs = uni(lvl_buf[1]);
                                 const uint32_t* fptr = lvl_buf + 2;
                                 const uint32_t* fitems = fptr + ((c1 - c0 + 2) & ~1u);
                                 const uint32_t* lptr = fitems + 2 * n_fwd;
                                 const uint32_t* lpairs = lptr + ((s1 - s0 + 2) & ~1u);
                                 const uint32_t* lcol = lpairs + 2 * n_pairs;
-                                chol_level(c0, c1, s0, s1, lvl_tab[3 * (nlev + 1) + lv] & 0xFFu, fptr - c0, fitems, lptr - s0, lpairs,
+                                chol_level(c0, c1, s0, s1, uni(lvl_tab[3 * (nlev + 1) + lv]) & 0xFFu, fptr - c0, fitems, lptr - s0, lpairs,
                                            lcol - s0);
+                                EZPZ_STAMP(2000 + lv);
                                 continue;
                             }
                         }
                     }
-                    chol_level(lvl_cptr[lv], lvl_cptr[lv + 1], lvl_sptr[lv], lvl_sptr[lv + 1], FUSE_LEVEL ? (lvl_grp[lv] & 0xFFu) : 1u,
-                               P.fwd_ptr, P.fwd_items, P.lpair_ptr, P.lpairs, P.l_col);
+                    chol_level(uni(lvl_cptr[lv]), uni(lvl_cptr[lv + 1]), uni(lvl_sptr[lv]), uni(lvl_sptr[lv + 1]),
+                               FUSE_LEVEL ? (uni(lvl_grp[lv]) & 0xFFu) : 1u, P.fwd_ptr, P.fwd_items, P.lpair_ptr, P.lpairs, P.l_col);
+                    EZPZ_STAMP(1000 + lv);
                 }
                 // a one-phase level stores its d_v after its rendezvous: order the last level's before the backward
                 // substitution, whose lane for v may sit in another wavefront (different group sizes)
@@ -1018,21 +1050,21 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 for (uint32_t lv = nlev; lv-- > 0;) {
                     if constexpr (LVL_STAGE) {
                         if (lvl_buf) {
-                            const uint32_t w0 = lvl_tab[4 * (nlev + 1) + lv], w1 = lvl_tab[4 * (nlev + 1) + lv + 1];
+                            const uint32_t w0 = uni(lvl_tab[4 * (nlev + 1) + lv]), w1 = uni(lvl_tab[4 * (nlev + 1) + lv + 1]);
                             if (w1 - w0 <= a.lvl_buf_words) {
-                                const uint32_t c0 = lvl_tab[lv], c1 = lvl_tab[lv + 1];
+                                const uint32_t c0 = uni(lvl_tab[lv]), c1 = uni(lvl_tab[lv + 1]);
                                 const uint4* src = reinterpret_cast<const uint4*>(P.lvl_bstream + w0);
                                 uint4* dst = reinterpret_cast<uint4*>(lvl_buf);
                                 for (uint32_t i = tm.lane; i < (w1 - w0) / 4; i += tm.stride) dst[i] = src[i];
                                 tm.phase_sync();
                                 const uint32_t* bptr = lvl_buf + 2;
                                 const uint32_t* bitems = bptr + ((c1 - c0 + 2) & ~1u);
-                                bwd_level(c0, c1, (lvl_tab[3 * (nlev + 1) + lv] >> 8) & 0xFFu, bptr - c0, bitems);
+                                bwd_level(c0, c1, (uni(lvl_tab[3 * (nlev + 1) + lv]) >> 8) & 0xFFu, bptr - c0, bitems);
                                 continue;
                             }
                         }
                     }
-                    bwd_level(lvl_cptr[lv], lvl_cptr[lv + 1], FUSE_LEVEL ? ((lvl_grp[lv] >> 8) & 0xFFu) : 1u, P.bwd_ptr,
+                    bwd_level(uni(lvl_cptr[lv]), uni(lvl_cptr[lv + 1]), FUSE_LEVEL ? ((uni(lvl_grp[lv]) >> 8) & 0xFFu) : 1u, P.bwd_ptr,
                               P.bwd_items);
                 }
                 }

@@ -33,14 +33,41 @@ __device__ __forceinline__ double dpp_move(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+// Lane l with lane l ^ 16 (HALVES false) or l ^ 32 (true) on gfx950's v_permlane16_swap / v_permlane32_swap: `a` and `b`
+// are the pair's two values in every lane of the pair (lower one in `a`), two VALU moves per 32-bit half instead of a
+// ds_bpermute round trip through the LDS crossbar.
+template <bool HALVES>
+__device__ __forceinline__ void lane_pairs(double v, double& a, double& b) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned ulo = (unsigned)u, uhi = (unsigned)(u >> 32);
+    if constexpr (HALVES) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(ulo, ulo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(uhi, uhi, false, false);
+        a = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+        b = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap(ulo, ulo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(uhi, uhi, false, false);
+        a = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+        b = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+}
 template <int WIDTH, class Op>
 __device__ __forceinline__ double reduce_lanes(double v, Op op) {
     if constexpr (WIDTH >= 2) v = op(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
     if constexpr (WIDTH >= 4) v = op(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]
     if constexpr (WIDTH >= 8) v = op(v, dpp_move<0x141>(v));  // row_half_mirror
     if constexpr (WIDTH >= 16) v = op(v, dpp_move<0x140>(v)); // row_mirror
-    if constexpr (WIDTH >= 32) v = op(v, __shfl_xor(v, 16, 64));
-    if constexpr (WIDTH >= 64) v = op(v, __shfl_xor(v, 32, 64));
+    if constexpr (WIDTH >= 32) {
+        double a, b;
+        lane_pairs<false>(v, a, b);
+        v = op(a, b);
+    }
+    if constexpr (WIDTH >= 64) {
+        double a, b;
+        lane_pairs<true>(v, a, b);
+        v = op(a, b);
+    }
     return v;
 }
 

@@ -1,7 +1,7 @@
 """Diagnostic: in-kernel s_memtime stamps of block 0 / lane 0 for one launch of the list-walk kernel.  Needs the stamped build:
 python -c "import ezpz_amd.build as b; b.build(extra_flags=['-DEZPZ_STAMPS'], lib_path=b.LIB.replace('.so', '_stamps.so'))" """
 import ctypes as C, os, sys
-os.environ["EZPZ_AMD_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ezpz_amd", "libezpz_amd_stamps.so")
+os.environ.setdefault("EZPZ_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ezpz_amd", "libezpz_amd_stamps.so"))
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 import ezpz_amd as E, gen

@@ -1,6 +1,6 @@
 """Diagnostic: in-kernel cycle stamps of block 0 / lane 0 for one solve of a test_cases fixture (needs libezpz_amd_stamps.so)."""
 import ctypes as C, os, sys
-os.environ["EZPZ_AMD_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ezpz_amd", "libezpz_amd_stamps.so")
+os.environ.setdefault("EZPZ_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ezpz_amd", "libezpz_amd_stamps.so"))
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 import ezpz_amd as E
@@ -33,9 +33,13 @@ names = {1: "start", 2: "x loaded", 10: "normal eq", 11: "chol+fwd", 12: "bwd", 
 prev = None; tot = {}
 for i, t in b:
     if i == 0: break
-    if int(i) in (40, 41, 42): continue
+    if int(i) in (40, 41, 42) or int(i) >= 1000: continue
     d = (t - prev) if prev is not None else 0
     tot[names.get(int(i), i)] = tot.get(names.get(int(i), i), 0) + d
     prev = t
+lv = [(int(i), int(t - b[k - 1][1])) for k, (i, t) in enumerate(b) if 1000 <= i < 3000]
+nl = max(i % 1000 for i, _ in lv) + 1 if lv else 0
+if lv:
+    print("Cholesky levels of the first iteration (cycles; 2xxx = staged from global):", [(i, d) for i, d in lv[:nl]])
 for k, v in tot.items(): print(f"{k:>18}: {v:8d} cycles total")
 print("total", b[b[:, 0] > 0][-1, 1] - b[0, 1])
