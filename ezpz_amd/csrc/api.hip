@@ -173,6 +173,7 @@ struct EzpzSystem {
     uint32_t prog_lds_doubles = 0;
     uint32_t lvl_lds_off = 0, lvl_tab_words = 0, lvl_buf_words = 0;  // level staging of the Cholesky lists (finish_team)
     uint32_t lvl_nlev = 0;
+    uint32_t root_k = 0, root_c0 = 0, root_s0 = 0, root_lds_off = 0, root_stride = 0;  // dense root block (make_root_block)
     bool lean_lds = false;  // batch-throughput workgroup: keep LDS per workgroup small (no whole-list staging)
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
@@ -306,8 +307,9 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
             s.lds_bytes = s.lds_ws ? prog_bytes + ws_bytes + 64 * 8 + 16 : prog_bytes + 80 * 8;
             if (lvl_ok) {
                 const size_t base = (s.lds_bytes + 15) & ~size_t(15);
-                const size_t room = s.lim.lds_bytes - 1024 > base + (size_t)lvl_tab_words * 4
-                                        ? s.lim.lds_bytes - 1024 - base - (size_t)lvl_tab_words * 4 : 0;
+                // (4 KB stay free for the dense root block, analyze_into)
+                const size_t room = s.lim.lds_bytes - 5120 > base + (size_t)lvl_tab_words * 4
+                                        ? s.lim.lds_bytes - 5120 - base - (size_t)lvl_tab_words * 4 : 0;
                 size_t buf_bytes = std::min<size_t>((size_t)s.view.lvl_words_max * 4, std::min<size_t>(room, 48 * 1024));
                 if (s.lean_lds) buf_bytes = std::min<size_t>(buf_bytes, std::max<size_t>(ws_bytes / 4, 2048));
                 buf_bytes &= ~size_t(15);
@@ -644,6 +646,7 @@ static size_t pack_program(const Program& P, bool idx16, bool pack_table, std::v
     v.o_fwd_items = put(P.fwd_items);
     v.o_bwd_ptr = put(P.bwd_ptr);
     v.o_bwd_items = put(P.bwd_items);
+    v.o_root_row = put(P.root_row);
     v.o_var_of = (uint32_t)append(blob, P.var_of);
     blob.resize((blob.size() + 15) & ~size_t(15));
     v.packed = 0;
@@ -901,6 +904,72 @@ static void choose_level_groups(Program& P, const EzpzSystem& s) {
     }
 }
 
+// Dense root block of a one-partition program (Program::root_k).  The top of a connected sketch's elimination tree is a
+// chain of separators: 15-20 levels of 1-10 columns whose lists hold 20-40 terms, each level a full round of dependent
+// hops, a reduction, a square root and a divide for a handful of entries (~2.7 k cycles a level in the factorisation,
+// ~1.2 k in the backward substitution).  The last <= 63 columns become one final level instead: its lists keep only the
+// terms of the columns before the block (the block's Schur complement, one parallel walk), and the block is factorised
+// and solved densely by one wavefront (lm_kernel.hip.hpp, root block).  Returns false -- program untouched -- when the
+// tail is not worth it (fewer than 6 levels or 8 columns) or the program has no levels before it.
+static bool make_root_block(Program& P) {
+    if (P.c.n_parts != 1 || P.c.dense || P.parts.size() != 1 || P.root_k) return false;
+    const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev, n = P.c.n_vars, zlo = P.c.zlo;
+    if (lvl0 != 0 || nlev < 8) return false;
+    static const uint32_t max_k = [] { const char* e = std::getenv("EZPZ_ROOT_K"); return e ? std::min(16u, (uint32_t)std::atoi(e)) : 16u; }();
+    uint32_t lr = nlev;
+    while (lr > 1 && n - P.lvl_cptr[lr - 1] <= max_k) --lr;
+    if (lr < 1 || nlev - lr < 6 || n - P.lvl_cptr[lr] < 8) return false;
+    const uint32_t c0 = P.lvl_cptr[lr], s0 = P.lvl_sptr[lr];
+    // rows of the block's slots, from the column lists of the backward substitution: (slot(i, j), i) per column j
+    std::vector<uint32_t> row(zlo - s0, 0xFFFFFFFFu);
+    for (uint32_t j = c0; j < n; ++j)
+        for (uint32_t q = P.bwd_ptr[j]; q < P.bwd_ptr[j + 1]; ++q) {
+            const uint32_t sl = P.bwd_items[2 * q], i = P.bwd_items[2 * q + 1];
+            if (sl < s0 || sl >= zlo || i <= j || i >= n) return false;
+            row[sl - s0] = i;
+        }
+    for (uint32_t sl = s0; sl < zlo; ++sl)
+        if (row[sl - s0] == 0xFFFFFFFFu || P.l_col[sl] < c0) return false;
+    // every list of the block keeps the terms that come from columns before it, in their order
+    {
+        std::vector<uint32_t> ptr(P.fwd_ptr.begin(), P.fwd_ptr.begin() + c0 + 1), items(P.fwd_items.begin(), P.fwd_items.begin() + 2 * (size_t)P.fwd_ptr[c0]);
+        for (uint32_t j = c0; j < n; ++j) {
+            for (uint32_t q = P.fwd_ptr[j]; q < P.fwd_ptr[j + 1]; ++q)
+                if (P.fwd_items[2 * q + 1] < c0) items.push_back(P.fwd_items[2 * q]), items.push_back(P.fwd_items[2 * q + 1]);
+            ptr.push_back((uint32_t)(items.size() / 2));
+        }
+        P.fwd_ptr.swap(ptr);
+        P.fwd_items.swap(items);
+    }
+    {
+        std::vector<uint32_t> ptr(P.lpair_ptr.begin(), P.lpair_ptr.begin() + s0 + 1), items(P.lpairs.begin(), P.lpairs.begin() + 2 * (size_t)P.lpair_ptr[s0]);
+        for (uint32_t sl = s0; sl < zlo; ++sl) {
+            for (uint32_t q = P.lpair_ptr[sl]; q < P.lpair_ptr[sl + 1]; ++q)
+                if (P.l_col[P.lpairs[2 * q]] < c0) items.push_back(P.lpairs[2 * q]), items.push_back(P.lpairs[2 * q + 1]);
+            ptr.push_back((uint32_t)(items.size() / 2));
+        }
+        P.lpair_ptr.swap(ptr);
+        P.lpairs.swap(items);
+        P.c.n_lpairs = P.lpairs.size() / 2;
+    }
+    {  // the block's backward substitution is dense: no lists
+        const uint32_t keep = P.bwd_ptr[c0];
+        P.bwd_items.resize(2 * (size_t)keep);
+        for (uint32_t j = c0 + 1; j <= n; ++j) P.bwd_ptr[j] = keep;
+    }
+    P.lvl_cptr.resize(lr + 2);
+    P.lvl_sptr.resize(lr + 2);
+    P.lvl_cptr[lr + 1] = n;
+    P.lvl_sptr[lr + 1] = zlo;
+    P.parts[0].nlev = lr + 1;
+    P.c.n_levels = lr + 1;
+    P.root_k = n - c0;
+    P.root_c0 = c0;
+    P.root_s0 = s0;
+    P.root_row.swap(row);
+    return true;
+}
+
 static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t team_size, EzpzSystem& s,
                         Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable) {
     BuildError be;
@@ -1076,23 +1145,51 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
                               P.c.n_apairs < 65536 && P.c.n_lpairs < 65536 && P.c.n_cons < 65536;
     ProgramView& v = s.view;
     size_t stage_bytes = 0;
-    if (small_counts) {
-        const size_t lists_bytes = pack_program(P, true, s.mode != MODE_SUB, blob, v);
-        const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
-        if (s.mode == MODE_SUB) {
-            if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
-        } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= s.lim.lds_bytes && !s.lean_lds) {
-            stage_bytes = lists_bytes;
+    auto pack_and_shape = [&]() {
+        stage_bytes = 0;
+        if (small_counts) {
+            const size_t lists_bytes = pack_program(P, true, s.mode != MODE_SUB, blob, v);
+            const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
+            if (s.mode == MODE_SUB) {
+                if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
+            } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= s.lim.lds_bytes && !s.lean_lds) {
+                stage_bytes = lists_bytes;
+            }
+        }
+        if (stage_bytes == 0) pack_program(P, false, false, blob, v);
+        v.stage_bytes = (uint32_t)stage_bytes;
+        s.lvl_nlev = P.parts.empty() ? 0 : P.parts[0].nlev;
+        finish_team(s, stage_bytes);
+    };
+    pack_and_shape();
+    // ---- dense root block: one solve of one connected sketch on a barrier workgroup --------------------------------------
+    s.root_k = s.root_c0 = s.root_s0 = s.root_lds_off = s.root_stride = 0;
+    static const bool root_enabled = [] {
+        const char* e = std::getenv("EZPZ_ROOT");
+        return !(e && e[0] == '0');
+    }();
+    constexpr size_t kRootBytes = 17 * 17 * 8;
+    if (root_enabled && for_latency && s.mode == MODE_WGB && s.grid_wgs == 1 &&
+        s.lds_bytes + kRootBytes + 64 <= s.lim.lds_bytes && make_root_block(P)) {
+        choose_level_groups(P, s);
+        s.counts = P.c;
+        pack_and_shape();  // (the lists only got shorter: the same shape again)
+        if (s.mode == MODE_WGB && s.lds_bytes + kRootBytes + 64 <= s.lim.lds_bytes) {
+            s.root_k = P.root_k;
+            s.root_c0 = P.root_c0;
+            s.root_s0 = P.root_s0;
+            s.root_stride = P.root_k | 1u;  // odd: the lanes of a column walk land on different banks
+            s.root_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);
+            s.lds_bytes = (size_t)s.root_lds_off * 8 + (size_t)(P.root_k + 1) * s.root_stride * 8;
+        } else {
+            be.code = EZPZ_ERR_TOO_LARGE;  // cannot happen: the same program with shorter lists
+            return fail();
         }
     }
-    if (stage_bytes == 0) pack_program(P, false, false, blob, v);
     if (blob.size() > 0xFFFFFFF0ull) {
         be.code = EZPZ_ERR_TOO_LARGE;
         return fail();
     }
-    v.stage_bytes = (uint32_t)stage_bytes;
-    s.lvl_nlev = P.parts.empty() ? 0 : P.parts[0].nlev;
-    finish_team(s, stage_bytes);
 
     EzpzSystemInfo& info = s.info;
     std::memset(&info, 0, sizeof(info));
@@ -1294,6 +1391,11 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.lvl_lds_off = sys->lvl_lds_off;
     a.lvl_tab_words = sys->lvl_tab_words;
     a.lvl_buf_words = sys->lvl_buf_words;
+    a.root_k = sys->root_k;
+    a.root_c0 = sys->root_c0;
+    a.root_s0 = sys->root_s0;
+    a.root_lds_off = sys->root_lds_off;
+    a.root_stride = sys->root_stride;
     a.stamps = g_stamps;
     a.unit_weights = sys->unit_weights ? 1u : 0u;
     a.grid_wgs = 1;

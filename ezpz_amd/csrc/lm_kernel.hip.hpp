@@ -46,6 +46,7 @@ struct ProgramView {
     uint32_t o_lpair_ptr, o_lpairs;
     uint32_t o_fwd_ptr, o_fwd_items;
     uint32_t o_bwd_ptr, o_bwd_items;
+    uint32_t o_root_row;                    // rows of the dense root block's slots (Program::root_row)
     uint32_t o_pos, o_weights, o_patterns;  // side arrays of a packed constraint table
     uint32_t packed;                        // constraint table holds 32-byte PackedCon records
     // Per-level stream of the Cholesky lists (32-bit programs of one partition; see pack_program): level lv is words
@@ -74,6 +75,7 @@ struct Prog {
     const IDX *lpair_ptr, *lpairs;
     const IDX *fwd_ptr, *fwd_items;
     const IDX *bwd_ptr, *bwd_items;
+    const IDX* root_row;
     const uint32_t *lvl_off, *lvl_stream;  // per-level blocks of the Cholesky lists (32-bit programs of one partition)
     const uint32_t *lvl_boff, *lvl_bstream;  // ... and of the backward substitution's
 };
@@ -105,6 +107,7 @@ __device__ __forceinline__ Prog<IDX> make_prog(const ProgramView& v, const unsig
     p.fwd_items = u(v.o_fwd_items);
     p.bwd_ptr = u(v.o_bwd_ptr);
     p.bwd_items = u(v.o_bwd_items);
+    p.root_row = u(v.o_root_row);
     p.lvl_off = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_off);
     p.lvl_stream = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_stream);
     p.lvl_boff = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_boff);
@@ -222,6 +225,9 @@ struct SolveArgs {
     // level staging (see the Cholesky loop): LDS offset (doubles) of the level tables, words reserved for the tables,
     // words of one level buffer (0 = off)
     uint32_t lvl_lds_off, lvl_tab_words, lvl_buf_words;
+    // dense root block (Program::root_k; barrier workgroups with program and workspace in LDS): columns, first column,
+    // first slot, LDS offset (doubles) and row stride (doubles) of the (root_k + 1) x root_k array; root_k == 0: none
+    uint32_t root_k, root_c0, root_s0, root_lds_off, root_stride;
 };
 
 #ifdef EZPZ_STAMPS
@@ -977,7 +983,120 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                         ws[o_l + s] = ws[o_l + s] / ws[o_d + lcol[s]];
                     tm.phase_sync();
                 };
+                // ---- dense root block (Program::root_k, api.hip: make_root_block) ------------------------------------------
+                // The last level of such a program is the elimination tree's top separators as ONE block of K
+                // columns (K <= 16).  (1) All lanes, g per list: the block's Schur complement -- every structural entry (i, j),
+                // the diagonal and b minus its terms from the columns before the block -- into a dense (K + 1) x K array
+                // in LDS (row K is b; structurally zero entries stay zero through the factorisation: no fill is
+                // created that the symbolic phase had not found).  (2) One wavefront, lane = row, no barriers:
+                // left-looking dense Cholesky with the forward substitution as row K (pivots travel by v_readlane),
+                // then the backward substitution.  The top ten levels (~4 k cycles each) become ~1 k cycles per column.
+                // The sums run in a different order than the list walk's (as between any two elimination orders).
+                constexpr bool ROOT_OK = MODE == MODE_WGB && !GRID && !DENSE;
+                auto readlane_f64 = [](double v, uint32_t l) {
+                    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, (int)l);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), (int)l);
+                    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                };
+                auto root_block = [&](uint32_t lv) __attribute__((always_inline)) {
+                    const uint32_t K = a.root_k, ST = a.root_stride, cR = a.root_c0, sR = a.root_s0;
+                    double* D = smem + a.root_lds_off;
+                    const uint32_t g = uni(lvl_grp[lv]) & 0xFFu;
+                    const uint32_t lg = (uint32_t)__builtin_ctz(g);
+                    const uint32_t sub = (uint32_t)tm.lane & (g - 1), grp = (uint32_t)tm.lane >> lg;
+                    const uint32_t ngrp = (uint32_t)tm.stride >> lg;
+                    const uint32_t nitem = K + (uni(lvl_sptr[lv + 1]) - sR);
+                    for (uint32_t t = grp; t < nitem; t += ngrp) {
+                        const bool iscol = t < K;
+                        const uint32_t sl_ = sR + (t - K);
+                        uint32_t q0, q1;
+                        if (iscol) {
+                            q0 = P.fwd_ptr[cR + t];
+                            q1 = P.fwd_ptr[cR + t + 1];
+                        } else {
+                            q0 = P.lpair_ptr[sl_];
+                            q1 = P.lpair_ptr[sl_ + 1];
+                        }
+                        const idx_t* lst = iscol ? P.fwd_items : P.lpairs;  // (l_jk, y_k) or (l_ik, l_jk)
+                        const uint32_t o_b = iscol ? o_v : o_l;
+                        double sp = 0.0, sd = 0.0;
+                        double va[4], vb[4];
+                        EZPZ_FOR_PAIRS_STRIDED(lst, q0 + sub, q1, g, ia, ib, (va[k] = ws[o_l + ia[k]], vb[k] = ws[o_b + ib[k]]),
+                                               (sp += va[k] * vb[k], sd += va[k] * va[k]))
+                        if (g > 1) group_sum2(sp, sd, g);
+                        if (sub == 0) {
+                            if (iscol) {
+                                D[t * ST + t] = ws[o_d + cR + t] - sd;
+                                D[K * ST + t] = ws[o_v + cR + t] - sp;
+                            } else {
+                                D[(P.root_row[sl_ - sR] - cR) * ST + (P.l_col[sl_] - cR)] = ws[o_l + sl_] - sp;
+                            }
+                        }
+                    }
+                    tm.phase_sync();
+                    if (tid < 64) {
+                        const uint32_t r = (uint32_t)tid, rr = r <= K ? r : K;
+                        // lane r holds row r of the block in registers (K <= 16; row K is b); right-looking: once column
+                        // j is done every later column k of every row takes its term l_rj * l_kj, l_kj by v_readlane --
+                        // each entry still receives its terms in ascending column order
+                        auto factor = [&](auto km_tag) __attribute__((always_inline)) {
+                            constexpr int KM = decltype(km_tag)::value;
+                            double rg[KM];
+#pragma unroll
+                            for (int c = 0; c < KM; ++c) rg[c] = (uint32_t)c < K ? D[rr * ST + c] : 0.0;
+#pragma unroll
+                            for (int j = 0; j < KM; ++j) {
+                                if ((uint32_t)j < K) {
+                                    const double piv = readlane_f64(rg[j], j);
+                                    if (!(piv > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                                    const double dj = sqrt(piv);
+                                    const double l = rg[j] / dj;
+                                    if (r == (uint32_t)j)
+                                        D[j * ST + j] = dj;
+                                    else if (r > (uint32_t)j && r <= K)
+                                        D[r * ST + j] = l;
+#pragma unroll
+                                    for (int k = j + 1; k < KM; ++k) rg[k] -= l * readlane_f64(l, k);
+                                }
+                            }
+                        };
+                        // (a 32-column variant beside this one costs the whole kernel its register allocation: one
+                        // 300-variable solve 296 -> 368 us even when only the 16-column code runs)
+                        factor(std::integral_constant<int, 16>());
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        // backward substitution: lane r carries y_r minus the terms of the rows already solved
+                        const uint32_t rc = r < K ? r : K - 1;
+                        double rem = D[K * ST + rc], xr = 0.0;
+                        const double dr = D[rc * ST + rc];
+                        for (uint32_t j = K; j-- > 0;) {
+                            const double xj = readlane_f64(rem / dr, j);
+                            if (r < j) rem -= D[j * ST + rc] * xj;
+                            if (r == j) xr = xj;
+                        }
+                        if (r < K) {
+                            ws[o_v + cR + r] = xr;
+                            dmax = fmax(dmax, fabs(xr));
+                        }
+                    }
+                    tm.phase_sync();
+                };
+                if constexpr (ROOT_OK) {
+                    if (a.root_k) {  // (the levels' rendezvous order this before the block's entries are written)
+                        double* D = smem + a.root_lds_off;
+                        for (uint32_t i = (uint32_t)tid; i < (a.root_k + 1) * a.root_stride; i += blockDim.x) D[i] = 0.0;
+                    }
+                }
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
+                    if constexpr (ROOT_OK) {
+                        if (a.root_k && lv + 1 == nlev) {
+                            root_block(lv);
+                            EZPZ_STAMP(1000 + lv);
+                            continue;
+                        }
+                    }
                     if constexpr (LVL_STAGE) {
                         if (lvl_buf) {
                             const uint32_t w0 = uni(lvl_tab[2 * (nlev + 1) + lv]), w1 = uni(lvl_tab[2 * (nlev + 1) + lv + 1]);
@@ -1048,6 +1167,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     tm.phase_sync();
                 };
                 for (uint32_t lv = nlev; lv-- > 0;) {
+                    if constexpr (ROOT_OK) {
+                        if (a.root_k && lv + 1 == nlev) continue;  // solved densely with the block
+                    }
                     if constexpr (LVL_STAGE) {
                         if (lvl_buf) {
                             const uint32_t w0 = uni(lvl_tab[4 * (nlev + 1) + lv]), w1 = uni(lvl_tab[4 * (nlev + 1) + lv + 1]);

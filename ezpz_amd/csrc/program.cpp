@@ -214,7 +214,9 @@ void nested_dissection(const std::vector<uint32_t>& verts, const IVecs& adj, std
             bfs(s0, t.region);
             bfs(queue.back(), t.region);  // pseudo-peripheral: restart from the farthest vertex
             const uint32_t depth = level[queue.back()];
-            if (queue.size() <= 16 || depth < 4) {  // small or compact piece: a leaf, in request order
+            static const uint32_t leaf = [] { const char* e = std::getenv("EZPZ_ND_LEAF"); return e ? (uint32_t)std::atoi(e) : 16u; }();
+            static const uint32_t mind = [] { const char* e = std::getenv("EZPZ_ND_DEPTH"); return e ? (uint32_t)std::atoi(e) : 4u; }();
+            if (queue.size() <= leaf || depth < mind) {  // small or compact piece: a leaf, in request order
                 IVec piece(queue.begin(), queue.end(), pool);
                 std::sort(piece.begin(), piece.end());
                 for (uint32_t v : piece) {

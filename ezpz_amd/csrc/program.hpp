@@ -51,6 +51,12 @@ struct Program {
     // per (partition, level): lanes that share one list of the level's Cholesky walks (a power of two; 1 = one lane
     // per list).  Filled by the launch-shape code (api.hip: choose_level_groups); empty means 1 everywhere.
     std::vector<uint32_t> lvl_grp;
+    // Dense root block (api.hip: make_root_block; one-partition programs of the latency shape only): the last root_k
+    // columns [root_c0, n_vars) -- the top separators of the elimination tree -- are one final "level" whose lists are cut
+    // to the columns before root_c0 (the Schur complement's terms); the block itself is factorised densely by one
+    // wavefront.  root_row[s - root_s0] = row (internal variable) of strictly-lower slot s >= root_s0.  root_k == 0: none.
+    uint32_t root_k = 0, root_c0 = 0, root_s0 = 0;
+    std::vector<uint32_t> root_row;
 };
 
 struct BuildError {

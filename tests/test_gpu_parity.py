@@ -665,6 +665,55 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
     assert_x_close(x[0], want.final_values)
 
 
+@pytest.mark.parametrize("npts", [60, 150, 260, 400, 1200])
+def test_connected_sketch_latency_shape_with_dense_root_block(E, npts):
+    """The launch shape of one solve (`TEAM_AUTO_LATENCY`, what `ezpz_solve` asks for) ends the elimination of a connected
+    sketch with a dense block: the last <= 16 columns -- the top separators, ten or so levels of one or two columns -- are
+    one final level whose Schur complement is gathered by all lanes and factorised in one wavefront's registers
+    (api.hip: make_root_block; lm_kernel.hip.hpp: root block), with the program staged in LDS (120-520 variables), read
+    from global memory (800) and with the workspace in global memory too (2400).  Against the oracle (iteration counts,
+    flags, masks, coordinates at 1e-6), against the plain level walk (an explicit team size keeps it), from run to
+    run, from a NaN start (every pivot fails: lambda grows, the iterations burn) and on an inconsistent system."""
+    recs, g = gen.connected_sketch(npts, 500 + npts)
+    n = len(g)
+    lat = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY)
+    walk = E.System(recs, n, team_size=512)
+    li, wi = lat.info(), walk.info()
+    assert li["team_mode"] == 2 and li["n_components"] == 1
+    assert li["n_levels"] + 5 <= wi["n_levels"], (li["n_levels"], wi["n_levels"])  # the top levels became the block
+    cfg = dict(max_iterations=40)
+    x0 = g[None, :] + gen.keyed_uniform(npts, 6, n, -0.02, 0.02)
+    x0[0] = g
+    x0[5, 3] = float("nan")
+    x, st, mask = lat.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    x2, st2, _ = lat.solve_batch(x0, E.Config(**cfg))
+    assert np.array_equal(x2, x, equal_nan=True) and np.array_equal(st2["iterations"], st["iterations"])
+    xw, stw, maskw = walk.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    for b in range(6):
+        want = O.solve(recs, x0[b], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert want.error == 0
+        assert bool(st["converged"][b]) == want.converged and np.nonzero(mask[b])[0].tolist() == want.unsatisfied, b
+        if b == 5:
+            assert not want.converged and int(st["iterations"][b]) == want.iterations == 40
+            assert np.array_equal(np.isnan(x[b]), np.isnan(want.final_values))
+            continue
+        assert want.converged and abs(int(st["iterations"][b]) - want.iterations) <= (0 if want.iterations <= 12 else 2), b
+        assert int(st["n_warnings"][b]) == len(want.warnings)
+        assert_x_close(x[b], want.final_values)
+        assert int(stw["iterations"][b]) == int(st["iterations"][b]) and np.array_equal(maskw[b], mask[b])
+        assert_x_close(x[b], xw[b], 1e-9)
+    # an inconsistent sketch (the last point pinned away from where its distances put it): least-squares exit, same
+    # unsatisfied rows as the oracle's
+    bad = O.stack(list(recs) + [O.fixed(n - 2, float(g[n - 2]) + 0.4)])
+    lat2 = E.System(bad, n, team_size=E.TEAM_AUTO_LATENCY)
+    xb, stb, maskb = lat2.solve_batch(g[None, :], E.Config(max_iterations=60), want_mask=True)
+    want = O.solve(bad, g, O.Config(max_iterations=60), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+    assert bool(stb["converged"][0]) == want.converged and np.nonzero(maskb[0])[0].tolist() == want.unsatisfied
+    # (a least-squares exit is the step test on a flat valley floor: the count hinges on the last bits, DESIGN.md section 4)
+    assert abs(float(stb["final_residual_inf"][0]) - want.final_residual_inf) <= 1e-6 * max(1.0, want.final_residual_inf)
+    assert_x_close(xb[0], want.final_values, 1e-4)
+
+
 def _hub_sketch(npts, seed, hub_last):
     """`npts` points each tied to one hub point (a distance and a horizontal distance): one connected component.  The
     hub's two variables come last or -- the way a sketch dimensioned from its origin is written -- first; the layout
