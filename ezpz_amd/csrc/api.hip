@@ -910,9 +910,10 @@ static void choose_level_groups(Program& P, const EzpzSystem& s) {
 // ~1.2 k in the backward substitution).  The last <= 63 columns become one final level instead: its lists keep only the
 // terms of the columns before the block (the block's Schur complement, one parallel walk), and the block is factorised
 // and solved densely by one wavefront (lm_kernel.hip.hpp, root block).  Returns false -- program untouched -- when the
-// tail is not worth it (fewer than 6 levels or 8 columns) or the program has no levels before it.
+// tail is not worth it (fewer than 6 levels or 8 columns), the program has no levels before it, or the system is not one
+// connected component (the top levels of a block system are not a chain).
 static bool make_root_block(Program& P) {
-    if (P.c.n_parts != 1 || P.c.dense || P.parts.size() != 1 || P.root_k) return false;
+    if (P.c.n_parts != 1 || P.c.n_components != 1 || P.c.dense || P.parts.size() != 1 || P.root_k) return false;
     const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev, n = P.c.n_vars, zlo = P.c.zlo;
     if (lvl0 != 0 || nlev < 8) return false;
     static const uint32_t max_k = [] { const char* e = std::getenv("EZPZ_ROOT_K"); return e ? std::min(16u, (uint32_t)std::atoi(e)) : 16u; }();
@@ -1169,7 +1170,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return !(e && e[0] == '0');
     }();
     constexpr size_t kRootBytes = 17 * 17 * 8;
-    if (root_enabled && for_latency && s.mode == MODE_WGB && s.grid_wgs == 1 &&
+    // (not on the lean 128-lane batch shape: 300 variables 1.61 -> 1.40 M solves/s with it; 256-512 lanes: 800 variables
+    // 41.7 -> 49.7 k/s, 2000: 90 -> 97 k/s)
+    if (root_enabled && auto_shape && s.mode == MODE_WGB && s.grid_wgs == 1 && (for_latency || s.team_size >= 256) &&
         s.lds_bytes + kRootBytes + 64 <= s.lim.lds_bytes && make_root_block(P)) {
         choose_level_groups(P, s);
         s.counts = P.c;

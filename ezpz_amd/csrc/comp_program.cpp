@@ -771,7 +771,7 @@ bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Batc
     if (n_cs == 0 || n_vars == 0 || n_vars > 60000 || n_cs > 60000) return false;
     Class cl;
     BuildError be;
-    if (!build_program(cs, n_cs, n_vars, cl.Q, be, 1, false)) return false;
+    if (!build_program(cs, n_cs, n_vars, cl.Q, be, 1, false, true)) return false;
     const Program& Q = cl.Q;
     if (Q.c.n_parts != 1 || Q.c.zj >= 0xFFFF || Q.c.zlo >= 0xFFFF || Q.c.n_rows >= 0xFFFF) return false;
     plan.unit_weights = true;

@@ -254,7 +254,7 @@ void nested_dissection(const std::vector<uint32_t>& verts, const IVecs& adj, std
 }  // namespace
 
 bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& P, BuildError& err,
-                   uint32_t want_parts, bool dense) {
+                   uint32_t want_parts, bool dense, bool serial) {
     P = Program();
     P.c.dense = dense ? 1u : 0u;
     if (dense) want_parts = 1;
@@ -432,7 +432,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
             // whenever nothing is gained by leaving it
             auto score = [&](const std::vector<uint32_t>& o) {
                 const OrderCost c = component_cost(o, adj, local_id, pool);
-                return c.fill + 64ull * c.height;
+                return c.fill + (serial ? 0ull : 64ull * c.height);  // (one lane per system: levels cost nothing)
             };
             uint64_t best = score(verts);
             const std::vector<uint32_t>* pick = &verts;

@@ -78,8 +78,10 @@ int kind_num_ids(uint16_t kind);
 // systems, one partition: L keeps every strictly-lower entry, column by column in elimination order
 // (slot of column j: lvl_sptr[j] + (i - j - 1)), every column is its own level, and no Cholesky / substitution
 // lists are emitted -- the kernel factorises with plain loops over i, j instead of walking lists level by level.
+// `serial`: the factorisation will be walked by ONE lane (lanes across the batch): the elimination order is chosen for
+// the fewest entries of L alone, not for few levels.
 bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program& out, BuildError& err,
-                   uint32_t want_parts = 1, bool dense = false);
+                   uint32_t want_parts = 1, bool dense = false, bool serial = false);
 
 // 64-bit topology hash (kinds, tags, ids; not params/weights) for the host-side program cache.
 uint64_t topology_hash(const EzpzConstraint* cs, size_t n_cs, size_t n_vars);

@@ -680,7 +680,7 @@ def test_connected_sketch_latency_shape_with_dense_root_block(E, npts):
     walk = E.System(recs, n, team_size=512)
     li, wi = lat.info(), walk.info()
     assert li["team_mode"] == 2 and li["n_components"] == 1
-    assert li["n_levels"] + 5 <= wi["n_levels"], (li["n_levels"], wi["n_levels"])  # the top levels became the block
+    assert li["n_levels"] + 4 <= wi["n_levels"], (li["n_levels"], wi["n_levels"])  # the top levels became the block
     cfg = dict(max_iterations=40)
     x0 = g[None, :] + gen.keyed_uniform(npts, 6, n, -0.02, 0.02)
     x0[0] = g
