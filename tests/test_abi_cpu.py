@@ -91,6 +91,22 @@ def test_symbolic_sizes_massive_and_square():
     assert (j["n_constraints"], j["n_rows"], j["n_vars"], j["nnz_j"], j["nnz_a"], j["nnz_l"]) == (10, 10, 8, 40, 36, 36)
 
 
+def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
+    """Host side of the dense root block (api.hip: make_root_block): on a 512-lane workgroup the last <= 16 columns of
+    a connected sketch's elimination order -- ten or so levels of one or two columns -- are one level of the schedule;
+    EZPZ_ROOT=0 keeps the plain schedule (read once per process, hence the child processes).  Block systems keep theirs."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import gen, ezpz_amd as E; "
+            "from oracle import textual as T; r, g = gen.connected_sketch(400, 7); cs = T.load(T.gen_big_problem(500)); "
+            "print(E.analyze(r, len(g))['n_levels'], E.analyze(cs.constraints, cs.num_vars)['n_levels'])") % (ROOT, os.path.join(ROOT, "tests"))
+    def levels(**env):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        return [int(v) for v in out.stdout.split()]
+    with_block, plain = levels(), levels(EZPZ_ROOT="0")
+    assert with_block[0] + 5 <= plain[0] and with_block[1] == plain[1] == 2, (with_block, plain)
+
+
 def test_symbolic_phase_reports_missing_guess():
     """solver.rs:142-189: first id (row0 then row1, constraint order) that has no guess."""
     with pytest.raises(E.NonLinearSystemError) as e:
