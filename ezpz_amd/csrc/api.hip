@@ -173,7 +173,7 @@ struct EzpzSystem {
     uint32_t prog_lds_doubles = 0;
     uint32_t lvl_lds_off = 0, lvl_tab_words = 0, lvl_buf_words = 0;  // level staging of the Cholesky lists (finish_team)
     uint32_t lvl_nlev = 0;
-    uint32_t root_k = 0, root_c0 = 0, root_s0 = 0, root_lds_off = 0, root_stride = 0;  // dense root block (make_root_block)
+    uint32_t n_dense = 0, dense_level0 = 0, dense_lds_off = 0, dense_lds_doubles = 0;  // dense phases (make_dense_phases)
     bool lean_lds = false;  // batch-throughput workgroup: keep LDS per workgroup small (no whole-list staging)
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
@@ -646,7 +646,9 @@ static size_t pack_program(const Program& P, bool idx16, bool pack_table, std::v
     v.o_fwd_items = put(P.fwd_items);
     v.o_bwd_ptr = put(P.bwd_ptr);
     v.o_bwd_items = put(P.bwd_items);
-    v.o_root_row = put(P.root_row);
+    v.o_dense_col = put(P.dense_col);
+    v.o_dense_slot = put(P.dense_slot);
+    v.o_dense_tab = put(P.dense_tab);
     v.o_var_of = (uint32_t)append(blob, P.var_of);
     blob.resize((blob.size() + 15) & ~size_t(15));
     v.packed = 0;
@@ -712,11 +714,14 @@ static size_t pack_program(const Program& P, bool idx16, bool pack_table, std::v
             while (stream.size() % to) stream.push_back(0);
         };
         uint32_t widest = 0;
+        // (dense phases read their lists in place: no blocks for them, and their width does not size the level buffer)
+        const uint32_t nwalk = P.n_dense ? P.dense_level0 : nlev;
         for (uint32_t lv = 0; lv < nlev; ++lv) {
+            off[lv] = (uint32_t)stream.size();
+            if (lv >= nwalk) continue;
             const uint32_t c0 = P.lvl_cptr[lvl0 + lv], c1 = P.lvl_cptr[lvl0 + lv + 1];
             const uint32_t s0 = P.lvl_sptr[lvl0 + lv], s1 = P.lvl_sptr[lvl0 + lv + 1];
             const uint32_t fq0 = P.fwd_ptr[c0], fq1 = P.fwd_ptr[c1], lq0 = P.lpair_ptr[s0], lq1 = P.lpair_ptr[s1];
-            off[lv] = (uint32_t)stream.size();
             stream.push_back(fq1 - fq0);
             stream.push_back(lq1 - lq0);
             for (uint32_t k = c0; k <= c1; ++k) stream.push_back(P.fwd_ptr[k] - fq0);
@@ -732,9 +737,10 @@ static size_t pack_program(const Program& P, bool idx16, bool pack_table, std::v
         off[nlev] = (uint32_t)stream.size();
         std::vector<uint32_t> boff(nlev + 1), bstream;
         for (uint32_t lv = 0; lv < nlev; ++lv) {
+            boff[lv] = (uint32_t)bstream.size();
+            if (lv >= nwalk) continue;
             const uint32_t c0 = P.lvl_cptr[lvl0 + lv], c1 = P.lvl_cptr[lvl0 + lv + 1];
             const uint32_t q0 = P.bwd_ptr[c0], q1 = P.bwd_ptr[c1];
-            boff[lv] = (uint32_t)bstream.size();
             bstream.push_back(q1 - q0);
             bstream.push_back(0);
             for (uint32_t k = c0; k <= c1; ++k) bstream.push_back(P.bwd_ptr[k] - q0);
@@ -904,70 +910,210 @@ static void choose_level_groups(Program& P, const EzpzSystem& s) {
     }
 }
 
-// Dense root block of a one-partition program (Program::root_k).  The top of a connected sketch's elimination tree is a
-// chain of separators: 15-20 levels of 1-10 columns whose lists hold 20-40 terms, each level a full round of dependent
-// hops, a reduction, a square root and a divide for a handful of entries (~2.7 k cycles a level in the factorisation,
-// ~1.2 k in the backward substitution).  The last <= 63 columns become one final level instead: its lists keep only the
-// terms of the columns before the block (the block's Schur complement, one parallel walk), and the block is factorised
-// and solved densely by one wavefront (lm_kernel.hip.hpp, root block).  Returns false -- program untouched -- when the
-// tail is not worth it (fewer than 6 levels or 8 columns), the program has no levels before it, or the system is not one
-// connected component (the top levels of a block system are not a chain).
-static bool make_root_block(Program& P) {
-    if (P.c.n_parts != 1 || P.c.n_components != 1 || P.c.dense || P.parts.size() != 1 || P.root_k) return false;
+// Dense phases of a one-partition program of one connected component (Program::n_dense).  The top of a connected
+// sketch's elimination tree is a tree of separators: chains of one or two columns per level whose lists hold 20-40 terms,
+// each level a full round of dependent hops, a reduction, a square root and a divide for a handful of entries (~3 k
+// cycles a level in the factorisation, ~1.2 k in the backward substitution).  From the top down, runs of whole levels
+// become phases: the columns of a phase fall into the connected pieces of the elimination tree inside it (at most one per
+// wavefront, <= 16 columns and <= 63 panel rows each), every piece a dense panel (lm_kernel.hip.hpp, dense phases).  The
+// last phase is the root block (the last <= 16 columns).  Returns false -- program untouched -- when the root block is
+// not worth it (fewer than 5 levels), or for anything but one connected component in one partition.
+static bool make_dense_phases(Program& P, uint32_t n_waves, size_t lds_room_bytes) {
+    if (P.c.n_parts != 1 || P.c.n_components != 1 || P.c.dense || P.parts.size() != 1 || P.n_dense) return false;
     const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev, n = P.c.n_vars, zlo = P.c.zlo;
-    if (lvl0 != 0 || nlev < 8) return false;
-    static const uint32_t max_k = [] { const char* e = std::getenv("EZPZ_ROOT_K"); return e ? std::min(16u, (uint32_t)std::atoi(e)) : 16u; }();
-    uint32_t lr = nlev;
-    while (lr > 1 && n - P.lvl_cptr[lr - 1] <= max_k) --lr;
-    if (lr < 1 || nlev - lr < 6 || n - P.lvl_cptr[lr] < 8) return false;
-    const uint32_t c0 = P.lvl_cptr[lr], s0 = P.lvl_sptr[lr];
-    // rows of the block's slots, from the column lists of the backward substitution: (slot(i, j), i) per column j
-    std::vector<uint32_t> row(zlo - s0, 0xFFFFFFFFu);
-    for (uint32_t j = c0; j < n; ++j)
+    if (lvl0 != 0 || nlev < 6 || n_waves == 0) return false;
+    constexpr uint32_t kMaxCols = 16, kMaxRows = 63, kMaxPhases = 4, NONE = 0xFFFFFFFFu;
+    n_waves = std::min(n_waves, 8u);
+    std::vector<uint32_t> level(n), parent(n, NONE);
+    for (uint32_t lv = 0; lv < nlev; ++lv)
+        for (uint32_t j = P.lvl_cptr[lv]; j < P.lvl_cptr[lv + 1]; ++j) level[j] = lv;
+    for (uint32_t j = 0; j < n; ++j)
         for (uint32_t q = P.bwd_ptr[j]; q < P.bwd_ptr[j + 1]; ++q) {
             const uint32_t sl = P.bwd_items[2 * q], i = P.bwd_items[2 * q + 1];
-            if (sl < s0 || sl >= zlo || i <= j || i >= n) return false;
-            row[sl - s0] = i;
+            if (sl >= zlo || i <= j || i >= n || P.l_col[sl] != j) return false;
+            parent[j] = std::min(parent[j], i);  // the first row below the diagonal is the parent in the elimination tree
         }
-    for (uint32_t sl = s0; sl < zlo; ++sl)
-        if (row[sl - s0] == 0xFFFFFFFFu || P.l_col[sl] < c0) return false;
-    // every list of the block keeps the terms that come from columns before it, in their order
+    struct Block {
+        std::vector<uint32_t> cols, below;  // ascending
+    };
+    struct Phase {
+        uint32_t la, lb;
+        std::vector<Block> blocks;
+    };
+    // the blocks of the levels [la, lb): connected pieces of the tree inside them, each with the later rows it touches
+    auto cut = [&](uint32_t la, uint32_t lb, std::vector<Block>& out) -> bool {
+        const uint32_t c0 = P.lvl_cptr[la], c1 = P.lvl_cptr[lb];
+        std::vector<uint32_t> top(c1 - c0);
+        // (parents come later in the numbering: one pass from the top labels every column with its piece's top column)
+        for (uint32_t j = c1; j-- > c0;) top[j - c0] = (parent[j] != NONE && parent[j] < c1) ? top[parent[j] - c0] : j;
+        std::vector<uint32_t> tops;
+        for (uint32_t j = c0; j < c1; ++j)
+            if (top[j - c0] == j) tops.push_back(j);
+        if (tops.size() > std::min(16u, 2 * n_waves)) return false;  // at most two blocks per wavefront
+        out.assign(tops.size(), Block());
+        for (uint32_t j = c0; j < c1; ++j) {
+            const size_t b = std::lower_bound(tops.begin(), tops.end(), top[j - c0]) - tops.begin();
+            out[b].cols.push_back(j);
+            for (uint32_t q = P.bwd_ptr[j]; q < P.bwd_ptr[j + 1]; ++q) {
+                const uint32_t i = P.bwd_items[2 * q + 1];
+                if (i >= c1)
+                    out[b].below.push_back(i);
+                else if (top[i - c0] != top[j - c0])
+                    return false;  // (cannot happen: a row of column j is an ancestor of j)
+            }
+        }
+        for (Block& b : out) {
+            std::sort(b.below.begin(), b.below.end());
+            b.below.erase(std::unique(b.below.begin(), b.below.end()), b.below.end());
+            if (b.cols.size() > kMaxCols || b.cols.size() + b.below.size() + 1 > kMaxRows) return false;
+        }
+        return true;
+    };
+    auto lds_doubles = [](const std::vector<Block>& bs) {
+        size_t d = 0;
+        for (const Block& b : bs) d += (b.cols.size() + b.below.size() + 1) * (b.cols.size() | 1u);
+        return d;
+    };
+    std::vector<Phase> phases;  // from the top down
+    size_t lds_used = 0;
     {
-        std::vector<uint32_t> ptr(P.fwd_ptr.begin(), P.fwd_ptr.begin() + c0 + 1), items(P.fwd_items.begin(), P.fwd_items.begin() + 2 * (size_t)P.fwd_ptr[c0]);
-        for (uint32_t j = c0; j < n; ++j) {
+        uint32_t la = nlev;
+        while (la > 1 && n - P.lvl_cptr[la - 1] <= kMaxCols) --la;
+        Phase root{la, nlev, {}};
+        if (nlev - la < 5 || !cut(la, nlev, root.blocks)) return false;
+        if (root.blocks.size() != 1) {  // several tree tops among the last columns: still one panel (no rows below it)
+            Block all;
+            for (uint32_t j = P.lvl_cptr[la]; j < n; ++j) all.cols.push_back(j);
+            root.blocks.assign(1, all);
+        }
+        lds_used = lds_doubles(root.blocks) * 8;
+        if (lds_used > lds_room_bytes) return false;
+        phases.push_back(std::move(root));
+    }
+    static const uint32_t max_phases = [] {
+        const char* e = std::getenv("EZPZ_DENSE_PHASES");
+        return e ? std::min<uint32_t>(4u, (uint32_t)std::atoi(e)) : 4u;
+    }();
+    while (phases.size() < max_phases) {
+        const uint32_t lb = phases.back().la;
+        // How far down?  A walked level costs ~4.1 k cycles (2.9 k in the factorisation, 1.2 k in the backward substitution).
+        // A phase costs ~9 k for its gather, write-back and rendezvous, ~3 k per round of blocks (one block per wavefront
+        // and round, the largest blocks first) and ~0.8 k per column of a round's largest block (stamps on the 300-variable
+        // sketch: 16 blocks of <= 3 columns 12.3 k + 6.7 k cycles, 4 blocks of <= 14: 14.6 k + 6.7 k, the root block of 16:
+        // 12.7 k + 6.7 k): the cut that saves most.
+        uint32_t la = lb, best_la = lb;
+        double best_saving = 0.0;
+        std::vector<Block> best, trial;
+        while (la > 1 && cut(la - 1, lb, trial) && lds_used + lds_doubles(trial) * 8 <= lds_room_bytes) {
+            --la;
+            std::sort(trial.begin(), trial.end(), [](const Block& x, const Block& y) { return x.cols.size() > y.cols.size(); });
+            double cost = 9000.0;
+            for (size_t b = 0; b < trial.size(); b += n_waves) cost += 3000.0 + 800.0 * (double)trial[b].cols.size();
+            const double saving = 4100.0 * (lb - la) - cost;
+            if (saving > best_saving) best_saving = saving, best_la = la, best = trial;
+        }
+        if (best_la == lb) break;
+        la = best_la;
+        lds_used += lds_doubles(best) * 8;
+        phases.push_back(Phase{la, lb, std::move(best)});
+    }
+    std::reverse(phases.begin(), phases.end());  // in the order they run
+    if (std::getenv("EZPZ_DENSE_DEBUG")) {
+        for (const Phase& ph : phases) {
+            std::fprintf(stderr, "dense phase: levels [%u, %u) of %u:", ph.la, ph.lb, nlev);
+            for (const Block& b : ph.blocks) std::fprintf(stderr, " %zu cols + %zu rows below;", b.cols.size(), b.below.size());
+            std::fprintf(stderr, "\n");
+        }
+        std::vector<Block> t;
+        const uint32_t lb = phases.front().la;
+        for (uint32_t la = lb; la-- > 0 && lb - la <= 8;) {
+            const bool ok = cut(la, lb, t);
+            std::fprintf(stderr, "  next phase [%u, %u): %s, %zu blocks:", la, lb, ok ? "ok" : "no", t.size());
+            for (const Block& b : t) std::fprintf(stderr, " %zu+%zu", b.cols.size(), b.below.size());
+            std::fprintf(stderr, "\n");
+        }
+    }
+    const uint32_t lw = phases.front().la, dc0 = P.lvl_cptr[lw], ds0 = P.lvl_sptr[lw];
+    // ---- tables ---------------------------------------------------------------------------------------------------------------
+    std::vector<uint32_t> dcol(n - dc0, 0), dslot(zlo - ds0, 0), cutcol(n - dc0, 0), tab(1 + phases.size(), 0);
+    tab[0] = (uint32_t)phases.size();
+    std::vector<uint32_t> lrow_of(n, NONE);  // scratch: local row of a variable inside the block being emitted
+    uint32_t lds_off = 0;
+    for (size_t p = 0; p < phases.size(); ++p) {
+        const Phase& ph = phases[p];
+        tab[1 + p] = (uint32_t)tab.size();
+        const size_t rec = tab.size();
+        tab.push_back((uint32_t)ph.blocks.size());
+        tab.resize(tab.size() + 5 * ph.blocks.size(), 0);
+        for (size_t b = 0; b < ph.blocks.size(); ++b) {
+            const Block& blk = ph.blocks[b];
+            const uint32_t K = (uint32_t)blk.cols.size(), R = K + (uint32_t)blk.below.size() + 1, st = K | 1u;
+            uint32_t* t = &tab[rec + 1 + 5 * b];
+            t[0] = K, t[1] = R, t[2] = lds_off, t[3] = st;
+            const uint32_t rv = (uint32_t)tab.size();
+            tab[rec + 1 + 5 * b + 4] = rv;  // (t is stale after the pushes below)
+            lds_off += R * st;
+            uint32_t lr = 0;
+            for (uint32_t j : blk.cols) lrow_of[j] = lr++, tab.push_back(j);
+            for (uint32_t i : blk.below) lrow_of[i] = lr++, tab.push_back(i);
+            for (uint32_t lc = 0; lc < K; ++lc) {
+                const uint32_t j = blk.cols[lc];
+                dcol[j - dc0] = (uint32_t)b | lc << 4;
+                cutcol[j - dc0] = P.lvl_cptr[ph.la];
+                for (uint32_t q = P.bwd_ptr[j]; q < P.bwd_ptr[j + 1]; ++q) {
+                    const uint32_t sl = P.bwd_items[2 * q], i = P.bwd_items[2 * q + 1];
+                    if (sl < ds0 || lrow_of[i] == NONE) return false;
+                    dslot[sl - ds0] = (uint32_t)b | lc << 4 | lrow_of[i] << 8;
+                }
+            }
+            for (uint32_t j : blk.cols) lrow_of[j] = NONE;
+            for (uint32_t i : blk.below) lrow_of[i] = NONE;
+        }
+    }
+    for (uint32_t sl = ds0; sl < zlo; ++sl)
+        if (P.l_col[sl] < dc0) return false;  // (level-major numbering: the slots of the phases' columns are the last)
+    // ---- every list of a phase keeps the terms of the columns before the phase, in their order ----------------------------------
+    {
+        std::vector<uint32_t> ptr(P.fwd_ptr.begin(), P.fwd_ptr.begin() + dc0 + 1), items(P.fwd_items.begin(), P.fwd_items.begin() + 2 * (size_t)P.fwd_ptr[dc0]);
+        for (uint32_t j = dc0; j < n; ++j) {
             for (uint32_t q = P.fwd_ptr[j]; q < P.fwd_ptr[j + 1]; ++q)
-                if (P.fwd_items[2 * q + 1] < c0) items.push_back(P.fwd_items[2 * q]), items.push_back(P.fwd_items[2 * q + 1]);
+                if (P.fwd_items[2 * q + 1] < cutcol[j - dc0]) items.push_back(P.fwd_items[2 * q]), items.push_back(P.fwd_items[2 * q + 1]);
             ptr.push_back((uint32_t)(items.size() / 2));
         }
         P.fwd_ptr.swap(ptr);
         P.fwd_items.swap(items);
     }
     {
-        std::vector<uint32_t> ptr(P.lpair_ptr.begin(), P.lpair_ptr.begin() + s0 + 1), items(P.lpairs.begin(), P.lpairs.begin() + 2 * (size_t)P.lpair_ptr[s0]);
-        for (uint32_t sl = s0; sl < zlo; ++sl) {
+        std::vector<uint32_t> ptr(P.lpair_ptr.begin(), P.lpair_ptr.begin() + ds0 + 1), items(P.lpairs.begin(), P.lpairs.begin() + 2 * (size_t)P.lpair_ptr[ds0]);
+        for (uint32_t sl = ds0; sl < zlo; ++sl) {
+            const uint32_t cutc = cutcol[P.l_col[sl] - dc0];
             for (uint32_t q = P.lpair_ptr[sl]; q < P.lpair_ptr[sl + 1]; ++q)
-                if (P.l_col[P.lpairs[2 * q]] < c0) items.push_back(P.lpairs[2 * q]), items.push_back(P.lpairs[2 * q + 1]);
+                if (P.l_col[P.lpairs[2 * q]] < cutc) items.push_back(P.lpairs[2 * q]), items.push_back(P.lpairs[2 * q + 1]);
             ptr.push_back((uint32_t)(items.size() / 2));
         }
         P.lpair_ptr.swap(ptr);
         P.lpairs.swap(items);
         P.c.n_lpairs = P.lpairs.size() / 2;
     }
-    {  // the block's backward substitution is dense: no lists
-        const uint32_t keep = P.bwd_ptr[c0];
+    {  // the phases' backward substitution is dense: no lists
+        const uint32_t keep = P.bwd_ptr[dc0];
         P.bwd_items.resize(2 * (size_t)keep);
-        for (uint32_t j = c0 + 1; j <= n; ++j) P.bwd_ptr[j] = keep;
+        for (uint32_t j = dc0 + 1; j <= n; ++j) P.bwd_ptr[j] = keep;
     }
-    P.lvl_cptr.resize(lr + 2);
-    P.lvl_sptr.resize(lr + 2);
-    P.lvl_cptr[lr + 1] = n;
-    P.lvl_sptr[lr + 1] = zlo;
-    P.parts[0].nlev = lr + 1;
-    P.c.n_levels = lr + 1;
-    P.root_k = n - c0;
-    P.root_c0 = c0;
-    P.root_s0 = s0;
-    P.root_row.swap(row);
+    {  // one level per phase
+        std::vector<uint32_t> cptr(P.lvl_cptr.begin(), P.lvl_cptr.begin() + lw + 1), sptr(P.lvl_sptr.begin(), P.lvl_sptr.begin() + lw + 1);
+        for (const Phase& ph : phases) cptr.push_back(P.lvl_cptr[ph.lb]), sptr.push_back(P.lvl_sptr[ph.lb]);
+        P.lvl_cptr.swap(cptr);
+        P.lvl_sptr.swap(sptr);
+    }
+    P.parts[0].nlev = lw + (uint32_t)phases.size();
+    P.c.n_levels = P.parts[0].nlev;
+    P.n_dense = (uint32_t)phases.size();
+    P.dense_level0 = lw;
+    P.dense_lds_doubles = lds_off;
+    P.dense_col.swap(dcol);
+    P.dense_slot.swap(dslot);
+    P.dense_tab.swap(tab);
     return true;
 }
 
@@ -1163,27 +1309,26 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         finish_team(s, stage_bytes);
     };
     pack_and_shape();
-    // ---- dense root block: one solve of one connected sketch on a barrier workgroup --------------------------------------
-    s.root_k = s.root_c0 = s.root_s0 = s.root_lds_off = s.root_stride = 0;
+    // ---- dense phases: the top of a connected sketch's elimination tree on a barrier workgroup ------------------------------
+    s.n_dense = s.dense_level0 = s.dense_lds_off = s.dense_lds_doubles = 0;
     static const bool root_enabled = [] {
         const char* e = std::getenv("EZPZ_ROOT");
         return !(e && e[0] == '0');
     }();
-    constexpr size_t kRootBytes = 17 * 17 * 8;
-    // (not on the lean 128-lane batch shape: 300 variables 1.61 -> 1.40 M solves/s with it; 256-512 lanes: 800 variables
-    // 41.7 -> 49.7 k/s, 2000: 90 -> 97 k/s)
+    // (not on the lean 128-lane batch shape: 300 variables 1.61 -> 1.40 M solves/s with the root block; 256-512 lanes: 800
+    // variables 41.7 -> 49.7 k/s, 2000: 90 -> 97 k/s)
     if (root_enabled && auto_shape && s.mode == MODE_WGB && s.grid_wgs == 1 && (for_latency || s.team_size >= 256) &&
-        s.lds_bytes + kRootBytes + 64 <= s.lim.lds_bytes && make_root_block(P)) {
+        s.lds_bytes + 4096 <= s.lim.lds_bytes &&
+        make_dense_phases(P, s.team_size / 64, std::min<size_t>(s.lim.lds_bytes - s.lds_bytes - 1024, 48 * 1024))) {
         choose_level_groups(P, s);
         s.counts = P.c;
-        pack_and_shape();  // (the lists only got shorter: the same shape again)
-        if (s.mode == MODE_WGB && s.lds_bytes + kRootBytes + 64 <= s.lim.lds_bytes) {
-            s.root_k = P.root_k;
-            s.root_c0 = P.root_c0;
-            s.root_s0 = P.root_s0;
-            s.root_stride = P.root_k | 1u;  // odd: the lanes of a column walk land on different banks
-            s.root_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);
-            s.lds_bytes = (size_t)s.root_lds_off * 8 + (size_t)(P.root_k + 1) * s.root_stride * 8;
+        pack_and_shape();  // (the lists only got shorter and the level buffer no wider: the same shape again)
+        if (s.mode == MODE_WGB && s.lds_bytes + (size_t)P.dense_lds_doubles * 8 + 64 <= s.lim.lds_bytes) {
+            s.n_dense = P.n_dense;
+            s.dense_level0 = P.dense_level0;
+            s.dense_lds_doubles = P.dense_lds_doubles;
+            s.dense_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);
+            s.lds_bytes = (size_t)s.dense_lds_off * 8 + (size_t)P.dense_lds_doubles * 8;
         } else {
             be.code = EZPZ_ERR_TOO_LARGE;  // cannot happen: the same program with shorter lists
             return fail();
@@ -1395,11 +1540,10 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.lvl_lds_off = sys->lvl_lds_off;
     a.lvl_tab_words = sys->lvl_tab_words;
     a.lvl_buf_words = sys->lvl_buf_words;
-    a.root_k = sys->root_k;
-    a.root_c0 = sys->root_c0;
-    a.root_s0 = sys->root_s0;
-    a.root_lds_off = sys->root_lds_off;
-    a.root_stride = sys->root_stride;
+    a.n_dense = sys->n_dense;
+    a.dense_level0 = sys->dense_level0;
+    a.dense_lds_off = sys->dense_lds_off;
+    a.dense_lds_doubles = sys->dense_lds_doubles;
     a.stamps = g_stamps;
     a.unit_weights = sys->unit_weights ? 1u : 0u;
     a.grid_wgs = 1;

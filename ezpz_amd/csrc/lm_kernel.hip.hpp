@@ -46,7 +46,7 @@ struct ProgramView {
     uint32_t o_lpair_ptr, o_lpairs;
     uint32_t o_fwd_ptr, o_fwd_items;
     uint32_t o_bwd_ptr, o_bwd_items;
-    uint32_t o_root_row;                    // rows of the dense root block's slots (Program::root_row)
+    uint32_t o_dense_col, o_dense_slot, o_dense_tab;  // dense phases (Program::dense_col ...)
     uint32_t o_pos, o_weights, o_patterns;  // side arrays of a packed constraint table
     uint32_t packed;                        // constraint table holds 32-byte PackedCon records
     // Per-level stream of the Cholesky lists (32-bit programs of one partition; see pack_program): level lv is words
@@ -75,7 +75,7 @@ struct Prog {
     const IDX *lpair_ptr, *lpairs;
     const IDX *fwd_ptr, *fwd_items;
     const IDX *bwd_ptr, *bwd_items;
-    const IDX* root_row;
+    const IDX *dense_col, *dense_slot, *dense_tab;
     const uint32_t *lvl_off, *lvl_stream;  // per-level blocks of the Cholesky lists (32-bit programs of one partition)
     const uint32_t *lvl_boff, *lvl_bstream;  // ... and of the backward substitution's
 };
@@ -107,7 +107,9 @@ __device__ __forceinline__ Prog<IDX> make_prog(const ProgramView& v, const unsig
     p.fwd_items = u(v.o_fwd_items);
     p.bwd_ptr = u(v.o_bwd_ptr);
     p.bwd_items = u(v.o_bwd_items);
-    p.root_row = u(v.o_root_row);
+    p.dense_col = u(v.o_dense_col);
+    p.dense_slot = u(v.o_dense_slot);
+    p.dense_tab = u(v.o_dense_tab);
     p.lvl_off = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_off);
     p.lvl_stream = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_stream);
     p.lvl_boff = reinterpret_cast<const uint32_t*>(lists + v.o_lvl_boff);
@@ -225,9 +227,9 @@ struct SolveArgs {
     // level staging (see the Cholesky loop): LDS offset (doubles) of the level tables, words reserved for the tables,
     // words of one level buffer (0 = off)
     uint32_t lvl_lds_off, lvl_tab_words, lvl_buf_words;
-    // dense root block (Program::root_k; barrier workgroups with program and workspace in LDS): columns, first column,
-    // first slot, LDS offset (doubles) and row stride (doubles) of the (root_k + 1) x root_k array; root_k == 0: none
-    uint32_t root_k, root_c0, root_s0, root_lds_off, root_stride;
+    // dense phases (Program::n_dense; barrier workgroups): how many, the first of their levels, LDS offset (doubles) of the
+    // blocks' panels and the doubles they take together; n_dense == 0: none
+    uint32_t n_dense, dense_level0, dense_lds_off, dense_lds_doubles;
 };
 
 #ifdef EZPZ_STAMPS
@@ -983,15 +985,20 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                         ws[o_l + s] = ws[o_l + s] / ws[o_d + lcol[s]];
                     tm.phase_sync();
                 };
-                // ---- dense root block (Program::root_k, api.hip: make_root_block) ------------------------------------------
-                // The last level of such a program is the elimination tree's top separators as ONE block of K
-                // columns (K <= 16).  (1) All lanes, g per list: the block's Schur complement -- every structural entry (i, j),
-                // the diagonal and b minus its terms from the columns before the block -- into a dense (K + 1) x K array
-                // in LDS (row K is b; structurally zero entries stay zero through the factorisation: no fill is
-                // created that the symbolic phase had not found).  (2) One wavefront, lane = row, no barriers:
-                // left-looking dense Cholesky with the forward substitution as row K (pivots travel by v_readlane),
-                // then the backward substitution.  The top ten levels (~4 k cycles each) become ~1 k cycles per column.
-                // The sums run in a different order than the list walk's (as between any two elimination orders).
+                // ---- dense phases (Program::n_dense, api.hip: make_dense_phases) ------------------------------------------
+                // The last levels of such a program are PHASES: runs of whole levels of the elimination tree's top, whose
+                // columns fall into independent blocks of K <= 16 columns (the last phase is the root block).  A block is a
+                // dense panel of R rows in LDS: its K columns, the later columns that have entries in them, and b.
+                // (1) All lanes, g per list: every structural entry of the phase minus its terms from the columns before
+                // the phase (the Schur complement; structurally zero entries stay zero through the factorisation: no fill
+                // is created that the symbolic phase had not found).  (2) One wavefront per block, lane = row, no barriers:
+                // right-looking dense Cholesky in registers with the forward substitution as row R - 1, pivots and
+                // multipliers by v_readlane -- each entry still receives its terms in ascending column order.  (3) All
+                // lanes: the factor's entries and y back to the workspace for the phases above.  The backward
+                // substitution runs the phases in reverse, one wavefront per block: the rows below the block first (their
+                // d is final), then the block's triangle.  ~1 k cycles per column of the longest block instead of
+                // ~4 k per level.  The sums run in a different order than the list walk's (as between any two elimination
+                // orders).
                 constexpr bool ROOT_OK = MODE == MODE_WGB && !GRID && !DENSE;
                 auto readlane_f64 = [](double v, uint32_t l) {
                     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -999,21 +1006,35 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), (int)l);
                     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
                 };
-                auto root_block = [&](uint32_t lv) __attribute__((always_inline)) {
-                    const uint32_t K = a.root_k, ST = a.root_stride, cR = a.root_c0, sR = a.root_s0;
-                    double* D = smem + a.root_lds_off;
+                const uint32_t dense_c0 = ROOT_OK && a.n_dense ? uni(lvl_cptr[a.dense_level0]) : 0u;
+                const uint32_t dense_s0 = ROOT_OK && a.n_dense ? uni(lvl_sptr[a.dense_level0]) : 0u;
+                auto dense_phase = [&](uint32_t lv) __attribute__((always_inline)) {
+                    const idx_t* rec = P.dense_tab + uni(P.dense_tab[1 + (lv - a.dense_level0)]);
+                    const uint32_t nb = uni(rec[0]);
+                    double* DB = smem + a.dense_lds_off;
+                    const uint32_t c0 = uni(lvl_cptr[lv]), s0 = uni(lvl_sptr[lv]);
+                    const uint32_t ncol = uni(lvl_cptr[lv + 1]) - c0, nitem = ncol + (uni(lvl_sptr[lv + 1]) - s0);
                     const uint32_t g = uni(lvl_grp[lv]) & 0xFFu;
                     const uint32_t lg = (uint32_t)__builtin_ctz(g);
                     const uint32_t sub = (uint32_t)tm.lane & (g - 1), grp = (uint32_t)tm.lane >> lg;
                     const uint32_t ngrp = (uint32_t)tm.stride >> lg;
-                    const uint32_t nitem = K + (uni(lvl_sptr[lv + 1]) - sR);
+                    const bool last = lv + 1 == nlev;
+                    // where an item's entry lives: (block, column, row) -> panel address; a column item also owns b's row
+                    auto place = [&](bool iscol, uint32_t t, uint32_t& e_main, uint32_t& e_b) {
+                        const uint32_t code = iscol ? P.dense_col[c0 + t - dense_c0] : P.dense_slot[s0 + (t - ncol) - dense_s0];
+                        const idx_t* bk = rec + 1 + 5 * (code & 15u);
+                        const uint32_t lc = (code >> 4) & 15u, lr = iscol ? lc : (code >> 8);
+                        const uint32_t off = bk[2], st = bk[3];
+                        e_main = off + lr * st + lc;
+                        e_b = off + (bk[1] - 1u) * st + lc;
+                    };
                     for (uint32_t t = grp; t < nitem; t += ngrp) {
-                        const bool iscol = t < K;
-                        const uint32_t sl_ = sR + (t - K);
+                        const bool iscol = t < ncol;
+                        const uint32_t sl_ = s0 + (t - ncol);
                         uint32_t q0, q1;
                         if (iscol) {
-                            q0 = P.fwd_ptr[cR + t];
-                            q1 = P.fwd_ptr[cR + t + 1];
+                            q0 = P.fwd_ptr[c0 + t];
+                            q1 = P.fwd_ptr[c0 + t + 1];
                         } else {
                             q0 = P.lpair_ptr[sl_];
                             q1 = P.lpair_ptr[sl_ + 1];
@@ -1026,50 +1047,68 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                                                (sp += va[k] * vb[k], sd += va[k] * va[k]))
                         if (g > 1) group_sum2(sp, sd, g);
                         if (sub == 0) {
+                            uint32_t e_main, e_b;
+                            place(iscol, t, e_main, e_b);
                             if (iscol) {
-                                D[t * ST + t] = ws[o_d + cR + t] - sd;
-                                D[K * ST + t] = ws[o_v + cR + t] - sp;
+                                DB[e_main] = ws[o_d + c0 + t] - sd;
+                                DB[e_b] = ws[o_v + c0 + t] - sp;
                             } else {
-                                D[(P.root_row[sl_ - sR] - cR) * ST + (P.l_col[sl_] - cR)] = ws[o_l + sl_] - sp;
+                                DB[e_main] = ws[o_l + sl_] - sp;
                             }
                         }
                     }
                     tm.phase_sync();
-                    if (tid < 64) {
-                        const uint32_t r = (uint32_t)tid, rr = r <= K ? r : K;
-                        // lane r holds row r of the block in registers (K <= 16; row K is b); right-looking: once column
-                        // j is done every later column k of every row takes its term l_rj * l_kj, l_kj by v_readlane --
-                        // each entry still receives its terms in ascending column order
-                        auto factor = [&](auto km_tag) __attribute__((always_inline)) {
-                            constexpr int KM = decltype(km_tag)::value;
-                            double rg[KM];
+                    for (uint32_t blk = uni((uint32_t)tid >> 6); blk < nb; blk += (uint32_t)tm.stride >> 6) {
+                        const idx_t* bk = rec + 1 + 5 * blk;
+                        const uint32_t K = uni(bk[0]), R = uni(bk[1]), ST = uni(bk[3]);
+                        double* D = DB + uni(bk[2]);
+                        const uint32_t r = (uint32_t)tid & 63u, rr = r < R ? r : R - 1;
+                        double rg[16];
 #pragma unroll
-                            for (int c = 0; c < KM; ++c) rg[c] = (uint32_t)c < K ? D[rr * ST + c] : 0.0;
+                        for (int c = 0; c < 16; ++c) rg[c] = (uint32_t)c < K ? D[rr * ST + c] : 0.0;
 #pragma unroll
-                            for (int j = 0; j < KM; ++j) {
-                                if ((uint32_t)j < K) {
-                                    const double piv = readlane_f64(rg[j], j);
-                                    if (!(piv > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
-                                    const double dj = sqrt(piv);
-                                    const double l = rg[j] / dj;
-                                    if (r == (uint32_t)j)
-                                        D[j * ST + j] = dj;
-                                    else if (r > (uint32_t)j && r <= K)
-                                        D[r * ST + j] = l;
+                        for (int j = 0; j < 16; ++j) {
+                            if ((uint32_t)j < K) {
+                                const double piv = readlane_f64(rg[j], j);
+                                if (!(piv > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                                const double dj = sqrt(piv);
+                                const double l = rg[j] / dj;
+                                if (r == (uint32_t)j)
+                                    D[j * ST + j] = dj;
+                                else if (r > (uint32_t)j && r < R)
+                                    D[r * ST + j] = l;
+                                // (a second, 32-column body beside this one costs the whole kernel its register
+                                // allocation: one 300-variable solve 296 -> 368 us even when only this one runs)
 #pragma unroll
-                                    for (int k = j + 1; k < KM; ++k) rg[k] -= l * readlane_f64(l, k);
-                                }
+                                for (int k = j + 1; k < 16; ++k) rg[k] -= l * readlane_f64(l, k);
                             }
-                        };
-                        // (a 32-column variant beside this one costs the whole kernel its register allocation: one
-                        // 300-variable solve 296 -> 368 us even when only the 16-column code runs)
-                        factor(std::integral_constant<int, 16>());
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        // backward substitution: lane r carries y_r minus the terms of the rows already solved
-                        const uint32_t rc = r < K ? r : K - 1;
-                        double rem = D[K * ST + rc], xr = 0.0;
+                        }
+                    }
+                    tm.phase_sync();
+                    if (!last) {  // the phases above read the factor's entries and y from the workspace
+                        for (uint32_t t = (uint32_t)tm.lane; t < nitem; t += (uint32_t)tm.stride) {
+                            const bool iscol = t < ncol;
+                            uint32_t e_main, e_b;
+                            place(iscol, t, e_main, e_b);
+                            if (iscol)
+                                ws[o_v + c0 + t] = DB[e_b];
+                            else
+                                ws[o_l + s0 + (t - ncol)] = DB[e_main];
+                        }
+                        tm.phase_sync();
+                    }
+                };
+                auto dense_bwd = [&](uint32_t lv) __attribute__((always_inline)) {
+                    const idx_t* rec = P.dense_tab + uni(P.dense_tab[1 + (lv - a.dense_level0)]);
+                    const uint32_t nb = uni(rec[0]);
+                    for (uint32_t blk = uni((uint32_t)tid >> 6); blk < nb; blk += (uint32_t)tm.stride >> 6) {
+                        const idx_t* bk = rec + 1 + 5 * blk;
+                        const uint32_t K = uni(bk[0]), R = uni(bk[1]), ST = uni(bk[3]);
+                        const double* D = smem + a.dense_lds_off + uni(bk[2]);
+                        const idx_t* rowvar = P.dense_tab + uni(bk[4]);
+                        const uint32_t r = (uint32_t)tid & 63u, rc = r < K ? r : K - 1;
+                        double rem = D[(R - 1) * ST + rc], xr = 0.0;  // y_r minus the terms of the rows already solved
+                        for (uint32_t q = K; q + 1 < R; ++q) rem -= D[q * ST + rc] * ws[o_v + uni(rowvar[q])];
                         const double dr = D[rc * ST + rc];
                         for (uint32_t j = K; j-- > 0;) {
                             const double xj = readlane_f64(rem / dr, j);
@@ -1077,22 +1116,22 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                             if (r == j) xr = xj;
                         }
                         if (r < K) {
-                            ws[o_v + cR + r] = xr;
+                            ws[o_v + rowvar[r]] = xr;
                             dmax = fmax(dmax, fabs(xr));
                         }
                     }
                     tm.phase_sync();
                 };
                 if constexpr (ROOT_OK) {
-                    if (a.root_k) {  // (the levels' rendezvous order this before the block's entries are written)
-                        double* D = smem + a.root_lds_off;
-                        for (uint32_t i = (uint32_t)tid; i < (a.root_k + 1) * a.root_stride; i += blockDim.x) D[i] = 0.0;
+                    if (a.n_dense) {  // (the levels' rendezvous order this before the panels' entries are written)
+                        double* DB = smem + a.dense_lds_off;
+                        for (uint32_t i = (uint32_t)tid; i < a.dense_lds_doubles; i += blockDim.x) DB[i] = 0.0;
                     }
                 }
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
                     if constexpr (ROOT_OK) {
-                        if (a.root_k && lv + 1 == nlev) {
-                            root_block(lv);
+                        if (a.n_dense && lv >= a.dense_level0) {
+                            dense_phase(lv);
                             EZPZ_STAMP(1000 + lv);
                             continue;
                         }
@@ -1168,7 +1207,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 };
                 for (uint32_t lv = nlev; lv-- > 0;) {
                     if constexpr (ROOT_OK) {
-                        if (a.root_k && lv + 1 == nlev) continue;  // solved densely with the block
+                        if (a.n_dense && lv >= a.dense_level0) {
+                            dense_bwd(lv);
+                            continue;
+                        }
                     }
                     if constexpr (LVL_STAGE) {
                         if (lvl_buf) {

@@ -51,12 +51,18 @@ struct Program {
     // per (partition, level): lanes that share one list of the level's Cholesky walks (a power of two; 1 = one lane
     // per list).  Filled by the launch-shape code (api.hip: choose_level_groups); empty means 1 everywhere.
     std::vector<uint32_t> lvl_grp;
-    // Dense root block (api.hip: make_root_block; one-partition programs of the latency shape only): the last root_k
-    // columns [root_c0, n_vars) -- the top separators of the elimination tree -- are one final "level" whose lists are cut
-    // to the columns before root_c0 (the Schur complement's terms); the block itself is factorised densely by one
-    // wavefront.  root_row[s - root_s0] = row (internal variable) of strictly-lower slot s >= root_s0.  root_k == 0: none.
-    uint32_t root_k = 0, root_c0 = 0, root_s0 = 0;
-    std::vector<uint32_t> root_row;
+    // Dense phases (api.hip: make_dense_phases; one-partition programs of one connected component on a barrier
+    // workgroup): the top of the elimination tree -- its last n_dense "levels", [dense_level0, nlev) -- is not walked
+    // column by column.  Each of these levels is a PHASE: a few whole levels of the original schedule merged, whose columns
+    // fall into <= 8 independent blocks (the connected pieces of the elimination tree inside the phase, <= 16 columns
+    // each; the last phase is the root block).  A block is a dense panel: rows = its columns, then the later columns
+    // that have entries in them, then b; the lists of its entries keep only the terms of columns before the phase.
+    //   dense_col[j - lvl_cptr[dense_level0]]  = block | local column << 4                      (columns of all phases)
+    //   dense_slot[s - lvl_sptr[dense_level0]] = block | local column << 4 | local row << 8     (their strictly-lower slots)
+    //   dense_tab = [n_dense] [offset of phase p's record]... ; record = [blocks] then per block [columns K, rows R (incl.
+    //   b), LDS offset (doubles, from the first block's), row stride, offset in dense_tab of the R - 1 row variables] ...
+    uint32_t n_dense = 0, dense_level0 = 0, dense_lds_doubles = 0;
+    std::vector<uint32_t> dense_col, dense_slot, dense_tab;
 };
 
 struct BuildError {

@@ -92,8 +92,8 @@ def test_symbolic_sizes_massive_and_square():
 
 
 def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
-    """Host side of the dense root block (api.hip: make_root_block): on a 512-lane workgroup the last <= 16 columns of
-    a connected sketch's elimination order -- ten or so levels of one or two columns -- are one level of the schedule;
+    """Host side of the dense phases (api.hip: make_dense_phases): on a 512-lane workgroup the top of a connected
+    sketch's elimination tree -- runs of levels of one or two columns per branch -- is a few phases of the schedule;
     EZPZ_ROOT=0 keeps the plain schedule (read once per process, hence the child processes).  Block systems keep theirs."""
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import gen, ezpz_amd as E; "

@@ -668,10 +668,11 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
 @pytest.mark.parametrize("npts", [60, 150, 260, 400, 1200])
 def test_connected_sketch_latency_shape_with_dense_root_block(E, npts):
     """The launch shape of one solve (`TEAM_AUTO_LATENCY`, what `ezpz_solve` asks for) ends the elimination of a connected
-    sketch with a dense block: the last <= 16 columns -- the top separators, ten or so levels of one or two columns -- are
-    one final level whose Schur complement is gathered by all lanes and factorised in one wavefront's registers
-    (api.hip: make_root_block; lm_kernel.hip.hpp: root block), with the program staged in LDS (120-520 variables), read
-    from global memory (800) and with the workspace in global memory too (2400).  Against the oracle (iteration counts,
+    sketch with dense phases: runs of levels at the top of the elimination tree whose columns fall into independent
+    blocks of <= 16 (the last one the root block: the last <= 16 columns), each block's Schur complement gathered by
+    all lanes and factorised in one wavefront's registers (api.hip: make_dense_phases; lm_kernel.hip.hpp: dense
+    phases), with the program staged in LDS (120-520 variables), read from global memory (800) and with the workspace
+    in global memory too (2400).  Against the oracle (iteration counts,
     flags, masks, coordinates at 1e-6), against the plain level walk (an explicit team size keeps it), from run to
     run, from a NaN start (every pivot fails: lambda grows, the iterations burn) and on an inconsistent system."""
     recs, g = gen.connected_sketch(npts, 500 + npts)
