@@ -1108,12 +1108,22 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                         const idx_t* rowvar = P.dense_tab + uni(bk[4]);
                         const uint32_t r = (uint32_t)tid & 63u, rc = r < K ? r : K - 1;
                         double rem = D[(R - 1) * ST + rc], xr = 0.0;  // y_r minus the terms of the rows already solved
-                        for (uint32_t q = K; q + 1 < R; ++q) rem -= D[q * ST + rc] * ws[o_v + uni(rowvar[q])];
+                        // lane q holds d of the q-th row below the block (final: its phase ran before this one)
+                        const double xb = ws[o_v + rowvar[K + r < R - 1 ? K + r : K > 0 ? K - 1 : 0]];
+                        for (uint32_t q = K; q + 1 < R; ++q) rem -= D[q * ST + rc] * readlane_f64(xb, q - K);
                         const double dr = D[rc * ST + rc];
-                        for (uint32_t j = K; j-- > 0;) {
-                            const double xj = readlane_f64(rem / dr, j);
-                            if (r < j) rem -= D[j * ST + rc] * xj;
-                            if (r == j) xr = xj;
+                        double lrow[16];  // column r of the triangle: what row j subtracts from y_r
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) lrow[j] = (uint32_t)j < K ? D[j * ST + rc] : 0.0;
+#pragma unroll
+                        for (int j = 15; j >= 0; --j) {
+                            if ((uint32_t)j < K) {
+                                // (rem * (1 / d_r) instead of the division was measured: 233.6 -> 228.1 us per 300-variable
+                                // solve, not worth leaving the correctly rounded quotient)
+                                const double xj = readlane_f64(rem / dr, j);
+                                if (r < (uint32_t)j) rem -= lrow[j] * xj;
+                                if (r == (uint32_t)j) xr = xj;
+                            }
                         }
                         if (r < K) {
                             ws[o_v + rowvar[r]] = xr;
