@@ -171,6 +171,9 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                 const CompRec8 nxt = comp_load8(prog + a.ops_off + (io + 1) * kCompRecWords);
                 const uint32_t op = rec.w[0] & 0xFFu, ni = (rec.w[0] >> 8) & 0xFFu;
                 const bool first = (rec.w[0] & kCompFirst) != 0, last = (rec.w[0] & kCompLast) != 0;
+                // (the stream is fused: an entry of JtJ + lambda I is assembled right before its column / slot is eliminated
+                // and stays in the accumulators -- no store and reload of the entry's row)
+                const bool keep = (rec.w[0] & kCompKeep) != 0, cont = (rec.w[0] & kCompCont) != 0;
                 const uint32_t oa = rec.w[1] & 0xFFFFu, ob = rec.w[1] >> 16;
                 double va[kCompItemsGen], vb[kCompItemsGen];
                 switch (op) {
@@ -184,8 +187,11 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                             y += va[k] * -vb[k];
                         }
                     if (last) {
-                        S[oa] = acc + lambda;  // newton.rs:77-84
-                        V[oa] = y;
+                        acc = acc + lambda;  // newton.rs:77-84
+                        if (!keep) {
+                            S[oa] = acc;
+                            V[oa] = y;
+                        }
                     }
                     break;
                 case COMP_OFF:
@@ -194,10 +200,10 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
 #pragma unroll
                     for (uint32_t k = 0; k < kCompItemsGen; ++k)
                         if (k < ni) acc += va[k] * vb[k];
-                    if (last) L[oa] = acc;
+                    if (last && !keep) L[oa] = acc;
                     break;
                 case COMP_COL:
-                    if (first) {
+                    if (first && !cont) {
                         acc = S[oa];
                         y = V[oa];
                     }
@@ -216,7 +222,7 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                     }
                     break;
                 case COMP_SLOT:
-                    if (first) acc = L[oa];
+                    if (first && !cont) acc = L[oa];
                     LOAD_ITEMS(L, L)
 #pragma unroll
                     for (uint32_t k = 0; k < kCompItemsGen; ++k)

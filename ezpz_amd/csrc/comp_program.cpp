@@ -93,7 +93,8 @@ void align4(std::vector<uint32_t>& w) {
 // One operation = one or more 8-word records.  `items` holds `words_per_item` words per item; `head` (0 or 2 words) goes
 // into w2:w3 of the first record (the linear build's constants), shrinking that build's item room to w4..w7.
 void emit_op(std::vector<uint32_t>& out, uint32_t opcode, uint32_t a, uint32_t b, const std::vector<uint32_t>& items,
-             uint32_t words_per_item, uint32_t items_per_rec, uint32_t item_word0, const uint32_t* head) {
+             uint32_t words_per_item, uint32_t items_per_rec, uint32_t item_word0, const uint32_t* head,
+             uint32_t first_flags = 0, uint32_t last_flags = 0) {
     const size_t n = items.size() / words_per_item;
     size_t done = 0;
     bool first = true;
@@ -101,7 +102,7 @@ void emit_op(std::vector<uint32_t>& out, uint32_t opcode, uint32_t a, uint32_t b
         const size_t take = std::min<size_t>(items_per_rec, n - done);
         const bool last = done + take == n;
         uint32_t rec[kCompRecWords] = {0, 0, 0, 0, 0, 0, 0, 0};
-        rec[0] = opcode | ((uint32_t)take << 8) | (first ? kCompFirst : 0u) | (last ? kCompLast : 0u);
+        rec[0] = opcode | ((uint32_t)take << 8) | (first ? kCompFirst | first_flags : 0u) | (last ? kCompLast | last_flags : 0u);
         rec[1] = a | (b << 16);
         if (head) rec[2] = head[0], rec[3] = head[1];
         for (size_t k = 0; k < take * words_per_item; ++k) rec[item_word0 + k] = items[done * words_per_item + k];
@@ -114,13 +115,29 @@ void emit_op(std::vector<uint32_t>& out, uint32_t opcode, uint32_t a, uint32_t b
 // The class program in the blob: the operation stream of the linear solve in execution order (+ one read-ahead pad
 // record) and the constraint records (+ pad).  `params`: requests whose parameters go into the records as literals
 // (w13:w14; a class that is a whole system shared by every lane) -- null: parameters come from per-instance tables.
-void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const EzpzConstraint* params, bool request_order = false) {
+// `fuse` (general records only): the assembly of an entry of JtJ sits right before the elimination of its column / slot
+// and hands its value over in the accumulator (kCompKeep / kCompCont) instead of through the entry's row of state.
+void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const EzpzConstraint* params, bool request_order = false,
+                        bool fuse = false) {
     const Program& Q = cl.Q;
     ClassLayout& H = cl.H;
     const uint32_t nv = Q.c.n_vars, zlo = Q.c.zlo, ncons = Q.c.n_cons;
     // ---- operation stream of the linear solve, in execution order ----
     std::vector<uint32_t> ops, items;
-    for (uint32_t v = 0; v < nv; ++v) {
+    fuse = fuse && !LIN;
+    auto emit_diag = [&](uint32_t v) {
+        items.clear();
+        for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q)
+            items.push_back(Q.colj_items[2 * q] | (Q.colj_items[2 * q + 1] << 16));
+        emit_op(ops, COMP_DIAG, v, 0, items, 1, kCompItemsGen, 2, nullptr, 0, fuse ? kCompKeep : 0);
+    };
+    auto emit_off = [&](uint32_t s) {
+        items.clear();
+        for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
+            items.push_back(Q.apairs[2 * q] | (Q.apairs[2 * q + 1] << 16));
+        emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 2, nullptr, 0, fuse ? kCompKeep : 0);
+    };
+    for (uint32_t v = 0; v < nv && !fuse; ++v) {
         items.clear();
         if (LIN) {
             double acc = 0.0;
@@ -134,12 +151,10 @@ void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const 
             push_double(head, acc);
             emit_op(ops, COMP_DIAG, v, 0, items, 2, kCompItemsLin, 4, head.data());
         } else {
-            for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q)
-                items.push_back(Q.colj_items[2 * q] | (Q.colj_items[2 * q + 1] << 16));
-            emit_op(ops, COMP_DIAG, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+            emit_diag(v);
         }
     }
-    for (uint32_t s = 0; s < zlo; ++s) {
+    for (uint32_t s = 0; s < zlo && !fuse; ++s) {
         items.clear();
         if (LIN) {
             double acc = 0.0;
@@ -149,9 +164,7 @@ void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const 
             push_double(head, acc);
             emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 4, head.data());
         } else {
-            for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
-                items.push_back(Q.apairs[2 * q] | (Q.apairs[2 * q + 1] << 16));
-            emit_op(ops, COMP_OFF, s, 0, items, 1, kCompItemsGen, 2, nullptr);
+            emit_off(s);
         }
     }
     const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
@@ -159,16 +172,18 @@ void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const 
         const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
         const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
         for (uint32_t v = c0; v < c1; ++v) {
+            if (fuse) emit_diag(v);
             items.clear();
             for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
                 items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
-            emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr);
+            emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr, fuse ? kCompCont : 0, 0);
         }
         for (uint32_t s = s0; s < s1; ++s) {
+            if (fuse) emit_off(s);
             items.clear();
             for (uint32_t q = Q.lpair_ptr[s]; q < Q.lpair_ptr[s + 1]; ++q)
                 items.push_back(Q.lpairs[2 * q] | (Q.lpairs[2 * q + 1] << 16));
-            emit_op(ops, COMP_SLOT, s, Q.l_col[s], items, 1, kCompItemsGen, 2, nullptr);
+            emit_op(ops, COMP_SLOT, s, Q.l_col[s], items, 1, kCompItemsGen, 2, nullptr, fuse ? kCompCont : 0, 0);
         }
     }
     for (uint32_t lv = part.nlev; lv-- > 0;) {
@@ -778,7 +793,7 @@ bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Batc
     for (const DevCon& d : Q.cons)
         if (d.weight != 1.0) plan.unit_weights = false;
     cl.linear = false;  // the general records: Jacobian values are stored (no constant folding here)
-    emit_class_program(plan.blob, cl, false, cs, true);
+    emit_class_program(plan.blob, cl, false, cs, true, true);
     align4(plan.blob);
     plan.var_off = (uint32_t)plan.blob.size();
     plan.blob.insert(plan.blob.end(), Q.var_of.begin(), Q.var_of.end());

@@ -40,6 +40,10 @@ enum CompOpcode : uint32_t { COMP_DIAG = 1, COMP_OFF = 2, COMP_COL = 3, COMP_SLO
 constexpr uint32_t kCompRecWords = 8;
 constexpr uint32_t kCompItemsGen = 6, kCompItemsLin = 2;
 constexpr uint32_t kCompFirst = 1u << 16, kCompLast = 2u << 16;
+// fused streams (one lane per system, batch_kernel.hip.hpp): the entry of JtJ is assembled right before its column /
+// slot is eliminated and stays in the accumulator -- kCompKeep on the last record of a DIAG / OFF: do not store;
+// kCompCont on the first record of the COL / SLOT that follows: do not load
+constexpr uint32_t kCompKeep = 4u << 16, kCompCont = 8u << 16;
 
 // Constraint record of a class: 16 words.
 //   w0 kind | tag << 8 | nrows << 16 | nslots << 24      w1 row0 | jbase << 16
