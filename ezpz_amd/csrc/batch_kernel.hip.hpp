@@ -44,8 +44,11 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const comp_cptr prog = (comp_cptr)(uintptr_t)a.prog;
-    const RowRef P{a.ws + wave_global * (uint64_t)a.rows * 64 + lane};
-    const RowRef V = P + a.o_d, R = P + a.o_r, RN = P + a.o_rn, J = P + a.o_j, S = P + a.o_dg, L = P + a.o_l;
+    const RowRef W{a.ws + wave_global * (uint64_t)a.rows * 64 + lane};
+    const RowRef V = W + a.o_d, J = W + a.o_j, L = W + a.o_l;
+    // x and the diagonal / tentative x, r and r_next: two row sets each whose roles a lane swaps when it accepts a step
+    // (a pointer per lane instead of copying n + m rows through memory)
+    RowRef P = W, S = W + a.o_dg, R = W + a.o_r, RN = W + a.o_rn;
 
     uint64_t next = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool have = false, fresh = false, r_is_at_x = true;
@@ -158,7 +161,8 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
             if (active) fresh = false;
             // -- normal equations, Cholesky, substitutions (newton.rs:73-102): the operation stream, every lane on its own system.
             //    The operands of a record's items are all requested before the first is used: one trip to L2 / HBM per
-            //    record instead of one per item; the terms are still folded in list order.  (Requesting the operands of
+            //    record instead of one per item; the terms are still folded in list order.  The stream runs column by column
+            //    (a column, then the slots below it while d_j is still in a register).  (Requesting the operands of
             //    record i + 1 before record i is computed -- a software pipeline, with the host flagging the one hazard of
             //    the fused order -- was measured and not kept: 7.0 -> 6.7 M solves/s at 262 144 systems of 300 variables,
             //    +2 % at 16 384; the number of loads in flight is not known statically (records hold 0-6 items), so the
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
         va[k] = vb[k] = 0.0;                                                          \
         if (k < ni) va[k] = A[rec.w[2 + k] & 0xFFFFu], vb[k] = B[rec.w[2 + k] >> 16]; \
     }
-            double acc = 0.0, y = 0.0, dmax = __builtin_nan("");
+            double acc = 0.0, y = 0.0, dmax = __builtin_nan(""), dcur = 0.0;  // dcur: d_j of the column whose slots follow
             bool bad = false;
             CompRec8 rec = comp_load8(prog + a.ops_off);
             for (uint32_t io = 0; io < a.n_ops; ++io) {
@@ -221,6 +225,7 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                     if (last) {
                         if (!(acc > 0.0)) bad = true;  // LltError::Numeric: non-positive pivot (newton.rs:93-99)
                         const double dv = sqrt(acc);
+                        dcur = dv;
                         S[oa] = dv;
                         V[oa] = y / dv;
                     }
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
 #pragma unroll
                     for (uint32_t k = 0; k < kCompItemsGen; ++k)
                         if (k < ni) acc -= va[k] * vb[k];
-                    if (last) L[oa] = acc / S[ob];
+                    if (last) L[oa] = acc / ((rec.w[0] & kCompDivReg) ? dcur : S[ob]);
                     break;
                 case COMP_BWD:
                     if (first) acc = V[oa];
@@ -263,13 +268,16 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
             const bool accept = stepping && sq < residual_sq;  // strict, newton.rs:118
             if (stepping) {
                 ++pass;
-                // accept: x = x + d; reject: x += d, x -= d like the reference (newton.rs:111-114,:124-131), not a copy
-                for (uint32_t k = 0; k < a.nv; ++k) {
-                    const double xt = S[k];
-                    P[k] = accept ? xt : xt - V[k];
+                // accept: x = x + d -- the tentative values' rows become x, r_next's rows become r; reject: x += d, x -= d like
+                // the reference (newton.rs:111-114,:124-131), not a copy
+                if (__any(stepping && !accept)) {
+                    for (uint32_t k = 0; k < a.nv; ++k)
+                        if (!accept) P[k] = S[k] - V[k];
                 }
                 if (accept) {
-                    for (uint32_t k = 0; k < a.m; ++k) R[k] = RN[k];
+                    const RowRef tx = P, tr = R;
+                    P = S, S = tx;
+                    R = RN, RN = tr;
                     lambda *= LM_LAMBDA_DECR;
                     residual_sq = sq;
                     largest = mx;

@@ -168,7 +168,26 @@ void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const 
         }
     }
     const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
-    for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+    if (fuse) {
+        // column by column in elimination order (the numbering is level-major, so every entry a column reads is done): its
+        // diagonal, then the slots below it while d_j is still in a register
+        for (uint32_t v = 0; v < nv; ++v) {
+            emit_diag(v);
+            items.clear();
+            for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
+                items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
+            emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr, kCompCont, 0);
+            for (uint32_t qs = Q.bwd_ptr[v]; qs < Q.bwd_ptr[v + 1]; ++qs) {
+                const uint32_t s = Q.bwd_items[2 * qs];
+                emit_off(s);
+                items.clear();
+                for (uint32_t q = Q.lpair_ptr[s]; q < Q.lpair_ptr[s + 1]; ++q)
+                    items.push_back(Q.lpairs[2 * q] | (Q.lpairs[2 * q + 1] << 16));
+                emit_op(ops, COMP_SLOT, s, Q.l_col[s], items, 1, kCompItemsGen, 2, nullptr, kCompCont, kCompDivReg);
+            }
+        }
+    }
+    for (uint32_t lv = 0; lv < part.nlev && !fuse; ++lv) {
         const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
         const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
         for (uint32_t v = c0; v < c1; ++v) {

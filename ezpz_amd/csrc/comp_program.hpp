@@ -44,6 +44,9 @@ constexpr uint32_t kCompFirst = 1u << 16, kCompLast = 2u << 16;
 // slot is eliminated and stays in the accumulator -- kCompKeep on the last record of a DIAG / OFF: do not store;
 // kCompCont on the first record of the COL / SLOT that follows: do not load
 constexpr uint32_t kCompKeep = 4u << 16, kCompCont = 8u << 16;
+// fused streams run column by column (a column, then its slots): kCompDivReg on a SLOT = its divisor d_j is the one the
+// COL before it just computed, still in a register
+constexpr uint32_t kCompDivReg = 16u << 16;
 
 // Constraint record of a class: 16 words.
 //   w0 kind | tag << 8 | nrows << 16 | nslots << 24      w1 row0 | jbase << 16
