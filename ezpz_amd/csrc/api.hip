@@ -1396,11 +1396,11 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         if (lane_plan_build(cs, n_cs, n_vars, *lp)) s.lane = std::move(lp);
     }
     // ---- lanes across the batch: one connected sketch too large for a lane's registers.  A lane walks its system alone, every
-    //      operand a trip to L2 / HBM, so the shape pays once the batch gives three of a CU's four SIMDs a wavefront
-    //      (64 x 3 x CUs systems: 49 152 on the MI355X; measured at 16 384 / 32 768 / 49 152 / 262 144 systems of 300
-    //      variables: 0.81 / 1.37 / 1.93 / 5.4 M solves/s against the teams' 1.59 M); smaller batches keep the teams.
+    //      operand a trip to L2 / HBM, so the shape pays once the batch gives half of a CU's SIMDs a wavefront (64 x 2 x CUs
+    //      systems: 32 768 on the MI355X; measured at 16 384 / 24 576 / 32 768 / 65 536 / 262 144 systems of 300 variables:
+    //      1.06 / 1.53 / 2.00 / 3.70 / 9.4 M solves/s against the teams' 1.50 M); smaller batches keep the teams.
     s.lanes.reset();
-    s.lanes_min = batch_lanes ? 1 : 64ull * 3 * (s.lim.cus ? s.lim.cus : 256);
+    s.lanes_min = batch_lanes ? 1 : 64ull * 2 * (s.lim.cus ? s.lim.cus : 256);
     static const bool lanes_enabled = [] {
         const char* e = std::getenv("EZPZ_LANES");
         return !(e && e[0] == '0');

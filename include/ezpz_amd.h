@@ -187,7 +187,7 @@ const char* ezpz_error_string(int err);
 /* automatic choice among the list-walk shapes only (team_mode 0-2): never the component-resident shape (A/B runs) */
 #define EZPZ_TEAM_AUTO_LISTS 0xFFFFFFFEu
 /* automatic, and a connected sketch of more than 20 variables runs one lane per system (lanes across the batch) at every
- * batch size instead of from 64 x 3 x CUs systems per call (A/B runs and tests) */
+ * batch size instead of from 64 x 2 x CUs systems per call (A/B runs and tests) */
 #define EZPZ_TEAM_BATCH_LANES 0xFFFFFFFDu
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);

@@ -210,7 +210,7 @@ def test_random_systems_of_all_kinds_on_the_lane_kernel(E):
 
 @pytest.mark.parametrize("npts,seed", [(12, 5), (30, 1), (75, 2), (150, 3)])
 def test_connected_sketches_lanes_across_the_batch(E, npts, seed):
-    """Device-filling batches (>= 64 x 3 x CUs systems; here forced with TEAM_BATCH_LANES) of one connected sketch of
+    """Device-filling batches (>= 64 x 2 x CUs systems; here forced with TEAM_BATCH_LANES) of one connected sketch of
     mixed kinds (tests/gen.py:connected_sketch: too large for a lane's registers) run one lane per system on the
     uniform-program kernel with its state in global memory (batch_kernel.hip.hpp): every system against the oracle
     (iteration counts, flags, unsatisfied masks, warnings, coordinates at 1e-6) and against the per-system list-walk

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 
 find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b16384_kernel_stats.csv; rm -rf $out/stats_m
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s -- python3 bench.py --workload square --batch 65536 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
 find $out/stats_s -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/square_b65536_kernel_stats.csv; rm -rf $out/stats_s
-(echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = batch-throughput launch shape)"; python tools/sketch_scaling.py 8 25 75 150 400 1000 2500 2>&1 | grep npts; echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve)"; TEAM=4294967295 python tools/sketch_scaling.py 25 75 150 250 400 1000 2500 2>&1 | grep npts; echo "# BATCH=262144 (a device-filling batch: from 64 x 3 x CUs systems per call a sketch of more than 20 variables runs one lane per system, batch_kernel.hip.hpp)"; BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts; echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZPZ_LANES=0 BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts) > $out/sketch_scaling.txt
+(echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = batch-throughput launch shape)"; python tools/sketch_scaling.py 8 25 75 150 400 1000 2500 2>&1 | grep npts; echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve)"; TEAM=4294967295 python tools/sketch_scaling.py 25 75 150 250 400 1000 2500 2>&1 | grep npts; echo "# BATCH=262144 (a device-filling batch: from 64 x 2 x CUs systems per call a sketch of more than 20 variables runs one lane per system, batch_kernel.hip.hpp)"; BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts; echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZPZ_LANES=0 BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts) > $out/sketch_scaling.txt
 (echo "# python tools/pcie_bw.py  (host link of the GPU box)"; python tools/pcie_bw.py 2>&1) > $out/pcie_bw.txt
 python tools/ab_microbench.py $out > /dev/null 2>&1
 (echo "# ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/<case>/problem.md  (the reference CLI's protocol, main.rs:86-100; steady state = the 100-run loop alone)"; for c in tiny square arc_radius two_rectangles massive_parallel_system; do echo "## $c"; ./ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/$c/problem.md | grep -E "Problem size|Iterations|Steady"; done) > $out/cli_latency.txt
