@@ -124,7 +124,15 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                 sys = next;
                 next += stride;
                 const double* row = a.x0 + sys * a.nv;
-                for (uint32_t k = 0; k < a.nv; ++k) P[k] = row[prog[a.var_off + k]];
+                // (four loads in flight, then four stores: a plain loop exposes one round trip per variable)
+                for (uint32_t k = 0; k < a.nv; k += 4) {
+                    double t[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) t[q] = k + q < a.nv ? row[prog[a.var_off + k + q]] : 0.0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q)
+                        if (k + q < a.nv) P[k + q] = t[q];
+                }
                 nwarn = 0;
             }
             double sq = 0.0, mx = __builtin_nan(""), none = 0.0;
@@ -327,7 +335,14 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
             }
             if (finish) {
                 double* row = a.x_out + sys * a.nv;
-                for (uint32_t k = 0; k < a.nv; ++k) row[prog[a.var_off + k]] = P[k];
+                for (uint32_t k = 0; k < a.nv; k += 4) {
+                    double t[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) t[q] = k + q < a.nv ? P[k + q] : 0.0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q)
+                        if (k + q < a.nv) row[prog[a.var_off + k + q]] = t[q];
+                }
                 EzpzStatus st;
                 st.iterations = iterations;
                 st.converged = converged;
