@@ -245,3 +245,33 @@ def test_connected_sketches_lanes_across_the_batch(E, npts, seed):
         assert (int(st2["iterations"][b]), bool(st2["converged"][b]), int(st2["n_warnings"][b])) == (want.iterations, want.converged, len(want.warnings)), b
         assert [p for _, p in logs[b]] == [w[0] for w in want.warnings][: len(logs[b])], b
         assert_x_close(x2[b], want.final_values)
+
+
+@pytest.mark.parametrize("npts", [40, 160])
+def test_weighted_inconsistent_sketch_on_the_lanes_and_on_dense_phases(E, npts):
+    """Non-unit weights and rows that cannot be satisfied on a connected sketch (every fifth constraint weighted 0.25 or
+    3, a few points pinned twice at different places): the weighted residual drives the LM loop, the unsatisfied check
+    re-evaluates the rows unweighted (lib.rs:305-327).  Lanes across the batch and the one-solve shape with its dense
+    phases against the oracle: flags, unsatisfied rows, residual and coordinates."""
+    recs, g = gen.connected_sketch(npts, 900 + npts)
+    recs = recs.copy()
+    for i in range(0, len(recs), 5):
+        recs[i]["weight"] = 0.25 if (i // 5) % 2 else 3.0
+    extra = [O.fixed(2 * k, float(g[2 * k]) + 0.3, weight=0.5) for k in (npts // 3, npts // 2)]
+    recs = O.stack(list(recs) + extra)
+    n = len(g)
+    cfg = dict(max_iterations=60)
+    x0 = g[None, :] + gen.keyed_uniform(npts, 96, n, -0.02, 0.02)
+    lanes = E.System(recs, n, team_size=E.TEAM_BATCH_LANES)
+    lat = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY)
+    xl, stl, ml = lanes.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    xt, stt, mt = lat.solve_batch(x0[:8], E.Config(**cfg), want_mask=True)
+    for b in range(8):
+        want = O.solve(recs, x0[b], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert want.error == 0 and want.unsatisfied
+        for st, mask, x in ((stl, ml, xl), (stt, mt, xt)):
+            assert bool(st["converged"][b]) == want.converged and np.nonzero(mask[b])[0].tolist() == want.unsatisfied, b
+            assert abs(float(st["final_residual_inf"][b]) - want.final_residual_inf) <= 1e-6 * max(1.0, want.final_residual_inf)
+            assert_x_close(x[b], want.final_values, 1e-5)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0 and np.array_equal(stl["converged"], conv) and np.array_equal(stl["n_unsatisfied"], nun)
