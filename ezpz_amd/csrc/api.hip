@@ -1317,18 +1317,35 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     }();
     // (not on the lean 128-lane batch shape: 300 variables 1.61 -> 1.40 M solves/s with the root block; 256-512 lanes: 800
     // variables 41.7 -> 49.7 k/s, 2000: 90 -> 97 k/s)
-    if (root_enabled && auto_shape && s.mode == MODE_WGB && s.grid_wgs == 1 && (for_latency || s.team_size >= 256) &&
-        s.lds_bytes + 4096 <= s.lim.lds_bytes &&
-        make_dense_phases(P, s.team_size / 64, std::min<size_t>(s.lim.lds_bytes - s.lds_bytes - 1024, 48 * 1024))) {
+    // One wavefront per system (batches of 100-220 variables): every team of the workgroup has its own panels, at most 6 KB.
+    // ... out of the LDS its workgroup leaves unused at the number of workgroups a CU holds now: the panels must not cost a
+    // batch its occupancy (150 variables: 4 workgroups of 2 teams -> 3 with 6 KB of panels per team: -5 % despite the
+    // shorter solve; with the root block alone in the 2.5 KB of slack per team the count stays).
+    const bool wave_teams = s.mode == MODE_SUB && s.team_size == 64;
+    const uint32_t teams = wave_teams ? s.block_threads / 64 : 1;
+    size_t dense_room = 0;
+    if (wave_teams) {
+        const size_t per_cu = std::max<size_t>(1, s.lim.lds_bytes / std::max<size_t>(s.lds_bytes, 1));
+        const size_t slack = s.lim.lds_bytes / per_cu > s.lds_bytes + 64 ? s.lim.lds_bytes / per_cu - s.lds_bytes - 64 : 0;
+        dense_room = slack / teams;
+    } else if (s.lds_bytes + 4096 <= s.lim.lds_bytes) {
+        dense_room = std::min<size_t>(s.lim.lds_bytes - s.lds_bytes - 1024, 48 * 1024);
+    }
+    if (root_enabled && auto_shape && s.grid_wgs == 1 &&
+        ((s.mode == MODE_WGB && (for_latency || s.team_size >= 256)) || wave_teams) && dense_room >= 1024 &&
+        make_dense_phases(P, wave_teams ? 1 : s.team_size / 64, dense_room)) {
+        const int mode_before = s.mode;
+        const uint32_t threads_before = s.block_threads;
         choose_level_groups(P, s);
         s.counts = P.c;
         pack_and_shape();  // (the lists only got shorter and the level buffer no wider: the same shape again)
-        if (s.mode == MODE_WGB && s.lds_bytes + (size_t)P.dense_lds_doubles * 8 + 64 <= s.lim.lds_bytes) {
+        if (s.mode == mode_before && s.block_threads == threads_before &&
+            s.lds_bytes + (size_t)P.dense_lds_doubles * 8 * teams + 64 <= s.lim.lds_bytes) {
             s.n_dense = P.n_dense;
             s.dense_level0 = P.dense_level0;
             s.dense_lds_doubles = P.dense_lds_doubles;
             s.dense_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);
-            s.lds_bytes = (size_t)s.dense_lds_off * 8 + (size_t)P.dense_lds_doubles * 8;
+            s.lds_bytes = (size_t)s.dense_lds_off * 8 + (size_t)P.dense_lds_doubles * 8 * teams;
         } else {
             be.code = EZPZ_ERR_TOO_LARGE;  // cannot happen: the same program with shorter lists
             return fail();

@@ -999,7 +999,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 // d is final), then the block's triangle.  ~1 k cycles per column of the longest block instead of
                 // ~4 k per level.  The sums run in a different order than the list walk's (as between any two elimination
                 // orders).
-                constexpr bool ROOT_OK = MODE == MODE_WGB && !GRID && !DENSE;
+                constexpr bool ROOT_OK = (MODE == MODE_WGB || (MODE == MODE_SUB && TEAM == 64)) && !GRID && !DENSE;
+                // (one wavefront per system: every team has its own panels and walks all blocks of a phase itself)
+                double* const dense_base = smem + a.dense_lds_off + (MODE == MODE_SUB ? (size_t)(tid >> 6) * a.dense_lds_doubles : 0);
+                const uint32_t dense_wave = MODE == MODE_SUB ? 0u : (uint32_t)tid >> 6;
                 auto readlane_f64 = [](double v, uint32_t l) {
                     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
                     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, (int)l);
@@ -1011,7 +1014,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 auto dense_phase = [&](uint32_t lv) __attribute__((always_inline)) {
                     const idx_t* rec = P.dense_tab + uni(P.dense_tab[1 + (lv - a.dense_level0)]);
                     const uint32_t nb = uni(rec[0]);
-                    double* DB = smem + a.dense_lds_off;
+                    double* DB = dense_base;
                     const uint32_t c0 = uni(lvl_cptr[lv]), s0 = uni(lvl_sptr[lv]);
                     const uint32_t ncol = uni(lvl_cptr[lv + 1]) - c0, nitem = ncol + (uni(lvl_sptr[lv + 1]) - s0);
                     const uint32_t g = uni(lvl_grp[lv]) & 0xFFu;
@@ -1058,7 +1061,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                         }
                     }
                     tm.phase_sync();
-                    for (uint32_t blk = uni((uint32_t)tid >> 6); blk < nb; blk += (uint32_t)tm.stride >> 6) {
+                    for (uint32_t blk = uni(dense_wave); blk < nb; blk += (uint32_t)tm.stride >> 6) {
                         const idx_t* bk = rec + 1 + 5 * blk;
                         const uint32_t K = uni(bk[0]), R = uni(bk[1]), ST = uni(bk[3]);
                         double* D = DB + uni(bk[2]);
@@ -1101,10 +1104,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 auto dense_bwd = [&](uint32_t lv) __attribute__((always_inline)) {
                     const idx_t* rec = P.dense_tab + uni(P.dense_tab[1 + (lv - a.dense_level0)]);
                     const uint32_t nb = uni(rec[0]);
-                    for (uint32_t blk = uni((uint32_t)tid >> 6); blk < nb; blk += (uint32_t)tm.stride >> 6) {
+                    for (uint32_t blk = uni(dense_wave); blk < nb; blk += (uint32_t)tm.stride >> 6) {
                         const idx_t* bk = rec + 1 + 5 * blk;
                         const uint32_t K = uni(bk[0]), R = uni(bk[1]), ST = uni(bk[3]);
-                        const double* D = smem + a.dense_lds_off + uni(bk[2]);
+                        const double* D = dense_base + uni(bk[2]);
                         const idx_t* rowvar = P.dense_tab + uni(bk[4]);
                         const uint32_t r = (uint32_t)tid & 63u, rc = r < K ? r : K - 1;
                         double rem = D[(R - 1) * ST + rc], xr = 0.0;  // y_r minus the terms of the rows already solved
@@ -1134,8 +1137,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 };
                 if constexpr (ROOT_OK) {
                     if (a.n_dense) {  // (the levels' rendezvous order this before the panels' entries are written)
-                        double* DB = smem + a.dense_lds_off;
-                        for (uint32_t i = (uint32_t)tid; i < a.dense_lds_doubles; i += blockDim.x) DB[i] = 0.0;
+                        for (uint32_t i = (uint32_t)tm.lane; i < a.dense_lds_doubles; i += (uint32_t)tm.stride) dense_base[i] = 0.0;
                     }
                 }
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
