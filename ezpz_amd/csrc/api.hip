@@ -1292,9 +1292,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
                               P.c.n_apairs < 65536 && P.c.n_lpairs < 65536 && P.c.n_cons < 65536;
     ProgramView& v = s.view;
     size_t stage_bytes = 0;
-    auto pack_and_shape = [&]() {
+    auto pack_and_shape = [&](bool may_stage) {
         stage_bytes = 0;
-        if (small_counts) {
+        if (small_counts && may_stage) {
             const size_t lists_bytes = pack_program(P, true, s.mode != MODE_SUB, blob, v);
             const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
             if (s.mode == MODE_SUB) {
@@ -1308,7 +1308,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         s.lvl_nlev = P.parts.empty() ? 0 : P.parts[0].nlev;
         finish_team(s, stage_bytes);
     };
-    pack_and_shape();
+    pack_and_shape(true);
     // ---- dense phases: the top of a connected sketch's elimination tree on a barrier workgroup ------------------------------
     s.n_dense = s.dense_level0 = s.dense_lds_off = s.dense_lds_doubles = 0;
     static const bool root_enabled = [] {
@@ -1338,7 +1338,22 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const uint32_t threads_before = s.block_threads;
         choose_level_groups(P, s);
         s.counts = P.c;
-        pack_and_shape();  // (the lists only got shorter and the level buffer no wider: the same shape again)
+        // (the lists only got shorter: the same shape again -- but a program that did not fit the LDS beside its workspace
+        // before must not move in now and take the panels' room)
+        pack_and_shape(stage_bytes > 0);
+        {  // the level staging buffer is optional space (levels wider than it are walked in place): the panels come first
+            const size_t need = s.lds_bytes + (size_t)P.dense_lds_doubles * 8 * teams + 64;
+            if (need > s.lim.lds_bytes && s.mode == MODE_WGB && s.lvl_buf_words) {
+                const size_t over = (need - s.lim.lds_bytes + 15) & ~size_t(15);
+                if ((size_t)s.lvl_buf_words * 4 >= over + 1024) {
+                    s.lvl_buf_words -= (uint32_t)(over / 4);
+                    s.lds_bytes -= over;
+                } else {  // no staging at all: its tables and buffer go
+                    s.lds_bytes = (size_t)s.lvl_lds_off * 8;
+                    s.lvl_lds_off = s.lvl_tab_words = s.lvl_buf_words = 0;
+                }
+            }
+        }
         if (s.mode == mode_before && s.block_threads == threads_before &&
             s.lds_bytes + (size_t)P.dense_lds_doubles * 8 * teams + 64 <= s.lim.lds_bytes) {
             s.n_dense = P.n_dense;
@@ -1347,6 +1362,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             s.dense_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);
             s.lds_bytes = (size_t)s.dense_lds_off * 8 + (size_t)P.dense_lds_doubles * 8 * teams;
         } else {
+            if (std::getenv("EZPZ_DENSE_DEBUG"))
+                std::fprintf(stderr, "dense phases: mode %d -> %d, threads %u -> %u, lds %zu + %zu x %u of %zu\n", mode_before, (int)s.mode,
+                             threads_before, s.block_threads, s.lds_bytes, (size_t)P.dense_lds_doubles * 8, teams, s.lim.lds_bytes);
             be.code = EZPZ_ERR_TOO_LARGE;  // cannot happen: the same program with shorter lists
             return fail();
         }

@@ -107,6 +107,47 @@ def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
     assert with_block[0] + 5 <= plain[0] and with_block[1] == plain[1] == 2, (with_block, plain)
 
 
+def test_symbolic_phase_survives_random_sketches_at_the_edge_of_the_lds():
+    """The launch-shape code re-packs a program after cutting its dense phases; sketches whose workspace almost fills
+    the LDS (1408 variables: 156 KB) once came back from that as "too large" (the shorter level table let the level
+    staging buffer in, or the shorter lists let the program move into LDS, and either took the panels' room).  The cases
+    a 3000-system fuzz found, and a sample of its four graph families (band, hub, grid, random tree with chords)."""
+    import gen
+    rng = np.random.default_rng(5)
+    for npts, seed in ((704, 288), (286, 500), (278, 688), (294, 1056)):
+        recs, g = gen.connected_sketch(npts, seed)
+        i = E.analyze(recs, len(g))
+        assert i["n_vars"] == 2 * npts and i["n_components"] == 1
+    pt = lambda i: (2 * i, 2 * i + 1)
+    for trial in range(48):
+        npts = int(rng.integers(10, 700))
+        cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
+        if trial % 4 == 0:
+            recs, g = gen.connected_sketch(npts, 100 + trial)
+        else:
+            if trial % 4 == 1:  # hub
+                for k in range(1, npts):
+                    cons += [O.distance(pt(k), pt(0), 1.0 + k), O.horizontal_distance(pt(k), pt(0), 0.5 * k)]
+            elif trial % 4 == 2:  # grid: every point tied to its left and upper neighbours
+                w = int(np.sqrt(npts)) + 1
+                npts = w * w
+                for k in range(1, npts):
+                    r, c = divmod(k, w)
+                    if c > 0:
+                        cons.append(O.distance(pt(k), pt(k - 1), 1.0))
+                    if r > 0:
+                        cons.append(O.distance(pt(k), pt(k - w), 1.0))
+                    cons.append(O.horizontal_distance(pt(k), pt(k - w), 0.0) if c == 0 else O.vertical_distance(pt(k), pt(k - 1), 0.0) if r == 0
+                                else O.fixed(2 * k, float(c)))
+            else:  # random tree with chords
+                for k in range(1, npts):
+                    a, b = int(rng.integers(0, k)), int(rng.integers(0, k))
+                    cons += [O.distance(pt(k), pt(a), 1.0), O.vertical_distance(pt(k), pt(b), 0.3) if a != b else O.horizontal_distance(pt(k), pt(a), 0.2)]
+            recs, g = O.stack(cons), rng.uniform(-5, 5, 2 * npts)
+        i = E.analyze(recs, len(g))
+        assert i["n_vars"] == len(g) and i["n_levels"] >= 1
+
+
 def test_symbolic_phase_reports_missing_guess():
     """solver.rs:142-189: first id (row0 then row1, constraint order) that has no guess."""
     with pytest.raises(E.NonLinearSystemError) as e:

@@ -715,6 +715,24 @@ def test_connected_sketch_latency_shape_with_dense_root_block(E, npts):
     assert_x_close(xb[0], want.final_values, 1e-4)
 
 
+def test_sketch_whose_workspace_fills_the_lds_keeps_its_dense_phases(E):
+    """1408 variables: 156 KB of workspace in LDS, the program read from global memory, and the few KB left go to the dense
+    panels rather than to the level staging buffer (api.hip, analyze_into).  Against the oracle."""
+    recs, g = gen.connected_sketch(704, 288)
+    s = E.System(recs, len(g), team_size=E.TEAM_AUTO_LATENCY)
+    plain = E.System(recs, len(g), team_size=512)
+    assert s.info()["workspace_in_lds"] == 1 and s.info()["n_levels"] + 5 <= plain.info()["n_levels"]
+    x0 = np.stack([g, g + 0.01])
+    cfg = dict(max_iterations=40)
+    x, st, mask = s.solve_batch(x0, E.Config(**cfg), want_mask=True)
+    for b in range(2):
+        want = O.solve(recs, x0[b], O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
+        assert want.error == 0 and bool(st["converged"][b]) == want.converged
+        assert abs(int(st["iterations"][b]) - want.iterations) <= (0 if want.iterations <= 12 else 2)
+        assert np.nonzero(mask[b])[0].tolist() == want.unsatisfied
+        assert_x_close(x[b], want.final_values)
+
+
 def _hub_sketch(npts, seed, hub_last):
     """`npts` points each tied to one hub point (a distance and a horizontal distance): one connected component.  The
     hub's two variables come last or -- the way a sketch dimensioned from its origin is written -- first; the layout
