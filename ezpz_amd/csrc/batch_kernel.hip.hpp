@@ -32,7 +32,7 @@ struct BatchArgs {
     EzpzStatus* status;
     uint8_t* unsat_mask;  // optional
     uint64_t* warn_log;   // optional
-    uint32_t warn_cap, max_iterations, unit_weights, pad;
+    uint32_t warn_cap, max_iterations, unit_weights, refill_lanes;  // refill_lanes: idle lanes of a wavefront that trigger a refill
     uint64_t batch;
     double residual_tolerance, step_tolerance, initial_lambda;
     double* ws;  // workspaces: one per wavefront of the launch, `rows` x 64 doubles each
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
         // ---- refill: idle lanes take the next systems of the batch; eval() for them (newton.rs:45, :232-236) -------------
         const bool want = !have && next < a.batch;
         const unsigned long long wanting = __ballot(want), busy = __ballot(have);
-        if (wanting && (!busy || __popcll(wanting) >= 22)) {
+        if (wanting && (!busy || (uint32_t)__popcll(wanting) >= a.refill_lanes)) {
             if (want) {
                 sys = next;
                 next += stride;

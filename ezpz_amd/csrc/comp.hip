@@ -90,6 +90,9 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
     a.warn_cap = L.warn_cap;
     a.max_iterations = L.max_iterations;
     a.unit_weights = plan.unit_weights ? 1u : 0u;
+    // (4 ... 32 measured on 262 144 jittered systems of 300 variables, 4-19 iterations each: no difference -- at one system
+    // per lane a wavefront lasts as long as its slowest lane)
+    a.refill_lanes = 22;
     a.batch = L.batch;
     a.residual_tolerance = L.residual_tolerance;
     a.step_tolerance = L.step_tolerance;

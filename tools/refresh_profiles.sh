@@ -13,6 +13,7 @@ python bench.py --workload massive500o --pmc 0 > $out/bench_massive500_overconst
 python bench.py --workload square --batch 65536 > $out/bench_square.json 2>/dev/null
 python bench.py --workload mixed --batch 1000000 --steps 20 > $out/bench_mixed_1M.json 2>/dev/null
 python bench.py --workload massive50000 --batch 64 --steps 20 > $out/bench_ladder200k.json 2>/dev/null
+python bench.py --workload sketch150 --batch 262144 --steps 10 --warmup 2 > $out/bench_sketch_300vars_b262144.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 bench.py --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
 find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b16384_kernel_stats.csv; rm -rf $out/stats_m
