@@ -1315,8 +1315,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const char* e = std::getenv("EZPZ_ROOT");
         return !(e && e[0] == '0');
     }();
-    // (not on the lean 128-lane batch shape: 300 variables 1.61 -> 1.40 M solves/s with the root block; 256-512 lanes: 800
-    // variables 41.7 -> 49.7 k/s, 2000: 90 -> 97 k/s)
+    // (256-512 lanes: 800 variables 41.7 -> 49.7 k/s, 2000: 90 -> 97 k/s; the lean 128-lane batch shape only out of the LDS
+    // slack that keeps its workgroups per CU: with 6 KB of panels 300 variables fell 1.50 -> 1.32 M solves/s, 400 rose
+    // 0.83 -> 0.92)
     // One wavefront per system (batches of 100-220 variables): every team of the workgroup has its own panels, at most 6 KB.
     // ... out of the LDS its workgroup leaves unused at the number of workgroups a CU holds now: the panels must not cost a
     // batch its occupancy (150 variables: 4 workgroups of 2 teams -> 3 with 6 KB of panels per team: -5 % despite the
@@ -1324,7 +1325,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     const bool wave_teams = s.mode == MODE_SUB && s.team_size == 64;
     const uint32_t teams = wave_teams ? s.block_threads / 64 : 1;
     size_t dense_room = 0;
-    if (wave_teams) {
+    if (wave_teams || (s.mode == MODE_WGB && !for_latency && s.team_size < 256)) {  // (the lean 128-lane batch shape as well)
         const size_t per_cu = std::max<size_t>(1, s.lim.lds_bytes / std::max<size_t>(s.lds_bytes, 1));
         const size_t slack = s.lim.lds_bytes / per_cu > s.lds_bytes + 64 ? s.lim.lds_bytes / per_cu - s.lds_bytes - 64 : 0;
         dense_room = slack / teams;
@@ -1332,7 +1333,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         dense_room = std::min<size_t>(s.lim.lds_bytes - s.lds_bytes - 1024, 48 * 1024);
     }
     if (root_enabled && auto_shape && s.grid_wgs == 1 &&
-        ((s.mode == MODE_WGB && (for_latency || s.team_size >= 256)) || wave_teams) && dense_room >= 1024 &&
+        ((s.mode == MODE_WGB && (for_latency || s.team_size >= 128)) || wave_teams) && dense_room >= 1024 &&
         make_dense_phases(P, wave_teams ? 1 : s.team_size / 64, dense_room)) {
         const int mode_before = s.mode;
         const uint32_t threads_before = s.block_threads;
