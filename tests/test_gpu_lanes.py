@@ -275,3 +275,19 @@ def test_weighted_inconsistent_sketch_on_the_lanes_and_on_dense_phases(E, npts):
             assert_x_close(x[b], want.final_values, 1e-5)
     rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
     assert rc == 0 and np.array_equal(stl["converged"], conv) and np.array_equal(stl["n_unsatisfied"], nun)
+
+
+def test_specialisation_survives_thousands_of_topologies(E):
+    """Specialised kernels are never unloaded, so a process has a budget of them (512) -- but a topology that was only
+    ever interpreted holds nothing but its source text and must not count: after 2300 distinct little systems have come
+    and gone (more than the registry keeps entries for), a new topology still gets its kernel."""
+    for k in range(2300):
+        s = E.System(O.stack([O.fixed(0, float(k)), O.fixed(1, 1.0)]), 2)
+        if k % 500 == 0:
+            x, st, _ = s.solve_batch(np.zeros((4, 2)))
+            assert np.allclose(x, [float(k), 1.0], rtol=0, atol=1e-6)
+        del s
+    recs = O.stack([O.distance((0, 1), (2, 3), 2.0), O.fixed(0, 0.0), O.fixed(1, 0.0), O.horizontal((0, 1), (2, 3))])
+    sysobj = lanes(E, recs, 4)
+    x, st, _ = sysobj.solve_batch(np.tile([0.1, -0.1, 1.7, 0.2], (64, 1)))
+    assert st["converged"].all() and np.allclose(x, [0.0, 0.0, 2.0, 0.0], atol=1e-9)
