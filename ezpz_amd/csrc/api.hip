@@ -1663,7 +1663,10 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
             return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 2) << 20;
         }();
         // (big systems: a launch needs several of them to fill the device, whatever their size in bytes)
-        const size_t piece = std::max<size_t>(std::min<size_t>(batch, 8), std::min<size_t>(piece_bytes / row, (batch + 5) / 6));
+        size_t piece = std::max<size_t>(std::min<size_t>(batch, 8), std::min<size_t>(piece_bytes / row, (batch + 5) / 6));
+        // (the lanes-across-the-batch kernel works in one workspace per system object: its launches must not overlap, so
+        // the pieces of this pipeline stay below its threshold and run on the teams, which keep their state in LDS)
+        if (sys->lanes && piece >= sys->lanes_min) piece = (size_t)sys->lanes_min - 1;
         // the statuses of the whole call collect in one device buffer and come back in one copy at the end
         if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
         size_t k = 0;
