@@ -159,6 +159,7 @@ struct EzpzSystem {
     uint32_t* dev_lanes = nullptr;
     DevBuf<double> lanes_ws;
     uint64_t lanes_ws_waves = 0;
+    hipEvent_t lanes_done = nullptr;  // completion of this system's last lanes launch: the next one (any stream) waits for it
     uint64_t lanes_min = ~0ull;  // systems per call from which `lanes` serves the call
     std::atomic<uint32_t> launches{0};  // a topology solved again and again (an interactive sketch) earns its specialised kernel
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
@@ -216,6 +217,7 @@ struct EzpzSystem {
         if (dev_grid_blob) (void)hipFree(dev_grid_blob);
         if (dev_comp) (void)hipFree(dev_comp);
         if (dev_lanes) (void)hipFree(dev_lanes);
+        if (lanes_done) (void)hipEventDestroy(lanes_done);
         comp_jit_destroy(jit);
     }
 };
@@ -483,9 +485,17 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             while (waves > 4 && waves * per > (24ull << 30)) waves /= 2;
             if (s.lanes_ws.ensure((size_t)(waves * per / 8)) == EZPZ_OK) s.lanes_ws_waves = waves;
         }
-        if (s.lanes_ws_waves &&
-            batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream) == EZPZ_OK)
-            return EZPZ_OK;
+        if (s.lanes_ws_waves) {
+            // one workspace per system object: launches on different streams are chained, never overlapped
+            if (!s.lanes_done)
+                HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
+            else
+                HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
+            if (batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream) == EZPZ_OK) {
+                HIP_TRY(hipEventRecord(s.lanes_done, stream));
+                return EZPZ_OK;
+            }
+        }
     }
     if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
