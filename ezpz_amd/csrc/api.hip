@@ -159,7 +159,8 @@ struct EzpzSystem {
     uint32_t* dev_lanes = nullptr;
     DevBuf<double> lanes_ws;
     uint64_t lanes_ws_waves = 0;
-    hipEvent_t lanes_done = nullptr;  // completion of this system's last lanes launch: the next one (any stream) waits for it
+    hipEvent_t lanes_done = nullptr;  // completion of this system's last launch that used its global-memory workspace (lanes
+                                      // kernel, list walk with the workspace in global memory): the next one, on any stream, waits for it
     uint64_t lanes_min = ~0ull;  // systems per call from which `lanes` serves the call
     std::atomic<uint32_t> launches{0};  // a topology solved again and again (an interactive sketch) earns its specialised kernel
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
@@ -547,12 +548,21 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         args.gws = s.gws_dev.p;
     }
     const bool staged = s.prog_in_lds;
-    if (s.mode == MODE_PART) {
-        if (!s.lds_ws) return launch_variant<64, MODE_PART, false, false>(s, args, grid, stream);
+    if (!s.lds_ws) {
+        // the workspace in global memory is one per system object: launches on different streams are chained on an event
+        // (like the lanes kernel's), never overlapped
+        if (!s.lanes_done)
+            HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
+        else
+            HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
+        const int rc = s.mode == MODE_PART ? launch_variant<64, MODE_PART, false, false>(s, args, grid, stream)
+                                           : launch_variant<64, MODE_WGB, false, false>(s, args, grid, stream);
+        if (rc == EZPZ_OK) HIP_TRY(hipEventRecord(s.lanes_done, stream));
+        return rc;
+    }
+    if (s.mode == MODE_PART)
         return staged ? launch_variant<64, MODE_PART, true, true>(s, args, grid, stream)
                       : launch_variant<64, MODE_PART, true, false>(s, args, grid, stream);
-    }
-    if (!s.lds_ws) return launch_variant<64, MODE_WGB, false, false>(s, args, grid, stream);
     return staged ? launch_variant<64, MODE_WGB, true, true>(s, args, grid, stream)
                   : launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream);
 }
