@@ -291,3 +291,46 @@ def test_specialisation_survives_thousands_of_topologies(E):
     sysobj = lanes(E, recs, 4)
     x, st, _ = sysobj.solve_batch(np.tile([0.1, -0.1, 1.7, 0.2], (64, 1)))
     assert st["converged"].all() and np.allclose(x, [0.0, 0.0, 2.0, 0.0], atol=1e-9)
+
+
+def test_one_system_object_on_two_streams(E):
+    """The lanes kernel (and the list walk of a sketch too large for the LDS) works in one global-memory workspace per
+    system object: calls on different streams are chained on an event, so interleaved launches on two streams give what
+    the same calls give one after the other.  (In a child process: the streams and device buffers are torch's, which must
+    initialise the device before the library does.)"""
+    import subprocess, sys
+    from conftest import ROOT
+    code = '''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+dev = torch.device("cuda", 0)
+torch.zeros(1, device=dev)
+import numpy as np, ezpz_amd as E, gen
+for npts, team in ((40, E.TEAM_BATCH_LANES), (1100, 0)):
+    recs, g = gen.connected_sketch(npts, 4000 + npts)
+    n = len(g)
+    s = E.System(recs, n, team_size=team)
+    B = 2048 if team else 24
+    cfg = E.Config(max_iterations=30)
+    xs = [torch.from_numpy(g[None, :] + gen.keyed_uniform(k, B, n, -0.02, 0.02)).to(dev) for k in range(4)]
+    outs = [torch.empty_like(x) for x in xs]
+    sts = [torch.zeros((B, 32), dtype=torch.uint8, device=dev) for _ in xs]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize(dev)
+    for rep in range(3):
+        for k, x in enumerate(xs):
+            s.solve_batch_device(x.data_ptr(), B, outs[k].data_ptr(), sts[k].data_ptr(), 0, streams[k %% 2].cuda_stream, cfg)
+    torch.cuda.synchronize(dev)
+    for k, x in enumerate(xs):
+        ref, st = torch.empty_like(x), torch.zeros((B, 32), dtype=torch.uint8, device=dev)
+        s.solve_batch_device(x.data_ptr(), B, ref.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream, cfg)
+        torch.cuda.synchronize(dev)
+        same = torch.equal(ref, outs[k]) and torch.equal(st, sts[k])
+        if not same:
+            print("MISMATCH", npts, k, int((ref != outs[k]).sum()), int((st != sts[k]).sum()))
+            sys.exit(3)
+print("two streams ok")
+''' % (ROOT, ROOT + "/tests")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "two streams ok" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
