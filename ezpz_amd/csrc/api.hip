@@ -1160,6 +1160,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         if (!build_program(cs, n_cs, n_vars, P, be, 1, allow_dense)) return fail();
         const bool dense = P.c.dense != 0;  // granted only when JtJ is mostly full
         if (dense) team = 4;
+        // one solve of a system too large for the register solve: a whole wavefront (its levels run as one phase each, the
+        // lists shared by groups of lanes, the top of the elimination tree as dense phases)
+        if (for_latency && !dense && width > 16) team = 64;
         // 64 / team workspaces share a wavefront: keep a wavefront's share of the LDS <= 32 KiB when choosing
         // automatically (>= 4 wavefronts per CU), and inside the hard limit in any case
         if (!team_size)
@@ -1345,12 +1348,12 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     const bool wave_teams = s.mode == MODE_SUB && s.team_size == 64;
     const uint32_t teams = wave_teams ? s.block_threads / 64 : 1;
     size_t dense_room = 0;
-    if (wave_teams || (s.mode == MODE_WGB && !for_latency && s.team_size < 256)) {  // (the lean 128-lane batch shape as well)
+    if (!for_latency && (wave_teams || (s.mode == MODE_WGB && s.team_size < 256))) {  // (the lean 128-lane batch shape as well)
         const size_t per_cu = std::max<size_t>(1, s.lim.lds_bytes / std::max<size_t>(s.lds_bytes, 1));
         const size_t slack = s.lim.lds_bytes / per_cu > s.lds_bytes + 64 ? s.lim.lds_bytes / per_cu - s.lds_bytes - 64 : 0;
         dense_room = slack / teams;
-    } else if (s.lds_bytes + 4096 <= s.lim.lds_bytes) {
-        dense_room = std::min<size_t>(s.lim.lds_bytes - s.lds_bytes - 1024, 48 * 1024);
+    } else if (s.lds_bytes + 4096 * teams <= s.lim.lds_bytes) {  // (one solve: occupancy does not matter)
+        dense_room = std::min<size_t>((s.lim.lds_bytes - s.lds_bytes - 1024) / teams, 48 * 1024);
     }
     if (root_enabled && auto_shape && s.grid_wgs == 1 &&
         ((s.mode == MODE_WGB && (for_latency || s.team_size >= 128)) || wave_teams) && dense_room >= 1024 &&

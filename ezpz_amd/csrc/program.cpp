@@ -446,7 +446,7 @@ bool build_program(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Program
                 }
             }
             nd.clear();
-            if (verts.size() > 64) {
+            if (verts.size() > 24) {  // (from 25 vertices: a 50-variable sketch walks 12 levels + phases in request order, 5 dissected)
                 nested_dissection(verts, adj, local_id, nd, pool);
                 if (nd.size() == verts.size() && score(nd) < best) pick = &nd;
             }
