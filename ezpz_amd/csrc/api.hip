@@ -1162,6 +1162,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         if (dense) team = 4;
         // one solve of a system too large for the register solve: a whole wavefront (its levels run as one phase each, the
         // lists shared by groups of lanes, the top of the elimination tree as dense phases)
+        // (not below 17: `square`, `two_rectangles` ... take as long on a wavefront with one dense phase as on their quads
+        // with the register solve, 109 / 51 us per call: an iteration is a dozen phases of 1.5-3 k cycles either way)
         if (for_latency && !dense && width > 16) team = 64;
         // 64 / team workspaces share a wavefront: keep a wavefront's share of the LDS <= 32 KiB when choosing
         // automatically (>= 4 wavefronts per CU), and inside the hard limit in any case
