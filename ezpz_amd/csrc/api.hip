@@ -1018,9 +1018,11 @@ static bool make_dense_phases(Program& P, uint32_t n_waves, size_t lds_room_byte
         const uint32_t lb = phases.back().la;
         // How far down?  A walked level costs ~4.1 k cycles (2.9 k in the factorisation, 1.2 k in the backward substitution).
         // A phase costs ~9 k for its gather, write-back and rendezvous, ~3 k per round of blocks (one block per wavefront
-        // and round, the largest blocks first) and ~0.8 k per column of a round's largest block (stamps on the 300-variable
+        // and round, the largest blocks first) and ~0.5 k per column of a round's largest block (stamps on the 300-variable
         // sketch: 16 blocks of <= 3 columns 12.3 k + 6.7 k cycles, 4 blocks of <= 14: 14.6 k + 6.7 k, the root block of 16:
-        // 12.7 k + 6.7 k): the cut that saves most.
+        // 12.7 k + 6.7 k; the constants swept on 150-2000 variables, one solve: 0.8 k per column keeps 800 and 2000 variables
+        // at two phases, 4.80 / 2.17 ms, 0.5 k gives them a third, 4.49 / 2.02 ms; a fixed cost of 4 k instead of 9 k costs
+        // 300 variables 234 -> 247 us): the cut that saves most.
         uint32_t la = lb, best_la = lb;
         double best_saving = 0.0;
         std::vector<Block> best, trial;
@@ -1028,7 +1030,7 @@ static bool make_dense_phases(Program& P, uint32_t n_waves, size_t lds_room_byte
             --la;
             std::sort(trial.begin(), trial.end(), [](const Block& x, const Block& y) { return x.cols.size() > y.cols.size(); });
             double cost = 9000.0;
-            for (size_t b = 0; b < trial.size(); b += n_waves) cost += 3000.0 + 800.0 * (double)trial[b].cols.size();
+            for (size_t b = 0; b < trial.size(); b += n_waves) cost += 3000.0 + 500.0 * (double)trial[b].cols.size();
             const double saving = 4100.0 * (lb - la) - cost;
             if (saving > best_saving) best_saving = saving, best_la = la, best = trial;
         }
