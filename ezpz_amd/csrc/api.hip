@@ -264,7 +264,8 @@ uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(512, std::max<
 
 // Fixes the launch shape once the program (and so the workspace size) is known.  `stage_bytes` > 0 means
 // that many leading bytes of the blob are copied to LDS by every workgroup (16-bit index lists).
-void finish_team(EzpzSystem& s, size_t stage_bytes) {
+// `panel_bytes`: LDS every team needs on top of its workspace (dense phases), counted when the workgroup is sized.
+void finish_team(EzpzSystem& s, size_t stage_bytes, size_t panel_bytes = 0) {
     s.ws_doubles = workspace_doubles(s.counts);
     const size_t ws_bytes = (size_t)s.ws_doubles * 8;
     s.prog_in_lds = stage_bytes > 0;
@@ -288,7 +289,7 @@ void finish_team(EzpzSystem& s, size_t stage_bytes) {
         // 256 lanes unless the workspaces would not fit; measured: smaller workgroups (more resident wavefronts for
         // big workspaces) are never faster, the kernels are issue-bound
         uint32_t threads = 256;
-        while (threads > 64 && prog_bytes + (size_t)(threads / team) * (ws_bytes + buf_bytes) > 64 * 1024) threads >>= 1;
+        while (threads > 64 && prog_bytes + (size_t)(threads / team) * (ws_bytes + buf_bytes + panel_bytes) > 64 * 1024) threads >>= 1;
         s.block_threads = std::max(threads, team);
         s.lds_bytes = prog_bytes + (size_t)(s.block_threads / team) * ws_bytes + 16;
         if (lvl_ok && buf_bytes >= 1024) {
@@ -1319,7 +1320,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
                               P.c.n_apairs < 65536 && P.c.n_lpairs < 65536 && P.c.n_cons < 65536;
     ProgramView& v = s.view;
     size_t stage_bytes = 0;
-    auto pack_and_shape = [&](bool may_stage) {
+    auto pack_and_shape = [&](bool may_stage, size_t panel_bytes = 0) {
         stage_bytes = 0;
         if (small_counts && may_stage) {
             const size_t lists_bytes = pack_program(P, true, s.mode != MODE_SUB, blob, v);
@@ -1333,7 +1334,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         if (stage_bytes == 0) pack_program(P, false, false, blob, v);
         v.stage_bytes = (uint32_t)stage_bytes;
         s.lvl_nlev = P.parts.empty() ? 0 : P.parts[0].nlev;
-        finish_team(s, stage_bytes);
+        finish_team(s, stage_bytes, panel_bytes);
     };
     pack_and_shape(true);
     // ---- dense phases: the top of a connected sketch's elimination tree on a barrier workgroup ------------------------------
@@ -1350,25 +1351,25 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     // batch its occupancy (150 variables: 4 workgroups of 2 teams -> 3 with 6 KB of panels per team: -5 % despite the
     // shorter solve; with the root block alone in the 2.5 KB of slack per team the count stays).
     const bool wave_teams = s.mode == MODE_SUB && s.team_size == 64;
-    const uint32_t teams = wave_teams ? s.block_threads / 64 : 1;
+    const uint32_t teams_now = wave_teams ? s.block_threads / 64 : 1;
     size_t dense_room = 0;
     if (!for_latency && (wave_teams || (s.mode == MODE_WGB && s.team_size < 256))) {  // (the lean 128-lane batch shape as well)
         const size_t per_cu = std::max<size_t>(1, s.lim.lds_bytes / std::max<size_t>(s.lds_bytes, 1));
         const size_t slack = s.lim.lds_bytes / per_cu > s.lds_bytes + 64 ? s.lim.lds_bytes / per_cu - s.lds_bytes - 64 : 0;
-        dense_room = slack / teams;
-    } else if (s.lds_bytes + 4096 * teams <= s.lim.lds_bytes) {  // (one solve: occupancy does not matter)
-        dense_room = std::min<size_t>((s.lim.lds_bytes - s.lds_bytes - 1024) / teams, 48 * 1024);
+        dense_room = slack / teams_now;
+    } else if (s.lds_bytes + 4096 * teams_now <= s.lim.lds_bytes) {  // (one solve: occupancy does not matter)
+        dense_room = std::min<size_t>((s.lim.lds_bytes - s.lds_bytes - 1024) / teams_now, 48 * 1024);
     }
     if (root_enabled && auto_shape && s.grid_wgs == 1 &&
         ((s.mode == MODE_WGB && (for_latency || s.team_size >= 128)) || wave_teams) && dense_room >= 1024 &&
         make_dense_phases(P, wave_teams ? 1 : s.team_size / 64, dense_room)) {
         const int mode_before = s.mode;
-        const uint32_t threads_before = s.block_threads;
         choose_level_groups(P, s);
         s.counts = P.c;
         // (the lists only got shorter: the same shape again -- but a program that did not fit the LDS beside its workspace
-        // before must not move in now and take the panels' room)
-        pack_and_shape(stage_bytes > 0);
+        // before must not move in now and take the panels' room; a workgroup of wavefront teams is sized with its panels)
+        pack_and_shape(stage_bytes > 0, wave_teams ? (size_t)P.dense_lds_doubles * 8 : 0);
+        const uint32_t teams = wave_teams ? s.block_threads / 64 : 1;
         {  // the level staging buffer is optional space (levels wider than it are walked in place): the panels come first
             const size_t need = s.lds_bytes + (size_t)P.dense_lds_doubles * 8 * teams + 64;
             if (need > s.lim.lds_bytes && s.mode == MODE_WGB && s.lvl_buf_words) {
@@ -1382,8 +1383,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
                 }
             }
         }
-        if (s.mode == mode_before && s.block_threads == threads_before &&
-            s.lds_bytes + (size_t)P.dense_lds_doubles * 8 * teams + 64 <= s.lim.lds_bytes) {
+        if (s.mode == mode_before && s.lds_bytes + (size_t)P.dense_lds_doubles * 8 * teams + 64 <= s.lim.lds_bytes) {
             s.n_dense = P.n_dense;
             s.dense_level0 = P.dense_level0;
             s.dense_lds_doubles = P.dense_lds_doubles;
@@ -1391,8 +1391,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             s.lds_bytes = (size_t)s.dense_lds_off * 8 + (size_t)P.dense_lds_doubles * 8 * teams;
         } else {
             if (std::getenv("EZPZ_DENSE_DEBUG"))
-                std::fprintf(stderr, "dense phases: mode %d -> %d, threads %u -> %u, lds %zu + %zu x %u of %zu\n", mode_before, (int)s.mode,
-                             threads_before, s.block_threads, s.lds_bytes, (size_t)P.dense_lds_doubles * 8, teams, s.lim.lds_bytes);
+                std::fprintf(stderr, "dense phases: mode %d -> %d, threads %u, lds %zu + %zu x %u of %zu\n", mode_before, (int)s.mode,
+                             s.block_threads, s.lds_bytes, (size_t)P.dense_lds_doubles * 8, teams, s.lim.lds_bytes);
             be.code = EZPZ_ERR_TOO_LARGE;  // cannot happen: the same program with shorter lists
             return fail();
         }

@@ -107,6 +107,16 @@ def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
     assert with_block[0] + 5 <= plain[0] and with_block[1] == plain[1] == 2, (with_block, plain)
 
 
+def _shapes_analyse(recs, n):
+    """Every automatic launch shape: where there is no device, creation analyses the system and then reports -100; where
+    there is one it succeeds."""
+    for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_BATCH_LANES):
+        try:
+            E.System(recs, n, team_size=team)
+        except E.NonLinearSystemError as e:
+            assert e.code == -100, (team, e.code)
+
+
 def test_symbolic_phase_survives_random_sketches_at_the_edge_of_the_lds():
     """The launch-shape code re-packs a program after cutting its dense phases; sketches whose workspace almost fills
     the LDS (1408 variables: 156 KB) once came back from that as "too large" (the shorter level table let the level
@@ -118,6 +128,14 @@ def test_symbolic_phase_survives_random_sketches_at_the_edge_of_the_lds():
         recs, g = gen.connected_sketch(npts, seed)
         i = E.analyze(recs, len(g))
         assert i["n_vars"] == 2 * npts and i["n_components"] == 1
+        _shapes_analyse(recs, len(g))
+    # (a 100-variable comb on wavefront teams: the re-pack chose a larger workgroup than the panels had been sized for)
+    ns = {}
+    exec(open(os.path.join(ROOT, "tools", "fuzz_graphs.py")).read().split("bad = tot = 0")[0], ns)
+    for seed in (159, 83, 121, 200):
+        r2 = np.random.default_rng(7000 + seed)
+        recs, true = ns["sketch"](["tree", "band", "hub", "comb"][seed % 4], int(r2.integers(20, 500)), r2)
+        _shapes_analyse(recs, len(true))
     pt = lambda i: (2 * i, 2 * i + 1)
     for trial in range(48):
         npts = int(rng.integers(10, 700))
@@ -146,6 +164,7 @@ def test_symbolic_phase_survives_random_sketches_at_the_edge_of_the_lds():
             recs, g = O.stack(cons), rng.uniform(-5, 5, 2 * npts)
         i = E.analyze(recs, len(g))
         assert i["n_vars"] == len(g) and i["n_levels"] >= 1
+        _shapes_analyse(recs, len(g))
 
 
 def test_symbolic_phase_reports_missing_guess():

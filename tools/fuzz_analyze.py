@@ -40,5 +40,10 @@ for trial in range(3000):
         i = E.analyze(recs, len(g))
     except Exception as e:
         print("FAIL trial", trial, "kind", kind, "npts", npts, e); continue
+    for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_BATCH_LANES):  # every automatic shape: without a device the analysis runs, then -100
+        try:
+            E.System(recs, len(g), team_size=team)
+        except E.NonLinearSystemError as e:
+            if e.code != -100: print("FAIL trial", trial, "kind", kind, "npts", npts, "team", team, e)
     n_ok += 1
 print("analysed", n_ok, "systems without a bounds assertion")
