@@ -1027,7 +1027,8 @@ static bool make_dense_phases(Program& P, uint32_t n_waves, size_t lds_room_byte
         uint32_t la = lb, best_la = lb;
         double best_saving = 0.0;
         std::vector<Block> best, trial;
-        while (la > 1 && cut(la - 1, lb, trial) && lds_used + lds_doubles(trial) * 8 <= lds_room_bytes) {
+        // (at most 32 levels per phase: every trial re-scans the whole run)
+        while (la > 1 && lb - la < 32 && cut(la - 1, lb, trial) && lds_used + lds_doubles(trial) * 8 <= lds_room_bytes) {
             --la;
             std::sort(trial.begin(), trial.end(), [](const Block& x, const Block& y) { return x.cols.size() > y.cols.size(); });
             double cost = 9000.0;
