@@ -65,9 +65,12 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
     // MODE 2: the unsatisfied check on the unweighted values (lib.rs:305-327) for the lanes in `store`.
     auto residual_sweep = [&](const RowRef& xs, const RowRef& dst, bool store, bool log, uint32_t p, int MODE, double& sq, double& mx,
                               double& unsat) {
+        // (the next constraint's record is requested while this one is evaluated: a pad record follows the last)
+        CompRec8 na = comp_load8(prog + a.cons_off), nb = comp_load8(prog + a.cons_off + 8);
         for (uint32_t ci = 0; ci < a.ncons; ++ci) {
-            const CompRec8 ra = comp_load8(prog + a.cons_off + ci * kCompConWords);
-            const CompRec8 rb = comp_load8(prog + a.cons_off + ci * kCompConWords + 8);
+            const CompRec8 ra = na, rb = nb;
+            na = comp_load8(prog + a.cons_off + (ci + 1) * kCompConWords);
+            nb = comp_load8(prog + a.cons_off + (ci + 1) * kCompConWords + 8);
             const DevCon c = comp_make_con(ra, rb, __hiloint2double((int)rb.w[6], (int)rb.w[5]));
             const uint32_t pos = rb.w[7];
             double r0, r1;
@@ -97,9 +100,11 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
     // Jacobian sweep at the accepted values (eval() and accepted steps, newton.rs:121; solver.rs:359-440) for the lanes
     // in `mask`: their J rows, their warnings.
     auto jacobian_sweep = [&](bool mask) {
+        CompRec8 na = comp_load8(prog + a.cons_off), nb = comp_load8(prog + a.cons_off + 8);
         for (uint32_t ci = 0; ci < a.ncons; ++ci) {
-            const CompRec8 ra = comp_load8(prog + a.cons_off + ci * kCompConWords);
-            const CompRec8 rb = comp_load8(prog + a.cons_off + ci * kCompConWords + 8);
+            const CompRec8 ra = na, rb = nb;
+            na = comp_load8(prog + a.cons_off + (ci + 1) * kCompConWords);
+            nb = comp_load8(prog + a.cons_off + (ci + 1) * kCompConWords + 8);
             const DevCon c = comp_make_con(ra, rb, __hiloint2double((int)rb.w[6], (int)rb.w[5]));
             if (mask) {
                 JacWriter<RowRef> w;
