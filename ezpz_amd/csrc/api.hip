@@ -1163,6 +1163,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const bool allow_dense = n_vars <= 8 && n_vars >= 2 && (team_size == 0 || team == 4);
         if (!build_program(cs, n_cs, n_vars, P, be, 1, allow_dense)) return fail();
         const bool dense = P.c.dense != 0;  // granted only when JtJ is mostly full
+        // (16 lanes for one solve -- sweeps and assembly in one round, the first quad factorising -- was measured: `square`
+        // 108 -> 148 us per call, `parallelogram` 57 -> 76: the quads stay)
         if (dense) team = 4;
         // one solve of a system too large for the register solve: a whole wavefront (its levels run as one phase each, the
         // lists shared by groups of lanes, the top of the elimination tree as dense phases)
