@@ -253,7 +253,18 @@ std::string hexf(double v) {
 
 // `lane`: the class is a whole system solved by one lane (jit_kernel.hip.hpp, lane_kernel): constraint parameters and
 // the caller's constraint positions are literals, and load / store / pos_of map the caller's numbering.
+// EZPZ_JIT_FASTDIV (measurements): bit 0 linear classes, bit 1 non-linear classes of the component kernels, bit 2 the
+// lane-per-system kernels get the shared-reciprocal division (jit_kernel.hip.hpp: recip_of / div_by); the others divide plainly.
+unsigned fastdiv_mask() {
+    static const unsigned mask = [] {
+        const char* e = std::getenv("EZPZ_JIT_FASTDIV");
+        return e ? (unsigned)std::atoi(e) : 3u;  // (lane kernels: per-lane reciprocals cost `square` its second wavefront per SIMD, 1148 -> 1008 M solves/s)
+    }();
+    return mask;
+}
+
 void emit_class(std::string& o, size_t k, const Class& cl, bool lane = false, const EzpzConstraint* cs = nullptr) {
+    const bool fastdiv = (fastdiv_mask() >> (lane ? 2 : cl.linear ? 0 : 1)) & 1u;
     const Program& Q = cl.Q;
     const uint32_t nv = Q.c.n_vars, m = Q.c.n_rows, zj = Q.c.zj, zlo = Q.c.zlo, nc = Q.c.n_cons;
     const bool lin = cl.linear;
@@ -280,9 +291,9 @@ void emit_class(std::string& o, size_t k, const Class& cl, bool lane = false, co
     for (uint32_t ci : sweep) {
         const DevCon& d = Q.cons[ci];
         o += "        { const DevCon c = " + con_expr(d, ci) + "; double r0, r1; const bool deg = ezpz::dev::con_residual<LINEAR>(c, x, r0, r1);\n";
-        o += "          const double w0 = c.weight * r0; r[" + S(d.row0) + "] = w0; if (active) { sq += w0 * w0; mx = fmax(mx, fabs(w0)); }\n";
+        o += "          const double w0 = c.weight * r0; r[" + S(d.row0) + "] = w0; if (active) { sq += w0 * w0; mx = ezpz::dev::fmax_abs(mx, w0); }\n";
         if (d.nrows > 1)
-            o += "          const double w1 = c.weight * r1; r[" + S(d.row0 + 1) + "] = w1; if (active) { sq += w1 * w1; mx = fmax(mx, fabs(w1)); }\n";
+            o += "          const double w1 = c.weight * r1; r[" + S(d.row0 + 1) + "] = w1; if (active) { sq += w1 * w1; mx = ezpz::dev::fmax_abs(mx, w1); }\n";
         o += "          if (!LINEAR && deg) wm |= 1ull << " + S(ci) + "; (void)r1; }\n";
     }
     o += "        (void)x; (void)par; (void)r; (void)active; (void)sq; (void)mx; (void)wm;\n    }\n";
@@ -300,50 +311,61 @@ void emit_class(std::string& o, size_t k, const Class& cl, bool lane = false, co
             o += "          if (ezpz::dev::con_jacobian<false>(c, x, w)) wm |= 1ull << " + S(ci) + "; }\n";
         }
     o += "        (void)x; (void)par; (void)J; (void)wm;\n    }\n";
-    // the linear solve (newton.rs:73-102)
-    o += "    static __device__ __forceinline__ bool solve(const double (&J)[" + S(lin ? 1u : std::max(zj, 1u)) + "], const double (&r)[" +
-         S(std::max(m, 1u)) + "], double lambda, double (&d)[" + S(nv) + "], double& dmax) {\n        bool bad = false;\n";
-    auto jv = [&](uint32_t slot) { return lin ? hexf(cl.jconst[slot]) : "J[" + S(slot) + "]"; };
-    for (uint32_t v = 0; v < nv; ++v) {
-        o += "        double D" + S(v) + " = 0.0, V" + S(v) + " = 0.0;\n";
-        for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
-            const std::string j = jv(Q.colj_items[2 * q]);
-            o += "        D" + S(v) + " += " + j + " * " + j + "; V" + S(v) + " += " + j + " * -r[" + S(Q.colj_items[2 * q + 1]) + "];\n";
-        }
-        o += "        D" + S(v) + " = D" + S(v) + " + lambda;\n";
-    }
-    for (uint32_t s2 = 0; s2 < zlo; ++s2) {
-        o += "        double L" + S(s2) + " = 0.0;\n";
-        for (uint32_t q = Q.apair_ptr[s2]; q < Q.apair_ptr[s2 + 1]; ++q)
-            o += "        L" + S(s2) + " += " + jv(Q.apairs[2 * q]) + " * " + jv(Q.apairs[2 * q + 1]) + ";\n";
-    }
-    const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
-    for (uint32_t lv = 0; lv < part.nlev; ++lv) {
-        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
-        const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
-        for (uint32_t v = c0; v < c1; ++v) {
-            for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q) {
-                const std::string l = "L" + S(Q.fwd_items[2 * q]);
-                o += "        D" + S(v) + " -= " + l + " * " + l + "; V" + S(v) + " -= " + l + " * V" + S(Q.fwd_items[2 * q + 1]) + ";\n";
+    // the linear solve (newton.rs:73-102), twice: `solve` divides by a column's diagonal through the column's refined
+    // reciprocal (jit_kernel.hip.hpp: recip_of / div_by -- the tail of the compiler's own division sequence, exact while
+    // no operand needs scaling; `ok` says whether every operand was in that range), `solve_exact` is the same
+    // statements with plain divisions and serves the lanes whose `ok` came back false
+    for (int fast = 1; fast >= 0; --fast) {
+        o += std::string("    static __device__ __forceinline__ bool ") + (fast ? "solve" : "solve_exact") + "(const double (&J)[" +
+             S(lin ? 1u : std::max(zj, 1u)) + "], const double (&r)[" + S(std::max(m, 1u)) + "], double lambda, double (&d)[" + S(nv) +
+             "], double& dmax" + (fast ? ", bool& ok" : "") + ") {\n        bool bad = false;\n";
+        auto div = [&](const std::string& num, uint32_t col) {
+            return fast && fastdiv ? "ezpz::jit::div_by(" + num + ", D" + S(col) + ", Y" + S(col) + ", ok)" : num + " / D" + S(col);
+        };
+        auto jv = [&](uint32_t slot) { return lin ? hexf(cl.jconst[slot]) : "J[" + S(slot) + "]"; };
+        for (uint32_t v = 0; v < nv; ++v) {
+            o += "        double D" + S(v) + " = 0.0, V" + S(v) + " = 0.0;\n";
+            for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
+                const std::string j = jv(Q.colj_items[2 * q]);
+                o += "        D" + S(v) + " += " + j + " * " + j + "; V" + S(v) + " += " + j + " * -r[" + S(Q.colj_items[2 * q + 1]) + "];\n";
             }
-            o += "        if (!(D" + S(v) + " > 0.0)) bad = true;\n";
-            o += "        D" + S(v) + " = sqrt(D" + S(v) + "); V" + S(v) + " = V" + S(v) + " / D" + S(v) + ";\n";
+            o += "        D" + S(v) + " = D" + S(v) + " + lambda;\n";
         }
-        for (uint32_t s2 = s0; s2 < s1; ++s2) {
-            for (uint32_t q = Q.lpair_ptr[s2]; q < Q.lpair_ptr[s2 + 1]; ++q)
-                o += "        L" + S(s2) + " -= L" + S(Q.lpairs[2 * q]) + " * L" + S(Q.lpairs[2 * q + 1]) + ";\n";
-            o += "        L" + S(s2) + " = L" + S(s2) + " / D" + S(Q.l_col[s2]) + ";\n";
+        for (uint32_t s2 = 0; s2 < zlo; ++s2) {
+            o += "        double L" + S(s2) + " = 0.0;\n";
+            for (uint32_t q = Q.apair_ptr[s2]; q < Q.apair_ptr[s2 + 1]; ++q)
+                o += "        L" + S(s2) + " += " + jv(Q.apairs[2 * q]) + " * " + jv(Q.apairs[2 * q + 1]) + ";\n";
         }
+        const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
+        for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+            const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
+            for (uint32_t v = c0; v < c1; ++v) {
+                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q) {
+                    const std::string l = "L" + S(Q.fwd_items[2 * q]);
+                    o += "        D" + S(v) + " -= " + l + " * " + l + "; V" + S(v) + " -= " + l + " * V" + S(Q.fwd_items[2 * q + 1]) + ";\n";
+                }
+                o += "        if (!(D" + S(v) + " > 0.0)) bad = true;\n";
+                o += "        D" + S(v) + " = sqrt(D" + S(v) + ");";
+                if (fast && fastdiv) o += " const double Y" + S(v) + " = ezpz::jit::recip_of(D" + S(v) + ", ok);";
+                o += " V" + S(v) + " = " + div("V" + S(v), v) + ";\n";
+            }
+            for (uint32_t s2 = s0; s2 < s1; ++s2) {
+                for (uint32_t q = Q.lpair_ptr[s2]; q < Q.lpair_ptr[s2 + 1]; ++q)
+                    o += "        L" + S(s2) + " -= L" + S(Q.lpairs[2 * q]) + " * L" + S(Q.lpairs[2 * q + 1]) + ";\n";
+                o += "        L" + S(s2) + " = " + div("L" + S(s2), Q.l_col[s2]) + ";\n";
+            }
+        }
+        for (uint32_t lv = part.nlev; lv-- > 0;) {
+            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+            for (uint32_t v = c0; v < c1; ++v) {
+                for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
+                    o += "        V" + S(v) + " -= L" + S(Q.bwd_items[2 * q]) + " * V" + S(Q.bwd_items[2 * q + 1]) + ";\n";
+                o += "        V" + S(v) + " = " + div("V" + S(v), v) + "; d[" + S(v) + "] = V" + S(v) + "; dmax = ezpz::dev::fmax_abs(dmax, V" + S(v) + ");\n";
+            }
+        }
+        o += std::string("        (void)J; (void)r;") + (fast ? " (void)ok;" : "") + "\n        return bad;\n    }\n";
     }
-    for (uint32_t lv = part.nlev; lv-- > 0;) {
-        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
-        for (uint32_t v = c0; v < c1; ++v) {
-            for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
-                o += "        V" + S(v) + " -= L" + S(Q.bwd_items[2 * q]) + " * V" + S(Q.bwd_items[2 * q + 1]) + ";\n";
-            o += "        V" + S(v) + " = V" + S(v) + " / D" + S(v) + "; d[" + S(v) + "] = V" + S(v) + "; dmax = fmax(dmax, fabs(V" + S(v) + "));\n";
-        }
-    }
-    o += "        (void)J; (void)r;\n        return bad;\n    }\n";
     // unsatisfied check (lib.rs:305-327, :358-370)
     o += "    static __device__ __forceinline__ void unsatisfied(" + xs + ", bool active, double& unsat, uint8_t* mask, const uint32_t* pos) {\n";
     for (uint32_t ci = 0; ci < nc; ++ci) {

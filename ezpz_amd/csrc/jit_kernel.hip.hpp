@@ -128,6 +128,7 @@ struct Slot {
     const uint32_t* pos;                  // the caller's positions of its constraints: pos[ci * STRIDE]
     unsigned long long wmask;             // degenerate evaluations of the speculative residual sweep
     bool active;
+    bool exact;                           // this lane's solve of the current iteration must be repeated with plain divisions
 };
 
 template <class P>
@@ -165,6 +166,48 @@ __device__ __forceinline__ double uniform(double v) {  // a value every lane hol
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// Division by a column's diagonal, shared by every numerator of the column.  The compiler expands `n / D` into
+//   div_scale x 2, y0 = rcp(D), two Newton steps on y, q0 = n * y, e = fma(-D, q0, n), q = div_fmas(e, y, q0), div_fixup
+// -- correctly rounded, 11 instructions, one of them quarter rate.  Everything before q0 depends on D alone whenever
+// div_scale leaves both operands as they are, and div_fmas / div_fixup are then a plain fma and the identity.  recip_of
+// is that denominator part, once per column (and, for a class of linear constraints, once per workgroup: D is a
+// function of lambda there, and the compiler hoists it out of the slots); div_by is the three-instruction tail.  `ok`
+// stays true while every operand was in the range where div_scale does not scale and div_fixup has nothing to fix
+// (V_DIV_SCALE_F64: denominator normal and its reciprocal normal, exponent(n) - exponent(D) in (-1022, 768),
+// exponent(n) > 53); the caller repeats the solve with plain divisions for the lanes where it is false, so results are
+// the correctly rounded quotients -- bit for bit what the interpreters and the oracle compute -- in every case.
+// Zero numerators stay on the short path: with e = fma(D, q0, -n) and q = fma(-e, y, q0) a zero keeps the sign of n
+// (D > 0), as div_fixup would give it.
+__device__ __forceinline__ double recip_of(double D, bool& ok) {
+    ok = ok && (D >= 0x1p-40) && (D <= 0x1p+40);  // (false for NaN: a failed pivot)
+    double y = __builtin_amdgcn_rcp(D);
+    double e = __builtin_fma(-D, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-D, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ double div_by(double n, double D, double y, bool& ok) {
+    const double a = __builtin_fabs(n);
+    ok = ok && !(a > 0x1p+600) && (!(a < 0x1p-900) || n == 0.0);  // (NaN passes: the quotient is NaN either way)
+    const double q0 = n * y;
+    const double e = __builtin_fma(D, q0, -n);
+    return __builtin_fma(-e, y, q0);
+}
+
+// A copy of `a` the optimiser cannot relate to the original: the fallback's inputs.  Without it the sums the two
+// solves have in common (the normal equations) are formed once and kept in registers across the short solve for a
+// fallback that almost never runs (`square`: 228 -> 332 VGPRs, one wavefront per SIMD instead of two).
+template <int N>
+__device__ __forceinline__ void opaque_copy(const double (&a)[N], double (&b)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double v = a[k];
+        asm volatile("" : "+v"(v));
+        b[k] = v;
+    }
+}
+
 // Workgroup reductions with one barrier (the same scheme as CompRed in comp_kernel.hip.hpp).
 struct Red {
     double* buf;  // 2 x 3 x 16 doubles
@@ -191,9 +234,9 @@ struct Red {
                 double v[4];
                 grid_wait4(&grid->arr[par][0][g], &grid->arr[par][1][g], &grid->arr[par][2][g], &grid->arr[par][3][g], seq, &grid->dead, v);
                 a0 = a0 + v[0];
-                a1 = fmax(a1, v[1]);
-                a2 = fmax(a2, v[2]);
-                a3 = fmax(a3, v[3]);
+                a1 = fmax_nc(a1, v[1]);
+                a2 = fmax_nc(a2, v[2]);
+                a3 = fmax_nc(a3, v[3]);
             }
             a0 = reduce_wave_to_last_lane(a0, OpSum());
             a1 = reduce_wave_to_last_lane(a1, OpMax());
@@ -227,6 +270,9 @@ struct Red {
             m3 = uniform(b[3]);
         }
     }
+    // (W: the power of two >= the number of wavefronts, <= 16 -- the fold of the wavefronts' partials stops there; the
+    // lanes beyond hold the identity, so the narrower tree gives the bits of the 16-lane one)
+    template <int W>
     __device__ __forceinline__ void sum_max(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
         s0 = reduce_wave_to_last_lane(s0, OpSum());
@@ -245,13 +291,14 @@ struct Red {
         __syncthreads();
         const bool in = (uint32_t)lane < nwaves;
         const int l = lane & 15;
-        s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
-        m1 = uniform(reduce_lanes<16>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
+        s0 = uniform(reduce_lanes<W>(in ? b[l] : 0.0, OpSum()));
+        m1 = uniform(reduce_lanes<W>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
         if (grid) {
             double m2 = __builtin_nan(""), m3 = __builtin_nan("");
             across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
         }
     }
+    template <int W>
     __device__ __forceinline__ bool step(double& s0, double& m1, double& m2, bool flag, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
         s0 = reduce_wave_to_last_lane(s0, OpSum());
@@ -279,9 +326,9 @@ struct Red {
         __syncthreads();
         const bool in = (uint32_t)lane < nwaves;
         const int l = lane & 15;
-        s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
-        m1 = uniform(reduce_lanes<16>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
-        m2 = uniform(reduce_lanes<16>(in ? b[32 + l] : __builtin_nan(""), OpMax()));
+        s0 = uniform(reduce_lanes<W>(in ? b[l] : 0.0, OpSum()));
+        m1 = uniform(reduce_lanes<W>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
+        m2 = uniform(reduce_lanes<W>(in ? b[32 + l] : __builtin_nan(""), OpMax()));
         bool failed = __builtin_amdgcn_readfirstlane(*f) != 0;
         if (grid) {
             double m3 = failed ? 1.0 : __builtin_nan("");
@@ -331,6 +378,7 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
         red.grid_seq = c0.z > c1.z ? c0.z : c1.z;
     }
     const uint32_t wave_global = grid_wg * NWAVES + wave;
+    constexpr int W = NWAVES <= 2 ? 2 : NWAVES <= 4 ? 4 : NWAVES <= 8 ? 8 : 16;
 
     // ---- this wavefront's slots: what never changes from system to system lives in registers for the whole launch ----
     SEQ seq;
@@ -377,7 +425,12 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
 #pragma unroll
             for (int k = 0; k < C::NV; ++k) s.x[k] = x0[s.ids[k]];
             unsigned long long wm = 0;
-            C::residuals(s.x, s.par, s.r, s.active, sq, mx, wm);
+            double sq_s = sq, mx_s = mx;
+            C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
+            if (s.active) {
+                sq = sq_s;
+                mx = mx_s;
+            }
             if constexpr (!C::LINEAR) {
                 log_mask(s, cls, wm, 0);
                 wm = 0;
@@ -385,7 +438,7 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
                 log_mask(s, cls, wm, 1);
             }
         });
-        red.sum_max(sq, mx, lane, wave, NWAVES);
+        red.template sum_max<W>(sq, mx, lane, wave, NWAVES);
         double residual_sq = sq, largest = mx;
         uint32_t pass = 2;
         double lambda = a.initial_lambda;
@@ -404,23 +457,52 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             double dmax = __builtin_nan("");
             sq = 0.0;
             mx = __builtin_nan("");
+            // Pass 1 -- normal equations, Cholesky, substitutions of every lane's components (newton.rs:73-102), on every lane,
+            // active or not, in one basic block: what depends on lambda alone (all of the factorisation of a linear
+            // class) is formed once for all the slots of the wavefront, and the slots' dependent chains interleave.
+            bool need_exact = false;
             seq.each([&](auto& s, auto* cls, int) {
                 using C = typename class_of<decltype(cls)>::type;
-                // normal equations, Cholesky, substitutions of this lane's component (newton.rs:73-102)
                 double cd = __builtin_nan("");
-                const bool cb = C::solve(s.J, s.r, lambda, s.d, cd);
-                if (s.active) {
-                    lane_bad = lane_bad || cb;
-                    dmax = fmax(dmax, cd);
-                }
-                // residual at the tentative values (newton.rs:111-116), speculative: x moves only after the rendezvous
+                bool ok = true;
+                const bool cb = C::solve(s.J, s.r, lambda, s.d, cd, ok);
+                s.exact = s.active && !ok && !cb;  // an operand outside the short division's range
+                const bool take = s.active && !s.exact;  // (selects, not a branch: the slots stay one basic block)
+                const double dm = fmax_nc(dmax, cd);
+                dmax = take ? dm : dmax;
+                lane_bad = lane_bad || (take && cb);
+                need_exact = need_exact || s.exact;
+            });
+            if (need_exact) {  // (almost never: the same solves with plain divisions for the lanes that asked)
+                seq.each([&](auto& s, auto* cls, int) {
+                    using C = typename class_of<decltype(cls)>::type;
+                    if (s.exact) {
+                        double cd = __builtin_nan("");
+                        double J2[C::ZJS > 0 ? C::ZJS : 1], r2[C::M > 0 ? C::M : 1];
+                        opaque_copy(s.J, J2);
+                        opaque_copy(s.r, r2);
+                        const bool cb = C::solve_exact(J2, r2, lambda, s.d, cd);
+                        lane_bad = lane_bad || cb;
+                        dmax = fmax_nc(dmax, cd);
+                    }
+                });
+            }
+            // Pass 2 -- residual at the tentative values (newton.rs:111-116), speculative: x moves only after the rendezvous.
+            // The sums continue the lane's running values and are taken over by one select per slot.
+            seq.each([&](auto& s, auto* cls, int) {
+                using C = typename class_of<decltype(cls)>::type;
                 double xt[C::NV];
 #pragma unroll
                 for (int k = 0; k < C::NV; ++k) xt[k] = s.x[k] + s.d[k];
                 s.wmask = 0;
-                C::residuals(xt, s.par, s.rn, s.active, sq, mx, s.wmask);
+                double sq_s = sq, mx_s = mx;
+                C::residuals(xt, s.par, s.rn, true, sq_s, mx_s, s.wmask);
+                if (s.active) {
+                    sq = sq_s;
+                    mx = mx_s;
+                }
             });
-            const bool bad = red.step(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
+            const bool bad = red.template step<W>(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
             if (bad) {  // numeric failure anywhere in the system => lambda *= 10, burn the iteration, x untouched
                 lambda *= LM_LAMBDA_INCR;
                 ++it;
@@ -490,7 +572,7 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
         });
         if (!all_satisfied || ANY_NONLINEAR) {
             double none = __builtin_nan("");
-            red.sum_max(unsat_cnt, none, lane, wave, NWAVES);
+            red.template sum_max<W>(unsat_cnt, none, lane, wave, NWAVES);
         }
         if (tid == 0 && grid_wg == 0) {
             EzpzStatus st;
@@ -597,7 +679,19 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
                 fresh = false;
             }
             double d[NV], dmax = __builtin_nan("");
-            const bool bad = C::solve(J, r, lambda, d, dmax);
+            bool ok = true;
+            bool bad = C::solve(J, r, lambda, d, dmax, ok);
+            if (!ok && !bad) {  // an operand outside the short division's range: plain divisions for this lane
+                dmax = __builtin_nan("");
+                double J2[ZJ], x2[NV], r2[M];  // (the Jacobian evaluated again rather than kept alive across the short solve)
+                opaque_copy(xj, x2);
+                opaque_copy(r, r2);
+                if constexpr (!C::LINEAR) {
+                    unsigned long long wm = 0;
+                    C::jacobian(x2, par, J2, wm);
+                }
+                bad = C::solve_exact(J2, r2, lambda, d, dmax);
+            }
             if (bad) {  // LltError::Numeric: lambda *= 10, burn the iteration (newton.rs:93-99)
                 lambda *= LM_LAMBDA_INCR;
                 ++it;

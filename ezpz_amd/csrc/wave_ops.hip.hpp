@@ -16,8 +16,23 @@ struct OpSum {
     __device__ __forceinline__ double operator()(double a, double b) const { return a + b; }
     __device__ __forceinline__ double identity() const { return 0.0; }
 };
+// fmax as ONE instruction.  The compiler's fmax is v_max_f64 behind a canonicalisation (v_max_f64 x, x, x) of every
+// operand it cannot prove free of signalling NaNs -- anything that came through a select, a DPP move or a load -- i.e.
+// three instructions per maximum in the reductions and accumulators of the LM control.  v_max_f64 itself ignores a
+// quiet NaN operand like libm's fmax (newton.rs:53,:108), and nothing here is a signalling NaN: every operand is the
+// result of arithmetic or the quiet NaN that starts a maximum.  fmax_abs is fmax(a, |b|).
+__device__ __forceinline__ double fmax_nc(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double fmax_abs(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 struct OpMax {  // libm::fmax (NaN-ignoring), newton.rs:53,:108
-    __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); }
+    __device__ __forceinline__ double operator()(double a, double b) const { return fmax_nc(a, b); }
     __device__ __forceinline__ double identity() const { return __builtin_nan(""); }  // dropped by fmax
 };
 
@@ -75,19 +90,21 @@ __device__ __forceinline__ double reduce_lanes(double v, Op op) {
 // wave-level DPP broadcasts of GFX9 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lanes the
 // row mask leaves out keep the operator's identity, so one unconditional op() per step serves every lane.  Same
 // pairing as the xor shuffles ((r0 + r1) + (r2 + r3)), so the same bits.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_move_rows(double v, double keep) {
+// (Only the last lane's value is meaningful afterwards: the broadcasts go to every row that has a source -- row 1 takes
+// r0, row 2 r1, row 3 r2, then rows 2 and 3 take lane 31 = r1 + r0 -- instead of to rows 1 / 3 and 2 / 3 only with the
+// operator's identity materialised for the others; rows without a source read zero, and their lanes are not read.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_rows(double v) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned long long o = __builtin_bit_cast(unsigned long long, keep);
-    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 template <class Op>
 __device__ __forceinline__ double reduce_wave_to_last_lane(double v, Op op) {
     v = reduce_lanes<16>(v, op);
-    v = op(v, dpp_move_rows<0x142, 0xA>(v, op.identity()));  // row_bcast:15
-    v = op(v, dpp_move_rows<0x143, 0xC>(v, op.identity()));  // row_bcast:31
+    v = op(v, dpp_move_rows<0x142>(v));  // row_bcast:15: lane 63 = r3 + r2, lane 31 = r1 + r0
+    v = op(v, dpp_move_rows<0x143>(v));  // row_bcast:31: lane 63 = (r3 + r2) + (r1 + r0)
     return v;
 }
 
