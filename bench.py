@@ -9,11 +9,17 @@ exits non-zero when the node has fewer than N devices.  It never reports fewer G
   metric   solves/sec on the 2000-row massive_parallel_system (BASELINE.json), plus iters-to-converge
   step     one launch of the LM kernel over a batch of `--batch` independent replicas of the workload system
            (jittered initial guesses), inputs already resident in HBM
+  warm-up  W launches, then launches in windows of 20 until two consecutive windows agree within 2 % (or 0.3 s have
+           passed): the first ~30 launches of a process run slower (clocks, first touch), and the timed region must not
+           depend on how many the caller asked for.  `warmup_launches_run` says how many ran in all.
   value    whole-job solves/s = N * batch * K / max-over-ranks wall time of the K timed steps, device-resident
            guesses in, device-resident results out (`config.value_is`).  `value_host_to_host` is the same batch
            through the host-pointer entry point (SURVEY.md 8d's "results back on host": H2D + kernel + D2H).
   scaling  weak: every rank owns its own shard of `--batch` systems; the path has no data-path collective
            (systems are independent), so none is issued inside the timed region
+  configs  after the headline, short legs (a few launches each, outside `value`) over the other BASELINE.json
+           configurations -- `square` x 65 536, the 1 M mixed batch, the 200 000-variable ladder, and a batch of one
+           connected 300-variable sketch -- each with its rate, iterations, an oracle check and its roofs
   roofline three roofs, the highest fraction is `bound`:
              hbm    compulsory bytes (x0 in, x* + status out: 16 n + 32 per solve) x solves/s against 8 TB/s; `traffic`
                     is what the PMC counters saw per launch in THIS run (FETCH_SIZE doubled per the gfx950 note of
@@ -31,6 +37,7 @@ import argparse
 import csv
 import glob
 import json
+import math
 import os
 import shutil
 import socket
@@ -42,12 +49,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from ezpz_amd.synthetic import keyed_uniform, make_workload  # noqa: E402  (re-exported: tests build workloads through bench)
 
 METRIC = "solves/sec on 2000-row massive_parallel_system @1/2/4/8 GPU; iters-to-converge"
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # HBM3E peak BW 8.0 TB/s (spec)
-N_CUS, N_SIMDS = 256, 1024
 PMC_SETS = [
     ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
      "SQ_INSTS_VALU", "SQ_INSTS_SALU"],
@@ -57,6 +64,9 @@ PMC_SETS = [
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
 ]
 SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel", "ezpz_jit_solve", "ezpz_jit_lane", "batch_lane_kernel")
+# The other BASELINE.json configurations, as (workload, systems per launch at N = 1): configs[2], [4], [3], and the
+# connected-sketch batch of DESIGN.md section 3.  Short legs after the headline; the mixed batch is sharded over the ranks.
+LEGS = [("square", 65536), ("mixed", 1 << 20), ("massive50000", 64), ("sketch150", 262144)]
 
 
 def algorithmic_bytes(info: dict, k: int) -> int:
@@ -64,53 +74,6 @@ def algorithmic_bytes(info: dict, k: int) -> int:
     C, n, m = info["n_constraints"], info["n_vars"], info["n_rows"]
     zj, za, zl = info["nnz_j"], info["nnz_a"], info["nnz_l"]
     return (1 + k) * (56 * C + 8 * n + 8 * m + 8 * zj) + k * (12 * zj + 8 * m + 16 * za + 24 * zl + 48 * n)
-
-
-def make_workload(name: str):
-    """Returns (description, side-resolved constraint records, file guesses, jitter amplitude, expected iterations or
-    None).  Built with the product's own front end (ezpz_amd.textual); nothing here touches oracle/."""
-    import ezpz_amd as E
-
-    if name.startswith("massive"):
-        over = name.endswith("o")  # gen_big_problem.py <lines> true: one distance per line on top (5 rows per line, non-linear)
-        lines = int(name[len("massive"):].rstrip("o") or 500)
-        cs = E.textual.Problem.from_str(E.textual.gen_big_problem(lines, over)).to_constraint_system()
-        rows = (5 if over else 4) * lines
-        return (f"massive_parallel_system gen_big_problem.py {lines}{' true' if over else ''} ({rows} rows x {4 * lines} vars)",
-                cs.records, cs.guesses, 0.25, None if over else 2)
-    if name.startswith("sketch"):
-        # one connected, fully determined sketch of mixed kinds: every point tied to its predecessors by two scalar
-        # conditions consistent with a hidden layout (the generator of tests/gen.py:connected_sketch, same random stream,
-        # on the product's own constructors)
-        import numpy as np
-        from ezpz_amd.api import DISTANCE, FIXED, HORIZONTAL_DISTANCE, VERTICAL_DISTANCE, _rec, stack_records
-
-        npts = int(name[len("sketch"):] or 150)
-        rng = np.random.default_rng(1000 + npts)
-        pt = lambda i: [2 * i, 2 * i + 1]
-        dist = lambda i, j: _rec(DISTANCE, pt(i) + pt(j), float(np.hypot(*(true[i] - true[j]))))
-        hd = lambda i, j: _rec(HORIZONTAL_DISTANCE, pt(i) + pt(j), float(true[i][0] - true[j][0]))
-        vd = lambda i, j: _rec(VERTICAL_DISTANCE, pt(i) + pt(j), float(true[i][1] - true[j][1]))
-        cons, true = [_rec(FIXED, [0], 0.0), _rec(FIXED, [1], 0.0)], [np.zeros(2)]
-        for i in range(1, npts):
-            true.append(true[-1] + rng.uniform(0.5, 2.0, 2) * rng.choice([-1.0, 1.0], 2))
-            a, b = i - 1, max(0, i - int(rng.integers(2, 4)))
-            choice = int(rng.integers(0, 5))
-            if choice == 0:
-                cons += [hd(i, a), vd(i, a)]
-            elif choice == 1:
-                cons += [dist(i, a), dist(i, b) if b != a else hd(i, a)]
-            elif choice == 2:
-                cons += [dist(i, a), vd(i, a)]
-            elif choice == 3:
-                cons += [_rec(FIXED, [2 * i], float(true[i][0])), dist(i, a)]
-            else:
-                cons += [hd(i, b), dist(i, a)]
-        guesses = np.concatenate(true) + rng.uniform(-0.05, 0.05, 2 * npts)
-        return f"one connected sketch of {npts} points ({2 * npts} rows x {2 * npts} vars)", stack_records(cons), guesses, 0.02, None
-    path = os.path.join(ROOT, "tests", "golden", "test_cases", name, "problem.md")
-    cs = E.textual.Problem.from_str(open(path).read()).to_constraint_system()
-    return f"test_cases/{name} ({cs.num_vars} vars)", E.resolve_sides(cs.records, cs.guesses), cs.guesses, 0.1, None
 
 
 def cpu_baseline(records, guesses, budget_s: float):
@@ -152,6 +115,7 @@ def parse_args(argv=None):
                     "for N>1, the rate with the RCCL scatter/gather of the batch) -- never part of `value`")
     ap.add_argument("--specialize", type=int, default=1, help="use the run-time compiled class-specialised kernel where the topology has one")
     ap.add_argument("--pmc", type=int, default=1, help="N=1: collect the roofline's PMC counters with rocprofv3 child passes of this script")
+    ap.add_argument("--legs", type=int, default=1, help="after the headline, short legs over the other BASELINE.json configurations (`configs` in the line)")
     return ap.parse_args(argv)
 
 
@@ -215,23 +179,25 @@ def dry_run(args, world, rank) -> int:
     return 0
 
 
-def collect_pmc(args) -> dict:
+def collect_pmc(args, workload=None, batch=None, sets=None) -> dict:
     """Per-launch means of the PMC counters of the solve kernel, from rocprofv3 child passes of this script with the
-    same workload (one counter set per pass; the profiler's child is `python3 bench.py ...` itself)."""
+    same workload (one counter set per pass; the profiler's child is this interpreter running bench.py itself)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
     base = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else tempfile.gettempdir()
     outdir = tempfile.mkdtemp(prefix="bench_pmc_", dir=base)
     env = dict(os.environ, TMPDIR="/tmp")
-    child = ["python3", os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch), "--team", str(args.team),
-             "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--check", "0", "--extras", "0", "--pmc", "0", "--specialize", str(args.specialize)]
+    # the interpreter that runs this script (a plain ELF placed directly after `--`: no env / shim hop under the profiler)
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--workload", workload or args.workload,
+             "--batch", str(batch or args.batch), "--team", str(args.team), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
+             "--check", "0", "--extras", "0", "--pmc", "0", "--legs", "0", "--specialize", str(args.specialize)]
     counters, errors = {}, []
-    for i, cset in enumerate(PMC_SETS):
+    for i, cset in enumerate(sets or PMC_SETS):
         d = os.path.join(outdir, f"set{i}")
         try:
             subprocess.run([exe, "--pmc"] + cset + ["--output-format", "csv", "-d", d, "--"] + child, env=env, cwd="/tmp",
-                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, check=True)
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300, check=True)
         except (subprocess.SubprocessError, OSError) as exc:
             errors.append(f"set{i}: {type(exc).__name__}: {str(getattr(exc, 'stderr', b'') or exc)[-200:]}")
             continue
@@ -248,12 +214,15 @@ def collect_pmc(args) -> dict:
     shutil.rmtree(outdir, ignore_errors=True)
     if errors:
         counters["errors"] = errors
+        print("bench.py: PMC pass failed: " + "; ".join(errors), file=sys.stderr)
     return counters
 
 
-def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels):
-    """The three roofs (module docstring).  `pmc` = per-launch counter means or {} / {"error": ...}."""
+def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels, n_cus):
+    """The three roofs (module docstring).  `pmc` = per-launch counter means or {} / {"error": ...}; `n_cus` = compute
+    units of the device the kernel ran on (4 SIMDs each)."""
     t = kernel_ms * 1e-3
+    n_simds = 4 * n_cus
     compulsory = sum((16 * p["info"]["n_vars"] + 32) * p["B"] for p in info_parts)  # bytes per launch
     hbm = {"achieved": compulsory / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "compulsory_bytes_per_solve": compulsory / B}
@@ -273,22 +242,21 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels):
         hbm["measured_gbs"] = traffic / t / 1e9
     cycles = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
     if cycles > 0 and "SQ_LDS_IDX_ACTIVE" in pmc:
-        roofs["lds"] = {"achieved": pmc["SQ_LDS_IDX_ACTIVE"], "peak": N_CUS * cycles, "unit": "LDS-array cycles per launch",
-                        "frac": pmc["SQ_LDS_IDX_ACTIVE"] / (N_CUS * cycles),
+        roofs["lds"] = {"achieved": pmc["SQ_LDS_IDX_ACTIVE"], "peak": n_cus * cycles, "unit": "LDS-array cycles per launch",
+                        "frac": pmc["SQ_LDS_IDX_ACTIVE"] / (n_cus * cycles),
                         "lds_insts_per_solve": pmc.get("SQ_INSTS_LDS", 0.0) / B,
                         "bank_conflict_frac": pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(pmc["SQ_LDS_IDX_ACTIVE"], 1.0)}
     if cycles > 0 and "SQ_ACTIVE_INST_VALU" in pmc:
-        roofs["issue"] = {"achieved": 4.0 * pmc["SQ_ACTIVE_INST_VALU"], "peak": N_SIMDS * cycles,
-                          "unit": "vector-ALU busy cycles per launch", "frac": 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (N_SIMDS * cycles),
-                          "valu_insts_per_solve": pmc.get("SQ_INSTS_VALU", 0.0) / B,
-                          "salu_insts_per_solve": pmc.get("SQ_INSTS_SALU", 0.0) / B,
-                          "wave_cycles_waiting_frac": pmc.get("SQ_WAIT_ANY", 0.0) / max(pmc.get("SQ_WAVE_CYCLES", 0.0), 1.0),
+        roofs["issue"] = {"achieved": 4.0 * pmc["SQ_ACTIVE_INST_VALU"], "peak": n_simds * cycles,
+                          "unit": "vector-ALU busy cycles per launch", "frac": 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (n_simds * cycles),
                           "kernel_cycles": cycles}
+        if "SQ_INSTS_VALU" in pmc:
+            roofs["issue"].update({"valu_insts_per_solve": pmc["SQ_INSTS_VALU"] / B, "salu_insts_per_solve": pmc.get("SQ_INSTS_SALU", 0.0) / B,
+                                   "wave_cycles_waiting_frac": pmc.get("SQ_WAIT_ANY", 0.0) / max(pmc.get("SQ_WAVE_CYCLES", 0.0), 1.0)})
     bound = max(roofs, key=lambda k: roofs[k]["frac"])
     top = roofs[bound]
-    assert all(r["frac"] <= 1.0 + 1e-9 for r in roofs.values()), roofs  # every roof is a bound
     algo = solves_per_launch_iters / t / 1e9
-    return {
+    out = {
         "bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
         "traffic": traffic,
         "roofs_measured": sorted(roofs),  # without PMC counters (--pmc 0, N>1) only the HBM roof is known
@@ -302,6 +270,164 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels):
         "kernel_ms": kernel_ms,
         "solves_per_launch": B,
     }
+    # every roof is meant to be a bound; one above 1 (a partitioned device whose counters cover another CU count, a
+    # traffic model served from cache) is reported, not asserted: the line must come out either way
+    over = sorted(k for k, r in roofs.items() if r["frac"] > 1.0 + 1e-9)
+    if over:
+        out["roof_violation"] = over
+    return out
+
+
+class Workload:
+    """One workload resident on this rank's device: systems (one per topology), jittered guesses in HBM, outputs."""
+
+    def __init__(self, E, torch, name, batch, device_index, dev, team, specialize, seed_rank):
+        # BASELINE configs[4] flavour: system i uses [circle_tangent, parallelogram, arc_radius][i mod 3]; the batch is
+        # grouped by topology (one launch per topology per step).  Everything else is a single-topology batch.
+        names = ["circle_tangent", "parallelogram", "arc_radius"] if name == "mixed" else [name]
+        self.E, self.torch, self.dev, self.batch = E, torch, dev, batch
+        self.stream = torch.cuda.current_stream(dev)
+        self.parts = []
+        for k, nm in enumerate(names):
+            desc, records, guesses, jitter, expect = make_workload(nm)
+            n = len(guesses)
+            B = batch // len(names) + (1 if k < batch % len(names) else 0)
+            system = E.System(records, n, device=device_index, team_size=team)
+            # component-resident systems: the class-specialised kernel (run-time compiled once per topology, outside the
+            # timed region like the symbolic phase; batch calls would start it themselves in the background)
+            spec = system.specialize(wait=True) == 2 if specialize else False
+            # synthetic inputs: replicas of the system with keyed-PRNG jitter on the guesses, resident in HBM
+            x0_host = guesses[None, :] + keyed_uniform(0x657A707A + seed_rank + 101 * k, B, n, -jitter, jitter)
+            x0_host[0] = guesses
+            x0 = torch.from_numpy(x0_host).to(dev)
+            self.parts.append(dict(desc=desc, records=records, guesses=guesses, jitter=jitter, expect=expect, n=n, B=B,
+                                   system=system, info=system.info(), specialized=spec, x0_host=x0_host, x0=x0,
+                                   x_out=torch.empty_like(x0), status=torch.zeros((B, 32), dtype=torch.uint8, device=dev)))
+        self.desc = self.parts[0]["desc"] if len(self.parts) == 1 else "mixed: " + " + ".join(p["desc"] for p in self.parts)
+
+    def step(self):
+        for p in self.parts:
+            p["system"].solve_batch_device(p["x0"].data_ptr(), p["B"], p["x_out"].data_ptr(), p["status"].data_ptr(), 0,
+                                           self.stream.cuda_stream)
+
+    def _window(self, launches):
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(self.stream)
+        for _ in range(launches):
+            self.step()
+        ev1.record(self.stream)
+        torch.cuda.synchronize(self.dev)
+        return ev0.elapsed_time(ev1) / launches
+
+    def warm_to_steady_state(self, at_least):
+        """`at_least` launches, then windows of 20 launches (fewer when a launch takes milliseconds) until two consecutive
+        windows agree within 2 % or 0.3 s have passed.  Returns the launches run."""
+        for _ in range(at_least):
+            self.step()
+        self.torch.cuda.synchronize(self.dev)
+        ran, t0 = at_least, time.perf_counter()
+        first = self._window(1)
+        ran += 1
+        window = int(min(20, max(2, math.ceil(20.0 / max(first, 1e-3)))))  # ~20 ms of launches, 20 at most
+        prev = None
+        while True:
+            ms = self._window(window)
+            ran += window
+            if prev is not None and abs(ms - prev) <= 0.02 * prev:
+                break
+            if time.perf_counter() - t0 >= 0.3:
+                break
+            prev = ms
+        return ran
+
+    def statuses(self):
+        import numpy as np
+
+        return np.concatenate([p["status"].cpu().numpy().view(self.E.STATUS_DTYPE).reshape(-1) for p in self.parts])
+
+    def oracle_check(self, per_part=16):
+        """Coordinates the constraints determine must match at 1e-6 (BASELINE north_star); coordinates the system's own
+        FreedomAnalysis reports as underconstrained are held only by lambda ~ 1e-9..1e-12 and are compared at the
+        oracle's sensitivity there.  The oracle is the checker, outside every timed region."""
+        import numpy as np
+        from oracle import oracle as O
+
+        torch = self.torch
+        err, err_free, it_equal, n_checked, bitwise = 0.0, 0.0, True, 0, True
+        for p in self.parts:
+            Bp = p["B"]
+            sample = np.arange(0, Bp, max(1, Bp // per_part))[:per_part]
+            rc, xo, it, conv, nun = O.solve_batch(p["records"], p["x0_host"][sample], linsolve=O.LINSOLVE_SPARSE)
+            xg = p["x_out"][torch.from_numpy(sample).to(self.dev)].cpu().numpy()
+            stp = p["status"].cpu().numpy().view(self.E.STATUS_DTYPE).reshape(-1)
+            rel = np.abs(xg - xo) / np.maximum(1.0, np.abs(xo))
+            free = p["system"].freedom_batch(xg)[0].astype(bool)[:, : xg.shape[1]]
+            err = max(err, float(np.max(np.where(free, 0.0, rel))))
+            err_free = max(err_free, float(np.max(np.where(free, rel, 0.0))))
+            it_equal = it_equal and bool(np.array_equal(stp["iterations"][sample], it))
+            bitwise = bitwise and bool(np.array_equal(xg, xo))
+            n_checked += len(sample)
+        return {"systems": int(n_checked), "max_rel_err": err, "max_rel_err_underconstrained": err_free,
+                "iterations_equal": it_equal, "bitwise_equal": bitwise}
+
+    def algorithmic_launch_bytes(self):
+        import numpy as np
+
+        total = 0
+        for p in self.parts:
+            stp = p["status"].cpu().numpy().view(self.E.STATUS_DTYPE).reshape(-1)
+            total += algorithmic_bytes(p["info"], int(round(float(np.mean(stp["iterations"]))))) * p["B"]
+        return total
+
+
+def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, backend, n_cus):
+    """One short leg over another BASELINE configuration: steady-state warm-up, a few timed launches bracketed like the
+    headline's (barrier + synchronize, max over ranks), iterations, oracle check, roofs (hbm always; issue from one PMC
+    pass at N = 1)."""
+    import numpy as np
+
+    w = Workload(E, torch, name, batch, device_index, dev, args.team, args.specialize, rank)
+    ran = w.warm_to_steady_state(2)
+    one = w._window(1)
+    steps = int(min(200, max(5, math.ceil(50.0 / max(one, 1e-3)))))  # ~50 ms of launches
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(w.stream)
+    for _ in range(steps):
+        w.step()
+    ev1.record(w.stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / steps
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+    st = w.statuses()
+    iters = np.unique(st["iterations"]).tolist()
+    ok = bool(np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0))
+    out = {"workload": w.desc, "systems_per_launch_per_gpu": batch, "value": world * batch * steps / elapsed, "unit": "solves/s",
+           "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup_launches_run": ran,
+           "iters": iters if len(iters) <= 8 else {"min": int(min(iters)), "max": int(max(iters)), "mean": float(np.mean(st["iterations"]))},
+           "class_specialised_kernel": [bool(p["specialized"]) for p in w.parts] if len(w.parts) > 1 else bool(w.parts[0]["specialized"])}
+    if rank == 0:
+        if args.check:
+            out["oracle_check"] = w.oracle_check(per_part=8)
+            ok = ok and out["oracle_check"]["max_rel_err"] <= 1e-6 and out["oracle_check"]["iterations_equal"]
+        pmc = collect_pmc(args, workload=name, batch=batch, sets=[PMC_SETS[1]]) if (args.pmc and world == 1) else {}
+        r = roofline(w.parts, batch, kernel_ms, w.algorithmic_launch_bytes(), pmc, len(w.parts), n_cus)
+        out["roofline"] = {"bound": r["bound"], "frac": r["frac"], "kernel_ms": kernel_ms,
+                           "roofs": {k: v["frac"] for k, v in r["roofs"].items()}}
+        if "roof_violation" in r:
+            out["roofline"]["roof_violation"] = r["roof_violation"]
+    out["results_ok"] = ok
+    return out
 
 
 def main():
@@ -321,78 +447,55 @@ def main():
     import torch.distributed as dist
 
     import ezpz_amd as E
-    import gen
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # Test hook (1-GPU boxes): EZPZ_BENCH_BACKEND=gloo runs the N>1 code path -- rendezvous, barriers, max-over-ranks
-    # timing, rank-0 line -- with every rank on GPU (LOCAL_RANK mod device count).  The driver never sets it.
+    # Test hooks (1-GPU boxes; the driver never sets them).  EZPZ_BENCH_BACKEND=gloo runs the N>1 code path --
+    # rendezvous, barriers, max-over-ranks timing, rank-0 line -- with every rank on GPU (LOCAL_RANK mod device count).
+    # EZPZ_BENCH_FORCE_DIST=1 takes every N>1 branch at world size 1: the RCCL process group on the device, barriers,
+    # the all-reduces on device tensors, the scatter / gather extra.
     backend = os.environ.get("EZPZ_BENCH_BACKEND", "nccl")
+    distributed = world > 1 or os.environ.get("EZPZ_BENCH_FORCE_DIST") == "1"
     if backend == "nccl" and torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but only {torch.cuda.device_count()} HIP device(s) visible")
     device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
-    if world > 1:
+    n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    # BASELINE configs[4] flavour: system i uses [circle_tangent, parallelogram, arc_radius][i mod 3]; the batch is
-    # grouped by topology (one launch per topology per step).  Everything else is a single-topology batch.
-    names = ["circle_tangent", "parallelogram", "arc_radius"] if args.workload == "mixed" else [args.workload]
-    stream = torch.cuda.current_stream(dev)
-    parts = []
-    for k, name in enumerate(names):
-        desc_k, records_k, guesses_k, jitter_k, expect_k = make_workload(name)
-        n_k = len(guesses_k)
-        B_k = args.batch // len(names) + (1 if k < args.batch % len(names) else 0)
-        system_k = E.System(records_k, n_k, device=device_index, team_size=args.team)
-        # component-resident systems: the class-specialised kernel (run-time compiled once per topology, outside the
-        # timed region like the symbolic phase; batch calls would start it themselves in the background)
-        spec_k = system_k.specialize(wait=True) == 2 if args.specialize else False
-        # synthetic inputs: replicas of the system with keyed-PRNG jitter on the guesses, resident in HBM
-        x0_host_k = guesses_k[None, :] + gen.keyed_uniform(0x657A707A + rank + 101 * k, B_k, n_k, -jitter_k, jitter_k)
-        x0_host_k[0] = guesses_k
-        x0_k = torch.from_numpy(x0_host_k).to(dev)
-        parts.append(dict(desc=desc_k, records=records_k, guesses=guesses_k, jitter=jitter_k, expect=expect_k, n=n_k,
-                          B=B_k, system=system_k, info=system_k.info(), specialized=spec_k, x0_host=x0_host_k, x0=x0_k,
-                          x_out=torch.empty_like(x0_k), status=torch.zeros((B_k, 32), dtype=torch.uint8, device=dev)))
-    # the single-topology names used below refer to the first (usually only) part
+    w = Workload(E, torch, args.workload, args.batch, device_index, dev, args.team, args.specialize, rank)
+    parts, stream, B = w.parts, w.stream, args.batch
     p0 = parts[0]
-    desc, records, guesses, jitter, expect_iters = p0["desc"], p0["records"], p0["guesses"], p0["jitter"], p0["expect"]
-    n, system, info, B = p0["n"], p0["system"], p0["info"], args.batch
-    x0_host, x0, x_out, status = p0["x0_host"], p0["x0"], p0["x_out"], p0["status"]
-    if len(parts) > 1:
-        desc = "mixed: " + " + ".join(p["desc"] for p in parts)
+    desc, records, guesses, jitter, expect_iters = w.desc, p0["records"], p0["guesses"], p0["jitter"], p0["expect"]
+    n, system, info = p0["n"], p0["system"], p0["info"]
+    x0_host, x0, x_out = p0["x0_host"], p0["x0"], p0["x_out"]
 
-    def step():
-        for p in parts:
-            p["system"].solve_batch_device(p["x0"].data_ptr(), p["B"], p["x_out"].data_ptr(), p["status"].data_ptr(), 0,
-                                           stream.cuda_stream)
-
-    for _ in range(args.warmup):
-        step()
+    warmup_ran = w.warm_to_steady_state(args.warmup)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if distributed:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        step()
+        w.step()
     ev1.record(stream)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if distributed:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # one kernel per step, back to back on this stream
     world_seen = 1
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed, kernel_ms, 1.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t[:2], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[2:], op=dist.ReduceOp.SUM)
@@ -479,14 +582,16 @@ def main():
             extras["freedom_analyses_per_s"] = 5 * Bf / (time.perf_counter() - tf)
             extras["underconstrained_systems"] = int((fa_cnt > 0).sum().item())
         # (3) N>1: whole batch starts and ends on rank 0; one RCCL scatter + one gather around the solve
-        if world > 1 and backend == "nccl":
+        if distributed and backend == "nccl" and len(parts) == 1:
             from ezpz_amd.distributed import solve_batch_sharded
 
             try:  # an extra: a failure here must not cost the run its headline line
                 full = torch.cat([x0] * world, dim=0) if rank == 0 else None
-                solve_batch_sharded(system, full, n, device=dev)
+                xs, sts = solve_batch_sharded(system, full, n, device=dev)
                 torch.cuda.synchronize(dev)
                 dist.barrier()
+                if rank == 0:  # the sharded results are the device path's, bit for bit (replicas of this rank's batch)
+                    extras["rccl_scatter_gather_equals_device_path"] = bool(torch.equal(xs[:B], x_out) and torch.equal(xs[-B:], x_out))
                 te = time.perf_counter()
                 reps = max(1, min(args.steps, 10))
                 for _ in range(reps):
@@ -497,41 +602,31 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 extras["with_rccl_scatter_gather_error"] = repr(exc)[:200]
 
-    st = np.concatenate([p["status"].cpu().numpy().view(E.STATUS_DTYPE).reshape(-1) for p in parts])
+    st = w.statuses()
     iters = np.unique(st["iterations"]).tolist()
     ok = bool(np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0))
     if expect_iters is not None:
         ok = ok and iters == [expect_iters]
     checked = None
     if args.check and rank == 0:
-        from oracle import oracle as O  # the checker (test infrastructure), outside every timed region
+        checked = w.oracle_check()
+        ok = ok and checked["max_rel_err"] <= 1e-6 and checked["max_rel_err_underconstrained"] <= 1e-3 and checked["iterations_equal"]
 
-        # coordinates the constraints determine must match at 1e-6 (BASELINE north_star); coordinates the system's own
-        # FreedomAnalysis reports as underconstrained are held only by lambda ~ 1e-9..1e-12 and are compared at the
-        # oracle's sensitivity there
-        err, err_free, it_equal, n_checked, bitwise = 0.0, 0.0, True, 0, True
-        for p in parts:
-            Bp = p["B"]
-            sample = np.arange(0, Bp, max(1, Bp // 16))[:16]
-            rc, xo, it, conv, nun = O.solve_batch(p["records"], p["x0_host"][sample], linsolve=O.LINSOLVE_SPARSE)
-            xg = p["x_out"][torch.from_numpy(sample).to(dev)].cpu().numpy()
-            stp = p["status"].cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
-            rel = np.abs(xg - xo) / np.maximum(1.0, np.abs(xo))
-            free = p["system"].freedom_batch(xg)[0].astype(bool)[:, : xg.shape[1]]
-            err = max(err, float(np.max(np.where(free, 0.0, rel))))
-            err_free = max(err_free, float(np.max(np.where(free, rel, 0.0))))
-            it_equal = it_equal and bool(np.array_equal(stp["iterations"][sample], it))
-            bitwise = bitwise and bool(np.array_equal(xg, xo))
-            n_checked += len(sample)
-        checked = {"systems": int(n_checked), "max_rel_err": err, "max_rel_err_underconstrained": err_free,
-                   "iterations_equal": it_equal, "bitwise_equal": bitwise}
-        ok = ok and err <= 1e-6 and err_free <= 1e-3 and checked["iterations_equal"]
+    # the other BASELINE configurations (outside `value`): every rank takes part in a leg's barriers; at N > 1 only the
+    # mixed batch -- BASELINE configs[4], "batch-sharded across 8 x MI355X" -- runs, split over the ranks
+    legs = []
+    if args.legs and args.workload == "massive500":
+        for name, lb in LEGS:
+            if world > 1 and name != "mixed":
+                continue
+            try:
+                # (the headline's tensors are small; a leg's go away with its Workload)
+                legs.append(run_leg(E, torch, dist, args, name, lb // world, world, rank, device_index, dev, backend, n_cus))
+            except Exception as exc:  # noqa: BLE001  (a leg must not cost the run its headline)
+                legs.append({"workload": name, "error": repr(exc)[:300]})
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        launch_bytes = 0
-        for p in parts:
-            stp = p["status"].cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
-            launch_bytes += algorithmic_bytes(p["info"], int(round(float(np.mean(stp["iterations"]))))) * p["B"]
         pmc = collect_pmc(args) if (args.pmc and world == 1) else {}
         line = {
             "metric": METRIC,
@@ -540,6 +635,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_launches_run": warmup_ran,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -563,20 +659,23 @@ def main():
                 "class_specialised_kernel": [bool(p["specialized"]) for p in parts] if len(parts) > 1 else bool(p0["specialized"]),
                 "parallelism": f"batch-sharded x{world}, no collective on the data path",
                 "inputs": "resident in HBM; guesses = file guesses + keyed U(-%.2f,%.2f)" % (jitter, jitter),
+                "compute_units": n_cus,
             },
-            "roofline": roofline(parts, B, kernel_ms, launch_bytes, pmc, len(parts)),
+            "roofline": roofline(parts, B, kernel_ms, w.algorithmic_launch_bytes(), pmc, len(parts), n_cus),
         }
         if pmc:
             line["pmc_per_launch"] = {k: v for k, v in pmc.items() if not k.startswith("_")}
         if checked:
             line["oracle_check"] = checked
+        if legs:
+            line["configs"] = legs
         if extras:
             line["extras"] = extras
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(records, guesses, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

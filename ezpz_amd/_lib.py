@@ -59,6 +59,8 @@ EXPORTS = [
     "ezpz_host_register",
     "ezpz_host_unregister",
     "ezpz_specialized_source",
+    "ezpz_multi_create", "ezpz_multi_destroy", "ezpz_multi_device_count", "ezpz_multi_device", "ezpz_multi_shard",
+    "ezpz_multi_specialize", "ezpz_multi_solve_batch", "ezpz_system_solve_batch_multi",
 ]
 
 _lib = None
@@ -105,6 +107,22 @@ def lib():
     L.ezpz_system_specialize.argtypes = [vp, C.c_int]
     L.ezpz_specialized_source.restype = C.c_long
     L.ezpz_specialized_source.argtypes = [vp, sz, sz, C.c_int, C.c_char_p, sz]
+    L.ezpz_multi_create.restype = C.c_int
+    L.ezpz_multi_create.argtypes = [vp, sz, sz, C.c_uint64, u32, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.ezpz_multi_destroy.restype = None
+    L.ezpz_multi_destroy.argtypes = [vp]
+    L.ezpz_multi_device_count.restype = C.c_int
+    L.ezpz_multi_device_count.argtypes = [vp]
+    L.ezpz_multi_device.restype = C.c_int
+    L.ezpz_multi_device.argtypes = [vp, C.c_int]
+    L.ezpz_multi_shard.restype = None
+    L.ezpz_multi_shard.argtypes = [vp, sz, C.c_int, C.POINTER(sz), C.POINTER(sz)]
+    L.ezpz_multi_specialize.restype = C.c_int
+    L.ezpz_multi_specialize.argtypes = [vp, C.c_int]
+    L.ezpz_multi_solve_batch.restype = C.c_int
+    L.ezpz_multi_solve_batch.argtypes = [vp, vp, sz, C.POINTER(CConfig), vp, vp, vp]
+    L.ezpz_system_solve_batch_multi.restype = C.c_int
+    L.ezpz_system_solve_batch_multi.argtypes = [vp, sz, sz, C.c_uint64, vp, sz, C.POINTER(CConfig), vp, vp]
     L.ezpz_resolve_sides.restype = C.c_int
     L.ezpz_resolve_sides.argtypes = [vp, sz, vp, sz]
     L.ezpz_cache_clear.restype = None

@@ -761,6 +761,70 @@ class System:
             raise NonLinearSystemError(rc)
 
 
+class MultiSystem:
+    """One analysed topology resident on several devices of the node (`ezpz_multi_*`): a batch is sharded contiguously
+    over them, one host worker thread per device, every shard over its own device's host link.  `device_mask` bit d =
+    HIP device d, 0 = all."""
+
+    def __init__(self, records, n_vars: int, device_mask: int = 0, team_size: int = 0):
+        self.records = stack_records(records)
+        self.n_vars = int(n_vars)
+        h = C.c_void_p()
+        ec, ev = C.c_int32(-1), C.c_int64(-1)
+        rc = lib().ezpz_multi_create(self.records.ctypes.data if len(self.records) else None, len(self.records), self.n_vars,
+                                     device_mask, team_size, C.byref(h), C.byref(ec), C.byref(ev))
+        if rc != 0:
+            raise NonLinearSystemError(rc, ec.value, ev.value)
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().ezpz_multi_destroy(h)
+            self._h = None
+
+    def devices(self):
+        return [lib().ezpz_multi_device(self._h, i) for i in range(lib().ezpz_multi_device_count(self._h))]
+
+    def shard(self, batch: int, index: int):
+        first, count = C.c_size_t(0), C.c_size_t(0)
+        lib().ezpz_multi_shard(self._h, batch, index, C.byref(first), C.byref(count))
+        return first.value, count.value
+
+    def specialize(self, wait: bool = True) -> int:
+        rc = lib().ezpz_multi_specialize(self._h, 1 if wait else 0)
+        if rc < 0:
+            raise NonLinearSystemError(rc)
+        return rc
+
+    def solve_batch(self, x0: np.ndarray, config: Optional[Config] = None, want_mask: bool = False, out=None):
+        """x0 [batch, n_vars] -> (x, status, mask or None).  `out` = (x, status) arrays to fill (e.g. registered ones)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, max(self.n_vars, 1))
+        batch = x0.shape[0]
+        cfg = (config or Config())._c()
+        x, st = out if out is not None else (np.empty_like(x0), np.zeros(batch, dtype=STATUS_DTYPE))
+        mask = np.zeros((batch, max(len(self.records), 1)), dtype=np.uint8) if want_mask else None
+        rc = lib().ezpz_multi_solve_batch(self._h, x0.ctypes.data, batch, C.byref(cfg), x.ctypes.data, st.ctypes.data,
+                                          mask.ctypes.data if want_mask else None)
+        if rc != 0:
+            raise NonLinearSystemError(rc)
+        return x, st, mask
+
+
+def solve_batch_multi(records, n_vars: int, x0: np.ndarray, device_mask: int = 0, config: Optional[Config] = None):
+    """`ezpz_system_solve_batch_multi`: the one-call form (handles cached by request bytes and mask)."""
+    recs = stack_records(records)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, max(int(n_vars), 1))
+    cfg = (config or Config())._c()
+    x = np.empty_like(x0)
+    st = np.zeros(x0.shape[0], dtype=STATUS_DTYPE)
+    rc = lib().ezpz_system_solve_batch_multi(recs.ctypes.data if len(recs) else None, len(recs), int(n_vars), device_mask,
+                                             x0.ctypes.data, x0.shape[0], C.byref(cfg), x.ctypes.data, st.ctypes.data)
+    if rc != 0:
+        raise NonLinearSystemError(rc)
+    return x, st
+
+
 def analyze(records, n_vars: int) -> dict:
     """Host-only symbolic analysis (`ezpz_analyze`): sizes of the topology program, no device needed."""
     a = stack_records(records)

@@ -180,6 +180,7 @@ struct EzpzSystem {
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
     size_t lds_bytes = 0;
+    std::mutex launch_mu;  // launch(): lazily created per-system state
     // grow-only scratch for the host-pointer entry points
     std::mutex mu;
     DevBuf<double> x_dev;
@@ -479,15 +480,20 @@ bool jit_sync() {
 
 int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (args.batch == 0) return EZPZ_OK;
+    // enqueueing on one EzpzSystem from several threads (each on its own stream) is allowed: what a launch creates on
+    // first use -- workspaces, events, occupancy figures -- is created under this lock, and launches that share a
+    // workspace are chained on an event below
+    std::lock_guard<std::mutex> launch_lock(s.launch_mu);
+    constexpr uint64_t kNoLanesWorkspace = ~0ull;  // the allocation failed once: not tried again on every call
     if (s.lanes && args.batch >= s.lanes_min) {  // a device-filling batch of one connected sketch: lanes across the batch
         if (s.lanes_ws_waves == 0) {
             // one workspace per wavefront the device holds (capped at 24 GiB of the 288: fewer wavefronts then)
             uint64_t waves = batch_launch_waves(s.lim.cus);
             const uint64_t per = (uint64_t)s.lanes->rows * 512;
             while (waves > 4 && waves * per > (24ull << 30)) waves /= 2;
-            if (s.lanes_ws.ensure((size_t)(waves * per / 8)) == EZPZ_OK) s.lanes_ws_waves = waves;
+            s.lanes_ws_waves = s.lanes_ws.ensure((size_t)(waves * per / 8)) == EZPZ_OK ? waves : kNoLanesWorkspace;
         }
-        if (s.lanes_ws_waves) {
+        if (s.lanes_ws_waves != kNoLanesWorkspace) {
             // one workspace per system object: launches on different streams are chained, never overlapped
             if (!s.lanes_done)
                 HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
@@ -1682,8 +1688,12 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     // MI355X boxes measured (tools/pcie_bw.py) the host link moves 56 GB/s one way but only 28-45 GB/s each way when
     // both directions run at once, so this buys ~5 % over the pageable path, not the 2x of a full-duplex link.  Only for launch shapes that keep no per-system
     // device scratch (kernels of one EzpzSystem may then overlap) and calls without mask / warning log.
-    const bool scratch_free = sys->comp || sys->lane || (sys->lds_ws && sys->grid_wgs == 1);
-    if (n && scratch_free && !unsat_mask && !want_log && host_range_registered(x0, x_bytes) &&
+    // (a system that runs lanes across the batch from a few systems on -- EZPZ_TEAM_BATCH_LANES -- has no piece size below
+    // its threshold worth pipelining: it takes the chunked path below, where the lanes kernel is legal)
+    const bool scratch_free = (sys->comp && (sys->comp->interpretable || sys->comp->jit_wgs <= 1)) || sys->lane ||
+                              (sys->lds_ws && sys->grid_wgs == 1);
+    const bool lanes_always = sys->lanes && sys->lanes_min <= std::min<size_t>(batch, 8);
+    if (n && scratch_free && !lanes_always && !unsat_mask && !want_log && host_range_registered(x0, x_bytes) &&
         host_range_registered(x_out, x_bytes)) {
         const size_t row = n * sizeof(double);
         // pieces of ~2 MB (measured 2 / 4 / 8 / 16 MB: 1.67 / 1.63 / 1.63 / 1.59 M solves/s on the 2000 x 2000 system), at
@@ -1696,31 +1706,46 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         size_t piece = std::max<size_t>(std::min<size_t>(batch, 8), std::min<size_t>(piece_bytes / row, (batch + 5) / 6));
         // (the lanes-across-the-batch kernel works in one workspace per system object: its launches must not overlap, so
         // the pieces of this pipeline stay below its threshold and run on the teams, which keep their state in LDS)
-        if (sys->lanes && piece >= sys->lanes_min) piece = (size_t)sys->lanes_min - 1;
+        if (sys->lanes && piece >= sys->lanes_min) piece = std::max<size_t>(1, (size_t)sys->lanes_min - 1);
         // the statuses of the whole call collect in one device buffer and come back in one copy at the end
         if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
+        // whatever happens after the first copy is enqueued, nothing returns while a copy may still be reading or
+        // writing the caller's buffers
+        auto drain = [&](int result) {
+            for (auto& sl : sys->slots)
+                if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (result == EZPZ_OK) result = EZPZ_ERR_HIP;
+                }
+            return result;
+        };
         size_t k = 0;
         for (size_t off = 0; off < batch; off += piece, ++k) {
             EzpzSystem::Slot& sl = sys->slots[k % 3];
             const size_t nb = std::min(piece, batch - off);
             if (!sl.stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+                if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return drain(EZPZ_ERR_HIP);
+                }
             }
             if (sl.x.cap < piece * n) {  // (re)allocation frees the old buffer: nothing may still be using it
-                HIP_TRY(hipStreamSynchronize(sl.stream));
-                if ((rc = sl.x.ensure(piece * n)) != EZPZ_OK) return rc;
+                if (hipStreamSynchronize(sl.stream) != hipSuccess) return drain(EZPZ_ERR_HIP);
+                if ((rc = sl.x.ensure(piece * n)) != EZPZ_OK) return drain(rc);
             }
             // a slot's stream runs its pieces in order, so its device buffer is free again when the copy-out of the
             // previous piece has been issued ahead of this copy-in on the same stream
-            HIP_TRY(hipMemcpyAsync(sl.x.p, x0 + off * n, nb * row, hipMemcpyHostToDevice, sl.stream));
+            if (hipMemcpyAsync(sl.x.p, x0 + off * n, nb * row, hipMemcpyHostToDevice, sl.stream) != hipSuccess) return drain(EZPZ_ERR_HIP);
             rc = ezpz_system_solve_batch_device(sys, sl.x.p, nb, cfg, sl.x.p, sys->st_dev.p + off, nullptr, nullptr, 0, sl.stream);
-            if (rc != EZPZ_OK) return rc;
-            HIP_TRY(hipMemcpyAsync(x_out + off * n, sl.x.p, nb * row, hipMemcpyDeviceToHost, sl.stream));
+            if (rc != EZPZ_OK) return drain(rc);
+            if (hipMemcpyAsync(x_out + off * n, sl.x.p, nb * row, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) return drain(EZPZ_ERR_HIP);
         }
-        for (auto& sl : sys->slots)
-            if (sl.stream) HIP_TRY(hipStreamSynchronize(sl.stream));
+        if ((rc = drain(EZPZ_OK)) != EZPZ_OK) return rc;
         HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
+        if (sys->comp && sys->comp->jit_wgs > 1)  // a specialised kernel spread over several workgroups: its rendezvous can time out
+            for (size_t b2 = 0; b2 < batch; ++b2)
+                if (status[b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
         return EZPZ_OK;
     }
     // Larger calls: DMA in pieces of <= 16 MB of guesses (pageable copies of that size run at ~43 GB/s on this
@@ -1772,7 +1797,7 @@ extern "C" {
 int ezpz_host_register(void* p, size_t bytes) {
     if (!p || !bytes) return EZPZ_ERR_INVALID_ARGUMENT;
     if (ezpz_device_count() < 1) return EZPZ_ERR_NO_DEVICE;
-    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
         (void)hipGetLastError();
         return EZPZ_ERR_HIP;
     }

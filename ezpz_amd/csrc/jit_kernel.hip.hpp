@@ -175,7 +175,7 @@ __device__ __forceinline__ double uniform(double v) {  // a value every lane hol
 // stays true while every operand was in the range where div_scale does not scale and div_fixup has nothing to fix
 // (V_DIV_SCALE_F64: denominator normal and its reciprocal normal, exponent(n) - exponent(D) in (-1022, 768),
 // exponent(n) > 53); the caller repeats the solve with plain divisions for the lanes where it is false, so results are
-// the correctly rounded quotients -- bit for bit what the interpreters and the oracle compute -- in every case.
+// the correctly rounded quotients -- bit for bit what the interpreters and a CPU `n / D` compute -- in every case.
 // Zero numerators stay on the short path: with e = fma(D, q0, -n) and q = fma(-e, y, q0) a zero keeps the sign of n
 // (D > 0), as div_fixup would give it.
 __device__ __forceinline__ double recip_of(double D, bool& ok) {

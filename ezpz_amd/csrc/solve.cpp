@@ -128,7 +128,10 @@ void set_from_initial_values(EzpzConstraint& c, const std::vector<double>& iv) {
 
 extern "C" {
 
+void ezpz_multi_cache_clear(void);  // multi.cpp: the handles behind ezpz_system_solve_batch_multi
+
 void ezpz_cache_clear(void) {
+    ezpz_multi_cache_clear();
     std::lock_guard<std::mutex> lock(g_cache_mu);
     g_cache.clear();
 }

@@ -216,6 +216,9 @@ int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t
  * the host form copies in, runs, copies out and synchronises.  Launches on one EzpzSystem must not overlap in time
  * when the system uses per-system device scratch (a global workspace or a grid team, see EzpzSystemInfo): enqueue
  * them on one stream, or create one EzpzSystem per stream.
+ * Thread safety: the _device form may be called on one EzpzSystem from several threads at once (each enqueueing on its
+ * own stream; what a launch creates on first use is created under a lock); the host form serialises its callers per
+ * EzpzSystem; ezpz_solve* may be called from any number of threads.
  * Grid teams (EzpzSystemInfo.grid_workgroups > 1) need all their workgroups resident at once; launches are sized to
  * the device's CU count, and should a rendezvous still time out (~1 s: another process occupying the device) the
  * affected systems report iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT, converged == 0 instead of hanging; the host
@@ -275,6 +278,32 @@ int ezpz_system_freedom_batch_device(EzpzSystem* sys, const double* x_dev, size_
 int ezpz_solve_batch(const EzpzConstraint* reqs, size_t n_reqs, size_t n_vars, const double* x0, size_t batch,
                      const EzpzConfig* cfg, double* x_out, EzpzStatus* status, uint32_t* priority_solved,
                      uint8_t* unsat_mask, int32_t* err_constraint, int64_t* err_variable);
+
+/* ---- one batch over several devices of a node (new; SURVEY.md 8b last row, 8e) ------------------------------------------
+ * The reference's caller is a host loop over independent solves (ezpz-cli/src/main.rs:96-98); independent systems have
+ * no exchange step, so a batch shards contiguously over the devices of `device_mask` (bit d = HIP device d; 0 = every
+ * device of the node): device index g of G gets systems [g * ceil(batch / G), ...), trailing devices may be short or
+ * idle.  One host worker thread and one analysed topology (an EzpzSystem) per device; every shard moves over its own
+ * device's host link, straight between the caller's buffers and that device -- no peer copies, no collective -- through
+ * the single-device path of ezpz_system_solve_batch (registered caller buffers, ezpz_host_register, are pipelined on
+ * every device at once).  Results are those of ezpz_system_solve_batch on the whole batch, bit for bit.
+ * `cs` is one side-resolved tier as for ezpz_system_create.  A handle serves one batch call at a time (calls from
+ * several threads queue); ezpz_multi_specialize is ezpz_system_specialize on every device (the smallest state is returned).
+ * ezpz_multi_shard tells which systems device index `index` takes of a batch.
+ * ezpz_system_solve_batch_multi is the same in one call: the handles live in a small cache keyed by the request bytes
+ * and the mask (dropped by ezpz_cache_clear). */
+typedef struct EzpzMultiSystem EzpzMultiSystem; /* opaque: one analysed topology resident on several devices */
+int ezpz_multi_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint64_t device_mask, uint32_t team_size,
+                      EzpzMultiSystem** out, int32_t* err_constraint, int64_t* err_variable);
+void ezpz_multi_destroy(EzpzMultiSystem* multi);
+int ezpz_multi_device_count(const EzpzMultiSystem* multi);        /* G */
+int ezpz_multi_device(const EzpzMultiSystem* multi, int index);  /* HIP device of device index `index`, -1 out of range */
+void ezpz_multi_shard(const EzpzMultiSystem* multi, size_t batch, int index, size_t* first, size_t* count);
+int ezpz_multi_specialize(EzpzMultiSystem* multi, int wait);
+int ezpz_multi_solve_batch(EzpzMultiSystem* multi, const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out,
+                           EzpzStatus* status, uint8_t* unsat_mask);
+int ezpz_system_solve_batch_multi(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint64_t device_mask,
+                                  const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out, EzpzStatus* status);
 
 /* Constraint::set_from_initial_values (ezpz/src/constraints.rs:146-193) over a request list, in place: every
  * LineTangentToCircle / CircleTangentToCircle whose side is EZPZ_SIDE_UNDEFINED gets the side the values imply

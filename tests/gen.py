@@ -49,22 +49,7 @@ def splitmix64(x):
     return z ^ (z >> 31)
 
 
-def keyed_uniform(seed, n_systems, n_vars, lo, hi, integer=False):
-    """Counter-based PRNG keyed (seed, system, var) -> uniform [lo, hi)."""
-    sys_idx = np.arange(n_systems, dtype=np.uint64)[:, None]
-    var_idx = np.arange(n_vars, dtype=np.uint64)[None, :]
-    with np.errstate(over="ignore"):
-        key = np.asarray([seed], dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-        x = key ^ (sys_idx * np.uint64(0xD1B54A32D192ED03)) ^ (var_idx * np.uint64(0x8CB92BA72F3D8DD7))
-        x = x + np.uint64(0x9E3779B97F4A7C15)
-        z = x
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
-    if integer:
-        return np.floor(lo + u * (hi - lo))
-    return lo + u * (hi - lo)
+from ezpz_amd.synthetic import keyed_uniform  # noqa: E402,F401  (the product's keyed PRNG; bench.py uses the same)
 
 
 def connected_sketch(npts, seed):
