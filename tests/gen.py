@@ -85,3 +85,28 @@ def connected_sketch(npts, seed):
     recs = O.stack(cons)
     g = np.concatenate(true) + rng.uniform(-0.05, 0.05, 2 * npts)
     return recs, g
+
+
+def graph_sketch(family, npts, rng):
+    """A consistent, fully determined sketch of one of four graph families -- random tree with chords, wide band, hub,
+    comb (a spine with teeth) -- built around a hidden true layout.  Returns the records and the true values."""
+    pt = lambda i: (2 * i, 2 * i + 1)
+    true = np.zeros((npts, 2))
+    cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
+    for i in range(1, npts):
+        if family == "tree":
+            a, b = int(rng.integers(0, i)), int(rng.integers(0, i))
+        elif family == "band":
+            a, b = i - 1, max(0, i - int(rng.integers(2, 13)))
+        elif family == "hub":
+            a, b = 0, max(0, i - 1)
+        else:  # comb
+            a, b = (i - 1, max(0, i - 2)) if i % 5 else (max(0, i - 5), max(0, i - 10))
+        true[i] = true[a] + rng.uniform(0.6, 2.0, 2) * rng.choice([-1.0, 1.0], 2)
+        cons.append(O.distance(pt(i), pt(a), float(np.hypot(*(true[i] - true[a])))))
+        if b != a:
+            cons.append(O.distance(pt(i), pt(b), float(np.hypot(*(true[i] - true[b])))) if rng.random() < 0.5
+                        else O.horizontal_distance(pt(i), pt(b), float(true[i][0] - true[b][0])))
+        else:
+            cons.append(O.vertical_distance(pt(i), pt(a), float(true[i][1] - true[a][1])))
+    return O.stack(cons), true.reshape(-1)

@@ -11,6 +11,7 @@ import gen
 from conftest import GOLDEN, read_case
 from oracle import oracle as O
 from oracle import textual as T
+from sensitivity import assert_batch_matches_oracle
 
 pytestmark = pytest.mark.gpu
 REL = 1e-6
@@ -228,11 +229,14 @@ def test_connected_sketches_lanes_across_the_batch(E, npts, seed):
     rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
     assert rc == 0
     assert np.array_equal(st["converged"], conv) and np.array_equal(st["n_unsatisfied"], nun) and np.array_equal(mask.sum(axis=1), nun)
-    # (a stop test decided in the last bits -- the elimination orders differ -- moves a system's count by one, and its
-    # coordinates along the sketch's soft direction with it: 1 system of 2500 at 30 points)
-    same = st["iterations"] == it
-    assert same.mean() >= 0.995 and np.max(np.abs(st["iterations"].astype(int) - it)) <= 3
-    assert_x_close(x[same], xo[same])
+    # every system, none excluded: equal iteration counts and 1e-6, or -- where a stop test is decided in the last bits (the
+    # elimination orders differ) -- a count and coordinates inside what the oracle itself does from one-ulp perturbations
+    # of the start (tests/sensitivity.py)
+    ok = ~np.isnan(x0).any(axis=1)
+    needed = assert_batch_matches_oracle(recs, x0[ok], x[ok], st["iterations"][ok], st["converged"][ok], O.Config(**cfg),
+                                         oracle_result=(xo[ok], it[ok], conv[ok]), what=("lanes", npts, seed))
+    assert needed <= B // 100
+    assert np.array_equal(st["iterations"][~ok], it[~ok]) and np.array_equal(np.isnan(x[~ok]), np.isnan(xo[~ok]))
     # (the lanes eliminate in the order with the least fill, the teams in the one with few levels)
     same = st["iterations"][:300] == sts["iterations"]
     assert same.mean() >= 0.99 and np.array_equal(mask[:300], masks)
@@ -273,7 +277,9 @@ def test_weighted_inconsistent_sketch_on_the_lanes_and_on_dense_phases(E, npts):
         for st, mask, x in ((stl, ml, xl), (stt, mt, xt)):
             assert bool(st["converged"][b]) == want.converged and np.nonzero(mask[b])[0].tolist() == want.unsatisfied, b
             assert abs(float(st["final_residual_inf"][b]) - want.final_residual_inf) <= 1e-6 * max(1.0, want.final_residual_inf)
-            assert_x_close(x[b], want.final_values, 1e-5)
+            assert_batch_matches_oracle(recs, x0[b:b + 1], x[b:b + 1], [st["iterations"][b]], [st["converged"][b]], O.Config(**cfg),
+                                        oracle_result=(np.asarray(want.final_values)[None, :], [want.iterations], [want.converged]),
+                                        what=("weighted", npts, b), check_iterations=False)
     rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
     assert rc == 0 and np.array_equal(stl["converged"], conv) and np.array_equal(stl["n_unsatisfied"], nun)
 

@@ -23,6 +23,5 @@ find $out/stats_s -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/sq
 (echo "# python tools/pcie_bw.py  (host link of the GPU box)"; python tools/pcie_bw.py 2>&1) > $out/pcie_bw.txt
 python tools/ab_microbench.py $out > /dev/null 2>&1
 (echo "# ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/<case>/problem.md  (the reference CLI's protocol, main.rs:86-100; steady state = the 100-run loop alone)"; for c in tiny square arc_radius two_rectangles massive_parallel_system; do echo "## $c"; ./ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/$c/problem.md | grep -E "Problem size|Iterations|Steady"; done) > $out/cli_latency.txt
-(echo "# python tools/fuzz_sketch.py 0 160  (random connected sketches of 40-640 variables x three starts x three launch shapes: automatic, one-solve, explicit 128 lanes; a MISMATCH line = iteration count or convergence flag different from the oracle, or coordinates beyond 1e-6 relative)"; python tools/fuzz_sketch.py 0 160 2>&1 | grep "MISMATCH\|checked") > $out/fuzz_sketch.txt
-(echo "# python tools/fuzz_graphs.py 0 240  (consistent sketches of four graph families x four launch shapes x two starts against the oracle; team 0 automatic, 4294967295 one-solve shape, 4294967293 lanes across the batch, 512 the plain level walk)"; python tools/fuzz_graphs.py 0 240 2>&1 | grep "MISMATCH\|checked") > $out/fuzz_graphs.txt
+(echo "# python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_proptests.py -m gpu  (parity fuzz of the connected-sketch shapes and the reference's property tests on the HIP path: sensitivity-aware bar, no exclusions)"; python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_proptests.py -q -m gpu 2>&1 | tail -3) > $out/fuzz_tests.txt
 head -3 $out/massive_b16384_kernel_stats.csv
