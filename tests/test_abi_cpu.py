@@ -130,11 +130,9 @@ def test_symbolic_phase_survives_random_sketches_at_the_edge_of_the_lds():
         assert i["n_vars"] == 2 * npts and i["n_components"] == 1
         _shapes_analyse(recs, len(g))
     # (a 100-variable comb on wavefront teams: the re-pack chose a larger workgroup than the panels had been sized for)
-    ns = {}
-    exec(open(os.path.join(ROOT, "tools", "fuzz_graphs.py")).read().split("bad = tot = 0")[0], ns)
     for seed in (159, 83, 121, 200):
         r2 = np.random.default_rng(7000 + seed)
-        recs, true = ns["sketch"](["tree", "band", "hub", "comb"][seed % 4], int(r2.integers(20, 500)), r2)
+        recs, true = gen.graph_sketch(["tree", "band", "hub", "comb"][seed % 4], int(r2.integers(20, 500)), r2)
         _shapes_analyse(recs, len(true))
     pt = lambda i: (2 * i, 2 * i + 1)
     for trial in range(48):
