@@ -601,13 +601,14 @@ def solve_batch(reqs, x0: np.ndarray, config: Optional[Config] = None, want_mask
     return x, st, prio, mask
 
 
-def specialized_source(records, n_vars: int, compile: bool = False) -> str:
+def specialized_source(records, n_vars: int, compile=False) -> str:
     """`ezpz_specialized_source`: the generated source of the request's class-specialised kernel ('' = none); with
-    compile=True it is also compiled for gfx950 (hiprtc; no device needed) and a failure raises with the log."""
+    compile=True it is also compiled for gfx950 (hiprtc; no device needed) and a failure raises with the log;
+    compile="cached": through the on-disk cache of code objects, like the solve entry points."""
     recs = stack_records(records)
     buf = C.create_string_buffer(1 << 22)
-    rc = lib().ezpz_specialized_source(recs.ctypes.data if len(recs) else None, len(recs), int(n_vars), 1 if compile else 0,
-                                       buf, len(buf))
+    rc = lib().ezpz_specialized_source(recs.ctypes.data if len(recs) else None, len(recs), int(n_vars),
+                                       2 if compile == "cached" else 1 if compile else 0, buf, len(buf))
     if rc < 0:
         raise RuntimeError("run-time compilation failed:\n" + buf.value.decode(errors="replace")[-4000:])
     return buf.value.decode() if rc > 0 else ""

@@ -505,6 +505,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             }
         }
     }
+    if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
     if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
         if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, jit_sync());
@@ -635,6 +636,7 @@ const char* ezpz_error_string(int err) {
     case EZPZ_ERR_HIP: return "HIP runtime error";
     case EZPZ_ERR_TOO_LARGE: return "system too large for this build";
     case EZPZ_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case EZPZ_ERR_KERNEL_BUDGET: return "the process already holds its budget of specialised kernels";
     case EZPZ_ERR_PARSE: return "could not parse problem text";
     case EZPZ_ERR_TEXT_MISSING_GUESS: return "No guess was given for a point";
     case EZPZ_ERR_TEXT_UNUSED_GUESSES: return "You gave a guess for points which weren't defined";
@@ -1824,6 +1826,7 @@ int ezpz_system_specialize(EzpzSystem* sys, int wait) {
     if (!sys) return EZPZ_ERR_INVALID_ARGUMENT;
     if (!sys->jit) return 0;
     const int st = comp_jit_request(sys->jit, wait != 0);
+    if (st == kJitBudgetExhausted) return EZPZ_ERR_KERNEL_BUDGET;
     return st < 0 ? EZPZ_ERR_HIP : st;
 }
 
@@ -1842,7 +1845,8 @@ long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_var
     if (compile) {
         std::vector<char> code;
         std::string log;
-        if (comp_jit_compile(source, code, log) != EZPZ_OK) {
+        // compile == 2: through the on-disk cache of code objects, like the solve entry points; otherwise a real compilation
+        if ((compile == 2 ? comp_jit_compile(source, code, log) : comp_jit_compile_uncached(source, code, log)) != EZPZ_OK) {
             text = log;
             rc = EZPZ_ERR_HIP;
         }

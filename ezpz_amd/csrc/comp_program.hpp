@@ -152,7 +152,8 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
 
 // The class-specialised kernel of a plan (jit.cpp): run-time compiled (hiprtc) on a background thread.
 // comp_jit_create returns nullptr when the plan carries no source or EZPZ_JIT=0.  comp_jit_request starts the
-// compilation if it has not started (and waits for it if asked); returns 0 idle, 1 compiling, 2 ready, -1 failed.
+// compilation if it has not started (and waits for it if asked); returns 0 idle, 1 compiling, 2 ready, -1 failed,
+// kJitBudgetExhausted.
 struct CompJit;
 CompJit* comp_jit_create(const CompPlan& plan);
 CompJit* comp_jit_create_source(const std::string& source, const char* entry);
@@ -165,6 +166,14 @@ int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob
                     void* grid_scratch = nullptr, uint32_t grid_slots = 0);
 // workgroups of the specialised kernel the device holds at once (loads the code object on first use); 0 on failure
 uint64_t comp_jit_capacity(CompJit* jit, const CompPlan& plan, int device, int cus);
+// (through the on-disk cache of code objects; _uncached always compiles; comp_jit_cached: is it in the cache?)
 int comp_jit_compile(const std::string& source, std::vector<char>& code, std::string& log);
+int comp_jit_compile_uncached(const std::string& source, std::vector<char>& code, std::string& log);
+bool comp_jit_cached(const std::string& source);
+// asks the on-disk cache for the kernel in the background, once (a system's first launch does this)
+void comp_jit_probe(CompJit* jit);
+// comp_jit_request when the process already holds its budget of resident specialised kernels (512: code objects are
+// never unloaded, jit.cpp): the entry stays idle and the interpreters serve
+constexpr int kJitBudgetExhausted = -2;
 
 }  // namespace ezpz

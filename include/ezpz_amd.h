@@ -105,6 +105,7 @@ enum EzpzError {
     EZPZ_ERR_HIP = -101,
     EZPZ_ERR_TOO_LARGE = -102,
     EZPZ_ERR_INVALID_ARGUMENT = -103,
+    EZPZ_ERR_KERNEL_BUDGET = -104,   /* ezpz_system_specialize: the process already holds its 512 specialised kernels */
     EZPZ_ERR_PARSE = -110,           /* textual front end: winnow parse failure */
     EZPZ_ERR_TEXT_MISSING_GUESS = -111,  /* TextualError, error.rs:10-33 */
     EZPZ_ERR_TEXT_UNUSED_GUESSES = -112,
@@ -320,9 +321,17 @@ int ezpz_resolve_sides(EzpzConstraint* cs, size_t n_cs, const double* values, si
  * lane-per-system form sums residuals in request order, i.e. agrees to rounding); EZPZ_JIT=0 in the
  * environment turns it off.  ezpz_system_specialize starts it explicitly and, with wait != 0, returns when it is
  * done: 2 = ready, 1 = still compiling, 0 = this system has no specialised form, negative = compilation failed.
+ * Compiled code objects are kept on disk ($EZPZ_JIT_CACHE_DIR, else $XDG_CACHE_HOME/ezpz_amd, else
+ * $HOME/.cache/ezpz_amd; EZPZ_JIT_CACHE=0 turns the cache off), keyed by the generated source, the embedded device
+ * headers, the compiler options and the hiprtc version: a process that finds its kernel there has it from its first few
+ * solves (a system's first launch asks the cache in the background) instead of after 256 solves and a compilation.
+ * Budget: a loaded code object is never unloaded, so a process holds at most 512 specialised kernels (distinct
+ * topologies; systems with the same generated source share one).  Beyond that ezpz_system_specialize returns
+ * EZPZ_ERR_KERNEL_BUDGET and batch calls keep running on the interpreting kernels (same results, lower rate).
  * ezpz_specialized_source (no device needed) writes the generated source of a request into buf (NUL-terminated,
  * truncated to cap) and returns its length, 0 when the request gets no component plan; with compile != 0 it also
- * compiles it for gfx950 and returns a negative error with the compiler's log in buf on failure. */
+ * compiles it for gfx950 (compile == 2: through the on-disk cache, like the solve entry points) and returns a negative
+ * error with the compiler's log in buf on failure. */
 int ezpz_system_specialize(EzpzSystem* sys, int wait);
 long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int compile, char* buf, size_t cap);
 

@@ -6,6 +6,7 @@ import ctypes as C
 import glob
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -323,3 +324,51 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "solve rc=" in r.stdout
+
+
+def test_code_object_cache_on_disk(tmp_path):
+    """jit.cpp keeps compiled kernels under $EZPZ_JIT_CACHE_DIR: the first compilation writes one file, the second run of the
+    same request reads it (no compiler), a damaged file is a miss that gets rewritten, another topology gets its own
+    file, and EZPZ_JIT_CACHE=0 writes nothing.  (Fresh processes: the directory is read from the environment once.)"""
+    import subprocess
+    import textwrap
+
+    script = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        import ezpz_amd as E
+        lines = int(sys.argv[1])
+        b = E.textual.Problem.from_str(E.textual.gen_big_problem(lines)).to_constraint_system()
+        t = time.perf_counter()
+        assert "ezpz_jit_solve" in E.specialized_source(b.records, b.num_vars, compile="cached")
+        print("seconds", time.perf_counter() - t)
+    """ % ROOT)
+    cache = tmp_path / "cache"
+
+    def run(lines, **env):
+        r = subprocess.run([sys.executable, "-c", script, str(lines)], env=dict(os.environ, EZPZ_JIT_CACHE_DIR=str(cache), **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return float(r.stdout.split()[-1])
+
+    cold = run(200)
+    files = sorted(os.listdir(cache))
+    assert len(files) == 1 and files[0].endswith(".co") and os.path.getsize(cache / files[0]) > 4096
+    warm = run(200)
+    assert sorted(os.listdir(cache)) == files and warm < cold / 4, (cold, warm)
+    # a damaged file (a flipped byte in the code) is a miss, and the kernel is compiled and stored again
+    path = cache / files[0]
+    blob = bytearray(path.read_bytes())
+    blob[-100] ^= 0xFF
+    path.write_bytes(bytes(blob))
+    again = run(200)
+    assert again > 4 * warm and path.read_bytes() != bytes(blob)
+    path.write_bytes(bytes(blob[: len(blob) // 2]))  # and a truncated one
+    run(200)
+    assert os.path.getsize(path) == len(blob)
+    run(240)  # another topology: its own file
+    assert len(os.listdir(cache)) == 2
+    off = tmp_path / "off"
+    subprocess.run([sys.executable, "-c", script, "200"], env=dict(os.environ, EZPZ_JIT_CACHE_DIR=str(off), EZPZ_JIT_CACHE="0"), check=True,
+                   capture_output=True, timeout=600)
+    assert not off.exists()
