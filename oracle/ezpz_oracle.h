@@ -160,6 +160,8 @@ int orc_freedom_analysis_dense(const double* jac_colmajor, size_t m, size_t n, u
 /* CLI timing protocol (ezpz-cli/src/main.rs:86-100): `repeats` back-to-back full solves; returns seconds. */
 double orc_time_solves(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
                        size_t n_guesses, const OrcConfig* cfg, int linsolve, int repeats, uint64_t* iterations_out);
+double orc_time_solves_analysis(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+                       size_t n_guesses, const OrcConfig* cfg, int linsolve, int repeats, uint64_t* iterations_out);
 
 /* Batch of independent systems sharing one request list; guesses AoS [batch][n]. OpenMP over systems. */
 int orc_solve_batch(const OrcConstraint* reqs, size_t n_reqs, size_t n_vars, const double* guesses, size_t batch,

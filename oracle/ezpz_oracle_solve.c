@@ -982,6 +982,27 @@ double orc_time_solves(const OrcConstraint* reqs, size_t n_reqs, const uint32_t*
     return t1 - t0;
 }
 
+/* The same loop over solve_analysis (lib.rs:134-146): what the reference's `*_analysis` benchmarks time
+ * (ezpz/benches/solver_bench.rs:27-41). */
+double orc_time_solves_analysis(const OrcConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
+                                size_t n_guesses, const OrcConfig* cfg, int linsolve, int repeats, uint64_t* iterations_out) {
+    double* x = (double*)malloc((n_guesses + 1) * sizeof(double));
+    uint64_t* unsat = (uint64_t*)malloc((n_reqs + 1) * sizeof(uint64_t));
+    uint32_t* under = (uint32_t*)malloc((n_guesses + 1) * sizeof(uint32_t));
+    uint64_t n_under = 0;
+    OrcOutcome o;
+    double t0 = now_seconds();
+    for (int i = 0; i < repeats; ++i) {
+        orc_solve_analysis(reqs, n_reqs, var_ids, guesses, n_guesses, cfg, linsolve, x, unsat, NULL, 0, &o, under, &n_under);
+    }
+    double t1 = now_seconds();
+    if (iterations_out) *iterations_out = o.iterations;
+    free(x);
+    free(unsat);
+    free(under);
+    return t1 - t0;
+}
+
 int orc_solve_batch(const OrcConstraint* reqs, size_t n_reqs, size_t n_vars, const double* guesses, size_t batch,
                     const OrcConfig* cfg, int linsolve, int nthreads, double* x_out, uint32_t* iterations,
                     uint8_t* converged, uint32_t* n_unsatisfied) {

@@ -191,6 +191,9 @@ def lib():
         L.orc_solve_inner.restype = C.c_int
         L.orc_solve_inner.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(_Config), C.c_int, vp,
                                       vp, vp, C.c_size_t, C.POINTER(_Outcome)]
+        L.orc_time_solves_analysis.restype = C.c_double
+        L.orc_time_solves_analysis.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(_Config), C.c_int, C.c_int,
+                                               C.POINTER(C.c_uint64)]
         L.orc_time_solves.restype = C.c_double
         L.orc_time_solves.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(_Config), C.c_int, C.c_int,
                                       C.POINTER(C.c_uint64)]
@@ -451,13 +454,15 @@ def freedom_analysis_dense(jac: np.ndarray):
 
 
 def time_solves(reqs, guesses, repeats: int = 100, config: Optional[Config] = None,
-                linsolve: int = LINSOLVE_SPARSE) -> Tuple[float, int]:
-    """CLI timing protocol (ezpz-cli/src/main.rs:86-100).  Returns (seconds for `repeats` solves, iterations)."""
+                linsolve: int = LINSOLVE_SPARSE, analysis: bool = False) -> Tuple[float, int]:
+    """CLI timing protocol (ezpz-cli/src/main.rs:86-100); analysis=True times solve_analysis instead (the reference's
+    `*_analysis` benchmarks).  Returns (seconds for `repeats` solves, iterations)."""
     cfg = (config or Config())._c()
     a = stack(reqs)
     ids, vals = _split_guesses(guesses)
     it = C.c_uint64(0)
-    secs = lib().orc_time_solves(a.ctypes.data, len(a), ids.ctypes.data, vals.ctypes.data, len(vals),
+    fn = lib().orc_time_solves_analysis if analysis else lib().orc_time_solves
+    secs = fn(a.ctypes.data, len(a), ids.ctypes.data, vals.ctypes.data, len(vals),
                                  C.byref(cfg), linsolve, repeats, C.byref(it))
     return secs, int(it.value)
 
