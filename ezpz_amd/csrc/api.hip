@@ -158,6 +158,7 @@ struct EzpzSystem {
     std::unique_ptr<BatchPlan> lanes;
     uint32_t* dev_lanes = nullptr;
     DevBuf<double> lanes_ws;
+    DevBuf<uint32_t> strag_list, strag_count;  // the systems a lanes launch hands over to the teams (device-side list + count)
     uint64_t lanes_ws_waves = 0;
     hipEvent_t lanes_done = nullptr;  // completion of this system's last launch that used its global-memory workspace (lanes
                                       // kernel, list walk with the workspace in global memory): the next one, on any stream, waits for it
@@ -485,6 +486,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     // workspace are chained on an event below
     std::lock_guard<std::mutex> launch_lock(s.launch_mu);
     constexpr uint64_t kNoLanesWorkspace = ~0ull;  // the allocation failed once: not tried again on every call
+    bool stragglers = false;  // the teams below serve what a lanes launch left over
     if (s.lanes && args.batch >= s.lanes_min) {  // a device-filling batch of one connected sketch: lanes across the batch
         if (s.lanes_ws_waves == 0) {
             // one workspace per wavefront the device holds (capped at 24 GiB of the 288: fewer wavefronts then)
@@ -499,19 +501,33 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                 HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
             else
                 HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
-            if (batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream) == EZPZ_OK) {
+            // the systems the lanes give up (stragglers, batch_kernel.hip.hpp) are listed on the device and solved from their
+            // guesses by this system's list-walk teams right after: an indirect batch whose count stays on the device
+            const uint32_t strag_cap = args.batch < (1ull << 32) && args.batch >= 256
+                                           ? (uint32_t)std::min<uint64_t>(args.batch, std::max<uint64_t>(4096, args.batch / 8)) : 0u;
+            bool list_ok = strag_cap && s.strag_list.ensure(strag_cap) == EZPZ_OK && s.strag_count.ensure(1) == EZPZ_OK;
+            if (list_ok && hipMemsetAsync(s.strag_count.p, 0, sizeof(uint32_t), stream) != hipSuccess) {
+                (void)hipGetLastError();
+                list_ok = false;
+            }
+            if (batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream,
+                             list_ok ? s.strag_list.p : nullptr, list_ok ? s.strag_count.p : nullptr, list_ok ? strag_cap : 0u) == EZPZ_OK) {
                 HIP_TRY(hipEventRecord(s.lanes_done, stream));
-                return EZPZ_OK;
+                if (!list_ok) return EZPZ_OK;
+                args.sys_list = s.strag_list.p;
+                args.sys_count = s.strag_count.p;
+                args.batch = strag_cap;
+                stragglers = true;
             }
         }
     }
     if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
-    if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
+    if (!stragglers && s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
         if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, jit_sync());
         if (st == 2 && lane_jit_launch(s.jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
     }
-    if (s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
+    if (!stragglers && s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
         const CompLaunch L = comp_launch_args(args);
         // the class-specialised kernel once it is compiled; large batches start its compilation (background thread)
         if (s.jit) {
@@ -1623,6 +1639,8 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.grid_wgs = 1;
     a.grid_scratch = nullptr;
     a.grid_views = nullptr;
+    a.sys_list = nullptr;
+    a.sys_count = nullptr;
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }

@@ -36,6 +36,12 @@ struct BatchArgs {
     uint64_t batch;
     double residual_tolerance, step_tolerance, initial_lambda;
     double* ws;  // workspaces: one per wavefront of the launch, `rows` x 64 doubles each
+    // Stragglers (optional): once a wavefront has no system left to take and at most `strag_lanes` of its lanes are still
+    // working, those lanes hand their systems over -- the system's index goes on this list and the lane drops it without
+    // writing anything; the per-system teams solve the listed systems from their guesses after this kernel (api.hip).
+    uint32_t* strag_list;
+    uint32_t* strag_count;
+    uint32_t strag_cap, strag_lanes;
 };
 
 __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
@@ -169,9 +175,12 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
             }
         }
         const bool active = have && !finish;
+        // the Jacobian at the accepted values: for the lanes that go on (newton.rs:121) and, in the same sweep, for the lanes
+        // that have just converged and still owe the refresh of their last accepted step its warnings (their J rows are
+        // written for nothing; a second, mostly masked sweep over the records cost every round in which a lane finished)
+        if (__any(have && fresh)) jacobian_sweep(have && fresh);
+        if (have) fresh = false;
         if (__any(active)) {
-            if (__any(active && fresh)) jacobian_sweep(active && fresh);
-            if (active) fresh = false;
             // -- normal equations, Cholesky, substitutions (newton.rs:73-102): the operation stream, every lane on its own system.
             //    The operands of a record's items are all requested before the first is used: one trip to L2 / HBM per
             //    record instead of one per item; the terms are still folded in list order.  The stream runs column by column
@@ -314,7 +323,7 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
         // ---- systems that are done: the refresh their last accepted step still owes its warnings, the unsatisfied check
         //      (lib.rs:305-327, :358-370), write-back ---------------------------------------------------------------------------------
         if (__any(finish)) {
-            if (__any(finish && fresh)) jacobian_sweep(finish && fresh);
+            if (__any(finish && fresh)) jacobian_sweep(finish && fresh);  // (a step-size stop right after an accepted step)
             const bool use_r = r_is_at_x && a.unit_weights != 0;
             const bool all_sat = use_r && largest < EPS && !isnan(residual_sq);
             double unsat = 0.0;
@@ -358,6 +367,24 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                 a.status[sys] = st;
                 have = false;
                 fresh = false;
+            }
+        }
+
+        // ---- stragglers: a round of LM iterations costs a wavefront the same whether 64 lanes work or one (every access is
+        //      a trip to memory; ~1.5 ms per round for a 300-variable sketch on an otherwise idle device), and at one system
+        //      per lane the last 0.1 % of a jittered batch took 11 rounds alone.  A wavefront that cannot refill and is down
+        //      to a few lanes hands them to the per-system teams, which solve one such system in a fraction of a round.
+        if (a.strag_list) {
+            const unsigned long long working = __ballot(have);
+            if (working && (uint32_t)__popcll(working) <= a.strag_lanes && !__any(next < a.batch)) {
+                if (have) {
+                    const uint32_t idx = atomicAdd(a.strag_count, 1u);
+                    if (idx < a.strag_cap) {  // (a full list: this lane simply carries on)
+                        a.strag_list[idx] = (uint32_t)sys;
+                        have = false;
+                        fresh = false;
+                    }
+                }
             }
         }
     }

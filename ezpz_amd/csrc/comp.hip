@@ -2,6 +2,8 @@
 // builds compile beside the list-walk kernels of api.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <atomic>
 
@@ -74,7 +76,7 @@ uint64_t batch_launch_waves(int cus) {
 }
 
 int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons, const CompLaunch& L,
-                 void* stream) {
+                 void* stream, uint32_t* strag_list, uint32_t* strag_count, uint32_t strag_cap) {
     if (L.batch == 0) return EZPZ_OK;
     BatchArgs a{};
     a.prog = dev_blob;
@@ -92,14 +94,24 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
     a.unit_weights = plan.unit_weights ? 1u : 0u;
     // (4 ... 32 measured on 262 144 jittered systems of 300 variables, 4-19 iterations each: no difference -- at one system
     // per lane a wavefront lasts as long as its slowest lane)
-    a.refill_lanes = 22;
+    static const int env_refill = [] { const char* e = std::getenv("EZPZ_LANES_REFILL"); return e ? std::atoi(e) : 0; }();
+    a.refill_lanes = env_refill > 0 ? (uint32_t)env_refill : 8;  // (524 288 jittered systems of 300 variables: 22 -> 8 lanes +9 %)
     a.batch = L.batch;
     a.residual_tolerance = L.residual_tolerance;
     a.step_tolerance = L.step_tolerance;
     a.initial_lambda = L.initial_lambda;
     a.ws = dev_ws;
+    // a wavefront down to 6 working lanes (of 64) with nothing left to take gives them up: continuing costs the whole
+    // wavefront a round per iteration, the teams ~40 lane-rounds per system (EZPZ_LANES_STRAGGLERS: that threshold, 0 = off)
+    static const int env_strag = [] { const char* e = std::getenv("EZPZ_LANES_STRAGGLERS"); return e ? std::atoi(e) : 6; }();
+    a.strag_list = env_strag > 0 && strag_cap ? strag_list : nullptr;
+    a.strag_count = strag_count;
+    a.strag_cap = strag_cap;
+    a.strag_lanes = (uint32_t)std::max(env_strag, 0);
     // persistent lanes: as many wavefronts as have a workspace (and systems to solve)
-    const uint64_t blocks = std::min<uint64_t>((L.batch + 255) / 256, ws_waves / 4);
+    static const int env_waves = [] { const char* e = std::getenv("EZPZ_LANES_WAVES"); return e ? std::atoi(e) : 0; }();
+    uint64_t blocks = std::min<uint64_t>((L.batch + 255) / 256, ws_waves / 4);
+    if (env_waves > 0) blocks = std::min<uint64_t>(blocks, (uint64_t)env_waves / 4);
     if (blocks == 0) return EZPZ_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(batch_lane_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     if (hipGetLastError() != hipSuccess) return EZPZ_ERR_HIP;

@@ -848,6 +848,20 @@ bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Batc
     plan.o_dg = plan.o_j + plan.zj;
     plan.o_l = plan.o_dg + plan.nv;
     plan.rows = plan.o_l + plan.zlo;
+    if (std::getenv("EZPZ_LANES_DEBUG")) {  // the operation stream by kind: records and items (an item is two loads)
+        uint64_t recs[8] = {}, items[8] = {};
+        for (uint32_t io = 0; io < plan.n_ops; ++io) {
+            const uint32_t w = plan.blob[plan.ops_off + io * kCompRecWords];
+            recs[w & 7u] += 1;
+            items[w & 7u] += (w >> 8) & 0xFFu;
+        }
+        std::fprintf(stderr, "[ezpz lanes] nv %u m %u zj %u zlo %u rows %u ops %u |", plan.nv, plan.m, plan.zj, plan.zlo, plan.rows, plan.n_ops);
+        const char* names[] = {"DIAG", "OFF", "COL", "SLOT", "BWD"};
+        const uint32_t codes[] = {COMP_DIAG, COMP_OFF, COMP_COL, COMP_SLOT, COMP_BWD};
+        for (int k = 0; k < 5; ++k)
+            std::fprintf(stderr, " %s %llu recs %llu items", names[k], (unsigned long long)recs[codes[k] & 7u], (unsigned long long)items[codes[k] & 7u]);
+        std::fputc('\n', stderr);
+    }
     return true;
 }
 

@@ -147,8 +147,11 @@ struct BatchPlan {
 bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, BatchPlan& plan);
 // wavefronts of the kernel the device holds at once (their workspaces are what the caller allocates)
 uint64_t batch_launch_waves(int cus);
+// strag_list / strag_count / strag_cap: where wavefronts that are down to their last few lanes leave the systems they
+// give up (batch_kernel.hip.hpp); null: every system is solved by its lane
 int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons,
-                 const CompLaunch& launch, void* stream);
+                 const CompLaunch& launch, void* stream, uint32_t* strag_list = nullptr, uint32_t* strag_count = nullptr,
+                 uint32_t strag_cap = 0);
 
 // The class-specialised kernel of a plan (jit.cpp): run-time compiled (hiprtc) on a background thread.
 // comp_jit_create returns nullptr when the plan carries no source or EZPZ_JIT=0.  comp_jit_request starts the

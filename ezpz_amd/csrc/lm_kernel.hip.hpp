@@ -230,6 +230,11 @@ struct SolveArgs {
     // dense phases (Program::n_dense; barrier workgroups): how many, the first of their levels, LDS offset (doubles) of the
     // blocks' panels and the doubles they take together; n_dense == 0: none
     uint32_t n_dense, dense_level0, dense_lds_off, dense_lds_doubles;
+    // an indirect batch (optional): the systems to solve are sys_list[0 .. min(*sys_count, batch)), indices into x0 / x_out /
+    // status -- the stragglers a lanes-across-the-batch launch handed over (batch_kernel.hip.hpp); the count is only known
+    // on the device, `batch` is the list's capacity
+    const uint32_t* sys_list;
+    const uint32_t* sys_count;
 };
 
 #ifdef EZPZ_STAMPS
@@ -713,8 +718,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
             x_id[j] = ci < call1 ? P.var_of[ci] : 0u;
         }
     }
-    for (uint64_t sys = (uint64_t)grid_slot * teams_per_block + team_in_block; sys < a.batch;
-         sys += n_teams, sys_parity ^= 1u) {
+    const uint64_t n_sys = a.sys_count ? (uint64_t)min(*a.sys_count, (uint32_t)a.batch) : a.batch;
+    for (uint64_t q = (uint64_t)grid_slot * teams_per_block + team_in_block; q < n_sys; q += n_teams, sys_parity ^= 1u) {
+        const uint64_t sys = a.sys_list ? (uint64_t)a.sys_list[q] : q;
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
 #ifdef EZPZ_STAMPS
         int stamp_n = 0;
@@ -733,9 +739,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 if (ci < call1) ws[o_x + ci] = x_have ? x_pre[j] : x0[x_id[j]];
             }
             for (uint32_t ci = call0 + tm.lane + XPRE * 64; ci < call1; ci += tm.stride) ws[o_x + ci] = x0[P.var_of[ci]];
-            x_have = sys + n_teams < a.batch;
+            x_have = q + n_teams < n_sys;
             if (x_have) {
-                const double* x1 = a.x0 + (sys + n_teams) * n_row;
+                const double* x1 = a.x0 + (a.sys_list ? (uint64_t)a.sys_list[q + n_teams] : q + n_teams) * n_row;
 #pragma unroll
                 for (uint32_t j = 0; j < XPRE; ++j) {
                     const uint32_t ci = call0 + tm.lane + j * 64;

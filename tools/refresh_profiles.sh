@@ -3,10 +3,11 @@
 # Bench lines carry their own PMC counters (bench.py runs rocprofv3 --pmc child passes); the kernel-trace stats of the
 # same command are filed beside them so that the kernel's average duration can be checked against roofline.kernel_ms.
 out=$1; mkdir -p $out
-python bench.py > $out/bench_massive.json 2>/dev/null
-python bench.py --specialize 0 > $out/bench_massive_interpreter.json 2>/dev/null
-EZPZ_COMP=0 python bench.py --specialize 0 > $out/bench_massive_listwalk.json 2>/dev/null
-python bench.py --batch 4096 --pmc 0 --cpu-seconds 0 --extras 0 > $out/bench_massive_b4096.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 > $out/bench_massive.json 2>/dev/null   # the driver's invocation: headline + legs over every BASELINE config
+python bench.py --specialize 0 --legs 0 > $out/bench_massive_interpreter.json 2>/dev/null
+EZPZ_COMP=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_listwalk.json 2>/dev/null
+EZPZ_JIT_FASTDIV=0 python bench.py --legs 0 --cpu-seconds 0 --extras 0 > $out/bench_massive_plain_divisions.json 2>/dev/null
+python bench.py --batch 4096 --pmc 0 --cpu-seconds 0 --extras 0 --legs 0 > $out/bench_massive_b4096.json 2>/dev/null
 python bench.py --workload massive600 --pmc 0 > $out/bench_massive600.json 2>/dev/null
 python bench.py --workload massive200 --pmc 0 > $out/bench_massive200.json 2>/dev/null
 python bench.py --workload massive500o --pmc 0 > $out/bench_massive500_overconstrained.json 2>/dev/null
@@ -19,6 +20,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 
 find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b16384_kernel_stats.csv; rm -rf $out/stats_m
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s -- python3 bench.py --workload square --batch 65536 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
 find $out/stats_s -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/square_b65536_kernel_stats.csv; rm -rf $out/stats_s
+for w in "mixed 1048576 mixed_1M" "massive50000 64 ladder200k" "sketch150 262144 sketch_300vars_b262144"; do set -- $w
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x -- python3 bench.py --workload $1 --batch $2 --steps 10 --warmup 2 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
+find $out/stats_x -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/$3_kernel_stats.csv; rm -rf $out/stats_x; done
+python tools/reference_benches.py > $out/reference_benches.txt 2>/dev/null
 (echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = batch-throughput launch shape)"; python tools/sketch_scaling.py 8 25 75 150 400 1000 2500 2>&1 | grep npts; echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve)"; TEAM=4294967295 python tools/sketch_scaling.py 25 75 150 250 400 1000 2500 2>&1 | grep npts; echo "# BATCH=262144 (a device-filling batch: from 64 x 2 x CUs systems per call a sketch of more than 20 variables runs one lane per system, batch_kernel.hip.hpp)"; BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts; echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZPZ_LANES=0 BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts) > $out/sketch_scaling.txt
 (echo "# python tools/pcie_bw.py  (host link of the GPU box)"; python tools/pcie_bw.py 2>&1) > $out/pcie_bw.txt
 python tools/ab_microbench.py $out > /dev/null 2>&1
