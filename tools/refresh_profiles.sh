@@ -25,6 +25,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x -- python3 
 find $out/stats_x -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/$3_kernel_stats.csv; rm -rf $out/stats_x; done
 python tools/reference_benches.py > $out/reference_benches.txt 2>/dev/null
 (echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = batch-throughput launch shape)"; python tools/sketch_scaling.py 8 25 75 150 400 1000 2500 2>&1 | grep npts; echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve)"; TEAM=4294967295 python tools/sketch_scaling.py 25 75 150 250 400 1000 2500 2>&1 | grep npts; echo "# BATCH=262144 (a device-filling batch: from 64 x 2 x CUs systems per call a sketch of more than 20 variables runs one lane per system, batch_kernel.hip.hpp)"; BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts; echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZPZ_LANES=0 BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts) > $out/sketch_scaling.txt
+(echo "# python tools/lanes_rounds.py 150 262144  (the jittered sketch150 batch with max_iterations capped: cost of each round of LM iterations on the lanes-across-the-batch kernel)"; python tools/lanes_rounds.py 150 262144 2>&1 | grep cap) > $out/lanes_rounds.txt
+(echo "# EZPZ_LANES_STRAGGLERS=0 python tools/lanes_rounds.py 150 262144  (no hand-over of stragglers to the teams)"; EZPZ_LANES_STRAGGLERS=0 python tools/lanes_rounds.py 150 262144 2>&1 | grep cap) >> $out/lanes_rounds.txt
 (echo "# python tools/pcie_bw.py  (host link of the GPU box)"; python tools/pcie_bw.py 2>&1) > $out/pcie_bw.txt
 python tools/ab_microbench.py $out > /dev/null 2>&1
 (echo "# ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/<case>/problem.md  (the reference CLI's protocol, main.rs:86-100; steady state = the 100-run loop alone)"; for c in tiny square arc_radius two_rectangles massive_parallel_system; do echo "## $c"; ./ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/$c/problem.md | grep -E "Problem size|Iterations|Steady"; done) > $out/cli_latency.txt
