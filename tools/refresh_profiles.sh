@@ -4,8 +4,8 @@
 # same command are filed beside them so that the kernel's average duration can be checked against roofline.kernel_ms.
 out=$1; mkdir -p $out
 python bench.py --steps 20 --warmup 5 > $out/bench_massive.json 2>/dev/null   # the driver's invocation: headline + legs over every BASELINE config
-python bench.py --specialize 0 --legs 0 > $out/bench_massive_interpreter.json 2>/dev/null
-EZPZ_COMP=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_listwalk.json 2>/dev/null
+EZPZ_JIT=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_interpreter.json 2>/dev/null   # (EZPZ_JIT=0: with the on-disk cache a kernel compiled earlier would be picked up)
+EZPZ_JIT=0 EZPZ_COMP=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_listwalk.json 2>/dev/null
 EZPZ_JIT_FASTDIV=0 python bench.py --legs 0 --cpu-seconds 0 --extras 0 > $out/bench_massive_plain_divisions.json 2>/dev/null
 python bench.py --batch 4096 --pmc 0 --cpu-seconds 0 --extras 0 --legs 0 > $out/bench_massive_b4096.json 2>/dev/null
 python bench.py --workload massive600 --pmc 0 > $out/bench_massive600.json 2>/dev/null
@@ -15,8 +15,11 @@ python bench.py --workload square --batch 65536 > $out/bench_square.json 2>/dev/
 python bench.py --workload mixed --batch 1000000 --steps 20 > $out/bench_mixed_1M.json 2>/dev/null
 python bench.py --workload massive50000 --batch 64 --steps 20 > $out/bench_ladder200k.json 2>/dev/null
 python bench.py --workload sketch150 --batch 262144 --steps 10 --warmup 2 > $out/bench_sketch_300vars_b262144.json 2>/dev/null
+python bench.py --workload sketch250 --batch 131072 --steps 5 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_500vars_b131072.json 2>/dev/null
+python bench.py --workload sketch400 --batch 65536 --steps 3 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_800vars_b65536.json 2>/dev/null
+python bench.py --workload sketch1000 --batch 32768 --steps 3 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_2000vars_b32768.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 bench.py --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 bench.py --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
 find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b16384_kernel_stats.csv; rm -rf $out/stats_m
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s -- python3 bench.py --workload square --batch 65536 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
 find $out/stats_s -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/square_b65536_kernel_stats.csv; rm -rf $out/stats_s
