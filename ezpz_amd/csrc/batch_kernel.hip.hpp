@@ -6,7 +6,8 @@
 // topology, so here the 64 lanes of a wavefront are 64 systems running the SAME program -- the class program of
 // comp_program.cpp built for the whole system (constraint records with their parameters, the operation stream of the
 // linear solve) read through the scalar unit, every branch on it a scalar branch -- each lane strictly sequentially
-// on its own system.  No lane ever waits for another: no barriers, no reductions, no LDS.  The state of a wavefront's
+// on its own system.  No lane ever waits for another: no barriers, no reductions (LDS only to transpose the rows of the
+// batch on their way in and out).  The state of a wavefront's
 // 64 systems lives in global memory as rows of 64 doubles (row r, lane l = word 64 r + l): every access is one
 // coalesced 512-byte line, served by L2 / the Infinity Cache / HBM -- this kernel trades the on-chip residency of the
 // list-walk kernels for full lanes, and is bound by that traffic.
@@ -24,7 +25,7 @@ namespace ezpz {
 
 struct BatchArgs {
     const uint32_t* prog;  // the plan's blob
-    uint32_t nv, m, zj, zlo, ncons, n_ops, ops_off, cons_off, var_off;
+    uint32_t nv, m, zj, zlo, ncons, n_ops, ops_off, cons_off, var_off, inv_off;
     uint32_t o_d, o_r, o_rn, o_j, o_dg, o_l, rows;  // rows of a wavefront's workspace: x at 0, b -> y -> d, r, r_next, J, diagonal / tentative x, L
     uint32_t n_cons;                                // unsat mask row
     const double* x0;
@@ -126,6 +127,47 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
         }
     };
 
+    // Rows of the batch move between the caller's AoS layout and the lanes' rows in tiles of eight of the caller's
+    // consecutive variables: a group of eight lanes moves the 64 contiguous bytes of ONE system (whole sectors -- a lane
+    // reading its own system's row alone touched 8 bytes of every 64 it fetched, and the 300 reads of a 300-variable
+    // system were a fifth of the batch's first round), and the wavefront transposes the tile through its own 4.6 KB of LDS
+    // (row pitch 9 doubles: conflict-free both ways; wave-local, in order, no barrier).
+    __shared__ double tiles[4][64 * 9];
+    double* tile = tiles[threadIdx.x >> 6];
+    const int sub = lane & 7, grp = lane >> 3;
+    // `mine`: this lane takes part (its system's row is read / written); rows in: x0 -> P, rows out: P -> x_out
+    auto move_rows = [&](bool mine, bool in) {
+        uint64_t sj[8];
+        bool mj[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            sj[t] = __shfl(sys, 8 * t + grp, 64);
+            mj[t] = __shfl((int)mine, 8 * t + grp, 64) != 0;
+        }
+        for (uint32_t c0 = 0; c0 < a.nv; c0 += 8) {
+            const bool col = c0 + sub < a.nv;
+            if (in) {
+                double v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = (mj[t] && col) ? a.x0[sj[t] * a.nv + c0 + sub] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) tile[(8 * t + grp) * 9 + sub] = v[t];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i)
+                    if (c0 + i < a.nv && mine) P[prog[a.inv_off + c0 + i]] = tile[lane * 9 + i];
+            } else {
+                double v[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) v[i] = (c0 + i < a.nv && mine) ? P[prog[a.inv_off + c0 + i]] : 0.0;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) tile[lane * 9 + i] = v[i];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (mj[t] && col) a.x_out[sj[t] * a.nv + c0 + sub] = tile[(8 * t + grp) * 9 + sub];
+            }
+        }
+    };
+
     for (;;) {
         // ---- refill: idle lanes take the next systems of the batch; eval() for them (newton.rs:45, :232-236) -------------
         const bool want = !have && next < a.batch;
@@ -134,18 +176,9 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
             if (want) {
                 sys = next;
                 next += stride;
-                const double* row = a.x0 + sys * a.nv;
-                // (four loads in flight, then four stores: a plain loop exposes one round trip per variable)
-                for (uint32_t k = 0; k < a.nv; k += 4) {
-                    double t[4];
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) t[q] = k + q < a.nv ? row[prog[a.var_off + k + q]] : 0.0;
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q)
-                        if (k + q < a.nv) P[k + q] = t[q];
-                }
                 nwarn = 0;
             }
+            move_rows(want, true);
             double sq = 0.0, mx = __builtin_nan(""), none = 0.0;
             residual_sweep(P, R, want, want, 0, 0, sq, mx, none);
             if (want) {
@@ -347,16 +380,8 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                     }
                 }
             }
+            move_rows(finish, false);
             if (finish) {
-                double* row = a.x_out + sys * a.nv;
-                for (uint32_t k = 0; k < a.nv; k += 4) {
-                    double t[4];
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) t[q] = k + q < a.nv ? P[k + q] : 0.0;
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q)
-                        if (k + q < a.nv) row[prog[a.var_off + k + q]] = t[q];
-                }
                 EzpzStatus st;
                 st.iterations = iterations;
                 st.converged = converged;

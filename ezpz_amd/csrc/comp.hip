@@ -81,7 +81,7 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
     BatchArgs a{};
     a.prog = dev_blob;
     a.nv = plan.nv, a.m = plan.m, a.zj = plan.zj, a.zlo = plan.zlo, a.ncons = plan.ncons;
-    a.n_ops = plan.n_ops, a.ops_off = plan.ops_off, a.cons_off = plan.cons_off, a.var_off = plan.var_off;
+    a.n_ops = plan.n_ops, a.ops_off = plan.ops_off, a.cons_off = plan.cons_off, a.var_off = plan.var_off, a.inv_off = plan.inv_off;
     a.o_d = plan.o_d, a.o_r = plan.o_r, a.o_rn = plan.o_rn, a.o_j = plan.o_j, a.o_dg = plan.o_dg, a.o_l = plan.o_l, a.rows = plan.rows;
     a.n_cons = n_cons;
     a.x0 = L.x0;

@@ -839,6 +839,13 @@ bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Batc
     plan.var_off = (uint32_t)plan.blob.size();
     plan.blob.insert(plan.blob.end(), Q.var_of.begin(), Q.var_of.end());
     plan.blob.resize(plan.blob.size() + 16, 0);
+    // ... and its inverse: the state row of the caller's variable c (the rows of a batch are moved in tiles of eight of the
+    // caller's consecutive variables, batch_kernel.hip.hpp)
+    plan.inv_off = (uint32_t)plan.blob.size();
+    std::vector<uint32_t> inv(Q.var_of.size(), 0);
+    for (uint32_t k = 0; k < (uint32_t)Q.var_of.size(); ++k) inv[Q.var_of[k]] = k;
+    plan.blob.insert(plan.blob.end(), inv.begin(), inv.end());
+    plan.blob.resize(plan.blob.size() + 16, 0);
     plan.nv = Q.c.n_vars, plan.m = Q.c.n_rows, plan.zj = Q.c.zj, plan.zlo = Q.c.zlo, plan.ncons = Q.c.n_cons;
     plan.n_ops = cl.H.n_ops, plan.ops_off = cl.H.ops_off, plan.cons_off = cl.H.cons_off;
     plan.o_d = plan.nv;

@@ -140,7 +140,7 @@ bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LaneP
 // program of the whole system (parameters in the constraint records, records in request order) + the workspace layout.
 struct BatchPlan {
     std::vector<uint32_t> blob;
-    uint32_t nv = 0, m = 0, zj = 0, zlo = 0, ncons = 0, n_ops = 0, ops_off = 0, cons_off = 0, var_off = 0;
+    uint32_t nv = 0, m = 0, zj = 0, zlo = 0, ncons = 0, n_ops = 0, ops_off = 0, cons_off = 0, var_off = 0, inv_off = 0;
     uint32_t o_d = 0, o_r = 0, o_rn = 0, o_j = 0, o_dg = 0, o_l = 0, rows = 0;  // workspace rows of 64 doubles per wavefront
     bool unit_weights = true;
 };
