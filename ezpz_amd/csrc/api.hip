@@ -479,74 +479,9 @@ bool jit_sync() {
     return sync;
 }
 
-int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
-    if (args.batch == 0) return EZPZ_OK;
-    // enqueueing on one EzpzSystem from several threads (each on its own stream) is allowed: what a launch creates on
-    // first use -- workspaces, events, occupancy figures -- is created under this lock, and launches that share a
-    // workspace are chained on an event below
-    std::lock_guard<std::mutex> launch_lock(s.launch_mu);
-    constexpr uint64_t kNoLanesWorkspace = ~0ull;  // the allocation failed once: not tried again on every call
-    bool stragglers = false;  // the teams below serve what a lanes launch left over
-    if (s.lanes && args.batch >= s.lanes_min) {  // a device-filling batch of one connected sketch: lanes across the batch
-        if (s.lanes_ws_waves == 0) {
-            // one workspace per wavefront the device holds (capped at 24 GiB of the 288: fewer wavefronts then)
-            uint64_t waves = batch_launch_waves(s.lim.cus);
-            const uint64_t per = (uint64_t)s.lanes->rows * 512;
-            while (waves > 4 && waves * per > (24ull << 30)) waves /= 2;
-            s.lanes_ws_waves = s.lanes_ws.ensure((size_t)(waves * per / 8)) == EZPZ_OK ? waves : kNoLanesWorkspace;
-        }
-        if (s.lanes_ws_waves != kNoLanesWorkspace) {
-            // one workspace per system object: launches on different streams are chained, never overlapped
-            if (!s.lanes_done)
-                HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
-            else
-                HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
-            // the systems the lanes give up (stragglers, batch_kernel.hip.hpp) are listed on the device and solved from their
-            // guesses by this system's list-walk teams right after: an indirect batch whose count stays on the device
-            const uint32_t strag_cap = args.batch < (1ull << 32) && args.batch >= 256
-                                           ? (uint32_t)std::min<uint64_t>(args.batch, std::max<uint64_t>(4096, args.batch / 8)) : 0u;
-            bool list_ok = strag_cap && s.strag_list.ensure(strag_cap) == EZPZ_OK && s.strag_count.ensure(1) == EZPZ_OK;
-            if (list_ok && hipMemsetAsync(s.strag_count.p, 0, sizeof(uint32_t), stream) != hipSuccess) {
-                (void)hipGetLastError();
-                list_ok = false;
-            }
-            if (batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream,
-                             list_ok ? s.strag_list.p : nullptr, list_ok ? s.strag_count.p : nullptr, list_ok ? strag_cap : 0u) == EZPZ_OK) {
-                HIP_TRY(hipEventRecord(s.lanes_done, stream));
-                if (!list_ok) return EZPZ_OK;
-                args.sys_list = s.strag_list.p;
-                args.sys_count = s.strag_count.p;
-                args.batch = strag_cap;
-                stragglers = true;
-            }
-        }
-    }
-    if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
-    if (!stragglers && s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
-        int st = comp_jit_state(s.jit);
-        if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, jit_sync());
-        if (st == 2 && lane_jit_launch(s.jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
-    }
-    if (!stragglers && s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
-        const CompLaunch L = comp_launch_args(args);
-        // the class-specialised kernel once it is compiled; large batches start its compilation (background thread)
-        if (s.jit) {
-            const bool sync = jit_sync();
-            int st = comp_jit_state(s.jit);
-            const bool big = args.batch >= 1024 || args.batch * (uint64_t)s.counts.n_vars >= (1ull << 21);
-            if (st == 0 && (big || sync || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, sync);
-            if (st == 2) {
-                if (s.comp->jit_wgs <= 1) {
-                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
-                } else if (launch_jit_grid(s, L, stream) == EZPZ_OK) {
-                    return EZPZ_OK;
-                }
-            }
-        }
-        if (s.comp->interpretable) return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
-        // (a system too large for the interpreter's LDS state: the list-walk grid team below until the specialised
-        // kernel is ready)
-    }
+// The list-walk teams of a system (lm_kernel.hip.hpp), whatever their shape: sub-wavefront teams, workgroups with their
+// workspace in LDS or in global memory, grid teams.  (launch() holds the system's launch lock.)
+int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     uint32_t grid;
     if (s.mode == MODE_SUB) {
         const uint32_t tpb = s.block_threads / s.team_size;
@@ -589,6 +524,80 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                       : launch_variant<64, MODE_PART, true, false>(s, args, grid, stream);
     return staged ? launch_variant<64, MODE_WGB, true, true>(s, args, grid, stream)
                   : launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream);
+}
+
+int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
+    if (args.batch == 0) return EZPZ_OK;
+    // enqueueing on one EzpzSystem from several threads (each on its own stream) is allowed: what a launch creates on
+    // first use -- workspaces, events, occupancy figures -- is created under this lock, and launches that share a
+    // workspace are chained on an event below
+    std::lock_guard<std::mutex> launch_lock(s.launch_mu);
+    constexpr uint64_t kNoLanesWorkspace = ~0ull;  // the allocation failed once: not tried again on every call
+    if (s.lanes && args.batch >= s.lanes_min) {  // a device-filling batch of one connected sketch: lanes across the batch
+        if (s.lanes_ws_waves == 0) {
+            // one workspace per wavefront the device holds (capped at 24 GiB of the 288: fewer wavefronts then)
+            uint64_t waves = batch_launch_waves(s.lim.cus);
+            const uint64_t per = (uint64_t)s.lanes->rows * 512;
+            while (waves > 4 && waves * per > (24ull << 30)) waves /= 2;
+            s.lanes_ws_waves = s.lanes_ws.ensure((size_t)(waves * per / 8)) == EZPZ_OK ? waves : kNoLanesWorkspace;
+        }
+        if (s.lanes_ws_waves != kNoLanesWorkspace) {
+            // one workspace per system object: launches on different streams are chained, never overlapped
+            if (!s.lanes_done)
+                HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
+            else
+                HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
+            // the systems the lanes give up (stragglers, batch_kernel.hip.hpp) are listed on the device and solved from their
+            // guesses by this system's list-walk teams right after: an indirect batch whose count stays on the device
+            const uint32_t strag_cap = args.batch < (1ull << 32) && args.batch >= 256
+                                           ? (uint32_t)std::min<uint64_t>(args.batch, std::max<uint64_t>(4096, args.batch / 8)) : 0u;
+            bool list_ok = strag_cap && s.strag_list.ensure(strag_cap) == EZPZ_OK && s.strag_count.ensure(1) == EZPZ_OK;
+            if (list_ok && hipMemsetAsync(s.strag_count.p, 0, sizeof(uint32_t), stream) != hipSuccess) {
+                (void)hipGetLastError();
+                list_ok = false;
+            }
+            if (batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream,
+                             list_ok ? s.strag_list.p : nullptr, list_ok ? s.strag_count.p : nullptr, list_ok ? strag_cap : 0u) == EZPZ_OK) {
+                int rc = EZPZ_OK;
+                if (list_ok) {
+                    args.sys_list = s.strag_list.p;
+                    args.sys_count = s.strag_count.p;
+                    args.batch = strag_cap;
+                    rc = launch_list_walk(s, args, stream);
+                }
+                // (after the teams: the next launch of this system, on whatever stream, resets the list's count)
+                HIP_TRY(hipEventRecord(s.lanes_done, stream));
+                return rc;
+            }
+        }
+    }
+    if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
+    if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
+        int st = comp_jit_state(s.jit);
+        if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, jit_sync());
+        if (st == 2 && lane_jit_launch(s.jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+    }
+    if (s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
+        const CompLaunch L = comp_launch_args(args);
+        // the class-specialised kernel once it is compiled; large batches start its compilation (background thread)
+        if (s.jit) {
+            const bool sync = jit_sync();
+            int st = comp_jit_state(s.jit);
+            const bool big = args.batch >= 1024 || args.batch * (uint64_t)s.counts.n_vars >= (1ull << 21);
+            if (st == 0 && (big || sync || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, sync);
+            if (st == 2) {
+                if (s.comp->jit_wgs <= 1) {
+                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+                } else if (launch_jit_grid(s, L, stream) == EZPZ_OK) {
+                    return EZPZ_OK;
+                }
+            }
+        }
+        if (s.comp->interpretable) return comp_launch(*s.comp, s.dev_comp, L, s.device, s.lim.cus, s.lim.lds_bytes, stream);
+        // (a system too large for the interpreter's LDS state: the list-walk grid team below until the specialised
+        // kernel is ready)
+    }
+    return launch_list_walk(s, args, stream);
 }
 
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only (tools/stamps.py sets it through ezpz_debug_set_stamps)
