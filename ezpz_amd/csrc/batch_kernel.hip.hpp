@@ -293,6 +293,59 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
                         if (k < ni) acc -= va[k] * vb[k];
                     if (last) L[oa] = acc / ((rec.w[0] & kCompDivReg) ? dcur : S[ob]);
                     break;
+                case COMP_DIAGCOL: {  // a column whose assembly and elimination fit one record: one round trip instead of two
+                    const uint32_t n0 = rec.w[0] >> 24;
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k) {
+                        va[k] = vb[k] = 0.0;
+                        if (k < ni) {
+                            const uint32_t ia = rec.w[2 + k] & 0xFFFFu, ib = rec.w[2 + k] >> 16;
+                            va[k] = k < n0 ? J[ia] : L[ia];
+                            vb[k] = k < n0 ? R[ib] : V[ib];
+                        }
+                    }
+                    acc = 0.0, y = 0.0;
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k < n0) {
+                            acc += va[k] * va[k];
+                            y += va[k] * -vb[k];
+                        }
+                    acc = acc + lambda;  // newton.rs:77-84
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k >= n0 && k < ni) {
+                            acc -= va[k] * va[k];
+                            y -= va[k] * vb[k];
+                        }
+                    if (!(acc > 0.0)) bad = true;  // LltError::Numeric: non-positive pivot (newton.rs:93-99)
+                    const double dv = sqrt(acc);
+                    dcur = dv;
+                    S[oa] = dv;
+                    V[oa] = y / dv;
+                    break;
+                }
+                case COMP_SLOTA: {  // likewise a slot: its entry of JtJ, the update, the division by d_j (in `dcur`)
+                    const uint32_t n0 = rec.w[0] >> 24;
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k) {
+                        va[k] = vb[k] = 0.0;
+                        if (k < ni) {
+                            const uint32_t ia = rec.w[2 + k] & 0xFFFFu, ib = rec.w[2 + k] >> 16;
+                            va[k] = k < n0 ? J[ia] : L[ia];
+                            vb[k] = k < n0 ? J[ib] : L[ib];
+                        }
+                    }
+                    acc = 0.0;
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k < n0) acc += va[k] * vb[k];
+#pragma unroll
+                    for (uint32_t k = 0; k < kCompItemsGen; ++k)
+                        if (k >= n0 && k < ni) acc -= va[k] * vb[k];
+                    L[oa] = acc / dcur;
+                    break;
+                }
                 case COMP_BWD:
                     if (first) acc = V[oa];
                     LOAD_ITEMS(L, V)

@@ -171,14 +171,42 @@ void emit_class_program(std::vector<uint32_t>& blob, Class& cl, bool LIN, const 
     if (fuse) {
         // column by column in elimination order (the numbering is level-major, so every entry a column reads is done): its
         // diagonal, then the slots below it while d_j is still in a register
+        // (an entry's assembly and its elimination share ONE record when their items fit it: COMP_DIAGCOL / COMP_SLOTA)
+        auto emit_merged = [&](uint32_t opcode, uint32_t a, uint32_t n0) {
+            uint32_t rec[kCompRecWords] = {0, 0, 0, 0, 0, 0, 0, 0};
+            rec[0] = opcode | ((uint32_t)items.size() << 8) | kCompFirst | kCompLast | (n0 << 24);
+            rec[1] = a;
+            for (size_t k = 0; k < items.size(); ++k) rec[2 + k] = items[k];
+            ops.insert(ops.end(), rec, rec + kCompRecWords);
+        };
         for (uint32_t v = 0; v < nv; ++v) {
-            emit_diag(v);
-            items.clear();
-            for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
-                items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
-            emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr, kCompCont, 0);
+            const uint32_t nd = Q.colj_ptr[v + 1] - Q.colj_ptr[v], nc = Q.fwd_ptr[v + 1] - Q.fwd_ptr[v];
+            if (nd + nc <= kCompItemsGen) {
+                items.clear();
+                for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q)
+                    items.push_back(Q.colj_items[2 * q] | (Q.colj_items[2 * q + 1] << 16));
+                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
+                    items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
+                emit_merged(COMP_DIAGCOL, v, nd);
+            } else {
+                emit_diag(v);
+                items.clear();
+                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
+                    items.push_back(Q.fwd_items[2 * q] | (Q.fwd_items[2 * q + 1] << 16));
+                emit_op(ops, COMP_COL, v, 0, items, 1, kCompItemsGen, 2, nullptr, kCompCont, 0);
+            }
             for (uint32_t qs = Q.bwd_ptr[v]; qs < Q.bwd_ptr[v + 1]; ++qs) {
                 const uint32_t s = Q.bwd_items[2 * qs];
+                const uint32_t na = Q.apair_ptr[s + 1] - Q.apair_ptr[s], nl = Q.lpair_ptr[s + 1] - Q.lpair_ptr[s];
+                if (na + nl <= kCompItemsGen) {
+                    items.clear();
+                    for (uint32_t q = Q.apair_ptr[s]; q < Q.apair_ptr[s + 1]; ++q)
+                        items.push_back(Q.apairs[2 * q] | (Q.apairs[2 * q + 1] << 16));
+                    for (uint32_t q = Q.lpair_ptr[s]; q < Q.lpair_ptr[s + 1]; ++q)
+                        items.push_back(Q.lpairs[2 * q] | (Q.lpairs[2 * q + 1] << 16));
+                    emit_merged(COMP_SLOTA, s, na);
+                    continue;
+                }
                 emit_off(s);
                 items.clear();
                 for (uint32_t q = Q.lpair_ptr[s]; q < Q.lpair_ptr[s + 1]; ++q)
@@ -863,9 +891,9 @@ bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Batc
             items[w & 7u] += (w >> 8) & 0xFFu;
         }
         std::fprintf(stderr, "[ezpz lanes] nv %u m %u zj %u zlo %u rows %u ops %u |", plan.nv, plan.m, plan.zj, plan.zlo, plan.rows, plan.n_ops);
-        const char* names[] = {"DIAG", "OFF", "COL", "SLOT", "BWD"};
-        const uint32_t codes[] = {COMP_DIAG, COMP_OFF, COMP_COL, COMP_SLOT, COMP_BWD};
-        for (int k = 0; k < 5; ++k)
+        const char* names[] = {"DIAG", "OFF", "COL", "SLOT", "BWD", "DIAGCOL", "SLOTA"};
+        const uint32_t codes[] = {COMP_DIAG, COMP_OFF, COMP_COL, COMP_SLOT, COMP_BWD, COMP_DIAGCOL, COMP_SLOTA};
+        for (int k = 0; k < 7; ++k)
             std::fprintf(stderr, " %s %llu recs %llu items", names[k], (unsigned long long)recs[codes[k] & 7u], (unsigned long long)items[codes[k] & 7u]);
         std::fputc('\n', stderr);
     }

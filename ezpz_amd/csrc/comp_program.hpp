@@ -36,7 +36,12 @@ namespace ezpz {
 //   BWD   a = variable v          items (L slot of (i,v), variable i):  dx_v = (y_v - sum l dx_i) / d_v
 // Linear build (every kind linear, Jacobian entries are class constants): DIAG carries sum j^2 in w2:w3 and up to two
 // items (row, j as f32) in w4..w7; OFF carries its constant in w2:w3.
-enum CompOpcode : uint32_t { COMP_DIAG = 1, COMP_OFF = 2, COMP_COL = 3, COMP_SLOT = 4, COMP_BWD = 5 };
+// Fused streams only (one lane per system): a column's DIAG + COL, and a slot's OFF + SLOT, as ONE record when their
+// items fit it -- every record is a round trip to memory for the lane, and the assembly records hold ~1 item of 6:
+//   DIAGCOL a = variable v     items [0, n0): (Jacobian slot, residual row), [n0, n): (L slot of (v,k), variable k)
+//   SLOTA   a = L slot s       items [0, n0): (Jacobian slot, slot),         [n0, n): (L slot (i,k), L slot (j,k));  n0 = w0 >> 24
+// (same operations in the same order as the two records they replace)
+enum CompOpcode : uint32_t { COMP_DIAG = 1, COMP_OFF = 2, COMP_COL = 3, COMP_SLOT = 4, COMP_BWD = 5, COMP_DIAGCOL = 6, COMP_SLOTA = 7 };
 constexpr uint32_t kCompRecWords = 8;
 constexpr uint32_t kCompItemsGen = 6, kCompItemsLin = 2;
 constexpr uint32_t kCompFirst = 1u << 16, kCompLast = 2u << 16;
