@@ -16,7 +16,6 @@ python bench.py --workload mixed --batch 1000000 --steps 20 > $out/bench_mixed_1
 python bench.py --workload massive50000 --batch 64 --steps 20 > $out/bench_ladder200k.json 2>/dev/null
 python bench.py --workload sketch150 --batch 262144 --steps 10 --warmup 2 > $out/bench_sketch_300vars_b262144.json 2>/dev/null
 python bench.py --workload sketch250 --batch 131072 --steps 5 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_500vars_b131072.json 2>/dev/null
-python bench.py --workload sketch400 --batch 65536 --steps 3 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_800vars_b65536.json 2>/dev/null
 python bench.py --workload sketch1000 --batch 32768 --steps 3 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_2000vars_b32768.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 bench.py --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
