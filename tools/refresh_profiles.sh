@@ -15,8 +15,6 @@ python bench.py --workload square --batch 65536 > $out/bench_square.json 2>/dev/
 python bench.py --workload mixed --batch 1000000 --steps 20 > $out/bench_mixed_1M.json 2>/dev/null
 python bench.py --workload massive50000 --batch 64 --steps 20 > $out/bench_ladder200k.json 2>/dev/null
 python bench.py --workload sketch150 --batch 262144 --steps 10 --warmup 2 > $out/bench_sketch_300vars_b262144.json 2>/dev/null
-python bench.py --workload sketch250 --batch 131072 --steps 5 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_500vars_b131072.json 2>/dev/null
-python bench.py --workload sketch1000 --batch 32768 --steps 3 --warmup 1 --extras 0 --cpu-seconds 0 > $out/bench_sketch_2000vars_b32768.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 bench.py --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
 find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b16384_kernel_stats.csv; rm -rf $out/stats_m
@@ -26,7 +24,7 @@ for w in "mixed 1048576 mixed_1M" "massive50000 64 ladder200k" "sketch150 262144
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x -- python3 bench.py --workload $1 --batch $2 --steps 10 --warmup 2 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
 find $out/stats_x -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/$3_kernel_stats.csv; rm -rf $out/stats_x; done
 python tools/reference_benches.py > $out/reference_benches.txt 2>/dev/null
-(echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = batch-throughput launch shape)"; python tools/sketch_scaling.py 8 25 75 150 400 1000 2500 2>&1 | grep npts; echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve)"; TEAM=4294967295 python tools/sketch_scaling.py 25 75 150 250 400 1000 2500 2>&1 | grep npts; echo "# BATCH=262144 (a device-filling batch: from 64 x 2 x CUs systems per call a sketch of more than 20 variables runs one lane per system, batch_kernel.hip.hpp)"; BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts; echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZPZ_LANES=0 BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts) > $out/sketch_scaling.txt
+(echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = batch-throughput launch shape)"; python tools/sketch_scaling.py 8 25 75 150 400 1000 2500 2>&1 | grep npts; echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve)"; TEAM=4294967295 python tools/sketch_scaling.py 25 75 150 250 400 1000 2500 2>&1 | grep npts; echo "# BATCH=262144 (a device-filling batch: from 64 x 2 x CUs systems per call a sketch of more than 20 variables runs one lane per system, batch_kernel.hip.hpp)"; BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts; echo "# BATCH=65536 / 32768 (larger sketches on the lanes: 500, 800 and 2000 variables)"; BATCH=65536 python tools/sketch_scaling.py 250 400 2>&1 | grep npts; BATCH=32768 python tools/sketch_scaling.py 1000 2>&1 | grep npts; echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZPZ_LANES=0 BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts) > $out/sketch_scaling.txt
 (echo "# python tools/lanes_rounds.py 150 262144  (the jittered sketch150 batch with max_iterations capped: cost of each round of LM iterations on the lanes-across-the-batch kernel)"; python tools/lanes_rounds.py 150 262144 2>&1 | grep cap) > $out/lanes_rounds.txt
 (echo "# EZPZ_LANES_STRAGGLERS=0 python tools/lanes_rounds.py 150 262144  (no hand-over of stragglers to the teams)"; EZPZ_LANES_STRAGGLERS=0 python tools/lanes_rounds.py 150 262144 2>&1 | grep cap) >> $out/lanes_rounds.txt
 (echo "# python tools/pcie_bw.py  (host link of the GPU box)"; python tools/pcie_bw.py 2>&1) > $out/pcie_bw.txt
