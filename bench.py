@@ -387,10 +387,27 @@ def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, b
     pass at N = 1)."""
     import numpy as np
 
-    w = Workload(E, torch, name, batch, device_index, dev, args.team, args.specialize, rank)
-    ran = w.warm_to_steady_state(2)
+    # (N > 1: a rank that cannot set the leg up must not leave the others waiting at the leg's barriers -- every rank says
+    # whether it is ready, and the leg runs only if all are)
+    w, ran, failure = None, 0, None
+    try:
+        w = Workload(E, torch, name, batch, device_index, dev, args.team, args.specialize, rank)
+        ran = w.warm_to_steady_state(2)
+    except Exception as exc:  # noqa: BLE001
+        failure = repr(exc)[:300]
+    if world > 1:
+        ready = torch.tensor([0.0 if failure else 1.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if float(ready[0]) < 1.0 and not failure:
+            failure = "another rank could not set this leg up"
+    if failure:
+        return {"workload": name, "error": failure}
     one = w._window(1)
     steps = int(min(200, max(5, math.ceil(50.0 / max(one, 1e-3)))))  # ~50 ms of launches
+    if world > 1:  # the same number of launches on every rank
+        st_ = torch.tensor([float(steps)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(st_, op=dist.ReduceOp.MAX)
+        steps = int(st_[0])
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -428,6 +445,91 @@ def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, b
             out["roofline"]["roof_violation"] = r["roof_violation"]
     out["results_ok"] = ok
     return out
+
+
+def rank0_extras(E, torch, np, args, extras, w, dev, stream):
+    """Rank 0's extras (never part of `value`): the host-pointer entry point, single-solve latencies, FreedomAnalysis.
+    Fills `extras`, returns value_host_to_host."""
+    parts, B = w.parts, args.batch
+    p0 = parts[0]
+    records, guesses, n, system = p0["records"], p0["guesses"], p0["n"], p0["system"]
+    x0_host, x0, x_out = p0["x0_host"], p0["x0"], p0["x_out"]
+    value_h2h = None
+    import ctypes as C
+
+    hb = min(B, 65536)  # the same systems per call as `value`
+    hx = np.ascontiguousarray(x0_host[:hb])
+    hxo = np.empty_like(hx)
+    hst = np.zeros(hb, dtype=E.STATUS_DTYPE)
+    hcfg = E.Config()._c()
+
+    def host_call():
+        rc = E.lib().ezpz_system_solve_batch(system._h, hx.ctypes.data, hb, C.byref(hcfg), hxo.ctypes.data,
+                                             hst.ctypes.data, None, None, 0)
+        assert rc == 0, rc
+
+    def rate(reps):
+        host_call()
+        host_call()
+        th = time.perf_counter()
+        for _ in range(reps):
+            host_call()
+        return reps * hb / (time.perf_counter() - th)
+
+    # pageable buffers first, then the same buffers page-locked once (ezpz_host_register: what a caller that
+    # reuses its buffers does); `value_host_to_host` is the registered rate
+    extras["host_to_host_pageable_solves_per_s"] = rate(3)
+    E.host_register(hx)
+    E.host_register(hxo)
+    try:
+        value_h2h = rate(8)
+    finally:
+        E.host_unregister(hx)
+        E.host_unregister(hxo)
+    extras["host_to_host_batch"] = hb
+    extras["host_to_host_results_equal_device_path"] = bool(
+        np.array_equal(hxo, x_out[:hb].cpu().numpy()) if len(parts) == 1 else True)
+    # (2) one system per launch, back to back on the stream: device-side latency of a single solve
+    one_x = x0[:1].clone()
+    one_o = torch.empty_like(one_x)
+    one_s = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+    for _ in range(10):
+        system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    tl = time.perf_counter()
+    for _ in range(200):
+        system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    extras["single_solve_latency_us"] = (time.perf_counter() - tl) / 200 * 1e6
+    # (2a) one full ezpz_solve() call from host buffers (the reference's solve(): lint + Model::new + LM +
+    # unsatisfied check): warm = topology served from the cache, cold = cache cleared before every call
+    E.solve_records(records, guesses)
+    tw = time.perf_counter()
+    for _ in range(50):
+        E.solve_records(records, guesses)
+    extras["full_solve_call_us_warm"] = (time.perf_counter() - tw) / 50 * 1e6
+    tc = 0.0
+    for _ in range(5):
+        E.lib().ezpz_cache_clear()
+        t_ = time.perf_counter()
+        E.solve_records(records, guesses)
+        tc += time.perf_counter() - t_
+    extras["full_solve_call_us_cold"] = tc / 5 * 1e6
+    # (2b) FreedomAnalysis (find_dof.rs) of the solved batch, device to device
+    Bf = p0["B"]
+    fa_mask = torch.zeros((Bf, n), dtype=torch.uint8, device=dev)
+    fa_cnt = torch.zeros(Bf, dtype=torch.int32, device=dev)
+    fa = lambda: system.freedom_batch_device(x_out.data_ptr(), Bf, fa_mask.data_ptr(), 0, fa_cnt.data_ptr(),
+                                             stream.cuda_stream)
+    fa()
+    torch.cuda.synchronize(dev)
+    tf = time.perf_counter()
+    for _ in range(5):
+        fa()
+    torch.cuda.synchronize(dev)
+    extras["freedom_analyses_per_s"] = 5 * Bf / (time.perf_counter() - tf)
+    extras["underconstrained_systems"] = int((fa_cnt > 0).sum().item())
+    return value_h2h
 
 
 def main():
@@ -505,82 +607,12 @@ def main():
     value_h2h = None
     if args.extras:
         # (1) host-pointer entry point: H2D + kernel + D2H per call -- SURVEY 8(d)'s "results back on host"
-        if rank == 0:
-            # (the C ABI itself, into buffers allocated once: what a host-language caller does)
-            import ctypes as C
-
-            hb = min(B, 65536)  # the same systems per call as `value`
-            hx = np.ascontiguousarray(x0_host[:hb])
-            hxo = np.empty_like(hx)
-            hst = np.zeros(hb, dtype=E.STATUS_DTYPE)
-            hcfg = E.Config()._c()
-
-            def host_call():
-                rc = E.lib().ezpz_system_solve_batch(system._h, hx.ctypes.data, hb, C.byref(hcfg), hxo.ctypes.data,
-                                                     hst.ctypes.data, None, None, 0)
-                assert rc == 0, rc
-
-            def rate(reps):
-                host_call()
-                host_call()
-                th = time.perf_counter()
-                for _ in range(reps):
-                    host_call()
-                return reps * hb / (time.perf_counter() - th)
-
-            # pageable buffers first, then the same buffers page-locked once (ezpz_host_register: what a caller that
-            # reuses its buffers does); `value_host_to_host` is the registered rate
-            extras["host_to_host_pageable_solves_per_s"] = rate(3)
-            E.host_register(hx)
-            E.host_register(hxo)
-            try:
-                value_h2h = rate(8)
-            finally:
-                E.host_unregister(hx)
-                E.host_unregister(hxo)
-            extras["host_to_host_batch"] = hb
-            extras["host_to_host_results_equal_device_path"] = bool(
-                np.array_equal(hxo, x_out[:hb].cpu().numpy()) if len(parts) == 1 else True)
-            # (2) one system per launch, back to back on the stream: device-side latency of a single solve
-            one_x = x0[:1].clone()
-            one_o = torch.empty_like(one_x)
-            one_s = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
-            for _ in range(10):
-                system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
-            torch.cuda.synchronize(dev)
-            tl = time.perf_counter()
-            for _ in range(200):
-                system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
-            torch.cuda.synchronize(dev)
-            extras["single_solve_latency_us"] = (time.perf_counter() - tl) / 200 * 1e6
-            # (2a) one full ezpz_solve() call from host buffers (the reference's solve(): lint + Model::new + LM +
-            # unsatisfied check): warm = topology served from the cache, cold = cache cleared before every call
-            E.solve_records(records, guesses)
-            tw = time.perf_counter()
-            for _ in range(50):
-                E.solve_records(records, guesses)
-            extras["full_solve_call_us_warm"] = (time.perf_counter() - tw) / 50 * 1e6
-            tc = 0.0
-            for _ in range(5):
-                E.lib().ezpz_cache_clear()
-                t_ = time.perf_counter()
-                E.solve_records(records, guesses)
-                tc += time.perf_counter() - t_
-            extras["full_solve_call_us_cold"] = tc / 5 * 1e6
-            # (2b) FreedomAnalysis (find_dof.rs) of the solved batch, device to device
-            Bf = p0["B"]
-            fa_mask = torch.zeros((Bf, n), dtype=torch.uint8, device=dev)
-            fa_cnt = torch.zeros(Bf, dtype=torch.int32, device=dev)
-            fa = lambda: system.freedom_batch_device(x_out.data_ptr(), Bf, fa_mask.data_ptr(), 0, fa_cnt.data_ptr(),
-                                                     stream.cuda_stream)
-            fa()
-            torch.cuda.synchronize(dev)
-            tf = time.perf_counter()
-            for _ in range(5):
-                fa()
-            torch.cuda.synchronize(dev)
-            extras["freedom_analyses_per_s"] = 5 * Bf / (time.perf_counter() - tf)
-            extras["underconstrained_systems"] = int((fa_cnt > 0).sum().item())
+        # (rank 0 only, and never fatal: at N > 1 the other ranks are waiting for it in the collective extra below)
+        try:
+            if rank == 0:
+                value_h2h = rank0_extras(E, torch, np, args, extras, w, dev, stream)
+        except Exception as exc:  # noqa: BLE001
+            extras["rank0_extras_error"] = repr(exc)[:300]
         # (3) N>1: whole batch starts and ends on rank 0; one RCCL scatter + one gather around the solve
         if distributed and backend == "nccl" and len(parts) == 1:
             from ezpz_amd.distributed import solve_batch_sharded
