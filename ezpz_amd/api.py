@@ -665,7 +665,7 @@ class System:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # (at interpreter shutdown the module's globals may be gone already)
             lib().ezpz_system_destroy(h)
             self._h = None
 
@@ -780,7 +780,7 @@ class MultiSystem:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:
             lib().ezpz_multi_destroy(h)
             self._h = None
 
