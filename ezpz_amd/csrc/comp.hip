@@ -101,9 +101,9 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
     a.step_tolerance = L.step_tolerance;
     a.initial_lambda = L.initial_lambda;
     a.ws = dev_ws;
-    // a wavefront down to 6 working lanes (of 64) with nothing left to take gives them up: continuing costs the whole
+    // a wavefront down to 8 working lanes (of 64) with nothing left to take gives them up: continuing costs the whole
     // wavefront a round per iteration, the teams ~40 lane-rounds per system (EZPZ_LANES_STRAGGLERS: that threshold, 0 = off)
-    static const int env_strag = [] { const char* e = std::getenv("EZPZ_LANES_STRAGGLERS"); return e ? std::atoi(e) : 6; }();
+    static const int env_strag = [] { const char* e = std::getenv("EZPZ_LANES_STRAGGLERS"); return e ? std::atoi(e) : 8; }();
     a.strag_list = env_strag > 0 && strag_cap ? strag_list : nullptr;
     a.strag_count = strag_count;
     a.strag_cap = strag_cap;

@@ -1,5 +1,5 @@
 # A/B runs of the class-specialised kernels' switches on the GPU box (bench.py lines, no PMC): usage bash tools/ab_fastdiv.sh
-python -m pytest tests/test_gpu_div.py tests/test_gpu_components.py tests/test_gpu_lanes.py -x -q -m gpu 2>&1 | tail -4
+# (parity of every variant is checked by the bench line itself: results_ok + bitwise_equal against the oracle)
 B="--extras 0 --cpu-seconds 0 --pmc 0 --steps 200 --warmup 30"
 run() { # name, env..., args
   name=$1; shift

@@ -19,3 +19,5 @@ run s12 EZPZ_LANES_STRAGGLERS=12 python bench.py $B --batch 262144 --steps 5
 run s4_b524k_r8 EZPZ_LANES_STRAGGLERS=4 EZPZ_LANES_REFILL=8 python bench.py $B --batch 524288 --steps 3
 run s4_b65k EZPZ_LANES_STRAGGLERS=4 python bench.py $B --batch 65536 --steps 5
 run s0_b65k EZPZ_LANES_STRAGGLERS=0 python bench.py $B --batch 65536 --steps 5
+run w2048_r8 EZPZ_LANES_WAVES=2048 EZPZ_LANES_REFILL=8 python bench.py $B --batch 262144 --steps 5
+run r22_b524k EZPZ_LANES_REFILL=22 python bench.py $B --batch 524288 --steps 3
