@@ -1499,7 +1499,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     //      systems: 32 768 on the MI355X; measured at 16 384 / 24 576 / 32 768 / 65 536 / 262 144 systems of 300 variables:
     //      1.06 / 1.53 / 2.00 / 3.70 / 9.4 M solves/s against the teams' 1.50 M); smaller batches keep the teams.
     s.lanes.reset();
-    s.lanes_min = batch_lanes ? 1 : 64ull * 2 * (s.lim.cus ? s.lim.cus : 256);
+    // (sketches of up to 64 variables: twice that -- their rounds are short, the lanes' time is a latency floor of ~3 ms
+    // whatever the batch, and the teams run them at 12-19 M solves/s: 32 768 systems of 50 variables 9.8 M/s on the lanes)
+    s.lanes_min = batch_lanes ? 1 : 64ull * (n_vars <= 64 ? 4 : 2) * (s.lim.cus ? s.lim.cus : 256);
     static const bool lanes_enabled = [] {
         const char* e = std::getenv("EZPZ_LANES");
         return !(e && e[0] == '0');
