@@ -81,3 +81,32 @@ def test_one_million_mixed_systems_full_size(E):
             assert np.array_equal(st2["iterations"], st["iterations"]) and np.all(st2["n_unsatisfied"] == 0), name
             rel2 = np.abs(x2[sample] - xo) / np.maximum(1.0, np.abs(xo))
             assert np.max(np.where(free, 0.0, rel2)) <= 1e-6, name
+
+
+def test_quarter_million_jittered_sketches_on_the_lanes_full_size(E):
+    """The connected-sketch leg of bench.py at its full size: 262 144 jittered starts of one 300-variable sketch -- one
+    system per lane of the 4096 wavefronts the device holds, 4 to 19 LM iterations each.  Every system converges with every
+    constraint satisfied, and a sample against the oracle with the measured bar of tests/sensitivity.py: spread over the
+    batch, plus the systems with the MOST iterations -- the stragglers whose wavefronts handed them to the per-system
+    teams (batch_kernel.hip.hpp), i.e. results that came out of the indirect team launch."""
+    from ezpz_amd.synthetic import keyed_uniform, make_workload
+    from sensitivity import assert_batch_matches_oracle
+
+    desc, recs, g, jitter, _ = make_workload("sketch150")
+    n, B = len(g), 262144
+    x0 = g[None, :] + keyed_uniform(0x657A707A, B, n, -jitter, jitter)
+    sysobj = E.System(recs, n)
+    x, st, _ = sysobj.solve_batch(x0)
+    assert np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0)
+    assert np.all(st["final_residual_inf"] <= 1e-8)
+    assert st["iterations"].min() >= 3 and st["iterations"].max() <= 35
+    late = np.argsort(st["iterations"])[-48:]  # 9 iterations and more: past the round in which the wavefronts give up their last lanes
+    assert st["iterations"][late].min() >= 9
+    sample = np.unique(np.concatenate([np.arange(0, B, B // 48)[:48], late]))
+    needed = assert_batch_matches_oracle(recs, x0[sample], x[sample], st["iterations"][sample], st["converged"][sample],
+                                         what="sketch150 x 262144")
+    assert needed <= len(sample) // 4
+    # the same batch again gives the same bits (the hand-over does not depend on timing: a lane gives up at a fixed point of
+    # its own wavefront's progress)
+    x2, st2, _ = sysobj.solve_batch(x0)
+    assert np.array_equal(st2["iterations"], st["iterations"]) and np.array_equal(x2, x)
