@@ -159,6 +159,7 @@ struct EzpzSystem {
     uint32_t* dev_lanes = nullptr;
     DevBuf<double> lanes_ws;
     DevBuf<uint32_t> strag_list, strag_count;  // the systems a lanes launch hands over to the teams (device-side list + count)
+    DevBuf<LmResume> strag_state;              // ... and the LM state each had reached
     uint64_t lanes_ws_waves = 0;
     hipEvent_t lanes_done = nullptr;  // completion of this system's last launch that used its global-memory workspace (lanes
                                       // kernel, list walk with the workspace in global memory): the next one, on any stream, waits for it
@@ -547,21 +548,24 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                 HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
             else
                 HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
-            // the systems the lanes give up (stragglers, batch_kernel.hip.hpp) are listed on the device and solved from their
-            // guesses by this system's list-walk teams right after: an indirect batch whose count stays on the device
+            // the systems the lanes give up (stragglers, batch_kernel.hip.hpp) are listed on the device and resumed by this
+            // system's list-walk teams right after: an indirect batch whose count stays on the device
             const uint32_t strag_cap = args.batch < (1ull << 32) && args.batch >= 256
                                            ? (uint32_t)std::min<uint64_t>(args.batch, std::max<uint64_t>(4096, args.batch / 8)) : 0u;
-            bool list_ok = strag_cap && s.strag_list.ensure(strag_cap) == EZPZ_OK && s.strag_count.ensure(1) == EZPZ_OK;
+            bool list_ok = strag_cap && s.strag_list.ensure(strag_cap) == EZPZ_OK && s.strag_count.ensure(1) == EZPZ_OK &&
+                           s.strag_state.ensure(strag_cap) == EZPZ_OK;
             if (list_ok && hipMemsetAsync(s.strag_count.p, 0, sizeof(uint32_t), stream) != hipSuccess) {
                 (void)hipGetLastError();
                 list_ok = false;
             }
             if (batch_launch(*s.lanes, s.dev_lanes, s.lanes_ws.p, s.lanes_ws_waves, s.counts.n_cons, comp_launch_args(args), stream,
-                             list_ok ? s.strag_list.p : nullptr, list_ok ? s.strag_count.p : nullptr, list_ok ? strag_cap : 0u) == EZPZ_OK) {
+                             list_ok ? s.strag_list.p : nullptr, list_ok ? s.strag_count.p : nullptr, list_ok ? strag_cap : 0u,
+                             list_ok ? s.strag_state.p : nullptr) == EZPZ_OK) {
                 int rc = EZPZ_OK;
                 if (list_ok) {
                     args.sys_list = s.strag_list.p;
                     args.sys_count = s.strag_count.p;
+                    args.resume = s.strag_state.p;  // (the teams go on from the values the lanes left in x_out)
                     args.batch = strag_cap;
                     rc = launch_list_walk(s, args, stream);
                 }
@@ -1652,6 +1656,7 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.grid_views = nullptr;
     a.sys_list = nullptr;
     a.sys_count = nullptr;
+    a.resume = nullptr;
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }

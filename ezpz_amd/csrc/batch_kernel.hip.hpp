@@ -38,11 +38,14 @@ struct BatchArgs {
     double residual_tolerance, step_tolerance, initial_lambda;
     double* ws;  // workspaces: one per wavefront of the launch, `rows` x 64 doubles each
     // Stragglers (optional): once a wavefront has no system left to take and at most `strag_lanes` of its lanes are still
-    // working, those lanes hand their systems over -- the system's index goes on this list and the lane drops it without
-    // writing anything; the per-system teams solve the listed systems from their guesses after this kernel (api.hip).
+    // working, those lanes hand their systems over -- the system's index goes on this list, its current values to x_out, its
+    // LM state (lambda, iteration and pass numbers, warnings so far) to `strag_state`, and the lane drops it; the per-system
+    // teams RESUME the listed systems after this kernel (api.hip; lm_kernel.hip.hpp: LmResume) -- a straggler is typically
+    // one or two iterations from done, and solving it again from its guesses cost the teams nine.
     uint32_t* strag_list;
     uint32_t* strag_count;
     uint32_t strag_cap, strag_lanes;
+    LmResume* strag_state;  // entry i: the LM state of the system listed at i (its current values go to x_out)
 };
 
 __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
@@ -455,13 +458,25 @@ __global__ void __launch_bounds__(256, 4) batch_lane_kernel(const BatchArgs a) {
         if (a.strag_list) {
             const unsigned long long working = __ballot(have);
             if (working && (uint32_t)__popcll(working) <= a.strag_lanes && !__any(next < a.batch)) {
+                bool handing = false;
                 if (have) {
                     const uint32_t idx = atomicAdd(a.strag_count, 1u);
                     if (idx < a.strag_cap) {  // (a full list: this lane simply carries on)
                         a.strag_list[idx] = (uint32_t)sys;
-                        have = false;
-                        fresh = false;
+                        LmResume rec;
+                        rec.lambda = lambda;
+                        rec.it = it;
+                        rec.pass = pass;
+                        rec.nwarn = nwarn;
+                        rec.jac_pass = fresh ? pass_jac : kNoPass;
+                        a.strag_state[idx] = rec;
+                        handing = true;
                     }
+                }
+                move_rows(handing, false);  // the current values: the teams' starting point
+                if (handing) {
+                    have = false;
+                    fresh = false;
                 }
             }
         }

@@ -76,7 +76,7 @@ uint64_t batch_launch_waves(int cus) {
 }
 
 int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons, const CompLaunch& L,
-                 void* stream, uint32_t* strag_list, uint32_t* strag_count, uint32_t strag_cap) {
+                 void* stream, uint32_t* strag_list, uint32_t* strag_count, uint32_t strag_cap, LmResume* strag_state) {
     if (L.batch == 0) return EZPZ_OK;
     BatchArgs a{};
     a.prog = dev_blob;
@@ -101,10 +101,13 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
     a.step_tolerance = L.step_tolerance;
     a.initial_lambda = L.initial_lambda;
     a.ws = dev_ws;
-    // a wavefront down to 8 working lanes (of 64) with nothing left to take gives them up: continuing costs the whole
-    // wavefront a round per iteration, the teams ~40 lane-rounds per system (EZPZ_LANES_STRAGGLERS: that threshold, 0 = off)
-    static const int env_strag = [] { const char* e = std::getenv("EZPZ_LANES_STRAGGLERS"); return e ? std::atoi(e) : 8; }();
-    a.strag_list = env_strag > 0 && strag_cap ? strag_list : nullptr;
+    // a wavefront down to 16 working lanes (of 64) with nothing left to take gives them up: continuing costs the whole
+    // wavefront a round per iteration, while the teams resume a system where it stands (EZPZ_LANES_STRAGGLERS: that
+    // threshold, 0 = off; 262 144 jittered 300-variable sketches: 8 / 12 / 16 / 24 lanes 7.50 / 7.49 / 7.69 / 5.09 M solves/s
+    // -- at 24 the list overflows and most of a round's lanes arrive at the teams at once)
+    static const int env_strag = [] { const char* e = std::getenv("EZPZ_LANES_STRAGGLERS"); return e ? std::atoi(e) : 16; }();
+    a.strag_list = env_strag > 0 && strag_cap && strag_state ? strag_list : nullptr;
+    a.strag_state = strag_state;
     a.strag_count = strag_count;
     a.strag_cap = strag_cap;
     a.strag_lanes = (uint32_t)std::max(env_strag, 0);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/ezpz_amd.h"
+#include "dev_types.hpp"
 
 namespace ezpz {
 
@@ -153,10 +154,10 @@ bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Batc
 // wavefronts of the kernel the device holds at once (their workspaces are what the caller allocates)
 uint64_t batch_launch_waves(int cus);
 // strag_list / strag_count / strag_cap: where wavefronts that are down to their last few lanes leave the systems they
-// give up (batch_kernel.hip.hpp); null: every system is solved by its lane
+// give up (batch_kernel.hip.hpp) and `strag_state` the LM state they had reached; null: every system is solved by its lane
 int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons,
                  const CompLaunch& launch, void* stream, uint32_t* strag_list = nullptr, uint32_t* strag_count = nullptr,
-                 uint32_t strag_cap = 0);
+                 uint32_t strag_cap = 0, LmResume* strag_state = nullptr);
 
 // The class-specialised kernel of a plan (jit.cpp): run-time compiled (hiprtc) on a background thread.
 // comp_jit_create returns nullptr when the plan carries no source or EZPZ_JIT=0.  comp_jit_request starts the

@@ -44,4 +44,14 @@ struct PartDesc {
     uint32_t lvl0, nlev;  // this partition's slice of lvl_cptr / lvl_sptr (nlev + 1 entries each)
 };
 
+// The LM state with which a system changes kernels in mid-solve: a straggler of a lanes-across-the-batch launch
+// (batch_kernel.hip.hpp) goes on in the per-system teams (lm_kernel.hip.hpp) from its current values.
+struct LmResume {
+    double lambda;
+    uint32_t it, pass, nwarn;
+    uint32_t jac_pass;  // pass number under which the resuming eval()'s Jacobian sweep logs (the refresh of the last accepted
+                        // step was still owed), or kNoPass: that refresh was logged before the hand-over
+};
+constexpr uint32_t kNoPass = 0xFFFFFFFFu;
+
 }  // namespace ezpz

@@ -235,7 +235,12 @@ struct SolveArgs {
     // on the device, `batch` is the list's capacity
     const uint32_t* sys_list;
     const uint32_t* sys_count;
+    // ... which may be RESUMED rather than solved from their guesses: entry q of `resume` carries the LM state the lanes
+    // kernel had reached for system sys_list[q] (whose current values it left in x_out): eval() runs at those values, its
+    // warnings are not logged again, and the loop goes on with that lambda, iteration count and pass number
+    const LmResume* resume;  // (dev_types.hpp)
 };
+
 
 #ifdef EZPZ_STAMPS
 #define EZPZ_STAMP(id)                                                                     \
@@ -726,7 +731,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
         int stamp_n = 0;
 #endif
         EZPZ_STAMP(1);
-        const double* x0 = a.x0 + sys * n_row;
+        const bool resuming = a.resume != nullptr;
+        const double* x0 = (resuming ? a.x_out : a.x0) + sys * n_row;
         if constexpr (MODE == MODE_PART) {
             // each wavefront loads (and later stores) its own partition's variables only: a wavefront that is already
             // on the next system never touches values another one has not stored yet.  The first four values per lane
@@ -756,7 +762,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
             // shared by the system's workgroups: zeroed by the host / by workgroup 0 two systems ago (see write-back)
             nwarn = &tm.grid->nwarn[sys_parity];
         } else if (tlane == 0) {
-            *nwarn = 0;
+            *nwarn = resuming ? (int)a.resume[q].nwarn : 0;
         }
         tm.team_sync();
         EZPZ_STAMP(2);
@@ -1325,7 +1331,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                     sq += w1 * w1;
                     mx = fmax(mx, fabs(w1));
                 }
-                if (deg) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
+                if (deg && !(resuming && mode == EVAL0)) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
                     int idx = atomicAdd(nwarn, 1);
                     if (a.warn_log && (uint32_t)idx < a.warn_cap)
                         a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
@@ -1344,10 +1350,13 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 w.loc[3] = loc.w;
                 w.weight = c.weight;
                 const bool deg = con_jacobian<LIN>(c, ws + o_x, w);
-                if (deg) {
+                // (a resumed system's eval(): this sweep is the refresh its last accepted step still owed -- logged under that
+                // step's pass number -- or one that was logged before the hand-over)
+                const uint32_t log_pass = (resuming && mode == EVAL0) ? a.resume[q].jac_pass : pass;
+                if (deg && log_pass != kNoPass) {
                     int idx = atomicAdd(nwarn, 1);
                     if (a.warn_log && (uint32_t)idx < a.warn_cap)
-                        a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | cref.pos(P, ci);
+                        a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)log_pass << 32) | cref.pos(P, ci);
                 }
             };
             for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
@@ -1407,7 +1416,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 }
                 ++it;
             }
-            if (mode == EVAL0) mode = STEP;
+            if (mode == EVAL0) {
+                mode = STEP;
+                if (resuming) {  // the loop goes on where the lanes kernel left it
+                    lambda = a.resume[q].lambda;
+                    it = a.resume[q].it;
+                    pass = a.resume[q].pass;
+                }
+            }
         }
 
         // ---- write-back -----------------------------------------------------------------------------------------------
