@@ -641,6 +641,7 @@ def resolve_sides(records, values) -> np.ndarray:
 
 TEAM_AUTO_LISTS = 0xFFFFFFFE  # `team_size`: automatic, list-walk shapes only (never component-resident)
 TEAM_BATCH_LANES = 0xFFFFFFFD  # `team_size`: automatic, connected sketches one lane per system at every batch size
+TEAM_LATENCY_PHASES = 0xFFFFFFFC  # `team_size`: TEAM_AUTO_LATENCY without the record walk (dense phases instead)
 TEAM_AUTO_LATENCY = 0xFFFFFFFF  # `team_size`: choose for the latency of one solve instead of batch throughput (ezpz_amd.h)
 
 

@@ -179,6 +179,11 @@ struct EzpzSystem {
     uint32_t lvl_nlev = 0;
     uint32_t n_dense = 0, dense_level0 = 0, dense_lds_off = 0, dense_lds_doubles = 0;  // dense phases (make_dense_phases)
     bool lean_lds = false;  // batch-throughput workgroup: keep LDS per workgroup small (no whole-list staging)
+    // record walk (build_records): the linear solve of one connected system on a barrier workgroup as rounds of per-lane
+    // records; rec_extra = doubles behind the workspace proper (the factor's diagonal, one zero), offsets into the blob
+    bool rec = false;
+    uint32_t rec_extra = 0, rec_rounds = 0, rec_desc_lds_off = 0;
+    size_t rec_desc_off = 0, rec_chunks_off = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
     size_t lds_bytes = 0;
@@ -269,7 +274,7 @@ uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(512, std::max<
 // that many leading bytes of the blob are copied to LDS by every workgroup (16-bit index lists).
 // `panel_bytes`: LDS every team needs on top of its workspace (dense phases), counted when the workgroup is sized.
 void finish_team(EzpzSystem& s, size_t stage_bytes, size_t panel_bytes = 0) {
-    s.ws_doubles = workspace_doubles(s.counts);
+    s.ws_doubles = workspace_doubles(s.counts) + s.rec_extra;
     const size_t ws_bytes = (size_t)s.ws_doubles * 8;
     s.prog_in_lds = stage_bytes > 0;
     s.prog_lds_doubles = (uint32_t)((stage_bytes + 15) / 16 * 2);
@@ -278,7 +283,7 @@ void finish_team(EzpzSystem& s, size_t stage_bytes, size_t panel_bytes = 0) {
     // barrier workgroup per system get LDS for the three level tables and for one level of lists (levels wider than
     // the buffer are walked from global memory as before).
     s.lvl_lds_off = s.lvl_tab_words = s.lvl_buf_words = 0;
-    const bool lvl_ok = s.view.lvl_words_max > 0 && !s.prog_in_lds && s.grid_wgs <= 1 &&
+    const bool lvl_ok = s.view.lvl_words_max > 0 && !s.prog_in_lds && s.grid_wgs <= 1 && s.rec_extra == 0 &&
                         ((s.mode == MODE_SUB && s.team_size == 64) || s.mode == MODE_WGB);
     const uint32_t lvl_tab_words = (5 * (s.lvl_nlev + 1) + 3) & ~3u;
     if (s.mode == MODE_SUB) {
@@ -335,9 +340,9 @@ bool sub_team_fits(const ProgramCounts& c, uint32_t team) {
     return team <= 64 && (size_t)workspace_doubles(c) * 8 * (64 / team) <= 60 * 1024;
 }
 
-template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool DENSE = false>
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool DENSE = false, bool REC = false>
 int launch_kernel(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
-    auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN, false, DENSE>;
+    auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN, false, DENSE, REC>;
     // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to the system: raised once per kernel
     // build and device, to everything the device allows, so that systems of different sizes sharing a build never
     // lower each other's limit
@@ -523,6 +528,13 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (s.mode == MODE_PART)
         return staged ? launch_variant<64, MODE_PART, true, true>(s, args, grid, stream)
                       : launch_variant<64, MODE_PART, true, false>(s, args, grid, stream);
+    if (s.rec) {  // one connected system, its linear solve as a record walk
+        if (s.linear_only)
+            return staged ? launch_kernel<64, MODE_WGB, true, true, true, false, true>(s, args, grid, stream)
+                          : launch_kernel<64, MODE_WGB, true, false, true, false, true>(s, args, grid, stream);
+        return staged ? launch_kernel<64, MODE_WGB, true, true, false, false, true>(s, args, grid, stream)
+                      : launch_kernel<64, MODE_WGB, true, false, false, false, true>(s, args, grid, stream);
+    }
     return staged ? launch_variant<64, MODE_WGB, true, true>(s, args, grid, stream)
                   : launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream);
 }
@@ -927,6 +939,166 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
     return true;
 }
 
+// Record walk (lm_kernel.hip.hpp, REC builds): the factorisation, the forward and the backward substitution of ONE connected
+// system on a barrier workgroup of T lanes, as rounds.  In a round a group of g lanes owns one item:
+//   factor, entry (i, j):  l_ij = (A_ij - sum_k l_ik l_jk) / sqrt(A_jj - sum_k l_jk^2)   over row j of L (k < j); where row i
+//                          has no entry in column k the pair's second operand is a double that stays zero
+//   factor, column j:      y_j  = (b_j  - sum_k l_jk y_k ) / sqrt(A_jj - sum_k l_jk^2)   and d_j = the square root
+//   backward, column j:    x_j  = (y_j  - sum_i l_ij x_i ) / d_j                          over column j of L (i > j)
+// -- one list per item (every lane of a column's entries recomputes d_j from the same terms in the same order), cut
+// into the lanes' shares at build time: a lane's record is ready workspace addresses, nothing is looked up on the device.
+// A level of the elimination tree takes ceil(items x g / T) rounds, longest lists first; g (a power of two per level)
+// minimises rounds x (a round's fixed cost + its longest share + the group's sum).
+// Layout: desc[(round x wavefronts + wavefront) x 2] = flags (chunks to load: 0 = nothing to do; log2 g; rendezvous first;
+// backward), first chunk; chunks[((chunk + c) x 64 + lane of the wavefront) x 4]: chunk 0 = target | diagonal << 16, destination
+// | lane flags, two (a | b << 16) pairs; chunks 1 and 2 = four pairs each (REC_* in lm_kernel.hip.hpp).  Only a wavefront that
+// has an item in a round has chunks for it, as many as its longest share needs.
+struct RecPlan {
+    std::vector<uint32_t> desc, chunks;
+    uint32_t rounds = 0;
+};
+static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, RecPlan& out) {
+    if (P.c.n_parts != 1 || P.parts.size() != 1 || P.c.dense || P.n_dense || T < 64 || T % 64) return false;
+    const uint32_t n = P.c.n_vars, m = P.c.n_rows, zj = P.c.zj, zlo = P.c.zlo;
+    // (addresses in the records count doubles from the start of the LDS; the workspace begins `lds_base` doubles in)
+    const uint32_t o_d = lds_base + n + 2 * m + zj, o_l = o_d + n, o_v = o_l + zlo, o_dd = lds_base + workspace_doubles(P.c),
+                   o_zero = o_dd + n;
+    if (o_zero >= 65536) return false;  // 16-bit addresses
+    const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev, n_waves = T / 64;
+    constexpr uint32_t kMaxShare = REC_MAX_PAIRS;
+    struct Item {
+        uint32_t target, diag, dest;
+        bool col;
+        std::vector<std::pair<uint32_t, uint32_t>> list;
+    };
+    const uint32_t zero_pair = o_zero | (o_zero << 16);
+    auto emit_level = [&](std::vector<Item>& items, bool bwd, bool barrier) {
+        if (items.empty()) return;
+        std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.list.size() > y.list.size(); });
+        const uint32_t longest = (uint32_t)items[0].list.size();
+        uint32_t best_g = 0, best_lg = 0;
+        double best = 0.0;
+        for (uint32_t g = 1, lg = 0; g <= 64; g <<= 1, ++lg) {
+            if ((longest + g - 1) / g > kMaxShare) continue;
+            const uint32_t ngrp = T / g;
+            double cost = 0.0;
+            for (size_t t = 0; t < items.size(); t += ngrp)
+                cost += 500.0 + 20.0 * (double)((items[t].list.size() + g - 1) / g) + (g > 1 ? 30.0 * lg : 0.0);
+            if (!best_g || cost < best - 1e-9) best = cost, best_g = g, best_lg = lg;
+            if ((uint64_t)items.size() * g >= T && g >= longest) break;  // more lanes per list buy nothing
+        }
+        if (!best_g) {
+            out.rounds = 0xFFFFFFFFu;  // a list longer than 64 lanes x 10 pairs
+            return;
+        }
+        const uint32_t g = best_g, ngrp = T / g;
+#ifdef EZPZ_STAMPS
+        std::fprintf(stderr, "rounds %3u..: %s level of %5zu items, longest list %3u, %2u lanes per list\n", out.rounds, bwd ? "bwd" : "fac",
+                     items.size(), longest, g);
+#endif
+        for (size_t t0 = 0; t0 < items.size(); t0 += ngrp) {
+            for (uint32_t w = 0; w < n_waves; ++w) {
+                // this wavefront's lanes: groups [w * 64 / g, (w + 1) * 64 / g)
+                uint32_t nch = 0;
+                for (uint32_t l = 0; l < 64; ++l) {
+                    const size_t t = t0 + (w * 64 + l) / g;
+                    if (t >= items.size()) continue;
+                    const uint32_t sub = l & (g - 1), len = (uint32_t)items[t].list.size();
+                    const uint32_t share = len > sub ? (len - sub + g - 1) / g : 0;
+                    nch = std::max(nch, share <= 2 ? 1u : 1u + (share - 2 + 3) / 4);
+                }
+                const uint32_t chunk0 = (uint32_t)(out.chunks.size() / (64 * 4));
+                out.desc.push_back(nch | (best_lg << REC_LG_SHIFT) | (barrier && t0 == 0 ? REC_BARRIER : 0u) | (bwd ? REC_BWD : 0u));
+                out.desc.push_back(chunk0);
+                out.chunks.resize(out.chunks.size() + (size_t)nch * 64 * 4, zero_pair);
+                if (!nch) continue;
+                for (uint32_t l = 0; l < 64; ++l) {
+                    uint32_t* c0 = &out.chunks[((size_t)chunk0 * 64 + l) * 4];
+                    const size_t t = t0 + (w * 64 + l) / g;
+                    c0[0] = zero_pair;  // an idle lane of a working wavefront: reads zeros, writes nothing
+                    c0[1] = o_zero;
+                    if (t >= items.size()) continue;
+                    const Item& it = items[t];
+                    const uint32_t sub = l & (g - 1);
+                    c0[0] = it.target | (it.diag << 16);
+                    c0[1] = it.dest | (sub == 0 ? REC_WRITER : 0u) | (it.col ? REC_ISCOL : 0u);
+                    uint32_t k = 0;
+                    for (size_t q = sub; q < it.list.size(); q += g, ++k) {
+                        const uint32_t word = it.list[q].first | (it.list[q].second << 16);
+                        if (k < 2)
+                            c0[2 + k] = word;
+                        else
+                            out.chunks[((size_t)(chunk0 + 1 + (k - 2) / 4) * 64 + l) * 4 + (k - 2) % 4] = word;
+                    }
+                }
+            }
+            ++out.rounds;
+        }
+    };
+    out.desc.clear();
+    out.chunks.clear();
+    out.rounds = 0;
+    std::vector<Item> items;
+    std::vector<uint32_t> other(zlo, 0xFFFFFFFFu);  // per slot (j, k) of the current column's row: the slot (i, k), if any
+    for (uint32_t lv = 0; lv < nlev; ++lv) {
+        const uint32_t c0 = P.lvl_cptr[lvl0 + lv], c1 = P.lvl_cptr[lvl0 + lv + 1];
+        const uint32_t s0 = P.lvl_sptr[lvl0 + lv], s1 = P.lvl_sptr[lvl0 + lv + 1];
+        items.clear();
+        for (uint32_t j = c0; j < c1; ++j) {
+            Item it{o_v + j, o_d + j, o_v + j, true, {}};
+            for (uint32_t q = P.fwd_ptr[j]; q < P.fwd_ptr[j + 1]; ++q)
+                it.list.push_back({o_l + P.fwd_items[2 * q], o_v + P.fwd_items[2 * q + 1]});
+            items.push_back(std::move(it));
+        }
+        for (uint32_t sl = s0; sl < s1; ++sl) {
+            const uint32_t j = P.l_col[sl];
+            if (j < c0 || j >= c1) return false;
+            // (slot_ik, slot_jk) pairs of this entry: which of the two lies in row j tells them apart
+            std::vector<uint32_t> touched;
+            for (uint32_t q = P.fwd_ptr[j]; q < P.fwd_ptr[j + 1]; ++q) other[P.fwd_items[2 * q]] = 0xFFFFFFFEu;
+            bool ok = true;
+            for (uint32_t q = P.lpair_ptr[sl]; q < P.lpair_ptr[sl + 1]; ++q) {
+                const uint32_t u = P.lpairs[2 * q], w = P.lpairs[2 * q + 1];
+                if (w < zlo && other[w] == 0xFFFFFFFEu)
+                    other[w] = u;
+                else if (u < zlo && other[u] == 0xFFFFFFFEu)
+                    other[u] = w;
+                else
+                    ok = false;
+            }
+            Item it{o_l + sl, o_d + j, o_l + sl, false, {}};
+            for (uint32_t q = P.fwd_ptr[j]; q < P.fwd_ptr[j + 1]; ++q) {
+                const uint32_t sjk = P.fwd_items[2 * q];
+                it.list.push_back({o_l + sjk, other[sjk] < zlo ? o_l + other[sjk] : o_zero});
+                other[sjk] = 0xFFFFFFFFu;
+            }
+            if (!ok) return false;
+            items.push_back(std::move(it));
+        }
+        emit_level(items, false, lv > 0);  // (the assembly ends with a rendezvous of its own)
+        if (out.rounds == 0xFFFFFFFFu) return false;
+    }
+    for (uint32_t lv = nlev; lv-- > 0;) {
+        const uint32_t c0 = P.lvl_cptr[lvl0 + lv], c1 = P.lvl_cptr[lvl0 + lv + 1];
+        items.clear();
+        for (uint32_t j = c0; j < c1; ++j) {
+            Item it{o_v + j, o_dd + j, o_v + j, true, {}};
+            for (uint32_t q = P.bwd_ptr[j]; q < P.bwd_ptr[j + 1]; ++q)
+                it.list.push_back({o_l + P.bwd_items[2 * q], o_v + P.bwd_items[2 * q + 1]});
+            items.push_back(std::move(it));
+        }
+        emit_level(items, true, true);
+        if (out.rounds == 0xFFFFFFFFu) return false;
+    }
+    // an even number of rounds (the kernel alternates between two sets of registers), then two idle ones: the requests a round
+    // makes for the next round's records need no condition
+    const uint32_t idle = 2 + (out.rounds & 1u);
+    out.desc.resize(out.desc.size() + (size_t)idle * n_waves * 2, 0u);
+    out.rounds += out.rounds & 1u;
+    out.chunks.resize(out.chunks.size() + 64 * 4, zero_pair);
+    return out.rounds > 0 && out.chunks.size() / (64 * 4) < 0xFFFFFFF0ull;
+}
+
 // Symbolic phase + launch-shape decision shared by ezpz_system_create and ezpz_analyze.
 // Lanes per list, level by level, for the teams that run a level as one phase (one wavefront or one barrier workgroup
 // on a one-partition program): a level lasts as long as its longest list, and the top levels of an elimination tree are
@@ -1187,7 +1359,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         if (err_variable) *err_variable = be.variable;
         return be.code;
     };
-    const bool for_latency = team_size == EZPZ_TEAM_AUTO_LATENCY;
+    const bool latency_phases = team_size == EZPZ_TEAM_LATENCY_PHASES;
+    const bool for_latency = team_size == EZPZ_TEAM_AUTO_LATENCY || latency_phases;
     const bool batch_lanes = team_size == EZPZ_TEAM_BATCH_LANES;
     const bool auto_shape = team_size == 0 || for_latency || batch_lanes;
     if (for_latency || batch_lanes || team_size == EZPZ_TEAM_AUTO_LISTS) team_size = 0;
@@ -1364,7 +1537,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         stage_bytes = 0;
         if (small_counts && may_stage) {
             const size_t lists_bytes = pack_program(P, true, s.mode != MODE_SUB, blob, v);
-            const size_t ws_bytes = (size_t)workspace_doubles(P.c) * 8;
+            const size_t ws_bytes = ((size_t)workspace_doubles(P.c) + s.rec_extra) * 8;
             if (s.mode == MODE_SUB) {
                 if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
             } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= s.lim.lds_bytes && !s.lean_lds) {
@@ -1376,7 +1549,41 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         s.lvl_nlev = P.parts.empty() ? 0 : P.parts[0].nlev;
         finish_team(s, stage_bytes, panel_bytes);
     };
+    // ---- one solve of one connected system on a barrier workgroup: the linear solve as a record walk (build_records) -----------
+    static const bool rec_enabled = [] {
+        const char* e = std::getenv("EZPZ_REC");
+        return !(e && e[0] == '0');
+    }();
+    RecPlan rec;
+    s.rec = false;
+    s.rec_rounds = 0;
+    s.rec_extra = 0;
+    const bool rec_try = rec_enabled && auto_shape && for_latency && !latency_phases && s.mode == MODE_WGB && s.grid_wgs == 1 && P.c.n_parts == 1 &&
+                         P.c.n_components == 1 && !P.c.dense;
+    if (rec_try) {
+        s.rec_extra = (P.c.n_vars + 2 + 1) & ~1u;
+#ifdef EZPZ_REC_TIMES
+        s.rec_extra += 128;  // (diagnostic build: a cycle stamp per round of the second iteration's walk, behind the zero)
+#endif
+        if (const char* e = std::getenv("EZPZ_REC_LANES")) {  // (A/B runs)
+            const uint32_t t = (uint32_t)std::atoi(e);
+            if (t >= 64 && t <= 512 && t % 64 == 0) s.team_size = t;
+        }
+    }
     pack_and_shape(true);
+    if (rec_try) {
+        if (s.lds_ws && build_records(P, s.team_size, s.prog_lds_doubles, rec)) {
+            s.rec = true;
+            s.rec_rounds = rec.rounds;
+            s.rec_desc_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);  // the descriptors' copy in LDS, behind everything else
+            s.lds_bytes = (size_t)s.rec_desc_lds_off * 8 + rec.desc.size() * 4;
+            if (s.lds_bytes > s.lim.lds_bytes) s.rec = false;
+        }
+        if (!s.rec) {
+            s.rec_extra = 0;
+            pack_and_shape(true);
+        }
+    }
     // ---- dense phases: the top of a connected sketch's elimination tree on a barrier workgroup ------------------------------
     s.n_dense = s.dense_level0 = s.dense_lds_off = s.dense_lds_doubles = 0;
     static const bool root_enabled = [] {
@@ -1400,7 +1607,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     } else if (s.lds_bytes + 4096 * teams_now <= s.lim.lds_bytes) {  // (one solve: occupancy does not matter)
         dense_room = std::min<size_t>((s.lim.lds_bytes - s.lds_bytes - 1024) / teams_now, 48 * 1024);
     }
-    if (root_enabled && auto_shape && s.grid_wgs == 1 &&
+    if (root_enabled && auto_shape && s.grid_wgs == 1 && !s.rec &&
         ((s.mode == MODE_WGB && (for_latency || s.team_size >= 128)) || wave_teams) && dense_room >= 1024 &&
         make_dense_phases(P, wave_teams ? 1 : s.team_size / 64, dense_room)) {
         const int mode_before = s.mode;
@@ -1437,6 +1644,13 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             return fail();
         }
     }
+    if (s.rec) {
+        s.rec_desc_off = append(blob, rec.desc);
+        s.rec_chunks_off = append(blob, rec.chunks);
+        if (std::getenv("EZPZ_REC_DEBUG"))
+            std::fprintf(stderr, "record walk: %u rounds on %u lanes, %zu KB of descriptors, %zu KB of records\n", rec.rounds, s.team_size,
+                         rec.desc.size() * 4 / 1024, rec.chunks.size() * 4 / 1024);
+    }
     if (blob.size() > 0xFFFFFFF0ull) {
         be.code = EZPZ_ERR_TOO_LARGE;
         return fail();
@@ -1456,7 +1670,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     info.workspace_bytes = (uint64_t)s.ws_doubles * 8;
     info.team_size = s.team_size;
     info.workspace_in_lds = s.lds_ws ? 1 : 0;
-    info.team_mode = (uint32_t)s.mode;
+    info.team_mode = s.rec ? 4u : (uint32_t)s.mode;
     info.n_partitions = P.c.n_parts;
     info.program_in_lds = s.prog_in_lds ? 1 : 0;
     info.grid_workgroups = s.grid_wgs;
@@ -1657,6 +1871,17 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.sys_list = nullptr;
     a.sys_count = nullptr;
     a.resume = nullptr;
+    if (sys->rec) {
+        const unsigned char* base = static_cast<const unsigned char*>(sys->dev_program);
+        a.rec_desc = reinterpret_cast<const uint2*>(base + sys->rec_desc_off);
+        a.rec_chunks = reinterpret_cast<const uint4*>(base + sys->rec_chunks_off);
+        a.rec_rounds = sys->rec_rounds;
+        a.rec_desc_off = sys->rec_desc_lds_off;
+        const uint32_t n = sys->counts.n_vars, m = sys->counts.n_rows;
+        const uint32_t o_d = n + 2 * m + sys->counts.zj, o_dd = workspace_doubles(sys->counts);
+        a.rec_dd_delta = o_dd - o_d;
+        a.rec_zero = o_dd + n;
+    }
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }

@@ -239,7 +239,23 @@ struct SolveArgs {
     // kernel had reached for system sys_list[q] (whose current values it left in x_out): eval() runs at those values, its
     // warnings are not logged again, and the loop goes on with that lambda, iteration count and pass number
     const LmResume* resume;  // (dev_types.hpp)
+    // record walk (REC builds; api.hip: build_records): the linear solve of one connected system as a sequence of ROUNDS.
+    // rec_desc[round * wavefronts + wavefront] = (flags, first chunk): what that wavefront does in that round (copied to
+    // LDS once per workgroup, rec_desc_off doubles in); rec_chunks[(chunk + c) * 64 + lane of the wavefront]: the lanes'
+    // records of a working wavefront, one to three 16-byte chunks each -- chunk 0 = target | diagonal << 16, destination
+    // | lane flags << 16 and two (a | b << 16) operand pairs, the others four pairs each; all addresses count doubles from
+    // the start of the LDS.  rec_dd_delta: from an entry's diagonal A_jj to where 1 / d_j goes (the factor's diagonal has
+    // its own n doubles behind the workspace proper, then one double that stays zero: the operand of padding pairs).
+    const uint2* rec_desc;
+    const uint4* rec_chunks;
+    uint32_t rec_rounds, rec_dd_delta, rec_zero, rec_desc_off;
 };
+
+// a round's descriptor (per wavefront): chunks to load (0 = the wavefront has no item), log2 of the lanes per list, ...
+constexpr uint32_t REC_NCH_MASK = 3u, REC_LG_SHIFT = 2u, REC_BARRIER = 1u << 7, REC_BWD = 1u << 8;
+// ... and a lane's own flags (high half of the record's second word)
+constexpr uint32_t REC_WRITER = 1u << 16, REC_ISCOL = 1u << 17;
+constexpr int REC_MAX_CHUNKS = 3, REC_MAX_PAIRS = 10;  // per lane and round: 2 pairs beside the header, then 4 + 4
 
 
 #ifdef EZPZ_STAMPS
@@ -567,10 +583,11 @@ struct ConRef<2, PROG> {
 // Cholesky and the substitutions are plain loops over rows and columns instead of level-by-level list walks.
 // Occupancy hints: sub-wavefront teams are compiled for 4 workgroups per CU (128 VGPRs; measured against 3 and 2:
 // +8 % on some topologies, -7 % on others), the register-resident dense solve for 2 (184 VGPRs, no spills: +12 %).
-template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false, bool DENSE = false>
-__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), MODE == MODE_SUB ? (DENSE ? 2 : 4) : 1)
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false, bool DENSE = false, bool REC = false>
+__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 : 512), MODE == MODE_SUB ? (DENSE ? 2 : 4) : 1)
     lm_solve_kernel(const SolveArgs a) {
     static_assert(!DENSE || (MODE == MODE_SUB && TEAM == 4), "the register-resident dense solve is for teams of four");
+    static_assert(!REC || (MODE == MODE_WGB && LDSWS && !GRID && !DENSE), "the record walk is for one barrier workgroup, state in LDS");
     static_assert(!GRID || (MODE == MODE_PART && LDSWS && PLDS), "grid teams are partitioned teams with staged lists");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using namespace dev;
@@ -690,7 +707,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
     // connected sketch's solve.  One wavefront / one barrier workgroup per system therefore copies each level's lists
     // (a contiguous block of lvl_stream, see pack_program) into LDS with one round of independent 16-byte loads and
     // walks them from there; the three level tables are copied once per workgroup.
-    constexpr bool LVL_STAGE = !PLDS && !DENSE && !GRID && (MODE == MODE_WGB || (MODE == MODE_SUB && TEAM == 64));
+    constexpr bool LVL_STAGE = !PLDS && !DENSE && !GRID && !REC && (MODE == MODE_WGB || (MODE == MODE_SUB && TEAM == 64));
     const uint32_t* lvl_tab = nullptr;  // [lvl_cptr | lvl_sptr | lvl_off | lvl_grp | lvl_boff], nlev + 1 words each
     uint32_t* lvl_buf = nullptr;
     if constexpr (LVL_STAGE) {
@@ -722,6 +739,12 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
             const uint32_t ci = call0 + tm.lane + j * 64;
             x_id[j] = ci < call1 ? P.var_of[ci] : 0u;
         }
+    }
+    if constexpr (REC) {  // (ordered before their first use by every system's first rendezvous)
+        if (tid == 0) ws[a.rec_zero] = 0.0;
+        uint2* dst = reinterpret_cast<uint2*>(smem + a.rec_desc_off);
+        const uint32_t nd = (a.rec_rounds + 2) * (blockDim.x >> 6);  // (two idle rounds behind the last)
+        for (uint32_t i = tid; i < nd; i += blockDim.x) dst[i] = a.rec_desc[i];
     }
     const uint64_t n_sys = a.sys_count ? (uint64_t)min(*a.sys_count, (uint32_t)a.batch) : a.batch;
     for (uint64_t q = (uint64_t)grid_slot * teams_per_block + team_in_block; q < n_sys; q += n_teams, sys_parity ^= 1u) {
@@ -797,6 +820,28 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 }
             }
             if (mode == STEP) {
+                // record walk: the first rounds' records do not depend on any value -- requested before the assembly
+                uint4 rpa[REC_MAX_CHUNKS] = {}, rpb[REC_MAX_CHUNKS] = {};
+                const uint32_t rec_nw = blockDim.x >> 6;
+                const uint2* const rec_d = reinterpret_cast<const uint2*>(smem + a.rec_desc_off) + (tid >> 6);
+                const uint4* const rec_c = a.rec_chunks + (tid & 63);
+                // this wavefront's chunks of the round with descriptor `d` (0-3 of them)
+                auto rec_load = [&](uint32_t fl, uint32_t chunk0, uint4 (&pr)[REC_MAX_CHUNKS]) __attribute__((always_inline)) {
+                    const uint32_t nch = fl & REC_NCH_MASK;
+                    const uint4* src = rec_c + (size_t)chunk0 * 64;
+#pragma unroll
+                    for (int c = 0; c < REC_MAX_CHUNKS; ++c)
+                        if ((uint32_t)c < nch) pr[c] = src[c * 64];
+                };
+                uint32_t rf0 = 0, rc0 = 0;  // this round's descriptor (scalars)
+                uint2 rd1 = {0, 0};         // the next round's, as read from LDS
+                if constexpr (REC) {  // (the descriptors end with two idle rounds: nothing here is conditional)
+                    const uint2 d0 = rec_d[0];
+                    rd1 = rec_d[rec_nw];
+                    rf0 = uni(d0.x);
+                    rc0 = uni(d0.y);
+                    rec_load(rf0, rc0, rpa);
+                }
                 // ---- A = JtJ + lambda I (into L's storage) and b = Jt(-r)  (newton.rs:77-84) ---------------------
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
                     const uint32_t v = ci;  // internal variable numbering = schedule order
@@ -825,7 +870,147 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 EZPZ_STAMP(10);
                 double bad = 0.0;
                 double dmax = __builtin_nan("");  // fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax)
-                if constexpr (DENSE) {
+                auto rec_group_sum = [&](double v, uint32_t g) {
+                    switch (g) {
+                    case 2: return reduce_lanes<2>(v, OpSum());
+                    case 4: return reduce_lanes<4>(v, OpSum());
+                    case 8: return reduce_lanes<8>(v, OpSum());
+                    case 16: return reduce_lanes<16>(v, OpSum());
+                    case 32: return reduce_lanes<32>(v, OpSum());
+                    default: return reduce_lanes<64>(v, OpSum());
+                    }
+                };
+                auto rec_group_sum2 = [&](double& u, double& w, uint32_t g) {  // (the two chains of cross-lane moves interleave)
+                    switch (g) {
+                    case 2: u = reduce_lanes<2>(u, OpSum()), w = reduce_lanes<2>(w, OpSum()); break;
+                    case 4: u = reduce_lanes<4>(u, OpSum()), w = reduce_lanes<4>(w, OpSum()); break;
+                    case 8: u = reduce_lanes<8>(u, OpSum()), w = reduce_lanes<8>(w, OpSum()); break;
+                    case 16: u = reduce_lanes<16>(u, OpSum()), w = reduce_lanes<16>(w, OpSum()); break;
+                    case 32: u = reduce_lanes<32>(u, OpSum()), w = reduce_lanes<32>(w, OpSum()); break;
+                    default: u = reduce_lanes<64>(u, OpSum()), w = reduce_lanes<64>(w, OpSum()); break;
+                    }
+                };
+                if constexpr (REC) {
+                    // ---- record walk (api.hip: build_records) ---------------------------------------------------------------
+                    // The factorisation and both substitutions of one connected system as ROUNDS: in a round a group of g
+                    // lanes owns one item -- an entry l_ij, or a column's y_j, = (target - sum a_k b_k) / sqrt(A_jj - sum
+                    // a_k^2) over ONE list (row j of L; b_k = l_ik or a zero for an entry, y_k for a column), or in the
+                    // backward substitution x_j = (y_j - sum l_ij x_i) / d_j -- and each lane's share of the list comes as
+                    // ready workspace addresses in records that are requested a round ahead: a round is value loads, a
+                    // handful of multiply-adds, the group's sum, a square root, a divide and a store.  A level of the
+                    // elimination tree is one or more rounds; the first one starts with the workgroup's rendezvous.
+                    // Order inside a round: everything that reads the records of THIS round (the addresses of its operands)
+                    // first, then the requests for the next round's records, then the work -- the counter that orders
+                    // memory loads is in-order, so a wait for this round's records placed after the new requests would wait
+                    // for those as well, a trip to L2 per round.
+                    const uint32_t R = a.rec_rounds;
+                    // a round's work for a wavefront whose lanes have NP operand pairs each (2, 6 or 10: one, two or three
+                    // chunks) -- one straight-line body per count, so that nothing in it is conditional
+                    auto rec_body = [&](auto npc, const uint4 (&cur)[REC_MAX_CHUNKS], uint32_t fl) __attribute__((always_inline)) {
+                        constexpr int NP = decltype(npc)::value;
+                        const uint32_t g = 1u << ((fl >> REC_LG_SHIFT) & 7u);
+                        // (addresses count doubles from the start of the LDS: the host knows where the workspace lies; kept as
+                        // indices -- pointers into LDS that pass through selects become generic pointers, their loads flat loads
+                        // that count with the record requests)
+                        uint32_t word[NP];
+                        word[0] = cur[0].z, word[1] = cur[0].w;
+                        if constexpr (NP > 2) word[2] = cur[1].x, word[3] = cur[1].y, word[4] = cur[1].z, word[5] = cur[1].w;
+                        if constexpr (NP > 6) word[6] = cur[2].x, word[7] = cur[2].y, word[8] = cur[2].z, word[9] = cur[2].w;
+                        double va[NP], vb[NP];
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) {
+                            va[k] = smem[word[k] & 0xFFFFu];
+                            vb[k] = smem[word[k] >> 16];
+                        }
+                        const uint32_t i_diag = cur[0].x >> 16, i_dest = cur[0].y & 0xFFFFu, lane_fl = cur[0].y;
+                        const double target = smem[cur[0].x & 0xFFFFu], diag = smem[i_diag];
+                        const bool writer = (lane_fl & REC_WRITER) != 0;
+                        // (fused multiply-adds, two partial sums each: the group's sum reorders the terms anyway)
+                        double sp0 = va[0] * vb[0], sp1 = va[1] * vb[1];
+#pragma unroll
+                        for (int k = 2; k < NP; k += 2) {
+                            sp0 = __builtin_fma(va[k], vb[k], sp0);
+                            sp1 = __builtin_fma(va[k + 1], vb[k + 1], sp1);
+                        }
+                        double sp = sp0 + sp1;
+                        if (fl & REC_BWD) {
+                            if (g > 1) sp = rec_group_sum(sp, g);
+                            const double res = (target - sp) * diag;  // (the factor's diagonal is kept as 1 / d_j)
+                            if (writer) {
+                                smem[i_dest] = res;
+                                dmax = fmax(dmax, fabs(res));
+                            }
+                        } else {
+                            double sd0 = va[0] * va[0], sd1 = va[1] * va[1];
+#pragma unroll
+                            for (int k = 2; k < NP; k += 2) {
+                                sd0 = __builtin_fma(va[k], va[k], sd0);
+                                sd1 = __builtin_fma(va[k + 1], va[k + 1], sd1);
+                            }
+                            double sd = sd0 + sd1;
+                            if (g > 1) rec_group_sum2(sd, sp, g);
+                            // 1 / sqrt(pivot) from the hardware's estimate and two coupled Newton steps (g -> sqrt, h -> 1 / (2
+                            // sqrt)): nine instructions on the level's critical path where a correctly rounded square root
+                            // followed by a correctly rounded division is forty; the last bit may differ from theirs
+                            const double acc = diag - sd;
+                            const double y0 = __builtin_amdgcn_rsq(acc);
+                            const double g0 = acc * y0, h0 = 0.5 * y0;
+                            const double r0 = __builtin_fma(-g0, h0, 0.5);
+                            const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+                            const double r1 = __builtin_fma(-g1, h1, 0.5);
+                            const double h2 = __builtin_fma(h1, r1, h1);
+                            const double rinv = h2 + h2;
+                            const double res = (target - sp) * rinv;
+                            if (lane_fl & REC_ISCOL) {
+                                if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
+                                if (writer) smem[i_diag + a.rec_dd_delta] = rinv;
+                            }
+                            if (writer) smem[i_dest] = res;
+                        }
+                    };
+                    auto rec_round = [&](uint32_t rd, uint4 (&cur)[REC_MAX_CHUNKS], uint4 (&nxt)[REC_MAX_CHUNKS]) __attribute__((always_inline)) {
+                        const uint32_t fl = rf0;
+                        const uint32_t nch = fl & REC_NCH_MASK;
+                        const uint32_t rf1 = uni(rd1.x), rc1 = uni(rd1.y);
+                        // this round's records must have arrived BEFORE the next round's are requested: the counter that orders
+                        // memory loads is in-order, a wait placed after the new requests would wait for those as well
+                        // (unconditionally, all three chunks: a wait under a condition leaves the compiler's bookkeeping with
+                        // "may be pending" at the join, and it waits again at the first use -- behind the new requests)
+                        asm volatile("" : "+v"(cur[0].x), "+v"(cur[0].y), "+v"(cur[0].z), "+v"(cur[0].w));
+                        asm volatile("" : "+v"(cur[1].x), "+v"(cur[1].y), "+v"(cur[1].z), "+v"(cur[1].w));
+                        asm volatile("" : "+v"(cur[2].x), "+v"(cur[2].y), "+v"(cur[2].z), "+v"(cur[2].w));
+                        __builtin_amdgcn_sched_barrier(0);
+                        rec_load(rf1, rc1, nxt);
+                        rd1 = rec_d[(rd + 2) * rec_nw];
+                        __builtin_amdgcn_sched_barrier(0);
+                        // (the rendezvous orders LDS traffic only: __syncthreads() would also wait for the record requests just
+                        // made -- a release at workgroup scope drains the memory-load counter -- a trip to L2 in every round)
+                        if (fl & REC_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        switch (nch) {
+                        case 1: rec_body(std::integral_constant<int, 2>{}, cur, fl); break;
+                        case 2: rec_body(std::integral_constant<int, 6>{}, cur, fl); break;
+                        case 3: rec_body(std::integral_constant<int, 10>{}, cur, fl); break;
+                        default: break;
+                        }
+                        rf0 = rf1;
+                        rc0 = rc1;
+#ifdef EZPZ_REC_TIMES
+                        if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 1 && rd < 126)
+                            reinterpret_cast<unsigned long long*>(&ws[a.rec_zero + 2])[rd] = __builtin_readcyclecounter();
+#endif
+                    };
+                    for (uint32_t rd = 0; rd < R; rd += 2) {  // (R is even: build_records pads)
+                        rec_round(rd, rpa, rpb);
+                        rec_round(rd + 1, rpb, rpa);
+                    }
+                    // (the rendezvous of the reduction below orders the last round's stores before x + d)
+#ifdef EZPZ_REC_TIMES
+                    if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 1)
+                        for (uint32_t rd = 0; rd < R && rd < 126; ++rd)
+                            a.stamps[4096 + rd] = reinterpret_cast<unsigned long long*>(&ws[a.rec_zero + 2])[rd];
+#endif
+                    EZPZ_STAMP(11);
+                } else if constexpr (DENSE) {
                     // ---- <= 8 variables, four lanes: the whole linear solve in registers (dense8_solve) --------------------
                     bad = dense8_solve(ws, o_d, o_l, o_v, lvl_sptr, n, tm.lane);
                     tm.phase_sync();
@@ -1011,7 +1196,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN ? 1024 : 512), M
                 // d is final), then the block's triangle.  ~1 k cycles per column of the longest block instead of
                 // ~4 k per level.  The sums run in a different order than the list walk's (as between any two elimination
                 // orders).
-                constexpr bool ROOT_OK = (MODE == MODE_WGB || (MODE == MODE_SUB && TEAM == 64)) && !GRID && !DENSE;
+                constexpr bool ROOT_OK = (MODE == MODE_WGB || (MODE == MODE_SUB && TEAM == 64)) && !GRID && !DENSE && !REC;
                 // (one wavefront per system: every team has its own panels and walks all blocks of a phase itself)
                 double* const dense_base = smem + a.dense_lds_off + (MODE == MODE_SUB ? (size_t)(tid >> 6) * a.dense_lds_doubles : 0);
                 const uint32_t dense_wave = MODE == MODE_SUB ? 0u : (uint32_t)tid >> 6;

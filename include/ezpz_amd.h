@@ -161,7 +161,8 @@ typedef struct EzpzSystemInfo {
     uint32_t workspace_in_lds;
     uint32_t team_mode;     /* 0 sub-wavefront teams, 1 wavefront-partitioned workgroup, 2 barrier workgroup,
                              * 3 component-resident (one lane per connected component; n_partitions = chunks of <= 64
-                             * components of one isomorphism class) */
+                             * components of one isomorphism class), 4 barrier workgroup whose linear solve is a record
+                             * walk (one solve of one connected sketch: EZPZ_TEAM_AUTO_LATENCY) */
     uint32_t n_partitions;  /* partitions (balanced unions of components), one per wavefront in mode 1 */
     uint32_t program_in_lds;
     uint32_t grid_workgroups; /* workgroups that share one system (grid team: one large system on many CUs), else 1 */
@@ -190,6 +191,9 @@ const char* ezpz_error_string(int err);
 /* automatic, and a connected sketch of more than 20 variables runs one lane per system (lanes across the batch) at every
  * batch size instead of from 64 x 2 x CUs systems per call (A/B runs and tests) */
 #define EZPZ_TEAM_BATCH_LANES 0xFFFFFFFDu
+/* EZPZ_TEAM_AUTO_LATENCY without the record walk (team_mode 4): one connected sketch then ends its elimination with
+ * dense phases on the barrier workgroup (team_mode 2), as every latency shape did before round 3 (A/B runs and tests) */
+#define EZPZ_TEAM_LATENCY_PHASES 0xFFFFFFFCu
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);
 void ezpz_system_destroy(EzpzSystem* sys);

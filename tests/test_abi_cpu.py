@@ -111,7 +111,7 @@ def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
 def _shapes_analyse(recs, n):
     """Every automatic launch shape: where there is no device, creation analyses the system and then reports -100; where
     there is one it succeeds."""
-    for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_BATCH_LANES):
+    for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_PHASES, E.TEAM_BATCH_LANES):
         try:
             E.System(recs, n, team_size=team)
         except E.NonLinearSystemError as e:

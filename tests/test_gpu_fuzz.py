@@ -42,7 +42,7 @@ def test_graph_families_on_every_launch_shape(E, chunk):
         cfg = dict(max_iterations=50)
         rc, xo, it, conv, _ = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
         assert rc == 0
-        for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_BATCH_LANES, 512):
+        for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_PHASES, E.TEAM_BATCH_LANES, 512):
             x, st, _ = E.System(recs, n, team_size=team).solve_batch(x0, E.Config(**cfg))
             needed += assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg),
                                                   oracle_result=(xo, it, conv), what=(family, seed, npts, team))
@@ -65,7 +65,7 @@ def test_connected_sketches_on_the_team_shapes(E, chunk):
         cfg = dict(max_iterations=60)
         rc, xo, it, conv, _ = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
         assert rc == 0
-        for team in (0, E.TEAM_AUTO_LATENCY, 128):
+        for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_PHASES, 128):
             x, st, _ = E.System(recs, n, team_size=team).solve_batch(x0, E.Config(**cfg))
             needed += assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg),
                                                   oracle_result=(xo, it, conv), what=(seed, npts, team))

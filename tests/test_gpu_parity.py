@@ -240,7 +240,8 @@ def test_single_large_component_uses_barrier_workgroup(E, team):
     sysobj = E.System(recs, len(g), team_size=E.TEAM_AUTO_LATENCY if team == "latency" else team)
     info = sysobj.info()
     assert info["n_components"] == 1 and info["n_partitions"] == 1
-    assert (info["team_mode"], info["team_size"]) == ((0, 64) if team == 0 else (2, info["team_size"]))
+    # (one solve's shape runs its linear solve as a record walk: team_mode 4)
+    assert info["team_mode"] == (0 if team == 0 else 4 if team == "latency" else 2) and (team != 0 or info["team_size"] == 64)
     x0 = g[None, :] + gen.keyed_uniform(5, 6, len(g), -0.05, 0.05)
     x, st, _ = sysobj.solve_batch(x0)
     rc, xo, it, conv, nun = O.solve_batch(recs, x0)
@@ -666,9 +667,14 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
 
 
 @pytest.mark.parametrize("npts", [60, 150, 260, 400, 1200])
-def test_connected_sketch_latency_shape_with_dense_root_block(E, npts):
-    """The launch shape of one solve (`TEAM_AUTO_LATENCY`, what `ezpz_solve` asks for) ends the elimination of a connected
-    sketch with dense phases: runs of levels at the top of the elimination tree whose columns fall into independent
+@pytest.mark.parametrize("shape", ["phases", "records"])
+def test_connected_sketch_latency_shape_with_dense_root_block(E, npts, shape):
+    """The launch shape of one solve (`TEAM_AUTO_LATENCY`, what `ezpz_solve` asks for) runs the linear solve of a connected
+    sketch whose state fits the LDS as a RECORD WALK (api.hip: build_records; lm_kernel.hip.hpp: REC builds): every level of
+    the elimination tree one or more rounds in which a group of lanes owns one entry, the lanes' operand addresses ready in
+    records requested a round ahead (`shape` "records": team_mode 4; 2400 variables do not fit and keep the phases).
+    `TEAM_LATENCY_PHASES` keeps what that shape did before: it ends the elimination
+    with dense phases: runs of levels at the top of the elimination tree whose columns fall into independent
     blocks of <= 16 (the last one the root block: the last <= 16 columns), each block's Schur complement gathered by
     all lanes and factorised in one wavefront's registers (api.hip: make_dense_phases; lm_kernel.hip.hpp: dense
     phases), with the program staged in LDS (120-520 variables), read from global memory (800) and with the workspace
@@ -677,11 +683,16 @@ def test_connected_sketch_latency_shape_with_dense_root_block(E, npts):
     run, from a NaN start (every pivot fails: lambda grows, the iterations burn) and on an inconsistent system."""
     recs, g = gen.connected_sketch(npts, 500 + npts)
     n = len(g)
-    lat = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY)
+    latency = E.TEAM_AUTO_LATENCY if shape == "records" else E.TEAM_LATENCY_PHASES
+    lat = E.System(recs, n, team_size=latency)
     walk = E.System(recs, n, team_size=512)
     li, wi = lat.info(), walk.info()
-    assert li["team_mode"] == 2 and li["n_components"] == 1
-    assert li["n_levels"] + 4 <= wi["n_levels"], (li["n_levels"], wi["n_levels"])  # the top levels became the block
+    assert li["n_components"] == 1
+    if shape == "records" and npts < 1200:
+        assert li["team_mode"] == 4 and li["workspace_in_lds"] and li["n_levels"] == wi["n_levels"]
+    else:
+        assert li["team_mode"] == 2
+        assert li["n_levels"] + 4 <= wi["n_levels"], (li["n_levels"], wi["n_levels"])  # the top levels became the block
     cfg = dict(max_iterations=40)
     x0 = g[None, :] + gen.keyed_uniform(npts, 6, n, -0.02, 0.02)
     x0[0] = g
@@ -706,7 +717,7 @@ def test_connected_sketch_latency_shape_with_dense_root_block(E, npts):
     # an inconsistent sketch (the last point pinned away from where its distances put it): least-squares exit, same
     # unsatisfied rows as the oracle's
     bad = O.stack(list(recs) + [O.fixed(n - 2, float(g[n - 2]) + 0.4)])
-    lat2 = E.System(bad, n, team_size=E.TEAM_AUTO_LATENCY)
+    lat2 = E.System(bad, n, team_size=latency)
     xb, stb, maskb = lat2.solve_batch(g[None, :], E.Config(max_iterations=60), want_mask=True)
     want = O.solve(bad, g, O.Config(max_iterations=60), linsolve=O.LINSOLVE_SPARSE, warn_cap=1 << 16)
     assert bool(stb["converged"][0]) == want.converged and np.nonzero(maskb[0])[0].tolist() == want.unsatisfied
@@ -719,9 +730,12 @@ def test_sketch_whose_workspace_fills_the_lds_keeps_its_dense_phases(E):
     """1408 variables: 156 KB of workspace in LDS, the program read from global memory, and the few KB left go to the dense
     panels rather than to the level staging buffer (api.hip, analyze_into).  Against the oracle."""
     recs, g = gen.connected_sketch(704, 288)
-    s = E.System(recs, len(g), team_size=E.TEAM_AUTO_LATENCY)
+    s = E.System(recs, len(g), team_size=E.TEAM_LATENCY_PHASES)
     plain = E.System(recs, len(g), team_size=512)
     assert s.info()["workspace_in_lds"] == 1 and s.info()["n_levels"] + 5 <= plain.info()["n_levels"]
+    # (the record walk needs the factor's diagonal a second time and its descriptors in LDS: no room here, so one solve's
+    # automatic shape is the same one)
+    assert E.System(recs, len(g), team_size=E.TEAM_AUTO_LATENCY).info()["team_mode"] == 2
     x0 = np.stack([g, g + 0.01])
     cfg = dict(max_iterations=40)
     x, st, mask = s.solve_batch(x0, E.Config(**cfg), want_mask=True)
