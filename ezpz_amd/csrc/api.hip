@@ -1363,7 +1363,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     const bool for_latency = team_size == EZPZ_TEAM_AUTO_LATENCY || latency_phases;
     const bool batch_lanes = team_size == EZPZ_TEAM_BATCH_LANES;
     const bool auto_shape = team_size == 0 || for_latency || batch_lanes;
-    if (for_latency || batch_lanes || team_size == EZPZ_TEAM_AUTO_LISTS) team_size = 0;
+    const bool lists_only = team_size == EZPZ_TEAM_AUTO_LISTS;  // the list-walk shapes as they are chosen for batches, dense phases included
+    if (for_latency || batch_lanes || lists_only) team_size = 0;
     bool want_sub = team_size ? team_size <= 64 : width <= 64;
     if (want_sub) {
         uint32_t team = team_size ? pow2_ceil(team_size) : auto_sub_team(cs, n_cs);
@@ -1558,12 +1559,33 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     s.rec = false;
     s.rec_rounds = 0;
     s.rec_extra = 0;
-    const bool rec_try = rec_enabled && auto_shape && for_latency && !latency_phases && s.mode == MODE_WGB && s.grid_wgs == 1 && P.c.n_parts == 1 &&
-                         P.c.n_components == 1 && !P.c.dense;
+    // Batches of one connected sketch on the per-system teams take the record walk as well -- one wavefront up to 160 variables,
+    // a 128-lane workgroup while two fit a CU, 512 lanes beyond -- instead of one wavefront / a lean workgroup walking level lists
+    // with dense phases on top: 100 / 150 / 200 / 300 / 500 / 800 variables 10.5 -> 23.0, 4.3 -> 8.7, 4.0 -> 7.5, 1.49 -> 3.10,
+    // 0.33 -> 0.61 M solves/s, 57 -> 86 k (EZPZ_REC_BATCH = lanes for A/B runs, 0 = the shapes above).
+    static const int rec_batch_lanes = [] {
+        const char* e = std::getenv("EZPZ_REC_BATCH");
+        return e ? std::atoi(e) : -1;
+    }();
+    const int saved_mode = s.mode;
+    const uint32_t saved_team = s.team_size;
+    const bool saved_lean = s.lean_lds;
+    const bool rec_batch = rec_enabled && rec_batch_lanes != 0 && auto_shape && team_size == 0 && !for_latency && !want_sub &&
+                           s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;
+    if (rec_batch) {
+        const size_t ws_b = ((size_t)workspace_doubles(P.c) + P.c.n_vars + 4) * 8;
+        uint32_t t = P.c.n_vars <= 160 ? 64u : ws_b + 4096 <= s.lim.lds_bytes / 2 ? 128u : 512u;
+        if (rec_batch_lanes >= 64 && rec_batch_lanes <= 512 && rec_batch_lanes % 64 == 0) t = (uint32_t)rec_batch_lanes;
+        s.mode = MODE_WGB;
+        s.team_size = t;
+        s.lean_lds = t <= 128;
+    }
+    const bool rec_try = rec_enabled && auto_shape && ((for_latency && !latency_phases) || rec_batch) && s.mode == MODE_WGB &&
+                         s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;
     if (rec_try) {
         s.rec_extra = (P.c.n_vars + 2 + 1) & ~1u;
 #ifdef EZPZ_REC_TIMES
-        s.rec_extra += 128;  // (diagnostic build: a cycle stamp per round of the second iteration's walk, behind the zero)
+        s.rec_extra += 6 * 128;  // (diagnostic build: six cycle stamps per round of the second iteration's walk, behind the zero)
 #endif
         if (const char* e = std::getenv("EZPZ_REC_LANES")) {  // (A/B runs)
             const uint32_t t = (uint32_t)std::atoi(e);
@@ -1581,6 +1603,11 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
         if (!s.rec) {
             s.rec_extra = 0;
+            if (rec_batch) {  // no room: the shape chosen before
+                s.mode = saved_mode;
+                s.team_size = saved_team;
+                s.lean_lds = saved_lean;
+            }
             pack_and_shape(true);
         }
     }
@@ -1607,7 +1634,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     } else if (s.lds_bytes + 4096 * teams_now <= s.lim.lds_bytes) {  // (one solve: occupancy does not matter)
         dense_room = std::min<size_t>((s.lim.lds_bytes - s.lds_bytes - 1024) / teams_now, 48 * 1024);
     }
-    if (root_enabled && auto_shape && s.grid_wgs == 1 && !s.rec &&
+    if (root_enabled && (auto_shape || lists_only) && s.grid_wgs == 1 && !s.rec &&
         ((s.mode == MODE_WGB && (for_latency || s.team_size >= 128)) || wave_teams) && dense_room >= 1024 &&
         make_dense_phases(P, wave_teams ? 1 : s.team_size / 64, dense_room)) {
         const int mode_before = s.mode;
@@ -1719,7 +1746,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     s.lanes.reset();
     // (sketches of up to 64 variables: twice that -- their rounds are short, the lanes' time is a latency floor of ~3 ms
     // whatever the batch, and the teams run them at 12-19 M solves/s: 32 768 systems of 50 variables 9.8 M/s on the lanes)
-    s.lanes_min = batch_lanes ? 1 : 64ull * (n_vars <= 64 ? 4 : 2) * (s.lim.cus ? s.lim.cus : 256);
+    // (and up to 400 variables since the teams walk records: 32 768 systems of 100 / 150 / 300 / 500 variables 15.2 / 5.9 / 2.3 / 0.69
+    // M solves/s on the lanes, 22.4 / 8.6 / 3.1 / 0.61 on the teams; 65 536: 26.4 / 10.5 / 4.3 / 1.27 against 22.8 / 8.7 / 3.1 / 0.61)
+    s.lanes_min = batch_lanes ? 1 : 64ull * (n_vars <= 400 ? 4 : 2) * (s.lim.cus ? s.lim.cus : 256);
     static const bool lanes_enabled = [] {
         const char* e = std::getenv("EZPZ_LANES");
         return !(e && e[0] == '0');

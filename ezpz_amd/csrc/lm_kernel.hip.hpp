@@ -826,12 +826,17 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                 const uint2* const rec_d = reinterpret_cast<const uint2*>(smem + a.rec_desc_off) + (tid >> 6);
                 const uint4* const rec_c = a.rec_chunks + (tid & 63);
                 // this wavefront's chunks of the round with descriptor `d` (0-3 of them)
+                // (always three requests: a request under a condition makes its registers a merge of "loaded" and "kept", the
+                // merge a copy, and the copy waits for the load right behind it; the chunks a wavefront does not have are read
+                // from one 16-byte address instead -- a single line for all its lanes -- and never looked at)
                 auto rec_load = [&](uint32_t fl, uint32_t chunk0, uint4 (&pr)[REC_MAX_CHUNKS]) __attribute__((always_inline)) {
                     const uint32_t nch = fl & REC_NCH_MASK;
                     const uint4* src = rec_c + (size_t)chunk0 * 64;
 #pragma unroll
-                    for (int c = 0; c < REC_MAX_CHUNKS; ++c)
-                        if ((uint32_t)c < nch) pr[c] = src[c * 64];
+                    for (int c = 0; c < REC_MAX_CHUNKS; ++c) {
+                        const uint4* from = (uint32_t)c < nch ? src + c * 64 : a.rec_chunks;
+                        pr[c] = *from;
+                    }
                 };
                 uint32_t rf0 = 0, rc0 = 0;  // this round's descriptor (scalars)
                 uint2 rd1 = {0, 0};         // the next round's, as read from LDS
@@ -870,24 +875,41 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                 EZPZ_STAMP(10);
                 double bad = 0.0;
                 double dmax = __builtin_nan("");  // fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax)
-                auto rec_group_sum = [&](double v, uint32_t g) {
-                    switch (g) {
-                    case 2: return reduce_lanes<2>(v, OpSum());
-                    case 4: return reduce_lanes<4>(v, OpSum());
-                    case 8: return reduce_lanes<8>(v, OpSum());
-                    case 16: return reduce_lanes<16>(v, OpSum());
-                    case 32: return reduce_lanes<32>(v, OpSum());
-                    default: return reduce_lanes<64>(v, OpSum());
+                // the sum over a group of g = 2^lg lanes, in every lane of the group: one body, each step behind a scalar test
+                // (a switch over g is a search through compares and one body per case: more instructions fetched per round)
+                auto rec_group_sum = [&](double v, uint32_t lg) __attribute__((always_inline)) {
+                    if (lg >= 1) v += dpp_move<0xB1>(v);
+                    if (lg >= 2) v += dpp_move<0x4E>(v);
+                    if (lg >= 3) v += dpp_move<0x141>(v);
+                    if (lg >= 4) v += dpp_move<0x140>(v);
+                    if (lg >= 5) {
+                        double x, y;
+                        lane_pairs<false>(v, x, y);
+                        v = x + y;
                     }
+                    if (lg >= 6) {
+                        double x, y;
+                        lane_pairs<true>(v, x, y);
+                        v = x + y;
+                    }
+                    return v;
                 };
-                auto rec_group_sum2 = [&](double& u, double& w, uint32_t g) {  // (the two chains of cross-lane moves interleave)
-                    switch (g) {
-                    case 2: u = reduce_lanes<2>(u, OpSum()), w = reduce_lanes<2>(w, OpSum()); break;
-                    case 4: u = reduce_lanes<4>(u, OpSum()), w = reduce_lanes<4>(w, OpSum()); break;
-                    case 8: u = reduce_lanes<8>(u, OpSum()), w = reduce_lanes<8>(w, OpSum()); break;
-                    case 16: u = reduce_lanes<16>(u, OpSum()), w = reduce_lanes<16>(w, OpSum()); break;
-                    case 32: u = reduce_lanes<32>(u, OpSum()), w = reduce_lanes<32>(w, OpSum()); break;
-                    default: u = reduce_lanes<64>(u, OpSum()), w = reduce_lanes<64>(w, OpSum()); break;
+                auto rec_group_sum2 = [&](double& u, double& w, uint32_t lg) __attribute__((always_inline)) {  // (two chains interleave)
+                    if (lg >= 1) u += dpp_move<0xB1>(u), w += dpp_move<0xB1>(w);
+                    if (lg >= 2) u += dpp_move<0x4E>(u), w += dpp_move<0x4E>(w);
+                    if (lg >= 3) u += dpp_move<0x141>(u), w += dpp_move<0x141>(w);
+                    if (lg >= 4) u += dpp_move<0x140>(u), w += dpp_move<0x140>(w);
+                    if (lg >= 5) {
+                        double x, y, p, q;
+                        lane_pairs<false>(u, x, y);
+                        lane_pairs<false>(w, p, q);
+                        u = x + y, w = p + q;
+                    }
+                    if (lg >= 6) {
+                        double x, y, p, q;
+                        lane_pairs<true>(u, x, y);
+                        lane_pairs<true>(w, p, q);
+                        u = x + y, w = p + q;
                     }
                 };
                 if constexpr (REC) {
@@ -906,9 +928,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                     const uint32_t R = a.rec_rounds;
                     // a round's work for a wavefront whose lanes have NP operand pairs each (2, 6 or 10: one, two or three
                     // chunks) -- one straight-line body per count, so that nothing in it is conditional
-                    auto rec_body = [&](auto npc, const uint4 (&cur)[REC_MAX_CHUNKS], uint32_t fl) __attribute__((always_inline)) {
+                    auto rec_body = [&](auto npc, const uint4 (&cur)[REC_MAX_CHUNKS], uint32_t fl, unsigned long long* tst) __attribute__((always_inline)) {
                         constexpr int NP = decltype(npc)::value;
-                        const uint32_t g = 1u << ((fl >> REC_LG_SHIFT) & 7u);
+                        const uint32_t lg = (fl >> REC_LG_SHIFT) & 7u;
                         // (addresses count doubles from the start of the LDS: the host knows where the workspace lies; kept as
                         // indices -- pointers into LDS that pass through selects become generic pointers, their loads flat loads
                         // that count with the record requests)
@@ -933,8 +955,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                             sp1 = __builtin_fma(va[k + 1], vb[k + 1], sp1);
                         }
                         double sp = sp0 + sp1;
+#ifdef EZPZ_REC_TIMES
+                        if (tst) { asm volatile("" : "+v"(sp)); tst[2] = __builtin_readcyclecounter(); }
+#endif
                         if (fl & REC_BWD) {
-                            if (g > 1) sp = rec_group_sum(sp, g);
+                            sp = rec_group_sum(sp, lg);
                             const double res = (target - sp) * diag;  // (the factor's diagonal is kept as 1 / d_j)
                             if (writer) {
                                 smem[i_dest] = res;
@@ -948,7 +973,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                                 sd1 = __builtin_fma(va[k + 1], va[k + 1], sd1);
                             }
                             double sd = sd0 + sd1;
-                            if (g > 1) rec_group_sum2(sd, sp, g);
+                            rec_group_sum2(sd, sp, lg);
+#ifdef EZPZ_REC_TIMES
+                            if (tst) { asm volatile("" : "+v"(sp), "+v"(sd)); tst[3] = __builtin_readcyclecounter(); }
+#endif
                             // 1 / sqrt(pivot) from the hardware's estimate and two coupled Newton steps (g -> sqrt, h -> 1 / (2
                             // sqrt)): nine instructions on the level's critical path where a correctly rounded square root
                             // followed by a correctly rounded division is forty; the last bit may differ from theirs
@@ -960,7 +988,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                             const double r1 = __builtin_fma(-g1, h1, 0.5);
                             const double h2 = __builtin_fma(h1, r1, h1);
                             const double rinv = h2 + h2;
-                            const double res = (target - sp) * rinv;
+                            double res = (target - sp) * rinv;
+#ifdef EZPZ_REC_TIMES
+                            if (tst) { asm volatile("" : "+v"(res)); tst[4] = __builtin_readcyclecounter(); }
+#endif
                             if (lane_fl & REC_ISCOL) {
                                 if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
                                 if (writer) smem[i_diag + a.rec_dd_delta] = rinv;
@@ -972,6 +1003,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                         const uint32_t fl = rf0;
                         const uint32_t nch = fl & REC_NCH_MASK;
                         const uint32_t rf1 = uni(rd1.x), rc1 = uni(rd1.y);
+#ifdef EZPZ_REC_TIMES
+                        const bool stamping = a.stamps && blockIdx.x == 0 && tid == 0 && it == 1 && rd < 126;
+                        unsigned long long* const tstamp = reinterpret_cast<unsigned long long*>(&ws[a.rec_zero + 2]) + 6 * rd;
+                        if (stamping) tstamp[0] = __builtin_readcyclecounter();
+#endif
                         // this round's records must have arrived BEFORE the next round's are requested: the counter that orders
                         // memory loads is in-order, a wait placed after the new requests would wait for those as well
                         // (unconditionally, all three chunks: a wait under a condition leaves the compiler's bookkeeping with
@@ -986,17 +1022,24 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                         // (the rendezvous orders LDS traffic only: __syncthreads() would also wait for the record requests just
                         // made -- a release at workgroup scope drains the memory-load counter -- a trip to L2 in every round)
                         if (fl & REC_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef EZPZ_REC_TIMES
+                        if (stamping) tstamp[1] = __builtin_readcyclecounter();
+#endif
+#ifdef EZPZ_REC_TIMES
+#define REC_TST (stamping ? tstamp : nullptr)
+#else
+#define REC_TST nullptr
+#endif
                         switch (nch) {
-                        case 1: rec_body(std::integral_constant<int, 2>{}, cur, fl); break;
-                        case 2: rec_body(std::integral_constant<int, 6>{}, cur, fl); break;
-                        case 3: rec_body(std::integral_constant<int, 10>{}, cur, fl); break;
+                        case 1: rec_body(std::integral_constant<int, 2>{}, cur, fl, REC_TST); break;
+                        case 2: rec_body(std::integral_constant<int, 6>{}, cur, fl, REC_TST); break;
+                        case 3: rec_body(std::integral_constant<int, 10>{}, cur, fl, REC_TST); break;
                         default: break;
                         }
                         rf0 = rf1;
                         rc0 = rc1;
 #ifdef EZPZ_REC_TIMES
-                        if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 1 && rd < 126)
-                            reinterpret_cast<unsigned long long*>(&ws[a.rec_zero + 2])[rd] = __builtin_readcyclecounter();
+                        if (stamping) tstamp[5] = __builtin_readcyclecounter();
 #endif
                     };
                     for (uint32_t rd = 0; rd < R; rd += 2) {  // (R is even: build_records pads)
@@ -1006,7 +1049,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                     // (the rendezvous of the reduction below orders the last round's stores before x + d)
 #ifdef EZPZ_REC_TIMES
                     if (a.stamps && blockIdx.x == 0 && tid == 0 && it == 1)
-                        for (uint32_t rd = 0; rd < R && rd < 126; ++rd)
+                        for (uint32_t rd = 0; rd < 6 * R && rd < 6 * 126; ++rd)
                             a.stamps[4096 + rd] = reinterpret_cast<unsigned long long*>(&ws[a.rec_zero + 2])[rd];
 #endif
                     EZPZ_STAMP(11);

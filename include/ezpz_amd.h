@@ -186,7 +186,8 @@ const char* ezpz_error_string(int err);
  * a connected sketch of a few hundred variables then runs on a 256-512 lane workgroup with its lists staged in LDS
  * instead of one wavefront / a lean 128-lane workgroup: ~35 % sooner per solve at less than half the batch rate). */
 #define EZPZ_TEAM_AUTO_LATENCY 0xFFFFFFFFu
-/* automatic choice among the list-walk shapes only (team_mode 0-2): never the component-resident shape (A/B runs) */
+/* automatic choice among the list-walk shapes only (team_mode 0-2, dense phases included): never the component-resident
+ * shape, one lane per system or the record walk (A/B runs and tests) */
 #define EZPZ_TEAM_AUTO_LISTS 0xFFFFFFFEu
 /* automatic, and a connected sketch of more than 20 variables runs one lane per system (lanes across the batch) at every
  * batch size instead of from 64 x 2 x CUs systems per call (A/B runs and tests) */

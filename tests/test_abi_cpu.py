@@ -95,7 +95,8 @@ def test_symbolic_sizes_massive_and_square():
 def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
     """Host side of the dense phases (api.hip: make_dense_phases): on a 512-lane workgroup the top of a connected
     sketch's elimination tree -- runs of levels of one or two columns per branch -- is a few phases of the schedule;
-    EZPZ_ROOT=0 keeps the plain schedule (read once per process, hence the child processes).  Block systems keep theirs."""
+    EZPZ_ROOT=0 keeps the plain schedule (read once per process, hence the child processes).  Block systems keep theirs, and
+    so does the record walk (api.hip: build_records), the automatic shape of such a sketch."""
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import gen, ezpz_amd as E; "
             "from oracle import textual as T; r, g = gen.connected_sketch(400, 7); cs = T.load(T.gen_big_problem(500)); "
@@ -104,8 +105,10 @@ def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         return [int(v) for v in out.stdout.split()]
-    with_block, plain = levels(), levels(EZPZ_ROOT="0")
+    # (EZPZ_REC=0: the list-walk shapes; by default a batch of one connected sketch walks records over every level)
+    with_block, plain, records = levels(EZPZ_REC="0"), levels(EZPZ_REC="0", EZPZ_ROOT="0"), levels()
     assert with_block[0] + 5 <= plain[0] and with_block[1] == plain[1] == 2, (with_block, plain)
+    assert records == plain, (records, plain)
 
 
 def _shapes_analyse(recs, n):

@@ -240,8 +240,8 @@ def test_single_large_component_uses_barrier_workgroup(E, team):
     sysobj = E.System(recs, len(g), team_size=E.TEAM_AUTO_LATENCY if team == "latency" else team)
     info = sysobj.info()
     assert info["n_components"] == 1 and info["n_partitions"] == 1
-    # (one solve's shape runs its linear solve as a record walk: team_mode 4)
-    assert info["team_mode"] == (0 if team == 0 else 4 if team == "latency" else 2) and (team != 0 or info["team_size"] == 64)
+    # (automatic shapes walk records: team_mode 4 -- 128 lanes for a batch of 240 variables, more for one solve)
+    assert info["team_mode"] == (4 if team in (0, "latency") else 2) and (team != 0 or info["team_size"] == 128)
     x0 = g[None, :] + gen.keyed_uniform(5, 6, len(g), -0.05, 0.05)
     x, st, _ = sysobj.solve_batch(x0)
     rc, xo, it, conv, nun = O.solve_batch(recs, x0)
@@ -640,19 +640,27 @@ def test_random_block_systems_are_deterministic_and_match_the_oracle(E, team, nc
             assert bool(st["converged"][0]) and float(st["final_residual_inf"][0]) <= 1e-8
 
 
-@pytest.mark.parametrize("npts,team,mode", [(90, 0, 0), (150, 0, 2), (150, 256, 2), (400, 0, 2), (1500, 0, 2)])
+LISTS = 0xFFFFFFFE  # E.TEAM_AUTO_LISTS
+
+
+@pytest.mark.parametrize("npts,team,mode", [(90, LISTS, 0), (150, LISTS, 2), (150, 256, 2), (400, LISTS, 2), (1500, 0, 2),
+                                            (60, 0, 4), (90, 0, 4), (150, 0, 4), (400, 0, 4)])
 def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, team, mode):
     """One connected component of mixed kinds (a random polyline-like sketch: every point tied to its predecessors by
-    one or two random constraints) on one wavefront (180 variables), on a lean 128-lane workgroup whose lists stay in
-    global memory (300), on the barrier workgroup with staged lists (300 on 256 lanes), with its workspace in LDS (800)
-    and in global memory (3000): deterministic from run to run, and -- it is fully determined by construction -- the
-    oracle's answer."""
-    recs, g = gen.connected_sketch(npts, 77 + npts + team)
+    one or two random constraints).  The list-walk shapes (`TEAM_AUTO_LISTS`, what batches ran on before the record walk):
+    one wavefront (180 variables), a lean 128-lane workgroup whose lists stay in
+    global memory (300), the barrier workgroup with staged lists (300 on 256 lanes), with its workspace in LDS (800)
+    and in global memory (3000: the automatic shape too, its state does not fit the LDS).  The automatic batch shape: the
+    record walk (team_mode 4) on one wavefront (120, 180 variables), on 128 lanes (300) and on 512 (800).  Deterministic
+    from run to run, and -- it is fully determined by construction -- the oracle's answer."""
+    recs, g = gen.connected_sketch(npts, 77 + npts + (team if team < 1024 else 0))
     sysobj = E.System(recs, len(g), team_size=team)
     info = sysobj.info()
     assert info["n_components"] == 1 and info["team_mode"] == mode and info["n_partitions"] == 1
-    if (npts, team) == (150, 0):
+    if (npts, team) == (150, LISTS):
         assert info["team_size"] == 128 and not info["program_in_lds"]
+    if mode == 4:
+        assert info["team_size"] == {60: 64, 90: 128, 150: 128, 400: 512}[npts] and info["workspace_in_lds"]
     x0 = np.tile(g, (5, 1))
     cfg = dict(max_iterations=60)
     x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
@@ -791,14 +799,15 @@ def test_hub_sketch_with_one_level_wider_than_the_team_and_its_staging_buffer(E,
         assert_x_close(x[b], want.final_values)
 
 
-@pytest.mark.parametrize("npts,hub_last,shape", [(40, True, (0, 64)), (100, False, (0, 64)), (300, True, (2, 128))])
+@pytest.mark.parametrize("npts,hub_last,shape", [(40, True, (0, 64)), (100, False, (0, 64)), (300, True, (2, 128)),
+                                                 (40, True, (4, 64)), (100, False, (4, 128)), (300, True, (4, 128))])
 def test_small_hub_sketch_on_one_wavefront_or_lean_workgroup(E, npts, hub_last, shape):
-    """The hub sketch at the sizes batches run on one wavefront per system (82, 202 variables) or on a lean 128-lane
-    workgroup (602): its first level is wider than the team (two-phase walk) and, from 100 points, larger than the
+    """The hub sketch at the sizes the list-walk shapes run on one wavefront per system (82, 202 variables) or on a lean
+    128-lane workgroup (602): its first level is wider than the team (two-phase walk) and, from 100 points, larger than the
     team's staging buffer (walked from global memory); the hub's levels are one phase with lists shared by groups of
-    lanes."""
+    lanes.  And on the automatic batch shape (record walk, team_mode 4): the wide level is several rounds."""
     recs, g = _hub_sketch(npts, 77 + npts, hub_last)
-    sysobj = E.System(recs, len(g))
+    sysobj = E.System(recs, len(g), team_size=0 if shape[0] == 4 else E.TEAM_AUTO_LISTS)
     info = sysobj.info()
     assert info["n_components"] == 1 and (info["team_mode"], info["team_size"]) == shape
     x0 = g[None, :] + gen.keyed_uniform(41, 64, len(g), -0.05, 0.05)

@@ -20,7 +20,13 @@ stream = torch.cuda.current_stream(dev).cuda_stream
 for _ in range(3):
     buf.zero_(); s.solve_batch_device(x0.data_ptr(), 1, xo.data_ptr(), st.data_ptr(), 0, stream)
 torch.cuda.synchronize()
-t = buf.cpu().numpy()[4096:4096 + 126]
-t = t[t > 0]
-print("rounds", len(t), "cycles per round:", list(np.diff(t)))
-print("mean", np.diff(t).mean())
+t = buf.cpu().numpy()[4096:4096 + 6 * 126].reshape(-1, 6)
+t = t[t[:, 0] > 0]
+print("# round: start -> rendezvous' exit (record wait, requests, the other wavefronts) | -> partial sums (operand loads) | -> group sums | -> 1/sqrt and quotient | -> end (stores) | -> next round's start   [backward rounds: no group-sum / sqrt stamps]")
+for r in range(len(t)):
+    nxt = t[r + 1, 0] - t[r, 5] if r + 1 < len(t) else 0
+    if t[r, 3] > 0:
+        print(f"round {r:3d}: {t[r, 1] - t[r, 0]:5d} | {t[r, 2] - t[r, 1]:5d} | {t[r, 3] - t[r, 2]:5d} | {t[r, 4] - t[r, 3]:5d} | {t[r, 5] - t[r, 4]:5d} | {nxt:5d}")
+    else:
+        print(f"round {r:3d}: {t[r, 1] - t[r, 0]:5d} | {t[r, 2] - t[r, 1]:5d} |     - |     - | {t[r, 5] - t[r, 2]:5d} | {nxt:5d}")
+print("rounds", len(t), "mean cycles per round", (t[-1, 5] - t[0, 0]) / len(t))
