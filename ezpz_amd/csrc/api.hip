@@ -183,7 +183,8 @@ struct EzpzSystem {
     // records; rec_extra = doubles behind the workspace proper (the factor's diagonal, one zero), offsets into the blob
     bool rec = false;
     uint32_t rec_extra = 0, rec_rounds = 0, rec_desc_lds_off = 0;
-    size_t rec_desc_off = 0, rec_chunks_off = 0;
+    size_t rec_desc_off = 0, rec_chunks_off = 0, rec_asm_cols_off = 0, rec_asm_slots_off = 0;
+    uint32_t rec_asm_kc = 0, rec_asm_ks = 0;
     uint32_t ws_doubles = 0;
     uint32_t block_threads = 256;
     size_t lds_bytes = 0;
@@ -956,6 +957,9 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
 struct RecPlan {
     std::vector<uint32_t> desc, chunks;
     uint32_t rounds = 0;
+    // packed assembly (SolveArgs::rec_asm_*): chunks per column / per entry of the strict lower part (0: none, the lists are walked)
+    std::vector<uint32_t> asm_cols, asm_slots;
+    uint32_t asm_kc = 0, asm_ks = 0;
 };
 static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, RecPlan& out) {
     if (P.c.n_parts != 1 || P.parts.size() != 1 || P.c.dense || P.n_dense || T < 64 || T % 64) return false;
@@ -1038,6 +1042,25 @@ static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, RecPl
     out.desc.clear();
     out.chunks.clear();
     out.rounds = 0;
+    {  // packed assembly: every column's (J slot, row of r) pairs and every lower entry's (J slot, J slot) pairs, four to a chunk
+        const uint32_t o_r = lds_base + n, o_j = lds_base + n + 2 * m;
+        const uint32_t call0 = P.lvl_cptr[lvl0], call1 = P.lvl_cptr[lvl0 + nlev], sall0 = P.lvl_sptr[lvl0], sall1 = P.lvl_sptr[lvl0 + nlev];
+        auto pack = [&](const std::vector<uint32_t>& ptr, const std::vector<uint32_t>& items, uint32_t i0, uint32_t i1, uint32_t off_a,
+                        uint32_t off_b, std::vector<uint32_t>& dst) -> uint32_t {
+            uint32_t longest = 0;
+            for (uint32_t i = i0; i < i1; ++i) longest = std::max(longest, ptr[i + 1] - ptr[i]);
+            const uint32_t K = std::max(1u, (longest + 3) / 4), N = i1 - i0;
+            if (K > 3) return 0;
+            dst.assign((size_t)K * N * 4 + 4, zero_pair);
+            for (uint32_t i = i0; i < i1; ++i)
+                for (uint32_t q = ptr[i], e = 0; q < ptr[i + 1]; ++q, ++e)
+                    dst[((size_t)(e / 4) * N + (i - i0)) * 4 + e % 4] = (off_a + items[2 * q]) | ((off_b + items[2 * q + 1]) << 16);
+            return K;
+        };
+        out.asm_kc = pack(P.colj_ptr, P.colj_items, call0, call1, o_j, o_r, out.asm_cols);
+        out.asm_ks = out.asm_kc ? pack(P.apair_ptr, P.apairs, sall0, sall1, o_j, o_j, out.asm_slots) : 0;
+        if (!out.asm_ks) out.asm_kc = 0;
+    }
     std::vector<Item> items;
     std::vector<uint32_t> other(zlo, 0xFFFFFFFFu);  // per slot (j, k) of the current column's row: the slot (i, k), if any
     for (uint32_t lv = 0; lv < nlev; ++lv) {
@@ -1674,6 +1697,12 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     if (s.rec) {
         s.rec_desc_off = append(blob, rec.desc);
         s.rec_chunks_off = append(blob, rec.chunks);
+        s.rec_asm_kc = rec.asm_kc;
+        s.rec_asm_ks = rec.asm_ks;
+        if (rec.asm_kc) {
+            s.rec_asm_cols_off = append(blob, rec.asm_cols);
+            s.rec_asm_slots_off = append(blob, rec.asm_slots);
+        }
         if (std::getenv("EZPZ_REC_DEBUG"))
             std::fprintf(stderr, "record walk: %u rounds on %u lanes, %zu KB of descriptors, %zu KB of records\n", rec.rounds, s.team_size,
                          rec.desc.size() * 4 / 1024, rec.chunks.size() * 4 / 1024);
@@ -1906,6 +1935,16 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
         a.rec_chunks = reinterpret_cast<const uint4*>(base + sys->rec_chunks_off);
         a.rec_rounds = sys->rec_rounds;
         a.rec_desc_off = sys->rec_desc_lds_off;
+        static const bool packed = [] {  // (A/B runs)
+            const char* e = std::getenv("EZPZ_REC_ASM");
+            return !(e && e[0] == '0');
+        }();
+        if (packed && sys->rec_asm_kc) {
+            a.rec_asm_cols = reinterpret_cast<const uint4*>(base + sys->rec_asm_cols_off);
+            a.rec_asm_slots = reinterpret_cast<const uint4*>(base + sys->rec_asm_slots_off);
+            a.rec_asm_kc = sys->rec_asm_kc;
+            a.rec_asm_ks = sys->rec_asm_ks;
+        }
         const uint32_t n = sys->counts.n_vars, m = sys->counts.n_rows;
         const uint32_t o_d = n + 2 * m + sys->counts.zj, o_dd = workspace_doubles(sys->counts);
         a.rec_dd_delta = o_dd - o_d;

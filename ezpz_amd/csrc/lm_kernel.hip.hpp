@@ -249,6 +249,13 @@ struct SolveArgs {
     const uint2* rec_desc;
     const uint4* rec_chunks;
     uint32_t rec_rounds, rec_dd_delta, rec_zero, rec_desc_off;
+    // packed assembly (REC builds; 0 chunks = the lists are walked): the Jacobian-slot pairs of every column of A (a = J slot, b
+    // = row of r) and of every entry of its strict lower part (a, b = J slots) as rec_asm_kc / rec_asm_ks 16-byte chunks of four
+    // (a | b << 16) pairs per item, chunk k of item i at [k * items + i] -- one coalesced request per chunk instead of pointer,
+    // items, values; padded with pairs of the zero
+    const uint4* rec_asm_cols;
+    const uint4* rec_asm_slots;
+    uint32_t rec_asm_kc, rec_asm_ks;
 };
 
 // a round's descriptor (per wavefront): chunks to load (0 = the wavefront has no item), log2 of the lanes per list, ...
@@ -848,6 +855,64 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                     rec_load(rf0, rc0, rpa);
                 }
                 // ---- A = JtJ + lambda I (into L's storage) and b = Jt(-r)  (newton.rs:77-84) ---------------------
+                // Record walk builds: from packed pair chunks (SolveArgs::rec_asm_*), one item per lane and trip, the next
+                // trip's chunks requested before this trip's are used.
+                auto packed_pass = [&](auto kc, const uint4* base, uint32_t N, auto&& emit) __attribute__((always_inline)) {
+                    constexpr int K = decltype(kc)::value;
+                    uint32_t i = (uint32_t)tid;
+                    if (i >= N) return;
+                    uint4 cur[K];
+                    for (int k = 0; k < K; ++k) cur[k] = base[(size_t)k * N + i];
+                    for (;;) {
+                        const uint32_t in = i + (uint32_t)blockDim.x;
+                        const bool more = in < N;
+                        const uint32_t il = more ? in : i;
+                        uint4 nxt[K];
+                        for (int k = 0; k < K; ++k) nxt[k] = base[(size_t)k * N + il];
+                        // (term by term in list order, products rounded before they are added, b's terms as J * -r: the
+                        // list walk's sums bit for bit -- a padding pair adds 0 * 0)
+                        double sd = 0.0, sp = 0.0, sn = 0.0;
+                        for (int k = 0; k < K; ++k) {
+                            const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+                            double va[4], vb[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                va[e] = smem[w[e] & 0xFFFFu];
+                                vb[e] = smem[w[e] >> 16];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                sd += va[e] * va[e];
+                                sp += va[e] * vb[e];
+                                sn += va[e] * -vb[e];
+                            }
+                        }
+                        emit(i, sd, sp, sn);
+                        if (!more) break;
+                        for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+                        i = in;
+                    }
+                };
+                bool packed_asm = false;
+                if constexpr (REC) packed_asm = a.rec_asm_kc != 0;
+                if constexpr (REC) if (packed_asm) {
+                    auto emit_col = [&](uint32_t v, double sd, double, double sn) {
+                        ws[o_d + call0 + v] = sd + lambda;
+                        ws[o_v + call0 + v] = sn;
+                    };
+                    auto emit_slot = [&](uint32_t sl, double, double sp, double) { ws[o_l + sall0 + sl] = sp; };
+                    switch (a.rec_asm_kc) {
+                    case 1: packed_pass(std::integral_constant<int, 1>{}, a.rec_asm_cols, call1 - call0, emit_col); break;
+                    case 2: packed_pass(std::integral_constant<int, 2>{}, a.rec_asm_cols, call1 - call0, emit_col); break;
+                    default: packed_pass(std::integral_constant<int, 3>{}, a.rec_asm_cols, call1 - call0, emit_col); break;
+                    }
+                    switch (a.rec_asm_ks) {
+                    case 1: packed_pass(std::integral_constant<int, 1>{}, a.rec_asm_slots, sall1 - sall0, emit_slot); break;
+                    case 2: packed_pass(std::integral_constant<int, 2>{}, a.rec_asm_slots, sall1 - sall0, emit_slot); break;
+                    default: packed_pass(std::integral_constant<int, 3>{}, a.rec_asm_slots, sall1 - sall0, emit_slot); break;
+                    }
+                }
+                if (!packed_asm) {
                 for (uint32_t ci = call0 + tm.lane; ci < call1; ci += tm.stride) {
                     const uint32_t v = ci;  // internal variable numbering = schedule order
                     double acc = 0.0, b = 0.0;
@@ -870,6 +935,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                                         (acc += va[k] * vb[k]))
                     }
                     ws[o_l + s] = acc;
+                }
                 }
                 tm.phase_sync();
                 EZPZ_STAMP(10);
@@ -1587,17 +1653,22 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                         a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)log_pass << 32) | cref.pos(P, ci);
                 }
             };
-            for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                EZPZ_STAMP_DRAIN(40);
-                const CRef cref(P, ci, unit_w);
-                EZPZ_STAMP_DRAIN(41);
+            // A sweep over this unit's constraints.  (Fetching the next constraint's record before evaluating this one was
+            // measured on the record-walk builds: one solve of 300 variables 192 -> 191 us, batches of 150 variables +13 %, of
+            // 300 variables -16 %: the copies cost issue slots where four workgroups share a CU.  Not kept.)
+            auto sweep = [&](auto&& f) __attribute__((always_inline)) {
+                for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
+                    const CRef cref(P, ci, unit_w);
+                    f(cref, ci);
+                }
+            };
+            sweep([&](const CRef& cref, uint32_t ci) {
                 residual_of(cref, ci);
-                EZPZ_STAMP_DRAIN(42);
                 // linear-only build: its one Jacobian sweep per solve (see below) shares eval()'s pass over the records
                 if constexpr (LIN) {
                     if (mode == EVAL0) jacobian_of(cref, ci);
                 }
-            }
+            });
             ++pass;
             tm.phase_sync();
             EZPZ_STAMP(20);
@@ -1607,20 +1678,19 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
             const bool accept = (mode == EVAL0) || (sq < residual_sq);  // strict, newton.rs:118
             if (accept) {
                 if (mode == STEP) {
-                    uint32_t t = o_r;
-                    o_r = o_rn;
-                    o_rn = t;
+                    if (REC && a.rec_asm_kc != 0) {  // (the packed pairs hold r's addresses: the accepted residuals move there)
+                        for (uint32_t i = tlane; i < m; i += tsize) ws[o_r + i] = ws[o_rn + i];
+                    } else {
+                        uint32_t t = o_r;
+                        o_r = o_rn;
+                        o_rn = t;
+                    }
                     lambda *= LM_LAMBDA_DECR;
                 }
                 // The nine linear kinds have constant partials (weight x +-1 or +-0.5) and no degenerate guard: after
                 // eval() the refresh of an accepted step (newton.rs:121) would store the same bits again, so the
                 // linear-only build sweeps the Jacobian once per solve -- inside eval()'s residual sweep above.
-                if constexpr (!LIN) {
-                    for (uint32_t ci = con0 + tm.lane; ci < con1; ci += tm.stride) {
-                        const CRef cref(P, ci, unit_w);
-                        jacobian_of(cref, ci);
-                    }
-                }
+                if constexpr (!LIN) sweep(jacobian_of);
                 ++pass;
                 residual_sq = sq;
                 largest = mx;
