@@ -181,7 +181,7 @@ struct EzpzSystem {
     bool lean_lds = false;  // batch-throughput workgroup: keep LDS per workgroup small (no whole-list staging)
     // record walk (build_records): the linear solve of one connected system on a barrier workgroup as rounds of per-lane
     // records; rec_extra = doubles behind the workspace proper (the factor's diagonal, one zero), offsets into the blob
-    bool rec = false;
+    bool rec = false, rec_wide = false;
     uint32_t rec_extra = 0, rec_rounds = 0, rec_desc_lds_off = 0;
     size_t rec_desc_off = 0, rec_chunks_off = 0, rec_asm_cols_off = 0, rec_asm_slots_off = 0;
     uint32_t rec_asm_kc = 0, rec_asm_ks = 0;
@@ -341,7 +341,7 @@ bool sub_team_fits(const ProgramCounts& c, uint32_t team) {
     return team <= 64 && (size_t)workspace_doubles(c) * 8 * (64 / team) <= 60 * 1024;
 }
 
-template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool DENSE = false, bool REC = false>
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool DENSE = false, int REC = 0>
 int launch_kernel(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t stream) {
     auto kernel = lm_solve_kernel<TEAM, MODE, LDSWS, PLDS, LIN, false, DENSE, REC>;
     // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to the system: raised once per kernel
@@ -522,7 +522,9 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         else
             HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
         const int rc = s.mode == MODE_PART ? launch_variant<64, MODE_PART, false, false>(s, args, grid, stream)
-                                           : launch_variant<64, MODE_WGB, false, false>(s, args, grid, stream);
+                       : !s.rec            ? launch_variant<64, MODE_WGB, false, false>(s, args, grid, stream)
+                       : s.linear_only     ? launch_kernel<64, MODE_WGB, false, false, true, false, 2>(s, args, grid, stream)
+                                           : launch_kernel<64, MODE_WGB, false, false, false, false, 2>(s, args, grid, stream);
         if (rc == EZPZ_OK) HIP_TRY(hipEventRecord(s.lanes_done, stream));
         return rc;
     }
@@ -531,10 +533,10 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                       : launch_variant<64, MODE_PART, true, false>(s, args, grid, stream);
     if (s.rec) {  // one connected system, its linear solve as a record walk
         if (s.linear_only)
-            return staged ? launch_kernel<64, MODE_WGB, true, true, true, false, true>(s, args, grid, stream)
-                          : launch_kernel<64, MODE_WGB, true, false, true, false, true>(s, args, grid, stream);
-        return staged ? launch_kernel<64, MODE_WGB, true, true, false, false, true>(s, args, grid, stream)
-                      : launch_kernel<64, MODE_WGB, true, false, false, false, true>(s, args, grid, stream);
+            return staged ? launch_kernel<64, MODE_WGB, true, true, true, false, 1>(s, args, grid, stream)
+                          : launch_kernel<64, MODE_WGB, true, false, true, false, 1>(s, args, grid, stream);
+        return staged ? launch_kernel<64, MODE_WGB, true, true, false, false, 1>(s, args, grid, stream)
+                      : launch_kernel<64, MODE_WGB, true, false, false, false, 1>(s, args, grid, stream);
     }
     return staged ? launch_variant<64, MODE_WGB, true, true>(s, args, grid, stream)
                   : launch_variant<64, MODE_WGB, true, false>(s, args, grid, stream);
@@ -961,21 +963,23 @@ struct RecPlan {
     std::vector<uint32_t> asm_cols, asm_slots;
     uint32_t asm_kc = 0, asm_ks = 0;
 };
-static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, RecPlan& out) {
+// `wide`: the workspace lives in global memory -- 32-bit addresses counted from its start (lds_base = 0), chunk 0 = target,
+// diagonal, destination, lane flags, then up to four chunks of two (a, b) pairs; no packed assembly.
+static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, bool wide, RecPlan& out) {
     if (P.c.n_parts != 1 || P.parts.size() != 1 || P.c.dense || P.n_dense || T < 64 || T % 64) return false;
     const uint32_t n = P.c.n_vars, m = P.c.n_rows, zj = P.c.zj, zlo = P.c.zlo;
     // (addresses in the records count doubles from the start of the LDS; the workspace begins `lds_base` doubles in)
     const uint32_t o_d = lds_base + n + 2 * m + zj, o_l = o_d + n, o_v = o_l + zlo, o_dd = lds_base + workspace_doubles(P.c),
                    o_zero = o_dd + n;
-    if (o_zero >= 65536) return false;  // 16-bit addresses
+    if (!wide && o_zero >= 65536) return false;  // 16-bit addresses
     const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev, n_waves = T / 64;
-    constexpr uint32_t kMaxShare = REC_MAX_PAIRS;
+    const uint32_t kMaxShare = wide ? REC_WIDE_PAIRS : REC_MAX_PAIRS;
     struct Item {
         uint32_t target, diag, dest;
         bool col;
         std::vector<std::pair<uint32_t, uint32_t>> list;
     };
-    const uint32_t zero_pair = o_zero | (o_zero << 16);
+    const uint32_t zero_pair = wide ? o_zero : o_zero | (o_zero << 16);  // (wide: every word of a chunk is an address)
     auto emit_level = [&](std::vector<Item>& items, bool bwd, bool barrier) {
         if (items.empty()) return;
         std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.list.size() > y.list.size(); });
@@ -1009,7 +1013,7 @@ static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, RecPl
                     if (t >= items.size()) continue;
                     const uint32_t sub = l & (g - 1), len = (uint32_t)items[t].list.size();
                     const uint32_t share = len > sub ? (len - sub + g - 1) / g : 0;
-                    nch = std::max(nch, share <= 2 ? 1u : 1u + (share - 2 + 3) / 4);
+                    nch = std::max(nch, wide ? 1u + (share + 1) / 2 : share <= 2 ? 1u : 1u + (share - 2 + 3) / 4);
                 }
                 const uint32_t chunk0 = (uint32_t)(out.chunks.size() / (64 * 4));
                 out.desc.push_back(nch | (best_lg << REC_LG_SHIFT) | (barrier && t0 == 0 ? REC_BARRIER : 0u) | (bwd ? REC_BWD : 0u));
@@ -1019,15 +1023,32 @@ static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, RecPl
                 for (uint32_t l = 0; l < 64; ++l) {
                     uint32_t* c0 = &out.chunks[((size_t)chunk0 * 64 + l) * 4];
                     const size_t t = t0 + (w * 64 + l) / g;
-                    c0[0] = zero_pair;  // an idle lane of a working wavefront: reads zeros, writes nothing
-                    c0[1] = o_zero;
+                    // (an idle lane of a working wavefront reads zeros and writes nothing)
+                    if (wide) {
+                        c0[0] = c0[1] = c0[2] = o_zero;
+                        c0[3] = 0u;
+                    } else {
+                        c0[0] = zero_pair;
+                        c0[1] = o_zero;
+                    }
                     if (t >= items.size()) continue;
                     const Item& it = items[t];
                     const uint32_t sub = l & (g - 1);
-                    c0[0] = it.target | (it.diag << 16);
-                    c0[1] = it.dest | (sub == 0 ? REC_WRITER : 0u) | (it.col ? REC_ISCOL : 0u);
+                    const uint32_t lane_flags = (sub == 0 ? REC_WRITER : 0u) | (it.col ? REC_ISCOL : 0u);
+                    if (wide) {
+                        c0[0] = it.target, c0[1] = it.diag, c0[2] = it.dest, c0[3] = lane_flags;
+                    } else {
+                        c0[0] = it.target | (it.diag << 16);
+                        c0[1] = it.dest | lane_flags;
+                    }
                     uint32_t k = 0;
                     for (size_t q = sub; q < it.list.size(); q += g, ++k) {
+                        if (wide) {
+                            uint32_t* c = &out.chunks[((size_t)(chunk0 + 1 + k / 2) * 64 + l) * 4 + 2 * (k % 2)];
+                            c[0] = it.list[q].first;
+                            c[1] = it.list[q].second;
+                            continue;
+                        }
                         const uint32_t word = it.list[q].first | (it.list[q].second << 16);
                         if (k < 2)
                             c0[2 + k] = word;
@@ -1057,7 +1078,7 @@ static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, RecPl
                     dst[((size_t)(e / 4) * N + (i - i0)) * 4 + e % 4] = (off_a + items[2 * q]) | ((off_b + items[2 * q + 1]) << 16);
             return K;
         };
-        out.asm_kc = pack(P.colj_ptr, P.colj_items, call0, call1, o_j, o_r, out.asm_cols);
+        out.asm_kc = wide ? 0 : pack(P.colj_ptr, P.colj_items, call0, call1, o_j, o_r, out.asm_cols);
         out.asm_ks = out.asm_kc ? pack(P.apair_ptr, P.apairs, sall0, sall1, o_j, o_j, out.asm_slots) : 0;
         if (!out.asm_ks) out.asm_kc = 0;
     }
@@ -1579,7 +1600,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return !(e && e[0] == '0');
     }();
     RecPlan rec;
-    s.rec = false;
+    s.rec = s.rec_wide = false;
     s.rec_rounds = 0;
     s.rec_extra = 0;
     // Batches of one connected sketch on the per-system teams take the record walk as well -- one wavefront up to 160 variables,
@@ -1616,14 +1637,34 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
     }
     pack_and_shape(true);
+    bool rec_wide = false;
+    if (rec_try && !s.lds_ws) {
+        // no room in the LDS with the walk's extra doubles: if the state fits without them the list walk keeps it there (with its dense
+        // phases); a state that lives in global memory anyway walks records in the wide form
+        static const bool wide_enabled = [] {
+            const char* e = std::getenv("EZPZ_REC_WIDE");
+            return !(e && e[0] == '0');
+        }();
+        const uint32_t extra = s.rec_extra;
+        s.rec_extra = 0;
+        pack_and_shape(true);
+        // (batches only: 4194 systems of 2000 variables 106 -> 114 k solves/s, 1677 of 5000 variables 6.3 -> 8.4 k; one solve 2.02 ->
+        // 1.82 ms but 25.0 -> 26.9 ms: a round through global memory is a store's acknowledgement, a rendezvous and a trip to L2)
+        if (!s.lds_ws && wide_enabled && rec_batch) {
+            rec_wide = true;
+            s.rec_extra = extra;
+            pack_and_shape(true);
+        }
+    }
     if (rec_try) {
-        if (s.lds_ws && build_records(P, s.team_size, s.prog_lds_doubles, rec)) {
+        if ((s.lds_ws || rec_wide) && s.rec_extra && build_records(P, s.team_size, rec_wide ? 0u : s.prog_lds_doubles, rec_wide, rec)) {
             s.rec = true;
             s.rec_rounds = rec.rounds;
             s.rec_desc_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);  // the descriptors' copy in LDS, behind everything else
             s.lds_bytes = (size_t)s.rec_desc_lds_off * 8 + rec.desc.size() * 4;
             if (s.lds_bytes > s.lim.lds_bytes) s.rec = false;
         }
+        s.rec_wide = s.rec && rec_wide;
         if (!s.rec) {
             s.rec_extra = 0;
             if (rec_batch) {  // no room: the shape chosen before

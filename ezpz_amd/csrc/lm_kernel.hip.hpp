@@ -259,10 +259,13 @@ struct SolveArgs {
 };
 
 // a round's descriptor (per wavefront): chunks to load (0 = the wavefront has no item), log2 of the lanes per list, ...
-constexpr uint32_t REC_NCH_MASK = 3u, REC_LG_SHIFT = 2u, REC_BARRIER = 1u << 7, REC_BWD = 1u << 8;
+constexpr uint32_t REC_NCH_MASK = 7u, REC_LG_SHIFT = 3u, REC_BARRIER = 1u << 7, REC_BWD = 1u << 8;
 // ... and a lane's own flags (high half of the record's second word)
 constexpr uint32_t REC_WRITER = 1u << 16, REC_ISCOL = 1u << 17;
 constexpr int REC_MAX_CHUNKS = 3, REC_MAX_PAIRS = 10;  // per lane and round: 2 pairs beside the header, then 4 + 4
+// The WIDE form (REC == 2: the workspace in global memory, 32-bit addresses counted from its start): chunk 0 = target, diagonal,
+// destination, lane flags; up to four more chunks of two (a, b) pairs each.
+constexpr int REC_WIDE_CHUNKS = 5, REC_WIDE_PAIRS = 8;
 
 
 #ifdef EZPZ_STAMPS
@@ -590,11 +593,14 @@ struct ConRef<2, PROG> {
 // Cholesky and the substitutions are plain loops over rows and columns instead of level-by-level list walks.
 // Occupancy hints: sub-wavefront teams are compiled for 4 workgroups per CU (128 VGPRs; measured against 3 and 2:
 // +8 % on some topologies, -7 % on others), the register-resident dense solve for 2 (184 VGPRs, no spills: +12 %).
-template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false, bool DENSE = false, bool REC = false>
-__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 : 512), MODE == MODE_SUB ? (DENSE ? 2 : 4) : 1)
+template <int TEAM, int MODE, bool LDSWS, bool PLDS, bool LIN, bool GRID = false, bool DENSE = false, int RECF = 0>
+__global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1024 : 512), MODE == MODE_SUB ? (DENSE ? 2 : 4) : 1)
     lm_solve_kernel(const SolveArgs a) {
+    // RECF: the record walk's form -- 0 none, 1 state in LDS (16-bit addresses), 2 state in global memory (32-bit addresses)
+    constexpr bool REC = RECF != 0;
+    constexpr int RCH = RECF == 2 ? REC_WIDE_CHUNKS : REC_MAX_CHUNKS;  // chunks per lane and round
     static_assert(!DENSE || (MODE == MODE_SUB && TEAM == 4), "the register-resident dense solve is for teams of four");
-    static_assert(!REC || (MODE == MODE_WGB && LDSWS && !GRID && !DENSE), "the record walk is for one barrier workgroup, state in LDS");
+    static_assert(!REC || (MODE == MODE_WGB && !GRID && !DENSE && (RECF == 1) == LDSWS), "the record walk is for one barrier workgroup");
     static_assert(!GRID || (MODE == MODE_PART && LDSWS && PLDS), "grid teams are partitioned teams with staged lists");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using namespace dev;
@@ -828,7 +834,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
             }
             if (mode == STEP) {
                 // record walk: the first rounds' records do not depend on any value -- requested before the assembly
-                uint4 rpa[REC_MAX_CHUNKS] = {}, rpb[REC_MAX_CHUNKS] = {};
+                uint4 rpa[RCH] = {}, rpb[RCH] = {};
                 const uint32_t rec_nw = blockDim.x >> 6;
                 const uint2* const rec_d = reinterpret_cast<const uint2*>(smem + a.rec_desc_off) + (tid >> 6);
                 const uint4* const rec_c = a.rec_chunks + (tid & 63);
@@ -836,11 +842,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                 // (always three requests: a request under a condition makes its registers a merge of "loaded" and "kept", the
                 // merge a copy, and the copy waits for the load right behind it; the chunks a wavefront does not have are read
                 // from one 16-byte address instead -- a single line for all its lanes -- and never looked at)
-                auto rec_load = [&](uint32_t fl, uint32_t chunk0, uint4 (&pr)[REC_MAX_CHUNKS]) __attribute__((always_inline)) {
+                auto rec_load = [&](uint32_t fl, uint32_t chunk0, uint4 (&pr)[RCH]) __attribute__((always_inline)) {
                     const uint32_t nch = fl & REC_NCH_MASK;
                     const uint4* src = rec_c + (size_t)chunk0 * 64;
 #pragma unroll
-                    for (int c = 0; c < REC_MAX_CHUNKS; ++c) {
+                    for (int c = 0; c < RCH; ++c) {
                         const uint4* from = (uint32_t)c < nch ? src + c * 64 : a.rec_chunks;
                         pr[c] = *from;
                     }
@@ -894,8 +900,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                     }
                 };
                 bool packed_asm = false;
-                if constexpr (REC) packed_asm = a.rec_asm_kc != 0;
-                if constexpr (REC) if (packed_asm) {
+                if constexpr (RECF == 1) packed_asm = a.rec_asm_kc != 0;
+                if constexpr (RECF == 1) if (packed_asm) {
                     auto emit_col = [&](uint32_t v, double sd, double, double sn) {
                         ws[o_d + call0 + v] = sd + lambda;
                         ws[o_v + call0 + v] = sn;
@@ -994,27 +1000,46 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                     const uint32_t R = a.rec_rounds;
                     // a round's work for a wavefront whose lanes have NP operand pairs each (2, 6 or 10: one, two or three
                     // chunks) -- one straight-line body per count, so that nothing in it is conditional
-                    auto rec_body = [&](auto npc, const uint4 (&cur)[REC_MAX_CHUNKS], uint32_t fl, unsigned long long* tst) __attribute__((always_inline)) {
+                    // (an operand: LDS form -- an index into the __shared__ array, pointers into LDS that pass through selects become
+                    // generic pointers and their loads flat loads that count with the record requests; wide form -- the workspace)
+                    auto at = [&](uint32_t i) -> double& {
+                        if constexpr (RECF == 2)
+                            return ws[i];
+                        else
+                            return smem[i];
+                    };
+                    auto rec_body = [&](auto npc, const uint4 (&cur)[RCH], uint32_t fl, unsigned long long* tst) __attribute__((always_inline)) {
                         constexpr int NP = decltype(npc)::value;
                         const uint32_t lg = (fl >> REC_LG_SHIFT) & 7u;
-                        // (addresses count doubles from the start of the LDS: the host knows where the workspace lies; kept as
-                        // indices -- pointers into LDS that pass through selects become generic pointers, their loads flat loads
-                        // that count with the record requests)
-                        uint32_t word[NP];
-                        word[0] = cur[0].z, word[1] = cur[0].w;
-                        if constexpr (NP > 2) word[2] = cur[1].x, word[3] = cur[1].y, word[4] = cur[1].z, word[5] = cur[1].w;
-                        if constexpr (NP > 6) word[6] = cur[2].x, word[7] = cur[2].y, word[8] = cur[2].z, word[9] = cur[2].w;
-                        double va[NP], vb[NP];
+                        uint32_t ia[NP + 1], ib[NP + 1], i_target, i_diag, i_dest, lane_fl;
+                        if constexpr (RECF == 2) {
+                            i_target = cur[0].x, i_diag = cur[0].y, i_dest = cur[0].z, lane_fl = cur[0].w;
+#pragma unroll
+                            for (int k = 0; k < NP; k += 2) {
+                                ia[k] = cur[1 + k / 2].x, ib[k] = cur[1 + k / 2].y;
+                                ia[k + 1] = cur[1 + k / 2].z, ib[k + 1] = cur[1 + k / 2].w;
+                            }
+                        } else {
+                            // (addresses count doubles from the start of the LDS: the host knows where the workspace lies)
+                            uint32_t word[NP];
+                            word[0] = cur[0].z, word[1] = cur[0].w;
+                            if constexpr (NP > 2) word[2] = cur[1].x, word[3] = cur[1].y, word[4] = cur[1].z, word[5] = cur[1].w;
+                            if constexpr (NP > 6) word[6] = cur[2].x, word[7] = cur[2].y, word[8] = cur[2].z, word[9] = cur[2].w;
+#pragma unroll
+                            for (int k = 0; k < NP; ++k) ia[k] = word[k] & 0xFFFFu, ib[k] = word[k] >> 16;
+                            i_target = cur[0].x & 0xFFFFu, i_diag = cur[0].x >> 16, i_dest = cur[0].y & 0xFFFFu, lane_fl = cur[0].y;
+                        }
+                        double va[NP + 1], vb[NP + 1];
 #pragma unroll
                         for (int k = 0; k < NP; ++k) {
-                            va[k] = smem[word[k] & 0xFFFFu];
-                            vb[k] = smem[word[k] >> 16];
+                            va[k] = at(ia[k]);
+                            vb[k] = at(ib[k]);
                         }
-                        const uint32_t i_diag = cur[0].x >> 16, i_dest = cur[0].y & 0xFFFFu, lane_fl = cur[0].y;
-                        const double target = smem[cur[0].x & 0xFFFFu], diag = smem[i_diag];
+                        const double target = at(i_target), diag = at(i_diag);
                         const bool writer = (lane_fl & REC_WRITER) != 0;
                         // (fused multiply-adds, two partial sums each: the group's sum reorders the terms anyway)
-                        double sp0 = va[0] * vb[0], sp1 = va[1] * vb[1];
+                        double sp0 = 0.0, sp1 = 0.0;
+                        if constexpr (NP > 0) sp0 = va[0] * vb[0], sp1 = va[1] * vb[1];
 #pragma unroll
                         for (int k = 2; k < NP; k += 2) {
                             sp0 = __builtin_fma(va[k], vb[k], sp0);
@@ -1028,11 +1053,12 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                             sp = rec_group_sum(sp, lg);
                             const double res = (target - sp) * diag;  // (the factor's diagonal is kept as 1 / d_j)
                             if (writer) {
-                                smem[i_dest] = res;
+                                at(i_dest) = res;
                                 dmax = fmax(dmax, fabs(res));
                             }
                         } else {
-                            double sd0 = va[0] * va[0], sd1 = va[1] * va[1];
+                            double sd0 = 0.0, sd1 = 0.0;
+                            if constexpr (NP > 0) sd0 = va[0] * va[0], sd1 = va[1] * va[1];
 #pragma unroll
                             for (int k = 2; k < NP; k += 2) {
                                 sd0 = __builtin_fma(va[k], va[k], sd0);
@@ -1060,12 +1086,12 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
 #endif
                             if (lane_fl & REC_ISCOL) {
                                 if (!(acc > 0.0)) bad = 1.0;  // LltError::Numeric: non-positive pivot
-                                if (writer) smem[i_diag + a.rec_dd_delta] = rinv;
+                                if (writer) at(i_diag + a.rec_dd_delta) = rinv;
                             }
-                            if (writer) smem[i_dest] = res;
+                            if (writer) at(i_dest) = res;
                         }
                     };
-                    auto rec_round = [&](uint32_t rd, uint4 (&cur)[REC_MAX_CHUNKS], uint4 (&nxt)[REC_MAX_CHUNKS]) __attribute__((always_inline)) {
+                    auto rec_round = [&](uint32_t rd, uint4 (&cur)[RCH], uint4 (&nxt)[RCH]) __attribute__((always_inline)) {
                         const uint32_t fl = rf0;
                         const uint32_t nch = fl & REC_NCH_MASK;
                         const uint32_t rf1 = uni(rd1.x), rc1 = uni(rd1.y);
@@ -1078,16 +1104,21 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
                         // memory loads is in-order, a wait placed after the new requests would wait for those as well
                         // (unconditionally, all three chunks: a wait under a condition leaves the compiler's bookkeeping with
                         // "may be pending" at the join, and it waits again at the first use -- behind the new requests)
-                        asm volatile("" : "+v"(cur[0].x), "+v"(cur[0].y), "+v"(cur[0].z), "+v"(cur[0].w));
-                        asm volatile("" : "+v"(cur[1].x), "+v"(cur[1].y), "+v"(cur[1].z), "+v"(cur[1].w));
-                        asm volatile("" : "+v"(cur[2].x), "+v"(cur[2].y), "+v"(cur[2].z), "+v"(cur[2].w));
+#pragma unroll
+                        for (int c = 0; c < RCH; ++c) asm volatile("" : "+v"(cur[c].x), "+v"(cur[c].y), "+v"(cur[c].z), "+v"(cur[c].w));
                         __builtin_amdgcn_sched_barrier(0);
                         rec_load(rf1, rc1, nxt);
                         rd1 = rec_d[(rd + 2) * rec_nw];
                         __builtin_amdgcn_sched_barrier(0);
                         // (the rendezvous orders LDS traffic only: __syncthreads() would also wait for the record requests just
                         // made -- a release at workgroup scope drains the memory-load counter -- a trip to L2 in every round)
-                        if (fl & REC_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        // (the wide form exchanges through global memory: there the release is what is needed)
+                        if (fl & REC_BARRIER) {
+                            if constexpr (RECF == 2)
+                                __syncthreads();
+                            else
+                                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        }
 #ifdef EZPZ_REC_TIMES
                         if (stamping) tstamp[1] = __builtin_readcyclecounter();
 #endif
@@ -1096,11 +1127,22 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && !REC ? 1024 :
 #else
 #define REC_TST nullptr
 #endif
-                        switch (nch) {
-                        case 1: rec_body(std::integral_constant<int, 2>{}, cur, fl, REC_TST); break;
-                        case 2: rec_body(std::integral_constant<int, 6>{}, cur, fl, REC_TST); break;
-                        case 3: rec_body(std::integral_constant<int, 10>{}, cur, fl, REC_TST); break;
-                        default: break;
+                        if constexpr (RECF == 2) {
+                            switch (nch) {
+                            case 1: rec_body(std::integral_constant<int, 0>{}, cur, fl, REC_TST); break;
+                            case 2: rec_body(std::integral_constant<int, 2>{}, cur, fl, REC_TST); break;
+                            case 3: rec_body(std::integral_constant<int, 4>{}, cur, fl, REC_TST); break;
+                            case 4: rec_body(std::integral_constant<int, 6>{}, cur, fl, REC_TST); break;
+                            case 5: rec_body(std::integral_constant<int, 8>{}, cur, fl, REC_TST); break;
+                            default: break;
+                            }
+                        } else {
+                            switch (nch) {
+                            case 1: rec_body(std::integral_constant<int, 2>{}, cur, fl, REC_TST); break;
+                            case 2: rec_body(std::integral_constant<int, 6>{}, cur, fl, REC_TST); break;
+                            case 3: rec_body(std::integral_constant<int, 10>{}, cur, fl, REC_TST); break;
+                            default: break;
+                            }
                         }
                         rf0 = rf1;
                         rc0 = rc1;

@@ -257,7 +257,7 @@ def test_long_polyline_gets_a_shallow_elimination_tree(E):
     recs, g = _chain_system(4000)
     sysobj = E.System(recs, len(g))
     info = sysobj.info()
-    assert info["n_components"] == 1 and info["team_mode"] == 2
+    assert info["n_components"] == 1 and info["team_mode"] == 4 and not info["workspace_in_lds"]  # (8000 variables: the wide record walk)
     assert info["n_levels"] <= 64 and info["nnz_l"] <= 2 * info["nnz_a"]
     x0 = g[None, :] + gen.keyed_uniform(3, 3, len(g), -0.02, 0.02)
     x, st, _ = sysobj.solve_batch(x0)
@@ -643,15 +643,16 @@ def test_random_block_systems_are_deterministic_and_match_the_oracle(E, team, nc
 LISTS = 0xFFFFFFFE  # E.TEAM_AUTO_LISTS
 
 
-@pytest.mark.parametrize("npts,team,mode", [(90, LISTS, 0), (150, LISTS, 2), (150, 256, 2), (400, LISTS, 2), (1500, 0, 2),
-                                            (60, 0, 4), (90, 0, 4), (150, 0, 4), (400, 0, 4)])
+@pytest.mark.parametrize("npts,team,mode", [(90, LISTS, 0), (150, LISTS, 2), (150, 256, 2), (400, LISTS, 2), (1500, LISTS, 2),
+                                            (60, 0, 4), (90, 0, 4), (150, 0, 4), (400, 0, 4), (1500, 0, 4)])
 def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, team, mode):
     """One connected component of mixed kinds (a random polyline-like sketch: every point tied to its predecessors by
     one or two random constraints).  The list-walk shapes (`TEAM_AUTO_LISTS`, what batches ran on before the record walk):
     one wavefront (180 variables), a lean 128-lane workgroup whose lists stay in
     global memory (300), the barrier workgroup with staged lists (300 on 256 lanes), with its workspace in LDS (800)
-    and in global memory (3000: the automatic shape too, its state does not fit the LDS).  The automatic batch shape: the
-    record walk (team_mode 4) on one wavefront (120, 180 variables), on 128 lanes (300) and on 512 (800).  Deterministic
+    and in global memory (3000).  The automatic batch shape: the
+    record walk (team_mode 4) on one wavefront (120, 180 variables), on 128 lanes (300), on 512 (800) and -- in its wide
+    form, 32-bit addresses into a workspace in global memory -- on 3000 variables.  Deterministic
     from run to run, and -- it is fully determined by construction -- the oracle's answer."""
     recs, g = gen.connected_sketch(npts, 77 + npts + (team if team < 1024 else 0))
     sysobj = E.System(recs, len(g), team_size=team)
@@ -660,7 +661,8 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
     if (npts, team) == (150, LISTS):
         assert info["team_size"] == 128 and not info["program_in_lds"]
     if mode == 4:
-        assert info["team_size"] == {60: 64, 90: 128, 150: 128, 400: 512}[npts] and info["workspace_in_lds"]
+        assert info["team_size"] == {60: 64, 90: 128, 150: 128, 400: 512, 1500: 512}[npts]
+        assert info["workspace_in_lds"] == (npts < 1500)
     x0 = np.tile(g, (5, 1))
     cfg = dict(max_iterations=60)
     x, st, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)

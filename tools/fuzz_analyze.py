@@ -40,7 +40,7 @@ for trial in range(3000):
         i = E.analyze(recs, len(g))
     except Exception as e:
         print("FAIL trial", trial, "kind", kind, "npts", npts, e); continue
-    for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_BATCH_LANES):  # every automatic shape: without a device the analysis runs, then -100
+    for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_PHASES, E.TEAM_AUTO_LISTS, E.TEAM_BATCH_LANES):  # every automatic shape: without a device the analysis runs, then -100
         try:
             E.System(recs, len(g), team_size=team)
         except E.NonLinearSystemError as e:
