@@ -65,8 +65,9 @@ PMC_SETS = [
 ]
 SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel", "ezpz_jit_solve", "ezpz_jit_lane", "batch_lane_kernel")
 # The other BASELINE.json configurations, as (workload, systems per launch at N = 1): configs[2], [4], [3], and the
-# connected-sketch batch of DESIGN.md section 3.  Short legs after the headline; the mixed batch is sharded over the ranks.
-LEGS = [("square", 65536), ("mixed", 1 << 20), ("massive50000", 64), ("sketch150", 262144)]
+# connected-sketch batches of DESIGN.md section 3 (one lane per system at 262 144 systems per launch; the per-system teams'
+# record walk at 32 768).  Short legs after the headline; the mixed batch is sharded over the ranks.
+LEGS = [("square", 65536), ("mixed", 1 << 20), ("massive50000", 64), ("sketch150", 262144), ("sketch150", 32768)]
 
 
 def algorithmic_bytes(info: dict, k: int) -> int:
