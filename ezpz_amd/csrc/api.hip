@@ -990,6 +990,8 @@ static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, bool 
             if ((longest + g - 1) / g > kMaxShare) continue;
             const uint32_t ngrp = T / g;
             double cost = 0.0;
+            // (measured and not kept: no rendezvous before a round whose items all sit in wavefront 0 while no other wavefront has
+            // stored since the last one -- half of a sketch's rounds -- changes nothing: the rendezvous is not what a round costs)
             for (size_t t = 0; t < items.size(); t += ngrp)
                 cost += 500.0 + 20.0 * (double)((items[t].list.size() + g - 1) / g) + (g > 1 ? 30.0 * lg : 0.0);
             if (!best_g || cost < best - 1e-9) best = cost, best_g = g, best_lg = lg;

@@ -1144,6 +1144,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
                             default: break;
                             }
                         }
+#undef REC_TST
                         rf0 = rf1;
                         rc0 = rc1;
 #ifdef EZPZ_REC_TIMES
