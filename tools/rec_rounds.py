@@ -25,7 +25,7 @@ t = t[t[:, 0] > 0]
 print("# round: start -> rendezvous' exit (record wait, requests, the other wavefronts) | -> partial sums (operand loads) | -> group sums | -> 1/sqrt and quotient | -> end (stores) | -> next round's start   [backward rounds: no group-sum / sqrt stamps]")
 for r in range(len(t)):
     nxt = t[r + 1, 0] - t[r, 5] if r + 1 < len(t) else 0
-    if t[r, 3] > 0:
+    if t[r, 2] <= t[r, 3] <= t[r, 4] <= t[r, 5]:  # (backward rounds leave the two middle stamps as they were)
         print(f"round {r:3d}: {t[r, 1] - t[r, 0]:5d} | {t[r, 2] - t[r, 1]:5d} | {t[r, 3] - t[r, 2]:5d} | {t[r, 4] - t[r, 3]:5d} | {t[r, 5] - t[r, 4]:5d} | {nxt:5d}")
     else:
         print(f"round {r:3d}: {t[r, 1] - t[r, 0]:5d} | {t[r, 2] - t[r, 1]:5d} |     - |     - | {t[r, 5] - t[r, 2]:5d} | {nxt:5d}")
