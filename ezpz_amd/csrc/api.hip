@@ -565,8 +565,10 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                 HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
             // the systems the lanes give up (stragglers, batch_kernel.hip.hpp) are listed on the device and resumed by this
             // system's list-walk teams right after: an indirect batch whose count stays on the device
-            const uint32_t strag_cap = args.batch < (1ull << 32) && args.batch >= 256
-                                           ? (uint32_t)std::min<uint64_t>(args.batch, std::max<uint64_t>(4096, args.batch / 8)) : 0u;
+            // (room for every wavefront handing over its threshold's worth of lanes once: a list that overflows leaves the lanes their tail)
+            const uint64_t strag_most = std::min<uint64_t>(s.lanes_ws_waves, (args.batch + 63) / 64) * batch_straggler_lanes();
+            const uint32_t strag_cap = args.batch < (1ull << 32) && args.batch >= 256 && strag_most
+                                           ? (uint32_t)std::min<uint64_t>(args.batch, std::max<uint64_t>(4096, strag_most)) : 0u;
             bool list_ok = strag_cap && s.strag_list.ensure(strag_cap) == EZPZ_OK && s.strag_count.ensure(1) == EZPZ_OK &&
                            s.strag_state.ensure(strag_cap) == EZPZ_OK;
             if (list_ok && hipMemsetAsync(s.strag_count.p, 0, sizeof(uint32_t), stream) != hipSuccess) {

@@ -75,6 +75,15 @@ uint64_t batch_launch_waves(int cus) {
     return (uint64_t)cus * (uint64_t)per_cu * 4;
 }
 
+// EZPZ_LANES_STRAGGLERS: the working lanes (of 64) at which a wavefront hands its systems to the teams, 0 = never.  262 144 jittered
+// 300-variable sketches, the list sized for every wavefront handing over that many (api.hip): 16 / 24 / 28 / 32 / 36 / 40 / 48 / 64
+// lanes 7.85 / 8.13 / 8.34 / 8.38 / 7.85 / 8.18 / 8.04 / 3.67 M solves/s (the teams walk records: they resume a system faster than a
+// thinning wavefront finishes it, until they are handed most of the batch); a list that overflows leaves the lanes their tail: 5.4.
+uint32_t batch_straggler_lanes() {
+    static const int env_strag = [] { const char* e = std::getenv("EZPZ_LANES_STRAGGLERS"); return e ? std::atoi(e) : 32; }();
+    return (uint32_t)std::min(std::max(env_strag, 0), 64);
+}
+
 int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons, const CompLaunch& L,
                  void* stream, uint32_t* strag_list, uint32_t* strag_count, uint32_t strag_cap, LmResume* strag_state) {
     if (L.batch == 0) return EZPZ_OK;
@@ -101,11 +110,9 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
     a.step_tolerance = L.step_tolerance;
     a.initial_lambda = L.initial_lambda;
     a.ws = dev_ws;
-    // a wavefront down to 16 working lanes (of 64) with nothing left to take gives them up: continuing costs the whole
-    // wavefront a round per iteration, while the teams resume a system where it stands (EZPZ_LANES_STRAGGLERS: that
-    // threshold, 0 = off; 262 144 jittered 300-variable sketches: 8 / 12 / 16 / 24 lanes 7.50 / 7.49 / 7.69 / 5.09 M solves/s
-    // -- at 24 the list overflows and most of a round's lanes arrive at the teams at once)
-    static const int env_strag = [] { const char* e = std::getenv("EZPZ_LANES_STRAGGLERS"); return e ? std::atoi(e) : 16; }();
+    // a wavefront down to half of its lanes working with nothing left to take gives them up: continuing costs the whole
+    // wavefront a round per iteration, while the teams resume a system where it stands (batch_straggler_lanes)
+    const int env_strag = (int)batch_straggler_lanes();
     a.strag_list = env_strag > 0 && strag_cap && strag_state ? strag_list : nullptr;
     a.strag_state = strag_state;
     a.strag_count = strag_count;

@@ -153,6 +153,7 @@ struct BatchPlan {
 bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, BatchPlan& plan);
 // wavefronts of the kernel the device holds at once (their workspaces are what the caller allocates)
 uint64_t batch_launch_waves(int cus);
+uint32_t batch_straggler_lanes();  // working lanes at which a wavefront hands its systems to the teams (0 = never)
 // strag_list / strag_count / strag_cap: where wavefronts that are down to their last few lanes leave the systems they
 // give up (batch_kernel.hip.hpp) and `strag_state` the LM state they had reached; null: every system is solved by its lane
 int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws, uint64_t ws_waves, uint32_t n_cons,
