@@ -1438,7 +1438,22 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         if (dense && team != 4) {  // many constraints on few variables pushed the team up: the list-walk build after all
             if (!build_program(cs, n_cs, n_vars, P, be, 1, false)) return fail();
         }
-        if (sub_team_fits(P.c, team)) {
+        // One connected system walks records (build_records) from 25 variables for one solve and from 57 in batches, on one
+        // wavefront: one solve of 32 / 50 / 64 variables 61 -> 54, 142 -> 112, 119 -> 82 us; batches of 64 variables 17.0 -> 23.1 M
+        // solves/s, but of 50 variables 19.2 -> 16.8 M and of 32 variables 60 -> 37 M (two to four systems share a wavefront
+        // there).  EZPZ_REC_SMALL = that bound for both (A/B runs), 0 = the sub-wavefront teams always.
+        static const int rec_small_env = [] {
+            const char* e = std::getenv("EZPZ_REC_SMALL");
+            return e ? std::atoi(e) : -1;
+        }();
+        const int rec_small = rec_small_env >= 0 ? rec_small_env : for_latency ? 24 : 56;
+        static const bool rec_on = [] {
+            const char* e = std::getenv("EZPZ_REC");
+            return !(e && e[0] == '0');
+        }();
+        const bool walk_records = rec_on && rec_small > 0 && !team_size && !lists_only && !latency_phases && P.c.n_components == 1 &&
+                                  !dense && (int)width > rec_small;
+        if (sub_team_fits(P.c, team) && !walk_records) {
             s.mode = MODE_SUB;
             s.team_size = team;
         } else {

@@ -676,6 +676,30 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
     assert_x_close(x[0], want.final_values)
 
 
+@pytest.mark.parametrize("npts,latency_mode,batch_mode", [(10, 0, 0), (16, 4, 0), (25, 4, 0), (32, 4, 4)])
+def test_small_connected_sketch_walks_records_where_it_pays(E, npts, latency_mode, batch_mode):
+    """One connected sketch of 20 ... 64 variables: one solve walks records from 25 variables (team_mode 4),
+    batches from 57 (below that two to four systems share a wavefront on the sub-wavefront teams: api.hip, analyze_into).
+    Both shapes against the oracle, jittered starts and a NaN start."""
+    recs, g = gen.connected_sketch(npts, 4100 + npts)
+    n = len(g)
+    x0 = g[None, :] + gen.keyed_uniform(npts, 8, n, -0.05, 0.05)
+    x0[0] = g
+    x0[7, 1] = float("nan")
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0
+    for team, mode in ((E.TEAM_AUTO_LATENCY, latency_mode), (0, batch_mode)):
+        sysobj = E.System(recs, n, team_size=team)
+        info = sysobj.info()
+        assert info["n_components"] == 1 and info["team_mode"] == mode, (team, info)
+        assert mode != 4 or info["team_size"] == (128 if team else 64)  # (one solve: two wavefronts, as fast as one)
+        x, st, _ = sysobj.solve_batch(x0)
+        assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv)
+        assert np.array_equal(st["n_unsatisfied"], nun)
+        assert np.array_equal(np.isnan(x), np.isnan(xo))
+        assert_x_close(x[:7], xo[:7])
+
+
 @pytest.mark.parametrize("npts", [60, 150, 260, 400, 1200])
 @pytest.mark.parametrize("shape", ["phases", "records"])
 def test_connected_sketch_latency_shape_with_dense_root_block(E, npts, shape):
