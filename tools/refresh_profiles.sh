@@ -24,11 +24,11 @@ for w in "mixed 1048576 mixed_1M" "massive50000 64 ladder200k" "sketch150 262144
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x -- python3 bench.py --workload $1 --batch $2 --steps 10 --warmup 2 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
 find $out/stats_x -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/$3_kernel_stats.csv; rm -rf $out/stats_x; done
 python tools/reference_benches.py > $out/reference_benches.txt 2>/dev/null
-(echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = the automatic batch shape: the record walk on 64 / 128 / 512 lanes per system while the state fits the LDS -- team_mode 4 -- and lanes across the batch from 65 536 systems per call)"; python tools/sketch_scaling.py 8 25 50 75 100 150 250 400 1000 2500 2>&1 | grep npts
-echo "# TEAM=4294967294 (EZPZ_TEAM_AUTO_LISTS: the list-walk shapes batches ran on before the record walk -- one wavefront, a lean 128-lane workgroup, dense phases on top)"; EZPZ_LANES=0 TEAM=4294967294 python tools/sketch_scaling.py 50 75 100 150 250 400 2>&1 | grep npts
-echo "# EZPZ_LANES=0 BATCH=32768 (the automatic batch shape on the per-system teams alone)"; EZPZ_LANES=0 BATCH=32768 python tools/sketch_scaling.py 50 75 100 150 250 400 2>&1 | grep npts
-echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve: the record walk on 256-512 lanes)"; TEAM=4294967295 python tools/sketch_scaling.py 25 75 150 250 400 1000 2500 2>&1 | grep npts
-echo "# TEAM=4294967292 (EZPZ_TEAM_LATENCY_PHASES: one solve's shape before the record walk: level lists and dense phases)"; TEAM=4294967292 python tools/sketch_scaling.py 75 150 250 400 2>&1 | grep npts
+(echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = the automatic batch shape: the record walk on 64 / 128 / 512 lanes per system while the state fits the LDS -- team_mode 4 -- and lanes across the batch from 65 536 systems per call)"; python tools/sketch_scaling.py 8 16 25 32 50 75 100 150 250 400 1000 2500 2>&1 | grep npts
+echo "# TEAM=4294967294 (EZPZ_TEAM_AUTO_LISTS: the list-walk shapes batches ran on before the record walk -- one wavefront, a lean 128-lane workgroup, dense phases on top)"; EZPZ_LANES=0 TEAM=4294967294 python tools/sketch_scaling.py 32 50 75 100 150 250 400 1000 2500 2>&1 | grep npts
+echo "# EZPZ_LANES=0 BATCH=32768 (the automatic batch shape on the per-system teams alone)"; EZPZ_LANES=0 BATCH=32768 python tools/sketch_scaling.py 32 50 75 100 150 250 400 2>&1 | grep npts
+echo "# TEAM=4294967295 (EZPZ_TEAM_AUTO_LATENCY: the launch shape ezpz_solve uses for one solve: the record walk on 256-512 lanes)"; TEAM=4294967295 python tools/sketch_scaling.py 10 16 25 32 75 150 250 400 1000 2500 2>&1 | grep npts
+echo "# TEAM=4294967292 (EZPZ_TEAM_LATENCY_PHASES: one solve's shape before the record walk: level lists and dense phases)"; TEAM=4294967292 python tools/sketch_scaling.py 16 25 32 75 150 250 400 2>&1 | grep npts
 echo "# BATCH=262144 (a device-filling batch: one lane per system, batch_kernel.hip.hpp)"; BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts
 echo "# BATCH=65536 / 32768 (larger sketches on the lanes: 500, 800 and 2000 variables)"; BATCH=65536 python tools/sketch_scaling.py 250 400 2>&1 | grep npts; BATCH=32768 python tools/sketch_scaling.py 1000 2>&1 | grep npts
 echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZPZ_LANES=0 BATCH=262144 python tools/sketch_scaling.py 25 75 150 2>&1 | grep npts) > $out/sketch_scaling.txt
