@@ -16,6 +16,8 @@ run s2 EZPZ_LANES_STRAGGLERS=2 python bench.py $B --batch 262144 --steps 5
 run s4 EZPZ_LANES_STRAGGLERS=4 python bench.py $B --batch 262144 --steps 5
 run s8 EZPZ_LANES_STRAGGLERS=8 python bench.py $B --batch 262144 --steps 5
 run s12 EZPZ_LANES_STRAGGLERS=12 python bench.py $B --batch 262144 --steps 5
+run s32 EZPZ_LANES_STRAGGLERS=32 python bench.py $B --batch 262144 --steps 5
+run s40 EZPZ_LANES_STRAGGLERS=40 python bench.py $B --batch 262144 --steps 5
 run s16 EZPZ_LANES_STRAGGLERS=16 python bench.py $B --batch 262144 --steps 5
 run s24 EZPZ_LANES_STRAGGLERS=24 python bench.py $B --batch 262144 --steps 5
 run s4_b524k_r8 EZPZ_LANES_STRAGGLERS=4 EZPZ_LANES_REFILL=8 python bench.py $B --batch 524288 --steps 3
