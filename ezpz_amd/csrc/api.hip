@@ -948,7 +948,8 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
 // system on a barrier workgroup of T lanes, as rounds.  In a round a group of g lanes owns one item:
 //   factor, entry (i, j):  l_ij = (A_ij - sum_k l_ik l_jk) / sqrt(A_jj - sum_k l_jk^2)   over row j of L (k < j); where row i
 //                          has no entry in column k the pair's second operand is a double that stays zero
-//   factor, column j:      y_j  = (b_j  - sum_k l_jk y_k ) / sqrt(A_jj - sum_k l_jk^2)   and d_j = the square root
+//   factor, column j:      y_j  = (b_j  - sum_k l_jk y_k ) / sqrt(A_jj - sum_k l_jk^2)   and 1 / d_j (kept beside A_jj: the entries of
+//                          column j read A_jj in the same round)
 //   backward, column j:    x_j  = (y_j  - sum_i l_ij x_i ) / d_j                          over column j of L (i > j)
 // -- one list per item (every lane of a column's entries recomputes d_j from the same terms in the same order), cut
 // into the lanes' shares at build time: a lane's record is ready workspace addresses, nothing is looked up on the device.
