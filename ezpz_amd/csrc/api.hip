@@ -1624,7 +1624,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     s.rec_rounds = 0;
     s.rec_extra = 0;
     // Batches of one connected sketch on the per-system teams take the record walk as well -- one wavefront up to 160 variables,
-    // a 128-lane workgroup while two fit a CU, 512 lanes beyond -- instead of one wavefront / a lean workgroup walking level lists
+    // then 128 / 256 / 512 lanes as four / two or three / one workgroup fit a CU -- instead of one wavefront / a lean workgroup walking level lists
     // with dense phases on top: 100 / 150 / 200 / 300 / 500 / 800 variables 10.5 -> 23.0, 4.3 -> 8.7, 4.0 -> 7.5, 1.49 -> 3.10,
     // 0.33 -> 0.61 M solves/s, 57 -> 86 k (EZPZ_REC_BATCH = lanes for A/B runs, 0 = the shapes above).
     static const int rec_batch_lanes = [] {
@@ -1638,11 +1638,14 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
                            s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;
     if (rec_batch) {
         const size_t ws_b = ((size_t)workspace_doubles(P.c) + P.c.n_vars + 4) * 8;
-        uint32_t t = P.c.n_vars <= 160 ? 64u : ws_b + 4096 <= s.lim.lds_bytes / 2 ? 128u : 512u;
+        // (about eight wavefronts per CU: 300 variables, four workgroups per CU, 3.19 M solves/s on 128 lanes against 2.94 M on 256;
+        // 500 variables, two per CU, 0.68 against 0.91 M; 800 variables, one per CU, 53 k / 73 k / 91 k on 128 / 256 / 512 lanes)
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, s.lim.lds_bytes / (ws_b + 4096));
+        uint32_t t = P.c.n_vars <= 160 ? 64u : std::min(512u, std::max(128u, pow2_ceil(512u / per_cu)));
         if (rec_batch_lanes >= 64 && rec_batch_lanes <= 512 && rec_batch_lanes % 64 == 0) t = (uint32_t)rec_batch_lanes;
         s.mode = MODE_WGB;
         s.team_size = t;
-        s.lean_lds = t <= 128;
+        s.lean_lds = true;  // (its lists stay in L2: the LDS is for as many systems as fit)
     }
     const bool rec_try = rec_enabled && auto_shape && ((for_latency && !latency_phases) || rec_batch) && s.mode == MODE_WGB &&
                          s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;

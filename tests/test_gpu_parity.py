@@ -826,7 +826,7 @@ def test_hub_sketch_with_one_level_wider_than_the_team_and_its_staging_buffer(E,
 
 
 @pytest.mark.parametrize("npts,hub_last,shape", [(40, True, (0, 64)), (100, False, (0, 64)), (300, True, (2, 128)),
-                                                 (40, True, (4, 64)), (100, False, (4, 128)), (300, True, (4, 128))])
+                                                 (40, True, (4, 64)), (100, False, (4, 128)), (300, True, (4, 256))])
 def test_small_hub_sketch_on_one_wavefront_or_lean_workgroup(E, npts, hub_last, shape):
     """The hub sketch at the sizes the list-walk shapes run on one wavefront per system (82, 202 variables) or on a lean
     128-lane workgroup (602): its first level is wider than the team (two-phase walk) and, from 100 points, larger than the
