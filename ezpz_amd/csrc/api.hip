@@ -1839,9 +1839,10 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     s.lanes.reset();
     // (sketches of up to 64 variables: twice that -- their rounds are short, the lanes' time is a latency floor of ~3 ms
     // whatever the batch, and the teams run them at 12-19 M solves/s: 32 768 systems of 50 variables 9.8 M/s on the lanes)
-    // (and up to 400 variables since the teams walk records: 32 768 systems of 100 / 150 / 300 / 500 variables 15.2 / 5.9 / 2.3 / 0.69
+    // (and up to 600 variables since the teams walk records: 32 768 systems of 100 / 150 / 300 / 500 variables 15.2 / 5.9 / 2.3 / 0.69
     // M solves/s on the lanes, 22.4 / 8.6 / 3.1 / 0.61 on the teams; 65 536: 26.4 / 10.5 / 4.3 / 1.27 against 22.8 / 8.7 / 3.1 / 0.61)
-    s.lanes_min = batch_lanes ? 1 : 64ull * (n_vars <= 400 ? 4 : 2) * (s.lim.cus ? s.lim.cus : 256);
+    // (500 variables: 0.91 M on the teams whatever the batch, 0.69 / 1.27 M on the lanes at 32 768 / 65 536)
+    s.lanes_min = batch_lanes ? 1 : 64ull * (n_vars <= 600 ? 4 : 2) * (s.lim.cus ? s.lim.cus : 256);
     static const bool lanes_enabled = [] {
         const char* e = std::getenv("EZPZ_LANES");
         return !(e && e[0] == '0');
