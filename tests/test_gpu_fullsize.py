@@ -110,3 +110,36 @@ def test_quarter_million_jittered_sketches_on_the_lanes_full_size(E):
     # its own wavefront's progress)
     x2, st2, _ = sysobj.solve_batch(x0)
     assert np.array_equal(st2["iterations"], st["iterations"]) and np.array_equal(x2, x)
+
+
+def test_thirty_two_thousand_jittered_sketches_on_the_record_walk_full_size(E):
+    """The teams' leg of bench.py at its full size: 32 768 jittered starts of the 300-variable sketch -- below the batch from
+    which the lanes serve a call, so every system is solved by a 128-lane workgroup walking records (team_mode 4: api.hip,
+    build_records).  Every system converges with every constraint satisfied, a sample spread over the batch plus the systems
+    with the most iterations against the oracle with the measured bar of tests/sensitivity.py, the same bits from run to run,
+    and the same iteration counts and flags as the 262 144-system batch gives these starts on the lanes."""
+    from ezpz_amd.synthetic import keyed_uniform, make_workload
+    from sensitivity import assert_batch_matches_oracle
+
+    desc, recs, g, jitter, _ = make_workload("sketch150")
+    n, B = len(g), 32768
+    x0 = g[None, :] + keyed_uniform(0x657A707A, B, n, -jitter, jitter)
+    sysobj = E.System(recs, n)
+    assert sysobj.info()["team_mode"] == 4 and sysobj.info()["team_size"] == 128
+    x, st, _ = sysobj.solve_batch(x0)
+    assert np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0)
+    assert np.all(st["final_residual_inf"] <= 1e-8)
+    assert st["iterations"].min() >= 3 and st["iterations"].max() <= 35
+    late = np.argsort(st["iterations"])[-32:]
+    sample = np.unique(np.concatenate([np.arange(0, B, B // 64)[:64], late]))
+    needed = assert_batch_matches_oracle(recs, x0[sample], x[sample], st["iterations"][sample], st["converged"][sample],
+                                         what="sketch150 x 32768")
+    assert needed <= len(sample) // 4
+    x2, st2, _ = sysobj.solve_batch(x0)
+    assert np.array_equal(st2["iterations"], st["iterations"]) and np.array_equal(x2, x)
+    # one lane per system (the shape of larger batches) on the same starts: the same LM paths
+    lanes = E.System(recs, n, team_size=E.TEAM_BATCH_LANES)
+    xl, stl, _ = lanes.solve_batch(x0[:4096])
+    assert np.array_equal(stl["converged"], st["converged"][:4096])
+    assert np.mean(stl["iterations"] == st["iterations"][:4096]) >= 0.99
+    assert np.max(np.abs(xl - x[:4096]) / np.maximum(1.0, np.abs(x[:4096]))) <= 1e-6
