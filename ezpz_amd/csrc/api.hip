@@ -1671,9 +1671,14 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const uint32_t extra = s.rec_extra;
         s.rec_extra = 0;
         pack_and_shape(true);
-        // (batches only: 4194 systems of 2000 variables 106 -> 114 k solves/s, 1677 of 5000 variables 6.3 -> 8.4 k; one solve 2.02 ->
-        // 1.82 ms but 25.0 -> 26.9 ms: a round through global memory is a store's acknowledgement, a rendezvous and a trip to L2)
-        if (!s.lds_ws && wide_enabled && rec_batch) {
+        // (batches: 4194 systems of 2000 variables 106 -> 114 k solves/s, 1677 of 5000 variables 6.3 -> 8.4 k; a round through
+        // global memory is a store's acknowledgement, a rendezvous and a trip to L2)
+        static const uint32_t wide_one_solve_max = [] {  // (A/B runs: one solve walks wide records up to this many variables)
+            const char* e = std::getenv("EZPZ_REC_WIDE_LATENCY");
+            return e ? (uint32_t)std::atol(e) : 3500u;
+        }();
+        // (one solve of 1600 / 2000 / 3000 / 4000 / 5000 variables: 1.23 -> 1.16, 2.02 -> 1.82, 1.77 -> 1.49, 2.47 -> 2.47, 25.0 -> 26.9 ms)
+        if (!s.lds_ws && wide_enabled && (rec_batch || P.c.n_vars <= wide_one_solve_max)) {
             rec_wide = true;
             s.rec_extra = extra;
             pack_and_shape(true);

@@ -706,7 +706,7 @@ def test_connected_sketch_latency_shape_with_dense_root_block(E, npts, shape):
     """The launch shape of one solve (`TEAM_AUTO_LATENCY`, what `ezpz_solve` asks for) runs the linear solve of a connected
     sketch whose state fits the LDS as a RECORD WALK (api.hip: build_records; lm_kernel.hip.hpp: REC builds): every level of
     the elimination tree one or more rounds in which a group of lanes owns one entry, the lanes' operand addresses ready in
-    records requested a round ahead (`shape` "records": team_mode 4; 2400 variables do not fit and keep the phases).
+    records requested a round ahead (`shape` "records": team_mode 4; 2400 variables do not fit the LDS and walk the wide form).
     `TEAM_LATENCY_PHASES` keeps what that shape did before: it ends the elimination
     with dense phases: runs of levels at the top of the elimination tree whose columns fall into independent
     blocks of <= 16 (the last one the root block: the last <= 16 columns), each block's Schur complement gathered by
@@ -722,8 +722,8 @@ def test_connected_sketch_latency_shape_with_dense_root_block(E, npts, shape):
     walk = E.System(recs, n, team_size=512)
     li, wi = lat.info(), walk.info()
     assert li["n_components"] == 1
-    if shape == "records" and npts < 1200:
-        assert li["team_mode"] == 4 and li["workspace_in_lds"] and li["n_levels"] == wi["n_levels"]
+    if shape == "records":  # (2400 variables: the wide form, 32-bit addresses into a workspace in global memory)
+        assert li["team_mode"] == 4 and li["workspace_in_lds"] == (npts < 1200) and li["n_levels"] == wi["n_levels"]
     else:
         assert li["team_mode"] == 2
         assert li["n_levels"] + 4 <= wi["n_levels"], (li["n_levels"], wi["n_levels"])  # the top levels became the block
