@@ -181,7 +181,7 @@ struct EzpzSystem {
     bool lean_lds = false;  // batch-throughput workgroup: keep LDS per workgroup small (no whole-list staging)
     // record walk (build_records): the linear solve of one connected system on a barrier workgroup as rounds of per-lane
     // records; rec_extra = doubles behind the workspace proper (the factor's diagonal, one zero), offsets into the blob
-    bool rec = false, rec_wide = false;
+    bool rec = false, rec_wide = false, rec_jglobal = false;
     uint32_t rec_extra = 0, rec_rounds = 0, rec_desc_lds_off = 0;
     size_t rec_desc_off = 0, rec_chunks_off = 0, rec_asm_cols_off = 0, rec_asm_slots_off = 0;
     uint32_t rec_asm_kc = 0, rec_asm_ks = 0;
@@ -247,6 +247,12 @@ uint32_t workspace_doubles(const ProgramCounts& c) {
     return (uint32_t)((doubles + 1) & ~1ull);
 }
 
+// The list walk's part of a record-walk workspace: without the Jacobian's values when those live in global memory.
+uint32_t rec_ws_base(const ProgramCounts& c, bool jglobal) {
+    const uint64_t doubles = 3ull * c.n_vars + 2ull * c.n_rows + (jglobal ? 0u : c.zj) + c.zlo + 2;
+    return (uint32_t)((doubles + 1) & ~1ull);
+}
+
 // Sub-wavefront team for small systems: lanes per system.
 // Lanes per system for sub-wavefront teams.  Every system of a batch runs the same program, so with few lanes per
 // system the constraints a wavefront evaluates in one round are of few kinds (less divergence) while each lane's
@@ -275,7 +281,7 @@ uint32_t auto_wg_team(uint32_t width) { return std::min<uint32_t>(512, std::max<
 // that many leading bytes of the blob are copied to LDS by every workgroup (16-bit index lists).
 // `panel_bytes`: LDS every team needs on top of its workspace (dense phases), counted when the workgroup is sized.
 void finish_team(EzpzSystem& s, size_t stage_bytes, size_t panel_bytes = 0) {
-    s.ws_doubles = workspace_doubles(s.counts) + s.rec_extra;
+    s.ws_doubles = rec_ws_base(s.counts, s.rec_jglobal) + s.rec_extra;
     const size_t ws_bytes = (size_t)s.ws_doubles * 8;
     s.prog_in_lds = stage_bytes > 0;
     s.prog_lds_doubles = (uint32_t)((stage_bytes + 15) / 16 * 2);
@@ -532,6 +538,24 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         return staged ? launch_variant<64, MODE_PART, true, true>(s, args, grid, stream)
                       : launch_variant<64, MODE_PART, true, false>(s, args, grid, stream);
     if (s.rec) {  // one connected system, its linear solve as a record walk
+        if (s.rec_jglobal) {
+            // the Jacobian's values of every workgroup in global memory: one array per system object, launches on different
+            // streams chained on an event (like the other per-system device scratch)
+            const size_t stride = (s.counts.zj + 2) & ~1u;
+            int rc = s.gws_dev.ensure((size_t)grid * stride);
+            if (rc != EZPZ_OK) return rc;
+            args.gws = s.gws_dev.p;
+            if (!s.lanes_done)
+                HIP_TRY(hipEventCreateWithFlags(&s.lanes_done, hipEventDisableTiming));
+            else
+                HIP_TRY(hipStreamWaitEvent(stream, s.lanes_done, 0));
+            rc = s.linear_only ? (staged ? launch_kernel<64, MODE_WGB, true, true, true, false, 1>(s, args, grid, stream)
+                                         : launch_kernel<64, MODE_WGB, true, false, true, false, 1>(s, args, grid, stream))
+                               : (staged ? launch_kernel<64, MODE_WGB, true, true, false, false, 1>(s, args, grid, stream)
+                                         : launch_kernel<64, MODE_WGB, true, false, false, false, 1>(s, args, grid, stream));
+            if (rc == EZPZ_OK) HIP_TRY(hipEventRecord(s.lanes_done, stream));
+            return rc;
+        }
         if (s.linear_only)
             return staged ? launch_kernel<64, MODE_WGB, true, true, true, false, 1>(s, args, grid, stream)
                           : launch_kernel<64, MODE_WGB, true, false, true, false, 1>(s, args, grid, stream);
@@ -968,12 +992,14 @@ struct RecPlan {
 };
 // `wide`: the workspace lives in global memory -- 32-bit addresses counted from its start (lds_base = 0), chunk 0 = target,
 // diagonal, destination, lane flags, then up to four chunks of two (a, b) pairs; no packed assembly.
-static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, bool wide, RecPlan& out) {
+// `jglobal` (LDS form): the Jacobian's values live in global memory (SolveArgs::rec_jglobal): no room for them in the workspace, and
+// the packed assembly's J operands are plain slot numbers (padding: slot zJ, a zero behind the values).
+static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, bool wide, bool jglobal, RecPlan& out) {
     if (P.c.n_parts != 1 || P.parts.size() != 1 || P.c.dense || P.n_dense || T < 64 || T % 64) return false;
     const uint32_t n = P.c.n_vars, m = P.c.n_rows, zj = P.c.zj, zlo = P.c.zlo;
     // (addresses in the records count doubles from the start of the LDS; the workspace begins `lds_base` doubles in)
-    const uint32_t o_d = lds_base + n + 2 * m + zj, o_l = o_d + n, o_v = o_l + zlo, o_dd = lds_base + workspace_doubles(P.c),
-                   o_zero = o_dd + n;
+    const uint32_t o_d = lds_base + n + 2 * m + (jglobal ? 0u : zj), o_l = o_d + n, o_v = o_l + zlo,
+                   o_dd = lds_base + rec_ws_base(P.c, jglobal), o_zero = o_dd + n;
     if (!wide && o_zero >= 65536) return false;  // 16-bit addresses
     const uint32_t lvl0 = P.parts[0].lvl0, nlev = P.parts[0].nlev, n_waves = T / 64;
     const uint32_t kMaxShare = wide ? REC_WIDE_PAIRS : REC_MAX_PAIRS;
@@ -1072,7 +1098,7 @@ static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, bool 
         const uint32_t o_r = lds_base + n, o_j = lds_base + n + 2 * m;
         const uint32_t call0 = P.lvl_cptr[lvl0], call1 = P.lvl_cptr[lvl0 + nlev], sall0 = P.lvl_sptr[lvl0], sall1 = P.lvl_sptr[lvl0 + nlev];
         auto pack = [&](const std::vector<uint32_t>& ptr, const std::vector<uint32_t>& items, uint32_t i0, uint32_t i1, uint32_t off_a,
-                        uint32_t off_b, std::vector<uint32_t>& dst) -> uint32_t {
+                        uint32_t off_b, uint32_t zero_pair, std::vector<uint32_t>& dst) -> uint32_t {
             uint32_t longest = 0;
             for (uint32_t i = i0; i < i1; ++i) longest = std::max(longest, ptr[i + 1] - ptr[i]);
             const uint32_t K = std::max(1u, (longest + 3) / 4), N = i1 - i0;
@@ -1083,8 +1109,10 @@ static bool build_records(const Program& P, uint32_t T, uint32_t lds_base, bool 
                     dst[((size_t)(e / 4) * N + (i - i0)) * 4 + e % 4] = (off_a + items[2 * q]) | ((off_b + items[2 * q + 1]) << 16);
             return K;
         };
-        out.asm_kc = wide ? 0 : pack(P.colj_ptr, P.colj_items, call0, call1, o_j, o_r, out.asm_cols);
-        out.asm_ks = out.asm_kc ? pack(P.apair_ptr, P.apairs, sall0, sall1, o_j, o_j, out.asm_slots) : 0;
+        // (J operands: LDS addresses, or -- jglobal -- slot numbers with slot zJ as the zero)
+        const uint32_t ja = jglobal ? 0u : o_j, jz = jglobal ? zj : o_zero;
+        out.asm_kc = wide ? 0 : pack(P.colj_ptr, P.colj_items, call0, call1, ja, o_r, jz | (o_zero << 16), out.asm_cols);
+        out.asm_ks = out.asm_kc ? pack(P.apair_ptr, P.apairs, sall0, sall1, ja, ja, jz | (jz << 16), out.asm_slots) : 0;
         if (!out.asm_ks) out.asm_kc = 0;
     }
     std::vector<Item> items;
@@ -1602,7 +1630,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         stage_bytes = 0;
         if (small_counts && may_stage) {
             const size_t lists_bytes = pack_program(P, true, s.mode != MODE_SUB, blob, v);
-            const size_t ws_bytes = ((size_t)workspace_doubles(P.c) + s.rec_extra) * 8;
+            const size_t ws_bytes = ((size_t)rec_ws_base(P.c, s.rec_jglobal) + s.rec_extra) * 8;
             if (s.mode == MODE_SUB) {
                 if (blob.size() <= kProgLdsMax) stage_bytes = blob.size();  // lists and constraint table
             } else if (s.grid_wgs == 1 && v.packed && lists_bytes + ws_bytes + 2048 <= s.lim.lds_bytes && !s.lean_lds) {
@@ -1620,7 +1648,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return !(e && e[0] == '0');
     }();
     RecPlan rec;
-    s.rec = s.rec_wide = false;
+    s.rec = s.rec_wide = s.rec_jglobal = false;
     s.rec_rounds = 0;
     s.rec_extra = 0;
     // Batches of one connected sketch on the per-system teams take the record walk as well -- one wavefront up to 160 variables,
@@ -1636,12 +1664,37 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     const bool saved_lean = s.lean_lds;
     const bool rec_batch = rec_enabled && rec_batch_lanes != 0 && auto_shape && team_size == 0 && !for_latency && !want_sub &&
                            s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;
+    // Batches keep the Jacobian's values in global memory (SolveArgs::rec_jglobal) when the assembly can read them from packed
+    // pairs (no list of more than twelve): a fifth of a system's LDS, one more workgroup per CU.  EZPZ_REC_JGLOBAL=0: in the LDS.
+    static const bool jglobal_enabled = [] {
+        const char* e = std::getenv("EZPZ_REC_JGLOBAL");
+        return !(e && e[0] == '0');
+    }();
+    bool jglobal = rec_batch && jglobal_enabled && P.c.zj < 65535 && !P.parts.empty();
+    if (jglobal) {
+        const uint32_t l0 = P.parts[0].lvl0, nl = P.parts[0].nlev;
+        for (uint32_t v = P.lvl_cptr[l0]; v < P.lvl_cptr[l0 + nl] && jglobal; ++v) jglobal = P.colj_ptr[v + 1] - P.colj_ptr[v] <= 12;
+        for (uint32_t sl = P.lvl_sptr[l0]; sl < P.lvl_sptr[l0 + nl] && jglobal; ++sl) jglobal = P.apair_ptr[sl + 1] - P.apair_ptr[sl] <= 12;
+    }
     if (rec_batch) {
-        const size_t ws_b = ((size_t)workspace_doubles(P.c) + P.c.n_vars + 4) * 8;
         // (about eight wavefronts per CU: 300 variables, four workgroups per CU, 3.19 M solves/s on 128 lanes against 2.94 M on 256;
         // 500 variables, two per CU, 0.68 against 0.91 M; 800 variables, one per CU, 53 k / 73 k / 91 k on 128 / 256 / 512 lanes)
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, s.lim.lds_bytes / (ws_b + 4096));
-        uint32_t t = P.c.n_vars <= 160 ? 64u : std::min(512u, std::max(128u, pow2_ceil(512u / per_cu)));
+        auto shape_for = [&](bool jg, uint32_t& per_cu) {
+            const size_t ws_b = ((size_t)rec_ws_base(P.c, jg) + P.c.n_vars + 4) * 8;
+            per_cu = (uint32_t)std::max<size_t>(1, s.lim.lds_bytes / (ws_b + 4096));
+            return P.c.n_vars <= 160 ? 64u : std::min(512u, std::max(128u, pow2_ceil(512u / per_cu)));
+        };
+        uint32_t per_cu = 1, per_cu_j = 1;
+        uint32_t t = shape_for(false, per_cu);
+        if (jglobal) {
+            // ... and J out of the LDS where that puts more wavefronts on a CU, or as many in more systems: 300 / 500 / 800 variables
+            // 3.15 -> 3.68, 0.90 -> 1.16 M solves/s, 88 -> 114 k (four -> five, two -> three, one -> two workgroups per CU); not at 400
+            // (three of 256 lanes -> four of 128: 2.48 -> 2.34 M), 600 (two either way: 1.44 -> 1.33 M) or on one wavefront (100: -8 %)
+            const uint32_t tj = shape_for(true, per_cu_j);
+            const uint32_t w = per_cu * t, wj = per_cu_j * tj;
+            jglobal = P.c.n_vars > 160 && (wj > w || (wj == w && per_cu_j > per_cu));
+            if (jglobal) t = tj;
+        }
         if (rec_batch_lanes >= 64 && rec_batch_lanes <= 512 && rec_batch_lanes % 64 == 0) t = (uint32_t)rec_batch_lanes;
         s.mode = MODE_WGB;
         s.team_size = t;
@@ -1650,6 +1703,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     const bool rec_try = rec_enabled && auto_shape && ((for_latency && !latency_phases) || rec_batch) && s.mode == MODE_WGB &&
                          s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;
     if (rec_try) {
+        s.rec_jglobal = jglobal;
         s.rec_extra = (P.c.n_vars + 2 + 1) & ~1u;
 #ifdef EZPZ_REC_TIMES
         s.rec_extra += 6 * 128;  // (diagnostic build: six cycle stamps per round of the second iteration's walk, behind the zero)
@@ -1670,6 +1724,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }();
         const uint32_t extra = s.rec_extra;
         s.rec_extra = 0;
+        s.rec_jglobal = false;  // (J in global memory is for states that fit the LDS with it)
         pack_and_shape(true);
         // (batches: 4194 systems of 2000 variables 106 -> 114 k solves/s, 1677 of 5000 variables 6.3 -> 8.4 k; a round through
         // global memory is a store's acknowledgement, a rendezvous and a trip to L2)
@@ -1685,7 +1740,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         }
     }
     if (rec_try) {
-        if ((s.lds_ws || rec_wide) && s.rec_extra && build_records(P, s.team_size, rec_wide ? 0u : s.prog_lds_doubles, rec_wide, rec)) {
+        if ((s.lds_ws || rec_wide) && s.rec_extra && build_records(P, s.team_size, rec_wide ? 0u : s.prog_lds_doubles, rec_wide, s.rec_jglobal, rec) &&
+            (!s.rec_jglobal || rec.asm_kc)) {
             s.rec = true;
             s.rec_rounds = rec.rounds;
             s.rec_desc_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);  // the descriptors' copy in LDS, behind everything else
@@ -1695,6 +1751,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         s.rec_wide = s.rec && rec_wide;
         if (!s.rec) {
             s.rec_extra = 0;
+            s.rec_jglobal = false;
             if (rec_batch) {  // no room: the shape chosen before
                 s.mode = saved_mode;
                 s.team_size = saved_team;
@@ -2009,16 +2066,18 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
             const char* e = std::getenv("EZPZ_REC_ASM");
             return !(e && e[0] == '0');
         }();
-        if (packed && sys->rec_asm_kc) {
+        if ((packed || sys->rec_jglobal) && sys->rec_asm_kc) {
             a.rec_asm_cols = reinterpret_cast<const uint4*>(base + sys->rec_asm_cols_off);
             a.rec_asm_slots = reinterpret_cast<const uint4*>(base + sys->rec_asm_slots_off);
             a.rec_asm_kc = sys->rec_asm_kc;
             a.rec_asm_ks = sys->rec_asm_ks;
         }
         const uint32_t n = sys->counts.n_vars, m = sys->counts.n_rows;
-        const uint32_t o_d = n + 2 * m + sys->counts.zj, o_dd = workspace_doubles(sys->counts);
+        const uint32_t o_d = n + 2 * m + (sys->rec_jglobal ? 0u : sys->counts.zj), o_dd = rec_ws_base(sys->counts, sys->rec_jglobal);
         a.rec_dd_delta = o_dd - o_d;
         a.rec_zero = o_dd + n;
+        a.rec_jglobal = sys->rec_jglobal ? 1u : 0u;
+        a.rec_jstride = (sys->counts.zj + 2) & ~1u;  // (the values, the zero of padding pairs)
     }
     fill_cfg(a, cfg);
     return launch(*sys, a, static_cast<hipStream_t>(stream));

@@ -249,6 +249,10 @@ struct SolveArgs {
     const uint2* rec_desc;
     const uint4* rec_chunks;
     uint32_t rec_rounds, rec_dd_delta, rec_zero, rec_desc_off;
+    // rec_jglobal (LDS form, batches): the Jacobian's values live in global memory (gws + workgroup x rec_jstride doubles), not in
+    // the workspace -- they are written once per accepted step by the sweep and read once per iteration by the packed assembly,
+    // and their zJ doubles are a fifth of a system's LDS: one more workgroup per CU
+    uint32_t rec_jglobal, rec_jstride;
     // packed assembly (REC builds; 0 chunks = the lists are walked): the Jacobian-slot pairs of every column of A (a = J slot, b
     // = row of r) and of every entry of its strict lower part (a, b = J slots) as rec_asm_kc / rec_asm_ks 16-byte chunks of four
     // (a | b << 16) pairs per item, chunk k of item i at [k * items + i] -- one coalesced request per chunk instead of pointer,
@@ -692,8 +696,11 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
     const uint32_t o_x = 0;
     uint32_t o_r = n;
     uint32_t o_rn = n + m;
+    bool rec_jglobal = false;
+    if constexpr (RECF == 1) rec_jglobal = a.rec_jglobal != 0;
+    double* const jglob = rec_jglobal ? a.gws + (size_t)blockIdx.x * a.rec_jstride : nullptr;
     const uint32_t o_j = n + 2 * m;
-    const uint32_t o_d = o_j + zj;   // Cholesky diagonal, by variable
+    const uint32_t o_d = o_j + (rec_jglobal ? 0u : zj);   // Cholesky diagonal, by variable
     const uint32_t o_l = o_d + n;    // strictly-lower L entries, (partition, level) grouped
     const uint32_t o_v = o_l + zlo;  // b, then y, then d (by variable)
     const uint32_t o_i = o_v + n;    // small int area
@@ -755,6 +762,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
     }
     if constexpr (REC) {  // (ordered before their first use by every system's first rendezvous)
         if (tid == 0) ws[a.rec_zero] = 0.0;
+        if (tid == 0 && rec_jglobal) jglob[zj] = 0.0;  // (the operand of a padding pair among the Jacobian's values)
         uint2* dst = reinterpret_cast<uint2*>(smem + a.rec_desc_off);
         const uint32_t nd = (a.rec_rounds + 2) * (blockDim.x >> 6);  // (two idle rounds behind the last)
         for (uint32_t i = tid; i < nd; i += blockDim.x) dst[i] = a.rec_desc[i];
@@ -863,8 +871,10 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
                 // ---- A = JtJ + lambda I (into L's storage) and b = Jt(-r)  (newton.rs:77-84) ---------------------
                 // Record walk builds: from packed pair chunks (SolveArgs::rec_asm_*), one item per lane and trip, the next
                 // trip's chunks requested before this trip's are used.
-                auto packed_pass = [&](auto kc, const uint4* base, uint32_t N, auto&& emit) __attribute__((always_inline)) {
+                // (AG / BG: the pair's first / second operand is a Jacobian value kept in global memory, SolveArgs::rec_jglobal)
+                auto packed_pass = [&](auto kc, auto ag, auto bg, const uint4* base, uint32_t N, auto&& emit) __attribute__((always_inline)) {
                     constexpr int K = decltype(kc)::value;
+                    constexpr bool AG = decltype(ag)::value, BG = decltype(bg)::value;
                     uint32_t i = (uint32_t)tid;
                     if (i >= N) return;
                     uint4 cur[K];
@@ -883,8 +893,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
                             double va[4], vb[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                va[e] = smem[w[e] & 0xFFFFu];
-                                vb[e] = smem[w[e] >> 16];
+                                va[e] = AG ? jglob[w[e] & 0xFFFFu] : smem[w[e] & 0xFFFFu];
+                                vb[e] = BG ? jglob[w[e] >> 16] : smem[w[e] >> 16];
                             }
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -907,15 +917,29 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
                         ws[o_v + call0 + v] = sn;
                     };
                     auto emit_slot = [&](uint32_t sl, double, double sp, double) { ws[o_l + sall0 + sl] = sp; };
+                    using T_ = std::true_type;
+                    using F_ = std::false_type;
+                    auto cols = [&](auto kc) {
+                        if (rec_jglobal)
+                            packed_pass(kc, T_{}, F_{}, a.rec_asm_cols, call1 - call0, emit_col);
+                        else
+                            packed_pass(kc, F_{}, F_{}, a.rec_asm_cols, call1 - call0, emit_col);
+                    };
+                    auto slots = [&](auto kc) {
+                        if (rec_jglobal)
+                            packed_pass(kc, T_{}, T_{}, a.rec_asm_slots, sall1 - sall0, emit_slot);
+                        else
+                            packed_pass(kc, F_{}, F_{}, a.rec_asm_slots, sall1 - sall0, emit_slot);
+                    };
                     switch (a.rec_asm_kc) {
-                    case 1: packed_pass(std::integral_constant<int, 1>{}, a.rec_asm_cols, call1 - call0, emit_col); break;
-                    case 2: packed_pass(std::integral_constant<int, 2>{}, a.rec_asm_cols, call1 - call0, emit_col); break;
-                    default: packed_pass(std::integral_constant<int, 3>{}, a.rec_asm_cols, call1 - call0, emit_col); break;
+                    case 1: cols(std::integral_constant<int, 1>{}); break;
+                    case 2: cols(std::integral_constant<int, 2>{}); break;
+                    default: cols(std::integral_constant<int, 3>{}); break;
                     }
                     switch (a.rec_asm_ks) {
-                    case 1: packed_pass(std::integral_constant<int, 1>{}, a.rec_asm_slots, sall1 - sall0, emit_slot); break;
-                    case 2: packed_pass(std::integral_constant<int, 2>{}, a.rec_asm_slots, sall1 - sall0, emit_slot); break;
-                    default: packed_pass(std::integral_constant<int, 3>{}, a.rec_asm_slots, sall1 - sall0, emit_slot); break;
+                    case 1: slots(std::integral_constant<int, 1>{}); break;
+                    case 2: slots(std::integral_constant<int, 2>{}); break;
+                    default: slots(std::integral_constant<int, 3>{}); break;
                     }
                 }
                 if (!packed_asm) {
@@ -1679,6 +1703,9 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
                 const DevCon& c = cref.get();
                 JacWriter<WsRef<WS_STRIDE>> w;
                 w.jv = ws + o_j;
+                if constexpr (RECF == 1) {
+                    if (rec_jglobal) w.jv.p = jglob;
+                }
                 w.jbase = c.jbase;
                 const uint4 loc = cref.jloc(P);
                 w.loc[0] = loc.x;
