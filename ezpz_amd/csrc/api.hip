@@ -983,6 +983,7 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
 // backward), first chunk; chunks[((chunk + c) x 64 + lane of the wavefront) x 4]: chunk 0 = target | diagonal << 16, destination
 // | lane flags, two (a | b << 16) pairs; chunks 1 and 2 = four pairs each (REC_* in lm_kernel.hip.hpp).  Only a wavefront that
 // has an item in a round has chunks for it, as many as its longest share needs.
+constexpr uint32_t kRecMaxComponents = 16;  // (analyze_into: up to this many components walk records as one partition)
 struct RecPlan {
     std::vector<uint32_t> desc, chunks;
     uint32_t rounds = 0;
@@ -1573,7 +1574,19 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             }
         }
         if (!have_program) {
-            if (!build_program(cs, n_cs, n_vars, P, be, W)) return fail();
+            // A FEW components (a document of several sketches) are one partition for the record walk, which needs levels, not
+            // connectivity: batches of 4 x 150 / 8 x 80 / 3 x 300 variables 0.64 -> 1.73, 0.68 -> 1.63, 0.57 -> 1.28 M solves/s against a
+            // wavefront per balanced share of the components.  (Many small components are the component-resident shape's.)
+            static const bool rec_multi = [] {
+                const char* e = std::getenv("EZPZ_REC_MULTI");
+                return !(e && e[0] == '0');
+            }();
+            static const bool rec_on2 = [] {
+                const char* e = std::getenv("EZPZ_REC");
+                return !(e && e[0] == '0');
+            }();
+            const bool few = rec_on2 && rec_multi && !team_size && !for_latency && !lists_only && n_pieces >= 2 && n_pieces <= kRecMaxComponents;
+            if (!build_program(cs, n_cs, n_vars, P, be, few ? 1u : W)) return fail();
             if (!team_size && (size_t)workspace_doubles(P.c) * 8 + 4096 > s.lim.lds_bytes && grid_wgs_for() > 1) {
                 Program one = std::move(P);
                 const int r = build_grid(grid_wgs_for());
@@ -1663,7 +1676,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     const uint32_t saved_team = s.team_size;
     const bool saved_lean = s.lean_lds;
     const bool rec_batch = rec_enabled && rec_batch_lanes != 0 && auto_shape && team_size == 0 && !for_latency && !want_sub &&
-                           s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;
+                           s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents && !P.c.dense;
     // Batches keep the Jacobian's values in global memory (SolveArgs::rec_jglobal) when the assembly can read them from packed
     // pairs (no list of more than twelve): a fifth of a system's LDS, one more workgroup per CU.  EZPZ_REC_JGLOBAL=0: in the LDS.
     static const bool jglobal_enabled = [] {
@@ -1701,7 +1714,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         s.lean_lds = true;  // (its lists stay in L2: the LDS is for as many systems as fit)
     }
     const bool rec_try = rec_enabled && auto_shape && ((for_latency && !latency_phases) || rec_batch) && s.mode == MODE_WGB &&
-                         s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components == 1 && !P.c.dense;
+                         s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents && !P.c.dense;
     if (rec_try) {
         s.rec_jglobal = jglobal;
         s.rec_extra = (P.c.n_vars + 2 + 1) & ~1u;

@@ -676,6 +676,42 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
     assert_x_close(x[0], want.final_values)
 
 
+@pytest.mark.parametrize("k,npts", [(4, 40), (7, 25), (3, 150)])
+def test_a_few_sketches_in_one_system_walk_records_as_one_partition(E, k, npts):
+    """A document of several sketches: k connected components of 50 ... 300 variables in ONE system.  The record walk needs
+    levels, not connectivity: the batch shape makes them one partition (team_mode 4; api.hip, analyze_into: up to 16 components)
+    where the list-walk shapes give each wavefront a balanced share (`TEAM_AUTO_LISTS`).  Both against the oracle on jittered
+    starts, and against each other."""
+    parts, guesses, off = [], [], 0
+    for c in range(k):
+        recs, g = gen.connected_sketch(npts, 7300 + 31 * c + npts)
+        r = recs.copy()
+        for i in range(len(r)):
+            r["ids"][i][:O.KIND_NUM_IDS[int(r["kind"][i])]] += off
+        parts.append(r)
+        guesses.append(g)
+        off += len(g)
+    recs, g = np.concatenate(parts), np.concatenate(guesses)
+    n = len(g)
+    x0 = g[None, :] + gen.keyed_uniform(k * 1000 + npts, 9, n, -0.03, 0.03)
+    x0[0] = g
+    cfg = dict(max_iterations=50)
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0
+    walk = E.System(recs, n)
+    lists = E.System(recs, n, team_size=E.TEAM_AUTO_LISTS)
+    wi, li = walk.info(), lists.info()
+    assert wi["n_components"] == k and wi["team_mode"] == 4 and wi["n_partitions"] == 1, wi
+    assert li["team_mode"] in (1, 2), li
+    from sensitivity import assert_batch_matches_oracle
+    for sysobj in (walk, lists):
+        x, st, _ = sysobj.solve_batch(x0, E.Config(**cfg))
+        # (some of these starts take 40 LM iterations: counts inside the oracle's own spread, tests/sensitivity.py)
+        assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg), oracle_result=(xo, it, conv),
+                                    what=(k, npts))
+        assert np.array_equal(st["n_unsatisfied"], nun)
+
+
 @pytest.mark.parametrize("npts,latency_mode,batch_mode", [(10, 0, 0), (16, 4, 0), (25, 4, 0), (32, 4, 4)])
 def test_small_connected_sketch_walks_records_where_it_pays(E, npts, latency_mode, batch_mode):
     """One connected sketch of 20 ... 64 variables: one solve walks records from 25 variables (team_mode 4),
