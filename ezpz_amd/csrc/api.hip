@@ -1585,7 +1585,9 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
                 const char* e = std::getenv("EZPZ_REC");
                 return !(e && e[0] == '0');
             }();
-            const bool few = rec_on2 && rec_multi && !team_size && !for_latency && !lists_only && n_pieces >= 2 && n_pieces <= kRecMaxComponents;
+            // (one solve of such a system too: 4 x 150 / 8 x 80 / 6 x 40 variables 790 -> 237, 727 -> 237, 224 -> 109 us)
+            const bool few = rec_on2 && rec_multi && !team_size && !latency_phases && !lists_only && n_pieces >= 2 &&
+                             n_pieces <= kRecMaxComponents;
             if (!build_program(cs, n_cs, n_vars, P, be, few ? 1u : W)) return fail();
             if (!team_size && (size_t)workspace_doubles(P.c) * 8 + 4096 > s.lim.lds_bytes && grid_wgs_for() > 1) {
                 Program one = std::move(P);

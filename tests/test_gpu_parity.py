@@ -704,7 +704,9 @@ def test_a_few_sketches_in_one_system_walk_records_as_one_partition(E, k, npts):
     assert wi["n_components"] == k and wi["team_mode"] == 4 and wi["n_partitions"] == 1, wi
     assert li["team_mode"] in (1, 2), li
     from sensitivity import assert_batch_matches_oracle
-    for sysobj in (walk, lists):
+    one = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY)  # (one solve's shape: the same walk on more lanes)
+    assert one.info()["team_mode"] == 4 and one.info()["n_partitions"] == 1
+    for sysobj in (walk, lists, one):
         x, st, _ = sysobj.solve_batch(x0, E.Config(**cfg))
         # (some of these starts take 40 LM iterations: counts inside the oracle's own spread, tests/sensitivity.py)
         assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg), oracle_result=(xo, it, conv),
