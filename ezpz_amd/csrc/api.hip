@@ -983,7 +983,11 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
 // backward), first chunk; chunks[((chunk + c) x 64 + lane of the wavefront) x 4]: chunk 0 = target | diagonal << 16, destination
 // | lane flags, two (a | b << 16) pairs; chunks 1 and 2 = four pairs each (REC_* in lm_kernel.hip.hpp).  Only a wavefront that
 // has an item in a round has chunks for it, as many as its longest share needs.
-constexpr uint32_t kRecMaxComponents = 16;  // (analyze_into: up to this many components walk records as one partition)
+// (analyze_into: up to this many components walk records as one partition; EZPZ_REC_MAX_COMPONENTS for A/B runs)
+static const uint32_t kRecMaxComponents = [] {
+    const char* e = std::getenv("EZPZ_REC_MAX_COMPONENTS");
+    return e ? (uint32_t)std::atol(e) : 127u;  // (from 128 the component-resident shape may take the system)
+}();
 struct RecPlan {
     std::vector<uint32_t> desc, chunks;
     uint32_t rounds = 0;

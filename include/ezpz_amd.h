@@ -162,7 +162,7 @@ typedef struct EzpzSystemInfo {
     uint32_t team_mode;     /* 0 sub-wavefront teams, 1 wavefront-partitioned workgroup, 2 barrier workgroup,
                              * 3 component-resident (one lane per connected component; n_partitions = chunks of <= 64
                              * components of one isomorphism class), 4 barrier workgroup whose linear solve is a record
-                             * walk (one connected sketch, or a system of up to 16 components: the automatic shapes) */
+                             * walk (one connected sketch, or a system of up to 127 components: the automatic shapes) */
     uint32_t n_partitions;  /* partitions (balanced unions of components), one per wavefront in mode 1 */
     uint32_t program_in_lds;
     uint32_t grid_workgroups; /* workgroups that share one system (grid team: one large system on many CUs), else 1 */

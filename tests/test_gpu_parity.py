@@ -676,10 +676,10 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
     assert_x_close(x[0], want.final_values)
 
 
-@pytest.mark.parametrize("k,npts", [(4, 40), (7, 25), (3, 150)])
+@pytest.mark.parametrize("k,npts", [(4, 40), (7, 25), (3, 150), (40, 8)])
 def test_a_few_sketches_in_one_system_walk_records_as_one_partition(E, k, npts):
     """A document of several sketches: k connected components of 50 ... 300 variables in ONE system.  The record walk needs
-    levels, not connectivity: the batch shape makes them one partition (team_mode 4; api.hip, analyze_into: up to 16 components)
+    levels, not connectivity: the automatic shapes make them one partition (team_mode 4; api.hip, analyze_into: up to 127 components)
     where the list-walk shapes give each wavefront a balanced share (`TEAM_AUTO_LISTS`).  Both against the oracle on jittered
     starts, and against each other."""
     parts, guesses, off = [], [], 0
