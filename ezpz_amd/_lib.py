@@ -61,6 +61,7 @@ EXPORTS = [
     "ezpz_specialized_source",
     "ezpz_multi_create", "ezpz_multi_destroy", "ezpz_multi_device_count", "ezpz_multi_device", "ezpz_multi_shard",
     "ezpz_multi_specialize", "ezpz_multi_solve_batch", "ezpz_system_solve_batch_multi",
+    "ezpz_debug_call_trace",
 ]
 
 _lib = None
@@ -125,6 +126,8 @@ def lib():
     L.ezpz_system_solve_batch_multi.argtypes = [vp, sz, sz, C.c_uint64, vp, sz, C.POINTER(CConfig), vp, vp]
     L.ezpz_resolve_sides.restype = C.c_int
     L.ezpz_resolve_sides.argtypes = [vp, sz, vp, sz]
+    L.ezpz_debug_call_trace.restype = sz
+    L.ezpz_debug_call_trace.argtypes = [vp, sz]
     L.ezpz_cache_clear.restype = None
     L.ezpz_cache_clear.argtypes = []
     L.ezpz_analyze.restype = C.c_int

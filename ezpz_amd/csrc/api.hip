@@ -21,10 +21,12 @@
 #include <vector>
 
 #include "../../include/ezpz_amd.h"
+#include "call_trace.hpp"
 #include "comp_program.hpp"
 #include "freedom.hip.hpp"
 #include "kinds.hpp"
 #include "lm_kernel.hip.hpp"
+#include "one_call.hpp"
 #include "program.hpp"
 
 using namespace ezpz;
@@ -151,6 +153,12 @@ struct EzpzSystem {
     // comp_solve_kernel and the list-walk program above serves only evaluation / FreedomAnalysis
     std::unique_ptr<CompPlan> comp;
     uint32_t* dev_comp = nullptr;
+    // A latency-shaped block system (ezpz_solve) is ready to solve as soon as its component plan is: the list-walk program of
+    // the whole system -- which then serves only evaluation, FreedomAnalysis and the sizes of EzpzSystemInfo -- is built
+    // and uploaded when one of those asks for it (ensure_program): 2000 x 2000, a request the process has not seen, 513 -> ~250 us.
+    std::atomic<bool> program_deferred{false};
+    std::vector<EzpzConstraint> deferred_cs;
+    std::mutex defer_mu;
     CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
     DevBuf<unsigned char> jit_scratch;  // ... and, when it spreads a system over several workgroups, their reduction scratch
     std::unique_ptr<LanePlan> lane;  // small systems: one lane per system, run-time compiled (jit stands for it then)
@@ -481,6 +489,7 @@ CompLaunch comp_launch_args(const SolveArgs& args) {
     L.residual_tolerance = args.residual_tolerance;
     L.step_tolerance = args.step_tolerance;
     L.initial_lambda = args.initial_lambda;
+    L.done = args.done;
     return L;
 }
 
@@ -1432,9 +1441,55 @@ static bool make_dense_phases(Program& P, uint32_t n_waves, size_t lds_room_byte
     return true;
 }
 
+// What EzpzSystemInfo says about a system that runs component-resident.
+static void comp_info(EzpzSystemInfo& info, const CompPlan& plan) {
+    info.team_mode = 3;
+    info.team_size = plan.n_waves * 64;
+    info.n_partitions = plan.n_chunks;
+    info.workspace_bytes = plan.lds_bytes;
+    info.workspace_in_lds = 1;
+    info.program_in_lds = 0;
+    info.grid_workgroups = 1;
+}
+
+// `may_defer`: a latency shape whose component plan is interpretable returns with that plan alone (EzpzSystem::program_deferred);
+// `keep_comp`: the system already has its component plan (ensure_program: the deferred rest).
 static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t team_size, EzpzSystem& s,
-                        Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable) {
+                        Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable,
+                        bool may_defer = false, bool keep_comp = false) {
     BuildError be;
+    static const bool comp_enabled0 = [] {
+        const char* e = std::getenv("EZPZ_COMP");
+        return !(e && e[0] == '0');
+    }();
+    static const bool defer_enabled = [] {
+        const char* e = std::getenv("EZPZ_DEFER");  // EZPZ_DEFER=0: every system is analysed whole at creation (A/B runs)
+        return !(e && e[0] == '0');
+    }();
+    if (may_defer && team_size == EZPZ_TEAM_AUTO_LATENCY && comp_enabled0 && defer_enabled && !keep_comp) {
+        std::unique_ptr<CompPlan> plan(new CompPlan());
+        CompLimits cl;
+        cl.lds_bytes = s.lim.lds_bytes;
+        if (comp_plan_build(cs, n_cs, n_vars, cl, *plan) && plan->interpretable) {
+            s.counts = ProgramCounts();
+            s.counts.n_cons = plan->n_cons;
+            s.counts.n_vars = plan->n_vars;
+            s.counts.n_rows = plan->n_rows;
+            s.unit_weights = plan->unit_weights;
+            EzpzSystemInfo& info = s.info;
+            std::memset(&info, 0, sizeof(info));
+            info.n_constraints = plan->n_cons;
+            info.n_vars = plan->n_vars;
+            info.n_rows = plan->n_rows;
+            info.program_bytes = plan->blob.size() * 4;
+            comp_info(info, *plan);
+            s.comp = std::move(plan);
+            s.deferred_cs.assign(cs, cs + n_cs);
+            s.program_deferred.store(true);
+            blob.clear();
+            return EZPZ_OK;
+        }
+    }
     const uint32_t width = (uint32_t)std::max<size_t>(1, std::max(n_cs, n_vars));
     auto fail = [&]() {
         if (err_constraint) *err_constraint = be.constraint;
@@ -1880,12 +1935,12 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     // Systems of many small independent components (>= 128 of them, in a few isomorphism classes, state within the LDS)
     // run one lane per component instead of walking per-system lists; chosen automatically only (an explicit team size
     // asks for one of the list-walk shapes; EZPZ_COMP=0 in the environment turns the shape off for A/B runs).
-    s.comp.reset();
-    static const bool comp_enabled = [] {
-        const char* e = std::getenv("EZPZ_COMP");
-        return !(e && e[0] == '0');
-    }();
-    if (auto_shape && comp_enabled) {
+    const bool comp_enabled = comp_enabled0;
+    if (keep_comp && s.comp) {
+        info.program_bytes += s.comp->blob.size() * 4;
+        if (s.comp->interpretable) comp_info(info, *s.comp);
+    } else if (auto_shape && comp_enabled) {
+        s.comp.reset();
         std::unique_ptr<CompPlan> plan(new CompPlan());
         CompLimits cl;
         cl.lds_bytes = s.lim.lds_bytes;
@@ -1896,16 +1951,12 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             info.program_bytes += plan->blob.size() * 4;
             s.comp = std::move(plan);
         } else if (planned) {
-            info.team_mode = 3;
-            info.team_size = plan->n_waves * 64;
-            info.n_partitions = plan->n_chunks;
-            info.workspace_bytes = plan->lds_bytes;
-            info.workspace_in_lds = 1;
-            info.program_in_lds = 0;
+            comp_info(info, *plan);
             info.program_bytes += plan->blob.size() * 4;
-            info.grid_workgroups = 1;
             s.comp = std::move(plan);
         }
+    } else {
+        s.comp.reset();
     }
     // ---- one lane per system: small systems that are not block systems (sub-wavefront teams otherwise) -----------------------
     s.lane.reset();
@@ -1949,17 +2000,22 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
         s->device = device;
         s->lim = device_limits(device);
     }
-    int rc = analyze_into(cs, n_cs, n_vars, team_size, *s, P, blob, err_constraint, err_variable);
+    int rc = analyze_into(cs, n_cs, n_vars, team_size, *s, P, blob, err_constraint, err_variable, /*may_defer=*/true);
+    call_stamp(COLD_ANALYSED);
     if (rc != EZPZ_OK) return rc;
     if (!have_device) return EZPZ_ERR_NO_DEVICE;
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
-    HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    s->view.base = static_cast<const unsigned char*>(s->dev_program);
+    if (!s->program_deferred.load()) {
+        HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
+        HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        s->view.base = static_cast<const unsigned char*>(s->dev_program);
+    }
     if (s->comp) {
         HIP_TRY(hipMalloc((void**)&s->dev_comp, s->comp->blob.size() * 4));
         HIP_TRY(hipMemcpy(s->dev_comp, s->comp->blob.data(), s->comp->blob.size() * 4, hipMemcpyHostToDevice));
+        call_stamp(COLD_UPLOADED);
         s->jit = comp_jit_create(*s->comp);
+        call_stamp(COLD_KERNEL_FOUND);
     } else if (s->lane) {
         s->jit = comp_jit_create_source(s->lane->jit_source, "ezpz_jit_lane");
     }
@@ -1971,6 +2027,33 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
     return EZPZ_OK;
 }
 
+}  // extern "C"
+
+// The rest of a deferred analysis (EzpzSystem::program_deferred): the list-walk program of the whole system, for
+// evaluation, FreedomAnalysis and the sizes of EzpzSystemInfo.  Solves never wait for it.
+static int ensure_program(EzpzSystem* sys) {
+    if (!sys->program_deferred.load(std::memory_order_acquire)) return EZPZ_OK;
+    std::lock_guard<std::mutex> lock(sys->defer_mu);
+    if (!sys->program_deferred.load()) return EZPZ_OK;
+    Program P;
+    std::vector<unsigned char> blob;
+    int rc = analyze_into(sys->deferred_cs.data(), sys->deferred_cs.size(), sys->counts.n_vars, EZPZ_TEAM_AUTO_LATENCY, *sys, P, blob,
+                          nullptr, nullptr, false, /*keep_comp=*/true);
+    if (rc != EZPZ_OK) return rc;
+    if (sys->device >= 0) {
+        HIP_TRY(hipSetDevice(sys->device));
+        HIP_TRY(hipMalloc(&sys->dev_program, blob.size()));
+        HIP_TRY(hipMemcpy(sys->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        sys->view.base = static_cast<const unsigned char*>(sys->dev_program);
+    }
+    sys->deferred_cs.clear();
+    sys->deferred_cs.shrink_to_fit();
+    sys->program_deferred.store(false, std::memory_order_release);
+    return EZPZ_OK;
+}
+
+extern "C" {
+
 void ezpz_system_destroy(EzpzSystem* sys) {
     if (!sys) return;
     (void)hipSetDevice(sys->device);
@@ -1979,6 +2062,7 @@ void ezpz_system_destroy(EzpzSystem* sys) {
 
 int ezpz_system_info(const EzpzSystem* sys, EzpzSystemInfo* info) {
     if (!sys || !info) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (int rc = ensure_program(const_cast<EzpzSystem*>(sys))) return rc;
     *info = sys->info;
     return EZPZ_OK;
 }
@@ -1997,6 +2081,7 @@ int ezpz_analyze(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, EzpzSyste
 
 int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t* cols) {
     if (!sys || !rows || !cols) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (int rc = ensure_program(const_cast<EzpzSystem*>(sys))) return rc;
     for (uint32_t s = 0; s < sys->counts.zj; ++s) {
         rows[s] = sys->host_slot_row[s];
         cols[s] = sys->host_slot_col[s];
@@ -2008,6 +2093,7 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
                            uint32_t* degenerate_count_out) {
     if (!sys || !x || !r_out || !jv_out) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch == 0) return EZPZ_OK;
+    if (int rc0 = ensure_program(sys)) return rc0;
     std::lock_guard<std::mutex> lock(sys->mu);
     HIP_TRY(hipSetDevice(sys->device));
     const size_t n = sys->counts.n_vars, m = sys->counts.n_rows, zj = sys->counts.zj;
@@ -2042,9 +2128,12 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
     return EZPZ_OK;
 }
 
-int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
-                                   double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
-                                   uint64_t* warn_log_dev, uint32_t warn_cap, void* stream) {
+}  // extern "C"
+
+// (done: the completion word of a one-call launch, system_solve_one; null for every other caller)
+static int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg, double* x_out_dev,
+                                   EzpzStatus* status_dev, uint8_t* unsat_mask_dev, uint64_t* warn_log_dev, uint32_t warn_cap,
+                                   void* stream, const DoneWord& done) {
     if (!sys || (batch && (!x_out_dev || !status_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch && sys->counts.n_vars && !x0_dev) return EZPZ_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(sys->device));
@@ -2075,6 +2164,7 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     a.sys_list = nullptr;
     a.sys_count = nullptr;
     a.resume = nullptr;
+    a.done = done;
     if (sys->rec) {
         const unsigned char* base = static_cast<const unsigned char*>(sys->dev_program);
         a.rec_desc = reinterpret_cast<const uint2*>(base + sys->rec_desc_off);
@@ -2102,6 +2192,15 @@ int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t
     return launch(*sys, a, static_cast<hipStream_t>(stream));
 }
 
+extern "C" {
+
+int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
+                                   double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
+                                   uint64_t* warn_log_dev, uint32_t warn_cap, void* stream) {
+    return solve_batch_device_impl(sys, x0_dev, batch, cfg, x_out_dev, status_dev, unsat_mask_dev, warn_log_dev, warn_cap, stream,
+                                   DoneWord{nullptr, 0, nullptr});
+}
+
 int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out,
                             EzpzStatus* status, uint8_t* unsat_mask, uint64_t* warn_log, uint32_t warn_cap) {
     if (!sys) return EZPZ_ERR_INVALID_ARGUMENT;
@@ -2115,6 +2214,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     const size_t mask_bytes = unsat_mask ? ((batch * std::max<size_t>(C, 1) + 15) & ~size_t(15)) : 0;
     const size_t log_bytes = want_log ? batch * (size_t)warn_cap * sizeof(uint64_t) : 0;
     int rc;
+    call_stamp(CALL_LOCKED);
     if (x_bytes + st_bytes + mask_bytes <= kZeroCopyBytes) {
         // Small call (the solve() case): no DMA at all.  The kernel reads the guesses from, and writes the
         // results to, pinned host memory mapped into the device address space; one launch + one stream sync.
@@ -2127,11 +2227,13 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         uint8_t* hmask = h + x_bytes + st_bytes;
         uint64_t* hlog = reinterpret_cast<uint64_t*>(h + x_bytes + st_bytes + mask_bytes);
         if (n) std::memcpy(hx, x0, batch * n * sizeof(double));
+        call_stamp(CALL_STAGED);
         // on the calling thread's own stream: solve() calls from different threads (on different systems) overlap on
         // the device instead of queueing behind each other on the null stream
         rc = ezpz_system_solve_batch_device(sys, hx, batch, cfg, hx, hst, unsat_mask ? hmask : nullptr,
                                             want_log ? hlog : nullptr, warn_cap, hipStreamPerThread);
         if (rc != EZPZ_OK) return rc;
+        call_stamp(CALL_LAUNCHED);
         // a solve() call is over in tens of microseconds: poll the stream for a while before blocking on it (the
         // blocking wait sleeps on an interrupt and comes back ~10 us late)
         {
@@ -2145,6 +2247,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                 HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
             }
         }
+        call_stamp(CALL_COMPLETE);
         std::memcpy(status, hst, st_bytes);
         if (sys->grid_wgs > 1)
             for (size_t b2 = 0; b2 < batch; ++b2)
@@ -2158,6 +2261,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                 std::memcpy(warn_log + b * warn_cap, hlog + b * warn_cap, cnt * sizeof(uint64_t));
             }
         }
+        call_stamp(CALL_UNPACKED);
         return EZPZ_OK;
     }
     // Registered (page-locked) caller buffers: the batch streams through three slots -- H2D of piece k+1, the kernel
@@ -2268,6 +2372,144 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
 }
 
 }  // extern "C"
+
+
+// ---- one solve() call ------------------------------------------------------------------------------------------------------------
+namespace {
+
+// What one thread's one-call launches on one device go through (grow-only; a thread's call has seen its completion word
+// before it returns, so the buffers are free for its next call).
+struct CallBufs {
+    unsigned char* host = nullptr;  // mapped host memory: [completion word, 64 B][status, 64 B][values out][values in, no BAR]
+    size_t host_cap = 0;
+    double* x0_bar = nullptr;  // fine-grained device memory the host stores the guesses into (large BAR), else null
+    size_t x0_cap = 0;
+    int bar = -1;  // -1 not asked yet, 0 no (the kernel reads the guesses from mapped host memory), 1 yes
+    DevBuf<uint8_t> mask;
+    DevBuf<uint64_t> log;
+    DevBuf<unsigned int> counter;
+    uint64_t seq = 0;
+    ~CallBufs() {
+        if (host) (void)hipHostFree(host);
+        if (x0_bar) (void)hipFree(x0_bar);
+    }
+};
+thread_local CallBufs t_call[16];
+
+bool device_has_large_bar(int device) {
+    static const bool allowed = [] {
+        const char* e = std::getenv("EZPZ_BAR");  // EZPZ_BAR=0: stage the guesses in mapped host memory (A/B runs)
+        return !(e && e[0] == '0');
+    }();
+    int v = 0;
+    if (!allowed || hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return v != 0;
+}
+
+}  // namespace
+
+int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* cfg, double* x_out, EzpzStatus* status,
+                           uint8_t* unsat_mask, uint64_t* warn_log, uint32_t warn_cap) {
+    if (!sys || !status) return EZPZ_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(sys->mu);
+    HIP_TRY(hipSetDevice(sys->device));
+    call_stamp(CALL_LOCKED);
+    const size_t n = sys->counts.n_vars, C = sys->counts.n_cons;
+    if (n && (!x0 || !x_out)) return EZPZ_ERR_INVALID_ARGUMENT;
+    CallBufs& cb = t_call[sys->device & 15];
+    int rc;
+    const size_t x_bytes = (std::max<size_t>(n, 1) * sizeof(double) + 63) & ~size_t(63);
+    if (cb.bar < 0) cb.bar = device_has_large_bar(sys->device) ? 1 : 0;
+    // A short unsatisfied mask / warning log is written straight to mapped host memory (a few byte / word stores across
+    // the link); long ones stay on the device and are fetched when the status says there is something in them.
+    const bool want_log = warn_log && warn_cap;
+    const bool host_mask = C <= 256, host_log = want_log && warn_cap <= 8192;
+    const size_t mask_bytes = host_mask ? 256 : 0, log_bytes = host_log ? (size_t)warn_cap * sizeof(uint64_t) : 0;
+    if (cb.host_cap < 128 + 2 * x_bytes + mask_bytes + log_bytes) {
+        if (cb.host) (void)hipHostFree(cb.host);
+        cb.host = nullptr;
+        cb.host_cap = 0;
+        const size_t want = std::max<size_t>(128 + 3 * x_bytes + 256 + 2 * log_bytes, 64 * 1024);
+        HIP_TRY(hipHostMalloc((void**)&cb.host, want, hipHostMallocMapped));
+        std::memset(cb.host, 0, 128);
+        cb.host_cap = want;
+        cb.seq = 0;
+    }
+    if (cb.bar == 1 && cb.x0_cap < x_bytes) {
+        if (cb.x0_bar) (void)hipFree(cb.x0_bar);
+        cb.x0_bar = nullptr;
+        cb.x0_cap = 0;
+        const size_t want = std::max<size_t>(x_bytes + x_bytes / 2, 64 * 1024);
+        if (hipExtMallocWithFlags((void**)&cb.x0_bar, want, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            cb.x0_bar = nullptr;
+            cb.bar = 0;  // the kernel reads the guesses from mapped host memory instead
+        } else {
+            cb.x0_cap = want;
+        }
+    }
+    if (cb.counter.cap == 0) {
+        if ((rc = cb.counter.ensure(16)) != EZPZ_OK) return rc;
+        HIP_TRY(hipMemset(cb.counter.p, 0, 16 * sizeof(unsigned int)));
+    }
+    if (!host_mask && (rc = cb.mask.ensure(C)) != EZPZ_OK) return rc;
+    if (want_log && !host_log && (rc = cb.log.ensure(warn_cap)) != EZPZ_OK) return rc;
+    volatile uint64_t* word = reinterpret_cast<volatile uint64_t*>(cb.host);
+    EzpzStatus* hst = reinterpret_cast<EzpzStatus*>(cb.host + 64);
+    double* hx_out = reinterpret_cast<double*>(cb.host + 128);
+    double* hx_in = reinterpret_cast<double*>(cb.host + 128 + x_bytes);
+    uint8_t* hmask = cb.host + 128 + 2 * x_bytes;
+    uint64_t* hlog = reinterpret_cast<uint64_t*>(cb.host + 128 + 2 * x_bytes + mask_bytes);
+    double* x_in = cb.bar == 1 ? cb.x0_bar : hx_in;
+    if (n) std::memcpy(x_in, x0, n * sizeof(double));
+    // (the stores above are write-combined when they go through the BAR: drained before the doorbell write of the launch)
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    call_stamp(CALL_STAGED);
+    const uint64_t seq = ++cb.seq;
+    rc = solve_batch_device_impl(sys, x_in, 1, cfg, hx_out, hst, host_mask ? hmask : cb.mask.p,
+                                 !want_log ? nullptr : host_log ? hlog : cb.log.p, warn_cap,
+                                 hipStreamPerThread, DoneWord{const_cast<unsigned long long*>(reinterpret_cast<volatile unsigned long long*>(word)), seq, cb.counter.p});
+    if (rc != EZPZ_OK) return rc;
+    call_stamp(CALL_LAUNCHED);
+    // The completion word first; a launch that never writes it (a shape without the epilogue, a failed kernel) is caught by
+    // the stream's own state, asked every few microseconds once the word is overdue.
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        auto next_query = t0 + std::chrono::microseconds(100);
+        uint32_t spins = 0;
+        while (*word != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 63u) != 0) continue;
+            const auto now = std::chrono::steady_clock::now();
+            if (now < next_query) continue;
+            const hipError_t q = hipStreamQuery(hipStreamPerThread);
+            if (q == hipSuccess) break;  // the stream is idle: the launch is over, word or no word
+            if (q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                return EZPZ_ERR_HIP;
+            }
+            next_query = now + std::chrono::microseconds(now - t0 > std::chrono::milliseconds(2) ? 200 : 5);
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    call_stamp(CALL_COMPLETE);
+    *status = *hst;
+    if (status->iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT && (sys->grid_wgs > 1 || (sys->comp && sys->comp->jit_wgs > 1))) return EZPZ_ERR_HIP;
+    if (n) std::memcpy(x_out, hx_out, n * sizeof(double));
+    const bool fetch_mask = unsat_mask && C && status->n_unsatisfied > 0;
+    const size_t n_log = want_log ? std::min<size_t>(status->n_warnings, warn_cap) : 0;
+    if (fetch_mask && host_mask) std::memcpy(unsat_mask, hmask, C);
+    if (n_log && host_log) std::memcpy(warn_log, hlog, n_log * sizeof(uint64_t));
+    if (fetch_mask && !host_mask) HIP_TRY(hipMemcpyAsync(unsat_mask, cb.mask.p, C, hipMemcpyDeviceToHost, hipStreamPerThread));
+    if (n_log && !host_log)
+        HIP_TRY(hipMemcpyAsync(warn_log, cb.log.p, n_log * sizeof(uint64_t), hipMemcpyDeviceToHost, hipStreamPerThread));
+    if ((fetch_mask && !host_mask) || (n_log && !host_log)) HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+    call_stamp(CALL_UNPACKED);
+    return EZPZ_OK;
+}
 
 extern "C" {
 
@@ -2451,9 +2693,11 @@ int build_freedom(EzpzSystem* sys) {
 int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* mask_dev, double* part_dev,
                    uint32_t* count_dev, hipStream_t stream) {
     auto& F = sys->freedom;
+    int rc = ensure_program(sys);
+    if (rc != EZPZ_OK) return rc;
     const size_t n = sys->counts.n_vars, zj = sys->counts.zj;
     if (n == 0 || sys->counts.n_rows == 0) return EZPZ_ERR_EMPTY_SYSTEM;  // find_dof.rs:43-44
-    int rc = build_freedom(sys);
+    rc = build_freedom(sys);
     if (rc != EZPZ_OK) return rc;
     if ((rc = F.x_int.ensure(batch * n)) != EZPZ_OK) return rc;
     if ((rc = F.jv.ensure(batch * std::max<size_t>(zj, 1))) != EZPZ_OK) return rc;

@@ -59,6 +59,7 @@ int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch
     a.residual_tolerance = L.residual_tolerance;
     a.step_tolerance = L.step_tolerance;
     a.initial_lambda = L.initial_lambda;
+    a.done = L.done;
     a.scratch_row0 = plan.rows_persistent;
     a.scratch_rows = plan.scratch_rows;
     a.red_row0 = plan.rows_persistent + plan.n_waves * plan.scratch_rows;

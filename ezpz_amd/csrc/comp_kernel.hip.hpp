@@ -47,6 +47,7 @@ struct CompArgs {
     double residual_tolerance, step_tolerance, initial_lambda;
     uint32_t scratch_row0, scratch_rows;  // LDS rows: first scratch row, rows per wavefront
     uint32_t red_row0;                    // LDS row of the reduction scratch (2 x 3 x 16 doubles), flag words, warning counters
+    DoneWord done;                        // one-call launches: the completion word (dev_types.hpp)
 };
 
 namespace dev {
@@ -540,6 +541,7 @@ __global__ void __launch_bounds__(512) comp_solve_kernel(const CompArgs a) {
             if (!LIN) *nwarn = 0;
         }
     }
+    publish_done(a.done);
 }
 
 }  // namespace ezpz

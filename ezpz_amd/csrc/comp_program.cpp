@@ -22,9 +22,18 @@ constexpr size_t kMinInstances = 128;     // fewer components than two wavefront
 constexpr size_t kMaxClasses = 32;
 constexpr size_t kMaxClassVars = 24, kMaxClassCons = 48;  // (the warning mask of a chunk is one 64-bit word per lane)
 
+// (views into two arrays shared by all components: a request of 1500 components is analysed on the path of a solve() call)
+struct Span {
+    const uint32_t* b = nullptr;
+    uint32_t n = 0;
+    size_t size() const { return n; }
+    const uint32_t* begin() const { return b; }
+    const uint32_t* end() const { return b + n; }
+    uint32_t operator[](size_t i) const { return b[i]; }
+};
 struct Component {
-    std::vector<uint32_t> verts;  // caller's variable ids, ascending
-    std::vector<uint32_t> cons;   // caller's constraint positions, ascending
+    Span verts;  // caller's variable ids, ascending
+    Span cons;   // caller's constraint positions, ascending
 };
 
 struct ClassLayout {  // what every chunk of a class shares (copied into its CompChunk)
@@ -465,18 +474,31 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
         m_total += K.n_rows;
     }
     std::vector<uint32_t> comp_of(n, NONE);
-    std::vector<Component> comps;
+    uint32_t n_comps = 0;
     for (uint32_t v = 0; v < n; ++v) {  // roots are the smallest member: components come out in order of first variable
         const uint32_t r = find(v);
-        if (comp_of[r] == NONE) {
-            comp_of[r] = (uint32_t)comps.size();
-            comps.emplace_back();
-        }
+        if (comp_of[r] == NONE) comp_of[r] = n_comps++;
         comp_of[v] = comp_of[r];
-        comps[comp_of[v]].verts.push_back(v);
     }
-    if (comps.size() < kMinInstances) COMP_REJECT("%zu components", comps.size());
-    for (uint32_t i = 0; i < C; ++i) comps[comp_of[cs[i].ids[kKinds[cs[i].kind].nz[0][0]]]].cons.push_back(i);
+    if (n_comps < kMinInstances) COMP_REJECT("%u components", n_comps);
+    // members by counting sort: variables and constraints of a component in ascending order
+    std::vector<uint32_t> vert_ptr(n_comps + 1, 0), con_ptr(n_comps + 1, 0), vert_items(n), con_items(C), con_comp(C);
+    for (uint32_t v = 0; v < n; ++v) ++vert_ptr[comp_of[v] + 1];
+    for (uint32_t i = 0; i < C; ++i) {
+        con_comp[i] = comp_of[cs[i].ids[kKinds[cs[i].kind].nz[0][0]]];
+        ++con_ptr[con_comp[i] + 1];
+    }
+    for (uint32_t c = 0; c < n_comps; ++c) vert_ptr[c + 1] += vert_ptr[c], con_ptr[c + 1] += con_ptr[c];
+    {
+        std::vector<uint32_t> vfill(vert_ptr.begin(), vert_ptr.end() - 1), cfill(con_ptr.begin(), con_ptr.end() - 1);
+        for (uint32_t v = 0; v < n; ++v) vert_items[vfill[comp_of[v]]++] = v;
+        for (uint32_t i = 0; i < C; ++i) con_items[cfill[con_comp[i]]++] = i;
+    }
+    std::vector<Component> comps(n_comps);
+    for (uint32_t c = 0; c < n_comps; ++c) {
+        comps[c].verts = Span{vert_items.data() + vert_ptr[c], vert_ptr[c + 1] - vert_ptr[c]};
+        comps[c].cons = Span{con_items.data() + con_ptr[c], con_ptr[c + 1] - con_ptr[c]};
+    }
     for (const Component& c : comps)
         if (c.verts.size() > kMaxClassVars || c.cons.size() > kMaxClassCons)
             COMP_REJECT("a component of %zu variables, %zu constraints", c.verts.size(), c.cons.size());
@@ -485,7 +507,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
     plan.unit_weights = true;
     for (uint32_t i = 0; i < C; ++i)
         if (cs[i].weight != 1.0) plan.unit_weights = false;
-    std::map<std::vector<uint32_t>, uint32_t> class_of_sig;
+    std::vector<std::vector<uint32_t>> class_sig;  // (at most kMaxClasses: compared one by one)
     std::vector<Class> classes;
     std::vector<uint32_t> sig;
     auto local_con = [&](const Component& comp, uint32_t ci, EzpzConstraint& out) {
@@ -518,14 +540,15 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             sig.push_back((uint32_t)(wbits >> 32));
             for (int k = 0; k < 8; ++k) sig.push_back(lc.ids[k]);
         }
-        auto it = class_of_sig.find(sig);
-        if (it == class_of_sig.end()) {
+        size_t k = 0;
+        while (k < class_sig.size() && class_sig[k] != sig) ++k;
+        if (k == class_sig.size()) {
             if (classes.size() >= kMaxClasses) COMP_REJECT("more than %zu classes", kMaxClasses);
-            it = class_of_sig.emplace(sig, (uint32_t)classes.size()).first;
+            class_sig.push_back(sig);
             classes.emplace_back();
             classes.back().rep = ic;
         }
-        classes[it->second].instances.push_back(ic);
+        classes[k].instances.push_back(ic);
     }
 
     // ---- per class: the symbolic phase of the representative, then its records -----------------------------------------------

@@ -125,6 +125,7 @@ struct CompLaunch {
     uint64_t batch;
     uint32_t max_iterations;
     double residual_tolerance, step_tolerance, initial_lambda;
+    DoneWord done;  // one-call launches: the completion word (dev_types.hpp), else null
 };
 int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus,
                 size_t lds_limit, void* stream);

@@ -54,4 +54,15 @@ struct LmResume {
 };
 constexpr uint32_t kNoPass = 0xFFFFFFFFu;
 
+// The completion word of a one-call launch (api.hip: system_solve_one; ezpz_solve is one launch per tier).  After its
+// last store the launch writes `seq` to `flag`, a word of host memory mapped into the device that the calling thread
+// polls: the call returns ~7 us sooner than through the runtime's completion signal (tools/launch_floor.hip:
+// 6.0 us launch-to-flag against 13.4 us launch-to-hipStreamQuery).  `counter` (device memory, zero between launches)
+// counts the workgroups of a launch that has several.  flag == null: an ordinary launch.
+struct DoneWord {
+    unsigned long long* flag;
+    unsigned long long seq;
+    unsigned int* counter;
+};
+
 }  // namespace ezpz

@@ -39,8 +39,9 @@ struct JitArgs {
     struct GridScratch* grid;  // systems too large for one workgroup: one scratch per system in flight (else null)
     uint32_t grid_wgs;         // workgroups that share a system (1 = the ordinary case)
     uint32_t pad;
+    DoneWord done;             // one-call launches: the completion word (dev_types.hpp)
 };
-static_assert(sizeof(JitArgs) == 120, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
+static_assert(sizeof(JitArgs) == 144, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
 
 // One system on several workgroups ("grid team", as in lm_kernel.hip.hpp): every workgroup owns its wavefronts' slots;
 // the reductions of the LM control cross workgroups through this per-system scratch.  Every workgroup publishes its
@@ -592,6 +593,7 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             if (ANY_NONLINEAR) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    publish_done(a.done);
 }
 
 // ---- one LANE per system ------------------------------------------------------------------------------------------------------
@@ -614,8 +616,9 @@ struct LaneArgs {
     uint32_t n_row, n_cons;
     uint64_t batch;
     double residual_tolerance, step_tolerance, initial_lambda;
+    DoneWord done;  // one-call launches: the completion word (dev_types.hpp)
 };
-static_assert(sizeof(LaneArgs) == 88, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
+static_assert(sizeof(LaneArgs) == 112, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
 
 template <class C, bool UNIT_W>
 __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
@@ -764,6 +767,7 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
             have = false;
         }
     }
+    publish_done(a.done);
 }
 
 }  // namespace jit

@@ -260,6 +260,7 @@ struct SolveArgs {
     const uint4* rec_asm_cols;
     const uint4* rec_asm_slots;
     uint32_t rec_asm_kc, rec_asm_ks;
+    DoneWord done;  // one-call launches: the completion word (dev_types.hpp), else null
 };
 
 // a round's descriptor (per wavefront): chunks to load (0 = the wavefront has no item), log2 of the lanes per list, ...
@@ -1840,6 +1841,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
         if constexpr (MODE != MODE_PART) tm.team_sync();
         EZPZ_STAMP(32);
     }
+    publish_done(a.done);
 }
 
 // Evaluation-only kernel (K1): one workgroup per value vector, everything in global memory.

@@ -5,9 +5,26 @@
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #endif
+#include "dev_types.hpp"
 
 namespace ezpz {
 namespace dev {
+
+// The last thing a kernel does when its launch carries a completion word (DoneWord, dev_types.hpp): every thread of the
+// workgroup has issued its stores; one thread per workgroup counts it in, and the last workgroup's release store at
+// system scope publishes everything the launch wrote before the word itself.
+__device__ __forceinline__ void publish_done(const DoneWord& w) {
+    if (!w.flag) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool last = true;
+        if (gridDim.x > 1) {
+            last = __hip_atomic_fetch_add(w.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            if (last) __hip_atomic_store(w.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(w.flag, w.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 constexpr double LM_LAMBDA_INCR = 10.0;  // newton.rs:15
 constexpr double LM_LAMBDA_DECR = 0.1;   // newton.rs:16

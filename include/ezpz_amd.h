@@ -345,6 +345,12 @@ long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_var
  * it (used to time cold solves). */
 void ezpz_cache_clear(void);
 
+/* Diagnostic: per-stage time stamps of the calling thread's ezpz_solve* calls.  While `buf` is set, every stage boundary of
+ * the one-call path appends an (id, CLOCK_MONOTONIC nanoseconds) pair (ids: csrc/call_trace.hpp, CallStage) up to `cap`
+ * words; buf == NULL turns it off.  Returns the number of words written since the previous call
+ * (tools/solve_call_breakdown.py -> profiles/r04_solve_call_breakdown.txt). */
+size_t ezpz_debug_call_trace(uint64_t* buf, size_t cap);
+
 /* ---- textual front end, ezpz/src/textual.rs:43-49 (Problem: FromStr) + executor.rs:40-445 ------------ */
 typedef struct EzpzProblem EzpzProblem; /* opaque: parsed + lowered problem text */
 int ezpz_problem_parse(const char* text, size_t len, EzpzProblem** out, char* errbuf, size_t errcap);
