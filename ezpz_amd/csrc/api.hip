@@ -204,17 +204,21 @@ struct EzpzSystem {
     DevBuf<uint8_t> mask_dev;
     DevBuf<uint64_t> log_dev;
     DevBuf<double> gws_dev;
-    // the three slots of the pipelined host-to-host path (registered caller buffers): device buffers, a pinned status
-    // staging buffer, a stream and an event each
-    struct Slot {
-        DevBuf<double> x;
-        hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
-        ~Slot() {
-            if (stream) (void)hipStreamDestroy(stream);
-            if (done) (void)hipEventDestroy(done);
+    // the pipelined host-to-host path (registered caller buffers): one stream per stage -- copies in, kernels, copies
+    // out -- and a ring of device buffers, each with an event per stage
+    struct Pipe {
+        static constexpr int kSlots = 4;
+        hipStream_t in = nullptr, run = nullptr, out = nullptr;
+        DevBuf<double> x[kSlots];
+        hipEvent_t arrived[kSlots] = {}, solved[kSlots] = {}, left[kSlots] = {};
+        ~Pipe() {
+            for (hipStream_t st : {in, run, out})
+                if (st) (void)hipStreamDestroy(st);
+            for (int k = 0; k < kSlots; ++k)
+                for (hipEvent_t e : {arrived[k], solved[k], left[k]})
+                    if (e) (void)hipEventDestroy(e);
         }
-    } slots[3];
+    } pipe;
     std::vector<uint32_t> host_var_of, host_row_of, host_slot_row, host_slot_col;  // internal -> caller numbering
     // FreedomAnalysis program (built on first use) and its scratch
     struct Freedom {
@@ -2264,67 +2268,96 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         call_stamp(CALL_UNPACKED);
         return EZPZ_OK;
     }
-    // Registered (page-locked) caller buffers: the batch streams through three slots -- H2D of piece k+1, the kernel
-    // of piece k and D2H of piece k-1 overlap, each slot on its own stream with its own device buffers.  On the
-    // MI355X boxes measured (tools/pcie_bw.py) the host link moves 56 GB/s one way but only 28-45 GB/s each way when
-    // both directions run at once, so this buys ~5 % over the pageable path, not the 2x of a full-duplex link.  Only for launch shapes that keep no per-system
-    // device scratch (kernels of one EzpzSystem may then overlap) and calls without mask / warning log.
+    // Registered (page-locked) caller buffers: the batch moves through a three-stage pipeline -- copies in, kernels, copies
+    // out, one stream each, pieces of 8 MB through a ring of four device buffers -- so that the link carries guesses in and
+    // results out at the same time.  What the link gives (tools/pcie_duplex.hip, profiles/r04_pcie_duplex.txt): 56 GB/s one
+    // way alone; both ways at once 46-48 GB/s each when every direction is ONE queue of pieces of >= 8 MB, 39 with 2 MB
+    // pieces, 34-40 with three queues per direction (round 3's shape: three streams each doing in / kernel / out in turn
+    // with 2 MB pieces: 32 GB/s each way).  All kernels of the call run on one stream in order, so every launch shape may
+    // use it (per-system device scratch is never shared by two kernels in flight).  Calls without mask / warning log.
     // (a system that runs lanes across the batch from a few systems on -- EZPZ_TEAM_BATCH_LANES -- has no piece size below
-    // its threshold worth pipelining: it takes the chunked path below, where the lanes kernel is legal)
-    const bool scratch_free = (sys->comp && (sys->comp->interpretable || sys->comp->jit_wgs <= 1)) || sys->lane ||
-                              (sys->lds_ws && sys->grid_wgs == 1);
+    // its threshold worth pipelining: it takes the chunked path below)
     const bool lanes_always = sys->lanes && sys->lanes_min <= std::min<size_t>(batch, 8);
-    if (n && scratch_free && !lanes_always && !unsat_mask && !want_log && host_range_registered(x0, x_bytes) &&
+    if (n && !lanes_always && !unsat_mask && !want_log && host_range_registered(x0, x_bytes) &&
         host_range_registered(x_out, x_bytes)) {
         const size_t row = n * sizeof(double);
-        // pieces of ~2 MB (measured 2 / 4 / 8 / 16 MB: 1.67 / 1.63 / 1.63 / 1.59 M solves/s on the 2000 x 2000 system), at
-        // least 6 of them when the batch allows it (EZPZ_H2H_PIECE_MB overrides, for measurements)
-        static const size_t piece_bytes = [] {
+        static const size_t piece_env = [] {  // (EZPZ_H2H_PIECE_MB: measurements)
             const char* e = std::getenv("EZPZ_H2H_PIECE_MB");
-            return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 2) << 20;
+            return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 0) << 20;
         }();
-        // (big systems: a launch needs several of them to fill the device, whatever their size in bytes)
-        size_t piece = std::max<size_t>(std::min<size_t>(batch, 8), std::min<size_t>(piece_bytes / row, (batch + 5) / 6));
-        // (the lanes-across-the-batch kernel works in one workspace per system object: its launches must not overlap, so
-        // the pieces of this pipeline stay below its threshold and run on the teams, which keep their state in LDS)
+        // Pieces of a sixteenth of the call, between 4 and 16 MB: filling and draining the pipeline costs one piece each
+        // way, and the link moves 2 / 4 / 8 / 16 MB pieces at 33 / 39 / 42 / 43 GB/s each way (2000 x 2000, 16 384 systems).
+        // Big systems at least 8 to a piece (a launch needs several of them to use the device).
+        const size_t piece_bytes = piece_env ? piece_env : std::min<size_t>(16u << 20, std::max<size_t>(4u << 20, x_bytes / 16));
+        size_t piece = std::max<size_t>(std::min<size_t>(batch, 8), std::min<size_t>(piece_bytes / row, (batch + 7) / 8));
+        // (the lanes-across-the-batch kernel is for device-filling calls: the pieces stay below its threshold and run on the
+        // teams, which resume nothing and keep their state in LDS)
         if (sys->lanes && piece >= sys->lanes_min) piece = std::max<size_t>(1, (size_t)sys->lanes_min - 1);
-        // the statuses of the whole call collect in one device buffer and come back in one copy at the end
+        EzpzSystem::Pipe& P = sys->pipe;
+        constexpr int K = EzpzSystem::Pipe::kSlots;
+        if (!P.in) {
+            bool ok = hipStreamCreateWithFlags(&P.in, hipStreamNonBlocking) == hipSuccess &&
+                      hipStreamCreateWithFlags(&P.run, hipStreamNonBlocking) == hipSuccess &&
+                      hipStreamCreateWithFlags(&P.out, hipStreamNonBlocking) == hipSuccess;
+            for (int k = 0; k < K && ok; ++k)
+                ok = hipEventCreateWithFlags(&P.arrived[k], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&P.solved[k], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&P.left[k], hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                return EZPZ_ERR_HIP;
+            }
+        }
+        for (int k = 0; k < K; ++k)  // (the previous call drained its streams: nothing is using the buffers)
+            if ((rc = P.x[k].ensure(piece * n)) != EZPZ_OK) return rc;
+        // the statuses of the whole call collect in one device buffer; they follow each piece out when the caller's status
+        // array is registered too (32 bytes per system: half of the traffic of an 8-variable system), else come back in one
+        // copy at the end
         if ((rc = sys->st_dev.ensure(batch)) != EZPZ_OK) return rc;
+        const bool st_registered = host_range_registered(status, st_bytes);
         // whatever happens after the first copy is enqueued, nothing returns while a copy may still be reading or
         // writing the caller's buffers
         auto drain = [&](int result) {
-            for (auto& sl : sys->slots)
-                if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess) {
+            for (hipStream_t st : {P.in, P.run, P.out})
+                if (hipStreamSynchronize(st) != hipSuccess) {
                     (void)hipGetLastError();
                     if (result == EZPZ_OK) result = EZPZ_ERR_HIP;
                 }
             return result;
         };
+        static const bool h2h_debug = std::getenv("EZPZ_H2H_DEBUG") != nullptr;
+        const auto t_enq0 = std::chrono::steady_clock::now();
         size_t k = 0;
         for (size_t off = 0; off < batch; off += piece, ++k) {
-            EzpzSystem::Slot& sl = sys->slots[k % 3];
+            const int sl = (int)(k % K);
             const size_t nb = std::min(piece, batch - off);
-            if (!sl.stream) {
-                if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return drain(EZPZ_ERR_HIP);
-                }
-            }
-            if (sl.x.cap < piece * n) {  // (re)allocation frees the old buffer: nothing may still be using it
-                if (hipStreamSynchronize(sl.stream) != hipSuccess) return drain(EZPZ_ERR_HIP);
-                if ((rc = sl.x.ensure(piece * n)) != EZPZ_OK) return drain(rc);
-            }
-            // a slot's stream runs its pieces in order, so its device buffer is free again when the copy-out of the
-            // previous piece has been issued ahead of this copy-in on the same stream
-            if (hipMemcpyAsync(sl.x.p, x0 + off * n, nb * row, hipMemcpyHostToDevice, sl.stream) != hipSuccess) return drain(EZPZ_ERR_HIP);
-            rc = ezpz_system_solve_batch_device(sys, sl.x.p, nb, cfg, sl.x.p, sys->st_dev.p + off, nullptr, nullptr, 0, sl.stream);
+            double* xd = P.x[sl].p;
+            // The buffer is free again when the results of the piece that used it last have left.  The HOST waits for that:
+            // it then never runs more than four pieces ahead of the device -- with a hundred pieces queued up front the
+            // runtime's enqueue calls slow down tenfold and the streams' cross-dependencies halve the link's rate (126
+            // pieces of 8 MB: 20 GB/s each way against 42 for 32 pieces).
+            if (k >= (size_t)K && hipEventSynchronize(P.left[sl]) != hipSuccess) return drain(EZPZ_ERR_HIP);
+            if (hipMemcpyAsync(xd, x0 + off * n, nb * row, hipMemcpyHostToDevice, P.in) != hipSuccess ||
+                hipEventRecord(P.arrived[sl], P.in) != hipSuccess || hipStreamWaitEvent(P.run, P.arrived[sl], 0) != hipSuccess)
+                return drain(EZPZ_ERR_HIP);
+            rc = ezpz_system_solve_batch_device(sys, xd, nb, cfg, xd, sys->st_dev.p + off, nullptr, nullptr, 0, P.run);
             if (rc != EZPZ_OK) return drain(rc);
-            if (hipMemcpyAsync(x_out + off * n, sl.x.p, nb * row, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) return drain(EZPZ_ERR_HIP);
+            if (hipEventRecord(P.solved[sl], P.run) != hipSuccess || hipStreamWaitEvent(P.out, P.solved[sl], 0) != hipSuccess ||
+                hipMemcpyAsync(x_out + off * n, xd, nb * row, hipMemcpyDeviceToHost, P.out) != hipSuccess ||
+                (st_registered && hipMemcpyAsync(status + off, sys->st_dev.p + off, nb * sizeof(EzpzStatus), hipMemcpyDeviceToHost, P.out) != hipSuccess) ||
+                hipEventRecord(P.left[sl], P.out) != hipSuccess)
+                return drain(EZPZ_ERR_HIP);
         }
+        const auto t_enq1 = std::chrono::steady_clock::now();
         if ((rc = drain(EZPZ_OK)) != EZPZ_OK) return rc;
-        HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
-        if (sys->comp && sys->comp->jit_wgs > 1)  // a specialised kernel spread over several workgroups: its rendezvous can time out
+        const auto t_enq2 = std::chrono::steady_clock::now();
+        if (!st_registered) HIP_TRY(hipMemcpy(status, sys->st_dev.p, batch * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
+        if (h2h_debug)
+            std::fprintf(stderr, "[ezpz h2h] %zu pieces of %zu systems: enqueue %.0f us, drain %.0f us, statuses %.0f us\n", k, piece,
+                         std::chrono::duration<double, std::micro>(t_enq1 - t_enq0).count(),
+                         std::chrono::duration<double, std::micro>(t_enq2 - t_enq1).count(),
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq2).count());
+        if (sys->grid_wgs > 1 || (sys->comp && sys->comp->jit_wgs > 1))  // a system spread over several workgroups: its rendezvous can time out
             for (size_t b2 = 0; b2 < batch; ++b2)
                 if (status[b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
         return EZPZ_OK;

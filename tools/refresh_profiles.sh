@@ -3,6 +3,8 @@
 # Bench lines carry their own PMC counters (bench.py runs rocprofv3 --pmc child passes); the kernel-trace stats of the
 # same command are filed beside them so that the kernel's average duration can be checked against roofline.kernel_ms.
 out=$1; mkdir -p $out
+# (the interpreter itself after `--`: a python3 shim that exec()s the real one would be an exec hop under the profiler)
+PY=$(python -c 'import os,sys;print(os.path.realpath(sys.executable))')
 python bench.py --steps 20 --warmup 5 > $out/bench_massive.json 2>/dev/null   # the driver's invocation: headline + legs over every BASELINE config
 EZPZ_JIT=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_interpreter.json 2>/dev/null   # (EZPZ_JIT=0: with the on-disk cache a kernel compiled earlier would be picked up)
 EZPZ_JIT=0 EZPZ_COMP=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_listwalk.json 2>/dev/null
@@ -17,14 +19,18 @@ python bench.py --workload massive50000 --batch 64 --steps 20 > $out/bench_ladde
 python bench.py --workload sketch150 --batch 262144 --steps 10 --warmup 2 > $out/bench_sketch_300vars_b262144.json 2>/dev/null
 python bench.py --workload sketch150 --batch 32768 --steps 10 --warmup 2 > $out/bench_sketch_300vars_b32768.json 2>/dev/null   # (below the lanes' batch: the teams' record walk)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- python3 bench.py --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- $PY bench.py --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
 find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b16384_kernel_stats.csv; rm -rf $out/stats_m
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s -- python3 bench.py --workload square --batch 65536 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s -- $PY bench.py --workload square --batch 65536 --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
 find $out/stats_s -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/square_b65536_kernel_stats.csv; rm -rf $out/stats_s
 for w in "mixed 1048576 mixed_1M" "massive50000 64 ladder200k" "sketch150 262144 sketch_300vars_b262144" "sketch150 32768 sketch_300vars_b32768"; do set -- $w
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x -- python3 bench.py --workload $1 --batch $2 --steps 10 --warmup 2 --cpu-seconds 0 --extras 0 --pmc 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x -- $PY bench.py --workload $1 --batch $2 --steps 10 --warmup 2 --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
 find $out/stats_x -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/$3_kernel_stats.csv; rm -rf $out/stats_x; done
 python tools/reference_benches.py > $out/reference_benches.txt 2>/dev/null
+# one solve() call, stage by stage, and the kernels' durations from a kernel trace of the same systems
+python tools/solve_call_breakdown.py > $out/solve_call_breakdown.txt 2>/dev/null
+rocprofv3 --kernel-trace -d $out/scb -o scb --output-format csv -- $PY tools/solve_call_breakdown.py --launch-only > /dev/null 2>&1
+find $out/scb -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/solve_call_breakdown.py --from-trace {} >> $out/solve_call_breakdown.txt; rm -rf $out/scb
 (echo "# python tools/sketch_scaling.py  (one connected sketch of mixed kinds, tests/gen.py:connected_sketch; default = the automatic batch shape: the record walk on 64 / 128 / 512 lanes per system while the state fits the LDS -- team_mode 4 -- and lanes across the batch from 65 536 systems per call)"; python tools/sketch_scaling.py 8 16 25 32 50 75 100 150 250 400 1000 2500 2>&1 | grep npts
 echo "# TEAM=4294967294 (EZPZ_TEAM_AUTO_LISTS: the list-walk shapes batches ran on before the record walk -- one wavefront, a lean 128-lane workgroup, dense phases on top)"; EZPZ_LANES=0 TEAM=4294967294 python tools/sketch_scaling.py 32 50 75 100 150 250 400 1000 2500 2>&1 | grep npts
 echo "# EZPZ_LANES=0 BATCH=32768 (the automatic batch shape on the per-system teams alone)"; EZPZ_LANES=0 BATCH=32768 python tools/sketch_scaling.py 32 50 75 100 150 250 400 2>&1 | grep npts
@@ -38,6 +44,6 @@ echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZP
 (echo "# EZPZ_LANES_STRAGGLERS=0 python tools/lanes_rounds.py 150 262144  (no hand-over of stragglers to the teams)"; EZPZ_LANES_STRAGGLERS=0 python tools/lanes_rounds.py 150 262144 2>&1 | grep cap) >> $out/lanes_rounds.txt
 (echo "# python tools/pcie_bw.py  (host link of the GPU box)"; python tools/pcie_bw.py 2>&1) > $out/pcie_bw.txt
 python tools/ab_microbench.py $out > /dev/null 2>&1
-(echo "# ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/<case>/problem.md  (the reference CLI's protocol, main.rs:86-100; steady state = the 100-run loop alone)"; for c in tiny square arc_radius two_rectangles massive_parallel_system; do echo "## $c"; ./ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/$c/problem.md | grep -E "Problem size|Iterations|Steady"; done) > $out/cli_latency.txt
+(echo "# ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/<case>/problem.md  (the reference CLI's protocol, main.rs:86-100; steady state = the 100-run loop alone)"; for c in tiny square arc_radius two_rectangles massive_parallel_system; do echo "## $c"; ./ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/$c/problem.md | grep -E "Problem size|Iterations|Solved in|i.e.|Steady"; done) > $out/cli_latency.txt
 (echo "# python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_proptests.py -m gpu  (parity fuzz of the connected-sketch shapes and the reference's property tests on the HIP path: sensitivity-aware bar, no exclusions)"; python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_proptests.py -q -m gpu 2>&1 | tail -3) > $out/fuzz_tests.txt
 head -3 $out/massive_b16384_kernel_stats.csv
