@@ -778,7 +778,11 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
         for (size_t k = 0; k < classes.size(); ++k) vg += per_slot(k) * slots_k[k];
         if (T && T <= 16 && vg <= 360 && G <= 256 && (plan.interpretable || G > 1)) {
             std::string& o = plan.jit_source;
-            o = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
+            static const bool peel = [] {  // (A/B runs; see jit_kernel.hip.hpp)
+                const char* e = std::getenv("EZPZ_JIT_PEEL");
+                return e && e[0] == '1';
+            }();
+            o = std::string(peel ? "#define EZPZ_JIT_PEEL 1\n" : "") + "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
             for (size_t k = 0; k < classes.size(); ++k) emit_class(o, k, classes[k]);
             std::string seq;
             uint32_t nslots = 0;
@@ -798,7 +802,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             const int min_waves = env_mw ? std::atoi(env_mw) : (int)std::min<uint64_t>(4, std::max<uint64_t>(1, 512 / (vg + 50)));
             const std::string bounds = std::to_string(T * 64) + (min_waves > 0 ? ", " + std::to_string(min_waves) : "");
             o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve(const ezpz::jit::JitArgs a) {\n";
-            o += "    __shared__ double smem[112];\n";
+            o += "    __shared__ double smem[ezpz::jit::kRedDoubles + 16];\n";
             o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
                  (plan.unit_weights ? "true" : "false") + ">(a, smem);\n}\n";
             align4(blob);
