@@ -228,12 +228,6 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels, 
     hbm = {"achieved": compulsory / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "compulsory_bytes_per_solve": compulsory / B}
     hbm["frac"] = hbm["achieved"] / hbm["peak"]
-    if pmc.get("_state_in_hbm"):
-        # lanes across the batch (batch_kernel.hip.hpp) keep the solver state in global memory by design: for this kernel
-        # SURVEY 8(d)'s BYTES formula IS the traffic model, and the HBM roof is priced with it
-        hbm.update({"achieved": solves_per_launch_iters / t / 1e9, "algorithmic_bytes_per_solve": solves_per_launch_iters / B,
-                    "state": "in HBM (one lane per system): SURVEY 8(d) BYTES per solve"})
-        hbm["frac"] = hbm["achieved"] / hbm["peak"]
     roofs = {"hbm": hbm}
     traffic = None
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -241,6 +235,18 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels, 
         traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         hbm["traffic_over_compulsory"] = traffic / compulsory
         hbm["measured_gbs"] = traffic / t / 1e9
+    if pmc.get("_state_in_hbm"):
+        # lanes across the batch (batch_kernel.hip.hpp) keep the solver state in global memory by design.  SURVEY 8(d)'s BYTES
+        # formula is the MODEL of that traffic (every access priced as if it reached HBM); the roof itself is what the counters
+        # saw -- much of the state is served from L2 / MALL -- whenever they were collected
+        hbm.update({"model_gbs": solves_per_launch_iters / t / 1e9, "model_frac": solves_per_launch_iters / t / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_solve": solves_per_launch_iters / B,
+                    "state": "in HBM (one lane per system); model = SURVEY 8(d) BYTES per solve, roof = measured traffic when counters were collected"})
+        if traffic is not None:
+            hbm["achieved"] = traffic / t / 1e9
+        else:
+            hbm["achieved"] = hbm["model_gbs"]
+        hbm["frac"] = hbm["achieved"] / hbm["peak"]
     cycles = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
     if cycles > 0 and "SQ_LDS_IDX_ACTIVE" in pmc:
         roofs["lds"] = {"achieved": pmc["SQ_LDS_IDX_ACTIVE"], "peak": n_cus * cycles, "unit": "LDS-array cycles per launch",
@@ -305,11 +311,85 @@ class Workload:
                                    system=system, info=system.info(), specialized=spec, x0_host=x0_host, x0=x0,
                                    x_out=torch.empty_like(x0), status=torch.zeros((B, 32), dtype=torch.uint8, device=dev)))
         self.desc = self.parts[0]["desc"] if len(self.parts) == 1 else "mixed: " + " + ".join(p["desc"] for p in self.parts)
+        # the mixed batch is ONE ragged batch, system i of topology i mod 3, through the heterogeneous entry
+        # (ezpz_mixed_solve_device: regrouped by topology inside, one launch per topology on parallel streams, results in
+        # caller order); the per-topology tensors above are filled from its results for the checks (sync_parts)
+        self.mixed = None
+        if len(self.parts) > 1:
+            import numpy as np
+
+            topo = (np.arange(batch) % len(self.parts)).astype(np.uint32)
+            self.mixed = E.MixedBatch([p["system"] for p in self.parts], topo)
+            ragged = np.empty(self.mixed.total)
+            for k, p in enumerate(self.parts):
+                idx = np.nonzero(topo == k)[0]
+                pos = self.mixed.offsets[idx][:, None].astype(np.int64) + np.arange(p["n"])[None, :]
+                ragged[pos] = p["x0_host"]
+                p["sys_idx"] = torch.from_numpy(idx).to(dev)
+                p["pos"] = torch.from_numpy(pos).to(dev)
+            self.x0_ragged_host = ragged
+            self.x0_ragged = torch.from_numpy(ragged).to(dev)
+            self.x_ragged = torch.empty_like(self.x0_ragged)
+            self.status_all = torch.zeros((batch, 32), dtype=torch.uint8, device=dev)
 
     def step(self):
+        if self.mixed is not None:
+            self.mixed.solve_device(self.x0_ragged.data_ptr(), self.x_ragged.data_ptr(), self.status_all.data_ptr(), self.stream.cuda_stream)
+            return
         for p in self.parts:
             p["system"].solve_batch_device(p["x0"].data_ptr(), p["B"], p["x_out"].data_ptr(), p["status"].data_ptr(), 0,
                                            self.stream.cuda_stream)
+
+    def sync_parts(self):
+        """The mixed batch's results, per topology (the checks below read the per-topology tensors)."""
+        if self.mixed is None:
+            return
+        self.torch.cuda.synchronize(self.dev)
+        for p in self.parts:
+            p["x_out"] = self.x_ragged[p["pos"]]
+            p["status"] = self.status_all[p["sys_idx"]]
+
+    def host_to_host_rate(self, reps=4):
+        """SURVEY 8(d)'s solve -- results back on host -- for this workload: the host-pointer entry point on buffers registered
+        once (ezpz_host_register): H2D, kernels and D2H pipelined.  Returns (solves/s, results equal to the device path's)."""
+        import ctypes as C
+
+        import numpy as np
+
+        E = self.E
+        cfg = E.Config()._c()
+        self.sync_parts()
+        if self.mixed is not None:
+            hx, hxo = np.ascontiguousarray(self.x0_ragged_host), np.empty_like(self.x0_ragged_host)
+            hst = np.zeros(self.batch, dtype=E.STATUS_DTYPE)
+            call = lambda: E.lib().ezpz_mixed_solve(self.mixed._h, hx.ctypes.data, C.byref(cfg), hxo.ctypes.data, hst.ctypes.data)
+            want = lambda: self.x_ragged.cpu().numpy()
+            n_sys = self.batch
+        else:
+            p = self.parts[0]
+            n_sys = min(p["B"], 262144)
+            hx, hxo = np.ascontiguousarray(p["x0_host"][:n_sys]), np.empty_like(p["x0_host"][:n_sys])
+            hst = np.zeros(n_sys, dtype=E.STATUS_DTYPE)
+            call = lambda: E.lib().ezpz_system_solve_batch(p["system"]._h, hx.ctypes.data, n_sys, C.byref(cfg), hxo.ctypes.data,
+                                                           hst.ctypes.data, None, None, 0)
+            want = lambda: p["x_out"][:n_sys].cpu().numpy()
+        for a in (hx, hxo, hst):
+            E.host_register(a)
+        try:
+            assert call() == 0 and call() == 0
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                assert call() == 0
+            rate = reps * n_sys / (time.perf_counter() - t0)
+            # (pieces of a pipelined call may run on another kernel of the topology than the device-filling launch -- the teams
+            # below the lanes' threshold: then equal to rounding, not bitwise)
+            ref = want()
+            with np.errstate(invalid="ignore"):
+                rel = float(np.nanmax(np.abs(hxo - ref) / np.maximum(1.0, np.abs(ref)))) if ref.size else 0.0
+            return rate, (True if np.array_equal(hxo, ref, equal_nan=True) else f"to rounding: max relative difference {rel:.2e}")
+        finally:
+            for a in (hx, hxo, hst):
+                E.host_unregister(a)
 
     def _window(self, launches):
         torch = self.torch
@@ -345,6 +425,7 @@ class Workload:
     def statuses(self):
         import numpy as np
 
+        self.sync_parts()
         return np.concatenate([p["status"].cpu().numpy().view(self.E.STATUS_DTYPE).reshape(-1) for p in self.parts])
 
     def oracle_check(self, per_part=16):
@@ -355,6 +436,7 @@ class Workload:
         from oracle import oracle as O
 
         torch = self.torch
+        self.sync_parts()
         err, err_free, it_equal, n_checked, bitwise = 0.0, 0.0, True, 0, True
         for p in self.parts:
             Bp = p["B"]
@@ -375,6 +457,7 @@ class Workload:
     def algorithmic_launch_bytes(self):
         import numpy as np
 
+        self.sync_parts()
         total = 0
         for p in self.parts:
             stp = p["status"].cpu().numpy().view(self.E.STATUS_DTYPE).reshape(-1)
@@ -436,12 +519,24 @@ def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, b
            "class_specialised_kernel": [bool(p["specialized"]) for p in w.parts] if len(w.parts) > 1 else bool(w.parts[0]["specialized"])}
     if rank == 0:
         if args.check:
-            out["oracle_check"] = w.oracle_check(per_part=8)
+            out["oracle_check"] = w.oracle_check(per_part=-(-64 // len(w.parts)))  # >= 64 systems of every leg
             ok = ok and out["oracle_check"]["max_rel_err"] <= 1e-6 and out["oracle_check"]["iterations_equal"]
-        pmc = collect_pmc(args, workload=name, batch=batch, sets=[PMC_SETS[1]]) if (args.pmc and world == 1) else {}
+        if args.extras:
+            try:
+                out["value_host_to_host"], out["host_to_host_results_equal_device_path"] = w.host_to_host_rate()
+            except Exception as exc:  # noqa: BLE001
+                out["value_host_to_host_error"] = repr(exc)[:200]
+        # (the kernel that keeps its state in HBM -- lanes across the batch, sketch150 x 262 144 -- gets its traffic measured too:
+        # its bound is read from the counters, not from the model)
+        sets = [PMC_SETS[1]] + (PMC_SETS[2:] if name.startswith("sketch") and batch >= 65536 else [])
+        pmc = collect_pmc(args, workload=name, batch=batch, sets=sets) if (args.pmc and world == 1) else {}
         r = roofline(w.parts, batch, kernel_ms, w.algorithmic_launch_bytes(), pmc, len(w.parts), n_cus)
         out["roofline"] = {"bound": r["bound"], "frac": r["frac"], "kernel_ms": kernel_ms,
                            "roofs": {k: v["frac"] for k, v in r["roofs"].items()}}
+        if "wave_cycles_waiting_frac" in r["roofs"].get("issue", {}):
+            out["roofline"]["wave_cycles_waiting_frac"] = r["roofs"]["issue"]["wave_cycles_waiting_frac"]
+        if r["roofs"]["hbm"].get("state"):
+            out["roofline"]["hbm_model"] = {k: r["roofs"]["hbm"][k] for k in ("state", "model_gbs", "model_frac", "measured_gbs") if k in r["roofs"]["hbm"]}
         if "roof_violation" in r:
             out["roofline"]["roof_violation"] = r["roof_violation"]
     out["results_ok"] = ok
@@ -458,7 +553,9 @@ def rank0_extras(E, torch, np, args, extras, w, dev, stream):
     value_h2h = None
     import ctypes as C
 
-    hb = min(B, 65536)  # the same systems per call as `value`
+    # pageable buffers first, then the same buffers page-locked once (ezpz_host_register: what a caller that
+    # reuses its buffers does); `value_host_to_host` is the registered rate
+    hb = min(B, 65536)
     hx = np.ascontiguousarray(x0_host[:hb])
     hxo = np.empty_like(hx)
     hst = np.zeros(hb, dtype=E.STATUS_DTYPE)
@@ -469,27 +566,15 @@ def rank0_extras(E, torch, np, args, extras, w, dev, stream):
                                              hst.ctypes.data, None, None, 0)
         assert rc == 0, rc
 
-    def rate(reps):
+    host_call()
+    host_call()
+    th = time.perf_counter()
+    for _ in range(3):
         host_call()
-        host_call()
-        th = time.perf_counter()
-        for _ in range(reps):
-            host_call()
-        return reps * hb / (time.perf_counter() - th)
-
-    # pageable buffers first, then the same buffers page-locked once (ezpz_host_register: what a caller that
-    # reuses its buffers does); `value_host_to_host` is the registered rate
-    extras["host_to_host_pageable_solves_per_s"] = rate(3)
-    E.host_register(hx)
-    E.host_register(hxo)
-    try:
-        value_h2h = rate(8)
-    finally:
-        E.host_unregister(hx)
-        E.host_unregister(hxo)
-    extras["host_to_host_batch"] = hb
-    extras["host_to_host_results_equal_device_path"] = bool(
-        np.array_equal(hxo, x_out[:hb].cpu().numpy()) if len(parts) == 1 else True)
+    extras["host_to_host_pageable_solves_per_s"] = 3 * hb / (time.perf_counter() - th)
+    value_h2h, equal = w.host_to_host_rate(reps=8)
+    extras["host_to_host_batch"] = min(B, 262144)
+    extras["host_to_host_results_equal_device_path"] = equal
     # (2) one system per launch, back to back on the stream: device-side latency of a single solve
     one_x = x0[:1].clone()
     one_o = torch.empty_like(one_x)
@@ -501,19 +586,34 @@ def rank0_extras(E, torch, np, args, extras, w, dev, stream):
     for _ in range(200):
         system.solve_batch_device(one_x.data_ptr(), 1, one_o.data_ptr(), one_s.data_ptr(), 0, stream.cuda_stream)
     torch.cuda.synchronize(dev)
-    extras["single_solve_latency_us"] = (time.perf_counter() - tl) / 200 * 1e6
-    # (2a) one full ezpz_solve() call from host buffers (the reference's solve(): lint + Model::new + LM +
-    # unsatisfied check): warm = topology served from the cache, cold = cache cleared before every call
-    E.solve_records(records, guesses)
+    # (a RATE: launches on one stream overlap their own overheads -- not the latency of a call, which is the next figure)
+    extras["back_to_back_launch_period_us"] = (time.perf_counter() - tl) / 200 * 1e6
+    # (2a) ONE full ezpz_solve() call per iteration from host buffers -- the protocol of the reference's published figure
+    # and of its criterion benchmarks (main.rs:86-100, solver_bench.rs:15-24): lint + Model::new + LM + unsatisfied check.
+    # warm = the request served from the plan cache, cold = ezpz_cache_clear before every call (symbolic phase included).
+    # (the C ABI itself on buffers prepared once: what a host-language caller does)
+    from ezpz_amd._lib import COutcome
+
+    rec_arr = E.stack_records(records)
+    ids = np.arange(n, dtype=np.uint32)
+    gv = np.ascontiguousarray(guesses, dtype=np.float64)
+    out_x, out_un, out_o = np.zeros(n), np.zeros(len(rec_arr) + 1, dtype=np.uint64), COutcome()
+    solve_args = [rec_arr.ctypes.data, len(rec_arr), ids.ctypes.data, gv.ctypes.data, n, C.byref(hcfg), out_x.ctypes.data,
+                  out_un.ctypes.data, None, 0, C.byref(out_o)]
+    one_call = lambda: E.lib().ezpz_solve(*solve_args)
+    for _ in range(300):  # (past the 256 solves after which a topology's specialised kernel takes over)
+        assert one_call() == 0
+    time.sleep(0.5)
     tw = time.perf_counter()
-    for _ in range(50):
-        E.solve_records(records, guesses)
-    extras["full_solve_call_us_warm"] = (time.perf_counter() - tw) / 50 * 1e6
+    for _ in range(200):
+        one_call()
+    extras["full_solve_call_us_warm"] = (time.perf_counter() - tw) / 200 * 1e6
+    extras["full_solve_call_iterations"] = int(out_o.iterations)
     tc = 0.0
     for _ in range(5):
         E.lib().ezpz_cache_clear()
         t_ = time.perf_counter()
-        E.solve_records(records, guesses)
+        one_call()
         tc += time.perf_counter() - t_
     extras["full_solve_call_us_cold"] = tc / 5 * 1e6
     # (2b) FreedomAnalysis (find_dof.rs) of the solved batch, device to device
@@ -614,6 +714,35 @@ def main():
                 value_h2h = rank0_extras(E, torch, np, args, extras, w, dev, stream)
         except Exception as exc:  # noqa: BLE001
             extras["rank0_extras_error"] = repr(exc)[:300]
+        # (2c) N>1: the whole job's batch from rank 0's HOST buffers over every device's own host link (ezpz_multi_solve_batch:
+        # one worker thread and one analysed topology per device, contiguous shards, no collective) -- the only path past
+        # one link.  The other ranks wait at the barrier.
+        if distributed and len(parts) == 1:
+            try:
+                if rank == 0:
+                    mask = (1 << world) - 1 if backend == "nccl" else 1
+                    multi = E.MultiSystem(records, n, device_mask=mask)
+                    if args.specialize:
+                        multi.specialize(wait=True)
+                    mb = world * min(B, 65536)
+                    mx = np.ascontiguousarray(np.tile(x0_host[: min(B, 65536)], (world, 1)))
+                    mxo, mst = np.empty_like(mx), np.zeros(mb, dtype=E.STATUS_DTYPE)
+                    for a_ in (mx, mxo, mst):
+                        E.host_register(a_)
+                    try:
+                        multi.solve_batch(mx, out=(mxo, mst))
+                        tm = time.perf_counter()
+                        for _ in range(4):
+                            multi.solve_batch(mx, out=(mxo, mst))
+                        extras["multi_host_to_host_solves_per_s"] = 4 * mb / (time.perf_counter() - tm)
+                        extras["multi_host_to_host_devices"] = multi.devices()
+                    finally:
+                        for a_ in (mx, mxo, mst):
+                            E.host_unregister(a_)
+                    del multi
+            except Exception as exc:  # noqa: BLE001
+                extras["multi_host_to_host_error"] = repr(exc)[:200]
+            dist.barrier()
         # (3) N>1: whole batch starts and ends on rank 0; one RCCL scatter + one gather around the solve
         if distributed and backend == "nccl" and len(parts) == 1:
             from ezpz_amd.distributed import solve_batch_sharded
@@ -683,8 +812,8 @@ def main():
                 "workload": desc,
                 "value_is": "device-resident guesses -> device-resident results (inputs in HBM when the timed region "
                             "starts); value_host_to_host = the same batch through ezpz_system_solve_batch from / to "
-                            "host buffers registered once with ezpz_host_register (H2D, kernels and D2H pipelined over three "
-                            "streams); extras.host_to_host_pageable_solves_per_s = unregistered (pageable) buffers",
+                            "host buffers registered once with ezpz_host_register (copies in, kernels and copies out pipelined, one "
+                            "stream each); extras.host_to_host_pageable_solves_per_s = unregistered (pageable) buffers",
                 "systems_per_launch_per_gpu": B,
                 "rows": info["n_rows"], "vars": info["n_vars"], "constraints": info["n_constraints"],
                 "nnz_j": info["nnz_j"], "nnz_a": info["nnz_a"], "nnz_l": info["nnz_l"], "levels": info["n_levels"],

@@ -42,6 +42,19 @@ class CSystemInfo(C.Structure):
                 ("program_in_lds", C.c_uint32), ("grid_workgroups", C.c_uint32)]
 
 
+class CLaunchPolicy(C.Structure):
+    _fields_ = [("compute_units", C.c_uint32), ("lanes_min_systems_small", C.c_uint64), ("lanes_min_systems_large", C.c_uint64),
+                ("lanes_large_from_vars", C.c_uint32), ("jit_lane_min_batch", C.c_uint64), ("jit_comp_min_batch", C.c_uint64),
+                ("jit_comp_min_values", C.c_uint64), ("jit_after_launches", C.c_uint32), ("lane_max_vars", C.c_uint32),
+                ("lane_max_constraints", C.c_uint32), ("comp_min_components", C.c_uint32), ("comp_max_component_vars", C.c_uint32),
+                ("comp_max_component_constraints", C.c_uint32), ("comp_max_classes", C.c_uint32), ("rec_min_vars_one_solve", C.c_uint32),
+                ("rec_min_vars_batch", C.c_uint32), ("rec_one_wavefront_max_vars", C.c_uint32), ("rec_max_components", C.c_uint32),
+                ("rec_wide_one_solve_max_vars", C.c_uint32), ("sub_team_max_width", C.c_uint32), ("dense8_max_vars", C.c_uint32),
+                ("zero_copy_max_bytes", C.c_uint64), ("h2h_piece_min_bytes", C.c_uint64), ("h2h_piece_max_bytes", C.c_uint64),
+                ("h2h_pieces_per_call", C.c_uint32), ("one_call_host_mask_max_constraints", C.c_uint32),
+                ("one_call_host_log_max_entries", C.c_uint32)]
+
+
 # every symbol include/ezpz_amd.h declares
 EXPORTS = [
     "ezpz_default_config", "ezpz_device_count", "ezpz_error_string", "ezpz_system_create", "ezpz_system_destroy",
@@ -61,7 +74,9 @@ EXPORTS = [
     "ezpz_specialized_source",
     "ezpz_multi_create", "ezpz_multi_destroy", "ezpz_multi_device_count", "ezpz_multi_device", "ezpz_multi_shard",
     "ezpz_multi_specialize", "ezpz_multi_solve_batch", "ezpz_system_solve_batch_multi",
-    "ezpz_debug_call_trace",
+    "ezpz_debug_call_trace", "ezpz_launch_policy",
+    "ezpz_mixed_create", "ezpz_mixed_destroy", "ezpz_mixed_total_values", "ezpz_mixed_offsets", "ezpz_mixed_solve_device",
+    "ezpz_mixed_solve", "ezpz_system_solve_batch_mixed", "ezpz_multi_solve_batch_mixed",
 ]
 
 _lib = None
@@ -126,6 +141,24 @@ def lib():
     L.ezpz_system_solve_batch_multi.argtypes = [vp, sz, sz, C.c_uint64, vp, sz, C.POINTER(CConfig), vp, vp]
     L.ezpz_resolve_sides.restype = C.c_int
     L.ezpz_resolve_sides.argtypes = [vp, sz, vp, sz]
+    L.ezpz_mixed_create.restype = C.c_int
+    L.ezpz_mixed_create.argtypes = [vp, sz, vp, sz, C.POINTER(vp)]
+    L.ezpz_mixed_destroy.restype = None
+    L.ezpz_mixed_destroy.argtypes = [vp]
+    L.ezpz_mixed_total_values.restype = sz
+    L.ezpz_mixed_total_values.argtypes = [vp]
+    L.ezpz_mixed_offsets.restype = None
+    L.ezpz_mixed_offsets.argtypes = [vp, vp]
+    L.ezpz_mixed_solve_device.restype = C.c_int
+    L.ezpz_mixed_solve_device.argtypes = [vp, vp, C.POINTER(CConfig), vp, vp, vp]
+    L.ezpz_mixed_solve.restype = C.c_int
+    L.ezpz_mixed_solve.argtypes = [vp, vp, C.POINTER(CConfig), vp, vp]
+    L.ezpz_system_solve_batch_mixed.restype = C.c_int
+    L.ezpz_system_solve_batch_mixed.argtypes = [vp, sz, vp, vp, sz, C.POINTER(CConfig), vp, vp]
+    L.ezpz_multi_solve_batch_mixed.restype = C.c_int
+    L.ezpz_multi_solve_batch_mixed.argtypes = [vp, sz, vp, vp, sz, C.POINTER(CConfig), vp, vp]
+    L.ezpz_launch_policy.restype = C.c_int
+    L.ezpz_launch_policy.argtypes = [C.c_int, C.POINTER(CLaunchPolicy)]
     L.ezpz_debug_call_trace.restype = sz
     L.ezpz_debug_call_trace.argtypes = [vp, sz]
     L.ezpz_cache_clear.restype = None

@@ -813,6 +813,78 @@ class MultiSystem:
         return x, st, mask
 
 
+class MixedBatch:
+    """One batch of systems of DIFFERENT topologies (`ezpz_mixed_*`): system b has the topology
+    `systems[topology_of_system[b]]`; x0 / x are RAGGED -- the systems' rows one after the other in batch order,
+    `offsets[b]` = where system b's values start (`offsets[-1]` = the total).  Reusable for any number of solves."""
+
+    def __init__(self, systems, topology_of_system):
+        self.systems = list(systems)  # (kept alive: the handle refers to them)
+        self.topology = np.ascontiguousarray(topology_of_system, dtype=np.uint32)
+        self.batch = len(self.topology)
+        handles = (C.c_void_p * len(self.systems))(*[s._h for s in self.systems])
+        h = C.c_void_p()
+        rc = lib().ezpz_mixed_create(handles, len(self.systems), self.topology.ctypes.data, self.batch, C.byref(h))
+        if rc != 0:
+            raise NonLinearSystemError(rc)
+        self._h = h
+        self.offsets = np.zeros(self.batch + 1, dtype=np.uint64)
+        lib().ezpz_mixed_offsets(self._h, self.offsets.ctypes.data)
+        self.total = int(lib().ezpz_mixed_total_values(self._h))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and lib is not None:
+            lib().ezpz_mixed_destroy(h)
+            self._h = None
+
+    def solve(self, x0: np.ndarray, config: Optional[Config] = None):
+        """x0: flat ragged array of `total` values -> (x flat, status [batch])."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1)
+        assert x0.size == self.total, (x0.size, self.total)
+        cfg = (config or Config())._c()
+        x, st = np.empty_like(x0), np.zeros(self.batch, dtype=STATUS_DTYPE)
+        rc = lib().ezpz_mixed_solve(self._h, x0.ctypes.data, C.byref(cfg), x.ctypes.data, st.ctypes.data)
+        if rc != 0:
+            raise NonLinearSystemError(rc)
+        return x, st
+
+    def solve_device(self, x0_ptr: int, x_out_ptr: int, status_ptr: int, stream: int = 0, config: Optional[Config] = None):
+        """Device pointers (e.g. torch tensors' data_ptr()); only enqueues on `stream`."""
+        cfg = (config or Config())._c()
+        rc = lib().ezpz_mixed_solve_device(self._h, x0_ptr, C.byref(cfg), x_out_ptr, status_ptr, stream)
+        if rc != 0:
+            raise NonLinearSystemError(rc)
+
+
+def solve_batch_mixed(systems, topology_of_system, x0: np.ndarray, config: Optional[Config] = None):
+    """`ezpz_system_solve_batch_mixed`: the one-call form."""
+    topo = np.ascontiguousarray(topology_of_system, dtype=np.uint32)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1)
+    handles = (C.c_void_p * len(systems))(*[s._h for s in systems])
+    cfg = (config or Config())._c()
+    x, st = np.empty_like(x0), np.zeros(len(topo), dtype=STATUS_DTYPE)
+    rc = lib().ezpz_system_solve_batch_mixed(handles, len(systems), topo.ctypes.data, x0.ctypes.data, len(topo), C.byref(cfg),
+                                             x.ctypes.data, st.ctypes.data)
+    if rc != 0:
+        raise NonLinearSystemError(rc)
+    return x, st
+
+
+def solve_batch_mixed_multi(multis, topology_of_system, x0: np.ndarray, config: Optional[Config] = None):
+    """`ezpz_multi_solve_batch_mixed`: the ragged batch sharded over the devices the MultiSystems share."""
+    topo = np.ascontiguousarray(topology_of_system, dtype=np.uint32)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1)
+    handles = (C.c_void_p * len(multis))(*[m._h for m in multis])
+    cfg = (config or Config())._c()
+    x, st = np.empty_like(x0), np.zeros(len(topo), dtype=STATUS_DTYPE)
+    rc = lib().ezpz_multi_solve_batch_mixed(handles, len(multis), topo.ctypes.data, x0.ctypes.data, len(topo), C.byref(cfg),
+                                            x.ctypes.data, st.ctypes.data)
+    if rc != 0:
+        raise NonLinearSystemError(rc)
+    return x, st
+
+
 def solve_batch_multi(records, n_vars: int, x0: np.ndarray, device_mask: int = 0, config: Optional[Config] = None):
     """`ezpz_system_solve_batch_multi`: the one-call form (handles cached by request bytes and mask)."""
     recs = stack_records(records)

@@ -27,6 +27,7 @@
 #include "kinds.hpp"
 #include "lm_kernel.hip.hpp"
 #include "one_call.hpp"
+#include "policy.hpp"
 #include "program.hpp"
 
 using namespace ezpz;
@@ -39,6 +40,7 @@ namespace {
 struct DeviceLimits {
     int cus = 256;                  // compute units
     size_t lds_bytes = 160 * 1024;  // LDS one workgroup may allocate (MI355X: 160 KiB per CU)
+    EzpzLaunchPolicy policy = launch_policy_for(256);  // the thresholds of policy.hpp at this CU count
 };
 const DeviceLimits& device_limits(int device) {
     static const DeviceLimits full_chip;
@@ -53,6 +55,7 @@ const DeviceLimits& device_limits(int device) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) d.cus = v;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
             d.lds_bytes = (size_t)v;
+        d.policy = launch_policy_for(d.cus);
         (void)hipGetLastError();
         cache[device] = d;
         have[device] = true;
@@ -127,7 +130,6 @@ bool host_range_registered(const void* p, size_t bytes) {
     return a >= it->first && a + bytes <= it->first + it->second;
 }
 
-constexpr size_t kZeroCopyBytes = 1 << 20;  // calls moving less than this skip DMA and use mapped host memory
 
 // The staging buffer of the zero-copy path belongs to the calling thread (one per device), not to the system: a
 // solve() on a new topology then does not pay a hipHostMalloc (~200 us) for its first launch, and threads never share
@@ -523,7 +525,11 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         default: return launch_sub<64>(s, args, grid, stream);
         }
     }
-    if (s.grid_wgs > 1) return launch_grid_team(s, args, stream);
+    if (s.grid_wgs > 1) {
+        // (a grid team starts every system from its guesses: its shared warning counter has no resumed value)
+        if (args.resume) return EZPZ_ERR_INVALID_ARGUMENT;
+        return launch_grid_team(s, args, stream);
+    }
     const uint32_t per_cu = s.lds_ws ? (uint32_t)std::max<size_t>(1, s.lim.lds_bytes / std::max<size_t>(s.lds_bytes, 1))
                                      : 2048u / s.block_threads;
     grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)s.lim.cus * std::min<uint32_t>(per_cu, 8) * 2);
@@ -632,7 +638,9 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
     if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
-        if (st == 0 && (args.batch >= 4096 || jit_sync() || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, jit_sync());
+        const EzpzLaunchPolicy& pol = s.lim.policy;
+        if (st == 0 && (args.batch >= pol.jit_lane_min_batch || jit_sync() || s.launches.fetch_add(1) >= pol.jit_after_launches))
+            st = comp_jit_request(s.jit, jit_sync());
         if (st == 2 && lane_jit_launch(s.jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
     }
     if (s.comp) {  // many small components in few classes: one lane per component (comp_kernel.hip.hpp)
@@ -641,8 +649,9 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         if (s.jit) {
             const bool sync = jit_sync();
             int st = comp_jit_state(s.jit);
-            const bool big = args.batch >= 1024 || args.batch * (uint64_t)s.counts.n_vars >= (1ull << 21);
-            if (st == 0 && (big || sync || s.launches.fetch_add(1) >= 256)) st = comp_jit_request(s.jit, sync);
+            const EzpzLaunchPolicy& pol = s.lim.policy;
+            const bool big = args.batch >= pol.jit_comp_min_batch || args.batch * (uint64_t)s.counts.n_vars >= pol.jit_comp_min_values;
+            if (st == 0 && (big || sync || s.launches.fetch_add(1) >= pol.jit_after_launches)) st = comp_jit_request(s.jit, sync);
             if (st == 2) {
                 if (s.comp->jit_wgs <= 1) {
                     if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
@@ -687,6 +696,12 @@ void ezpz_default_config(EzpzConfig* cfg) {
     cfg->residual_tolerance = 1e-8;
     cfg->step_tolerance = 1e-12;
     cfg->initial_lambda = 1e-9;
+}
+
+int ezpz_launch_policy(int compute_units, EzpzLaunchPolicy* out) {
+    if (!out || compute_units < 0) return EZPZ_ERR_INVALID_ARGUMENT;
+    *out = launch_policy_for(compute_units > 0 ? compute_units : 256);
+    return EZPZ_OK;
 }
 
 int ezpz_device_count(void) {
@@ -999,7 +1014,7 @@ static bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32
 // (analyze_into: up to this many components walk records as one partition; EZPZ_REC_MAX_COMPONENTS for A/B runs)
 static const uint32_t kRecMaxComponents = [] {
     const char* e = std::getenv("EZPZ_REC_MAX_COMPONENTS");
-    return e ? (uint32_t)std::atol(e) : 127u;  // (from 128 the component-resident shape may take the system)
+    return e ? (uint32_t)std::atol(e) : launch_policy_for(256).rec_max_components;  // (from 128 the component-resident shape may take the system)
 }();
 struct RecPlan {
     std::vector<uint32_t> desc, chunks;
@@ -1539,7 +1554,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
             const char* e = std::getenv("EZPZ_REC_SMALL");
             return e ? std::atoi(e) : -1;
         }();
-        const int rec_small = rec_small_env >= 0 ? rec_small_env : for_latency ? 24 : 56;
+        const int rec_small = rec_small_env >= 0 ? rec_small_env
+                                                 : (int)(for_latency ? s.lim.policy.rec_min_vars_one_solve : s.lim.policy.rec_min_vars_batch) - 1;
         static const bool rec_on = [] {
             const char* e = std::getenv("EZPZ_REC");
             return !(e && e[0] == '0');
@@ -1760,7 +1776,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         auto shape_for = [&](bool jg, uint32_t& per_cu) {
             const size_t ws_b = ((size_t)rec_ws_base(P.c, jg) + P.c.n_vars + 4) * 8;
             per_cu = (uint32_t)std::max<size_t>(1, s.lim.lds_bytes / (ws_b + 4096));
-            return P.c.n_vars <= 160 ? 64u : std::min(512u, std::max(128u, pow2_ceil(512u / per_cu)));
+            return P.c.n_vars <= s.lim.policy.rec_one_wavefront_max_vars ? 64u : std::min(512u, std::max(128u, pow2_ceil(512u / per_cu)));
         };
         uint32_t per_cu = 1, per_cu_j = 1;
         uint32_t t = shape_for(false, per_cu);
@@ -1808,7 +1824,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         // global memory is a store's acknowledgement, a rendezvous and a trip to L2)
         static const uint32_t wide_one_solve_max = [] {  // (A/B runs: one solve walks wide records up to this many variables)
             const char* e = std::getenv("EZPZ_REC_WIDE_LATENCY");
-            return e ? (uint32_t)std::atol(e) : 3500u;
+            return e ? (uint32_t)std::atol(e) : launch_policy_for(256).rec_wide_one_solve_max_vars;
         }();
         // (one solve of 1600 / 2000 / 3000 / 4000 / 5000 variables: 1.23 -> 1.16, 2.02 -> 1.82, 1.77 -> 1.49, 2.47 -> 2.47, 25.0 -> 26.9 ms)
         if (!s.lds_ws && wide_enabled && (rec_batch || P.c.n_vars <= wide_one_solve_max)) {
@@ -1978,7 +1994,8 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
     // (and up to 600 variables since the teams walk records: 32 768 systems of 100 / 150 / 300 / 500 variables 15.2 / 5.9 / 2.3 / 0.69
     // M solves/s on the lanes, 22.4 / 8.6 / 3.1 / 0.61 on the teams; 65 536: 26.4 / 10.5 / 4.3 / 1.27 against 22.8 / 8.7 / 3.1 / 0.61)
     // (500 variables: 0.91 M on the teams whatever the batch, 0.69 / 1.27 M on the lanes at 32 768 / 65 536)
-    s.lanes_min = batch_lanes ? 1 : 64ull * (n_vars <= 600 ? 4 : 2) * (s.lim.cus ? s.lim.cus : 256);
+    s.lanes_min = batch_lanes ? 1 : n_vars < s.lim.policy.lanes_large_from_vars ? s.lim.policy.lanes_min_systems_small
+                                                                                 : s.lim.policy.lanes_min_systems_large;
     static const bool lanes_enabled = [] {
         const char* e = std::getenv("EZPZ_LANES");
         return !(e && e[0] == '0');
@@ -2060,8 +2077,17 @@ extern "C" {
 
 void ezpz_system_destroy(EzpzSystem* sys) {
     if (!sys) return;
-    (void)hipSetDevice(sys->device);
+    // the system's allocations are freed with its device current; the caller's own current device is put back (a torch
+    // caller on an 8-GPU node must not find itself on device 7 after a handle was collected)
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    const int device = sys->device;
+    if (device >= 0) (void)hipSetDevice(device);
     delete sys;
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
 }
 
 int ezpz_system_info(const EzpzSystem* sys, EzpzSystemInfo* info) {
@@ -2219,7 +2245,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     const size_t log_bytes = want_log ? batch * (size_t)warn_cap * sizeof(uint64_t) : 0;
     int rc;
     call_stamp(CALL_LOCKED);
-    if (x_bytes + st_bytes + mask_bytes <= kZeroCopyBytes) {
+    if (x_bytes + st_bytes + mask_bytes <= sys->lim.policy.zero_copy_max_bytes) {
         // Small call (the solve() case): no DMA at all.  The kernel reads the guesses from, and writes the
         // results to, pinned host memory mapped into the device address space; one launch + one stream sync.
         const size_t total = x_bytes + st_bytes + mask_bytes + log_bytes;
@@ -2288,7 +2314,9 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         // Pieces of a sixteenth of the call, between 4 and 16 MB: filling and draining the pipeline costs one piece each
         // way, and the link moves 2 / 4 / 8 / 16 MB pieces at 33 / 39 / 42 / 43 GB/s each way (2000 x 2000, 16 384 systems).
         // Big systems at least 8 to a piece (a launch needs several of them to use the device).
-        const size_t piece_bytes = piece_env ? piece_env : std::min<size_t>(16u << 20, std::max<size_t>(4u << 20, x_bytes / 16));
+        const EzpzLaunchPolicy& pol = sys->lim.policy;
+        const size_t piece_bytes = piece_env ? piece_env
+                                             : std::min<size_t>(pol.h2h_piece_max_bytes, std::max<size_t>(pol.h2h_piece_min_bytes, x_bytes / pol.h2h_pieces_per_call));
         size_t piece = std::max<size_t>(std::min<size_t>(batch, 8), std::min<size_t>(piece_bytes / row, (batch + 7) / 8));
         // (the lanes-across-the-batch kernel is for device-filling calls: the pieces stay below its threshold and run on the
         // teams, which resume nothing and keep their state in LDS)
@@ -2318,11 +2346,15 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         // whatever happens after the first copy is enqueued, nothing returns while a copy may still be reading or
         // writing the caller's buffers
         auto drain = [&](int result) {
-            for (hipStream_t st : {P.in, P.run, P.out})
-                if (hipStreamSynchronize(st) != hipSuccess) {
+            for (hipStream_t st : {P.in, P.run, P.out}) {
+                hipError_t q;
+                while ((q = hipStreamQuery(st)) == hipErrorNotReady) __builtin_ia32_pause();
+                if (q != hipSuccess) {
                     (void)hipGetLastError();
+                    if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
                     if (result == EZPZ_OK) result = EZPZ_ERR_HIP;
                 }
+            }
             return result;
         };
         static const bool h2h_debug = std::getenv("EZPZ_H2H_DEBUG") != nullptr;
@@ -2336,7 +2368,16 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
             // it then never runs more than four pieces ahead of the device -- with a hundred pieces queued up front the
             // runtime's enqueue calls slow down tenfold and the streams' cross-dependencies halve the link's rate (126
             // pieces of 8 MB: 20 GB/s each way against 42 for 32 pieces).
-            if (k >= (size_t)K && hipEventSynchronize(P.left[sl]) != hipSuccess) return drain(EZPZ_ERR_HIP);
+            // (polled, not hipEventSynchronize: in a process whose runtime waits on interrupts -- torch sets the device up that
+            // way -- every blocking wait wakes ~100 us late, a third of a piece's transfer: 2.7 -> 1.9 M solves/s)
+            if (k >= (size_t)K) {
+                hipError_t q;
+                while ((q = hipEventQuery(P.left[sl])) == hipErrorNotReady) __builtin_ia32_pause();
+                if (q != hipSuccess) {
+                    (void)hipGetLastError();
+                    return drain(EZPZ_ERR_HIP);
+                }
+            }
             if (hipMemcpyAsync(xd, x0 + off * n, nb * row, hipMemcpyHostToDevice, P.in) != hipSuccess ||
                 hipEventRecord(P.arrived[sl], P.in) != hipSuccess || hipStreamWaitEvent(P.run, P.arrived[sl], 0) != hipSuccess)
                 return drain(EZPZ_ERR_HIP);
@@ -2459,7 +2500,8 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
     // A short unsatisfied mask / warning log is written straight to mapped host memory (a few byte / word stores across
     // the link); long ones stay on the device and are fetched when the status says there is something in them.
     const bool want_log = warn_log && warn_cap;
-    const bool host_mask = C <= 256, host_log = want_log && warn_cap <= 8192;
+    const bool host_mask = C <= sys->lim.policy.one_call_host_mask_max_constraints,
+               host_log = want_log && warn_cap <= sys->lim.policy.one_call_host_log_max_entries;
     const size_t mask_bytes = host_mask ? 256 : 0, log_bytes = host_log ? (size_t)warn_cap * sizeof(uint64_t) : 0;
     if (cb.host_cap < 128 + 2 * x_bytes + mask_bytes + log_bytes) {
         if (cb.host) (void)hipHostFree(cb.host);

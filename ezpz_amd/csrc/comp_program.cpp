@@ -1,5 +1,6 @@
 // Component plan (see comp_program.hpp).  Plain C++17, no device code.
 #include "comp_program.hpp"
+#include "policy.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -18,9 +19,11 @@ namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 // What is worth a component plan, and what its 16-bit fields hold.
-constexpr size_t kMinInstances = 128;     // fewer components than two wavefronts' lanes: the other launch shapes serve
-constexpr size_t kMaxClasses = 32;
-constexpr size_t kMaxClassVars = 24, kMaxClassCons = 48;  // (the warning mask of a chunk is one 64-bit word per lane)
+// (policy.hpp: the one table of launch-shape thresholds)
+const EzpzLaunchPolicy kPolicy = launch_policy_for(256);
+const size_t kMinInstances = kPolicy.comp_min_components;  // fewer components than two wavefronts' lanes: the other launch shapes serve
+const size_t kMaxClasses = kPolicy.comp_max_classes;
+const size_t kMaxClassVars = kPolicy.comp_max_component_vars, kMaxClassCons = kPolicy.comp_max_component_constraints;  // (the warning mask of a chunk is one 64-bit word per lane)
 
 // (views into two arrays shared by all components: a request of 1500 components is analysed on the path of a solve() call)
 struct Span {
@@ -836,7 +839,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
 bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LanePlan& plan) {
     plan = LanePlan();
     // what a lane can hold in registers: x, the accepted x, r, r_next, d, the Jacobian values of one iteration, L
-    if (n_cs == 0 || n_vars == 0 || n_vars > 20 || n_cs > 40) return false;
+    if (n_cs == 0 || n_vars == 0 || n_vars > kPolicy.lane_max_vars || n_cs > kPolicy.lane_max_constraints) return false;
     Class cl;
     BuildError be;
     if (!build_program(cs, n_cs, n_vars, cl.Q, be, 1, false)) return false;

@@ -792,7 +792,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
             for (uint32_t ci = call0 + tm.lane + XPRE * 64; ci < call1; ci += tm.stride) ws[o_x + ci] = x0[P.var_of[ci]];
             x_have = q + n_teams < n_sys;
             if (x_have) {
-                const double* x1 = a.x0 + (a.sys_list ? (uint64_t)a.sys_list[q + n_teams] : q + n_teams) * n_row;
+                // (a resumed system continues from the values the lanes kernel left in x_out, like the load above)
+                const double* x1 = (resuming ? a.x_out : a.x0) + (a.sys_list ? (uint64_t)a.sys_list[q + n_teams] : q + n_teams) * n_row;
 #pragma unroll
                 for (uint32_t j = 0; j < XPRE; ++j) {
                     const uint32_t ci = call0 + tm.lane + j * 64;
@@ -805,6 +806,7 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
         const bool grid_team = GRID_OK && grid_wgs > 1;
         if (grid_team) {
             // shared by the system's workgroups: zeroed by the host / by workgroup 0 two systems ago (see write-back)
+            // (grid teams never resume a system: api.hip, launch_list_walk, passes `resume` to one-workgroup shapes only)
             nwarn = &tm.grid->nwarn[sys_parity];
         } else if (tlane == 0) {
             *nwarn = resuming ? (int)a.resume[q].nwarn : 0;

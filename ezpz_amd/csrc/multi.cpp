@@ -9,10 +9,14 @@
 // is host code on the C ABI of api.hip; there is no numeric work in this file.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -32,7 +36,54 @@ struct Job {
     EzpzStatus* status = nullptr;
     uint8_t* unsat_mask = nullptr;
     int specialize = -1;  // >= 0: ezpz_system_specialize(sys, specialize) instead of a solve
+    std::function<int(EzpzSystem*)> fn;  // anything else that must run on the device's own thread (mixed batches)
 };
+
+// The worker of a device runs on the CPUs of the device's NUMA node (an 8-GPU node has two sockets: pageable copies are
+// staged by the calling thread, and a pipeline's enqueue calls ring the device's doorbells -- both across the socket link
+// for half the devices otherwise).  Best effort: /sys/bus/pci/devices/<bdf>/numa_node and that node's cpulist; a missing
+// file, node -1 (one socket) or a failing sched_setaffinity leave the thread where the scheduler puts it.
+void pin_to_device_node(int device) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("EZPZ_MULTI_PIN");  // EZPZ_MULTI_PIN=0: no affinity (A/B runs)
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled) return;
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (char* c = bdf; *c; ++c)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[128];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE* f = std::fopen(path, "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node < 0) return;
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int a = 0, b = 0, any = 0;
+    for (;;) {  // "0-31,64-95"
+        if (std::fscanf(f, "%d", &a) != 1) break;
+        b = a;
+        int ch = std::fgetc(f);
+        if (ch == '-') {
+            if (std::fscanf(f, "%d", &b) != 1) break;
+            ch = std::fgetc(f);
+        }
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET(c, &set), any = 1;
+        if (ch != ',') break;
+    }
+    std::fclose(f);
+    if (any) (void)sched_setaffinity(0, sizeof(set), &set);
+}
 
 // A device's worker: its thread keeps the device current, owns the EzpzSystem and runs one job at a time.
 struct Worker {
@@ -47,14 +98,22 @@ struct Worker {
 
     void run() {
         (void)hipSetDevice(device);
+        pin_to_device_node(device);
         std::unique_lock<std::mutex> lock(mu);
         for (;;) {
             cv.wait(lock, [&] { return has_job || quit; });
-            if (quit) return;
+            if (quit) {
+                // the system goes where its device is current: the thread that destroys the handle keeps its own device
+                if (sys) ezpz_system_destroy(sys);
+                sys = nullptr;
+                return;
+            }
             const Job j = job;
             lock.unlock();
             int r;
-            if (j.specialize >= 0)
+            if (j.fn)
+                r = j.fn(sys);
+            else if (j.specialize >= 0)
                 r = ezpz_system_specialize(sys, j.specialize);
             else
                 r = ezpz_system_solve_batch(sys, j.x0, j.batch, j.cfg, j.x_out, j.status, j.unsat_mask, nullptr, 0);
@@ -94,7 +153,7 @@ struct EzpzMultiSystem {
                 w->cv.notify_all();
             }
             if (w->thread.joinable()) w->thread.join();
-            if (w->sys) ezpz_system_destroy(w->sys);
+            if (w->sys) ezpz_system_destroy(w->sys);  // (a worker whose thread never started: ezpz_system_destroy restores the caller's device)
         }
     }
 };
@@ -258,6 +317,57 @@ int ezpz_system_solve_batch_multi(const EzpzConstraint* cs, size_t n_cs, size_t 
         while (g_multi.size() > kMultiMax) g_multi.pop_back();
     }
     return ezpz_multi_solve_batch(multi.get(), x0, batch, cfg, x_out, status, nullptr);
+}
+
+int ezpz_multi_solve_batch_mixed(EzpzMultiSystem* const* multis, size_t n_multis, const uint32_t* topology_of_system, const double* x0,
+                                 size_t batch, const EzpzConfig* cfg, double* x_out, EzpzStatus* status) {
+    if (batch == 0) return EZPZ_OK;
+    if (!multis || !n_multis || !topology_of_system || !status) return EZPZ_ERR_INVALID_ARGUMENT;
+    for (size_t t = 0; t < n_multis; ++t) {
+        if (!multis[t] || multis[t]->workers.size() != multis[0]->workers.size()) return EZPZ_ERR_INVALID_ARGUMENT;
+        for (size_t g = 0; g < multis[0]->workers.size(); ++g)
+            if (multis[t]->workers[g]->device != multis[0]->workers[g]->device) return EZPZ_ERR_INVALID_ARGUMENT;
+    }
+    // every handle serves one batch call at a time; locked in address order (two mixed calls over the same handles in
+    // another order must not deadlock)
+    std::vector<EzpzMultiSystem*> order(multis, multis + n_multis);
+    std::sort(order.begin(), order.end());
+    order.erase(std::unique(order.begin(), order.end()), order.end());
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (EzpzMultiSystem* m : order) locks.emplace_back(m->call_mu);
+    // row offsets of the ragged batch (system b: n_vars of its topology)
+    std::vector<uint64_t> off(batch + 1);
+    uint64_t total = 0;
+    for (size_t b = 0; b < batch; ++b) {
+        if (topology_of_system[b] >= n_multis) return EZPZ_ERR_INVALID_ARGUMENT;
+        off[b] = total;
+        total += multis[topology_of_system[b]]->n_vars;
+    }
+    off[batch] = total;
+    if (total && (!x0 || !x_out)) return EZPZ_ERR_INVALID_ARGUMENT;
+    EzpzMultiSystem* lead = multis[0];
+    const size_t G = lead->workers.size();
+    std::vector<size_t> posted;
+    for (size_t g = 0; g < G; ++g) {
+        size_t first, count;
+        ezpz_multi_shard(lead, batch, (int)g, &first, &count);
+        if (!count) continue;
+        Job j;
+        j.fn = [=](EzpzSystem*) {  // on device g's worker thread: this device's systems of every topology, this shard of the batch
+            std::vector<EzpzSystem*> handles(n_multis);
+            for (size_t t = 0; t < n_multis; ++t) handles[t] = multis[t]->workers[g]->sys;
+            return ezpz_system_solve_batch_mixed(handles.data(), n_multis, topology_of_system + first, x0 ? x0 + off[first] : nullptr, count,
+                                                 cfg, x_out ? x_out + off[first] : nullptr, status + first);
+        };
+        lead->workers[g]->post(j);
+        posted.push_back(g);
+    }
+    int rc = EZPZ_OK;
+    for (size_t g : posted) {
+        const int r = lead->workers[g]->wait();
+        if (rc == EZPZ_OK) rc = r;
+    }
+    return rc;
 }
 
 void ezpz_multi_cache_clear(void) {

@@ -292,7 +292,10 @@ int ezpz_solve_batch(const EzpzConstraint* reqs, size_t n_reqs, size_t n_vars, c
  * idle.  One host worker thread and one analysed topology (an EzpzSystem) per device; every shard moves over its own
  * device's host link, straight between the caller's buffers and that device -- no peer copies, no collective -- through
  * the single-device path of ezpz_system_solve_batch (registered caller buffers, ezpz_host_register, are pipelined on
- * every device at once).  Results are those of ezpz_system_solve_batch on the whole batch, bit for bit.
+ * every device at once).  Results are those of ezpz_system_solve_batch on each shard: a kernel is chosen by the size of the
+ * call it serves (lanes across the batch from 64 x 4 x CUs systems, run-time compilation from 1024), so a shard may run on
+ * another kernel of its topology than the whole batch would on one device -- bit-identical for component-resident block
+ * systems, equal to rounding (and in iteration counts) for connected sketches.
  * `cs` is one side-resolved tier as for ezpz_system_create.  A handle serves one batch call at a time (calls from
  * several threads queue); ezpz_multi_specialize is ezpz_system_specialize on every device (the smallest state is returned).
  * ezpz_multi_shard tells which systems device index `index` takes of a batch.
@@ -310,6 +313,34 @@ int ezpz_multi_solve_batch(EzpzMultiSystem* multi, const double* x0, size_t batc
                            EzpzStatus* status, uint8_t* unsat_mask);
 int ezpz_system_solve_batch_multi(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint64_t device_mask,
                                   const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out, EzpzStatus* status);
+
+/* ---- one batch of systems of DIFFERENT topologies (new; SURVEY.md 8b last row) -------------------------------------------
+ * The reference's callers loop over arbitrary systems, one solve() after the other (ezpz-cli/src/main.rs:96-98,
+ * ezpz-wasm/src/lib.rs:96); this is that loop as one call.  System b of the batch has the topology
+ * handles[topology_of_system[b]] (side-resolved tiers, all on the calling thread's current device); the batch is RAGGED:
+ * x0 / x_out hold the systems' rows one after the other in batch order, system b's n_vars(b) values at
+ * x_offset[b] = sum of n_vars over the systems before it (ezpz_mixed_offsets gives the batch + 1 offsets,
+ * ezpz_mixed_total_values their last entry).  Inside, the batch is regrouped by topology -- each topology's rows gathered
+ * into one block, solved by that topology's kernels on a stream of its own, scattered back -- and every result is the one
+ * ezpz_system_solve_batch gives for that system's topology, bit for bit, in caller order.
+ * An EzpzMixedBatch is the grouping of one (handles, topology_of_system) pair, reusable for any number of solves (one at
+ * a time; the handles must outlive it); the _device form takes device pointers and only enqueues on `stream`;
+ * ezpz_system_solve_batch_mixed is create + solve + destroy in one call.  ezpz_multi_solve_batch_mixed shards the
+ * batch contiguously (by systems) over the devices the EzpzMultiSystems share -- multis[t] is topology t on every device
+ * of one mask -- each device running its shard through the single-device path over its own host link. */
+typedef struct EzpzMixedBatch EzpzMixedBatch;
+int ezpz_mixed_create(EzpzSystem* const* handles, size_t n_handles, const uint32_t* topology_of_system, size_t batch,
+                      EzpzMixedBatch** out);
+void ezpz_mixed_destroy(EzpzMixedBatch* mixed);
+size_t ezpz_mixed_total_values(const EzpzMixedBatch* mixed);
+void ezpz_mixed_offsets(const EzpzMixedBatch* mixed, uint64_t* x_offset /* batch + 1 */);
+int ezpz_mixed_solve_device(EzpzMixedBatch* mixed, const double* x0_dev, const EzpzConfig* cfg, double* x_out_dev,
+                            EzpzStatus* status_dev, void* stream);
+int ezpz_mixed_solve(EzpzMixedBatch* mixed, const double* x0, const EzpzConfig* cfg, double* x_out, EzpzStatus* status);
+int ezpz_system_solve_batch_mixed(EzpzSystem* const* handles, size_t n_handles, const uint32_t* topology_of_system,
+                                  const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out, EzpzStatus* status);
+int ezpz_multi_solve_batch_mixed(EzpzMultiSystem* const* multis, size_t n_multis, const uint32_t* topology_of_system,
+                                 const double* x0, size_t batch, const EzpzConfig* cfg, double* x_out, EzpzStatus* status);
 
 /* Constraint::set_from_initial_values (ezpz/src/constraints.rs:146-193) over a request list, in place: every
  * LineTangentToCircle / CircleTangentToCircle whose side is EZPZ_SIDE_UNDEFINED gets the side the values imply
@@ -344,6 +375,31 @@ long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_var
  * repeated solves of one problem (ezpz-cli's 100-run loop, main.rs:96-98) skip the symbolic phase.  This drops
  * it (used to time cold solves). */
 void ezpz_cache_clear(void);
+
+/* The launch-shape thresholds (csrc/policy.hpp has each number's measurement): what decides which kernel serves a call,
+ * for a device of `compute_units` CUs.  "systems per call that fill the device" scale with the CU count; what belongs to
+ * one workgroup or one CU's LDS does not.  ezpz_launch_policy(0, ...) = the full 256-CU MI355X. */
+typedef struct EzpzLaunchPolicy {
+    uint32_t compute_units;
+    /* scaled by the CU count */
+    uint64_t lanes_min_systems_small;  /* systems per call from which a connected sketch runs one lane per system (64 x 4 x CUs) */
+    uint64_t lanes_min_systems_large;  /* ... a sketch of >= lanes_large_from_vars variables (64 x 2 x CUs) */
+    uint32_t lanes_large_from_vars;
+    uint64_t jit_lane_min_batch;       /* a call this large starts the run-time compilation at once: one lane per system (16 x CUs) */
+    uint64_t jit_comp_min_batch;       /* ... component-resident block systems (4 x CUs) */
+    uint64_t jit_comp_min_values;      /* ... or this many variables in the call (8192 x CUs) */
+    /* not scaled */
+    uint32_t jit_after_launches;       /* smaller calls earn the compilation by repetition */
+    uint32_t lane_max_vars, lane_max_constraints;
+    uint32_t comp_min_components, comp_max_component_vars, comp_max_component_constraints, comp_max_classes;
+    uint32_t rec_min_vars_one_solve, rec_min_vars_batch, rec_one_wavefront_max_vars, rec_max_components;
+    uint32_t rec_wide_one_solve_max_vars;
+    uint32_t sub_team_max_width, dense8_max_vars;
+    uint64_t zero_copy_max_bytes, h2h_piece_min_bytes, h2h_piece_max_bytes;
+    uint32_t h2h_pieces_per_call;
+    uint32_t one_call_host_mask_max_constraints, one_call_host_log_max_entries;
+} EzpzLaunchPolicy;
+int ezpz_launch_policy(int compute_units, EzpzLaunchPolicy* out);
 
 /* Diagnostic: per-stage time stamps of the calling thread's ezpz_solve* calls.  While `buf` is set, every stage boundary of
  * the one-call path appends an (id, CLOCK_MONOTONIC nanoseconds) pair (ids: csrc/call_trace.hpp, CallStage) up to `cap`

@@ -8,18 +8,58 @@ when every start coordinate is moved by one ulp.  So the bar for a system is mea
 
     coordinates   |x - x_oracle| <= max(1e-6, 20 x the largest difference among the oracle's own answers from the
                   start and from K copies of it with every coordinate moved by +-1 ulp), relative to max(1, |x_oracle|)
+                  -- and never above 1e-4, the tolerance of the reference's own tests (`assert_nearly_eq`,
+                  ezpz/src/tests.rs:1167-1171, with EPSILON = 1e-4, ezpz/src/lib.rs:43): a measured bar may widen 1e-6, it
+                  cannot widen the reference's.  A system whose ORACLE answers already differ among themselves by more
+                  than 1e-4 / 20 under those one-ulp moves (five of the ~1200 fuzz systems: long bands and combs held by
+                  lambda alone) has no coordinates the reference itself could reproduce to its tolerance; it is not
+                  excused but judged on what remains well defined -- its answer must satisfy the constraints as well as
+                  the oracle's runs do (max |r| <= 10 x the worst of theirs, floor 1e-8 = residual_tolerance; the same
+                  constraints unsatisfied at EPSILON) on top of the iteration and convergence checks, and still lie within
+                  20 x the oracle's own spread -- and is counted separately in the log ("beyond the ceiling")
     iterations    equal to the oracle's, or inside the range of counts those K + 1 oracle runs produce (the counts of a
                   chaotic path are samples -- comb 51 of the graph fuzz gives 18, 20, 22, 24, 28, 32 ... 50 over 96
                   perturbations -- so K grows 8 -> 32 -> 96 before a count is declared outside)
     converged     among the flags those runs produce
 
 and every system of a test is checked -- none is excluded.  The K extra oracle runs are only made for the systems that
-miss the plain bar (1e-6, equal iterations), which keeps the tests fast."""
+miss the plain bar (1e-6, equal iterations), which keeps the tests fast.  Every call appends one line to
+gpurun_out/parity_bar.txt (when that directory exists): what was checked, how many systems needed the measured bar, the
+largest error among them and the widest bar granted -- profiles/r04_parity_bar.txt is that file from the round's GPU run."""
+import os
+
 import numpy as np
 
 from oracle import oracle as O
 
 K_PERTURBED = 8
+BAR_CEILING = 1e-4  # the reference's own test tolerance: the measured bar never exceeds it
+_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_bar.txt")
+
+
+def _log(what, total, needed, worst_err, widest_bar, iteration_exceptions, beyond):
+    if os.path.isdir(os.path.dirname(_LOG)):
+        with open(_LOG, "a") as f:
+            f.write(f"{what!r} | systems {total} | measured bar needed {needed} | largest error among them {worst_err:.3e} | "
+                    f"widest bar granted {widest_bar:.3e} | iteration counts inside the oracle's range only {iteration_exceptions} | "
+                    f"beyond the ceiling (oracle spread > {BAR_CEILING / 20:.0e}: judged by residual) {beyond}\n")
+
+
+def residual_inf(recs, x):
+    """max |unweighted residual| of the constraints at x and the set of constraints unsatisfied at EPSILON (lib.rs:305-327)."""
+    import ctypes as C
+    a, L = O.stack(recs), O.lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    r, deg = np.zeros(3), C.c_int(0)
+    worst, unsat = 0.0, set()
+    for i in range(len(a)):
+        rec = a[i:i + 1]
+        L.orc_residual(rec.ctypes.data, x.ctypes.data, r.ctypes.data, C.byref(deg))
+        m = float(np.max(np.abs(r[: L.orc_residual_dim(rec.ctypes.data)])))
+        worst = max(worst, m)
+        if not m < 1e-4:
+            unsat.add(i)
+    return worst, unsat
 
 
 def perturbed_starts(x0_row, k=K_PERTURBED, seed=0):
@@ -32,16 +72,17 @@ def perturbed_starts(x0_row, k=K_PERTURBED, seed=0):
     return np.stack(out[:k])
 
 
-def oracle_spread(recs, x0_row, cfg=None, linsolve=O.LINSOLVE_SPARSE, k=K_PERTURBED):
+def oracle_spread(recs, x0_row, cfg=None, linsolve=O.LINSOLVE_SPARSE, k=K_PERTURBED, answers=False):
     """(iteration counts, converged flags, largest relative difference of the answers) over the oracle's runs from the
-    start and from its k one-ulp perturbations."""
+    start and from its k one-ulp perturbations (answers=True: and the answers themselves)."""
     starts = np.concatenate([x0_row[None, :], perturbed_starts(x0_row, k)])
     rc, xo, it, conv, nun = O.solve_batch(recs, starts, cfg, linsolve=linsolve)
     assert rc == 0
     with np.errstate(invalid="ignore"):
         diff = np.abs(xo[1:] - xo[0]) / np.maximum(1.0, np.abs(xo[0]))
     spread = float(np.nanmax(diff)) if np.any(~np.isnan(diff)) else 0.0
-    return set(int(v) for v in it), set(bool(v) for v in conv), spread
+    out = (set(int(v) for v in it), set(bool(v) for v in conv), spread)
+    return out + (xo,) if answers else out
 
 
 def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, linsolve=O.LINSOLVE_SPARSE, rel=1e-6,
@@ -63,17 +104,32 @@ def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, li
     plain = (err <= rel) & (np.asarray(converged).astype(bool) == np.asarray(conv).astype(bool))
     if check_iterations:
         plain &= np.asarray(iterations).astype(np.int64) == np.asarray(it).astype(np.int64)
-    needed = 0
+    needed = beyond = 0
+    worst_err = widest_bar = 0.0
+    iteration_exceptions = 0
     for b in np.nonzero(~plain)[0]:
         needed += 1
         for k in (K_PERTURBED, 32, 96):
-            its, convs, spread = oracle_spread(recs, x0[b], cfg, linsolve, k)
+            its, convs, spread, answers = oracle_spread(recs, x0[b], cfg, linsolve, k, answers=True)
+            over = 20.0 * spread > BAR_CEILING  # the oracle's own answers are not reproducible to the reference's tolerance
+            bar = 20.0 * spread if over else max(rel, 20.0 * spread)
             inside = (not check_iterations or min(its) <= int(iterations[b]) <= max(its)) and bool(converged[b]) in convs and \
-                err[b] <= max(rel, 20.0 * spread)
+                err[b] <= bar
             if inside:
                 break
+        iteration_exceptions += int(check_iterations and int(iterations[b]) != int(np.asarray(it)[b]))
         if check_iterations:
             assert min(its) <= int(iterations[b]) <= max(its), (what, int(b), int(iterations[b]), sorted(its))
         assert bool(converged[b]) in convs, (what, int(b), bool(converged[b]), convs)
-        assert err[b] <= max(rel, 20.0 * spread), (what, int(b), float(err[b]), spread)
+        assert err[b] <= bar, (what, int(b), float(err[b]), spread, bar)
+        if over:  # judged by what is still well defined: the quality of the answer as a solution of the constraints
+            beyond += 1
+            r_mine, unsat_mine = residual_inf(recs, x[b])
+            theirs = [residual_inf(recs, a) for a in answers if not np.any(np.isnan(a))]
+            r_theirs = max([r for r, _ in theirs] + [1e-8])
+            assert r_mine <= 10.0 * r_theirs, (what, int(b), "residual", r_mine, r_theirs)
+            assert any(unsat_mine == u for _, u in theirs), (what, int(b), "unsatisfied", sorted(unsat_mine))
+        else:
+            worst_err, widest_bar = max(worst_err, float(err[b])), max(widest_bar, bar)
+    _log(what, len(x), needed, worst_err, widest_bar, iteration_exceptions, beyond)
     return needed

@@ -28,6 +28,47 @@ def test_library_exports_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_launch_policy_table_and_its_scaling():
+    """csrc/policy.hpp: the one table of launch-shape thresholds.  The 256-CU values are the measured ones; the
+    device-filling ones scale with the CU count (a CPX partition of 32 CUs, a 64-CU DPX-like mask), the per-workgroup ones
+    do not; and the symbolic phase obeys them (a 20-variable system gets a lane plan, a 21-variable one does not)."""
+    from ezpz_amd._lib import CLaunchPolicy
+
+    def policy(cus):
+        p = CLaunchPolicy()
+        assert E.lib().ezpz_launch_policy(cus, C.byref(p)) == 0
+        return p
+
+    full = policy(256)
+    assert (full.lanes_min_systems_small, full.lanes_min_systems_large, full.lanes_large_from_vars) == (65536, 32768, 601)
+    assert (full.jit_lane_min_batch, full.jit_comp_min_batch, full.jit_comp_min_values, full.jit_after_launches) == (4096, 1024, 1 << 21, 256)
+    assert (full.rec_min_vars_one_solve, full.rec_min_vars_batch, full.rec_one_wavefront_max_vars, full.rec_max_components) == (25, 57, 160, 127)
+    assert (full.lane_max_vars, full.lane_max_constraints, full.comp_min_components) == (20, 40, 128)
+    assert (full.zero_copy_max_bytes, full.h2h_piece_min_bytes, full.h2h_piece_max_bytes, full.h2h_pieces_per_call) == (1 << 20, 4 << 20, 16 << 20, 16)
+    zero = policy(0)  # 0 = the full chip
+    assert all(getattr(zero, f) == getattr(full, f) for f, _ in CLaunchPolicy._fields_)
+    for cus in (32, 64, 128, 304):
+        p = policy(cus)
+        assert p.compute_units == cus
+        for f in ("lanes_min_systems_small", "lanes_min_systems_large", "jit_lane_min_batch", "jit_comp_min_batch", "jit_comp_min_values"):
+            assert getattr(p, f) * 256 == getattr(full, f) * cus, (f, cus)
+        for f, _ in CLaunchPolicy._fields_:
+            if not f.startswith(("lanes_min", "jit_lane_min", "jit_comp_min", "compute_units")):
+                assert getattr(p, f) == getattr(full, f), (f, cus)
+    assert E.lib().ezpz_launch_policy(-1, C.byref(CLaunchPolicy())) == -103
+    # the symbolic phase obeys the table: one lane per system up to lane_max_vars variables
+    def chain(npts):
+        cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
+        for i in range(1, npts):
+            cons.append(O.distance((2 * i, 2 * i + 1), (2 * i - 2, 2 * i - 1), 1.0))
+            cons.append(O.vertical((2 * i, 2 * i + 1), (2 * i - 2, 2 * i - 1)))
+        return O.stack(cons), 2 * npts
+    recs, n = chain(full.lane_max_vars // 2)
+    assert "ezpz_jit_lane" in E.specialized_source(recs, n)
+    recs, n = chain(full.lane_max_vars // 2 + 1)
+    assert "ezpz_jit_lane" not in E.specialized_source(recs, n)
+
+
 def test_struct_layouts_match_the_header():
     from ezpz_amd._lib import CConfig, COutcome, CSystemInfo, CWarning
 

@@ -83,6 +83,64 @@ def test_one_million_mixed_systems_full_size(E):
             assert np.max(np.where(free, 0.0, rel2)) <= 1e-6, name
 
 
+def test_one_million_mixed_systems_through_the_heterogeneous_entry(E):
+    """BASELINE configs[4] as ONE call (SURVEY.md 8b last row: a batch of different topologies): 1 M systems interleaved
+    i mod 3 over circle_tangent / parallelogram / arc_radius in a ragged batch through ezpz_mixed_* -- regrouped by
+    topology inside, one launch per topology on parallel streams, results back in caller order -- bitwise what the three
+    per-topology calls give, from host buffers and from device buffers; and a topology that is one contiguous run of
+    the batch (solved in place)."""
+    import torch
+    total = 1_000_000
+    systems, rows, refs = [], [], []
+    for k, name in enumerate(["circle_tangent", "parallelogram", "arc_radius"]):
+        ref = T.load(read_case(name))
+        recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
+        B = total // 3 + (1 if k < total % 3 else 0)
+        rows.append(ref.guesses[None, :] + gen.keyed_uniform(0x657A707A + 101 * k, B, ref.num_vars, -0.1, 0.1))
+        systems.append(E.System(recs, ref.num_vars))
+        refs.append(ref)
+    want = [s.solve_batch(r) for s, r in zip(systems, rows)]  # the per-topology calls: (x, status, _)
+    topo = (np.arange(total) % 3).astype(np.uint32)
+    mixed = E.MixedBatch(systems, topo)
+    nv = np.array([r.num_vars for r in refs], dtype=np.uint64)
+    assert mixed.total == int(nv[topo].sum()) and np.array_equal(mixed.offsets[:-1], np.concatenate([[0], np.cumsum(nv[topo])[:-1]]))
+    x0 = np.empty(mixed.total)
+    for k in range(3):
+        idx = np.nonzero(topo == k)[0]
+        pos = mixed.offsets[idx][:, None].astype(np.int64) + np.arange(int(nv[k]))[None, :]
+        x0[pos] = rows[k]
+    x, st = mixed.solve(x0)
+    for k in range(3):
+        idx = np.nonzero(topo == k)[0]
+        pos = mixed.offsets[idx][:, None].astype(np.int64) + np.arange(int(nv[k]))[None, :]
+        assert np.array_equal(x[pos], want[k][0]), k
+        for f in st.dtype.names:
+            assert np.array_equal(st[f][idx], want[k][1][f]), (k, f)
+    assert np.all(st["converged"] == 1) and np.all(st["n_unsatisfied"] == 0)
+    # device buffers, on torch's stream
+    dev = torch.device("cuda", 0)
+    dx0 = torch.from_numpy(x0).to(dev)
+    dx = torch.empty_like(dx0)
+    dst = torch.zeros((total, 32), dtype=torch.uint8, device=dev)
+    mixed.solve_device(dx0.data_ptr(), dx.data_ptr(), dst.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(dx.cpu().numpy(), x) and np.array_equal(dst.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1), st)
+    # the one-call form on a batch sorted by topology (every topology one contiguous run: solved in place), ragged tail
+    sizes = [1000, 7, 333]
+    topo2 = np.concatenate([np.full(c, k, dtype=np.uint32) for k, c in enumerate(sizes)])
+    x02 = np.concatenate([rows[k][:c].reshape(-1) for k, c in enumerate(sizes)])
+    x2, st2 = E.solve_batch_mixed(systems, topo2, x02)
+    assert np.array_equal(x2, np.concatenate([want[k][0][:c].reshape(-1) for k, c in enumerate(sizes)]))
+    assert np.array_equal(st2["iterations"], np.concatenate([want[k][1]["iterations"][:c] for k, c in enumerate(sizes)]))
+    # a topology the batch does not use, and an empty batch
+    x3, st3 = E.solve_batch_mixed(systems, np.full(5, 2, dtype=np.uint32), rows[2][:5].reshape(-1))
+    assert np.array_equal(x3, want[2][0][:5].reshape(-1))
+    x4, st4 = E.solve_batch_mixed(systems, np.zeros(0, dtype=np.uint32), np.zeros(0))
+    assert x4.size == 0 and st4.size == 0
+    with pytest.raises(E.NonLinearSystemError):
+        E.solve_batch_mixed(systems, np.full(2, 3, dtype=np.uint32), np.zeros(16))  # topology index out of range
+
+
 def test_quarter_million_jittered_sketches_on_the_lanes_full_size(E):
     """The connected-sketch leg of bench.py at its full size: 262 144 jittered starts of one 300-variable sketch -- one
     system per lane of the 4096 wavefronts the device holds, 4 to 19 LM iterations each.  Every system converges with every
@@ -105,7 +163,7 @@ def test_quarter_million_jittered_sketches_on_the_lanes_full_size(E):
     sample = np.unique(np.concatenate([np.arange(0, B, B // 48)[:48], late]))
     needed = assert_batch_matches_oracle(recs, x0[sample], x[sample], st["iterations"][sample], st["converged"][sample],
                                          what="sketch150 x 262144")
-    assert needed <= len(sample) // 4
+    assert needed <= 2  # (measured in round 4: 0; profiles/r04_parity_bar.txt)
     # the same batch again gives the same bits (the hand-over does not depend on timing: a lane gives up at a fixed point of
     # its own wavefront's progress)
     x2, st2, _ = sysobj.solve_batch(x0)
@@ -134,7 +192,7 @@ def test_thirty_two_thousand_jittered_sketches_on_the_record_walk_full_size(E):
     sample = np.unique(np.concatenate([np.arange(0, B, B // 64)[:64], late]))
     needed = assert_batch_matches_oracle(recs, x0[sample], x[sample], st["iterations"][sample], st["converged"][sample],
                                          what="sketch150 x 32768")
-    assert needed <= len(sample) // 4
+    assert needed <= 2  # (measured in round 4: 0; profiles/r04_parity_bar.txt)
     x2, st2, _ = sysobj.solve_batch(x0)
     assert np.array_equal(st2["iterations"], st["iterations"]) and np.array_equal(x2, x)
     # one lane per system (the shape of larger batches) on the same starts: the same LM paths

@@ -25,6 +25,11 @@ def E():
 # seeds 0..47 plus the three of round 2's list beyond them whose oracle answers move the most under one-ulp perturbations
 # (comb 51, band 153, band 189; band 29 and tree 8 are below 48)
 GRAPH_SEEDS = list(range(48)) + [51, 153, 189]
+# How many (system, start, shape) of each chunk needed the measured bar of tests/sensitivity.py in round 4's GPU run
+# (profiles/r04_parity_bar.txt): comb 51, band 153, tree 8, hub 38, band 189, comb 11, band 29 -- systems whose oracle
+# answers move by more than 5e-6 under one-ulp moves of the start, on all five shapes -- and hub 26 (bar 3.7e-5).  The
+# assertion is that count plus a margin of three, not "half of them".
+GRAPH_NEEDED = [10, 10, 25, 0, 0, 10]
 
 
 @pytest.mark.parametrize("chunk", range(6))
@@ -47,8 +52,8 @@ def test_graph_families_on_every_launch_shape(E, chunk):
             needed += assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg),
                                                   oracle_result=(xo, it, conv), what=(family, seed, npts, team))
             total += 2
-    # the measured bar is the exception, not the rule
-    assert needed <= total // 2, (needed, total)
+    # the measured bar is the exception, not the rule: the share measured in round 4, plus a small margin
+    assert needed <= GRAPH_NEEDED[chunk] + 3, (needed, total)
 
 
 @pytest.mark.parametrize("chunk", range(4))
@@ -70,4 +75,4 @@ def test_connected_sketches_on_the_team_shapes(E, chunk):
             needed += assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg),
                                                   oracle_result=(xo, it, conv), what=(seed, npts, team))
             total += 3
-    assert needed <= total // 2, (needed, total)
+    assert needed <= 2, (needed, total)  # (round 4's GPU run: none of the 576 needed it)

@@ -235,7 +235,7 @@ def test_connected_sketches_lanes_across_the_batch(E, npts, seed):
     ok = ~np.isnan(x0).any(axis=1)
     needed = assert_batch_matches_oracle(recs, x0[ok], x[ok], st["iterations"][ok], st["converged"][ok], O.Config(**cfg),
                                          oracle_result=(xo[ok], it[ok], conv[ok]), what=("lanes", npts, seed))
-    assert needed <= B // 100
+    assert needed <= 6  # (measured in round 4: 2 of 2498; profiles/r04_parity_bar.txt)
     assert np.array_equal(st["iterations"][~ok], it[~ok]) and np.array_equal(np.isnan(x[~ok]), np.isnan(xo[~ok]))
     # (the lanes eliminate in the order with the least fill, the teams in the one with few levels)
     same = st["iterations"][:300] == sts["iterations"]

@@ -136,6 +136,28 @@ OVERSUBSCRIBED = textwrap.dedent("""
     [t.start() for t in ts]; [t.join() for t in ts]
     for i in range(2):
         assert np.array_equal(results[i][0], want[i * 1000:(i + 1) * 1000 + 77])
+    # a ragged batch of three topologies sharded over the three workers (ezpz_multi_solve_batch_mixed): every device index
+    # runs its contiguous shard through the single-device heterogeneous entry; bitwise the per-topology answers
+    tops, rows_of, singles, multis = [], [], [], []
+    for k, name in enumerate(("circle_tangent", "parallelogram", "arc_radius")):
+        r = T.load(read_case(name))
+        rc_ = O.stack([O.set_from_initial_values(c, r.guesses) for c in r.constraints])
+        singles.append(E.System(rc_, r.num_vars))
+        multis.append(E.MultiSystem(rc_, r.num_vars, device_mask=0b111))
+        rows_of.append(r.guesses[None, :] + gen.keyed_uniform(70 + k, 4000, r.num_vars, -0.1, 0.1))
+    rng = np.random.default_rng(5)
+    for B in (1, 2, 10, 9001):
+        topo = rng.integers(0, 3, B).astype(np.uint32)
+        used = [0, 0, 0]
+        parts, want_x, want_it = [], [], []
+        per_top = [singles[k].solve_batch(rows_of[k]) for k in range(3)]
+        for b in range(B):
+            k = int(topo[b]); i = used[k]; used[k] += 1
+            parts.append(rows_of[k][i]); want_x.append(per_top[k][0][i]); want_it.append(per_top[k][1]["iterations"][i])
+        xm, stm = E.solve_batch_mixed_multi(multis, topo, np.concatenate(parts))
+        assert np.array_equal(xm, np.concatenate(want_x)) and np.array_equal(stm["iterations"], np.array(want_it)), B
+        x1, st1 = E.solve_batch_mixed(singles, topo, np.concatenate(parts))
+        assert np.array_equal(x1, xm) and same_status(st1, stm), B
     print("oversubscribed ok")
 """)
 
