@@ -63,13 +63,19 @@ const DeviceLimits& device_limits(int device) {
     return cache[device];
 }
 
-#define HIP_TRY(expr)                                  \
-    do {                                               \
-        hipError_t _e = (expr);                        \
-        if (_e != hipSuccess) {                        \
-            (void)hipGetLastError();                   \
-            return EZPZ_ERR_HIP;                       \
-        }                                              \
+// (EZPZ_HIP_DEBUG=1: the failing call and the runtime's message on stderr)
+inline bool hip_debug() {
+    static const bool on = std::getenv("EZPZ_HIP_DEBUG") != nullptr;
+    return on;
+}
+#define HIP_TRY(expr)                                                                                             \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) {                                                                                   \
+            if (hip_debug()) std::fprintf(stderr, "[ezpz hip] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            (void)hipGetLastError();                                                                              \
+            return EZPZ_ERR_HIP;                                                                                  \
+        }                                                                                                         \
     } while (0)
 
 template <class T>
@@ -510,6 +516,9 @@ bool jit_sync() {
 // The list-walk teams of a system (lm_kernel.hip.hpp), whatever their shape: sub-wavefront teams, workgroups with their
 // workspace in LDS or in global memory, grid teams.  (launch() holds the system's launch lock.)
 int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
+    // a resident launch (DoneWord::request) is one workgroup that keeps nothing another launch of this system waits for:
+    // not a grid team, not a shape whose workspace or Jacobian lives in the system's one global scratch
+    if (s.grid_wgs > 1 || args.batch != 1 || (s.mode != MODE_SUB && (!s.lds_ws || (s.rec && s.rec_jglobal)))) args.done.request = nullptr;
     uint32_t grid;
     if (s.mode == MODE_SUB) {
         const uint32_t tpb = s.block_threads / s.team_size;
@@ -592,7 +601,9 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     // workspace are chained on an event below
     std::lock_guard<std::mutex> launch_lock(s.launch_mu);
     constexpr uint64_t kNoLanesWorkspace = ~0ull;  // the allocation failed once: not tried again on every call
-    if (s.lanes && args.batch >= s.lanes_min) {  // a device-filling batch of one connected sketch: lanes across the batch
+    if (args.batch != 1) args.done.request = nullptr;  // (residency is for one-call launches: one system, one workgroup)
+    if (s.lanes && args.batch >= s.lanes_min) {
+        args.done.request = nullptr;  // a device-filling batch of one connected sketch: lanes across the batch
         if (s.lanes_ws_waves == 0) {
             // one workspace per wavefront the device holds (capped at 24 GiB of the 288: fewer wavefronts then)
             uint64_t waves = batch_launch_waves(s.lim.cus);
@@ -655,8 +666,13 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             if (st == 2) {
                 if (s.comp->jit_wgs <= 1) {
                     if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
-                } else if (launch_jit_grid(s, L, stream) == EZPZ_OK) {
-                    return EZPZ_OK;
+                } else {
+                    CompLaunch Lg = L;
+                    Lg.done.request = nullptr;  // (several workgroups per system: never resident)
+                    if (launch_jit_grid(s, Lg, stream) == EZPZ_OK) {
+                        args.done.request = nullptr;
+                        return EZPZ_OK;
+                    }
                 }
             }
         }
@@ -2052,6 +2068,8 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
 
 // The rest of a deferred analysis (EzpzSystem::program_deferred): the list-walk program of the whole system, for
 // evaluation, FreedomAnalysis and the sizes of EzpzSystemInfo.  Solves never wait for it.
+static void dismiss_resident_of(EzpzSystem* sys);  // (the one-call section below)
+
 static int ensure_program(EzpzSystem* sys) {
     if (!sys->program_deferred.load(std::memory_order_acquire)) return EZPZ_OK;
     std::lock_guard<std::mutex> lock(sys->defer_mu);
@@ -2086,6 +2104,7 @@ void ezpz_system_destroy(EzpzSystem* sys) {
     }
     const int device = sys->device;
     if (device >= 0) (void)hipSetDevice(device);
+    dismiss_resident_of(sys);
     delete sys;
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
 }
@@ -2123,6 +2142,7 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
                            uint32_t* degenerate_count_out) {
     if (!sys || !x || !r_out || !jv_out) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch == 0) return EZPZ_OK;
+    release_thread_kernel(sys->device);
     if (int rc0 = ensure_program(sys)) return rc0;
     std::lock_guard<std::mutex> lock(sys->mu);
     HIP_TRY(hipSetDevice(sys->device));
@@ -2161,9 +2181,10 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
 }  // extern "C"
 
 // (done: the completion word of a one-call launch, system_solve_one; null for every other caller)
+// (`resident`: whether the launch stays on the device for further requests, DoneWord::request)
 static int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg, double* x_out_dev,
                                    EzpzStatus* status_dev, uint8_t* unsat_mask_dev, uint64_t* warn_log_dev, uint32_t warn_cap,
-                                   void* stream, const DoneWord& done) {
+                                   void* stream, const DoneWord& done, bool* resident = nullptr) {
     if (!sys || (batch && (!x_out_dev || !status_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch && sys->counts.n_vars && !x0_dev) return EZPZ_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(sys->device));
@@ -2219,7 +2240,9 @@ static int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t
         a.rec_jstride = (sys->counts.zj + 2) & ~1u;  // (the values, the zero of padding pairs)
     }
     fill_cfg(a, cfg);
-    return launch(*sys, a, static_cast<hipStream_t>(stream));
+    const int rc = launch(*sys, a, static_cast<hipStream_t>(stream));
+    if (resident) *resident = rc == EZPZ_OK && a.done.request != nullptr;
+    return rc;
 }
 
 extern "C" {
@@ -2227,6 +2250,7 @@ extern "C" {
 int ezpz_system_solve_batch_device(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg,
                                    double* x_out_dev, EzpzStatus* status_dev, uint8_t* unsat_mask_dev,
                                    uint64_t* warn_log_dev, uint32_t warn_cap, void* stream) {
+    if (sys) release_thread_kernel(sys->device);
     return solve_batch_device_impl(sys, x0_dev, batch, cfg, x_out_dev, status_dev, unsat_mask_dev, warn_log_dev, warn_cap, stream,
                                    DoneWord{nullptr, 0, nullptr});
 }
@@ -2235,6 +2259,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                             EzpzStatus* status, uint8_t* unsat_mask, uint64_t* warn_log, uint32_t warn_cap) {
     if (!sys) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch == 0) return EZPZ_OK;
+    release_thread_kernel(sys->device);
     std::lock_guard<std::mutex> lock(sys->mu);
     HIP_TRY(hipSetDevice(sys->device));
     const size_t n = sys->counts.n_vars, C = sys->counts.n_cons;
@@ -2454,21 +2479,38 @@ namespace {
 // What one thread's one-call launches on one device go through (grow-only; a thread's call has seen its completion word
 // before it returns, so the buffers are free for its next call).
 struct CallBufs {
-    unsigned char* host = nullptr;  // mapped host memory: [completion word, 64 B][status, 64 B][values out][values in, no BAR]
+    // mapped host memory: [completion word, 64 B][the resident kernel's "gone" word, 64 B][status, 64 B][values out]
+    // [values in, no BAR][short unsatisfied mask][short warning log]
+    unsigned char* host = nullptr;
     size_t host_cap = 0;
-    double* x0_bar = nullptr;  // fine-grained device memory the host stores the guesses into (large BAR), else null
-    size_t x0_cap = 0;
+    // fine-grained device memory the host stores into through the BAR: [request word, 64 B][guesses], else null
+    unsigned char* bar_mem = nullptr;
+    size_t bar_cap = 0;
     int bar = -1;  // -1 not asked yet, 0 no (the kernel reads the guesses from mapped host memory), 1 yes
     DevBuf<uint8_t> mask;
     DevBuf<uint64_t> log;
     DevBuf<unsigned int> counter;
     uint64_t seq = 0;
+    // the resident kernel of this thread's last one-call launch, if it stayed (DoneWord::request)
+    bool res_alive = false;
+    EzpzSystem* res_sys = nullptr;
+    uint64_t res_generation = 0;
+    EzpzConfig res_cfg{};
+    bool res_jit = false;      // it was the topology's specialised kernel
+    uint32_t res_warn_cap = 0;
+    bool res_log = false;
     ~CallBufs() {
+        if (res_alive && bar_mem) {  // (thread exit: the kernel is told to leave before its buffers go)
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            *reinterpret_cast<volatile uint64_t*>(bar_mem) = ~0ull;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+        }
         if (host) (void)hipHostFree(host);
-        if (x0_bar) (void)hipFree(x0_bar);
+        if (bar_mem) (void)hipFree(bar_mem);
     }
 };
 thread_local CallBufs t_call[16];
+constexpr size_t kCallHeader = 192;
 
 bool device_has_large_bar(int device) {
     static const bool allowed = [] {
@@ -2481,6 +2523,29 @@ bool device_has_large_bar(int device) {
         return false;
     }
     return v != 0;
+}
+
+// EZPZ_RESIDENT_US: how long a one-call kernel waits on the device for the calling thread's next request before it ends
+// (0 = never resident; default 200).  A solve() loop -- the reference's benchmark protocol, an interactive drag -- keeps
+// its kernel; anything that synchronises the whole device waits at most this long for it; no kernel stays longer than 50 ms.
+unsigned resident_lease_us() {
+    static const unsigned us = [] {
+        const char* e = std::getenv("EZPZ_RESIDENT_US");
+        return e ? (unsigned)std::max(0, std::atoi(e)) : 200u;
+    }();
+    return us;
+}
+
+void store_request(CallBufs& cb, uint64_t v) {  // through the BAR, after everything stored before it
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    *reinterpret_cast<volatile uint64_t*>(cb.bar_mem) = v;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
+void dismiss_resident(CallBufs& cb) {  // "leave": the kernel ends within a poll; nothing waits for it (its stream runs in order)
+    if (cb.res_alive && cb.bar_mem) store_request(cb, ~0ull);
+    cb.res_alive = false;
+    cb.res_sys = nullptr;
 }
 
 }  // namespace
@@ -2503,59 +2568,145 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
     const bool host_mask = C <= sys->lim.policy.one_call_host_mask_max_constraints,
                host_log = want_log && warn_cap <= sys->lim.policy.one_call_host_log_max_entries;
     const size_t mask_bytes = host_mask ? 256 : 0, log_bytes = host_log ? (size_t)warn_cap * sizeof(uint64_t) : 0;
-    if (cb.host_cap < 128 + 2 * x_bytes + mask_bytes + log_bytes) {
+    if (cb.host_cap < kCallHeader + 2 * x_bytes + mask_bytes + log_bytes) {
+        dismiss_resident(cb);  // (it writes into the buffer that goes away)
         if (cb.host) (void)hipHostFree(cb.host);
         cb.host = nullptr;
         cb.host_cap = 0;
-        const size_t want = std::max<size_t>(128 + 3 * x_bytes + 256 + 2 * log_bytes, 64 * 1024);
+        const size_t want = std::max<size_t>(kCallHeader + 3 * x_bytes + 256 + 2 * log_bytes, 64 * 1024);
         HIP_TRY(hipHostMalloc((void**)&cb.host, want, hipHostMallocMapped));
-        std::memset(cb.host, 0, 128);
+        std::memset(cb.host, 0, kCallHeader);
         cb.host_cap = want;
         cb.seq = 0;
     }
-    if (cb.bar == 1 && cb.x0_cap < x_bytes) {
-        if (cb.x0_bar) (void)hipFree(cb.x0_bar);
-        cb.x0_bar = nullptr;
-        cb.x0_cap = 0;
-        const size_t want = std::max<size_t>(x_bytes + x_bytes / 2, 64 * 1024);
-        if (hipExtMallocWithFlags((void**)&cb.x0_bar, want, hipDeviceMallocFinegrained) != hipSuccess) {
+    if (cb.bar == 1 && cb.bar_cap < 64 + x_bytes) {
+        dismiss_resident(cb);
+        if (cb.bar_mem) (void)hipFree(cb.bar_mem);
+        cb.bar_mem = nullptr;
+        cb.bar_cap = 0;
+        const size_t want = std::max<size_t>(64 + x_bytes + x_bytes / 2, 64 * 1024);
+        if (hipExtMallocWithFlags((void**)&cb.bar_mem, want, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
-            cb.x0_bar = nullptr;
+            cb.bar_mem = nullptr;
             cb.bar = 0;  // the kernel reads the guesses from mapped host memory instead
         } else {
-            cb.x0_cap = want;
+            cb.bar_cap = want;
         }
     }
     if (cb.counter.cap == 0) {
         if ((rc = cb.counter.ensure(16)) != EZPZ_OK) return rc;
         HIP_TRY(hipMemset(cb.counter.p, 0, 16 * sizeof(unsigned int)));
     }
-    if (!host_mask && (rc = cb.mask.ensure(C)) != EZPZ_OK) return rc;
-    if (want_log && !host_log && (rc = cb.log.ensure(warn_cap)) != EZPZ_OK) return rc;
+    if (!host_mask && cb.mask.cap < C) {
+        dismiss_resident(cb);
+        if ((rc = cb.mask.ensure(C)) != EZPZ_OK) return rc;
+    }
+    if (want_log && !host_log && cb.log.cap < warn_cap) {
+        dismiss_resident(cb);
+        if ((rc = cb.log.ensure(warn_cap)) != EZPZ_OK) return rc;
+    }
     volatile uint64_t* word = reinterpret_cast<volatile uint64_t*>(cb.host);
-    EzpzStatus* hst = reinterpret_cast<EzpzStatus*>(cb.host + 64);
-    double* hx_out = reinterpret_cast<double*>(cb.host + 128);
-    double* hx_in = reinterpret_cast<double*>(cb.host + 128 + x_bytes);
-    uint8_t* hmask = cb.host + 128 + 2 * x_bytes;
-    uint64_t* hlog = reinterpret_cast<uint64_t*>(cb.host + 128 + 2 * x_bytes + mask_bytes);
-    double* x_in = cb.bar == 1 ? cb.x0_bar : hx_in;
+    volatile uint64_t* gone = reinterpret_cast<volatile uint64_t*>(cb.host + 64);
+    EzpzStatus* hst = reinterpret_cast<EzpzStatus*>(cb.host + 128);
+    double* hx_out = reinterpret_cast<double*>(cb.host + kCallHeader);
+    double* hx_in = reinterpret_cast<double*>(cb.host + kCallHeader + x_bytes);
+    uint8_t* hmask = cb.host + kCallHeader + 2 * x_bytes;
+    uint64_t* hlog = reinterpret_cast<uint64_t*>(cb.host + kCallHeader + 2 * x_bytes + mask_bytes);
+    double* x_in = cb.bar == 1 ? reinterpret_cast<double*>(cb.bar_mem + 64) : hx_in;
+    EzpzConfig dcfg;
+    if (!cfg) {
+        ezpz_default_config(&dcfg);
+        cfg = &dcfg;
+    }
+    // ---- the topology's kernel still on the device from this thread's previous call? ------------------------------------------
+    const unsigned lease_us = cb.bar == 1 ? resident_lease_us() : 0;
+    const bool jit_now = sys->jit && comp_jit_state(sys->jit) == 2;
+    bool resident = cb.res_alive && cb.res_sys == sys && lease_us && std::memcmp(&cb.res_cfg, cfg, sizeof(EzpzConfig)) == 0 &&
+                    cb.res_jit == jit_now && cb.res_log == want_log && (!want_log || cb.res_warn_cap == warn_cap);
+    if (cb.res_alive && !resident) dismiss_resident(cb);
+    // (what launch() does for a topology solved again and again: its specialised kernel is asked for after so many solves)
+    if (sys->jit && !jit_now && !jit_sync() && comp_jit_state(sys->jit) == 0 &&
+        sys->launches.load(std::memory_order_relaxed) >= sys->lim.policy.jit_after_launches)
+        (void)comp_jit_request(sys->jit, false);
     if (n) std::memcpy(x_in, x0, n * sizeof(double));
-    // (the stores above are write-combined when they go through the BAR: drained before the doorbell write of the launch)
-    std::atomic_thread_fence(std::memory_order_seq_cst);
+    // the request's tag: the generation of the launch that is to serve it (a resident kernel of an earlier launch that
+    // still polls the word leaves when it sees another generation) and a sequence number
+    constexpr uint64_t kSeqMask = (1ull << 40) - 1;
+    ++cb.seq;
+    if (!resident) ++cb.res_generation;
+    const uint64_t generation = cb.res_generation & 0xFFFFFFull;
+    const uint64_t seq = (generation << 40) | (cb.seq & kSeqMask);
     call_stamp(CALL_STAGED);
-    const uint64_t seq = ++cb.seq;
-    rc = solve_batch_device_impl(sys, x_in, 1, cfg, hx_out, hst, host_mask ? hmask : cb.mask.p,
-                                 !want_log ? nullptr : host_log ? hlog : cb.log.p, warn_cap,
-                                 hipStreamPerThread, DoneWord{const_cast<unsigned long long*>(reinterpret_cast<volatile unsigned long long*>(word)), seq, cb.counter.p});
-    if (rc != EZPZ_OK) return rc;
-    call_stamp(CALL_LAUNCHED);
-    // The completion word first; a launch that never writes it (a shape without the epilogue, a failed kernel) is caught by
-    // the stream's own state, asked every few microseconds once the word is overdue.
-    {
+    if (resident) {
+        sys->launches.fetch_add(1, std::memory_order_relaxed);
+        store_request(cb, seq);  // (the guesses above are write-combined stores through the BAR: drained first)
+        call_stamp(CALL_LAUNCHED);
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (*word != seq) {
+            if (*gone == generation) {  // the lease ran out between the calls: an ordinary launch serves this request
+                resident = false;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                // (the kernel neither answered nor left: its stream says what happened)
+                const hipError_t q = hipStreamQuery(hipStreamPerThread);
+                if (q != hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    resident = false;
+                    if (q != hipSuccess) {
+                        cb.res_alive = false;
+                        return EZPZ_ERR_HIP;
+                    }
+                    break;
+                }
+            }
+        }
+        if (!resident) {
+            cb.res_alive = false;
+            cb.res_sys = nullptr;
+        }
+    }
+    if (!resident) {
+        // (a resident kernel that left between the calls: the request above carried ITS generation; this launch gets a new
+        // one, and the request is stored again under it)
+        uint64_t tag = seq;
+        if ((cb.res_generation & 0xFFFFFFull) == generation && *gone == generation) {
+            ++cb.res_generation;
+            tag = ((cb.res_generation & 0xFFFFFFull) << 40) | (cb.seq & kSeqMask);
+        }
+        // (the stores above are write-combined when they go through the BAR: drained before the doorbell write of the launch)
+        DoneWord done{const_cast<unsigned long long*>(reinterpret_cast<volatile unsigned long long*>(word)), tag, cb.counter.p};
+        if (lease_us) {
+            *gone = 0;
+            store_request(cb, tag);  // (the request word reads this launch's own tag when the kernel first polls it: nothing new yet)
+            done.request = reinterpret_cast<const unsigned long long*>(cb.bar_mem);
+            done.gone = const_cast<unsigned long long*>(reinterpret_cast<volatile unsigned long long*>(gone));
+            done.generation = cb.res_generation & 0xFFFFFFull;
+            done.lease_ticks = lease_us * 100u;
+            done.life_ticks = 50000u * 100u;
+        }
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        bool stays = false;
+        rc = solve_batch_device_impl(sys, x_in, 1, cfg, hx_out, hst, host_mask ? hmask : cb.mask.p,
+                                     !want_log ? nullptr : host_log ? hlog : cb.log.p, warn_cap, hipStreamPerThread, done, &stays);
+        if (rc != EZPZ_OK) return rc;
+        if (stays) {
+            cb.res_alive = true;
+            cb.res_sys = sys;
+            cb.res_cfg = *cfg;
+            cb.res_jit = sys->jit && comp_jit_state(sys->jit) == 2;
+            cb.res_log = want_log;
+            cb.res_warn_cap = warn_cap;
+        }
+        call_stamp(CALL_LAUNCHED);
+        // The completion word first; a launch that never writes it (a shape without the epilogue, a failed kernel) is caught by
+        // the stream's own state, asked every few microseconds once the word is overdue.
         const auto t0 = std::chrono::steady_clock::now();
         auto next_query = t0 + std::chrono::microseconds(100);
         uint32_t spins = 0;
-        while (*word != seq) {
+        while (*word != tag) {
             __builtin_ia32_pause();
             if ((++spins & 63u) != 0) continue;
             const auto now = std::chrono::steady_clock::now();
@@ -2564,12 +2715,13 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
             if (q == hipSuccess) break;  // the stream is idle: the launch is over, word or no word
             if (q != hipErrorNotReady) {
                 (void)hipGetLastError();
+                cb.res_alive = false;
                 return EZPZ_ERR_HIP;
             }
             next_query = now + std::chrono::microseconds(now - t0 > std::chrono::milliseconds(2) ? 200 : 5);
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
     }
+    std::atomic_thread_fence(std::memory_order_acquire);
     call_stamp(CALL_COMPLETE);
     *status = *hst;
     if (status->iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT && (sys->grid_wgs > 1 || (sys->comp && sys->comp->jit_wgs > 1))) return EZPZ_ERR_HIP;
@@ -2578,12 +2730,32 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
     const size_t n_log = want_log ? std::min<size_t>(status->n_warnings, warn_cap) : 0;
     if (fetch_mask && host_mask) std::memcpy(unsat_mask, hmask, C);
     if (n_log && host_log) std::memcpy(warn_log, hlog, n_log * sizeof(uint64_t));
-    if (fetch_mask && !host_mask) HIP_TRY(hipMemcpyAsync(unsat_mask, cb.mask.p, C, hipMemcpyDeviceToHost, hipStreamPerThread));
-    if (n_log && !host_log)
-        HIP_TRY(hipMemcpyAsync(warn_log, cb.log.p, n_log * sizeof(uint64_t), hipMemcpyDeviceToHost, hipStreamPerThread));
-    if ((fetch_mask && !host_mask) || (n_log && !host_log)) HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+    if ((fetch_mask && !host_mask) || (n_log && !host_log)) {
+        // (copies on the thread's stream would queue behind a resident kernel: it leaves first)
+        dismiss_resident(cb);
+        if (fetch_mask && !host_mask) HIP_TRY(hipMemcpyAsync(unsat_mask, cb.mask.p, C, hipMemcpyDeviceToHost, hipStreamPerThread));
+        if (n_log && !host_log)
+            HIP_TRY(hipMemcpyAsync(warn_log, cb.log.p, n_log * sizeof(uint64_t), hipMemcpyDeviceToHost, hipStreamPerThread));
+        HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+    }
     call_stamp(CALL_UNPACKED);
     return EZPZ_OK;
+}
+
+// Anything else the calling thread is about to enqueue on this device -- a batch on its per-thread stream, copies on the
+// null stream -- would queue behind its resident kernel until the lease runs out: the kernel is told to leave first.
+void ezpz::release_thread_kernel(int device) {
+    if (device < 0) return;
+    CallBufs& cb = t_call[device & 15];
+    if (cb.res_alive) dismiss_resident(cb);
+}
+
+// A system that goes away takes its resident kernel along: the calling thread's is told to leave (another thread's runs out
+// of its lease; hipFree waits for the device either way).
+static void dismiss_resident_of(EzpzSystem* sys) {
+    if (sys->device < 0) return;
+    CallBufs& cb = t_call[sys->device & 15];
+    if (cb.res_alive && cb.res_sys == sys) dismiss_resident(cb);
 }
 
 extern "C" {
@@ -2768,6 +2940,7 @@ int build_freedom(EzpzSystem* sys) {
 int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* mask_dev, double* part_dev,
                    uint32_t* count_dev, hipStream_t stream) {
     auto& F = sys->freedom;
+    release_thread_kernel(sys->device);
     int rc = ensure_program(sys);
     if (rc != EZPZ_OK) return rc;
     const size_t n = sys->counts.n_vars, zj = sys->counts.zj;

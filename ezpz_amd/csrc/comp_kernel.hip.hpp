@@ -194,6 +194,12 @@ __global__ void __launch_bounds__(512) comp_solve_kernel(const CompArgs a) {
     __syncthreads();
 
     uint32_t parity = 0;
+    // (a resident launch -- DoneWord::request, one workgroup -- serves one request after the other on the same buffers)
+    // (thread 0's word to the others, behind the flag words of the reduction scratch: no static LDS beside the dynamic block)
+    unsigned long long* const resident_word = reinterpret_cast<unsigned long long*>(red.buf + 104);
+    const unsigned long long born = wall_clock64();
+    DoneWord done = a.done;
+    do {
     for (uint64_t sys = blockIdx.x; sys < a.batch; sys += gridDim.x, parity ^= 1u) {
         const double* x0 = a.x0 + sys * a.n_row;
         int* nwarn = nwarn2 + parity;
@@ -541,7 +547,8 @@ __global__ void __launch_bounds__(512) comp_solve_kernel(const CompArgs a) {
             if (!LIN) *nwarn = 0;
         }
     }
-    publish_done(a.done);
+    publish_done(done);
+    } while (resident_next(done, born, resident_word));
 }
 
 }  // namespace ezpz

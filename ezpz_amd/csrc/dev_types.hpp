@@ -59,10 +59,21 @@ constexpr uint32_t kNoPass = 0xFFFFFFFFu;
 // polls: the call returns ~7 us sooner than through the runtime's completion signal (tools/launch_floor.hip:
 // 6.0 us launch-to-flag against 13.4 us launch-to-hipStreamQuery).  `counter` (device memory, zero between launches)
 // counts the workgroups of a launch that has several.  flag == null: an ordinary launch.
+// RESIDENT launches (one workgroup; api.hip: system_solve_one): after publishing, the kernel does not end but waits for the
+// host's next request on the same buffers -- `request` is a word of device memory the host stores into through the PCIe
+// BAR: the tag of the latest request (the launch's generation in the upper 24 bits, a sequence number below; any other
+// generation, e.g. ~0, means "leave") -- for at most `lease_ticks` of the 100 MHz clock, and for `life_ticks` in all;
+// when it ends it stores `generation` to `gone` (mapped host memory).  `seq` is the tag of the request being served.  A solve() call that finds its
+// topology's kernel resident costs a store, the solve and a poll: ~3 us of round trip instead of the ~8 us of a launch
+// (tools/launch_floor.hip).  request == null: an ordinary launch.
 struct DoneWord {
     unsigned long long* flag;
     unsigned long long seq;
     unsigned int* counter;
+    const unsigned long long* request;
+    unsigned long long* gone;
+    unsigned long long generation;
+    unsigned int lease_ticks, life_ticks;
 };
 
 }  // namespace ezpz

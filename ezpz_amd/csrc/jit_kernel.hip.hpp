@@ -47,7 +47,7 @@ struct JitArgs {
     uint32_t pad;
     DoneWord done;             // one-call launches: the completion word (dev_types.hpp)
 };
-static_assert(sizeof(JitArgs) == 144, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
+static_assert(sizeof(JitArgs) == 176, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
 
 // One system on several workgroups ("grid team", as in lm_kernel.hip.hpp): every workgroup owns its wavefronts' slots;
 // the reductions of the LM control cross workgroups through this per-system scratch.  Every workgroup publishes its
@@ -473,6 +473,10 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     });
 
     uint32_t parity = 0;
+    // (a resident launch -- DoneWord::request, one workgroup -- serves one request after the other on the same buffers)
+    const unsigned long long born = wall_clock64();
+    DoneWord done = a.done;
+    do {
     for (uint64_t sys = grid_slot; sys < a.batch; sys += n_slots, parity ^= 1u) {
         const double* x0 = a.x0 + sys * a.n_row;
         // (Pulling the NEXT system's guesses towards L2 while this one is solved -- one 4-byte load per 64 bytes of its row
@@ -708,7 +712,8 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             if (ANY_NONLINEAR) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    publish_done(a.done);
+    publish_done(done);
+    } while (resident_next(done, born, reinterpret_cast<unsigned long long*>(smem + kRedDoubles + 8)));
 }
 
 // ---- one LANE per system ------------------------------------------------------------------------------------------------------
@@ -733,13 +738,18 @@ struct LaneArgs {
     double residual_tolerance, step_tolerance, initial_lambda;
     DoneWord done;  // one-call launches: the completion word (dev_types.hpp)
 };
-static_assert(sizeof(LaneArgs) == 112, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
+static_assert(sizeof(LaneArgs) == 144, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
 
 template <class C, bool UNIT_W>
 __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
     using namespace ezpz::dev;
     constexpr int NV = C::NV, M = C::M > 0 ? C::M : 1, ZJ = C::ZJS > 0 ? C::ZJS : 1;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    // (a resident launch -- DoneWord::request, one workgroup -- serves one request after the other on the same buffers)
+    __shared__ unsigned long long resident_word;
+    const unsigned long long born = wall_clock64();
+    DoneWord done = a.done;
+    do {
     uint64_t next = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool have = false;
     uint64_t sys = 0;
@@ -882,7 +892,8 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
             have = false;
         }
     }
-    publish_done(a.done);
+    publish_done(done);
+    } while (resident_next(done, born, &resident_word));
 }
 
 }  // namespace jit

@@ -769,6 +769,14 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
         for (uint32_t i = tid; i < nd; i += blockDim.x) dst[i] = a.rec_desc[i];
     }
     const uint64_t n_sys = a.sys_count ? (uint64_t)min(*a.sys_count, (uint32_t)a.batch) : a.batch;
+    // (a resident launch -- DoneWord::request, one workgroup -- serves one request after the other on the same buffers)
+    // (the word through which thread 0 tells the others: the first double of the workspaces, free between two requests --
+    // no static LDS in this kernel, whose dynamic allocation may take the CU's whole 160 KB)
+    unsigned long long* const resident_word = reinterpret_cast<unsigned long long*>(LDSWS ? smem + a.prog_lds_doubles : smem);
+    const unsigned long long born = wall_clock64();
+    DoneWord done = a.done;
+    do {
+    x_have = false;
     for (uint64_t q = (uint64_t)grid_slot * teams_per_block + team_in_block; q < n_sys; q += n_teams, sys_parity ^= 1u) {
         const uint64_t sys = a.sys_list ? (uint64_t)a.sys_list[q] : q;
         // ---- load the initial values (AoS row, coalesced) ------------------------------------------------------------
@@ -1843,7 +1851,8 @@ __global__ void __launch_bounds__(MODE == MODE_SUB ? 256 : (LIN && RECF == 0 ? 1
         if constexpr (MODE != MODE_PART) tm.team_sync();
         EZPZ_STAMP(32);
     }
-    publish_done(a.done);
+    publish_done(done);
+    } while (resident_next(done, born, resident_word));
 }
 
 // Evaluation-only kernel (K1): one workgroup per value vector, everything in global memory.

@@ -18,4 +18,9 @@ namespace ezpz {
 int system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* cfg, double* x_out, EzpzStatus* status,
                      uint8_t* unsat_mask, uint64_t* warn_log, uint32_t warn_cap);
 
+// The calling thread's one-call kernel may still be on the device, waiting for the thread's next request (a resident
+// launch, dev_types.hpp: DoneWord): whatever else the thread is about to enqueue there would queue behind it until its
+// lease (EZPZ_RESIDENT_US) runs out -- it is told to leave first.  Cheap when there is none.
+void release_thread_kernel(int device);
+
 }  // namespace ezpz

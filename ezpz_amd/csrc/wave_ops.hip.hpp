@@ -53,6 +53,37 @@ struct OpMax {  // libm::fmax (NaN-ignoring), newton.rs:53,:108
     __device__ __forceinline__ double identity() const { return __builtin_nan(""); }  // dropped by fmax
 };
 
+// A resident launch (DoneWord::request): every thread of the (one) workgroup calls this after publish_done; true = another
+// request is to be served (w.seq is its sequence number), false = the kernel ends (no request within the lease, the host's
+// "leave", or the launch's lifetime is over) -- after it has said so to the host.  `born` = wall_clock64() at kernel start.
+__device__ __forceinline__ bool resident_next(DoneWord& w, unsigned long long born, unsigned long long* shared_word) {
+    if (!w.request) return false;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long next = 0;
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(w.request, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v != w.seq) {
+                // a request carries the generation of the launch it is meant for in its upper 24 bits: anything else in
+                // the word -- "leave" (~0), or the request of the launch that replaces this one -- ends this kernel
+                next = (v >> 40) == (w.seq >> 40) ? v : 0;
+                break;
+            }
+            const unsigned long long now = wall_clock64();
+            if (now - t0 > w.lease_ticks || now - born > w.life_ticks) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (next == 0) __hip_atomic_store(w.gone, w.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *shared_word = next;
+    }
+    __syncthreads();
+    const unsigned long long next = *shared_word;
+    __syncthreads();
+    if (next == 0) return false;
+    w.seq = next;
+    return true;
+}
+
 // Cross-lane moves inside a row of 16 lanes without touching the LDS crossbar (DPP modifiers on v_mov):
 // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror.  After the four steps every lane of a row holds
 // the row's reduction (the two mirror steps work because all lanes of a quad / half-row already agree).
