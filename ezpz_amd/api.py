@@ -601,14 +601,14 @@ def solve_batch(reqs, x0: np.ndarray, config: Optional[Config] = None, want_mask
     return x, st, prio, mask
 
 
-def specialized_source(records, n_vars: int, compile=False) -> str:
+def specialized_source(records, n_vars: int, compile=False, wave=False) -> str:
     """`ezpz_specialized_source`: the generated source of the request's class-specialised kernel ('' = none); with
     compile=True it is also compiled for gfx950 (hiprtc; no device needed) and a failure raises with the log;
     compile="cached": through the on-disk cache of code objects, like the solve entry points."""
     recs = stack_records(records)
     buf = C.create_string_buffer(1 << 22)
     rc = lib().ezpz_specialized_source(recs.ctypes.data if len(recs) else None, len(recs), int(n_vars),
-                                       2 if compile == "cached" else 1 if compile else 0, buf, len(buf))
+                                       (2 if compile == "cached" else 1 if compile else 0) | (4 if wave else 0), buf, len(buf))
     if rc < 0:
         raise RuntimeError("run-time compilation failed:\n" + buf.value.decode(errors="replace")[-4000:])
     return buf.value.decode() if rc > 0 else ""
@@ -642,6 +642,7 @@ def resolve_sides(records, values) -> np.ndarray:
 TEAM_AUTO_LISTS = 0xFFFFFFFE  # `team_size`: automatic, list-walk shapes only (never component-resident)
 TEAM_BATCH_LANES = 0xFFFFFFFD  # `team_size`: automatic, connected sketches one lane per system at every batch size
 TEAM_LATENCY_PHASES = 0xFFFFFFFC  # `team_size`: TEAM_AUTO_LATENCY without the record walk (dense phases instead)
+TEAM_LATENCY_WAVE = 0xFFFFFFFB  # `team_size`: TEAM_AUTO_LATENCY, a small system always on one wavefront per system where that form exists
 TEAM_AUTO_LATENCY = 0xFFFFFFFF  # `team_size`: choose for the latency of one solve instead of batch throughput (ezpz_amd.h)
 
 

@@ -170,6 +170,7 @@ struct EzpzSystem {
     CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
     DevBuf<unsigned char> jit_scratch;  // ... and, when it spreads a system over several workgroups, their reduction scratch
     std::unique_ptr<LanePlan> lane;  // small systems: one lane per system, run-time compiled (jit stands for it then)
+    CompJit* wave_jit = nullptr;     // ... and, for the latency of one solve, the same class on one wavefront per system
     // connected sketches in large batches: one lane per system, uniform program, state in global memory (batch_kernel.hip.hpp)
     std::unique_ptr<BatchPlan> lanes;
     uint32_t* dev_lanes = nullptr;
@@ -249,6 +250,7 @@ struct EzpzSystem {
         if (dev_lanes) (void)hipFree(dev_lanes);
         if (lanes_done) (void)hipEventDestroy(lanes_done);
         comp_jit_destroy(jit);
+        comp_jit_destroy(wave_jit);
     }
 };
 
@@ -647,6 +649,14 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         }
     }
     if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
+    if (s.lane && s.wave_jit && args.batch <= (uint64_t)s.lim.cus) {
+        // one solve (or a few) of a small system built for latency: one wavefront per system, sweeps and assembly across its
+        // lanes (jit_kernel.hip.hpp: wave_kernel), compiled like the lane kernel
+        if (s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.wave_jit);
+        int st = comp_jit_state(s.wave_jit);
+        if (st == 0 && (jit_sync() || s.launches.load(std::memory_order_relaxed) >= s.lim.policy.jit_after_launches)) st = comp_jit_request(s.wave_jit, jit_sync());
+        if (st == 2 && wave_jit_launch(s.wave_jit, *s.lane, comp_launch_args(args), s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+    }
     if (s.lane && s.jit) {  // a small system: one lane per system once the specialised kernel is compiled
         int st = comp_jit_state(s.jit);
         const EzpzLaunchPolicy& pol = s.lim.policy;
@@ -1501,7 +1511,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         const char* e = std::getenv("EZPZ_DEFER");  // EZPZ_DEFER=0: every system is analysed whole at creation (A/B runs)
         return !(e && e[0] == '0');
     }();
-    if (may_defer && team_size == EZPZ_TEAM_AUTO_LATENCY && comp_enabled0 && defer_enabled && !keep_comp) {
+    if (may_defer && (team_size == EZPZ_TEAM_AUTO_LATENCY || team_size == EZPZ_TEAM_LATENCY_WAVE) && comp_enabled0 && defer_enabled && !keep_comp) {
         std::unique_ptr<CompPlan> plan(new CompPlan());
         CompLimits cl;
         cl.lds_bytes = s.lim.lds_bytes;
@@ -1532,6 +1542,7 @@ static int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, ui
         return be.code;
     };
     const bool latency_phases = team_size == EZPZ_TEAM_LATENCY_PHASES;
+    if (team_size == EZPZ_TEAM_LATENCY_WAVE) team_size = EZPZ_TEAM_AUTO_LATENCY;  // (the wavefront form is chosen by ezpz_system_create)
     const bool for_latency = team_size == EZPZ_TEAM_AUTO_LATENCY || latency_phases;
     const bool batch_lanes = team_size == EZPZ_TEAM_BATCH_LANES;
     const bool auto_shape = team_size == 0 || for_latency || batch_lanes;
@@ -2055,6 +2066,19 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
         call_stamp(COLD_KERNEL_FOUND);
     } else if (s->lane) {
         s->jit = comp_jit_create_source(s->lane->jit_source, "ezpz_jit_lane");
+        static const bool wave_enabled = [] {
+            const char* e = std::getenv("EZPZ_JIT_WAVE");  // EZPZ_JIT_WAVE=0: one solve of a small system stays on one lane (A/B runs)
+            return !(e && e[0] == '0');
+        }();
+        // one solve of a small system on one wavefront per system: where the sweeps are worth spreading (measured: `square`,
+        // 8 variables / 4 non-linear constraints, 47 -> 40 us; 14 variables / 4 distances 63 -> 53; arc_radius, 8 / 1, 7.2 -> 8.5;
+        // a 4-variable linear system 12 -> 16) -- or always, when the caller asks for the form (EZPZ_TEAM_LATENCY_WAVE)
+        size_t non_linear = 0;
+        for (size_t i = 0; i < n_cs; ++i) non_linear += kind_is_linear(cs[i].kind) ? 0 : 1;
+        const bool pays = n_vars >= 8 && non_linear >= 3;
+        if (wave_enabled && !s->lane->wave_source.empty() &&
+            (team_size == EZPZ_TEAM_LATENCY_WAVE || (team_size == EZPZ_TEAM_AUTO_LATENCY && pays)))
+            s->wave_jit = comp_jit_create_source(s->lane->wave_source, "ezpz_jit_wave");
     }
     if (s->lanes) {
         HIP_TRY(hipMalloc((void**)&s->dev_lanes, s->lanes->blob.size() * 4));
@@ -2496,7 +2520,7 @@ struct CallBufs {
     EzpzSystem* res_sys = nullptr;
     uint64_t res_generation = 0;
     EzpzConfig res_cfg{};
-    bool res_jit = false;      // it was the topology's specialised kernel
+    int res_stage = 0;         // which of the topology's kernels it is: 0 interpreting, 1 specialised, 2 one wavefront per system
     uint32_t res_warn_cap = 0;
     bool res_log = false;
     ~CallBufs() {
@@ -2620,14 +2644,18 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
     }
     // ---- the topology's kernel still on the device from this thread's previous call? ------------------------------------------
     const unsigned lease_us = cb.bar == 1 ? resident_lease_us() : 0;
-    const bool jit_now = sys->jit && comp_jit_state(sys->jit) == 2;
+    // (which of the topology's kernels a launch would take now: a resident one of an earlier stage makes room for it)
+    auto kernel_stage = [&] {
+        return sys->wave_jit && comp_jit_state(sys->wave_jit) == 2 ? 2 : sys->jit && comp_jit_state(sys->jit) == 2 ? 1 : 0;
+    };
+    const int stage_now = kernel_stage();
     bool resident = cb.res_alive && cb.res_sys == sys && lease_us && std::memcmp(&cb.res_cfg, cfg, sizeof(EzpzConfig)) == 0 &&
-                    cb.res_jit == jit_now && cb.res_log == want_log && (!want_log || cb.res_warn_cap == warn_cap);
+                    cb.res_stage == stage_now && cb.res_log == want_log && (!want_log || cb.res_warn_cap == warn_cap);
     if (cb.res_alive && !resident) dismiss_resident(cb);
-    // (what launch() does for a topology solved again and again: its specialised kernel is asked for after so many solves)
-    if (sys->jit && !jit_now && !jit_sync() && comp_jit_state(sys->jit) == 0 &&
-        sys->launches.load(std::memory_order_relaxed) >= sys->lim.policy.jit_after_launches)
-        (void)comp_jit_request(sys->jit, false);
+    // (what launch() does for a topology solved again and again: its specialised kernels are asked for after so many solves)
+    if (!jit_sync() && sys->launches.load(std::memory_order_relaxed) >= sys->lim.policy.jit_after_launches)
+        for (CompJit* j : {sys->jit, sys->wave_jit})
+            if (j && comp_jit_state(j) == 0) (void)comp_jit_request(j, false);
     if (n) std::memcpy(x_in, x0, n * sizeof(double));
     // the request's tag: the generation of the launch that is to serve it (a resident kernel of an earlier launch that
     // still polls the word leaves when it sees another generation) and a sequence number
@@ -2696,7 +2724,7 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
             cb.res_alive = true;
             cb.res_sys = sys;
             cb.res_cfg = *cfg;
-            cb.res_jit = sys->jit && comp_jit_state(sys->jit) == 2;
+            cb.res_stage = stage_now;  // (a kernel that became ready during the launch is noticed by the next call)
             cb.res_log = want_log;
             cb.res_warn_cap = warn_cap;
         }
@@ -2791,6 +2819,12 @@ int ezpz_system_specialize(EzpzSystem* sys, int wait) {
     if (!sys->jit) return 0;
     const int st = comp_jit_request(sys->jit, wait != 0);
     if (st == kJitBudgetExhausted) return EZPZ_ERR_KERNEL_BUDGET;
+    // (a latency-shaped small system has a second kernel -- one wavefront per system: requested along; the state returned is
+    // the first one's unless the second failed)
+    if (st >= 0 && sys->wave_jit) {
+        const int sw = comp_jit_request(sys->wave_jit, wait != 0);
+        if (sw < 0 && sw != kJitBudgetExhausted) return EZPZ_ERR_HIP;
+    }
     return st < 0 ? EZPZ_ERR_HIP : st;
 }
 
@@ -2799,10 +2833,12 @@ long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_var
     CompLimits cl;
     LanePlan lane;
     std::string text;
+    const bool wave = (compile & 4) != 0;  // the one-wavefront-per-system form of a small system instead of its lane form
+    compile &= 3;
     if (comp_plan_build(cs, n_cs, n_vars, cl, plan))
-        text = plan.jit_source;
+        text = wave ? std::string() : plan.jit_source;
     else if (lane_plan_build(cs, n_cs, n_vars, lane))
-        text = lane.jit_source;
+        text = wave ? lane.wave_source : lane.jit_source;
     if (text.empty()) return 0;
     const std::string source = text;
     long rc = (long)text.size();

@@ -291,6 +291,47 @@ std::string hexf(double v) {
     return std::string("(") + buf + ")";
 }
 
+// The elimination of one class as straight-line statements on the scalars D<v> (diagonal), V<v> (right-hand side, then y,
+// then the step) and L<s> (strict lower entries), which the caller has assembled: level by level the left-looking Cholesky
+// with the forward substitution riding along, then the backward substitution into d[] and dmax -- the same statements in
+// the lane kernels' `solve` and the wavefront kernel's `tail`.  `fast`: divisions by a column's diagonal through its
+// refined reciprocal (jit_kernel.hip.hpp: recip_of / div_by).
+void emit_elimination(std::string& o, const Class& cl, bool fast, bool fastdiv) {
+    const Program& Q = cl.Q;
+    auto S = [](uint32_t v) { return std::to_string(v); };
+    auto div = [&](const std::string& num, uint32_t col) {
+        return fast && fastdiv ? "ezpz::jit::div_by(" + num + ", D" + S(col) + ", Y" + S(col) + ", ok)" : num + " / D" + S(col);
+    };
+    const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
+    for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+        const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
+        for (uint32_t v = c0; v < c1; ++v) {
+            for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q) {
+                const std::string l = "L" + S(Q.fwd_items[2 * q]);
+                o += "        D" + S(v) + " -= " + l + " * " + l + "; V" + S(v) + " -= " + l + " * V" + S(Q.fwd_items[2 * q + 1]) + ";\n";
+            }
+            o += "        if (!(D" + S(v) + " > 0.0)) bad = true;\n";
+            o += "        D" + S(v) + " = sqrt(D" + S(v) + ");";
+            if (fast && fastdiv) o += " const double Y" + S(v) + " = ezpz::jit::recip_of(D" + S(v) + ", ok);";
+            o += " V" + S(v) + " = " + div("V" + S(v), v) + ";\n";
+        }
+        for (uint32_t s2 = s0; s2 < s1; ++s2) {
+            for (uint32_t q = Q.lpair_ptr[s2]; q < Q.lpair_ptr[s2 + 1]; ++q)
+                o += "        L" + S(s2) + " -= L" + S(Q.lpairs[2 * q]) + " * L" + S(Q.lpairs[2 * q + 1]) + ";\n";
+            o += "        L" + S(s2) + " = " + div("L" + S(s2), Q.l_col[s2]) + ";\n";
+        }
+    }
+    for (uint32_t lv = part.nlev; lv-- > 0;) {
+        const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+        for (uint32_t v = c0; v < c1; ++v) {
+            for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
+                o += "        V" + S(v) + " -= L" + S(Q.bwd_items[2 * q]) + " * V" + S(Q.bwd_items[2 * q + 1]) + ";\n";
+            o += "        V" + S(v) + " = " + div("V" + S(v), v) + "; d[" + S(v) + "] = V" + S(v) + "; dmax = ezpz::dev::fmax_abs(dmax, V" + S(v) + ");\n";
+        }
+    }
+}
+
 // `lane`: the class is a whole system solved by one lane (jit_kernel.hip.hpp, lane_kernel): constraint parameters and
 // the caller's constraint positions are literals, and load / store / pos_of map the caller's numbering.
 // EZPZ_JIT_FASTDIV (measurements): bit 0 linear classes, bit 1 non-linear classes of the component kernels, bit 2 the
@@ -376,34 +417,7 @@ void emit_class(std::string& o, size_t k, const Class& cl, bool lane = false, co
             for (uint32_t q = Q.apair_ptr[s2]; q < Q.apair_ptr[s2 + 1]; ++q)
                 o += "        L" + S(s2) + " += " + jv(Q.apairs[2 * q]) + " * " + jv(Q.apairs[2 * q + 1]) + ";\n";
         }
-        const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
-        for (uint32_t lv = 0; lv < part.nlev; ++lv) {
-            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
-            const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
-            for (uint32_t v = c0; v < c1; ++v) {
-                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q) {
-                    const std::string l = "L" + S(Q.fwd_items[2 * q]);
-                    o += "        D" + S(v) + " -= " + l + " * " + l + "; V" + S(v) + " -= " + l + " * V" + S(Q.fwd_items[2 * q + 1]) + ";\n";
-                }
-                o += "        if (!(D" + S(v) + " > 0.0)) bad = true;\n";
-                o += "        D" + S(v) + " = sqrt(D" + S(v) + ");";
-                if (fast && fastdiv) o += " const double Y" + S(v) + " = ezpz::jit::recip_of(D" + S(v) + ", ok);";
-                o += " V" + S(v) + " = " + div("V" + S(v), v) + ";\n";
-            }
-            for (uint32_t s2 = s0; s2 < s1; ++s2) {
-                for (uint32_t q = Q.lpair_ptr[s2]; q < Q.lpair_ptr[s2 + 1]; ++q)
-                    o += "        L" + S(s2) + " -= L" + S(Q.lpairs[2 * q]) + " * L" + S(Q.lpairs[2 * q + 1]) + ";\n";
-                o += "        L" + S(s2) + " = " + div("L" + S(s2), Q.l_col[s2]) + ";\n";
-            }
-        }
-        for (uint32_t lv = part.nlev; lv-- > 0;) {
-            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
-            for (uint32_t v = c0; v < c1; ++v) {
-                for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
-                    o += "        V" + S(v) + " -= L" + S(Q.bwd_items[2 * q]) + " * V" + S(Q.bwd_items[2 * q + 1]) + ";\n";
-                o += "        V" + S(v) + " = " + div("V" + S(v), v) + "; d[" + S(v) + "] = V" + S(v) + "; dmax = ezpz::dev::fmax_abs(dmax, V" + S(v) + ");\n";
-            }
-        }
+        emit_elimination(o, cl, fast != 0, fastdiv);
         o += std::string("        (void)J; (void)r;") + (fast ? " (void)ok;" : "") + "\n        return bad;\n    }\n";
     }
     // unsatisfied check (lib.rs:305-327, :358-370)
@@ -835,6 +849,103 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
     return true;
 }
 
+// ---- one wavefront per system (jit_kernel.hip.hpp, wave_kernel): the latency shape of a small system -------------------------------
+// The lane class (same statements, same order) plus what spreads the sweeps and the assembly over 64 lanes: the constraint
+// records as a table (lane ci evaluates constraint ci through a dispatch over the kinds present), the operand pairs of
+// every assembled quantity -- D_v and V_v per variable, L_s per strict lower entry -- padded to the longest list (a padding
+// pair multiplies the zero behind the Jacobian's slots), and the elimination as `tail` on the assembled quantities.
+// Empty when a list is too long for a lane's registers (a hub variable of dozens of constraints): the lane kernel serves.
+void emit_wave(std::string& o, const std::string& cls, const Class& cl, const EzpzConstraint* cs, bool unit_weights) {
+    o.clear();
+    const Program& Q = cl.Q;
+    const uint32_t nv = Q.c.n_vars, m = Q.c.n_rows, zj = Q.c.zj, zlo = Q.c.zlo, nc = Q.c.n_cons;
+    if (nc > 64 || m > 64 || nv > 64 || zj + 1 + m >= 0xFFFFu) return;
+    auto S = [](uint32_t v) { return std::to_string(v); };
+    const uint32_t nq = 2 * nv + zlo, nqr = (nq + 63) / 64;
+    // operand pairs (a | b << 16): indices into A = [J slots | 0 | -r rows]
+    std::vector<std::vector<uint32_t>> pairs(nq);
+    for (uint32_t v = 0; v < nv; ++v)
+        for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
+            const uint32_t slot = Q.colj_items[2 * q], row = Q.colj_items[2 * q + 1];
+            pairs[v].push_back(slot | (slot << 16));
+            pairs[nv + v].push_back(slot | ((zj + 1 + row) << 16));
+        }
+    for (uint32_t s2 = 0; s2 < zlo; ++s2)
+        for (uint32_t q = Q.apair_ptr[s2]; q < Q.apair_ptr[s2 + 1]; ++q) pairs[2 * nv + s2].push_back(Q.apairs[2 * q] | (Q.apairs[2 * q + 1] << 16));
+    uint32_t pmax = 1;
+    for (const auto& p : pairs) pmax = std::max<uint32_t>(pmax, (uint32_t)p.size());
+    if (pmax > 16 || nqr > 3) return;
+    o = cls;
+    // tables
+    o += "namespace {\n__device__ const ezpz::DevCon kWaveCons[" + S(nc) + "] = {\n";
+    for (uint32_t ci = 0; ci < nc; ++ci) {
+        const DevCon& d = Q.cons[ci];
+        o += "    {{";
+        for (int i = 0; i < 8; ++i) o += (i ? ", " : "") + S(d.ids[i]);
+        o += "}, " + hexf(cs[d.pos].param) + ", " + hexf(d.weight) + ", " + S(d.row0) + ", " + S(d.jbase) + ", " + S(d.pos) + ", " + S(d.kind) +
+             ", " + S(d.tag) + ", " + S(d.nrows) + ", " + S(d.nslots) + ", {";
+        for (int i = 0; i < 16; ++i) o += (i ? ", " : "") + S(d.jloc[i]);
+        o += "}},\n";
+    }
+    o += "};\n__device__ const uint32_t kWavePairs[" + S(nqr * pmax * 64) + "] = {";
+    const uint32_t pad = zj | (zj << 16);
+    for (uint32_t k = 0; k < nqr; ++k)
+        for (uint32_t p = 0; p < pmax; ++p)
+            for (uint32_t l = 0; l < 64; ++l) {
+                const uint32_t q = k * 64 + l;
+                o += (((k * pmax + p) * 64 + l) % 16 == 0 ? "\n    " : " ") + S(q < nq && p < pairs[q].size() ? pairs[q][p] : pad) + "u,";
+            }
+    o += "\n};\n";
+    // rows in request order (constraints by position, their rows in order), the caller's id of every internal variable
+    std::vector<uint32_t> order(nc);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return Q.cons[a].pos < Q.cons[b].pos; });
+    o += "__device__ const uint8_t kWaveVarOf[" + S(nv) + "] = {";
+    for (uint32_t v = 0; v < nv; ++v) o += S(Q.var_of[v]) + ", ";
+    o += "};\n";
+    if (cl.linear) {
+        o += "__device__ const double kWaveJ[" + S(std::max(zj, 1u)) + "] = {";
+        for (uint32_t s2 = 0; s2 < zj; ++s2) o += hexf(cl.jconst[s2]) + ", ";
+        o += "};\n";
+    }
+    o += "}  // namespace\n\nstruct ClsW : Cls0 {\n";
+    o += "    static constexpr int ZJ = " + S(zj) + ", NQ = " + S(nq) + ", PMAX = " + S(pmax) + ";\n";
+    o += "    static __device__ __forceinline__ DevCon con(int ci) { return kWaveCons[ci]; }\n";
+    o += "    static __device__ __forceinline__ uint32_t pair(int k, int p, int lane) { return kWavePairs[(k * PMAX + p) * 64 + lane]; }\n";
+    // the sum of squares and maximum of a residual vector in request order, straight-line (literal LDS offsets)
+    o += "    static __device__ __forceinline__ void sum_rows(const double* rows, double& sq, double& mx) {\n        double w;\n";
+    for (uint32_t ci : order)
+        for (uint32_t rr = 0; rr < Q.cons[ci].nrows; ++rr)
+            o += "        w = rows[" + S(Q.cons[ci].row0 + rr) + "]; sq += w * w; mx = ezpz::dev::fmax_abs(mx, w);\n";
+    o += "        (void)w; (void)rows;\n    }\n";
+    o += "    static __device__ __forceinline__ uint32_t var_of(int v) { return kWaveVarOf[v]; }\n";
+    o += std::string("    static __device__ __forceinline__ double jconst(int s) { return ") + (cl.linear ? "kWaveJ[s]" : "0.0") + "; }\n";
+    // the kinds present, each with its evaluator instantiated for that kind alone
+    std::vector<uint32_t> kinds;
+    for (const DevCon& d : Q.cons)
+        if (std::find(kinds.begin(), kinds.end(), (uint32_t)d.kind) == kinds.end()) kinds.push_back(d.kind);
+    o += "    template <class XP>\n    static __device__ __forceinline__ bool residual_of(const DevCon& c, XP xs, double& r0, double& r1) {\n        switch (c.kind) {\n";
+    for (uint32_t k : kinds)
+        o += "        case " + S(k) + ": { DevCon k = c; k.kind = " + S(k) + "; return ezpz::dev::con_residual<LINEAR>(k, xs, r0, r1); }\n";
+    o += "        default: r0 = 0.0; r1 = 0.0; return false;\n        }\n    }\n";
+    o += "    template <class XP, class JP>\n    static __device__ __forceinline__ bool jacobian_of(const DevCon& c, XP xs, const ezpz::dev::JacWriter<JP>& w) {\n        switch (c.kind) {\n";
+    for (uint32_t k : kinds)
+        o += "        case " + S(k) + ": { DevCon k = c; k.kind = " + S(k) + "; return ezpz::dev::con_jacobian<false>(k, xs, w); }\n";
+    o += "        default: return false;\n        }\n    }\n";
+    const bool fastdiv = (fastdiv_mask() >> 2) & 1u;
+    for (int fast = 1; fast >= 0; --fast) {
+        o += std::string("    static __device__ __forceinline__ bool ") + (fast ? "tail" : "tail_exact") +
+             "(const double* Q, double lambda, double* d, double& dmax" + (fast ? ", bool& ok" : "") + ") {\n        bool bad = false;\n";
+        for (uint32_t v = 0; v < nv; ++v)
+            o += "        double D" + S(v) + " = Q[" + S(v) + "] + lambda, V" + S(v) + " = Q[" + S(nv + v) + "];\n";
+        for (uint32_t s2 = 0; s2 < zlo; ++s2) o += "        double L" + S(s2) + " = Q[" + S(2 * nv + s2) + "];\n";
+        emit_elimination(o, cl, fast != 0, fastdiv);
+        o += std::string("        (void)Q; (void)lambda;") + (fast ? " (void)ok;" : "") + "\n        return bad;\n    }\n";
+    }
+    o += "};\n\nextern \"C\" __global__ void __launch_bounds__(64) ezpz_jit_wave(const ezpz::jit::LaneArgs a) {\n";
+    o += std::string("    ezpz::jit::wave_kernel<ClsW, ") + (unit_weights ? "true" : "false") + ">(a);\n}\n";
+}
+
 // ---- one lane per system (jit_kernel.hip.hpp, lane_kernel) --------------------------------------------------------------------------
 bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LanePlan& plan) {
     plan = LanePlan();
@@ -867,15 +978,17 @@ bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LaneP
         }
     }
     cl.H.ninst_pad = 1;
+    std::string cls = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
+    emit_class(cls, 0, cl, true, cs);
     std::string& o = plan.jit_source;
-    o = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
-    emit_class(o, 0, cl, true, cs);
+    o = cls;
     static const char* env_lb = std::getenv("EZPZ_JIT_LANE_BOUNDS");  // e.g. "256, 2" -- for measurements
     o += std::string("extern \"C\" __global__ void __launch_bounds__(") + (env_lb ? env_lb : "256") + ") ezpz_jit_lane(const ezpz::jit::LaneArgs a) {\n";
     o += std::string("    ezpz::jit::lane_kernel<Cls0, ") + (plan.unit_weights ? "true" : "false") + ">(a);\n}\n";
     plan.n_vars = (uint32_t)n_vars;
     plan.n_cons = (uint32_t)n_cs;
     plan.n_rows = Q.c.n_rows;
+    emit_wave(plan.wave_source, cls, cl, cs, plan.unit_weights);
     return true;
 }
 

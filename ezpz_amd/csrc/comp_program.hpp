@@ -138,6 +138,7 @@ namespace ezpz {
 // compiled straight-line code, every lane running the whole LM loop of its own system.
 struct LanePlan {
     std::string jit_source;
+    std::string wave_source;  // the same class on one wavefront per system (one solve()'s shape), or empty
     uint32_t n_vars = 0, n_cons = 0, n_rows = 0;
     bool unit_weights = true;
 };
@@ -168,6 +169,7 @@ int batch_launch(const BatchPlan& plan, const uint32_t* dev_blob, double* dev_ws
 struct CompJit;
 CompJit* comp_jit_create(const CompPlan& plan);
 CompJit* comp_jit_create_source(const std::string& source, const char* entry);
+int wave_jit_launch(CompJit* jit, const LanePlan& plan, const CompLaunch& launch, int device, int cus, void* stream);
 int lane_jit_launch(CompJit* jit, const LanePlan& plan, const CompLaunch& launch, int device, int cus, void* stream);
 void comp_jit_destroy(CompJit* jit);
 int comp_jit_request(CompJit* jit, bool wait);

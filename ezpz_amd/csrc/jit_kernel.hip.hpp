@@ -896,5 +896,220 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
     } while (resident_next(done, born, &resident_word));
 }
 
+// ---- one WAVEFRONT per system: the latency shape of a small system ----------------------------------------------------------------
+// One solve() call of a sketch fixture is one lane of lane_kernel above walking ~2000 dependent instructions per LM
+// iteration at one instruction per 6-8 cycles: `square` 6.7 us per iteration.  Of those, the constraint sweeps and the
+// assembly of the normal equations are embarrassingly parallel -- a constraint per lane, a sum of JtJ / Jt r per lane --
+// and only the elimination is a chain.  This kernel keeps the lane kernel's arithmetic OPERATION FOR OPERATION (same
+// class program, same order of every sum: bit-identical results, tests compare the two) and spreads the parallel part over
+// the 64 lanes of one wavefront:
+//   sweeps      lane ci evaluates constraint ci (its DevCon in registers, from a table in the code object); lanes diverge
+//               only by the kinds present (the generated dispatch lists those);
+//   assembly    lane q forms quantity q -- the diagonal / right-hand side of variable v, or one entry of the strict lower
+//               part -- as the lane kernel's sum over its (a, b) operand pairs, padded to the longest list;
+//   elimination every lane runs the lane kernel's straight-line factorisation and substitutions on the assembled
+//               quantities (uniform: one lane's cost), so the step needs no broadcast;
+// values live in LDS (x, the Jacobian's slots followed by a zero and -r, the assembled quantities, d): one wavefront, so
+// LDS operations are ordered without barriers.  C: the generated class (ClsW: the lane class plus tables and dispatch).
+// Between two phases of the wavefront kernel whose lanes exchange values through LDS: the lanes run in lockstep and the LDS
+// executes a wavefront's operations in issue order, so no barrier instruction is needed -- but the COMPILER must not move a
+// lane's LDS loads above the stores other lanes make before them in program order (it would: a lane that stores nothing in
+// a phase looks free to load early), nor keep values other lanes overwrite in registers.  A wavefront-scope fence is that
+// promise in its memory model, and costs an s_waitcnt at most.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class C, bool UNIT_W>
+__device__ __forceinline__ void wave_kernel(const LaneArgs& a) {
+    using namespace ezpz::dev;
+    constexpr int NV = C::NV, M = C::M > 0 ? C::M : 1, ZJ = C::ZJ, NQ = C::NQ, NQR = (NQ + 63) / 64, PMAX = C::PMAX;
+    constexpr int O_A = 0, O_NR = ZJ + 1, O_X = ZJ + 1 + M, O_XT = O_X + NV, O_R = O_XT + NV, O_RN = O_R + M, O_Q = O_RN + M,
+                  O_D = O_Q + NQ, LDS_DOUBLES = O_D + NV;
+    __shared__ double lds[LDS_DOUBLES];
+    __shared__ unsigned long long resident_word;
+    double* const A = lds + O_A;    // Jacobian slots, then one zero (the operand of padding pairs), then -r by row
+    double* const nr = lds + O_NR;  // -r (the right-hand side's operands)
+    double* const xs = lds + O_X;
+    double* const xt = lds + O_XT;
+    double* const r = lds + O_R;
+    double* const rn = lds + O_RN;
+    double* const Q = lds + O_Q;
+    double* const dl = lds + O_D;
+    const int lane = threadIdx.x;
+    const bool is_con = lane < C::NC;
+    const DevCon c = C::con(is_con ? lane : 0);
+    uint32_t pr[NQR][PMAX];
+#pragma unroll
+    for (int k = 0; k < NQR; ++k)
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) pr[k][p] = C::pair(k, p, lane);
+    if (lane == 0) A[ZJ] = 0.0;
+    if constexpr (C::LINEAR) {
+        for (int s2 = lane; s2 < ZJ; s2 += 64) A[s2] = C::jconst(s2);
+    }
+    wave_sync();
+    const unsigned long long born = wall_clock64();
+    DoneWord done = a.done;
+    do {
+    for (uint64_t sys = blockIdx.x; sys < a.batch; sys += gridDim.x) {
+        uint32_t nwarn = 0;
+        auto log_mask = [&](unsigned long long m, uint32_t p) {  // Warning::Degenerate, in evaluation order (solver.rs:340-346)
+            while (m) {
+                const int ci = __builtin_ctzll(m);
+                m &= m - 1;
+                if (lane == 0 && a.warn_log && nwarn < a.warn_cap) a.warn_log[sys * a.warn_cap + nwarn] = ((uint64_t)p << 32) | C::pos_of(ci);
+                ++nwarn;
+            }
+        };
+        // residuals of the constraints at `xv` into `out` (weighted) and, NEG, their negatives into nr; degenerate lanes
+        auto residuals_at = [&](const double* xv, double* out, bool neg) -> unsigned long long {
+            bool deg = false;
+            if (is_con) {
+                double r0, r1;
+                deg = C::residual_of(c, xv, r0, r1);
+                const double w0 = c.weight * r0;
+                out[c.row0] = w0;
+                if (neg) nr[c.row0] = -w0;
+                if (c.nrows > 1) {
+                    const double w1 = c.weight * r1;
+                    out[c.row0 + 1] = w1;
+                    if (neg) nr[c.row0 + 1] = -w1;
+                }
+            }
+            wave_sync();
+            return C::LINEAR ? 0ull : __ballot(deg);
+        };
+        auto jacobian_at = [&](const double* xv) -> unsigned long long {
+            if constexpr (C::LINEAR) {
+                return 0ull;
+            } else {
+                bool deg = false;
+                if (is_con) {
+                    JacWriter<double*> w;
+                    w.jv = A;
+                    w.jbase = c.jbase;
+                    w.loc[0] = ((const uint32_t*)c.jloc)[0], w.loc[1] = ((const uint32_t*)c.jloc)[1];
+                    w.loc[2] = ((const uint32_t*)c.jloc)[2], w.loc[3] = ((const uint32_t*)c.jloc)[3];
+                    w.weight = c.weight;
+                    deg = C::jacobian_of(c, xv, w);
+                }
+                wave_sync();
+                return __ballot(deg);
+            }
+        };
+        // the sum of squares and maximum in request order, on every lane alike (the reference's sequential sum over the rows:
+        // the accept test `sum < previous` of a stalled solve hinges on its last bit)
+        auto sum_rows = [&](const double* rows, double& sq, double& mx) {
+            sq = 0.0;
+            mx = __builtin_nan("");
+            C::sum_rows(rows, sq, mx);
+        };
+        // ---- load; eval() (newton.rs:45, :232-236) ----------------------------------------------------------------------------
+        wave_sync();  // (the previous system's last reads of the values)
+        if (lane < NV) xs[lane] = a.x0[sys * a.n_row + C::var_of(lane)];
+        wave_sync();
+        log_mask(residuals_at(xs, r, true), 0);
+        log_mask(jacobian_at(xs), 1);
+        double residual_sq, largest;
+        sum_rows(r, residual_sq, largest);
+        double lambda = a.initial_lambda;
+        uint32_t it = 0, pass = 2, iterations = a.max_iterations, converged = 0;
+        bool r_is_at_x = true;
+        for (;;) {
+            if (it >= a.max_iterations) break;            // newton.rs:141-144
+            if (largest <= a.residual_tolerance) {        // newton.rs:50-60
+                iterations = it;
+                converged = 1;
+                break;
+            }
+            // normal equations: quantity q = the lane kernel's sum over its operand pairs (newton.rs:73-86)
+#pragma unroll
+            for (int k = 0; k < NQR; ++k) {
+                double acc = 0.0;
+#pragma unroll
+                for (int p = 0; p < PMAX; ++p) acc += A[pr[k][p] & 0xFFFFu] * A[pr[k][p] >> 16];
+                if (k * 64 + lane < NQ) Q[k * 64 + lane] = acc;
+            }
+            wave_sync();
+            double dmax = __builtin_nan("");
+            bool ok = true;
+            bool bad = C::tail(Q, lambda, dl, dmax, ok);
+            if (!ok && !bad) {  // an operand outside the short division's range: plain divisions
+                dmax = __builtin_nan("");
+                bad = C::tail_exact(Q, lambda, dl, dmax);
+            }
+            wave_sync();  // (every lane has written the same d: read back by lane index below)
+            if (bad) {  // LltError::Numeric: lambda *= 10, burn the iteration (newton.rs:93-99)
+                lambda *= LM_LAMBDA_INCR;
+                ++it;
+                continue;
+            }
+            if (lane < NV) xt[lane] = xs[lane] + dl[lane];  // newton.rs:111-114
+            wave_sync();
+            log_mask(residuals_at(xt, rn, false), pass++);
+            double sq, mx;
+            sum_rows(rn, sq, mx);
+            if (sq < residual_sq) {  // strict, newton.rs:118
+                if (lane < NV) xs[lane] = xt[lane];
+                if (lane < C::M) {
+                    const double w = rn[lane];
+                    r[lane] = w;
+                    nr[lane] = -w;
+                }
+                lambda *= LM_LAMBDA_DECR;
+                residual_sq = sq;
+                largest = mx;
+                r_is_at_x = true;
+                wave_sync();
+                log_mask(jacobian_at(xs), pass++);  // newton.rs:121: refresh_jacobian
+            } else {  // reject: x += d, x -= d like the reference (newton.rs:124-131), not a copy
+                if (lane < NV) xs[lane] = xt[lane] - dl[lane];
+                lambda *= LM_LAMBDA_INCR;
+                r_is_at_x = false;
+                wave_sync();
+            }
+            if (dmax <= a.step_tolerance) {  // newton.rs:134-139
+                iterations = it;
+                converged = 1;
+                break;
+            }
+            ++it;
+        }
+        // ---- unsatisfied check (lib.rs:305-327, :358-370) and write-back --------------------------------------------------------------
+        uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
+        const bool use_r = r_is_at_x && UNIT_W;
+        bool unsat_lane = false;
+        if (!(use_r && largest < EPS && !isnan(residual_sq)) && is_con) {
+            double r0, r1;
+            if (use_r) {
+                r0 = r[c.row0];
+                r1 = c.nrows > 1 ? r[c.row0 + 1] : 0.0;
+            } else {
+                C::residual_of(c, xs, r0, r1);
+                if (c.nrows <= 1) r1 = 0.0;
+            }
+            unsat_lane = !(fabs(r0) < EPS) || !(fabs(r1) < EPS);
+        }
+        if (mask && is_con) mask[c.pos] = unsat_lane ? 1 : 0;
+        const uint32_t n_unsat = (uint32_t)__popcll(__ballot(unsat_lane));
+        if (lane < NV) a.x_out[sys * a.n_row + C::var_of(lane)] = xs[lane];
+        if (lane == 0) {
+            EzpzStatus st;
+            st.iterations = iterations;
+            st.converged = converged;
+            st.n_unsatisfied = n_unsat;
+            st.n_warnings = nwarn;
+            st.final_residual_inf = (C::M > 0) ? largest : 0.0;
+            st.final_lambda = lambda;
+            a.status[sys] = st;
+        }
+    }
+    publish_done(done);
+    } while (resident_next(done, born, &resident_word));
+}
+
 }  // namespace jit
 }  // namespace ezpz

@@ -195,6 +195,12 @@ const char* ezpz_error_string(int err);
 /* EZPZ_TEAM_AUTO_LATENCY without the record walk (team_mode 4): one connected sketch then ends its elimination with
  * dense phases on the barrier workgroup (team_mode 2), as every latency shape did before round 3 (A/B runs and tests) */
 #define EZPZ_TEAM_LATENCY_PHASES 0xFFFFFFFCu
+/* EZPZ_TEAM_AUTO_LATENCY, and a small system (<= 20 variables) runs one solve on one WAVEFRONT per system -- constraint
+ * sweeps and the assembly of the normal equations across its lanes, the lane kernel's arithmetic operation for operation
+ * -- whenever that form exists; EZPZ_TEAM_AUTO_LATENCY itself takes it only where it pays (>= 8 variables and >= 3
+ * constraints of the non-linear kinds: `square` 47 -> 40 us of kernel, `two rectangles dependent` 63 -> 53; a 4-variable
+ * linear system loses 12 -> 16) (A/B runs and tests) */
+#define EZPZ_TEAM_LATENCY_WAVE 0xFFFFFFFBu
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);
 void ezpz_system_destroy(EzpzSystem* sys);

@@ -304,6 +304,9 @@ def test_specialized_kernel_source_compiles_without_a_device():
         recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
         src = E.specialized_source(recs, ref.num_vars, compile=True)
         assert "ezpz_jit_lane" in src and "lane_kernel" in src, case
+        # ... and, for the latency of one solve, the same class on one wavefront per system (tables + dispatch + tail)
+        wsrc = E.specialized_source(recs, ref.num_vars, compile=True, wave=True)
+        assert "ezpz_jit_wave" in wsrc and "kWavePairs" in wsrc and wsrc.startswith(src[: src.index('extern "C"')]), case
     # too large for either form: a connected sketch of 60 variables
     import gen
 

@@ -209,6 +209,83 @@ def test_random_systems_of_all_kinds_on_the_lane_kernel(E):
     assert compared >= 400 and exact >= 40 and len(kinds_seen) == O.NUM_KINDS, (compared, exact, sorted(kinds_seen))
 
 
+def test_one_wavefront_per_system_equals_the_lane_kernel_bitwise(E):
+    """The latency shape of a small system (jit_kernel.hip.hpp: wave_kernel -- what one ezpz_solve call of a sketch fixture
+    runs on): constraint sweeps and the assembly of the normal equations across the 64 lanes of a wavefront, the lane
+    kernel's arithmetic operation for operation.  Every fixture, jittered and wild starts, weights, degenerate
+    evaluations, NaN guesses, two configurations; random systems of all 25 kinds: values, statuses, unsatisfied masks
+    and warning logs bit for bit the lane kernel's (which the tests above hold against the oracle) -- and ezpz_solve
+    itself switches to it after 256 calls without changing an answer."""
+    import ctypes as C
+
+    def both(recs, n, x0, cfg):
+        lane = E.System(recs, n)
+        wave = E.System(recs, n, team_size=E.TEAM_LATENCY_WAVE)
+        assert lane.specialize(wait=True) == 2 and wave.specialize(wait=True) == 2
+        assert "ezpz_jit_wave" in E.specialized_source(recs, n, wave=True)
+        out = []
+        for sysobj in (lane, wave):
+            x, st, logs = sysobj.solve_batch_logged(x0, E.Config(**cfg), warn_cap=256)
+            _, _, mask = sysobj.solve_batch(x0, E.Config(**cfg), want_mask=True)
+            out.append((x, st, logs, mask))
+        (xl, stl, logl, ml), (xw, stw, logw, mw) = out
+        assert np.array_equal(xl, xw, equal_nan=True)
+        for f in stl.dtype.names:
+            assert np.array_equal(stl[f], stw[f], equal_nan=True), f
+        assert logl == logw and np.array_equal(ml, mw)
+        return stw
+
+    checked = 0
+    for name in sorted(os.listdir(os.path.join(GOLDEN, "test_cases"))):
+        ref = T.load(read_case(name))
+        if ref.num_vars > 20 or len(ref.constraints) > 40 or not len(ref.constraints):
+            continue
+        recs = O.stack([O.set_from_initial_values(c, ref.guesses) for c in ref.constraints])
+        if not E.specialized_source(recs, ref.num_vars, wave=True):
+            continue
+        n = ref.num_vars
+        x0 = np.concatenate([ref.guesses[None, :], ref.guesses[None, :] + gen.keyed_uniform(3, 40, n, -0.3, 0.3),
+                             gen.keyed_uniform(4, 20, n, -8.0, 8.0)])
+        x0[7, 0] = np.nan
+        for cfg in (dict(), dict(initial_lambda=1e-30, max_iterations=9)):
+            both(recs, n, x0, cfg)  # (a device holds > 61 wavefronts: the batch runs one system per workgroup)
+            checked += 1
+    assert checked >= 40
+    # weights, degenerate starts, failed pivots
+    recs = O.stack([O.distance((0, 1), (2, 3), 3.0), O.fixed(0, 0.0, weight=2.5), O.fixed(1, 0.0), O.horizontal((0, 1), (2, 3)),
+                    O.fixed(2, 3.0, weight=0.5), O.points_at_angle((0, 1), (2, 3), (4, 5), ("deg", 90.0)), O.fixed(5, 2.0)])
+    x0 = gen.keyed_uniform(5, 200, 6, -2.0, 2.0)
+    x0[::7, 2:4] = x0[::7, 0:2]
+    st = both(recs, 6, x0, dict())
+    assert int(st["n_warnings"].sum()) > 20
+    # random systems of all kinds
+    rng = np.random.default_rng(99)
+    kinds = set()
+    for _ in range(40):
+        nvars = int(rng.integers(4, 13))
+        cons = []
+        for _ in range(int(rng.integers(1, 9))):
+            c = gen.arb_constraint(rng, int(rng.integers(0, O.NUM_KINDS)), hi=nvars)
+            c["weight"] = float(rng.choice([1.0, 1.0, 0.25, 3.0]))
+            cons.append(c)
+        recs = O.stack(cons)
+        if not E.specialized_source(recs, nvars, wave=True):
+            continue
+        kinds.update(int(k) for k in recs["kind"])
+        both(recs, nvars, rng.uniform(-8.0, 8.0, (24, nvars)), dict(max_iterations=int(rng.choice([35, 10, 60]))))
+    assert len(kinds) >= 20
+    # ezpz_solve: the same answer before and after its topology's kernels take over (and from the resident kernel)
+    ref = T.load(read_case("square"))
+    first = E.solve_records(ref.constraints, ref.variables())
+    for _ in range(400):
+        got = E.solve_records(ref.constraints, ref.variables())
+    import time
+    time.sleep(1.5)
+    for _ in range(20):
+        got = E.solve_records(ref.constraints, ref.variables())
+        assert got.iterations == first.iterations and np.allclose(got.final_values, first.final_values, rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("npts,seed", [(12, 5), (30, 1), (75, 2), (150, 3)])
 def test_connected_sketches_lanes_across_the_batch(E, npts, seed):
     """Device-filling batches (>= 64 x 2 x CUs systems; here forced with TEAM_BATCH_LANES) of one connected sketch of
