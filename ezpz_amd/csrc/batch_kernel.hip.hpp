@@ -40,7 +40,7 @@ struct BatchArgs {
     // Stragglers (optional): once a wavefront has no system left to take and at most `strag_lanes` of its lanes are still
     // working, those lanes hand their systems over -- the system's index goes on this list, its current values to x_out, its
     // LM state (lambda, iteration and pass numbers, warnings so far) to `strag_state`, and the lane drops it; the per-system
-    // teams RESUME the listed systems after this kernel (api.hip; lm_kernel.hip.hpp: LmResume) -- a straggler is typically
+    // teams RESUME the listed systems after this kernel (launch.hip; lm_kernel.hip.hpp: LmResume) -- a straggler is typically
     // one or two iterations from done, and solving it again from its guesses cost the teams nine.
     uint32_t* strag_list;
     uint32_t* strag_count;

@@ -1,5 +1,5 @@
 // Launch of the component-resident LM kernel (comp_kernel.hip.hpp) -- its own translation unit so that the two kernel
-// builds compile beside the list-walk kernels of api.hip.
+// builds compile beside the list-walk kernels of launch.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -17,7 +17,7 @@ namespace {
 template <bool LIN>
 int launch_build(const CompPlan& plan, const CompArgs& args, int device, int cus, size_t lds_limit, hipStream_t stream) {
     auto kernel = comp_solve_kernel<LIN>;
-    static std::atomic<bool> raised[16];  // per kernel build and device (see launch_kernel in api.hip)
+    static std::atomic<bool> raised[16];  // per kernel build and device (see launch_kernel in launch.hip)
     if (plan.lds_bytes > 48 * 1024 && !raised[device & 15].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_limit) != hipSuccess) {
@@ -77,7 +77,7 @@ uint64_t batch_launch_waves(int cus) {
 }
 
 // EZPZ_LANES_STRAGGLERS: the working lanes (of 64) at which a wavefront hands its systems to the teams, 0 = never.  262 144 jittered
-// 300-variable sketches, the list sized for every wavefront handing over that many (api.hip): 16 / 24 / 28 / 32 / 36 / 40 / 48 / 64
+// 300-variable sketches, the list sized for every wavefront handing over that many (launch.hip): 16 / 24 / 28 / 32 / 36 / 40 / 48 / 64
 // lanes 7.85 / 8.13 / 8.34 / 8.38 / 7.85 / 8.18 / 8.04 / 3.67 M solves/s (the teams walk records: they resume a system faster than a
 // thinning wavefront finishes it, until they are handed most of the batch); a list that overflows leaves the lanes their tail: 5.4.
 uint32_t batch_straggler_lanes() {

@@ -54,12 +54,12 @@ struct LmResume {
 };
 constexpr uint32_t kNoPass = 0xFFFFFFFFu;
 
-// The completion word of a one-call launch (api.hip: system_solve_one; ezpz_solve is one launch per tier).  After its
+// The completion word of a one-call launch (pipeline.cpp: system_solve_one; ezpz_solve is one launch per tier).  After its
 // last store the launch writes `seq` to `flag`, a word of host memory mapped into the device that the calling thread
 // polls: the call returns ~7 us sooner than through the runtime's completion signal (tools/launch_floor.hip:
 // 6.0 us launch-to-flag against 13.4 us launch-to-hipStreamQuery).  `counter` (device memory, zero between launches)
 // counts the workgroups of a launch that has several.  flag == null: an ordinary launch.
-// RESIDENT launches (one workgroup; api.hip: system_solve_one): after publishing, the kernel does not end but waits for the
+// RESIDENT launches (one workgroup; pipeline.cpp: system_solve_one): after publishing, the kernel does not end but waits for the
 // host's next request on the same buffers -- `request` is a word of device memory the host stores into through the PCIe
 // BAR: the tag of the latest request (the launch's generation in the upper 24 bits, a sequence number below; any other
 // generation, e.g. ~0, means "leave") -- for at most `lease_ticks` of the 100 MHz clock, and for `life_ticks` in all;

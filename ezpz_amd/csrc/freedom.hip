@@ -1,0 +1,260 @@
+// FreedomAnalysis on the device (reference ezpz/src/solver/find_dof.rs:14-103, analysis.rs:24-77): the host side of
+// freedom.hip.hpp's kernels -- the per-component program (build_freedom), the LANE / TEAM / WIDE launch paths and the two
+// entry points of the C ABI.
+#include "system.hpp"
+
+#include "freedom.hip.hpp"
+
+using namespace ezpz;
+
+// ---- FreedomAnalysis (solver/find_dof.rs, analysis.rs) ----------------------------------------------------------------
+namespace {
+
+// Connected components of the Jacobian's row/variable graph and, per component, the dense placement of its slots.
+int build_freedom(EzpzSystem* sys) {
+    auto& F = sys->freedom;
+    if (F.built) return EZPZ_OK;
+    const uint32_t n = sys->counts.n_vars, m = sys->counts.n_rows, zj = sys->counts.zj;
+    std::vector<uint32_t> parent(n + m);
+    for (uint32_t i = 0; i < n + m; ++i) parent[i] = i;
+    auto find = [&](uint32_t a) {
+        while (parent[a] != a) {
+            parent[a] = parent[parent[a]];
+            a = parent[a];
+        }
+        return a;
+    };
+    for (uint32_t s = 0; s < zj; ++s) {
+        uint32_t a = find(sys->host_slot_col[s]), b = find(n + sys->host_slot_row[s]);
+        if (a != b) parent[std::max(a, b)] = std::min(a, b);
+    }
+    std::vector<uint32_t> comp_of(n + m, UINT32_MAX), lidx(n + m, 0);
+    std::vector<FreedomComp> comps;
+    std::vector<uint32_t> col_count(n, 0);
+    for (uint32_t s = 0; s < zj; ++s) col_count[sys->host_slot_col[s]]++;
+    for (uint32_t v = 0; v < n; ++v) {  // components in order of their smallest variable; local columns ascending
+        if (!col_count[v]) continue;
+        uint32_t r = find(v);
+        if (comp_of[r] == UINT32_MAX) {
+            comp_of[r] = (uint32_t)comps.size();
+            comps.push_back(FreedomComp{0, 0, 0, 0, 0, 0});
+        }
+        comp_of[v] = comp_of[r];
+        lidx[v] = comps[comp_of[v]].n++;
+    }
+    for (uint32_t r = 0; r < m; ++r) {
+        uint32_t root = find(n + r);
+        if (comp_of[root] == UINT32_MAX) continue;  // a row without entries
+        comp_of[n + r] = comp_of[root];
+        lidx[n + r] = comps[comp_of[root]].m++;
+    }
+    uint32_t var_total = 0, ws = 0, max_n = 0;
+    for (auto& c : comps) {
+        c.var0 = var_total;
+        var_total += c.n;
+        const uint64_t w = (uint64_t)c.m * c.n + 2ull * c.n * c.n + 2ull * c.n;
+        if (w > (1ull << 31)) return EZPZ_ERR_TOO_LARGE;
+        ws = std::max<uint32_t>(ws, (uint32_t)w);
+        max_n = std::max(max_n, c.n);
+    }
+    std::vector<uint32_t> comp_vars(std::max<uint32_t>(var_total, 1));
+    for (uint32_t v = 0; v < n; ++v)
+        if (col_count[v]) comp_vars[comps[comp_of[v]].var0 + lidx[v]] = v;
+    // slots grouped by component
+    std::vector<uint32_t> per_comp(comps.size() + 1, 0);
+    for (uint32_t s = 0; s < zj; ++s) per_comp[comp_of[sys->host_slot_col[s]] + 1]++;
+    for (size_t c = 0; c < comps.size(); ++c) per_comp[c + 1] += per_comp[c];
+    for (size_t c = 0; c < comps.size(); ++c) {
+        comps[c].item0 = per_comp[c];
+        comps[c].item1 = per_comp[c];
+    }
+    std::vector<uint32_t> items(2 * std::max<uint32_t>(zj, 1));
+    for (uint32_t s = 0; s < zj; ++s) {
+        const uint32_t v = sys->host_slot_col[s], r = sys->host_slot_row[s];
+        FreedomComp& c = comps[comp_of[v]];
+        items[2 * c.item1] = s;
+        items[2 * c.item1 + 1] = lidx[v] * c.m + lidx[n + r];
+        c.item1++;
+    }
+    std::vector<uint32_t> col_ptr(n + 1, 0), col_slots(std::max<uint32_t>(zj, 1));
+    for (uint32_t v = 0; v < n; ++v) col_ptr[v + 1] = col_ptr[v] + col_count[v];
+    {
+        std::vector<uint32_t> next(col_ptr.begin(), col_ptr.end() - 1);
+        for (uint32_t s = 0; s < zj; ++s) col_slots[next[sys->host_slot_col[s]]++] = s;
+    }
+    // one allocation for the four index lists
+    std::vector<uint32_t> lists;
+    lists.insert(lists.end(), items.begin(), items.end());
+    F.o_vars = (uint32_t)lists.size();
+    lists.insert(lists.end(), comp_vars.begin(), comp_vars.end());
+    F.o_col_ptr = (uint32_t)lists.size();
+    lists.insert(lists.end(), col_ptr.begin(), col_ptr.end());
+    F.o_col_slots = (uint32_t)lists.size();
+    lists.insert(lists.end(), col_slots.begin(), col_slots.end());
+    int rc;
+    if ((rc = F.comps.ensure(std::max<size_t>(comps.size(), 1))) != EZPZ_OK) return rc;
+    if ((rc = F.lists.ensure(lists.size())) != EZPZ_OK) return rc;
+    if (!comps.empty())
+        HIP_TRY(hipMemcpy(F.comps.p, comps.data(), comps.size() * sizeof(FreedomComp), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(F.lists.p, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    F.ncomp = (uint32_t)comps.size();
+    if (!comps.empty()) F.comp0 = comps[0];
+    F.ws = std::max<uint32_t>(ws, 1);
+    F.max_n = max_n;
+    // LANE: a lane per (system, component) with 128 private workspaces in <= 64 KiB of LDS
+    F.lane = F.ws <= 64;
+    if (F.lane) {
+        F.threads = 128;
+        F.group = F.ncomp >= 128 ? 1 : 128 / std::max<uint32_t>(F.ncomp, 1);
+    } else {
+        F.threads = max_n <= 64 ? 64 : 256;
+        F.group = 1;
+    }
+    F.built = true;
+    return EZPZ_OK;
+}
+
+// x_dev: final values, caller order.  Everything on `stream`.
+int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* mask_dev, double* part_dev,
+                   uint32_t* count_dev, hipStream_t stream) {
+    auto& F = sys->freedom;
+    release_thread_kernel(sys->device);
+    int rc = ensure_program(sys);
+    if (rc != EZPZ_OK) return rc;
+    const size_t n = sys->counts.n_vars, zj = sys->counts.zj;
+    if (n == 0 || sys->counts.n_rows == 0) return EZPZ_ERR_EMPTY_SYSTEM;  // find_dof.rs:43-44
+    rc = build_freedom(sys);
+    if (rc != EZPZ_OK) return rc;
+    if ((rc = F.x_int.ensure(batch * n)) != EZPZ_OK) return rc;
+    if ((rc = F.jv.ensure(batch * std::max<size_t>(zj, 1))) != EZPZ_OK) return rc;
+    if (!part_dev) {
+        if ((rc = F.part.ensure(batch * n)) != EZPZ_OK) return rc;
+        part_dev = F.part.p;
+    }
+    const uint32_t* var_of = reinterpret_cast<const uint32_t*>(sys->view.base + sys->view.o_var_of);
+    const uint64_t total = (uint64_t)batch * n;
+    hipLaunchKernelGGL(gather_values_kernel, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0,
+                       stream, x_dev, var_of, F.x_int.p, (uint32_t)n, total);
+    launch_eval(sys, F.x_int.p, batch, nullptr, F.jv.p, nullptr, (uint32_t)std::min<size_t>(batch, 8192), stream);
+    FreedomArgs a{};
+    a.jv = F.jv.p;
+    a.comps = F.comps.p;
+    a.items = F.lists.p;
+    a.comp_vars = F.lists.p + F.o_vars;
+    a.col_ptr = F.lists.p + F.o_col_ptr;
+    a.col_slots = F.lists.p + F.o_col_slots;
+    a.part = part_dev;
+    a.mask = mask_dev;
+    a.n_under = count_dev;
+    a.batch = batch;
+    a.n = (uint32_t)n;
+    a.zj = (uint32_t)zj;
+    a.ncomp = F.ncomp;
+    a.ws = F.ws;
+    a.group = F.group;
+    const size_t head = (2 * (size_t)F.group + (F.group + 1) / 2 + 16) * sizeof(double);
+    if (F.lane) {
+        const size_t lds = head + (size_t)F.threads * F.ws * sizeof(double);
+        const uint32_t grid = (uint32_t)std::min<size_t>((batch + F.group - 1) / F.group, 1u << 16);
+        HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(freedom_kernel<true>, dim3(grid), dim3(F.threads), lds, stream, a);
+    } else {
+        size_t lds = head + (size_t)F.ws * sizeof(double);
+        uint32_t grid = (uint32_t)std::min<size_t>(batch, 1u << 16);
+        if (lds > 128 * 1024) {  // workspace of the largest component does not fit LDS: global, bounded to 4 GiB
+            lds = head;
+            const size_t per = (size_t)F.ws * sizeof(double);
+            grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(batch, 1024), (4ull << 30) / per));
+            if ((rc = F.gws.ensure((size_t)grid * F.ws)) != EZPZ_OK) return rc;
+            a.gws = F.gws.p;
+            if (F.ncomp == 1 && F.comp0.n >= 96) {
+                // One big component: its pivoted QR as a chain of step launches over the whole device (freedom.hip.hpp),
+                // `grid` systems side by side, then the ordinary kernel for rank / null space / participation.
+                if ((rc = F.step_done.ensure(grid)) != EZPZ_OK) return rc;
+                if ((rc = F.step_tau.ensure(grid)) != EZPZ_OK) return rc;
+                HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                const uint32_t m = F.comp0.m, nc = F.comp0.n, ndiag = std::min(m, nc);
+                for (size_t base = 0; base < batch; base += grid) {
+                    const uint32_t nb = (uint32_t)std::min<size_t>(grid, batch - base);
+                    FreedomStepArgs sa{};
+                    sa.gws = F.gws.p;
+                    sa.jv = F.jv.p + base * zj;
+                    sa.items = a.items;
+                    sa.done = F.step_done.p;
+                    sa.tau = F.step_tau.p;
+                    sa.ws = F.ws;
+                    sa.zj = (uint32_t)zj;
+                    sa.m = m;
+                    sa.n = nc;
+                    sa.item0 = F.comp0.item0;
+                    sa.item1 = F.comp0.item1;
+                    const uint32_t bl_mn = (uint32_t)std::min<uint64_t>(((uint64_t)m * nc + 255) / 256, 4096);
+                    const uint32_t bl_it = std::max<uint32_t>(1, std::min<uint32_t>((sa.item1 - sa.item0 + 255) / 256, 1024));
+                    hipLaunchKernelGGL(fr_init_kernel, dim3(bl_mn, nb), dim3(256), 0, stream, sa);
+                    hipLaunchKernelGGL(fr_scatter_kernel, dim3(bl_it, nb), dim3(256), 0, stream, sa);
+                    hipLaunchKernelGGL(fr_norms_kernel, dim3((nc + 255) / 256, nb), dim3(256), 0, stream, sa);
+                    for (uint32_t k = 0; k < ndiag; ++k) {
+                        sa.k = k;
+                        hipLaunchKernelGGL(fr_pivot_kernel, dim3(nb), dim3(256), 0, stream, sa);
+                        if (nc - k - 1 > 0)
+                            hipLaunchKernelGGL(fr_apply_kernel, dim3((nc - k - 1 + 63) / 64, nb), dim3(1024), 0, stream, sa);
+                    }
+                    FreedomArgs fa = a;
+                    fa.jv = a.jv + base * zj;
+                    fa.part = a.part + base * n;
+                    fa.mask = a.mask + base * n;
+                    fa.n_under = a.n_under ? a.n_under + base : nullptr;
+                    fa.batch = nb;
+                    fa.qr_done = 1;
+                    hipLaunchKernelGGL(freedom_kernel<false>, dim3(nb), dim3(F.threads), lds, stream, fa);
+                }
+                HIP_TRY(hipGetLastError());
+                return EZPZ_OK;
+            }
+        }
+        HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(freedom_kernel<false>, dim3(grid), dim3(F.threads), lds, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return EZPZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ezpz_system_freedom_batch_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* under_mask_dev,
+                                     double* participation_dev, uint32_t* n_under_dev, void* stream) {
+    if (!sys || (batch && (!x_dev || !under_mask_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return EZPZ_OK;
+    std::lock_guard<std::mutex> lock(sys->mu);
+    HIP_TRY(hipSetDevice(sys->device));
+    return freedom_device(sys, x_dev, batch, under_mask_dev, participation_dev, n_under_dev, (hipStream_t)stream);
+}
+
+int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, uint8_t* under_mask,
+                              double* participation) {
+    if (!sys || (batch && (!x || !under_mask))) return EZPZ_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return EZPZ_OK;
+    std::lock_guard<std::mutex> lock(sys->mu);
+    HIP_TRY(hipSetDevice(sys->device));
+    auto& F = sys->freedom;
+    const size_t n = sys->counts.n_vars;
+    if (n == 0 || sys->counts.n_rows == 0) return EZPZ_ERR_EMPTY_SYSTEM;
+    int rc;
+    DevBuf<double> xd;
+    if ((rc = xd.ensure(batch * n)) != EZPZ_OK) return rc;
+    if ((rc = F.mask.ensure(batch * n)) != EZPZ_OK) return rc;
+    if ((rc = F.part.ensure(batch * n)) != EZPZ_OK) return rc;
+    HIP_TRY(hipMemcpy(xd.p, x, batch * n * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = freedom_device(sys, xd.p, batch, F.mask.p, F.part.p, nullptr, nullptr)) != EZPZ_OK) return rc;
+    HIP_TRY(hipMemcpy(under_mask, F.mask.p, batch * n, hipMemcpyDeviceToHost));
+    if (participation) HIP_TRY(hipMemcpy(participation, F.part.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
+    return EZPZ_OK;
+}
+
+}  // extern "C"
+

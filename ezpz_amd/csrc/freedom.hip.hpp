@@ -19,14 +19,9 @@
 
 #include <cstdint>
 
-namespace ezpz {
+#include "launch_types.hpp"
 
-struct FreedomComp {
-    uint32_t m, n;          // rows / variables of the component
-    uint32_t item0, item1;  // its Jacobian slots: items[2i] = internal slot, items[2i+1] = lcol * m + lrow
-    uint32_t var0;          // comp_vars[var0 + lcol] = caller's variable id
-    uint32_t pad;
-};
+namespace ezpz {
 
 struct FreedomArgs {
     const double* jv;  // [batch][zj] weighted Jacobian values at the final point, internal slot order

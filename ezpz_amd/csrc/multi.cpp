@@ -6,7 +6,7 @@
 // straight between the caller's buffers and that device.  One worker thread per device owns that device's analysed
 // topology (an EzpzSystem) and runs the ordinary single-device entry point on its shard -- pageable buffers in 16 MB
 // pieces, registered buffers through the three-stream pipeline -- so G devices move G shards at once.  Everything here
-// is host code on the C ABI of api.hip; there is no numeric work in this file.
+// is host code on the C ABI (api.hip, launch.hip, pipeline.cpp); there is no numeric work in this file.
 #include <hip/hip_runtime.h>
 
 #include <sched.h>

@@ -1,5 +1,5 @@
 // The device half of ONE solve() call (reference protocol: ezpz-cli/src/main.rs:86-100, ezpz/benches/solver_bench.rs:15-24
-// time exactly one `solve` per iteration).  Implemented in api.hip, used by solve.cpp.
+// time exactly one `solve` per iteration).  Implemented in pipeline.cpp, used by solve.cpp.
 #pragma once
 #include <cstdint>
 

@@ -1,7 +1,7 @@
 // The launch-shape thresholds in ONE place (include/ezpz_amd.h: EzpzLaunchPolicy / ezpz_launch_policy).
 //
-// Which kernel serves a call is decided from the topology (api.hip: analyze_into) and from the size of the call
-// (api.hip: launch).  Every number below was measured on one 256-CU MI355X; the ones that are "how many systems fill the
+// Which kernel serves a call is decided from the topology (shape.cpp: analyze_into) and from the size of the call
+// (launch.hip: launch).  Every number below was measured on one 256-CU MI355X; the ones that are "how many systems fill the
 // device" are stored per compute unit and scaled by the CU count of the device the system lives on (a partitioned MI355X
 // -- CPX / DPX -- or a CU-masked process sees fewer), the others are properties of one workgroup / one CU's LDS and do not
 // scale.  tests/test_abi_cpu.py pins the table (the 256-CU values and the scaling).
@@ -38,7 +38,7 @@ inline EzpzLaunchPolicy launch_policy_for(int compute_units) {
     p.comp_max_component_vars = 24;
     p.comp_max_component_constraints = 48;
     p.comp_max_classes = 32;
-    // one connected system walks records (api.hip: build_records) instead of level lists from this many variables: one
+    // one connected system walks records (records.cpp: build_records) instead of level lists from this many variables: one
     // solve of 32 / 50 / 64 variables 61 -> 54, 142 -> 112, 119 -> 82 us; batches of 64 variables 17.0 -> 23.1 M solves/s but
     // of 50 variables 19.2 -> 16.8 M
     p.rec_min_vars_one_solve = 25;

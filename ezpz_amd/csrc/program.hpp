@@ -49,9 +49,9 @@ struct Program {
     std::vector<uint32_t> fwd_ptr, fwd_items;          // per var j: (slot(j,k), var k)*  -- row of L
     std::vector<uint32_t> bwd_ptr, bwd_items;          // per var j: (slot(i,j), var i)*  -- column of L
     // per (partition, level): lanes that share one list of the level's Cholesky walks (a power of two; 1 = one lane
-    // per list).  Filled by the launch-shape code (api.hip: choose_level_groups); empty means 1 everywhere.
+    // per list).  Filled by the launch-shape code (records.cpp: choose_level_groups); empty means 1 everywhere.
     std::vector<uint32_t> lvl_grp;
-    // Dense phases (api.hip: make_dense_phases; one-partition programs of one connected component on a barrier
+    // Dense phases (records.cpp: make_dense_phases; one-partition programs of one connected component on a barrier
     // workgroup): the top of the elimination tree -- its last n_dense "levels", [dense_level0, nlev) -- is not walked
     // column by column.  Each of these levels is a PHASE: a few whole levels of the original schedule merged, whose columns
     // fall into <= 8 independent blocks (the connected pieces of the elimination tree inside the phase, <= 16 columns

@@ -1,4 +1,4 @@
-// Host orchestration the reference keeps above its numeric core, restated on the C ABI of api.hip (no device code
+// Host orchestration the reference keeps above its numeric core, restated on the C ABI (api.hip, launch.hip, pipeline.cpp) (no device code
 // here: everything numeric goes through ezpz_system_solve_batch / ezpz_system_freedom_batch) --
 //   solve_inner                 reference ezpz/src/lib.rs:265-356
 //   solve_with_priority_inner   reference ezpz/src/lib.rs:148-263 (solve, solve_analysis)

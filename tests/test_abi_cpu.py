@@ -134,10 +134,10 @@ def test_symbolic_sizes_massive_and_square():
 
 
 def test_symbolic_phase_of_a_connected_sketch_ends_in_a_dense_root_block():
-    """Host side of the dense phases (api.hip: make_dense_phases): on a 512-lane workgroup the top of a connected
+    """Host side of the dense phases (records.cpp: make_dense_phases): on a 512-lane workgroup the top of a connected
     sketch's elimination tree -- runs of levels of one or two columns per branch -- is a few phases of the schedule;
     EZPZ_ROOT=0 keeps the plain schedule (read once per process, hence the child processes).  Block systems keep theirs, and
-    so does the record walk (api.hip: build_records), the automatic shape of such a sketch."""
+    so does the record walk (records.cpp: build_records), the automatic shape of such a sketch."""
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import gen, ezpz_amd as E; "
             "from oracle import textual as T; r, g = gen.connected_sketch(400, 7); cs = T.load(T.gen_big_problem(500)); "

@@ -172,7 +172,7 @@ def test_quarter_million_jittered_sketches_on_the_lanes_full_size(E):
 
 def test_thirty_two_thousand_jittered_sketches_on_the_record_walk_full_size(E):
     """The teams' leg of bench.py at its full size: 32 768 jittered starts of the 300-variable sketch -- below the batch from
-    which the lanes serve a call, so every system is solved by a 128-lane workgroup walking records (team_mode 4: api.hip,
+    which the lanes serve a call, so every system is solved by a 128-lane workgroup walking records (team_mode 4: shape.cpp,
     build_records).  Every system converges with every constraint satisfied, a sample spread over the batch plus the systems
     with the most iterations against the oracle with the measured bar of tests/sensitivity.py, the same bits from run to run,
     and the same iteration counts and flags as the 262 144-system batch gives these starts on the lanes."""

@@ -679,7 +679,7 @@ def test_random_connected_sketch_in_one_wavefront_or_barrier_workgroup(E, npts, 
 @pytest.mark.parametrize("k,npts", [(4, 40), (7, 25), (3, 150), (40, 8)])
 def test_a_few_sketches_in_one_system_walk_records_as_one_partition(E, k, npts):
     """A document of several sketches: k connected components of 50 ... 300 variables in ONE system.  The record walk needs
-    levels, not connectivity: the automatic shapes make them one partition (team_mode 4; api.hip, analyze_into: up to 127 components)
+    levels, not connectivity: the automatic shapes make them one partition (team_mode 4; shape.cpp, analyze_into: up to 127 components)
     where the list-walk shapes give each wavefront a balanced share (`TEAM_AUTO_LISTS`).  Both against the oracle on jittered
     starts, and against each other."""
     parts, guesses, off = [], [], 0
@@ -717,7 +717,7 @@ def test_a_few_sketches_in_one_system_walk_records_as_one_partition(E, k, npts):
 @pytest.mark.parametrize("npts,latency_mode,batch_mode", [(10, 0, 0), (16, 4, 0), (25, 4, 0), (32, 4, 4)])
 def test_small_connected_sketch_walks_records_where_it_pays(E, npts, latency_mode, batch_mode):
     """One connected sketch of 20 ... 64 variables: one solve walks records from 25 variables (team_mode 4),
-    batches from 57 (below that two to four systems share a wavefront on the sub-wavefront teams: api.hip, analyze_into).
+    batches from 57 (below that two to four systems share a wavefront on the sub-wavefront teams: shape.cpp, analyze_into).
     Both shapes against the oracle, jittered starts and a NaN start."""
     recs, g = gen.connected_sketch(npts, 4100 + npts)
     n = len(g)
@@ -742,13 +742,13 @@ def test_small_connected_sketch_walks_records_where_it_pays(E, npts, latency_mod
 @pytest.mark.parametrize("shape", ["phases", "records"])
 def test_connected_sketch_latency_shape_with_dense_root_block(E, npts, shape):
     """The launch shape of one solve (`TEAM_AUTO_LATENCY`, what `ezpz_solve` asks for) runs the linear solve of a connected
-    sketch whose state fits the LDS as a RECORD WALK (api.hip: build_records; lm_kernel.hip.hpp: REC builds): every level of
+    sketch whose state fits the LDS as a RECORD WALK (records.cpp: build_records; lm_kernel.hip.hpp: REC builds): every level of
     the elimination tree one or more rounds in which a group of lanes owns one entry, the lanes' operand addresses ready in
     records requested a round ahead (`shape` "records": team_mode 4; 2400 variables do not fit the LDS and walk the wide form).
     `TEAM_LATENCY_PHASES` keeps what that shape did before: it ends the elimination
     with dense phases: runs of levels at the top of the elimination tree whose columns fall into independent
     blocks of <= 16 (the last one the root block: the last <= 16 columns), each block's Schur complement gathered by
-    all lanes and factorised in one wavefront's registers (api.hip: make_dense_phases; lm_kernel.hip.hpp: dense
+    all lanes and factorised in one wavefront's registers (records.cpp: make_dense_phases; lm_kernel.hip.hpp: dense
     phases), with the program staged in LDS (120-520 variables), read from global memory (800) and with the workspace
     in global memory too (2400).  Against the oracle (iteration counts,
     flags, masks, coordinates at 1e-6), against the plain level walk (an explicit team size keeps it), from run to
@@ -800,7 +800,7 @@ def test_connected_sketch_latency_shape_with_dense_root_block(E, npts, shape):
 
 def test_sketch_whose_workspace_fills_the_lds_keeps_its_dense_phases(E):
     """1408 variables: 156 KB of workspace in LDS, the program read from global memory, and the few KB left go to the dense
-    panels rather than to the level staging buffer (api.hip, analyze_into).  Against the oracle."""
+    panels rather than to the level staging buffer (shape.cpp, analyze_into).  Against the oracle."""
     recs, g = gen.connected_sketch(704, 288)
     s = E.System(recs, len(g), team_size=E.TEAM_LATENCY_PHASES)
     plain = E.System(recs, len(g), team_size=512)
