@@ -195,7 +195,31 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                     hipLaunchKernelGGL(fr_init_kernel, dim3(bl_mn, nb), dim3(256), 0, stream, sa);
                     hipLaunchKernelGGL(fr_scatter_kernel, dim3(bl_it, nb), dim3(256), 0, stream, sa);
                     hipLaunchKernelGGL(fr_norms_kernel, dim3((nc + 255) / 256, nb), dim3(256), 0, stream, sa);
-                    for (uint32_t k = 0; k < ndiag; ++k) {
+                    // the QR itself: one cooperative launch for all steps (fr_qr_kernel) when the device can hold its
+                    // workgroups at once, else (or EZPZ_FREEDOM_CHAIN=1, A/B runs) the chain of one launch pair per step
+                    const char* const chain_env = std::getenv("EZPZ_FREEDOM_CHAIN");  // (read per call: tests switch it)
+                    const bool chain_only = chain_env && chain_env[0] == '1';
+                    bool cooperative = false;
+                    if (!chain_only) {
+                        int per_cu = 0, coop = 0;
+                        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
+                        if (hip_debug()) std::fprintf(stderr, "[ezpz hip] cooperative launch attribute %d\n", coop);
+                        if (coop && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fr_qr_kernel, 1024, 0) == hipSuccess && per_cu > 0) {
+                            const uint64_t capacity = (uint64_t)sys->lim.cus * (uint64_t)per_cu;
+                            const uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1, (nc + kQrCols - 1) / kQrCols), capacity / nb);
+                            if (G >= 1 && (uint64_t)G * nb <= capacity) {
+                                uint32_t nd = ndiag;
+                                void* params[] = {&sa, &nd};
+                                const hipError_t ce = hipLaunchCooperativeKernel((const void*)fr_qr_kernel, dim3(G, nb), dim3(1024), params, 0, stream);
+                                cooperative = ce == hipSuccess;
+                                if (!cooperative && hip_debug())
+                                    std::fprintf(stderr, "[ezpz hip] cooperative QR launch (%u x %u workgroups of %llu) -> %s\n", G, nb,
+                                                 (unsigned long long)capacity, hipGetErrorString(ce));
+                            }
+                        }
+                        (void)hipGetLastError();
+                    }
+                    for (uint32_t k = 0; k < ndiag && !cooperative; ++k) {
                         sa.k = k;
                         hipLaunchKernelGGL(fr_pivot_kernel, dim3(nb), dim3(256), 0, stream, sa);
                         if (nc - k - 1 > 0)

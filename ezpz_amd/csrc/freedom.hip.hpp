@@ -508,4 +508,223 @@ __global__ void __launch_bounds__(1024) fr_apply_kernel(const FreedomStepArgs a)
     }
 }
 
+// The whole pivoted QR of the WIDE layout as ONE cooperative launch (round 4).  The chain above is one launch pair per
+// Householder step -- 2000 variables: 4000 launches, ~30 us per pair, 0.12 s -- although the two kernels only ever wait
+// for each other.  Here every workgroup stays for all steps:
+//   * the pivot search runs redundantly in every workgroup (the running norms are a few KB: same inputs, same deterministic
+//     result, nothing to exchange);
+//   * the column swap and the scaling of the reflector are one pass over the rows, dealt round-robin to the whole grid;
+//   * the reflector is applied by tiles of kQrCols columns x kQrChunks row chunks per workgroup (16 columns = one 128-byte
+//     line per row; a 2000-variable system has 125 workgroups streaming its trailing matrix instead of the chain's 32).  The
+//     reflector itself goes to LDS once per step; a lane's chunk of its column (up to kQrKeep rows) is loaded with all loads
+//     in flight, stays in registers between the dot product and the update, and is written once: the trailing matrix is
+//     read once and written once per step.  A chunk's partial sums fold by shuffles inside a wavefront, then over the 16
+//     wavefronts through LDS.
+// The sums are formed in another (fixed) order than the chain's: deterministic, equal to rounding, held against the oracle's
+// dense QR by the same tests.  Two rendezvous per step among the workgroups of a system (qr_rendezvous; the launch is
+// cooperative, so co-residency is the runtime's guarantee).  Measured per step of a 2000-variable system (wall_clock64
+// around the phases, workgroup 0): pivot search 3.5 us, swap + scale 1.9, first rendezvous 2.8, apply 17.5, second
+// rendezvous 9.3 (its wait for the slowest workgroup included) = 35 us against the chain's 61: 2000 variables 122 -> 72 ms
+// per analysis, 800 variables 23.5 -> 16.8 ms.  The step is bound by memory latency and by the rendezvous' cache
+// maintenance (every step ends with the L2's dirty lines written back and the next begins with cold lines: ~32 MB moved
+// in ~25 us); what would change that is a blocked (BLAS-3) factorisation, which the reference's column pivoting on
+// running norms does not allow without changing which columns are chosen on near-ties.
+// What was tried on the way: the chain's own 16 chunks and one running sum per lane as a persistent kernel (bit-identical
+// to the chain): 71 us per step, no gain; cooperative groups' grid.sync(): ~20 us each; 8-column tiles x 128 chunks with 16
+// kept rows (half-line tiles, 250 workgroups): apply no faster and the rendezvous twice as long.
+// grid = (workgroups per system, systems side by side); 1024 lanes.
+constexpr uint32_t kQrCols = 16, kQrChunks = 64, kQrKeep = 32;
+// The rendezvous of one system's workgroups inside fr_qr_kernel: a counter that only grows (every arrival adds one, the k-th
+// rendezvous is over when it reaches k x workgroups), zeroed by fr_init_kernel.  One lane per workgroup arrives and polls;
+// its agent-scope fences publish the workgroup's stores (they sit in the XCD's L2, which the write-back covers) and drop
+// stale lines before anybody reads on.  (cooperative groups' grid.sync() does the same for the whole grid and took ~20 us
+// with 125 workgroups of 1024 lanes: two of them were 40 of a step's 50 us.)
+__device__ __forceinline__ void qr_rendezvous(unsigned int* counter, unsigned int& target, unsigned int workgroups) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        target += workgroups;
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+__global__ void __launch_bounds__(1024) fr_qr_kernel(const FreedomStepArgs a, const uint32_t ndiag) {
+    unsigned int* const arrivals = a.done + blockIdx.y;  // (zeroed by fr_init_kernel; the chain's "done" flag is not used here)
+    unsigned int arrived = 0;
+    __shared__ double red[32];
+    __shared__ double part[16][kQrCols];
+    __shared__ double colk[kQrChunks * kQrKeep + 2 * kQrKeep];
+    double* W = a.gws + (size_t)blockIdx.y * a.ws;
+    const uint32_t m = a.m, n = a.n, oPerm = m * n + 2 * n * n, oTau = oPerm + n;
+    const uint32_t G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t c = tid % kQrCols, w = tid / kQrCols;  // column of the tile, row chunk
+    const uint32_t tile0 = wg;
+    bool done = false;  // nothing left (or NaN): the remaining diagonal is exactly zero -- the same in every workgroup
+    for (uint32_t k = 0; k < ndiag; ++k) {
+        double tau = 0.0, beta = 0.0;
+        uint32_t bj = k;
+        if (!done) {
+            double bv = -1.0;
+            for (uint32_t j = k + tid; j < n; j += blockDim.x) {
+                const double sq = W[oTau + j];
+                if (sq > bv) {
+                    bv = sq;
+                    bj = j;
+                }
+            }
+            // largest value, smallest index among equals; every lane gets the result (16 wavefronts: BlockCtx::argmax is for <= 8)
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(bv, off);
+                const uint32_t oi = (uint32_t)__shfl_xor((int)bj, off);
+                if (ov > bv || (ov == bv && oi < bj)) {
+                    bv = ov;
+                    bj = oi;
+                }
+            }
+            __syncthreads();
+            if ((tid & 63u) == 0) {
+                red[tid >> 6] = bv;
+                red[16 + (tid >> 6)] = (double)bj;
+            }
+            __syncthreads();
+            bv = red[0];
+            bj = (uint32_t)red[16];
+            for (uint32_t q = 1; q < (blockDim.x >> 6); ++q) {
+                const double ov = red[q];
+                const uint32_t oi = (uint32_t)red[16 + q];
+                if (ov > bv || (ov == bv && oi < bj)) {
+                    bv = ov;
+                    bj = oi;
+                }
+            }
+            if (!(bv > 0.0)) {
+                done = true;
+            } else {
+                // Row k itself is left alone in this pass -- every workgroup reads alpha = W(k, bj) here, and W(k, k) is read by
+                // the tile of column bj below: the swap of row k happens where its entries are consumed (the apply phase
+                // writes W(k, bj), W(k, k) = beta is stored after the step's second rendezvous).
+                const double norm = sqrt(bv);
+                const double alpha = W[(size_t)k * n + bj];  // (W(k, k) once swapped)
+                beta = alpha >= 0.0 ? -norm : norm;
+                const double denom = alpha - beta;
+                tau = (beta - alpha) / beta;
+                // (rows dealt round-robin to the workgroups: every lane's two loads are lines of their own -- column accesses to a
+                // row-major matrix -- and two workgroups taking them all took 11.6 us of a 2000-variable step)
+                for (uint32_t i = tid * G + wg; i < m; i += G * blockDim.x) {
+                    if (i == k) continue;
+                    const double vk = W[(size_t)i * n + k];
+                    double nk = vk;
+                    if (bj != k) {
+                        nk = W[(size_t)i * n + bj];
+                        W[(size_t)i * n + bj] = vk;
+                    }
+                    if (i > k) nk /= denom;
+                    W[(size_t)i * n + k] = nk;
+                }
+                if (wg == 0 && tid == 0 && bj != k) {
+                    const double t = W[oPerm + k];
+                    W[oPerm + k] = W[oPerm + bj];
+                    W[oPerm + bj] = t;
+                    W[oTau + bj] = W[oTau + k];
+                }
+            }
+        }
+        qr_rendezvous(arrivals, arrived, G);  // column k is the reflector (and the norm of the column that left position k sits at its new place)
+        if (!done && n - k - 1 > 0) {
+            const uint32_t rows = m - (k + 1), per = (rows + kQrChunks - 1) / kQrChunks;
+            const uint32_t i0 = min(m, k + 1 + w * per), i1 = min(m, i0 + per), r0 = i0 - (k + 1);
+            const uint32_t tiles = (n - k - 1 + kQrCols - 1) / kQrCols;
+            const bool kept = per <= kQrKeep && n >= 8;  // (the rows below the diagonal fit colk with kQrKeep to spare)
+            // the reflector (column k below the diagonal) once into LDS: both passes of every lane read it from there
+            if (kept) {
+                for (uint32_t i = k + 1 + tid; i < m + kQrKeep; i += blockDim.x) colk[i - (k + 1)] = i < m ? W[(size_t)i * n + k] : 0.0;
+                __syncthreads();
+            }
+            for (uint32_t t = tile0; t < tiles; t += G) {
+                const uint32_t j = k + 1 + t * kQrCols + c;
+                const bool live = j < n;
+                // The chunk's entries of column j stay in registers between the dot pass and the update pass (up to kQrKeep rows:
+                // 2048 + rows), with all their loads in flight at once: the trailing matrix is read once and written once per step
+                // instead of read twice (the step is bound by HBM: 2000 variables = up to 32 MB of trailing matrix, whose lines the
+                // rendezvous' fences drop from the L2 every step).
+                double keep[kQrKeep];
+                const uint32_t at_j = i0 * n + j;
+                double d0 = 0.0, d1 = 0.0;
+                if (live && kept) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kQrKeep; ++q) {
+                        // (a uniform row base and one 32-bit lane offset for all rows; rows past the chunk's end are still inside
+                        // the workspace -- Q follows the matrix -- and are read as zeros)
+                        const double* const row = W + (size_t)q * n;
+                        const double vj = row[at_j];
+                        keep[q] = i0 + q < i1 ? vj : 0.0;
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < kQrKeep; q += 2) {
+                        d0 += colk[r0 + q] * keep[q];
+                        d1 += colk[r0 + q + 1] * keep[q + 1];
+                    }
+                } else if (live) {
+                    uint32_t i = i0;
+                    for (; i + 2 <= i1; i += 2) {
+                        d0 += W[(size_t)i * n + k] * W[(size_t)i * n + j];
+                        d1 += W[(size_t)(i + 1) * n + k] * W[(size_t)(i + 1) * n + j];
+                    }
+                    for (; i < i1; ++i) d0 += W[(size_t)i * n + k] * W[(size_t)i * n + j];
+                }
+                // (the kQrCols columns repeat every kQrCols lanes: the chunks of a wavefront are summed by shuffles first)
+                double d = d0 + d1;
+                for (uint32_t off = kQrCols; off < 64; off <<= 1) d += __shfl_xor(d, off);
+                if ((tid & 63u) < kQrCols) part[tid >> 6][c] = d;
+                __syncthreads();
+                // (row k of column j: the swapped-in value -- the old W(k, k) -- for the column the pivot came from)
+                const double rowk = !live ? 0.0 : (bj != k && j == bj) ? W[(size_t)k * n + k] : W[(size_t)k * n + j];
+                double dot = rowk;
+                for (uint32_t q = 0; q < 16; ++q) dot += part[q][c];
+                dot *= tau;
+                __syncthreads();
+                double s0 = 0.0, s1 = 0.0;
+                if (live && w == 0) W[(size_t)k * n + j] = rowk - dot;
+                if (live && kept) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kQrKeep; ++q) {
+                        const double v = keep[q] - dot * colk[r0 + q];
+                        if (i0 + q < i1) {
+                            (W + (size_t)q * n)[at_j] = v;
+                            if (q & 1) s1 += v * v; else s0 += v * v;
+                        }
+                    }
+                } else if (live) {
+                    uint32_t i = i0;
+                    for (; i + 2 <= i1; i += 2) {
+                        const double v0 = W[(size_t)i * n + j] - dot * W[(size_t)i * n + k];
+                        const double v1 = W[(size_t)(i + 1) * n + j] - dot * W[(size_t)(i + 1) * n + k];
+                        W[(size_t)i * n + j] = v0;
+                        W[(size_t)(i + 1) * n + j] = v1;
+                        s0 += v0 * v0;
+                        s1 += v1 * v1;
+                    }
+                    for (; i < i1; ++i) {
+                        const double v = W[(size_t)i * n + j] - dot * W[(size_t)i * n + k];
+                        W[(size_t)i * n + j] = v;
+                        s0 += v * v;
+                    }
+                }
+                double sq = s0 + s1;
+                for (uint32_t off = kQrCols; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
+                if ((tid & 63u) < kQrCols) part[tid >> 6][c] = sq;
+                __syncthreads();
+                if (tid < kQrCols && live) {
+                    sq = 0.0;
+                    for (uint32_t q = 0; q < 16; ++q) sq += part[q][c];
+                    W[oTau + j] = sq;
+                }
+                __syncthreads();
+            }
+        }
+        qr_rendezvous(arrivals, arrived, G);  // the trailing matrix and its norms are those of step k + 1
+        if (!done && wg == 0 && tid == 0) W[(size_t)k * n + k] = beta;
+    }
+}
+
 }  // namespace ezpz

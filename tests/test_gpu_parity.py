@@ -989,8 +989,8 @@ def test_freedom_workgroup_mode_with_global_workspace(E):
 
 
 def test_freedom_of_one_large_component_spread_over_the_device(E):
-    """A 300-variable connected sketch that lost its last three constraints: one component, so its pivoted QR runs as a
-    chain of step launches over the whole device (dot products and norms in 16 partial sums) before the ordinary
+    """A 300-variable connected sketch that lost its last three constraints: one component, so its pivoted QR runs over the
+    whole device (one cooperative launch for all Householder steps, freedom.hip.hpp:fr_qr_kernel) before the ordinary
     kernel takes rank, null space and participation; three systems side by side.  Against the oracle's dense QR."""
     recs, g = gen.connected_sketch(150, 4242)
     recs = recs[:-3]
@@ -1002,6 +1002,27 @@ def test_freedom_of_one_large_component_spread_over_the_device(E):
     # the same analysis for every system of a batch larger than one launch's worth is consistent
     mask2, part2 = sysobj.freedom_batch(np.repeat(x[:1], 5, axis=0))
     assert np.all(mask2 == mask[0]) and np.allclose(part2, part[0], atol=1e-12)
+
+
+@pytest.mark.parametrize("points", [150, 400])
+def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, monkeypatch):
+    """The two routes of the WIDE layout -- one cooperative launch for all steps, and the chain of one launch pair per step
+    it falls back to when the device cannot hold a system's workgroups at once (EZPZ_FREEDOM_CHAIN=1 forces it) -- sum in
+    different fixed orders: the same underconstrained set, participation equal to rounding, each against the oracle's
+    dense QR (300 and 800 variables; 800: 50 workgroups of 1024 lanes through 800 steps, rows of a chunk kept in
+    registers), and each bitwise repeatable."""
+    recs, g = gen.connected_sketch(points, 4242)
+    recs = recs[:-3]
+    sysobj = E.System(recs, len(g))
+    x, st, _ = sysobj.solve_batch(g[None, :] + gen.keyed_uniform(53, 2, len(g), -0.01, 0.01), E.Config(max_iterations=60))
+    monkeypatch.delenv("EZPZ_FREEDOM_CHAIN", raising=False)
+    _, mask, part = _freedom_vs_oracle(E, recs, len(g), x, atol=1e-8)
+    mask_again, part_again = sysobj.freedom_batch(x)
+    assert np.array_equal(part, part_again) and np.array_equal(mask, mask_again)
+    monkeypatch.setenv("EZPZ_FREEDOM_CHAIN", "1")
+    mask_chain, part_chain = sysobj.freedom_batch(x)
+    assert np.array_equal(mask_chain, mask) and mask.any()
+    assert np.allclose(part_chain, part, atol=1e-10)
 
 
 def test_freedom_two_large_components_on_one_workgroup(E):

@@ -46,4 +46,9 @@ echo "# EZPZ_LANES=0 BATCH=262144 (the per-system teams on the same batch)"; EZP
 python tools/ab_microbench.py $out > /dev/null 2>&1
 (echo "# ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/<case>/problem.md  (the reference CLI's protocol, main.rs:86-100; steady state = the 100-run loop alone)"; for c in tiny square arc_radius two_rectangles massive_parallel_system; do echo "## $c"; ./ezpz_amd/ezpz-amd --filepath tests/golden/test_cases/$c/problem.md | grep -E "Problem size|Iterations|Solved in|i.e.|Steady"; done) > $out/cli_latency.txt
 (echo "# python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_proptests.py -m gpu  (parity fuzz of the connected-sketch shapes and the reference's property tests on the HIP path: sensitivity-aware bar, no exclusions)"; python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_proptests.py -q -m gpu 2>&1 | tail -3) > $out/fuzz_tests.txt
+# round 4: the floors the one-call path and the host-to-host pipeline were designed against, and what they reach
+hipcc --offload-arch=gfx950 -O2 -o tools/launch_floor.bin tools/launch_floor.hip 2>/dev/null && (echo "# tools/launch_floor.bin  (host -> device -> host round trips by completion method)"; ./tools/launch_floor.bin 2>&1) > $out/launch_floor.txt
+hipcc --offload-arch=gfx950 -O2 -o tools/pcie_duplex.bin tools/pcie_duplex.hip 2>/dev/null && (echo "# tools/pcie_duplex.bin  (both directions of the host link at once: queues and piece sizes)"; ./tools/pcie_duplex.bin 2>&1) > $out/pcie_duplex.txt
+(echo "# python tools/h2h_rate.py [lines batch]  (ezpz_system_solve_batch between host buffers: pageable, then registered = the pipelined path)"; python tools/h2h_rate.py 2>&1 | tail -1; python tools/h2h_rate.py 600 16384 2>&1 | tail -1; python tools/h2h_rate.py 200 65536 2>&1 | tail -1) > $out/h2h_rate.txt
+(echo "# python tools/freedom_wide.py 150 400 1000  (FreedomAnalysis of one large component: the pivoted QR as one cooperative launch, then EZPZ_FREEDOM_CHAIN=1: round 3's chain of a launch pair per Householder step)"; python tools/freedom_wide.py 150 400 1000 2>&1 | grep variables; EZPZ_FREEDOM_CHAIN=1 python tools/freedom_wide.py 150 400 1000 2>&1 | grep variables) > $out/freedom_wide.txt
 head -3 $out/massive_b16384_kernel_stats.csv
