@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(1024) fr_apply_kernel(const FreedomStepArgs a)
 //     in flight, stays in registers between the dot product and the update, and is written once: the trailing matrix is
 //     read once and written once per step.  A chunk's partial sums fold by shuffles inside a wavefront, then over the 16
 //     wavefronts through LDS.
-// The sums are formed in another (fixed) order than the chain's: deterministic, equal to rounding, held against the oracle's
+// The sums are formed in another (fixed) order than the chain's: deterministic, equal to rounding, held against the CPU restatement's
 // dense QR by the same tests.  Two rendezvous per step among the workgroups of a system (qr_rendezvous; the launch is
 // cooperative, so co-residency is the runtime's guarantee).  Measured per step of a 2000-variable system (wall_clock64
 // around the phases, workgroup 0): pivot search 3.5 us, swap + scale 1.9, first rendezvous 2.8, apply 17.5, second
