@@ -107,7 +107,11 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
         // a 4-variable linear system 12 -> 16) -- or always, when the caller asks for the form (EZPZ_TEAM_LATENCY_WAVE)
         size_t non_linear = 0;
         for (size_t i = 0; i < n_cs; ++i) non_linear += kind_is_linear(cs[i].kind) ? 0 : 1;
-        const bool pays = n_vars >= 8 && non_linear >= 3;
+        static const bool wave_all = [] {
+            const char* e = std::getenv("EZPZ_JIT_WAVE");  // EZPZ_JIT_WAVE=all: every small system (measurements of the rule below)
+            return e && std::strcmp(e, "all") == 0;
+        }();
+        const bool pays = wave_all || (n_vars >= 8 && non_linear >= 3);
         if (wave_enabled && !s->lane->wave_source.empty() &&
             (team_size == EZPZ_TEAM_LATENCY_WAVE || (team_size == EZPZ_TEAM_AUTO_LATENCY && pays)))
             s->wave_jit = comp_jit_create_source(s->lane->wave_source, "ezpz_jit_wave");

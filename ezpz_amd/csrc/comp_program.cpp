@@ -849,6 +849,169 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
     return true;
 }
 
+// The elimination of the wavefront kernel ACROSS its lanes (`tail_wave`): lane i holds row i of L (its entries a<k> = L(i, k),
+// its diagonal and its right-hand side), columns are eliminated right-looking in the class program's order -- the pivot's
+// square root and the column's division once per column instead of once per entry, the update of the later columns one
+// multiply-subtract per column pair on all lanes at once, operands of other lanes through v_readlane -- and the backward
+// substitution walks every column's entries in the serial order.  Every entry receives exactly the operations of `tail`
+// (emit_elimination) in the same order -- the columns are taken in an order that respects every list of the class program
+// (a row's updates, an entry's updates), the backward sums follow their lists;
+// entries that are structurally zero hold zeros and receive multiples of zero -- so the step is the same bits
+// (tests/test_gpu_lanes.py) as long as those multiples ARE zero: a right-hand side that is not finite (a NaN guess, an
+// overflow) would turn 0 x y_k into NaN on rows the serial order never touches, so `fin` reports whether every y_k was
+// finite and the kernel repeats the solve with the serial `tail` when not (pivots never see the right-hand side: `bad` is
+// the same either way; a non-finite entry of L fails its row's pivot in both orders).  wave_row_structure checks what that rests on (lists complete and compatible with one column order, fill closed) and the serial
+// `tail` stays when it does not hold (or EZPZ_JIT_WAVE_TAIL=0, A/B runs).
+struct WaveRows {
+    bool ok = false;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> col;  // per column k: (row i, slot) ascending in i
+    std::vector<std::vector<uint32_t>> bwd;                         // per column k: its rows in the backward sum's order
+    std::vector<uint32_t> order;                                    // the columns in elimination order
+    std::vector<uint32_t> slot_row;
+};
+WaveRows wave_row_structure(const Class& cl) {
+    WaveRows w;
+    auto why = [&](int code) {
+        static const bool dbg = std::getenv("EZPZ_JIT_DEBUG") != nullptr;
+        if (dbg) std::fprintf(stderr, "[ezpz jit] wave: elimination across lanes not used (check %d)\n", code);
+        return w;
+    };
+    const Program& Q = cl.Q;
+    const uint32_t nv = Q.c.n_vars, zlo = Q.c.zlo;
+    static const bool off = [] {
+        const char* e = std::getenv("EZPZ_JIT_WAVE_TAIL");
+        return e && e[0] == '0';
+    }();
+    if (off || nv < 2 || nv > 64) return why(1);
+    w.col.assign(nv, {});
+    w.slot_row.assign(zlo, ~0u);
+    std::vector<std::vector<uint32_t>> slot_of(nv, std::vector<uint32_t>(nv, ~0u));
+    // edges of "column a is eliminated before column b": what fixes the order in which an entry receives its updates
+    std::vector<std::vector<uint32_t>> after(nv);
+    std::vector<uint32_t> waiting(nv, 0);
+    auto before = [&](uint32_t x, uint32_t y) {
+        after[x].push_back(y);
+        ++waiting[y];
+    };
+    for (uint32_t j = 0; j < nv; ++j) {
+        uint32_t last = ~0u;
+        for (uint32_t q = Q.fwd_ptr[j]; q < Q.fwd_ptr[j + 1]; ++q) {
+            const uint32_t slot = Q.fwd_items[2 * q], k = Q.fwd_items[2 * q + 1];
+            if (slot >= zlo || k >= j || Q.l_col[slot] != k || slot_of[j][k] != ~0u) return why(2);
+            // row j's diagonal and right-hand side take their updates in the list's order, then column j is eliminated
+            if (last != ~0u) before(last, k);
+            before(k, j);
+            last = k;
+            w.slot_row[slot] = j;
+            slot_of[j][k] = slot;
+        }
+    }
+    for (uint32_t s2 = 0; s2 < zlo; ++s2)
+        if (w.slot_row[s2] == ~0u) return why(3);
+    w.bwd.assign(nv, {});
+    for (uint32_t k = 0; k < nv; ++k) {
+        for (uint32_t i = k + 1; i < nv; ++i)
+            if (slot_of[i][k] != ~0u) w.col[k].push_back({i, slot_of[i][k]});
+        // backward list of column k: the same entries, in the order the serial sum takes them
+        if (Q.bwd_ptr[k + 1] - Q.bwd_ptr[k] != w.col[k].size()) return why(4);
+        for (uint32_t q = Q.bwd_ptr[k]; q < Q.bwd_ptr[k + 1]; ++q) {
+            const uint32_t slot = Q.bwd_items[2 * q], i = Q.bwd_items[2 * q + 1];
+            if (i >= nv || i <= k || slot_of[i][k] != slot) return why(5);
+            w.bwd[k].push_back(i);
+        }
+    }
+    // an entry's updates: one per earlier column in which both its row and its column have entries, in the list's order
+    for (uint32_t s2 = 0; s2 < zlo; ++s2) {
+        const uint32_t i = w.slot_row[s2], j = Q.l_col[s2];
+        size_t want = 0;
+        for (uint32_t k = 0; k < j; ++k) want += slot_of[i][k] != ~0u && slot_of[j][k] != ~0u;
+        if (Q.lpair_ptr[s2 + 1] - Q.lpair_ptr[s2] != want) return why(6);
+        uint32_t last = ~0u;
+        for (uint32_t q = Q.lpair_ptr[s2]; q < Q.lpair_ptr[s2 + 1]; ++q) {
+            const uint32_t sa = Q.lpairs[2 * q], sb = Q.lpairs[2 * q + 1];
+            if (sa >= zlo || sb >= zlo) return why(7);
+            const uint32_t k = Q.l_col[sa];
+            if (k >= j || Q.l_col[sb] != k || slot_of[i][k] != sa || slot_of[j][k] != sb) return why(7);
+            if (last != ~0u) before(last, k);
+            last = k;
+        }
+    }
+    // fill closed: two entries of a column imply the entry between their rows
+    for (uint32_t k = 0; k < nv; ++k)
+        for (size_t x = 0; x < w.col[k].size(); ++x)
+            for (size_t y = x + 1; y < w.col[k].size(); ++y)
+                if (slot_of[w.col[k][y].first][w.col[k][x].first] == ~0u) return why(8);
+    // one order of the columns that respects every list (smallest ready column first: the class program's own order when
+    // its lists ascend)
+    std::vector<char> done(nv, 0);
+    for (uint32_t step = 0; step < nv; ++step) {
+        uint32_t pick = ~0u;
+        for (uint32_t v = 0; v < nv && pick == ~0u; ++v)
+            if (!done[v] && waiting[v] == 0) pick = v;
+        if (pick == ~0u) return why(9);  // (lists that contradict each other: no such order)
+        done[pick] = 1;
+        w.order.push_back(pick);
+        for (uint32_t y : after[pick]) --waiting[y];
+    }
+    w.ok = true;
+    return w;
+}
+void emit_wave_row_table(std::string& o, const Class& cl) {
+    const WaveRows w = wave_row_structure(cl);
+    if (!w.ok) return;
+    const Program& Q = cl.Q;
+    const uint32_t nv = Q.c.n_vars, nq = 2 * nv + Q.c.zlo;
+    auto S = [](uint32_t v) { return std::to_string(v); };
+    // kWaveRow[k * 64 + lane] = where lane's entry of column k sits among the assembled quantities (nq = a zero)
+    o += "__device__ const uint16_t kWaveRow[" + S((nv - 1) * 64) + "] = {";
+    for (uint32_t k = 0; k + 1 < nv; ++k)
+        for (uint32_t l = 0; l < 64; ++l) {
+            const uint32_t row = std::min(l, nv - 1);
+            uint32_t at = nq;
+            for (const auto& e : w.col[k])
+                if (e.first == row) at = 2 * nv + e.second;
+            o += ((k * 64 + l) % 32 == 0 ? "\n    " : " ") + S(at) + ",";
+        }
+    o += "\n};\n";
+}
+void emit_tail_wave(std::string& o, const Class& cl) {
+    const WaveRows w = wave_row_structure(cl);
+    auto S = [](uint32_t v) { return std::to_string(v); };
+    if (!w.ok) {
+        o += "    static constexpr bool HAS_TAIL_WAVE = false;\n    static constexpr int NROW = 1;\n";
+        o += "    static __device__ __forceinline__ uint32_t row_slot(int, int) { return 0; }\n";
+        o += "    static __device__ __forceinline__ bool tail_wave(const double*, double, const uint32_t (&)[1], int, double*, double&, bool&) { return false; }\n";
+        return;
+    }
+    const uint32_t nv = cl.Q.c.n_vars;
+    o += "    static constexpr bool HAS_TAIL_WAVE = true;\n    static constexpr int NROW = " + S(nv - 1) + ";\n";
+    o += "    static __device__ __forceinline__ uint32_t row_slot(int k, int lane) { return kWaveRow[k * 64 + lane]; }\n";
+    o += "    static __device__ __forceinline__ bool tail_wave(const double* Q, double lambda, const uint32_t (&rs)[" + S(nv - 1) +
+         "], int lane, double* d, double& dmax, bool& fin) {\n        using ezpz::jit::lane_value;\n        bool bad = false;\n";
+    o += "        const int me = lane < NV ? lane : NV - 1;\n        double Dm = Q[me] + lambda, Vm = Q[NV + me];\n";
+    for (uint32_t k = 0; k + 1 < nv; ++k) o += "        double a" + S(k) + " = Q[rs[" + S(k) + "]];\n";
+    for (uint32_t k : w.order) {
+        const std::string K = S(k);
+        o += "        const double P" + K + " = lane_value(Dm, " + K + "); if (!(P" + K + " > 0.0)) bad = true;\n";
+        o += "        const double D" + K + " = sqrt(P" + K + "), Y" + K + " = lane_value(Vm, " + K + ") / D" + K + "; fin = fin && __builtin_isfinite(Y" + K + ");\n";
+        if (w.col[k].empty()) continue;
+        o += "        a" + K + " = a" + K + " / D" + K + ";\n";
+        for (size_t x = 0; x + 1 < w.col[k].size(); ++x) {
+            const std::string J = S(w.col[k][x].first);
+            o += "        a" + J + " -= a" + K + " * lane_value(a" + K + ", " + J + ");\n";
+        }
+        o += "        Dm -= a" + K + " * a" + K + "; Vm -= a" + K + " * Y" + K + ";\n";
+    }
+    for (size_t t = w.order.size(); t-- > 0;) {
+        const uint32_t k = w.order[t];
+        const std::string K = S(k);
+        o += "        double X" + K + " = Y" + K + ";\n";
+        for (uint32_t i : w.bwd[k]) o += "        X" + K + " -= lane_value(a" + K + ", " + S(i) + ") * X" + S(i) + ";\n";
+        o += "        X" + K + " = X" + K + " / D" + K + "; d[" + K + "] = X" + K + "; dmax = ezpz::dev::fmax_abs(dmax, X" + K + ");\n";
+    }
+    o += "        (void)Vm; (void)Dm;\n        return bad;\n    }\n";
+}
+
 // ---- one wavefront per system (jit_kernel.hip.hpp, wave_kernel): the latency shape of a small system -------------------------------
 // The lane class (same statements, same order) plus what spreads the sweeps and the assembly over 64 lanes: the constraint
 // records as a table (lane ci evaluates constraint ci through a dispatch over the kinds present), the operand pairs of
@@ -908,6 +1071,7 @@ void emit_wave(std::string& o, const std::string& cls, const Class& cl, const Ez
         for (uint32_t s2 = 0; s2 < zj; ++s2) o += hexf(cl.jconst[s2]) + ", ";
         o += "};\n";
     }
+    emit_wave_row_table(o, cl);
     o += "}  // namespace\n\nstruct ClsW : Cls0 {\n";
     o += "    static constexpr int ZJ = " + S(zj) + ", NQ = " + S(nq) + ", PMAX = " + S(pmax) + ";\n";
     o += "    static __device__ __forceinline__ DevCon con(int ci) { return kWaveCons[ci]; }\n";
@@ -942,6 +1106,7 @@ void emit_wave(std::string& o, const std::string& cls, const Class& cl, const Ez
         emit_elimination(o, cl, fast != 0, fastdiv);
         o += std::string("        (void)Q; (void)lambda;") + (fast ? " (void)ok;" : "") + "\n        return bad;\n    }\n";
     }
+    emit_tail_wave(o, cl);
     o += "};\n\nextern \"C\" __global__ void __launch_bounds__(64) ezpz_jit_wave(const ezpz::jit::LaneArgs a) {\n";
     o += std::string("    ezpz::jit::wave_kernel<ClsW, ") + (unit_weights ? "true" : "false") + ">(a);\n}\n";
 }

@@ -98,7 +98,12 @@ int build_freedom(EzpzSystem* sys) {
         HIP_TRY(hipMemcpy(F.comps.p, comps.data(), comps.size() * sizeof(FreedomComp), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(F.lists.p, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     F.ncomp = (uint32_t)comps.size();
-    if (!comps.empty()) F.comp0 = comps[0];
+    F.big = 0;
+    for (size_t c = 1; c < comps.size(); ++c) {
+        auto words = [](const FreedomComp& k) { return (uint64_t)k.m * k.n + 2ull * k.n * k.n + 2ull * k.n; };
+        if (words(comps[c]) > words(comps[F.big])) F.big = (uint32_t)c;
+    }
+    if (!comps.empty()) F.comp0 = comps[F.big];
     F.ws = std::max<uint32_t>(ws, 1);
     F.max_n = max_n;
     // LANE: a lane per (system, component) with 128 private workspaces in <= 64 KiB of LDS
@@ -168,8 +173,8 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
             grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(batch, 1024), (4ull << 30) / per));
             if ((rc = F.gws.ensure((size_t)grid * F.ws)) != EZPZ_OK) return rc;
             a.gws = F.gws.p;
-            if (F.ncomp == 1 && F.comp0.n >= 96) {
-                // One big component: its pivoted QR as a chain of step launches over the whole device (freedom.hip.hpp),
+            if (F.comp0.n >= 96) {
+                // A big component (the system's largest; the others, if any, follow on the ordinary kernel): its pivoted QR as a chain of step launches over the whole device (freedom.hip.hpp),
                 // `grid` systems side by side, then the ordinary kernel for rank / null space / participation.
                 if ((rc = F.step_done.ensure(grid)) != EZPZ_OK) return rc;
                 if ((rc = F.step_tau.ensure(grid)) != EZPZ_OK) return rc;
@@ -231,7 +236,7 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                     fa.mask = a.mask + base * n;
                     fa.n_under = a.n_under ? a.n_under + base : nullptr;
                     fa.batch = nb;
-                    fa.qr_done = 1;
+                    fa.qr_done = F.big + 1;
                     hipLaunchKernelGGL(freedom_kernel<false>, dim3(nb), dim3(F.threads), lds, stream, fa);
                 }
                 HIP_TRY(hipGetLastError());

@@ -38,7 +38,7 @@ struct FreedomArgs {
     uint32_t n, zj, ncomp;
     uint32_t ws;     // workspace doubles of the largest component
     uint32_t group;  // LANE: systems per workgroup
-    uint32_t qr_done;  // TEAM, global workspace: the pivoted QR is already in the workspace (step kernels below)
+    uint32_t qr_done;  // TEAM, global workspace: 1 + the component whose pivoted QR is already in the workspace (step kernels below), 0 = none
 };
 
 constexpr double kFreedomRankTol = 1e-8;  // find_dof.rs:12
@@ -358,10 +358,12 @@ __global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
         } else {
             const double tol = kFreedomRankTol * __longlong_as_double((long long)sysmax[0]);
             double* w = a.gws ? a.gws + (size_t)blockIdx.x * a.ws : wsl;
-            for (uint32_t c = 0; c < a.ncomp; ++c) {
+            // (the component whose QR the step kernels left in the workspace goes first: the others reuse the workspace)
+            for (uint32_t q = 0; q < a.ncomp; ++q) {
+                const uint32_t c = !a.qr_done ? q : q == 0 ? a.qr_done - 1 : q <= a.qr_done - 1 ? q - 1 : q;
                 const FreedomComp cd = a.comps[c];
                 freedom_component(BlockCtx{red}, Ws{w, 1}, cd, a.items, a.jv + base * a.zj, tol, a.comp_vars + cd.var0,
-                                  a.part + base * a.n, &partmax[0], a.qr_done != 0);
+                                  a.part + base * a.n, &partmax[0], a.qr_done != 0 && q == 0);
             }
         }
         __threadfence_block();

@@ -922,12 +922,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// lane `l`'s value of v on every lane (l a literal after unrolling: two v_readlane_b32 into a scalar register pair)
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 template <class C, bool UNIT_W>
 __device__ __forceinline__ void wave_kernel(const LaneArgs& a) {
     using namespace ezpz::dev;
     constexpr int NV = C::NV, M = C::M > 0 ? C::M : 1, ZJ = C::ZJ, NQ = C::NQ, NQR = (NQ + 63) / 64, PMAX = C::PMAX;
     constexpr int O_A = 0, O_NR = ZJ + 1, O_X = ZJ + 1 + M, O_XT = O_X + NV, O_R = O_XT + NV, O_RN = O_R + M, O_Q = O_RN + M,
-                  O_D = O_Q + NQ, LDS_DOUBLES = O_D + NV;
+                  O_D = O_Q + NQ + 1, LDS_DOUBLES = O_D + NV;  // (Q[NQ] = 0: the entries of L a row does not have)
     __shared__ double lds[LDS_DOUBLES];
     __shared__ unsigned long long resident_word;
     double* const A = lds + O_A;    // Jacobian slots, then one zero (the operand of padding pairs), then -r by row
@@ -946,7 +952,10 @@ __device__ __forceinline__ void wave_kernel(const LaneArgs& a) {
     for (int k = 0; k < NQR; ++k)
 #pragma unroll
         for (int p = 0; p < PMAX; ++p) pr[k][p] = C::pair(k, p, lane);
-    if (lane == 0) A[ZJ] = 0.0;
+    if (lane == 0) A[ZJ] = 0.0, Q[NQ] = 0.0;
+    uint32_t rs[C::NROW];  // where this lane's row of L sits among the assembled quantities (tail_wave)
+#pragma unroll
+    for (int k = 0; k < C::NROW; ++k) rs[k] = C::row_slot(k, lane);
     if constexpr (C::LINEAR) {
         for (int s2 = lane; s2 < ZJ; s2 += 64) A[s2] = C::jconst(s2);
     }
@@ -1036,10 +1045,21 @@ __device__ __forceinline__ void wave_kernel(const LaneArgs& a) {
             wave_sync();
             double dmax = __builtin_nan("");
             bool ok = true;
-            bool bad = C::tail(Q, lambda, dl, dmax, ok);
-            if (!ok && !bad) {  // an operand outside the short division's range: plain divisions
-                dmax = __builtin_nan("");
-                bad = C::tail_exact(Q, lambda, dl, dmax);
+            bool bad;
+            if constexpr (C::HAS_TAIL_WAVE) {  // the elimination across the lanes (comp_program.cpp: emit_tail_wave), same bits
+                bool fin = true;
+                bad = C::tail_wave(Q, lambda, rs, lane, dl, dmax, fin);
+                if (!fin && !bad) {  // a right-hand side that is not finite: the serial order (comp_program.cpp: emit_tail_wave)
+                    wave_sync();
+                    dmax = __builtin_nan("");
+                    bad = C::tail_exact(Q, lambda, dl, dmax);
+                }
+            } else {
+                bad = C::tail(Q, lambda, dl, dmax, ok);
+                if (!ok && !bad) {  // an operand outside the short division's range: plain divisions
+                    dmax = __builtin_nan("");
+                    bad = C::tail_exact(Q, lambda, dl, dmax);
+                }
             }
             wave_sync();  // (every lane has written the same d: read back by lane index below)
             if (bad) {  // LltError::Numeric: lambda *= 10, burn the iteration (newton.rs:93-99)

@@ -225,7 +225,8 @@ struct EzpzSystem {
         uint32_t o_vars = 0, o_col_ptr = 0, o_col_slots = 0;
         DevBuf<double> x_int, jv, part, gws, step_tau;
         DevBuf<uint32_t> step_done;
-        FreedomComp comp0{};  // host copy of the first component (the wide QR path runs on one-component systems)
+        FreedomComp comp0{};  // host copy of the largest component (the wide QR path factorises it over the whole device)
+        uint32_t big = 0;     // ... and its index
         DevBuf<uint8_t> mask;
         DevBuf<uint32_t> count;
     } freedom;

@@ -1026,8 +1026,9 @@ def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, monke
 
 
 def test_freedom_two_large_components_on_one_workgroup(E):
-    """Two 120-variable chains in one system: not a one-component system, so each system's components are factorised in
-    sequence by one workgroup out of the global workspace (rows contiguous, norms summed during the update)."""
+    """Two 120-variable chains in one system: the larger workspace of the two is factorised over the whole device (its QR
+    left in the global workspace for the ordinary kernel, which takes that component first), the other in sequence by one
+    workgroup out of the same workspace (rows contiguous, norms summed during the update)."""
     recs, g = _chain_system(60)
     recs2 = recs.copy()
     recs2["ids"] = recs2["ids"] + len(g)

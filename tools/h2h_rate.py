@@ -4,6 +4,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+if os.environ.get('TORCH') == '1':  # (the same call inside a process that has initialised torch's HIP runtime, like bench.py)
+    import torch
+    torch.zeros(1, device='cuda:0')
 import ezpz_amd as E
 import gen
 lines = int(sys.argv[1]) if len(sys.argv) > 1 else 500
