@@ -818,10 +818,13 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             // the state does not fit costs spills: 2400 x 2400 at 3 instead of 2: 53 -> 43)
             const int min_waves = env_mw ? std::atoi(env_mw) : (int)std::min<uint64_t>(4, std::max<uint64_t>(1, 512 / (vg + 50)));
             const std::string bounds = std::to_string(T * 64) + (min_waves > 0 ? ", " + std::to_string(min_waves) : "");
-            o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve(const ezpz::jit::JitArgs a) {\n";
-            o += "    __shared__ double smem[ezpz::jit::kRedDoubles + 16];\n";
-            o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
-                 (plan.unit_weights ? "true" : "false") + ">(a, smem);\n}\n";
+            // two entries: batches, and (`_one`) one-call launches that stay resident for the caller's next request
+            for (int one = 0; one < 2; ++one) {
+                o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve" + (one ? "_one" : "") + "(const ezpz::jit::JitArgs a) {\n";
+                o += "    __shared__ double smem[ezpz::jit::kRedDoubles + 16];\n";
+                o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
+                     (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ">(a, smem);\n}\n";
+            }
             align4(blob);
             plan.o_jit_slots = (uint32_t)blob.size();
             for (uint32_t w = 0; w < G * T; ++w)  // wavefront w of the system (workgroup w / T) owns consecutive chunks
@@ -1148,8 +1151,10 @@ bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LaneP
     std::string& o = plan.jit_source;
     o = cls;
     static const char* env_lb = std::getenv("EZPZ_JIT_LANE_BOUNDS");  // e.g. "256, 2" -- for measurements
-    o += std::string("extern \"C\" __global__ void __launch_bounds__(") + (env_lb ? env_lb : "256") + ") ezpz_jit_lane(const ezpz::jit::LaneArgs a) {\n";
-    o += std::string("    ezpz::jit::lane_kernel<Cls0, ") + (plan.unit_weights ? "true" : "false") + ">(a);\n}\n";
+    for (int one = 0; one < 2; ++one) {  // (batches; `_one`: one-call launches that stay resident, jit_kernel.hip.hpp)
+        o += std::string("extern \"C\" __global__ void __launch_bounds__(") + (env_lb ? env_lb : "256") + ") ezpz_jit_lane" + (one ? "_one" : "") + "(const ezpz::jit::LaneArgs a) {\n";
+        o += std::string("    ezpz::jit::lane_kernel<Cls0, ") + (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ">(a);\n}\n";
+    }
     plan.n_vars = (uint32_t)n_vars;
     plan.n_cons = (uint32_t)n_cs;
     plan.n_rows = Q.c.n_rows;

@@ -427,8 +427,11 @@ __device__ __forceinline__ DevCon mkcon(uint32_t kind, uint32_t tag, uint32_t nr
     return c;
 }
 
-// SEQ: Slots<...> of one wavefront; NWAVES wavefronts share a system; UNIT_W: every weight is 1.
-template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W>
+// SEQ: Slots<...> of one wavefront; NWAVES wavefronts share a system; UNIT_W: every weight is 1.  RESIDENT: the entry of
+// one-call launches (`<entry>_one`), which publishes its completion word and waits for the calling thread's next request
+// (wave_ops.hip.hpp: publish_done, resident_next).  The batch entry is compiled without that loop: everything set up before it would stay
+// live across it -- 2000 x 2000 at three wavefronts per SIMD: 39 -> 75 spilled scalar registers, 88 -> 78 M solves/s.
+template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W, bool RESIDENT = false>
 __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     using namespace ezpz::dev;
     const int tid = threadIdx.x;
@@ -712,8 +715,8 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             if (ANY_NONLINEAR) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    publish_done(done);
-    } while (resident_next(done, born, reinterpret_cast<unsigned long long*>(smem + kRedDoubles + 8)));
+    if constexpr (RESIDENT) publish_done(done);
+    } while (RESIDENT && resident_next(done, born, reinterpret_cast<unsigned long long*>(smem + kRedDoubles + 8)));
 }
 
 // ---- one LANE per system ------------------------------------------------------------------------------------------------------
@@ -740,7 +743,7 @@ struct LaneArgs {
 };
 static_assert(sizeof(LaneArgs) == 144, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
 
-template <class C, bool UNIT_W>
+template <class C, bool UNIT_W, bool RESIDENT = false>
 __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
     using namespace ezpz::dev;
     constexpr int NV = C::NV, M = C::M > 0 ? C::M : 1, ZJ = C::ZJS > 0 ? C::ZJS : 1;
@@ -892,8 +895,8 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
             have = false;
         }
     }
-    publish_done(done);
-    } while (resident_next(done, born, &resident_word));
+    if constexpr (RESIDENT) publish_done(done);
+    } while (RESIDENT && resident_next(done, born, &resident_word));
 }
 
 // ---- one WAVEFRONT per system: the latency shape of a small system ----------------------------------------------------------------

@@ -408,6 +408,19 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
 }
 
 
+// The pipelined host-to-host path's copy out, as a kernel (pipeline.cpp): `bytes` (a multiple of 16) from device memory
+// into registered host memory through its device address, 16 bytes per lane and store.  Which engine moves a
+// hipMemcpyAsync is the runtime's choice; this one is ours (tools/pcie_duplex.hip: a copy kernel out beside copies in
+// keeps 41-43 GB/s each way whatever moves the copies in).
+__global__ void __launch_bounds__(256) copy_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+void launch_copy_out(void* dst_host_as_device, const void* src_dev, size_t bytes, void* stream) {
+    hipLaunchKernelGGL(copy_out_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(src_dev),
+                       static_cast<uint4*>(dst_host_as_device), bytes / 16);
+}
+
 // The evaluation-only kernel (K1: residuals and Jacobian values at given points, internal numbering) on `stream`.
 void launch_eval(EzpzSystem* sys, const double* x_int_dev, size_t batch, double* r_out_dev, double* jv_out_dev, uint32_t* deg_out_dev,
                  uint32_t grid, hipStream_t stream) {

@@ -164,6 +164,24 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
             return result;
         };
         static const bool h2h_debug = std::getenv("EZPZ_H2H_DEBUG") != nullptr;
+        // How the results leave: copies by the runtime (hipMemcpyAsync), or a copy kernel of ours into the registered buffer's
+        // device address (EZPZ_H2H_OUT=dma / kernel).  Both directions as runtime copies is the fastest pair where the
+        // runtime gives each direction an SDMA engine (46-48 GB/s each way, ROCm 7.2); the runtime PyTorch bundles (7.0)
+        // moves the copies in with a shader when a kernel's results wait on another stream, and a shader in beside SDMA out
+        // is the slowest pair there is (27-29 GB/s each way, tools/pcie_duplex.hip) -- a copy kernel out keeps 41-43 either way.
+        static const int out_env = [] {
+            const char* e = std::getenv("EZPZ_H2H_OUT");
+            return !e ? 0 : e[0] == 'k' ? 1 : e[0] == 'd' ? 2 : 0;
+        }();
+        static const bool out_auto_kernel = [] {
+            int v = 0;
+            return hipRuntimeGetVersion(&v) == hipSuccess && v < 70200000;  // (HIP_VERSION: major * 10^7 + minor * 10^5 + patch)
+        }();
+        void *x_out_mapped = nullptr, *st_mapped = nullptr;
+        bool out_by_kernel = (out_env == 1 || (out_env == 0 && out_auto_kernel)) &&
+                             hipHostGetDevicePointer(&x_out_mapped, x_out, 0) == hipSuccess;
+        if (out_by_kernel && st_registered && hipHostGetDevicePointer(&st_mapped, status, 0) != hipSuccess) out_by_kernel = false;
+        if (!out_by_kernel) (void)hipGetLastError();
         const auto t_enq0 = std::chrono::steady_clock::now();
         size_t k = 0;
         for (size_t off = 0; off < batch; off += piece, ++k) {
@@ -189,11 +207,16 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                 return drain(EZPZ_ERR_HIP);
             rc = ezpz_system_solve_batch_device(sys, xd, nb, cfg, xd, sys->st_dev.p + off, nullptr, nullptr, 0, P.run);
             if (rc != EZPZ_OK) return drain(rc);
-            if (hipEventRecord(P.solved[sl], P.run) != hipSuccess || hipStreamWaitEvent(P.out, P.solved[sl], 0) != hipSuccess ||
-                hipMemcpyAsync(x_out + off * n, xd, nb * row, hipMemcpyDeviceToHost, P.out) != hipSuccess ||
-                (st_registered && hipMemcpyAsync(status + off, sys->st_dev.p + off, nb * sizeof(EzpzStatus), hipMemcpyDeviceToHost, P.out) != hipSuccess) ||
-                hipEventRecord(P.left[sl], P.out) != hipSuccess)
+            if (hipEventRecord(P.solved[sl], P.run) != hipSuccess || hipStreamWaitEvent(P.out, P.solved[sl], 0) != hipSuccess) return drain(EZPZ_ERR_HIP);
+            if (out_by_kernel) {
+                launch_copy_out(reinterpret_cast<char*>(x_out_mapped) + off * row, xd, nb * row, P.out);
+                if (st_registered) launch_copy_out(reinterpret_cast<char*>(st_mapped) + off * sizeof(EzpzStatus), sys->st_dev.p + off, nb * sizeof(EzpzStatus), P.out);
+                if (hipGetLastError() != hipSuccess) return drain(EZPZ_ERR_HIP);
+            } else if (hipMemcpyAsync(x_out + off * n, xd, nb * row, hipMemcpyDeviceToHost, P.out) != hipSuccess ||
+                       (st_registered && hipMemcpyAsync(status + off, sys->st_dev.p + off, nb * sizeof(EzpzStatus), hipMemcpyDeviceToHost, P.out) != hipSuccess)) {
                 return drain(EZPZ_ERR_HIP);
+            }
+            if (hipEventRecord(P.left[sl], P.out) != hipSuccess) return drain(EZPZ_ERR_HIP);
         }
         const auto t_enq1 = std::chrono::steady_clock::now();
         if ((rc = drain(EZPZ_OK)) != EZPZ_OK) return rc;
@@ -549,7 +572,7 @@ extern "C" {
 int ezpz_host_register(void* p, size_t bytes) {
     if (!p || !bytes) return EZPZ_ERR_INVALID_ARGUMENT;
     if (ezpz_device_count() < 1) return EZPZ_ERR_NO_DEVICE;
-    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
         (void)hipGetLastError();
         return EZPZ_ERR_HIP;
     }

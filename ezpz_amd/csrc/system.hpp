@@ -223,7 +223,7 @@ struct EzpzSystem {
         DevBuf<FreedomComp> comps;
         DevBuf<uint32_t> lists;  // items | comp_vars | col_ptr | col_slots
         uint32_t o_vars = 0, o_col_ptr = 0, o_col_slots = 0;
-        DevBuf<double> x_int, jv, part, gws, step_tau;
+        DevBuf<double> x_in, x_int, jv, part, gws, step_tau;
         DevBuf<uint32_t> step_done;
         FreedomComp comp0{};  // host copy of the largest component (the wide QR path factorises it over the whole device)
         uint32_t big = 0;     // ... and its index
@@ -311,6 +311,8 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
 
 void launch_eval(EzpzSystem* sys, const double* x_int_dev, size_t batch, double* r_out_dev, double* jv_out_dev, uint32_t* deg_out_dev,
                  uint32_t grid, hipStream_t stream);  // the evaluation-only kernel (values in internal numbering)
+
+void launch_copy_out(void* dst_host_as_device, const void* src_dev, size_t bytes, void* stream);  // a copy kernel into mapped host memory
 
 // ---- api.hip ----------------------------------------------------------------------------------------------------------------
 int ensure_program(EzpzSystem* sys);  // the rest of a deferred analysis (EzpzSystem::program_deferred)
