@@ -795,11 +795,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
         for (size_t k = 0; k < classes.size(); ++k) vg += per_slot(k) * slots_k[k];
         if (T && T <= 16 && vg <= 360 && G <= 256 && (plan.interpretable || G > 1)) {
             std::string& o = plan.jit_source;
-            static const bool peel = [] {  // (A/B runs; see jit_kernel.hip.hpp)
-                const char* e = std::getenv("EZPZ_JIT_PEEL");
-                return e && e[0] == '1';
-            }();
-            o = std::string(peel ? "#define EZPZ_JIT_PEEL 1\n" : "") + "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
+            o = "#include \"jit_kernel.hip.hpp\"\nusing ezpz::DevCon;\n\n";
             for (size_t k = 0; k < classes.size(); ++k) emit_class(o, k, classes[k]);
             std::string seq;
             uint32_t nslots = 0;

@@ -98,7 +98,7 @@ struct CompPlan {
     bool interpretable = true;   // the state fits one CU's LDS: comp_solve_kernel can run the plan (else specialised only)
 };
 
-constexpr size_t kJitGridScratchBytes = 114752;  // sizeof(ezpz::jit::GridScratch), one per system in flight
+constexpr size_t kJitGridScratchBytes = 65600;  // sizeof(ezpz::jit::GridScratch), one per system in flight
 
 struct CompLimits {
     size_t lds_bytes = 160 * 1024;

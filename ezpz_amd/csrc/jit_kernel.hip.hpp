@@ -18,12 +18,6 @@
 #include "constraint_eval.hip.hpp"
 #include "wave_ops.hip.hpp"
 
-// EZPZ_JIT_PEEL (set by the generated source, comp_program.cpp; environment EZPZ_JIT_PEEL for A/B runs): the first LM
-// iteration shares eval()'s rendezvous (solve_kernel below).
-#ifndef EZPZ_JIT_PEEL
-#define EZPZ_JIT_PEEL 0
-#endif
-
 namespace ezpz {
 namespace jit {
 
@@ -56,16 +50,16 @@ static_assert(sizeof(JitArgs) == 176, "JitArgs is restated on the host (jit.cpp:
 // chunk moved by one device-coherent (sc0 sc1) 128-bit access, so it validates itself: no atomics, no fences.  All
 // workgroups of a launch must be resident at once (the host sizes the launch; the spin is bounded all the same).
 constexpr int kGridMaxWgs = 256;
-constexpr int kGridVals = 6;  // values of the widest reduction (the first iteration's: eval()'s two + the step's four)
+constexpr int kRedDoubles = 96;  // Red::buf: two turns of 3 x 16 partials; flag words and the resident word follow (smem[kRedDoubles + 16])
 typedef unsigned int gridchunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, seq, 0)
 struct GridScratch {
     int nwarn[2];  // Degenerate-warning counters, by parity of the system's turn in this slot
     int dead;      // a rendezvous timed out
     int pad[13];
-    gridchunk_t arr[2][kGridVals][kGridMaxWgs];  // [parity of the sequence number][value][workgroup]: partials
-    gridchunk_t out[2][kGridMaxWgs][8];          // [parity][workgroup]: the results in one 128-byte line
+    gridchunk_t arr[2][4][kGridMaxWgs];  // [parity of the sequence number][value][workgroup]: partials
+    gridchunk_t out[2][kGridMaxWgs][4];  // [parity][workgroup]: the four results in one 64-byte line
 };
-static_assert(sizeof(GridScratch) == 114752, "GridScratch is sized on the host (comp_program.hpp: kJitGridScratchBytes)");
+static_assert(sizeof(GridScratch) == 65600, "GridScratch is sized on the host (comp_program.hpp: kJitGridScratchBytes)");
 
 __device__ __forceinline__ void grid_store(gridchunk_t* p, double v, unsigned int seq) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -81,75 +75,48 @@ __device__ __forceinline__ gridchunk_t grid_peek(const gridchunk_t* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(c) : "v"(p) : "memory");
     return c;
 }
-__device__ __forceinline__ double grid_value(const gridchunk_t& c) {
-    return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
-}
-__device__ __forceinline__ bool grid_give_up(unsigned int spins, int* dead) {  // the spin is bounded: the system reports a time-out
-    if ((spins & 1023u) != 1023u) return false;
-    if (spins < (1u << 21) && !__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
-}
 __device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int seq, int* dead) {
     gridchunk_t c;
     for (unsigned int spins = 0;; ++spins) {
         c = grid_peek(p);
         if (c.z == seq) break;
-        if (grid_give_up(spins, dead)) return __builtin_nan("");
+        if ((spins & 1023u) == 1023u &&
+            (spins >= (1u << 21) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return __builtin_nan("");
+        }
         __builtin_amdgcn_s_sleep(1);
     }
-    return grid_value(c);
+    return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
 }
-// NV chunks at once (the partials of one workgroup, `stride` chunks apart): the loads are in flight together, one round
-// trip to the memory side instead of NV.
-template <int NV>
-__device__ __forceinline__ void grid_wait_all(const gridchunk_t* p, size_t stride, unsigned int seq, int* dead, double (&v)[NV]) {
-    static_assert(NV == 2 || NV == 4 || NV == 6, "reductions of two, four or six values");
-    gridchunk_t c[6];
+// Four chunks at once (the four partials of one workgroup): the four loads are in flight together, one round trip to
+// the memory side instead of four.
+__device__ __forceinline__ void grid_wait4(const gridchunk_t* p0, const gridchunk_t* p1, const gridchunk_t* p2, const gridchunk_t* p3,
+                                           unsigned int seq, int* dead, double (&v)[4]) {
+    gridchunk_t c0, c1, c2, c3;
     for (unsigned int spins = 0;; ++spins) {
-        if constexpr (NV == 2) {
-            asm volatile(
-                "global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
-                "global_load_dwordx4 %1, %3, off sc0 sc1\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(c[0]), "=&v"(c[1])
-                : "v"(p), "v"(p + stride)
-                : "memory");
-            c[2] = c[3] = c[4] = c[5] = c[0];
-        } else if constexpr (NV == 4) {
-            asm volatile(
-                "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
-                "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-                "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
-                "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
-                : "v"(p), "v"(p + stride), "v"(p + 2 * stride), "v"(p + 3 * stride)
-                : "memory");
-            c[4] = c[5] = c[0];
-        } else {
-            asm volatile(
-                "global_load_dwordx4 %0, %6, off sc0 sc1\n\t"
-                "global_load_dwordx4 %1, %7, off sc0 sc1\n\t"
-                "global_load_dwordx4 %2, %8, off sc0 sc1\n\t"
-                "global_load_dwordx4 %3, %9, off sc0 sc1\n\t"
-                "global_load_dwordx4 %4, %10, off sc0 sc1\n\t"
-                "global_load_dwordx4 %5, %11, off sc0 sc1\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5])
-                : "v"(p), "v"(p + stride), "v"(p + 2 * stride), "v"(p + 3 * stride), "v"(p + 4 * stride), "v"(p + 5 * stride)
-                : "memory");
-        }
-        if (c[0].z == seq && c[1].z == seq && c[2].z == seq && c[3].z == seq && c[4].z == seq && c[5].z == seq) break;
-        if (grid_give_up(spins, dead)) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) v[k] = __builtin_nan("");
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+            "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+            "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+            "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+            : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+            : "memory");
+        if (c0.z == seq && c1.z == seq && c2.z == seq && c3.z == seq) break;
+        if ((spins & 1023u) == 1023u &&
+            (spins >= (1u << 21) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[0] = v[1] = v[2] = v[3] = __builtin_nan("");
             return;
         }
         __builtin_amdgcn_s_sleep(1);
     }
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = grid_value(c[k]);
+    v[0] = __builtin_bit_cast(double, ((unsigned long long)c0.y << 32) | c0.x);
+    v[1] = __builtin_bit_cast(double, ((unsigned long long)c1.y << 32) | c1.x);
+    v[2] = __builtin_bit_cast(double, ((unsigned long long)c2.y << 32) | c2.x);
+    v[3] = __builtin_bit_cast(double, ((unsigned long long)c3.y << 32) | c3.x);
 }
 
 // One component per lane of one class: everything in registers (every index below is a literal after inlining).
@@ -192,11 +159,6 @@ struct Slots<C, Rest...> {
         f(head, static_cast<C*>(nullptr), index);
         tail.each(f, index + 1);
     }
-};
-
-template <bool B>
-struct BoolTag {
-    static constexpr bool value = B;
 };
 
 __device__ __forceinline__ double uniform(double v) {  // a value every lane holds -> scalar registers
@@ -248,169 +210,133 @@ __device__ __forceinline__ void opaque_copy(const double (&a)[N], double (&b)[N]
     }
 }
 
-// Workgroup reductions with one barrier (the same scheme as CompRed in comp_kernel.hip.hpp): NS sums, then NM NaN-ignoring
-// maxima, and (FLAG) one "any lane says so".  Wavefronts reduce by DPP, park their partials in LDS, and every lane folds
-// the <= 16 partials in the same fixed tree after the barrier.
-constexpr int kRedVals = 6;              // the widest reduction: two sums, three maxima, and across workgroups the flag
-constexpr int kRedDoubles = 2 * kRedVals * 16;  // buf: two turns of kRedVals x 16 partials; the flag words follow
+// Workgroup reductions with one barrier (the same scheme as CompRed in comp_kernel.hip.hpp).
 struct Red {
-    double* buf;
+    double* buf;  // 2 x 3 x 16 doubles
     int* flags;   // 3 words
     int flip, turn;
     GridScratch* grid;  // null: the workgroup owns its system alone
     uint32_t grid_wgs, grid_wg;
     unsigned int grid_seq;
-    // NS sums then NM maxima over the workgroups of a system; every thread passes the workgroup's values, every thread gets
-    // the system's.  (NV = 2, 4 or 6: a flag travels as one more maximum.)  Every workgroup publishes its partials;
-    // workgroup 0 alone polls them, folds them in a fixed tree and writes the results to one line per workgroup; every
-    // other workgroup polls only its own line.  (Measured against it on the 200 000-variable ladder, 98 workgroups per
-    // system: an ALL-GATHER -- every workgroup polls everybody's partials and folds them itself, one trip to the memory
-    // side instead of two -- 406 -> 243 k solves/s: 98 x 98 x 4 uncached loads per poll round and a fold in every workgroup
-    // cost more than the second trip.)
-    template <int NS, int NV>
-    __device__ __forceinline__ void across_workgroups(double (&v)[NV], int lane, uint32_t wave, uint32_t nwaves) {
+    // (sum, max, max, max) over the workgroups of a system; every thread passes the workgroup's values, every thread
+    // gets the system's
+    __device__ __forceinline__ void across_workgroups(double& s0, double& m1, double& m2, double& m3, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
         const int tid = threadIdx.x;
         const unsigned int seq = ++grid_seq;
         const unsigned int par = seq & 1u;
         // (a workgroup publishes sequence number s+1 only after it has consumed the result of s, and workgroup 0 writes
         // the result of s+2 only after every arrival for s+2: parities never collide)
-        if (tid < NV) {
-            double mine = v[0];
-#pragma unroll
-            for (int k = 1; k < NV; ++k) mine = tid == k ? v[k] : mine;
-            grid_store(&grid->arr[par][tid][grid_wg], mine, seq);
-        }
-        double* b = buf + (flip ? kRedVals * 16 : 0);
+        if (tid < 4) grid_store(&grid->arr[par][tid][grid_wg], tid == 0 ? s0 : tid == 1 ? m1 : tid == 2 ? m2 : m3, seq);
+        double* b = buf + (flip ? 48 : 0);
         flip ^= 1;
         if (grid_wg == 0) {
-            double acc[NV];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) acc[k] = k < NS ? 0.0 : __builtin_nan("");
+            double a0 = 0.0, a1 = __builtin_nan(""), a2 = a1, a3 = a1;
             for (uint32_t g = tid; g < grid_wgs; g += blockDim.x) {
-                double w[NV];
-                grid_wait_all<NV>(&grid->arr[par][0][g], kGridMaxWgs, seq, &grid->dead, w);
-#pragma unroll
-                for (int k = 0; k < NV; ++k) acc[k] = k < NS ? acc[k] + w[k] : fmax_nc(acc[k], w[k]);
+                double v[4];
+                grid_wait4(&grid->arr[par][0][g], &grid->arr[par][1][g], &grid->arr[par][2][g], &grid->arr[par][3][g], seq, &grid->dead, v);
+                a0 = a0 + v[0];
+                a1 = fmax_nc(a1, v[1]);
+                a2 = fmax_nc(a2, v[2]);
+                a3 = fmax_nc(a3, v[3]);
             }
-            static_assert(NV <= kRedVals, "Red::buf holds kRedVals rows per turn");
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                acc[k] = k < NS ? reduce_wave_to_last_lane(acc[k], OpSum()) : reduce_wave_to_last_lane(acc[k], OpMax());
-                if (lane == 63) b[16 * k + wave] = acc[k];
+            a0 = reduce_wave_to_last_lane(a0, OpSum());
+            a1 = reduce_wave_to_last_lane(a1, OpMax());
+            a2 = reduce_wave_to_last_lane(a2, OpMax());
+            a3 = reduce_wave_to_last_lane(a3, OpMax());
+            if (lane == 63) {
+                b[wave] = a0;
+                b[12 + wave] = a1;
+                b[24 + wave] = a2;
+                b[36 + wave] = a3;
             }
             __syncthreads();
             const bool in = (uint32_t)lane < nwaves;
             const int l = lane & 15;
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-                v[k] = k < NS ? uniform(reduce_lanes<16>(in ? b[16 * k + l] : 0.0, OpSum()))
-                              : uniform(reduce_lanes<16>(in ? b[16 * k + l] : __builtin_nan(""), OpMax()));
+            s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
+            m1 = uniform(reduce_lanes<16>(in ? b[12 + l] : __builtin_nan(""), OpMax()));
+            m2 = uniform(reduce_lanes<16>(in ? b[24 + l] : __builtin_nan(""), OpMax()));
+            m3 = uniform(reduce_lanes<16>(in ? b[36 + l] : __builtin_nan(""), OpMax()));
             for (uint32_t g = 1 + tid; g < grid_wgs; g += blockDim.x) {  // one line per workgroup
-#pragma unroll
-                for (int k = 0; k < NV; ++k) grid_store(&grid->out[par][g][k], v[k], seq);
+                grid_store(&grid->out[par][g][0], s0, seq);
+                grid_store(&grid->out[par][g][1], m1, seq);
+                grid_store(&grid->out[par][g][2], m2, seq);
+                grid_store(&grid->out[par][g][3], m3, seq);
             }
         } else {
-            if (tid < NV) b[tid] = grid_wait(&grid->out[par][grid_wg][tid], seq, &grid->dead);
+            if (tid < 4) b[tid] = grid_wait(&grid->out[par][grid_wg][tid], seq, &grid->dead);
             __syncthreads();
-#pragma unroll
-            for (int k = 0; k < NV; ++k) v[k] = uniform(b[k]);
+            s0 = uniform(b[0]);
+            m1 = uniform(b[1]);
+            m2 = uniform(b[2]);
+            m3 = uniform(b[3]);
         }
     }
     // (W: the power of two >= the number of wavefronts, <= 16 -- the fold of the wavefronts' partials stops there; the
     // lanes beyond hold the identity, so the narrower tree gives the bits of the 16-lane one)
-    // (PRE: bit k set = value k is already the wavefront's total, the same in every lane -- wave_total below)
-    template <int W, int NS, int NM, bool FLAG, unsigned PRE = 0>
-    __device__ __forceinline__ bool reduce(double (&v)[NS + NM], bool flag, int lane, uint32_t wave, uint32_t nwaves) {
+    template <int W>
+    __device__ __forceinline__ void sum_max(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
-        constexpr int NV = NS + NM;
-        static_assert(NV <= kRedVals, "Red::buf holds kRedVals rows per turn");
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-            if (!((PRE >> k) & 1u)) v[k] = k < NS ? reduce_wave_to_last_lane(v[k], OpSum()) : reduce_wave_to_last_lane(v[k], OpMax());
-        const bool any = FLAG && __ballot(flag) != 0;
+        s0 = reduce_wave_to_last_lane(s0, OpSum());
+        m1 = reduce_wave_to_last_lane(m1, OpMax());
         if (nwaves == 1) {  // one wavefront per system: no LDS, no barrier
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-                if (!((PRE >> k) & 1u)) v[k] = uniform(__shfl(v[k], 63, 64));
-            return any;
+            s0 = uniform(__shfl(s0, 63, 64));
+            m1 = uniform(__shfl(m1, 63, 64));
+            return;
         }
-        double* b = buf + (flip ? kRedVals * 16 : 0);
+        double* b = buf + (flip ? 48 : 0);
         flip ^= 1;
-        int* f = flags + turn;
         if (lane == 63) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) b[16 * k + wave] = v[k];
-        }
-        if constexpr (FLAG) {
-            const int next = turn == 2 ? 0 : turn + 1;
-            if (lane == 63) {
-                if (any) atomicOr(f, 1);
-                if (wave == 0) flags[next] = 0;  // last read two reductions ago, next set after this barrier
-            }
-            turn = next;
+            b[wave] = s0;
+            b[16 + wave] = m1;
         }
         __syncthreads();
         const bool in = (uint32_t)lane < nwaves;
         const int l = lane & 15;
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-            v[k] = k < NS ? uniform(reduce_lanes<W>(in ? b[16 * k + l] : 0.0, OpSum()))
-                          : uniform(reduce_lanes<W>(in ? b[16 * k + l] : __builtin_nan(""), OpMax()));
-        bool failed = FLAG && __builtin_amdgcn_readfirstlane(*f) != 0;
+        s0 = uniform(reduce_lanes<W>(in ? b[l] : 0.0, OpSum()));
+        m1 = uniform(reduce_lanes<W>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
         if (grid) {
-            if constexpr (FLAG) {
-                double w[NV + 1];
-#pragma unroll
-                for (int k = 0; k < NV; ++k) w[k] = v[k];
-                w[NV] = failed ? 1.0 : __builtin_nan("");
-                across_workgroups<NS, NV + 1>(w, lane, wave, nwaves);
-#pragma unroll
-                for (int k = 0; k < NV; ++k) v[k] = w[k];
-                failed = w[NV] > 0.0;
-            } else {
-                across_workgroups<NS, NV>(v, lane, wave, nwaves);
-            }
+            double m2 = __builtin_nan(""), m3 = __builtin_nan("");
+            across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
         }
-        return failed;
-    }
-    template <int W>
-    __device__ __forceinline__ void sum_max(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
-        double v[2] = {s0, m1};
-        reduce<W, 1, 1, false>(v, false, lane, wave, nwaves);
-        s0 = v[0];
-        m1 = v[1];
     }
     template <int W>
     __device__ __forceinline__ bool step(double& s0, double& m1, double& m2, bool flag, int lane, uint32_t wave, uint32_t nwaves) {
-        double v[3] = {s0, m1, m2};
-        const bool failed = reduce<W, 1, 2, true>(v, flag, lane, wave, nwaves);
-        s0 = v[0];
-        m1 = v[1];
-        m2 = v[2];
-        return failed;
-    }
-    // A wavefront's total, the same in every lane and therefore in scalar registers: what eval() leaves for the first
-    // step's rendezvous costs no vector register while the step's solve runs.
-    template <class Op>
-    static __device__ __forceinline__ double wave_total(double v, Op op) {
-        v = ezpz::dev::reduce_wave_to_last_lane(v, op);
-        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-        const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, 63), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), 63);
-        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-    }
-    // eval()'s sum of squares and maximum (wavefront totals) together with the first step's (newton.rs:45 and :96-118 in
-    // one rendezvous)
-    template <int W>
-    __device__ __forceinline__ bool first_step(double& e_sq, double& e_mx, double& s0, double& m1, double& m2, bool flag, int lane,
-                                               uint32_t wave, uint32_t nwaves) {
-        double v[5] = {e_sq, s0, e_mx, m1, m2};
-        const bool failed = reduce<W, 2, 3, true, 0x5u>(v, flag, lane, wave, nwaves);
-        e_sq = v[0];
-        s0 = v[1];
-        e_mx = v[2];
-        m1 = v[3];
-        m2 = v[4];
+        using namespace ezpz::dev;
+        s0 = reduce_wave_to_last_lane(s0, OpSum());
+        m1 = reduce_wave_to_last_lane(m1, OpMax());
+        m2 = reduce_wave_to_last_lane(m2, OpMax());
+        const bool any = __ballot(flag) != 0;
+        if (nwaves == 1) {
+            s0 = uniform(__shfl(s0, 63, 64));
+            m1 = uniform(__shfl(m1, 63, 64));
+            m2 = uniform(__shfl(m2, 63, 64));
+            return any;
+        }
+        double* b = buf + (flip ? 48 : 0);
+        flip ^= 1;
+        int* f = flags + turn;
+        const int next = turn == 2 ? 0 : turn + 1;
+        if (lane == 63) {
+            b[wave] = s0;
+            b[16 + wave] = m1;
+            b[32 + wave] = m2;
+            if (any) atomicOr(f, 1);
+            if (wave == 0) flags[next] = 0;  // last read two reductions ago, next set after this barrier
+        }
+        turn = next;
+        __syncthreads();
+        const bool in = (uint32_t)lane < nwaves;
+        const int l = lane & 15;
+        s0 = uniform(reduce_lanes<W>(in ? b[l] : 0.0, OpSum()));
+        m1 = uniform(reduce_lanes<W>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
+        m2 = uniform(reduce_lanes<W>(in ? b[32 + l] : __builtin_nan(""), OpMax()));
+        bool failed = __builtin_amdgcn_readfirstlane(*f) != 0;
+        if (grid) {
+            double m3 = failed ? 1.0 : __builtin_nan("");
+            across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
+            failed = m3 > 0.0;
+        }
         return failed;
     }
 };
@@ -439,7 +365,7 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
     Red red;
     red.buf = smem;
-    red.flags = reinterpret_cast<int*>(smem + kRedDoubles);
+    red.flags = reinterpret_cast<int*>(smem + 96);
     red.flip = 0;
     red.turn = 0;
     int* nwarn2 = red.flags + 4;
@@ -521,44 +447,20 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
                 log_mask(s, cls, wm, 1);
             }
         });
-        // EZPZ_JIT_PEEL (off; measured, see DESIGN.md "Round 4"): when an iteration follows eval() (max_iterations > 0) its
-        // sum of squares and maximum are reduced TOGETHER with the first step's -- that step needs nothing of eval() but
-        // the residuals every lane already holds, so it runs speculatively and the loop's first rendezvous settles eval()'s
-        // convergence test (newton.rs:50-60) and the step's accept test (newton.rs:118) at once: two rendezvous per
-        // 2-iteration solve instead of three.  A system that turns out converged at its guesses drops the speculative step
-        // (x was not moved; its warnings were only collected).  Bitwise the same results.  2000 x 2000: +2.5 % at two
-        // wavefronts per SIMD (70.4 -> 72.1 M solves/s), but the second copy of the loop body costs ~100 bytes of scratch
-        // per lane at the three per SIMD the kernel runs at: 85.5 -> 74.4 M (vector memory reads x 2.5, waiting 42 -> 58 %).
-        const bool peel = EZPZ_JIT_PEEL && a.max_iterations > 0;
-        double eval_sq = sq, eval_mx = mx;
-        if (peel) {
-            eval_sq = Red::wave_total(sq, OpSum());
-            eval_mx = Red::wave_total(mx, OpMax());
-        } else {
-            red.template sum_max<W>(eval_sq, eval_mx, lane, wave, NWAVES);
-        }
-        double residual_sq = eval_sq, largest = eval_mx;
+        red.template sum_max<W>(sq, mx, lane, wave, NWAVES);
+        double residual_sq = sq, largest = mx;
         uint32_t pass = 2;
         double lambda = a.initial_lambda;
-        // (opaque: the peeled first iteration always runs at the launch's initial lambda, and what depends on lambda alone --
-        // all of a linear class's factorisation -- would otherwise be formed once per launch and held in registers across
-        // the systems, where there are none to spare)
-        asm volatile("" : "+s"(lambda));
         uint32_t it = 0, iterations = a.max_iterations, converged = 0;
         bool r_is_at_x = true;
 
         // ---- the LM loop (newton.rs:47-139) ------------------------------------------------------------------------------------------
-        // One iteration from "solve" to the step test.  FIRST (the hand-peeled first iteration): the loop-top tests come
-        // after the rendezvous, from the reduced eval() values.  Returns true when the loop ends.
-        auto iteration = [&](auto first_tag) -> bool {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            if constexpr (!FIRST) {
-                if (it >= a.max_iterations) return true;      // newton.rs:141-144
-                if (largest <= a.residual_tolerance) {        // newton.rs:50-60
-                    iterations = it;
-                    converged = 1;
-                    return true;
-                }
+        for (;;) {
+            if (it >= a.max_iterations) break;            // newton.rs:141-144
+            if (largest <= a.residual_tolerance) {        // newton.rs:50-60
+                iterations = it;
+                converged = 1;
+                break;
             }
             bool lane_bad = false;
             double dmax = __builtin_nan("");
@@ -609,23 +511,11 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
                     mx = mx_s;
                 }
             });
-            bool bad;
-            if constexpr (FIRST) {
-                bad = red.template first_step<W>(eval_sq, eval_mx, sq, mx, dmax, lane_bad, lane, wave, NWAVES);
-                residual_sq = eval_sq;
-                largest = eval_mx;
-                if (largest <= a.residual_tolerance) {  // newton.rs:50-60, at iteration 0: the speculative step is dropped
-                    iterations = 0;
-                    converged = 1;
-                    return true;
-                }
-            } else {
-                bad = red.template step<W>(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
-            }
+            const bool bad = red.template step<W>(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
             if (bad) {  // numeric failure anywhere in the system => lambda *= 10, burn the iteration, x untouched
                 lambda *= LM_LAMBDA_INCR;
                 ++it;
-                return false;
+                continue;
             }
             const double step_inf_norm = (a.n_row > 0) ? dmax : 0.0;
             const bool accept = sq < residual_sq;  // strict, newton.rs:118
@@ -662,14 +552,10 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             if (step_inf_norm <= a.step_tolerance) {  // newton.rs:134-139
                 iterations = it;
                 converged = 1;
-                return true;
+                break;
             }
             ++it;
-            return false;
-        };
-        if (!peel || !iteration(BoolTag<true>()))
-            while (!iteration(BoolTag<false>())) {
-            }
+        }
 
         // ---- unsatisfied check (lib.rs:305-327, :358-370) and write-back -----------------------------------------------------------------
         const bool use_r = r_is_at_x && UNIT_W;
