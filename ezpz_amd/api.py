@@ -914,3 +914,15 @@ def analyze(records, n_vars: int) -> dict:
 
 def device_count() -> int:
     return lib().ezpz_device_count()
+
+
+def launch_policy(compute_units: int = 0):
+    """The table of launch-shape thresholds (include/ezpz_amd.h: EzpzLaunchPolicy) for a device of `compute_units` CUs
+    (0 = the current device)."""
+    from ._lib import CLaunchPolicy
+
+    p = CLaunchPolicy()
+    rc = lib().ezpz_launch_policy(int(compute_units), C.byref(p))
+    if rc != 0:
+        raise NonLinearSystemError(rc, -1, -1)
+    return p

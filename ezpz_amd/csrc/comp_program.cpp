@@ -940,17 +940,21 @@ WaveRows wave_row_structure(const Class& cl) {
         for (size_t x = 0; x < w.col[k].size(); ++x)
             for (size_t y = x + 1; y < w.col[k].size(); ++y)
                 if (slot_of[w.col[k][y].first][w.col[k][x].first] == ~0u) return why(8);
-    // one order of the columns that respects every list (smallest ready column first: the class program's own order when
-    // its lists ascend)
+    // one order of the columns that respects every list, taken in rounds (every column whose predecessors are all in earlier
+    // rounds, ascending): the class program's own order when its lists ascend, and columns of different branches of the
+    // elimination tree stay next to each other, which is what lets emit_tail_wave group their pivots
     std::vector<char> done(nv, 0);
-    for (uint32_t step = 0; step < nv; ++step) {
-        uint32_t pick = ~0u;
-        for (uint32_t v = 0; v < nv && pick == ~0u; ++v)
-            if (!done[v] && waiting[v] == 0) pick = v;
-        if (pick == ~0u) return why(9);  // (lists that contradict each other: no such order)
-        done[pick] = 1;
-        w.order.push_back(pick);
-        for (uint32_t y : after[pick]) --waiting[y];
+    while (w.order.size() < nv) {
+        std::vector<uint32_t> round;
+        for (uint32_t v = 0; v < nv; ++v)
+            if (!done[v] && waiting[v] == 0) round.push_back(v);
+        if (round.empty()) return why(9);  // (lists that contradict each other: no such order)
+        for (uint32_t v : round) {
+            done[v] = 1;
+            w.order.push_back(v);
+        }
+        for (uint32_t v : round)
+            for (uint32_t y : after[v]) --waiting[y];
     }
     w.ok = true;
     return w;
@@ -989,24 +993,67 @@ void emit_tail_wave(std::string& o, const Class& cl) {
          "], int lane, double* d, double& dmax, bool& fin) {\n        using ezpz::jit::lane_value;\n        bool bad = false;\n";
     o += "        const int me = lane < NV ? lane : NV - 1;\n        double Dm = Q[me] + lambda, Vm = Q[NV + me];\n";
     for (uint32_t k = 0; k + 1 < nv; ++k) o += "        double a" + S(k) + " = Q[rs[" + S(k) + "]];\n";
-    for (uint32_t k : w.order) {
-        const std::string K = S(k);
-        o += "        const double P" + K + " = lane_value(Dm, " + K + "); if (!(P" + K + " > 0.0)) bad = true;\n";
-        o += "        const double D" + K + " = sqrt(P" + K + "), Y" + K + " = lane_value(Vm, " + K + ") / D" + K + "; fin = fin && __builtin_isfinite(Y" + K + ");\n";
-        if (w.col[k].empty()) continue;
-        o += "        a" + K + " = a" + K + " / D" + K + ";\n";
-        for (size_t x = 0; x + 1 < w.col[k].size(); ++x) {
-            const std::string J = S(w.col[k][x].first);
-            o += "        a" + J + " -= a" + K + " * lane_value(a" + K + ", " + J + ");\n";
+    // Updates are applied in w.order (what fixes every entry's rounding); a column's pivot, its square root and its divisions
+    // only need the updates of ITS row to have been applied, so they are issued as early as that allows, together with the
+    // other columns that are ready then: independent square-root / division chains next to each other instead of one after
+    // the other (a sparse sketch's elimination tree is wide: 14 columns in 8 such groups for two rectangles).
+    {
+        const Program& Q = cl.Q;
+        std::vector<char> pivoted(nv, 0), applied(nv, 0);
+        auto ready = [&](uint32_t j) {
+            for (uint32_t q = Q.fwd_ptr[j]; q < Q.fwd_ptr[j + 1]; ++q)
+                if (!applied[Q.fwd_items[2 * q + 1]]) return false;
+            return true;
+        };
+        size_t pos = 0;
+        while (pos < w.order.size()) {
+            std::vector<uint32_t> R;
+            for (uint32_t j = 0; j < nv; ++j)
+                if (!pivoted[j] && ready(j)) R.push_back(j);
+            for (uint32_t k : R) o += "        const double P" + S(k) + " = lane_value(Dm, " + S(k) + "); if (!(P" + S(k) + " > 0.0)) bad = true;\n";
+            for (uint32_t k : R) o += "        const double D" + S(k) + " = sqrt(P" + S(k) + ");\n";
+            for (uint32_t k : R)
+                o += "        const double Y" + S(k) + " = lane_value(Vm, " + S(k) + ") / D" + S(k) + "; fin = fin && __builtin_isfinite(Y" + S(k) + ");\n";
+            for (uint32_t k : R) {
+                pivoted[k] = 1;
+                if (!w.col[k].empty()) o += "        a" + S(k) + " = a" + S(k) + " / D" + S(k) + ";\n";
+            }
+            while (pos < w.order.size() && pivoted[w.order[pos]]) {
+                const uint32_t k = w.order[pos++];
+                applied[k] = 1;
+                if (w.col[k].empty()) continue;
+                const std::string K = S(k);
+                for (size_t x = 0; x + 1 < w.col[k].size(); ++x) {
+                    const std::string J = S(w.col[k][x].first);
+                    o += "        a" + J + " -= a" + K + " * lane_value(a" + K + ", " + J + ");\n";
+                }
+                o += "        Dm -= a" + K + " * a" + K + "; Vm -= a" + K + " * Y" + K + ";\n";
+            }
         }
-        o += "        Dm -= a" + K + " * a" + K + "; Vm -= a" + K + " * Y" + K + ";\n";
     }
-    for (size_t t = w.order.size(); t-- > 0;) {
-        const uint32_t k = w.order[t];
-        const std::string K = S(k);
-        o += "        double X" + K + " = Y" + K + ";\n";
-        for (uint32_t i : w.bwd[k]) o += "        X" + K + " -= lane_value(a" + K + ", " + S(i) + ") * X" + S(i) + ";\n";
-        o += "        X" + K + " = X" + K + " / D" + K + "; d[" + K + "] = X" + K + "; dmax = ezpz::dev::fmax_abs(dmax, X" + K + ");\n";
+    // backward substitution: a column as soon as the rows of its entries are known, the ready columns' sums and divisions
+    // side by side (every sum in its list's order)
+    {
+        std::vector<char> known(nv, 0);
+        uint32_t left = nv;
+        while (left) {
+            std::vector<uint32_t> G;
+            for (uint32_t k = nv; k-- > 0;) {
+                if (known[k]) continue;
+                bool ok = true;
+                for (uint32_t i : w.bwd[k]) ok = ok && known[i];
+                if (ok) G.push_back(k);
+            }
+            for (uint32_t k : G) {
+                o += "        double X" + S(k) + " = Y" + S(k) + ";\n";
+                for (uint32_t i : w.bwd[k]) o += "        X" + S(k) + " -= lane_value(a" + S(k) + ", " + S(i) + ") * X" + S(i) + ";\n";
+            }
+            for (uint32_t k : G) {
+                o += "        X" + S(k) + " = X" + S(k) + " / D" + S(k) + "; d[" + S(k) + "] = X" + S(k) + "; dmax = ezpz::dev::fmax_abs(dmax, X" + S(k) + ");\n";
+                known[k] = 1;
+                --left;
+            }
+        }
     }
     o += "        (void)Vm; (void)Dm;\n        return bad;\n    }\n";
 }

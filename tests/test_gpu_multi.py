@@ -158,6 +158,28 @@ OVERSUBSCRIBED = textwrap.dedent("""
         assert np.array_equal(xm, np.concatenate(want_x)) and np.array_equal(stm["iterations"], np.array(want_it)), B
         x1, st1 = E.solve_batch_mixed(singles, topo, np.concatenate(parts))
         assert np.array_equal(x1, xm) and same_status(st1, stm), B
+    # a batch that crosses a launch-shape threshold when it is sharded: one connected sketch, more systems than lanes across
+    # the batch start at (64 x 4 x CUs), so the single-device call runs one lane per system while each of the three shards
+    # stays below the threshold and runs on the per-system teams -- another elimination order, another rounding: the header
+    # promises each shard the single-device entry's answer FOR THAT SHARD (checked bit for bit) and agreement with the
+    # whole-batch call to rounding (iteration counts, flags, coordinates at 1e-9 on this well-conditioned sketch)
+    recs, g = gen.connected_sketch(12, 1005)
+    n = len(g)
+    pol = E.launch_policy(0)
+    B = int(pol.lanes_min_systems_small) + 300
+    x0 = g[None, :] + gen.keyed_uniform(77, B, n, -0.02, 0.02)
+    single = E.System(recs, n)
+    multi = E.MultiSystem(recs, n, device_mask=0b111)
+    xs, sts, _ = single.solve_batch(x0)
+    xm, stm, _ = multi.solve_batch(x0)
+    for gi in range(3):
+        lo, cnt = multi.shard(B, gi)
+        assert cnt < pol.lanes_min_systems_small
+        xg, stg, _ = single.solve_batch(x0[lo:lo + cnt])
+        assert np.array_equal(xm[lo:lo + cnt], xg) and same_status(stm[lo:lo + cnt], stg), gi
+    assert np.array_equal(stm["converged"], sts["converged"]) and np.array_equal(stm["n_unsatisfied"], sts["n_unsatisfied"])
+    assert np.mean(stm["iterations"] == sts["iterations"]) > 0.999
+    assert np.allclose(xm, xs, rtol=0, atol=1e-9)
     print("oversubscribed ok")
 """)
 

@@ -1,0 +1,32 @@
+"""profiles/rNN_parity_bar.txt from the raw log tests/sensitivity.py appends to gpurun_out/parity_bar.txt during a GPU run:
+totals first, then every call in which a system needed the measured bar (calls that needed none are only counted).
+usage: python tools/parity_bar_summary.py gpurun_out/parity_bar.txt "<what was run>" > profiles/r04_parity_bar.txt"""
+import re
+import sys
+
+rx = re.compile(r"systems (\d+) \| measured bar needed (\d+) \| largest error among them ([\d.e+-]+) \| widest bar granted ([\d.e+-]+) \| "
+                r"iteration counts inside the oracle's range only (\d+) \| beyond the ceiling .*?\) (\d+)")
+lines = [l.rstrip("\n") for l in open(sys.argv[1]) if l.strip()]
+tot = need = beyond = its = clean = 0
+worst = widest = 0.0
+listed = []
+for l in lines:
+    m = rx.search(l)
+    if not m:
+        continue
+    t, n, e, w, i, b = int(m[1]), int(m[2]), float(m[3]), float(m[4]), int(m[5]), int(m[6])
+    tot, need, beyond, its = tot + t, need + n, beyond + b, its + i
+    worst, widest = max(worst, e), max(widest, w)
+    if n:
+        listed.append(l)
+    else:
+        clean += 1
+print(f"# tests/sensitivity.py: one line per assert_batch_matches_oracle call of {sys.argv[2] if len(sys.argv) > 2 else 'a GPU run'}.")
+print(f"# {tot} systems checked in {len(lines)} calls; {need} ({100.0 * need / max(tot, 1):.2f} %) missed the plain bar (1e-6, equal iterations) and were held "
+      f"to the measured one: coordinates within max(1e-6, 20 x the oracle's own spread under one-ulp moves of the start), never above "
+      f"the reference's 1e-4.  {need - beyond} of them were judged by coordinates (largest error {worst:.2e}, widest bar granted {widest:.2e}); "
+      f"{beyond} are (system, shape, start) checks of systems whose ORACLE answers differ among themselves by more than 5e-6: judged by "
+      f"residual and unsatisfied set instead (last column).  {its} iteration counts were inside the oracle's range rather than equal.")
+print(f"# calls in which no system needed the measured bar: {clean} (not listed); the other {len(listed)} follow.")
+for l in listed:
+    print(l)
