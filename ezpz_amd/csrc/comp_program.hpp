@@ -126,6 +126,9 @@ struct CompLaunch {
     uint32_t max_iterations;
     double residual_tolerance, step_tolerance, initial_lambda;
     DoneWord done;  // one-call launches: the completion word (dev_types.hpp), else null
+    // lane-per-system kernel only: the systems of one topology inside a ragged batch, in place (jit_kernel.hip.hpp: LaneArgs)
+    const uint64_t* row_offset = nullptr;
+    const uint32_t* sys_of = nullptr;
 };
 int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus,
                 size_t lds_limit, void* stream);

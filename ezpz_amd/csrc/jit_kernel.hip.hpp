@@ -625,9 +625,13 @@ struct LaneArgs {
     uint32_t n_row, n_cons;
     uint64_t batch;
     double residual_tolerance, step_tolerance, initial_lambda;
+    // a heterogeneous batch's systems of this topology, in place (mixed.hip): system i's values start at row_offset[i] of the
+    // caller's ragged x0 / x_out and its status goes to status[sys_of[i]]; null: dense rows of n_row values, status[i]
+    const uint64_t* row_offset;
+    const uint32_t* sys_of;
     DoneWord done;  // one-call launches: the completion word (dev_types.hpp)
 };
-static_assert(sizeof(LaneArgs) == 144, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
+static_assert(sizeof(LaneArgs) == 160, "LaneArgs is restated on the host (jit.cpp: LaneArgsHost)");
 
 template <class C, bool UNIT_W, bool RESIDENT = false>
 __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
@@ -660,7 +664,7 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
             sys = next;
             next += stride;
             have = true;
-            C::load(a.x0 + sys * a.n_row, x);
+            C::load(a.x0 + (a.row_offset ? a.row_offset[sys] : sys * a.n_row), x);
 #pragma unroll
             for (int k = 0; k < NV; ++k) xj[k] = x[k];
             nwarn = 0;
@@ -769,7 +773,7 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
             } else {
                 C::unsatisfied(x, par, true, unsat, mask, nullptr);
             }
-            C::store(a.x_out + sys * a.n_row, x);
+            C::store(a.x_out + (a.row_offset ? a.row_offset[sys] : sys * a.n_row), x);
             EzpzStatus st;
             st.iterations = iterations;
             st.converged = converged;
@@ -777,7 +781,7 @@ __device__ __forceinline__ void lane_kernel(const LaneArgs& a) {
             st.n_warnings = nwarn;
             st.final_residual_inf = (C::M > 0) ? largest : 0.0;
             st.final_lambda = lambda;
-            a.status[sys] = st;
+            a.status[a.sys_of ? (uint64_t)a.sys_of[sys] : sys] = st;
             have = false;
         }
     }

@@ -408,6 +408,29 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
 }
 
 
+// The systems of one topology inside a heterogeneous batch, solved IN PLACE by the lane-per-system kernel (mixed.hip): lane i
+// reads its values at row_offset[i] of the caller's ragged buffer, writes them back there and its status to
+// status[sys_of[i]] -- no gather into a block, no scatter back.  EZPZ_OK when it ran that way; 1 when this topology is not
+// (yet) served by that kernel (not a small system, kernel not compiled): the caller gathers, calls the ordinary entry, scatters.
+int lane_indexed_launch(EzpzSystem* sys, const double* x_ragged, const uint64_t* row_offset_dev, const uint32_t* sys_of_dev,
+                        uint64_t count, const EzpzConfig* cfg, double* x_out_ragged, EzpzStatus* status_all, void* stream) {
+    if (!sys || !sys->lane || !sys->jit || count == 0) return 1;
+    std::lock_guard<std::mutex> launch_lock(sys->launch_mu);
+    int st = comp_jit_state(sys->jit);
+    if (st == 0 && (count >= sys->lim.policy.jit_lane_min_batch || jit_sync())) st = comp_jit_request(sys->jit, jit_sync());
+    if (st != 2) return 1;
+    SolveArgs a{};
+    fill_cfg(a, cfg);
+    CompLaunch L = comp_launch_args(a);
+    L.x0 = x_ragged;
+    L.x_out = x_out_ragged;
+    L.status = status_all;
+    L.batch = count;
+    L.row_offset = row_offset_dev;
+    L.sys_of = sys_of_dev;
+    return lane_jit_launch(sys->jit, *sys->lane, L, sys->device, sys->lim.cus, static_cast<hipStream_t>(stream)) == EZPZ_OK ? EZPZ_OK : 1;
+}
+
 // The pipelined host-to-host path's copy out, as a kernel (pipeline.cpp): `bytes` (a multiple of 16) from device memory
 // into registered host memory through its device address, 16 bytes per lane and store.  Which engine moves a
 // hipMemcpyAsync is the runtime's choice; this one is ours (tools/pcie_duplex.hip: a copy kernel out beside copies in

@@ -312,6 +312,8 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
 void launch_eval(EzpzSystem* sys, const double* x_int_dev, size_t batch, double* r_out_dev, double* jv_out_dev, uint32_t* deg_out_dev,
                  uint32_t grid, hipStream_t stream);  // the evaluation-only kernel (values in internal numbering)
 
+int lane_indexed_launch(EzpzSystem* sys, const double* x_ragged, const uint64_t* row_offset_dev, const uint32_t* sys_of_dev, uint64_t count,
+                        const EzpzConfig* cfg, double* x_out_ragged, EzpzStatus* status_all, void* stream);  // launch.hip
 void launch_copy_out(void* dst_host_as_device, const void* src_dev, size_t bytes, void* stream);  // a copy kernel into mapped host memory
 
 // ---- api.hip ----------------------------------------------------------------------------------------------------------------
