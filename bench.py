@@ -107,7 +107,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=16384, help="systems per launch per GPU (4096 fills the 768 resident workgroups 5.3 times: the last round runs a third empty)")
+    ap.add_argument("--batch", type=int, default=65536,
+                    help="systems per launch per GPU (the gap between launches and the partly empty last round of the 768 resident "
+                         "workgroups are 2000 x 2000's 4096: 81.9, 16 384: 88.4, 32 768: 92.0, 65 536: 93.5, 131 072: 92.8 M solves/s)")
     ap.add_argument("--workload", default="massive500", help="massive<lines>[o] (o = over-constrained variant), sketch<points> (one connected sketch), a test_cases/ directory name, or mixed")
     ap.add_argument("--team", type=int, default=0, help="override lanes per system (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
@@ -724,8 +726,8 @@ def main():
                     multi = E.MultiSystem(records, n, device_mask=mask)
                     if args.specialize:
                         multi.specialize(wait=True)
-                    mb = world * min(B, 65536)
-                    mx = np.ascontiguousarray(np.tile(x0_host[: min(B, 65536)], (world, 1)))
+                    mb = world * min(B, 16384)  # (16 KB per system: 0.27 GB each way per device)
+                    mx = np.ascontiguousarray(np.tile(x0_host[: min(B, 16384)], (world, 1)))
                     mxo, mst = np.empty_like(mx), np.zeros(mb, dtype=E.STATUS_DTYPE)
                     for a_ in (mx, mxo, mst):
                         E.host_register(a_)

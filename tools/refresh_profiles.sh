@@ -10,6 +10,7 @@ EZPZ_JIT=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_interpre
 EZPZ_JIT=0 EZPZ_COMP=0 python bench.py --specialize 0 --legs 0 > $out/bench_massive_listwalk.json 2>/dev/null
 EZPZ_JIT_FASTDIV=0 python bench.py --legs 0 --cpu-seconds 0 --extras 0 > $out/bench_massive_plain_divisions.json 2>/dev/null
 python bench.py --batch 4096 --pmc 0 --cpu-seconds 0 --extras 0 --legs 0 > $out/bench_massive_b4096.json 2>/dev/null
+python bench.py --batch 16384 --pmc 0 --cpu-seconds 0 --extras 0 --legs 0 > $out/bench_massive_b16384.json 2>/dev/null   # (rounds 2-3 quoted this batch)
 python bench.py --workload massive600 --pmc 0 > $out/bench_massive600.json 2>/dev/null
 python bench.py --workload massive200 --pmc 0 > $out/bench_massive200.json 2>/dev/null
 python bench.py --workload massive500o --pmc 0 > $out/bench_massive500_overconstrained.json 2>/dev/null
@@ -20,7 +21,7 @@ python bench.py --workload sketch150 --batch 262144 --steps 10 --warmup 2 > $out
 python bench.py --workload sketch150 --batch 32768 --steps 10 --warmup 2 > $out/bench_sketch_300vars_b32768.json 2>/dev/null   # (below the lanes' batch: the teams' record walk)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m -- $PY bench.py --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
-find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b16384_kernel_stats.csv; rm -rf $out/stats_m
+find $out/stats_m -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/massive_b65536_kernel_stats.csv; rm -rf $out/stats_m
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s -- $PY bench.py --workload square --batch 65536 --cpu-seconds 0 --extras 0 --pmc 0 --legs 0 > /dev/null 2>&1
 find $out/stats_s -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/square_b65536_kernel_stats.csv; rm -rf $out/stats_s
 for w in "mixed 1048576 mixed_1M" "massive50000 64 ladder200k" "sketch150 262144 sketch_300vars_b262144" "sketch150 32768 sketch_300vars_b32768"; do set -- $w
@@ -51,4 +52,4 @@ hipcc --offload-arch=gfx950 -O2 -o tools/launch_floor.bin tools/launch_floor.hip
 hipcc --offload-arch=gfx950 -O2 -o tools/pcie_duplex.bin tools/pcie_duplex.hip 2>/dev/null && (echo "# tools/pcie_duplex.bin  (both directions of the host link at once: queues and piece sizes)"; ./tools/pcie_duplex.bin 2>&1) > $out/pcie_duplex.txt
 (echo "# python tools/h2h_rate.py [lines batch]  (ezpz_system_solve_batch between host buffers: pageable, then registered = the pipelined path)"; python tools/h2h_rate.py 2>&1 | tail -1; python tools/h2h_rate.py 600 16384 2>&1 | tail -1; python tools/h2h_rate.py 200 65536 2>&1 | tail -1) > $out/h2h_rate.txt
 (echo "# python tools/freedom_wide.py 150 400 1000  (FreedomAnalysis of one large component: the pivoted QR as one cooperative launch, then EZPZ_FREEDOM_CHAIN=1: round 3's chain of a launch pair per Householder step)"; python tools/freedom_wide.py 150 400 1000 2>&1 | grep variables; EZPZ_FREEDOM_CHAIN=1 python tools/freedom_wide.py 150 400 1000 2>&1 | grep variables) > $out/freedom_wide.txt
-head -3 $out/massive_b16384_kernel_stats.csv
+head -3 $out/massive_b65536_kernel_stats.csv
