@@ -205,7 +205,31 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                     const char* const chain_env = std::getenv("EZPZ_FREEDOM_CHAIN");  // (read per call: tests switch it)
                     const bool chain_only = chain_env && chain_env[0] == '1';
                     bool cooperative = false;
-                    if (!chain_only) {
+                    // ... first choice: the matrix resident in the workgroups' registers for the whole factorisation
+                    // (fr_qrc_kernel: up to 2048 rows, 8 columns per workgroup); EZPZ_FREEDOM_CHAIN=2: not this one (A/B runs)
+                    if (!chain_only && !(chain_env && chain_env[0] == '2') && m <= kQcRows) {
+                        int per_cu = 0, coop = 0;
+                        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
+                        if (coop && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fr_qrc_kernel, 1024, 0) == hipSuccess && per_cu > 0) {
+                            const uint64_t capacity = (uint64_t)sys->lim.cus * (uint64_t)per_cu;
+                            const uint32_t g_max = (uint32_t)std::min<uint64_t>(256, capacity / nb);
+                            uint32_t cper = g_max ? (nc + g_max - 1) / g_max : kQcCols + 1;
+                            if (cper <= kQcCols) {
+                                cper = std::max(cper, 1u);
+                                const uint32_t G = (nc + cper - 1) / cper;
+                                uint32_t nd = ndiag;
+                                void* params[] = {&sa, &nd, &cper};
+                                if (hip_debug()) std::fprintf(stderr, "[ezpz hip] resident QR: m %u n %u, %u workgroups x %u columns, %u systems\n", m, nc, G, cper, nb);
+                                const hipError_t ce = hipLaunchCooperativeKernel((const void*)fr_qrc_kernel, dim3(G, nb), dim3(1024), params, 0, stream);
+                                cooperative = ce == hipSuccess;
+                                if (!cooperative && hip_debug())
+                                    std::fprintf(stderr, "[ezpz hip] resident QR launch (%u x %u workgroups of %llu) -> %s\n", G, nb,
+                                                 (unsigned long long)capacity, hipGetErrorString(ce));
+                            }
+                        }
+                        (void)hipGetLastError();
+                    }
+                    if (!chain_only && !cooperative) {
                         int per_cu = 0, coop = 0;
                         (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
                         if (hip_debug()) std::fprintf(stderr, "[ezpz hip] cooperative launch attribute %d\n", coop);

@@ -404,6 +404,9 @@ __global__ void __launch_bounds__(256) fr_init_kernel(const FreedomStepArgs a) {
     const uint32_t mn = a.m * a.n, oPerm = mn + 2 * a.n * a.n;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < mn; e += gridDim.x * blockDim.x) W[e] = 0.0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n; j += gridDim.x * blockDim.x) W[oPerm + j] = (double)j;
+    // (fr_qrc_kernel's chunk area at the start of the null-space block: sequence numbers zero)
+    const uint32_t chunk_doubles = a.n * a.n < 6666u ? a.n * a.n : 6666u;  // = kQcChunkDoubles + 2 (alignment), defined below
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < chunk_doubles; e += gridDim.x * blockDim.x) W[mn + e] = 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.done[blockIdx.y] = 0;
 }
 __global__ void __launch_bounds__(256) fr_scatter_kernel(const FreedomStepArgs a) {
@@ -727,6 +730,246 @@ __global__ void __launch_bounds__(1024) fr_qr_kernel(const FreedomStepArgs a, co
         qr_rendezvous(arrivals, arrived, G);  // the trailing matrix and its norms are those of step k + 1
         if (!done && wg == 0 && tid == 0) W[(size_t)k * n + k] = beta;
     }
+}
+
+// The pivoted QR of the WIDE layout with the matrix RESIDENT ON CHIP (round 4, second form).  fr_qr_kernel above streams the
+// trailing matrix through the device once per Householder step (32 MB for 2000 variables: 17 us of a step) between two
+// rendezvous whose cache maintenance covers those 32 MB.  But the device's registers hold 128 MB: here every workgroup OWNS up
+// to kQcCols whole columns for the whole factorisation -- a column is 128 lanes x kQcPer rows in registers, rows interleaved
+// so that the rows still below the diagonal stay spread over the lanes -- and nothing of the matrix moves until the end:
+//   * a step's dot products, updates and new column norms are local to the owning workgroup (no partial sums to exchange);
+//   * the pivot is found from one (norm, position) candidate per workgroup: the largest norm, the smallest POSITION among equals
+//     -- positions as the swaps of the serial algorithm would leave them, tracked by every workgroup in a table of its own, so
+//     ties break exactly as in the chain.  Workgroup 0 gathers the candidates and scatters the winner, one line per workgroup;
+//   * the pivot column's owner scales it into the reflector and publishes it, tau in the slot of row k.
+// Everything that crosses workgroups travels as self-validating 16-byte chunks (value, sequence number, position) moved by
+// single device-coherent 128-bit accesses, like the reductions of the LM kernels' grid teams (lm_kernel.hip.hpp): a reader
+// polls until the chunk carries the step's sequence number -- no atomics, no fences, no cache maintenance.  (A first version
+// with two counter rendezvous per step, release / acquire fences around them, took 27 us per step whatever the size: 800
+// variables 18.4 ms, slower than fr_qr_kernel.)  The chunk area is zeroed by fr_init_kernel; sequence numbers start at 1.
+// R (every column at its final position) and the permutation are written once, at the end; the reflectors are not kept (the
+// rank / null-space stage reads R and the permutation only).  Sums run in another fixed order than the chain's and than
+// fr_qr_kernel's: deterministic, equal to rounding, held against the CPU restatement's dense QR by the same tests.
+// Limits: m <= kQcRows rows, n <= kQcCols x workgroups columns; beyond, fr_qr_kernel serves.  The launch is cooperative
+// (co-residency is the runtime's guarantee); the polls are bounded all the same (a time-out poisons the result with NaN).
+// grid = (workgroups per system, systems side by side); 1024 lanes = kQcCols column groups of 128.
+constexpr uint32_t kQcRows = 2048, kQcCols = 8, kQcSeg = 128, kQcPer = kQcRows / kQcSeg, kQcMaxWgs = 256;
+constexpr uint32_t kQcChunkDoubles = 2 * kQcRows + 2 * kQcMaxWgs + 8 * kQcMaxWgs + 8;  // reflector | candidates | results (a line each) | flags
+static_assert(kQcChunkDoubles == 6664, "fr_init_kernel zeroes this many doubles");
+typedef unsigned int qc_chunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, sequence number, position)
+__device__ __forceinline__ void qc_store(qc_chunk_t* p, double v, unsigned int seq, unsigned int pos) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    qc_chunk_t c;
+    c.x = (unsigned int)u, c.y = (unsigned int)(u >> 32), c.z = seq, c.w = pos;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(c) : "memory");
+}
+__device__ __forceinline__ qc_chunk_t qc_wait(const qc_chunk_t* p, unsigned int seq, unsigned int* dead) {
+    qc_chunk_t c;
+    for (unsigned int spins = 0;; ++spins) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(c) : "v"(p) : "memory");
+        if (c.z == seq) break;
+        if ((spins & 1023u) == 1023u && (spins >= (1u << 22) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
+            c.x = (unsigned int)nan, c.y = (unsigned int)(nan >> 32), c.w = 0;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return c;
+}
+__device__ __forceinline__ double qc_value(const qc_chunk_t& c) { return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x); }
+__device__ __forceinline__ double qc_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__global__ void __launch_bounds__(1024) fr_qrc_kernel(const FreedomStepArgs a, const uint32_t ndiag, const uint32_t C) {
+    __shared__ double v_lds[kQcRows];
+    __shared__ double part[kQcCols][2];
+    __shared__ double wgc_v[kQcCols];
+    __shared__ uint32_t wgc_p[kQcCols];
+    __shared__ double red[32];
+    __shared__ unsigned short col_at[kQcRows];  // position -> column, as the serial algorithm's swaps would leave it
+    __shared__ double bcast[4];
+    double* W = a.gws + (size_t)blockIdx.y * a.ws;
+    const uint32_t m = a.m, n = a.n, oNS = m * n, oPerm = m * n + 2 * n * n, oTau = oPerm + n;
+    const uint32_t G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
+    // the chunk area (the null-space block is not in use yet; zeroed by fr_init_kernel)
+    // (16-byte aligned: a chunk must be ONE access; m x n may be odd)
+    qc_chunk_t* const vch = reinterpret_cast<qc_chunk_t*>(W + oNS + ((reinterpret_cast<uintptr_t>(W + oNS) >> 3) & 1u));  // [row]: the reflector, tau at row k
+    qc_chunk_t* const candc = vch + kQcRows;                                               // [workgroup]: its candidate
+    qc_chunk_t* const resc = candc + kQcMaxWgs;                                            // [workgroup][4]: the winner, a 64-byte line each
+    unsigned int* const dead = reinterpret_cast<unsigned int*>(resc + 4 * kQcMaxWgs);
+    const uint32_t cg = tid >> 7, seg = tid & 127u, half = (tid >> 6) & 1u;
+    const uint32_t col = wg * C + cg;
+    const bool have = cg < C && col < n;
+    double areg[kQcPer];
+#pragma unroll
+    for (uint32_t q = 0; q < kQcPer; ++q) {
+        const uint32_t i = seg + kQcSeg * q;
+        areg[q] = have && i < m ? W[(size_t)i * n + col] : 0.0;
+    }
+    double nrm = have ? W[oTau + col] : -1.0;
+    uint32_t pos = col;
+    bool active = have;
+    for (uint32_t i = tid; i < n; i += blockDim.x) col_at[i] = (unsigned short)i;
+    __syncthreads();
+    for (uint32_t k = 0; k < ndiag; ++k) {
+        const unsigned int seq = k + 1;
+        // this workgroup's candidate: largest squared norm, smallest position among equals
+        if (seg == 0 && cg < kQcCols) {
+            wgc_v[cg] = active ? nrm : -1.0;
+            wgc_p[cg] = active ? pos : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = -1.0;
+            uint32_t bp = 0xFFFFFFFFu;
+            for (uint32_t c2 = 0; c2 < kQcCols; ++c2) {
+                const double v = wgc_v[c2];
+                const uint32_t p2 = wgc_p[c2];
+                if (v > bv || (v == bv && p2 < bp)) bv = v, bp = p2;
+            }
+            qc_store(candc + wg, bv, seq, bp);
+        }
+        double bv = -1.0;
+        uint32_t bp = 0xFFFFFFFFu;
+        if (wg == 0) {  // gather, decide, scatter
+            if (tid < G) {
+                const qc_chunk_t c = qc_wait(candc + tid, seq, dead);
+                bv = qc_value(c);
+                bp = c.w;
+                if (!(bv >= 0.0)) bv = -1.0, bp = 0xFFFFFFFFu;  // (NaN norms never win, like the chain's `s > bv`)
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(bv, off);
+                const uint32_t op = (uint32_t)__shfl_xor((int)bp, off);
+                if (ov > bv || (ov == bv && op < bp)) bv = ov, bp = op;
+            }
+            if ((tid & 63u) == 0) {
+                red[tid >> 6] = bv;
+                red[16 + (tid >> 6)] = (double)bp;
+            }
+            __syncthreads();
+            bv = red[0];
+            bp = (uint32_t)red[16];
+            for (uint32_t q = 1; q < 16; ++q) {
+                const double ov = red[q];
+                const uint32_t op = (uint32_t)red[16 + q];
+                if (ov > bv || (ov == bv && op < bp)) bv = ov, bp = op;
+            }
+            if (tid > 0 && tid < G) qc_store(resc + 4 * tid, bv, seq, bp);
+        } else {
+            if (tid == 0) {
+                const qc_chunk_t c = qc_wait(resc + 4 * wg, seq, dead);
+                bcast[1] = qc_value(c);
+                bcast[2] = (double)c.w;
+            }
+            __syncthreads();
+            bv = bcast[1];
+            bp = (uint32_t)bcast[2];
+        }
+        if (!(bv > 0.0)) break;  // nothing left (or NaN, or a time-out): the remaining diagonal is exactly zero -- the same decision everywhere
+        const uint32_t pc = col_at[bp], ck = col_at[k];
+        __syncthreads();
+        if (tid == 0) {
+            col_at[k] = (unsigned short)pc;
+            col_at[bp] = (unsigned short)ck;
+        }
+        const bool mine = have && col == pc;  // this column group holds the pivot column
+        if (have && col == ck) pos = bp;
+        if (mine) pos = k;
+        if (pc / C == wg) {  // the owner: the reflector (find_dof.rs' Householder step, as fr_pivot_kernel forms it)
+            if (mine && seg == (k & 127u)) bcast[0] = areg[k >> 7];  // alpha = the entry of row k
+            __syncthreads();
+            const double norm = sqrt(bv), alpha = bcast[0];
+            const double beta = alpha >= 0.0 ? -norm : norm, denom = alpha - beta;
+            if (mine) {
+#pragma unroll
+                for (uint32_t q = 0; q < kQcPer; ++q) {
+                    const uint32_t i = seg + kQcSeg * q;
+                    if (i > k && i < m) qc_store(vch + i, areg[q] / denom, seq, 0);
+                    if (i == k) {
+                        areg[q] = beta;
+                        qc_store(vch + k, (beta - alpha) / beta, seq, 0);  // tau rides in the slot of row k (v_k = 1)
+                    }
+                }
+                active = false;
+            }
+        }
+        {  // the reflector: a lane's (up to) two chunks requested together, one round trip instead of two
+            const uint32_t i0 = k + tid, i1 = i0 + 1024u;
+            if (i1 < m) {
+                qc_chunk_t c0, c1;
+                for (unsigned int spins = 0;; ++spins) {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
+                        "global_load_dwordx4 %1, %3, off sc0 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(c0), "=&v"(c1)
+                        : "v"(vch + i0), "v"(vch + i1)
+                        : "memory");
+                    if (c0.z == seq && c1.z == seq) break;
+                    if ((spins & 1023u) == 1023u && (spins >= (1u << 22) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
+                        c0.x = c1.x = (unsigned int)nan, c0.y = c1.y = (unsigned int)(nan >> 32);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                v_lds[i0] = qc_value(c0);
+                v_lds[i1] = qc_value(c1);
+            } else if (i0 < m) {
+                v_lds[i0] = qc_value(qc_wait(vch + i0, seq, dead));
+            }
+        }
+        __syncthreads();
+        const double tau = v_lds[k];
+        double dot = 0.0;
+        if (active) {
+#pragma unroll
+            for (uint32_t q = 0; q < kQcPer; ++q) {
+                const uint32_t i = seg + kQcSeg * q;
+                if (i > k && i < m) dot += v_lds[i] * areg[q];
+                if (i == k) dot += areg[q];
+            }
+        }
+        dot = qc_wave_sum(dot);
+        if ((tid & 63u) == 0) part[cg][half] = dot;
+        __syncthreads();
+        dot = (part[cg][0] + part[cg][1]) * tau;
+        __syncthreads();
+        double sq = 0.0;
+        if (active) {
+#pragma unroll
+            for (uint32_t q = 0; q < kQcPer; ++q) {
+                const uint32_t i = seg + kQcSeg * q;
+                if (i > k && i < m) {
+                    const double v = areg[q] - dot * v_lds[i];
+                    areg[q] = v;
+                    sq += v * v;
+                }
+                if (i == k) areg[q] -= dot;
+            }
+        }
+        sq = qc_wave_sum(sq);
+        if ((tid & 63u) == 0) part[cg][half] = sq;
+        __syncthreads();
+        if (active) nrm = part[cg][0] + part[cg][1];
+        __syncthreads();
+    }
+    // R at the columns' final positions, and the permutation
+    if (have) {
+#pragma unroll
+        for (uint32_t q = 0; q < kQcPer; ++q) {
+            const uint32_t i = seg + kQcSeg * q;
+            if (i < m) W[(size_t)i * n + pos] = areg[q];
+        }
+    }
+    if (wg == 0)
+        for (uint32_t p2 = tid; p2 < n; p2 += blockDim.x) W[oPerm + p2] = (double)col_at[p2];
 }
 
 }  // namespace ezpz

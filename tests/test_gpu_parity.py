@@ -1006,11 +1006,12 @@ def test_freedom_of_one_large_component_spread_over_the_device(E):
 
 @pytest.mark.parametrize("points", [150, 400])
 def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, monkeypatch):
-    """The two routes of the WIDE layout -- one cooperative launch for all steps, and the chain of one launch pair per step
-    it falls back to when the device cannot hold a system's workgroups at once (EZPZ_FREEDOM_CHAIN=1 forces it) -- sum in
-    different fixed orders: the same underconstrained set, participation equal to rounding, each against the oracle's
-    dense QR (300 and 800 variables; 800: 50 workgroups of 1024 lanes through 800 steps, rows of a chunk kept in
-    registers), and each bitwise repeatable."""
+    """The three routes of the WIDE layout -- the matrix resident in the workgroups' registers for the whole factorisation
+    (fr_qrc_kernel, the default up to 2048 rows), the trailing matrix streamed once per step inside one cooperative launch
+    (fr_qr_kernel, EZPZ_FREEDOM_CHAIN=2), and the chain of one launch pair per step they fall back to when the device
+    cannot hold a system's workgroups at once (EZPZ_FREEDOM_CHAIN=1) -- sum in different fixed orders: the same
+    underconstrained set, participation equal to rounding, the default against the oracle's dense QR (300 and 800
+    variables), and bitwise repeatable."""
     recs, g = gen.connected_sketch(points, 4242)
     recs = recs[:-3]
     sysobj = E.System(recs, len(g))
@@ -1019,10 +1020,11 @@ def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, monke
     _, mask, part = _freedom_vs_oracle(E, recs, len(g), x, atol=1e-8)
     mask_again, part_again = sysobj.freedom_batch(x)
     assert np.array_equal(part, part_again) and np.array_equal(mask, mask_again)
-    monkeypatch.setenv("EZPZ_FREEDOM_CHAIN", "1")
-    mask_chain, part_chain = sysobj.freedom_batch(x)
-    assert np.array_equal(mask_chain, mask) and mask.any()
-    assert np.allclose(part_chain, part, atol=1e-10)
+    for route in ("2", "1"):  # the streaming cooperative kernel (fr_qr_kernel), then the chain of launch pairs
+        monkeypatch.setenv("EZPZ_FREEDOM_CHAIN", route)
+        mask_other, part_other = sysobj.freedom_batch(x)
+        assert np.array_equal(mask_other, mask) and mask.any(), route
+        assert np.allclose(part_other, part, atol=1e-10), route
 
 
 def test_freedom_two_large_components_on_one_workgroup(E):

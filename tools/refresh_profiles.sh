@@ -51,5 +51,5 @@ python tools/ab_microbench.py $out > /dev/null 2>&1
 hipcc --offload-arch=gfx950 -O2 -o tools/launch_floor.bin tools/launch_floor.hip 2>/dev/null && (echo "# tools/launch_floor.bin  (host -> device -> host round trips by completion method)"; ./tools/launch_floor.bin 2>&1) > $out/launch_floor.txt
 hipcc --offload-arch=gfx950 -O2 -o tools/pcie_duplex.bin tools/pcie_duplex.hip 2>/dev/null && (echo "# tools/pcie_duplex.bin  (both directions of the host link at once: queues and piece sizes)"; ./tools/pcie_duplex.bin 2>&1) > $out/pcie_duplex.txt
 (echo "# python tools/h2h_rate.py [lines batch]  (ezpz_system_solve_batch between host buffers: pageable, then registered = the pipelined path)"; python tools/h2h_rate.py 2>&1 | tail -1; python tools/h2h_rate.py 600 16384 2>&1 | tail -1; python tools/h2h_rate.py 200 65536 2>&1 | tail -1) > $out/h2h_rate.txt
-(echo "# python tools/freedom_wide.py 150 400 1000  (FreedomAnalysis of one large component: the pivoted QR as one cooperative launch, then EZPZ_FREEDOM_CHAIN=1: round 3's chain of a launch pair per Householder step)"; python tools/freedom_wide.py 150 400 1000 2>&1 | grep variables; EZPZ_FREEDOM_CHAIN=1 python tools/freedom_wide.py 150 400 1000 2>&1 | grep variables) > $out/freedom_wide.txt
+(echo "# python tools/freedom_wide.py 150 400 850 1000  (FreedomAnalysis of one large component: the pivoted QR with the matrix resident in registers, then EZPZ_FREEDOM_CHAIN=2: one cooperative launch streaming the trailing matrix, then EZPZ_FREEDOM_CHAIN=1: round 3's chain of a launch pair per Householder step)"; python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables; EZPZ_FREEDOM_CHAIN=2 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables; EZPZ_FREEDOM_CHAIN=1 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables) > $out/freedom_wide.txt
 head -3 $out/massive_b65536_kernel_stats.csv
