@@ -197,36 +197,45 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                     sa.item1 = F.comp0.item1;
                     const uint32_t bl_mn = (uint32_t)std::min<uint64_t>(((uint64_t)m * nc + 255) / 256, 4096);
                     const uint32_t bl_it = std::max<uint32_t>(1, std::min<uint32_t>((sa.item1 - sa.item0 + 255) / 256, 1024));
-                    hipLaunchKernelGGL(fr_init_kernel, dim3(bl_mn, nb), dim3(256), 0, stream, sa);
-                    hipLaunchKernelGGL(fr_scatter_kernel, dim3(bl_it, nb), dim3(256), 0, stream, sa);
-                    hipLaunchKernelGGL(fr_norms_kernel, dim3((nc + 255) / 256, nb), dim3(256), 0, stream, sa);
-                    // the QR itself: one cooperative launch for all steps (fr_qr_kernel) when the device can hold its
-                    // workgroups at once, else (or EZPZ_FREEDOM_CHAIN=1, A/B runs) the chain of one launch pair per step
-                    const char* const chain_env = std::getenv("EZPZ_FREEDOM_CHAIN");  // (read per call: tests switch it)
+                    // The route of the QR, decided before the initialisation (which zeroes the resident route's chunk area):
+                    // first choice the matrix resident in the workgroups' registers for the whole factorisation (fr_qrc_kernel: up
+                    // to 2048 rows, 8 columns per workgroup, its reflector slots inside the null-space and Q blocks); then one
+                    // cooperative launch streaming the trailing matrix (fr_qr_kernel); then the chain of one launch pair per step.
+                    // EZPZ_FREEDOM_CHAIN=2 / 1 (read per call: tests switch it): not the first / only the last.
+                    const char* const chain_env = std::getenv("EZPZ_FREEDOM_CHAIN");
                     const bool chain_only = chain_env && chain_env[0] == '1';
-                    bool cooperative = false;
-                    // ... first choice: the matrix resident in the workgroups' registers for the whole factorisation
-                    // (fr_qrc_kernel: up to 2048 rows, 8 columns per workgroup); EZPZ_FREEDOM_CHAIN=2: not this one (A/B runs)
+                    uint32_t res_cper = 0, res_G = 0;
+                    sa.k = 0;
                     if (!chain_only && !(chain_env && chain_env[0] == '2') && m <= kQcRows) {
                         int per_cu = 0, coop = 0;
                         (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
                         if (coop && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fr_qrc_kernel, 1024, 0) == hipSuccess && per_cu > 0) {
                             const uint64_t capacity = (uint64_t)sys->lim.cus * (uint64_t)per_cu;
-                            const uint32_t g_max = (uint32_t)std::min<uint64_t>(256, capacity / nb);
-                            uint32_t cper = g_max ? (nc + g_max - 1) / g_max : kQcCols + 1;
-                            if (cper <= kQcCols) {
-                                cper = std::max(cper, 1u);
+                            const uint32_t g_max = (uint32_t)std::min<uint64_t>(kQcMaxWgs, capacity / nb);
+                            const uint64_t m_slot = ((uint64_t)m + 3) & ~3ull, room = 2ull * nc * nc;  // doubles of the two blocks
+                            for (uint32_t cper = g_max ? std::max(1u, (nc + g_max - 1) / g_max) : kQcCols + 1; cper <= kQcCols; ++cper) {
                                 const uint32_t G = (nc + cper - 1) / cper;
-                                uint32_t nd = ndiag;
-                                void* params[] = {&sa, &nd, &cper};
-                                if (hip_debug()) std::fprintf(stderr, "[ezpz hip] resident QR: m %u n %u, %u workgroups x %u columns, %u systems\n", m, nc, G, cper, nb);
-                                const hipError_t ce = hipLaunchCooperativeKernel((const void*)fr_qrc_kernel, dim3(G, nb), dim3(1024), params, 0, stream);
-                                cooperative = ce == hipSuccess;
-                                if (!cooperative && hip_debug())
-                                    std::fprintf(stderr, "[ezpz hip] resident QR launch (%u x %u workgroups of %llu) -> %s\n", G, nb,
-                                                 (unsigned long long)capacity, hipGetErrorString(ce));
+                                const uint64_t need = kQcSmallDoubles + 4ull * G * m_slot;  // two sets of slots, two doubles a chunk
+                                if (need <= room && need < 0xFFFFFFFFull) {
+                                    res_cper = cper, res_G = G;
+                                    sa.k = (uint32_t)need;
+                                    break;
+                                }
                             }
                         }
+                        (void)hipGetLastError();
+                    }
+                    hipLaunchKernelGGL(fr_init_kernel, dim3(bl_mn, nb), dim3(256), 0, stream, sa);
+                    hipLaunchKernelGGL(fr_scatter_kernel, dim3(bl_it, nb), dim3(256), 0, stream, sa);
+                    hipLaunchKernelGGL(fr_norms_kernel, dim3((nc + 255) / 256, nb), dim3(256), 0, stream, sa);
+                    bool cooperative = false;
+                    if (res_cper) {
+                        uint32_t nd = ndiag, cper = res_cper;
+                        void* params[] = {&sa, &nd, &cper};
+                        if (hip_debug()) std::fprintf(stderr, "[ezpz hip] resident QR: m %u n %u, %u workgroups x %u columns, %u systems\n", m, nc, res_G, cper, nb);
+                        const hipError_t ce = hipLaunchCooperativeKernel((const void*)fr_qrc_kernel, dim3(res_G, nb), dim3(1024), params, 0, stream);
+                        cooperative = ce == hipSuccess;
+                        if (!cooperative && hip_debug()) std::fprintf(stderr, "[ezpz hip] resident QR launch -> %s\n", hipGetErrorString(ce));
                         (void)hipGetLastError();
                     }
                     if (!chain_only && !cooperative) {

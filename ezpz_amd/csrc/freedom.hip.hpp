@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) fr_init_kernel(const FreedomStepArgs a) {
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < mn; e += gridDim.x * blockDim.x) W[e] = 0.0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n; j += gridDim.x * blockDim.x) W[oPerm + j] = (double)j;
     // (fr_qrc_kernel's chunk area at the start of the null-space block: sequence numbers zero)
-    const uint32_t chunk_doubles = a.n * a.n < 6666u ? a.n * a.n : 6666u;  // = kQcChunkDoubles + 2 (alignment), defined below
+    const uint32_t chunk_doubles = a.k;  // fr_qrc_kernel's chunk area (the host's figure; 0: not in use)
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < chunk_doubles; e += gridDim.x * blockDim.x) W[mn + e] = 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.done[blockIdx.y] = 0;
 }
@@ -741,7 +741,9 @@ __global__ void __launch_bounds__(1024) fr_qr_kernel(const FreedomStepArgs a, co
 //   * the pivot is found from one (norm, position) candidate per workgroup: the largest norm, the smallest POSITION among equals
 //     -- positions as the swaps of the serial algorithm would leave them, tracked by every workgroup in a table of its own, so
 //     ties break exactly as in the chain.  Workgroup 0 gathers the candidates and scatters the winner, one line per workgroup;
-//   * the pivot column's owner scales it into the reflector and publishes it, tau in the slot of row k.
+//   * every workgroup scales ITS candidate column into a reflector and publishes it (tau in the slot of row k) while the winner
+//     is being decided: when the others learn who won, the winner's reflector is already on its way -- two hops through
+//     memory per step on the critical path instead of three, for up to 8 MB of speculative stores per step.
 // Everything that crosses workgroups travels as self-validating 16-byte chunks (value, sequence number, position) moved by
 // single device-coherent 128-bit accesses, like the reductions of the LM kernels' grid teams (lm_kernel.hip.hpp): a reader
 // polls until the chunk carries the step's sequence number -- no atomics, no fences, no cache maintenance.  (A first version
@@ -752,16 +754,18 @@ __global__ void __launch_bounds__(1024) fr_qr_kernel(const FreedomStepArgs a, co
 // fr_qr_kernel's: deterministic, equal to rounding, held against the CPU restatement's dense QR by the same tests.
 // Limits: m <= kQcRows rows, n <= kQcCols x workgroups columns; beyond, fr_qr_kernel serves.  The launch is cooperative
 // (co-residency is the runtime's guarantee); the polls are bounded all the same (a time-out poisons the result with NaN).
-// Measured (workgroup 1, wall-clock stamps, 2000 variables): a step is 12.6 us -- its candidate 0.8, waiting for the winner 3.3
-// (two hops through memory), owner + swap 0.2, waiting for the reflector 5.3 (the owner's divisions and stores, one hop), the
-// two passes 3.0 -- against fr_qr_kernel's 35: 2000 variables 72 -> 25 ms per analysis, 800: 16.3 -> 9.0, 300: 4.4 -> 2.6.  Tried
-// on top and not kept: a wavefront as 8 columns x 8 rows (reads of the reflector become broadcasts, but the owner's scaling
-// and stores spread over 16 wavefronts: 25.9 -> 37 ms); row blocks above the diagonal skipped by scalar branches (the
-// blocks' LDS reads no longer overlap: 31 ms); the reflector kept in registers between the passes (32 spilled registers).
+// Measured (workgroup 1, wall-clock stamps, 2000 variables) with the OWNER publishing after the decision: a step was 12.6 us
+// -- its candidate 0.8, waiting for the winner 3.3 (two hops through memory), owner + swap 0.2, waiting for the reflector 5.3
+// (the owner's divisions and stores, one hop), the two passes 3.0 -- against fr_qr_kernel's 35: 2000 variables 72 -> 25.9 ms.
+// With every workgroup publishing its candidate's reflector ahead of the decision: 9.5 us, 2000 variables **19 ms** per
+// analysis (122 on the launch chain), 1700: 15.5, 800: 8.2 (16.3 streaming, 23.5 chain), 300: 2.6 (4.4).  Tried on top and
+// not kept: a wavefront as 8 columns x 8 rows (reads of the reflector become broadcasts, but the scaling and its stores
+// spread over 16 wavefronts: 25.9 -> 37 ms); row blocks above the diagonal skipped by scalar branches (the blocks' LDS
+// reads no longer overlap: 31 ms); the reflector kept in registers between the passes (32 spilled registers).
 // grid = (workgroups per system, systems side by side); 1024 lanes = kQcCols column groups of 128.
 constexpr uint32_t kQcRows = 2048, kQcCols = 8, kQcSeg = 128, kQcPer = kQcRows / kQcSeg, kQcMaxWgs = 256;
-constexpr uint32_t kQcChunkDoubles = 2 * kQcRows + 2 * kQcMaxWgs + 8 * kQcMaxWgs + 8;  // reflector | candidates | results (a line each) | flags
-static_assert(kQcChunkDoubles == 6664, "fr_init_kernel zeroes this many doubles");
+constexpr uint32_t kQcSmallDoubles = 2 * kQcMaxWgs + 8 * kQcMaxWgs + 8 + 2;  // candidates | results (a line each) | flags, alignment
+// (then the reflector slots: 2 sets x workgroups x rows chunks; the host sizes the area and fr_init_kernel zeroes it)
 typedef unsigned int qc_chunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, sequence number, position)
 __device__ __forceinline__ void qc_store(qc_chunk_t* p, double v, unsigned int seq, unsigned int pos) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -803,10 +807,16 @@ __global__ void __launch_bounds__(1024) fr_qrc_kernel(const FreedomStepArgs a, c
     const uint32_t G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
     // the chunk area (the null-space block is not in use yet; zeroed by fr_init_kernel)
     // (16-byte aligned: a chunk must be ONE access; m x n may be odd)
-    qc_chunk_t* const vch = reinterpret_cast<qc_chunk_t*>(W + oNS + ((reinterpret_cast<uintptr_t>(W + oNS) >> 3) & 1u));  // [row]: the reflector, tau at row k
-    qc_chunk_t* const candc = vch + kQcRows;                                               // [workgroup]: its candidate
-    qc_chunk_t* const resc = candc + kQcMaxWgs;                                            // [workgroup][4]: the winner, a 64-byte line each
+    qc_chunk_t* const area = reinterpret_cast<qc_chunk_t*>(W + oNS + ((reinterpret_cast<uintptr_t>(W + oNS) >> 3) & 1u));
+    qc_chunk_t* const candc = area;                              // [workgroup]: its candidate
+    qc_chunk_t* const resc = candc + kQcMaxWgs;                  // [workgroup][4]: the winner, a 64-byte line each
     unsigned int* const dead = reinterpret_cast<unsigned int*>(resc + 4 * kQcMaxWgs);
+    // [parity of the step][workgroup][row]: the reflector every workgroup forms from ITS candidate column while the winner is
+    // being decided (tau at row k) -- the winner's is then already on its way when the others learn who won.  Two sets: a
+    // workgroup overwrites its slot two steps later, which it only reaches after everybody has sent the next step's candidate,
+    // i.e. has read this one.
+    const uint32_t m_slot = (m + 3u) & ~3u;
+    qc_chunk_t* const slots = resc + 4 * kQcMaxWgs + 4;
     const uint32_t cg = tid >> 7, seg = tid & 127u, half = (tid >> 6) & 1u;
     const uint32_t col = wg * C + cg;
     const bool have = cg < C && col < n;
@@ -831,50 +841,78 @@ __global__ void __launch_bounds__(1024) fr_qrc_kernel(const FreedomStepArgs a, c
         __syncthreads();
         if (tid == 0) {
             double bv = -1.0;
-            uint32_t bp = 0xFFFFFFFFu;
+            uint32_t bp = 0xFFFFFFFFu, bc = 0;
             for (uint32_t c2 = 0; c2 < kQcCols; ++c2) {
                 const double v = wgc_v[c2];
                 const uint32_t p2 = wgc_p[c2];
-                if (v > bv || (v == bv && p2 < bp)) bv = v, bp = p2;
+                if (v > bv || (v == bv && p2 < bp)) bv = v, bp = p2, bc = c2;
             }
             qc_store(candc + wg, bv, seq, bp);
+            bcast[3] = bv > 0.0 ? (double)bc : -1.0;
         }
+        qc_chunk_t* const my_slot = slots + ((size_t)(k & 1u) * G + wg) * m_slot;
+        // the reflector of this workgroup's candidate (find_dof.rs' Householder step, as fr_pivot_kernel forms it), published
+        // before anybody knows whether it wins; workgroup 0 decides first (everybody waits for that) and publishes after
         double bv = -1.0;
         uint32_t bp = 0xFFFFFFFFu;
-        if (wg == 0) {  // gather, decide, scatter
-            if (tid < G) {
-                const qc_chunk_t c = qc_wait(candc + tid, seq, dead);
-                bv = qc_value(c);
-                bp = c.w;
-                if (!(bv >= 0.0)) bv = -1.0, bp = 0xFFFFFFFFu;  // (NaN norms never win, like the chain's `s > bv`)
+        // (two turns of ONE copy of the code: workgroups other than 0 publish, then wait for the decision; workgroup 0 decides
+        // first -- everybody waits for that -- and publishes after)
+#pragma unroll 1
+        for (uint32_t turn = 0; turn < 2; ++turn) {
+            if ((turn == 0) == (wg != 0)) {
+                __syncthreads();
+                const int bc = (int)bcast[3];
+                const bool cand_group = bc >= 0 && cg == (uint32_t)bc;
+                if (cand_group && seg == (k & 127u)) bcast[0] = areg[k >> 7];  // alpha = the entry of row k
+                __syncthreads();
+                if (cand_group) {
+                    const double norm = sqrt(nrm), alpha = bcast[0];
+                    const double beta = alpha >= 0.0 ? -norm : norm, denom = alpha - beta;
+#pragma unroll
+                    for (uint32_t q = 0; q < kQcPer; ++q) {
+                        const uint32_t i = seg + kQcSeg * q;
+                        if (i > k && i < m) qc_store(my_slot + i, areg[q] / denom, seq, 0);
+                        if (i == k) qc_store(my_slot + k, (beta - alpha) / beta, seq, 0);  // tau rides in the slot of row k (v_k = 1)
+                    }
+                }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_xor(bv, off);
-                const uint32_t op = (uint32_t)__shfl_xor((int)bp, off);
-                if (ov > bv || (ov == bv && op < bp)) bv = ov, bp = op;
+            if (turn == 0) {
+                if (wg == 0) {  // gather, decide, scatter
+                    if (tid < G) {
+                        const qc_chunk_t c = qc_wait(candc + tid, seq, dead);
+                        bv = qc_value(c);
+                        bp = c.w;
+                        if (!(bv >= 0.0)) bv = -1.0, bp = 0xFFFFFFFFu;  // (NaN norms never win, like the chain's `s > bv`)
+                    }
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const double ov = __shfl_xor(bv, off);
+                        const uint32_t op = (uint32_t)__shfl_xor((int)bp, off);
+                        if (ov > bv || (ov == bv && op < bp)) bv = ov, bp = op;
+                    }
+                    if ((tid & 63u) == 0) {
+                        red[tid >> 6] = bv;
+                        red[16 + (tid >> 6)] = (double)bp;
+                    }
+                    __syncthreads();
+                    bv = red[0];
+                    bp = (uint32_t)red[16];
+                    for (uint32_t q = 1; q < 16; ++q) {
+                        const double ov = red[q];
+                        const uint32_t op = (uint32_t)red[16 + q];
+                        if (ov > bv || (ov == bv && op < bp)) bv = ov, bp = op;
+                    }
+                    if (tid > 0 && tid < G) qc_store(resc + 4 * tid, bv, seq, bp);
+                } else {
+                    if (tid == 0) {
+                        const qc_chunk_t c = qc_wait(resc + 4 * wg, seq, dead);
+                        bcast[1] = qc_value(c);
+                        bcast[2] = (double)c.w;
+                    }
+                    __syncthreads();
+                    bv = bcast[1];
+                    bp = (uint32_t)bcast[2];
+                }
             }
-            if ((tid & 63u) == 0) {
-                red[tid >> 6] = bv;
-                red[16 + (tid >> 6)] = (double)bp;
-            }
-            __syncthreads();
-            bv = red[0];
-            bp = (uint32_t)red[16];
-            for (uint32_t q = 1; q < 16; ++q) {
-                const double ov = red[q];
-                const uint32_t op = (uint32_t)red[16 + q];
-                if (ov > bv || (ov == bv && op < bp)) bv = ov, bp = op;
-            }
-            if (tid > 0 && tid < G) qc_store(resc + 4 * tid, bv, seq, bp);
-        } else {
-            if (tid == 0) {
-                const qc_chunk_t c = qc_wait(resc + 4 * wg, seq, dead);
-                bcast[1] = qc_value(c);
-                bcast[2] = (double)c.w;
-            }
-            __syncthreads();
-            bv = bcast[1];
-            bp = (uint32_t)bcast[2];
         }
         if (!(bv > 0.0)) break;  // nothing left (or NaN, or a time-out): the remaining diagonal is exactly zero -- the same decision everywhere
         const uint32_t pc = col_at[bp], ck = col_at[k];
@@ -886,24 +924,14 @@ __global__ void __launch_bounds__(1024) fr_qrc_kernel(const FreedomStepArgs a, c
         const bool mine = have && col == pc;  // this column group holds the pivot column
         if (have && col == ck) pos = bp;
         if (mine) pos = k;
-        if (pc / C == wg) {  // the owner: the reflector (find_dof.rs' Householder step, as fr_pivot_kernel forms it)
-            if (mine && seg == (k & 127u)) bcast[0] = areg[k >> 7];  // alpha = the entry of row k
-            __syncthreads();
-            const double norm = sqrt(bv), alpha = bcast[0];
-            const double beta = alpha >= 0.0 ? -norm : norm, denom = alpha - beta;
-            if (mine) {
+        if (mine) {  // the winner's column: its diagonal entry of R, and out of the running (its reflector is published already)
+            const double norm = sqrt(bv);
 #pragma unroll
-                for (uint32_t q = 0; q < kQcPer; ++q) {
-                    const uint32_t i = seg + kQcSeg * q;
-                    if (i > k && i < m) qc_store(vch + i, areg[q] / denom, seq, 0);
-                    if (i == k) {
-                        areg[q] = beta;
-                        qc_store(vch + k, (beta - alpha) / beta, seq, 0);  // tau rides in the slot of row k (v_k = 1)
-                    }
-                }
-                active = false;
-            }
+            for (uint32_t q = 0; q < kQcPer; ++q)
+                if (seg + kQcSeg * q == k) areg[q] = areg[q] >= 0.0 ? -norm : norm;
+            active = false;
         }
+        const qc_chunk_t* const vch = slots + ((size_t)(k & 1u) * G + pc / C) * m_slot;
         {  // the reflector: a lane's (up to) two chunks requested together, one round trip instead of two
             const uint32_t i0 = k + tid, i1 = i0 + 1024u;
             if (i1 < m) {
