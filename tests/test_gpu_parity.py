@@ -1004,8 +1004,8 @@ def test_freedom_of_one_large_component_spread_over_the_device(E):
     assert np.all(mask2 == mask[0]) and np.allclose(part2, part[0], atol=1e-12)
 
 
-@pytest.mark.parametrize("points", [150, 400])
-def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, monkeypatch):
+@pytest.mark.parametrize("points,repeated", [(150, 0), (400, 0), (200, 60)])
+def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, repeated, monkeypatch):
     """The three routes of the WIDE layout -- the matrix resident in the workgroups' registers for the whole factorisation
     (fr_qrc_kernel, the default up to 2048 rows), the trailing matrix streamed once per step inside one cooperative launch
     (fr_qr_kernel, EZPZ_FREEDOM_CHAIN=2), and the chain of one launch pair per step they fall back to when the device
@@ -1014,6 +1014,8 @@ def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, monke
     variables), and bitwise repeatable."""
     recs, g = gen.connected_sketch(points, 4242)
     recs = recs[:-3]
+    if repeated:  # more rows than variables: some constraints twice (dependent rows; the factorisation runs out of pivots early)
+        recs = np.concatenate([recs, recs[:repeated]])
     sysobj = E.System(recs, len(g))
     x, st, _ = sysobj.solve_batch(g[None, :] + gen.keyed_uniform(53, 2, len(g), -0.01, 0.01), E.Config(max_iterations=60))
     monkeypatch.delenv("EZPZ_FREEDOM_CHAIN", raising=False)
