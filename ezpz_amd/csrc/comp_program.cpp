@@ -814,12 +814,21 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             // the state does not fit costs spills: 2400 x 2400 at 3 instead of 2: 53 -> 43)
             const int min_waves = env_mw ? std::atoi(env_mw) : (int)std::min<uint64_t>(4, std::max<uint64_t>(1, 512 / (vg + 50)));
             const std::string bounds = std::to_string(T * 64) + (min_waves > 0 ? ", " + std::to_string(min_waves) : "");
+            // eval()'s sums riding in the first iteration's rendezvous (jit_kernel.hip.hpp: FUSE) -- one rendezvous less per system.
+            // Measured on one box, 65 536 systems per launch: 800 x 800 (two wavefronts per system) 192.6 -> 203.0 M solves/s,
+            // 2000 x 2000 (four) 93.3 -> 90.3, 2400 x 2400 (four, two per SIMD) 64.5 -> 64.3, the over-constrained variant 24.5
+            // -> 24.2: taken where two wavefronts share a system; EZPZ_JIT_FUSE=1 / 0 forces it on / off (A/B runs).
+            static const int fuse_env = [] {
+                const char* e = std::getenv("EZPZ_JIT_FUSE");
+                return !e ? -1 : e[0] == '1' ? 1 : 0;
+            }();
+            const bool fuse = fuse_env < 0 ? T == 2 : fuse_env == 1;
             // two entries: batches, and (`_one`) one-call launches that stay resident for the caller's next request
             for (int one = 0; one < 2; ++one) {
                 o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve" + (one ? "_one" : "") + "(const ezpz::jit::JitArgs a) {\n";
                 o += "    __shared__ double smem[ezpz::jit::kRedDoubles + 16];\n";
                 o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
-                     (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ">(a, smem);\n}\n";
+                     (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse && G == 1 ? "true" : "false") + ">(a, smem);\n}\n";
             }
             align4(blob);
             plan.o_jit_slots = (uint32_t)blob.size();

@@ -50,7 +50,7 @@ static_assert(sizeof(JitArgs) == 176, "JitArgs is restated on the host (jit.cpp:
 // chunk moved by one device-coherent (sc0 sc1) 128-bit access, so it validates itself: no atomics, no fences.  All
 // workgroups of a launch must be resident at once (the host sizes the launch; the spin is bounded all the same).
 constexpr int kGridMaxWgs = 256;
-constexpr int kRedDoubles = 96;  // Red::buf: two turns of 3 x 16 partials; flag words and the resident word follow (smem[kRedDoubles + 16])
+constexpr int kRedDoubles = 160;  // Red::buf: two turns of up to 5 x 16 partials; flag words and the resident word follow (smem[kRedDoubles + 16])
 typedef unsigned int gridchunk_t __attribute__((ext_vector_type(4)));  // (value lo, value hi, seq, 0)
 struct GridScratch {
     int nwarn[2];  // Degenerate-warning counters, by parity of the system's turn in this slot
@@ -300,6 +300,54 @@ struct Red {
             across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
         }
     }
+    // step() with eval()'s two wave totals (e_s: a sum, e_m: a maximum; uniform per wavefront) riding in the same exchange:
+    // the system's first iteration then needs no rendezvous of its own for eval() (solve_kernel, FUSE).  One workgroup per
+    // system only (no grid teams).  buf holds 2 x 5 x 16 doubles for this form (kRedDoubles).
+    template <int W>
+    __device__ __forceinline__ bool step5(double& s0, double& m1, double& m2, double& e_s, double& e_m, bool flag, int lane, uint32_t wave,
+                                          uint32_t nwaves) {
+        using namespace ezpz::dev;
+        s0 = reduce_wave_to_last_lane(s0, OpSum());
+        m1 = reduce_wave_to_last_lane(m1, OpMax());
+        m2 = reduce_wave_to_last_lane(m2, OpMax());
+        const bool any = __ballot(flag) != 0;
+        if (nwaves == 1) {
+            s0 = uniform(__shfl(s0, 63, 64));
+            m1 = uniform(__shfl(m1, 63, 64));
+            m2 = uniform(__shfl(m2, 63, 64));
+            return any;
+        }
+        double* b = buf + (flip ? 80 : 0);
+        flip ^= 1;
+        int* f = flags + turn;
+        const int next = turn == 2 ? 0 : turn + 1;
+        if (lane == 63) {
+            b[wave] = s0;
+            b[16 + wave] = m1;
+            b[32 + wave] = m2;
+            b[48 + wave] = e_s;
+            b[64 + wave] = e_m;
+            if (any) atomicOr(f, 1);
+            if (wave == 0) flags[next] = 0;
+        }
+        turn = next;
+        __syncthreads();
+        const bool in = (uint32_t)lane < nwaves;
+        const int l = lane & 15;
+        s0 = uniform(reduce_lanes<W>(in ? b[l] : 0.0, OpSum()));
+        m1 = uniform(reduce_lanes<W>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
+        m2 = uniform(reduce_lanes<W>(in ? b[32 + l] : __builtin_nan(""), OpMax()));
+        e_s = uniform(reduce_lanes<W>(in ? b[48 + l] : 0.0, OpSum()));
+        e_m = uniform(reduce_lanes<W>(in ? b[64 + l] : __builtin_nan(""), OpMax()));
+        return __builtin_amdgcn_readfirstlane(*f) != 0;
+    }
+    template <class Op>
+    static __device__ __forceinline__ double wave_total(double v, Op op) {  // the wavefront's reduction as a scalar-register value
+        v = ezpz::dev::reduce_wave_to_last_lane(v, op);
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, 63), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), 63);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
     template <int W>
     __device__ __forceinline__ bool step(double& s0, double& m1, double& m2, bool flag, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
@@ -357,7 +405,7 @@ __device__ __forceinline__ DevCon mkcon(uint32_t kind, uint32_t tag, uint32_t nr
 // one-call launches (`<entry>_one`), which publishes its completion word and waits for the calling thread's next request
 // (wave_ops.hip.hpp: publish_done, resident_next).  The batch entry is compiled without that loop: everything set up before it would stay
 // live across it -- 2000 x 2000 at three wavefronts per SIMD: 39 -> 75 spilled scalar registers, 88 -> 78 M solves/s.
-template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W, bool RESIDENT = false>
+template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W, bool RESIDENT = false, bool FUSE = false>
 __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     using namespace ezpz::dev;
     const int tid = threadIdx.x;
@@ -365,7 +413,7 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
     Red red;
     red.buf = smem;
-    red.flags = reinterpret_cast<int*>(smem + 96);
+    red.flags = reinterpret_cast<int*>(smem + kRedDoubles);
     red.flip = 0;
     red.turn = 0;
     int* nwarn2 = red.flags + 4;
@@ -447,17 +495,29 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
                 log_mask(s, cls, wm, 1);
             }
         });
-        red.template sum_max<W>(sq, mx, lane, wave, NWAVES);
+        // FUSE: eval()'s sums do not get a rendezvous of their own -- the wavefront's totals wait in scalar registers and ride in
+        // the first iteration's exchange (Red::step5; the first step is computed before anybody knows whether the system had
+        // converged already: x only moves after the rendezvous).  Every iteration runs the same five-value exchange: ONE loop
+        // body (a peeled first iteration cost the compiler its schedule).
+        const bool fused = FUSE && a.max_iterations > 0;
+        double eval_sq = 0.0, eval_mx = __builtin_nan("");
+        if (fused) {
+            eval_sq = Red::wave_total(sq, OpSum());
+            eval_mx = Red::wave_total(mx, OpMax());
+        } else {
+            red.template sum_max<W>(sq, mx, lane, wave, NWAVES);
+        }
         double residual_sq = sq, largest = mx;
         uint32_t pass = 2;
         double lambda = a.initial_lambda;
         uint32_t it = 0, iterations = a.max_iterations, converged = 0;
         bool r_is_at_x = true;
+        bool eval_pending = fused;  // residual_sq / largest are not the system's yet
 
         // ---- the LM loop (newton.rs:47-139) ------------------------------------------------------------------------------------------
         for (;;) {
             if (it >= a.max_iterations) break;            // newton.rs:141-144
-            if (largest <= a.residual_tolerance) {        // newton.rs:50-60
+            if (!eval_pending && largest <= a.residual_tolerance) {  // newton.rs:50-60
                 iterations = it;
                 converged = 1;
                 break;
@@ -511,7 +571,22 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
                     mx = mx_s;
                 }
             });
-            const bool bad = red.template step<W>(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
+            bool bad;
+            if constexpr (FUSE) {
+                bad = red.template step5<W>(sq, mx, dmax, eval_sq, eval_mx, lane_bad, lane, wave, NWAVES);
+                if (eval_pending) {  // eval()'s verdict, one rendezvous late (newton.rs:45-60)
+                    eval_pending = false;
+                    residual_sq = eval_sq;
+                    largest = eval_mx;
+                    if (largest <= a.residual_tolerance) {  // converged before the first iteration: the speculative step is dropped
+                        iterations = 0;
+                        converged = 1;
+                        break;
+                    }
+                }
+            } else {
+                bad = red.template step<W>(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
+            }
             if (bad) {  // numeric failure anywhere in the system => lambda *= 10, burn the iteration, x untouched
                 lambda *= LM_LAMBDA_INCR;
                 ++it;
