@@ -815,20 +815,22 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             const int min_waves = env_mw ? std::atoi(env_mw) : (int)std::min<uint64_t>(4, std::max<uint64_t>(1, 512 / (vg + 50)));
             const std::string bounds = std::to_string(T * 64) + (min_waves > 0 ? ", " + std::to_string(min_waves) : "");
             // eval()'s sums riding in the first iteration's rendezvous (jit_kernel.hip.hpp: FUSE) -- one rendezvous less per system.
-            // Measured on one box, 65 536 systems per launch: 800 x 800 (two wavefronts per system) 192.6 -> 203.0 M solves/s,
-            // 2000 x 2000 (four) 93.3 -> 90.3, 2400 x 2400 (four, two per SIMD) 64.5 -> 64.3, the over-constrained variant 24.5
-            // -> 24.2: taken where two wavefronts share a system; EZPZ_JIT_FUSE=1 / 0 forces it on / off (A/B runs).
+            // Measured on one box, 65 536 systems per launch, once the kernels of one-workgroup systems carried no grid code:
+            // 2000 x 2000 (four wavefronts per system, three per SIMD) 96.0 -> 101.9 M solves/s, 800 x 800 (two, three) 195.8 ->
+            // 214.2, 2400 x 2400 (four, two per SIMD: eight slots per lane) 65.3 -> 60.1, the over-constrained variant (non-linear
+            // classes) 24.8 -> 23.8: taken for linear systems compiled for three or more wavefronts per SIMD;
+            // EZPZ_JIT_FUSE=1 / 0 forces it on / off (A/B runs).  One workgroup per system only.
             static const int fuse_env = [] {
                 const char* e = std::getenv("EZPZ_JIT_FUSE");
                 return !e ? -1 : e[0] == '1' ? 1 : 0;
             }();
-            const bool fuse = fuse_env < 0 ? T == 2 : fuse_env == 1;
+            const bool fuse = fuse_env < 0 ? (!any_nonlinear && min_waves >= 3) : fuse_env == 1;
             // two entries: batches, and (`_one`) one-call launches that stay resident for the caller's next request
             for (int one = 0; one < 2; ++one) {
                 o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve" + (one ? "_one" : "") + "(const ezpz::jit::JitArgs a) {\n";
                 o += "    __shared__ double smem[ezpz::jit::kRedDoubles + 16];\n";
                 o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
-                     (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse && G == 1 ? "true" : "false") + ">(a, smem);\n}\n";
+                     (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse && G == 1 ? "true" : "false") + ", " + (G > 1 ? "true" : "false") + ">(a, smem);\n}\n";
             }
             align4(blob);
             plan.o_jit_slots = (uint32_t)blob.size();

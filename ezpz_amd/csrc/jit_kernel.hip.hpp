@@ -272,6 +272,63 @@ struct Red {
             m3 = uniform(b[3]);
         }
     }
+    // across_workgroups for eval()'s two values alone (a sum, a maximum): two chunks per workgroup to publish, gather and
+    // scatter instead of four with two of them padding (a grid reduction costs by the lines it touches)
+    __device__ __forceinline__ void across_workgroups2(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
+        using namespace ezpz::dev;
+        const int tid = threadIdx.x;
+        const unsigned int seq = ++grid_seq;
+        const unsigned int par = seq & 1u;
+        if (tid < 2) grid_store(&grid->arr[par][tid][grid_wg], tid == 0 ? s0 : m1, seq);
+        double* b = buf + (flip ? 48 : 0);
+        flip ^= 1;
+        if (grid_wg == 0) {
+            double a0 = 0.0, a1 = __builtin_nan("");
+            for (uint32_t g = tid; g < grid_wgs; g += blockDim.x) {
+                gridchunk_t c0, c1;
+                for (unsigned int spins = 0;; ++spins) {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
+                        "global_load_dwordx4 %1, %3, off sc0 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(c0), "=&v"(c1)
+                        : "v"(&grid->arr[par][0][g]), "v"(&grid->arr[par][1][g])
+                        : "memory");
+                    if (c0.z == seq && c1.z == seq) break;
+                    if ((spins & 1023u) == 1023u &&
+                        (spins >= (1u << 21) || __hip_atomic_load(&grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(&grid->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
+                        c0.x = c1.x = (unsigned int)nan, c0.y = c1.y = (unsigned int)(nan >> 32);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                a0 = a0 + __builtin_bit_cast(double, ((unsigned long long)c0.y << 32) | c0.x);
+                a1 = fmax_nc(a1, __builtin_bit_cast(double, ((unsigned long long)c1.y << 32) | c1.x));
+            }
+            a0 = reduce_wave_to_last_lane(a0, OpSum());
+            a1 = reduce_wave_to_last_lane(a1, OpMax());
+            if (lane == 63) {
+                b[wave] = a0;
+                b[12 + wave] = a1;
+            }
+            __syncthreads();
+            const bool in = (uint32_t)lane < nwaves;
+            const int l = lane & 15;
+            s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
+            m1 = uniform(reduce_lanes<16>(in ? b[12 + l] : __builtin_nan(""), OpMax()));
+            for (uint32_t g = 1 + tid; g < grid_wgs; g += blockDim.x) {
+                grid_store(&grid->out[par][g][0], s0, seq);
+                grid_store(&grid->out[par][g][1], m1, seq);
+            }
+        } else {
+            if (tid < 2) b[tid] = grid_wait(&grid->out[par][grid_wg][tid], seq, &grid->dead);
+            __syncthreads();
+            s0 = uniform(b[0]);
+            m1 = uniform(b[1]);
+        }
+    }
     // (W: the power of two >= the number of wavefronts, <= 16 -- the fold of the wavefronts' partials stops there; the
     // lanes beyond hold the identity, so the narrower tree gives the bits of the 16-lane one)
     template <int W>
@@ -295,10 +352,7 @@ struct Red {
         const int l = lane & 15;
         s0 = uniform(reduce_lanes<W>(in ? b[l] : 0.0, OpSum()));
         m1 = uniform(reduce_lanes<W>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
-        if (grid) {
-            double m2 = __builtin_nan(""), m3 = __builtin_nan("");
-            across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
-        }
+        if (grid) across_workgroups2(s0, m1, lane, wave, nwaves);
     }
     // step() with eval()'s two wave totals (e_s: a sum, e_m: a maximum; uniform per wavefront) riding in the same exchange:
     // the system's first iteration then needs no rendezvous of its own for eval() (solve_kernel, FUSE).  One workgroup per
@@ -403,9 +457,10 @@ __device__ __forceinline__ DevCon mkcon(uint32_t kind, uint32_t tag, uint32_t nr
 
 // SEQ: Slots<...> of one wavefront; NWAVES wavefronts share a system; UNIT_W: every weight is 1.  RESIDENT: the entry of
 // one-call launches (`<entry>_one`), which publishes its completion word and waits for the calling thread's next request
-// (wave_ops.hip.hpp: publish_done, resident_next).  The batch entry is compiled without that loop: everything set up before it would stay
+// (wave_ops.hip.hpp: publish_done, resident_next).  FUSE: eval()'s sums ride in the first iteration's rendezvous.  GRID: the system
+// may be spread over several workgroups (the reductions' grid stage is compiled in).  The batch entry is compiled without that loop: everything set up before it would stay
 // live across it -- 2000 x 2000 at three wavefronts per SIMD: 39 -> 75 spilled scalar registers, 88 -> 78 M solves/s.
-template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W, bool RESIDENT = false, bool FUSE = false>
+template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W, bool RESIDENT = false, bool FUSE = false, bool GRID = true>
 __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     using namespace ezpz::dev;
     const int tid = threadIdx.x;
@@ -420,9 +475,11 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     if (tid < 8) red.flags[tid] = 0;
     if (NWAVES > 1) __syncthreads();
     // a system on several workgroups (NWAVES > 1 then): workgroup g of the G that share it, slot = which system in flight
-    const uint32_t grid_wgs = a.grid ? a.grid_wgs : 1u;
+    // (GRID false -- what the generator says of a system on one workgroup -- folds every grid branch of the reductions away:
+    // code the kernel never runs still costs it its schedule, 92.8 -> 90.4 M solves/s for 70 lines added to one of them)
+    const uint32_t grid_wgs = GRID && a.grid ? a.grid_wgs : 1u;
     const uint32_t grid_wg = blockIdx.x % grid_wgs, grid_slot = blockIdx.x / grid_wgs, n_slots = gridDim.x / grid_wgs;
-    red.grid = a.grid ? a.grid + grid_slot : nullptr;
+    red.grid = GRID && a.grid ? a.grid + grid_slot : nullptr;
     red.grid_wgs = grid_wgs;
     red.grid_wg = grid_wg;
     red.grid_seq = 0;
