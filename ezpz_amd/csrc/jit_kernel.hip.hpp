@@ -272,6 +272,100 @@ struct Red {
             m3 = uniform(b[3]);
         }
     }
+    // across_workgroups for step()'s three values with its flag riding in the spare word of the first chunk: three chunks per
+    // workgroup to publish, gather and scatter instead of four
+    __device__ __forceinline__ bool across_workgroups3(double& s0, double& m1, double& m2, bool flag, int lane, uint32_t wave, uint32_t nwaves) {
+        using namespace ezpz::dev;
+        const int tid = threadIdx.x;
+        const unsigned int seq = ++grid_seq;
+        const unsigned int par = seq & 1u;
+        auto put = [&](gridchunk_t* p, double v, unsigned int w) {
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+            gridchunk_t c;
+            c.x = (unsigned int)u, c.y = (unsigned int)(u >> 32), c.z = seq, c.w = w;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(c) : "memory");
+        };
+        if (tid < 3) put(&grid->arr[par][tid][grid_wg], tid == 0 ? s0 : tid == 1 ? m1 : m2, tid == 0 && flag ? 1u : 0u);
+        double* b = buf + (flip ? 48 : 0);
+        flip ^= 1;
+        bool failed;
+        if (grid_wg == 0) {
+            double a0 = 0.0, a1 = __builtin_nan(""), a2 = a1, a3 = a1;
+            for (uint32_t g = tid; g < grid_wgs; g += blockDim.x) {
+                gridchunk_t c0, c1, c2;
+                for (unsigned int spins = 0;; ++spins) {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+                        "global_load_dwordx4 %1, %4, off sc0 sc1\n\t"
+                        "global_load_dwordx4 %2, %5, off sc0 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(c0), "=&v"(c1), "=&v"(c2)
+                        : "v"(&grid->arr[par][0][g]), "v"(&grid->arr[par][1][g]), "v"(&grid->arr[par][2][g])
+                        : "memory");
+                    if (c0.z == seq && c1.z == seq && c2.z == seq) break;
+                    if ((spins & 1023u) == 1023u &&
+                        (spins >= (1u << 21) || __hip_atomic_load(&grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(&grid->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
+                        c0.x = c1.x = c2.x = (unsigned int)nan, c0.y = c1.y = c2.y = (unsigned int)(nan >> 32);
+                        c0.w = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                a0 = a0 + __builtin_bit_cast(double, ((unsigned long long)c0.y << 32) | c0.x);
+                a1 = fmax_nc(a1, __builtin_bit_cast(double, ((unsigned long long)c1.y << 32) | c1.x));
+                a2 = fmax_nc(a2, __builtin_bit_cast(double, ((unsigned long long)c2.y << 32) | c2.x));
+                if (c0.w) a3 = 1.0;
+            }
+            a0 = reduce_wave_to_last_lane(a0, OpSum());
+            a1 = reduce_wave_to_last_lane(a1, OpMax());
+            a2 = reduce_wave_to_last_lane(a2, OpMax());
+            a3 = reduce_wave_to_last_lane(a3, OpMax());
+            if (lane == 63) {
+                b[wave] = a0;
+                b[12 + wave] = a1;
+                b[24 + wave] = a2;
+                b[36 + wave] = a3;
+            }
+            __syncthreads();
+            const bool in = (uint32_t)lane < nwaves;
+            const int l = lane & 15;
+            s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
+            m1 = uniform(reduce_lanes<16>(in ? b[12 + l] : __builtin_nan(""), OpMax()));
+            m2 = uniform(reduce_lanes<16>(in ? b[24 + l] : __builtin_nan(""), OpMax()));
+            failed = uniform(reduce_lanes<16>(in ? b[36 + l] : __builtin_nan(""), OpMax())) > 0.0;
+            for (uint32_t g = 1 + tid; g < grid_wgs; g += blockDim.x) {
+                put(&grid->out[par][g][0], s0, failed ? 1u : 0u);
+                put(&grid->out[par][g][1], m1, 0u);
+                put(&grid->out[par][g][2], m2, 0u);
+            }
+        } else {
+            if (tid < 3) {
+                gridchunk_t c;
+                for (unsigned int spins = 0;; ++spins) {
+                    c = grid_peek(&grid->out[par][grid_wg][tid]);
+                    if (c.z == seq) break;
+                    if ((spins & 1023u) == 1023u &&
+                        (spins >= (1u << 21) || __hip_atomic_load(&grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(&grid->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
+                        c.x = (unsigned int)nan, c.y = (unsigned int)(nan >> 32), c.w = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                b[tid] = __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
+                if (tid == 0) b[3] = c.w ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            s0 = uniform(b[0]);
+            m1 = uniform(b[1]);
+            m2 = uniform(b[2]);
+            failed = uniform(b[3]) > 0.0;
+        }
+        return failed;
+    }
     // across_workgroups for eval()'s two values alone (a sum, a maximum): two chunks per workgroup to publish, gather and
     // scatter instead of four with two of them padding (a grid reduction costs by the lines it touches)
     __device__ __forceinline__ void across_workgroups2(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
@@ -434,11 +528,7 @@ struct Red {
         m1 = uniform(reduce_lanes<W>(in ? b[16 + l] : __builtin_nan(""), OpMax()));
         m2 = uniform(reduce_lanes<W>(in ? b[32 + l] : __builtin_nan(""), OpMax()));
         bool failed = __builtin_amdgcn_readfirstlane(*f) != 0;
-        if (grid) {
-            double m3 = failed ? 1.0 : __builtin_nan("");
-            across_workgroups(s0, m1, m2, m3, lane, wave, nwaves);
-            failed = m3 > 0.0;
-        }
+        if (grid) failed = across_workgroups3(s0, m1, m2, failed, lane, wave, nwaves);
         return failed;
     }
 };
