@@ -52,7 +52,8 @@ class CLaunchPolicy(C.Structure):
                 ("rec_wide_one_solve_max_vars", C.c_uint32), ("sub_team_max_width", C.c_uint32), ("dense8_max_vars", C.c_uint32),
                 ("zero_copy_max_bytes", C.c_uint64), ("h2h_piece_min_bytes", C.c_uint64), ("h2h_piece_max_bytes", C.c_uint64),
                 ("h2h_pieces_per_call", C.c_uint32), ("one_call_host_mask_max_constraints", C.c_uint32),
-                ("one_call_host_log_max_entries", C.c_uint32)]
+                ("one_call_host_log_max_entries", C.c_uint32), ("front_min_vars_one_solve", C.c_uint32),
+                ("front_min_vars_batch", C.c_uint32), ("front_vars_per_workgroup", C.c_uint32), ("front_max_workgroups", C.c_uint32)]
 
 
 # every symbol include/ezpz_amd.h declares
@@ -74,7 +75,7 @@ EXPORTS = [
     "ezpz_specialized_source",
     "ezpz_multi_create", "ezpz_multi_destroy", "ezpz_multi_device_count", "ezpz_multi_device", "ezpz_multi_shard",
     "ezpz_multi_specialize", "ezpz_multi_solve_batch", "ezpz_system_solve_batch_multi",
-    "ezpz_debug_call_trace", "ezpz_launch_policy",
+    "ezpz_debug_call_trace", "ezpz_launch_policy", "ezpz_debug_front_plan",
     "ezpz_mixed_create", "ezpz_mixed_destroy", "ezpz_mixed_total_values", "ezpz_mixed_offsets", "ezpz_mixed_solve_device",
     "ezpz_mixed_solve", "ezpz_system_solve_batch_mixed", "ezpz_multi_solve_batch_mixed",
 ]
@@ -161,6 +162,8 @@ def lib():
     L.ezpz_launch_policy.argtypes = [C.c_int, C.POINTER(CLaunchPolicy)]
     L.ezpz_debug_call_trace.restype = sz
     L.ezpz_debug_call_trace.argtypes = [vp, sz]
+    L.ezpz_debug_front_plan.restype = C.c_long
+    L.ezpz_debug_front_plan.argtypes = [vp, sz, sz, u32, u32, C.c_uint64, vp, sz, vp]
     L.ezpz_cache_clear.restype = None
     L.ezpz_cache_clear.argtypes = []
     L.ezpz_analyze.restype = C.c_int

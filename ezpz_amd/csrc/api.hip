@@ -116,6 +116,10 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
             (team_size == EZPZ_TEAM_LATENCY_WAVE || (team_size == EZPZ_TEAM_AUTO_LATENCY && pays)))
             s->wave_jit = comp_jit_create_source(s->lane->wave_source, "ezpz_jit_wave");
     }
+    if (s->fronts) {
+        HIP_TRY(hipMalloc(&s->dev_fronts, s->fronts->blob.size()));
+        HIP_TRY(hipMemcpy(s->dev_fronts, s->fronts->blob.data(), s->fronts->blob.size(), hipMemcpyHostToDevice));
+    }
     if (s->lanes) {
         HIP_TRY(hipMalloc((void**)&s->dev_lanes, s->lanes->blob.size() * 4));
         HIP_TRY(hipMemcpy(s->dev_lanes, s->lanes->blob.data(), s->lanes->blob.size() * 4, hipMemcpyHostToDevice));

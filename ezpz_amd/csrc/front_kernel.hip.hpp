@@ -1,0 +1,633 @@
+// The FRONTAL solve kernel: the Levenberg-Marquardt loop of one constraint system (reference ezpz/src/solver/newton.rs:29-145,
+// solver.rs:318-440, lib.rs:305-327 -- the same control flow as lm_kernel.hip.hpp) with the linear solve
+// (JtJ + lambda I) d = -Jt r (newton.rs:73-102: faer's sparse matmul, Llt::try_new_with_symbolic, solve) as a MULTIFRONTAL
+// supernodal Cholesky factorisation on dense fronts (front_types.hpp, fronts.cpp):
+//
+//   * a wavefront owns a front: it assembles the front's entries of JtJ and -Jt r from the Jacobian values of the constraints
+//     whose earliest variable is eliminated there (one lane per entry, operand pairs streamed from the plan), adds its children's
+//     update matrices through their row maps (extend-add), factors the K pivot columns in registers (lane = row, pivots and
+//     multipliers by v_readlane, the right-hand side as row S so that the forward substitution rides along), and leaves the
+//     Schur complement of the rows below as its own update matrix;
+//   * the fronts of one level of the tree run side by side on the wavefronts of the workgroup, one barrier per level; the
+//     backward substitution walks the levels top down, a front solving its K unknowns from its panel;
+//   * a system too large for one CU's LDS -- or too slow on one CU -- is cut at the top of the tree: whole subtrees go to
+//     workgroups 1 .. G-1, the top to workgroup 0; update matrices and steps cross workgroups as self-validating 16-byte chunks
+//     (grid_ops.hip.hpp), the LM control's sums gather at workgroup 0 and scatter.
+//
+// State per workgroup (LDS): x, d, r, r_next, Jacobian values, the fronts' panels (the factor), a pool of update matrices.
+// Results are those of a valid Cholesky factorisation in another elimination order than the list walks': coordinates at the
+// 1e-6 bar of connected sketches, not bitwise.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "constraint_eval.hip.hpp"
+#include "front_types.hpp"
+#include "grid_ops.hip.hpp"
+#include "wave_ops.hip.hpp"
+
+namespace ezpz {
+namespace frontal {
+
+using namespace dev;
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// lanes of one wavefront execute in lockstep and the LDS serves a wavefront's accesses in issue order: only the compiler must
+// not move accesses across
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double readlane_f64(double v, uint32_t l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, (int)l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), (int)l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// 1 / sqrt(p) from the hardware's estimate and two coupled Newton steps (as the record walk's rounds)
+__device__ __forceinline__ double rsqrt_newton(double p) {
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const double g0 = p * y0, h0 = 0.5 * y0;
+    const double r0 = __builtin_fma(-g0, h0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double r1 = __builtin_fma(-g1, h1, 0.5);
+    const double h2 = __builtin_fma(h1, r1, h1);
+    return h2 + h2;
+}
+
+// What a wavefront needs to work on a front of its workgroup.
+struct Ctx {
+    double* ws;                  // workspace (LDS)
+    const FrontDesc* descs;      // staged tables (LDS)
+    const uint32_t* level_ptr;
+    const FrontChild* children;
+    const uint16_t* rows;
+    const uint32_t* exports;
+    const uint8_t* maps;
+    const uint16_t* tri;         // entry -> (a | b << 8) of a packed lower triangle
+    const uint32_t* stream;      // assembly streams (global)
+    gridchunk_t* chunks;         // the system's scratch chunks (null on one workgroup)
+    int* dead;
+    uint32_t l_jv, l_d;
+};
+
+__device__ __forceinline__ uint32_t tri_index(uint32_t a, uint32_t b) { return a * (a + 1) / 2 + b; }
+
+// Assembly + extend-add + partial factorisation + Schur complement of front k by the calling wavefront.  Returns true when a
+// pivot was not positive (LltError::Numeric, newton.rs:93-99).
+template <int KMAX>
+__device__ __forceinline__ bool front_pivots(double* P, uint32_t K, uint32_t S, int lane) {
+    const uint32_t S1 = S + 1;
+    const uint32_t rr = (uint32_t)lane <= S ? (uint32_t)lane : S;
+    double a[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) a[c] = (uint32_t)c < K ? P[c * S1 + rr] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        if ((uint32_t)j < K) {
+            const double piv = readlane_f64(a[j], j);
+            if (!(piv > 0.0)) bad = true;
+            const double rinv = rsqrt_newton(piv);
+            const double l = a[j] * rinv;
+            a[j] = lane == j ? rinv : l;  // (the factor's diagonal is kept as 1 / d_j)
+#pragma unroll
+            for (int k = j + 1; k < KMAX; ++k) a[k] = __builtin_fma(-l, readlane_f64(l, k), a[k]);
+        }
+    }
+    if ((uint32_t)lane <= S) {
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if ((uint32_t)c < K) P[c * S1 + lane] = a[c];
+    }
+    return bad;
+}
+
+__device__ __forceinline__ bool front_factor(const Ctx& cx, uint32_t k, int lane, double lambda, uint32_t l_r, unsigned int epoch) {
+    const FrontDesc& d = cx.descs[k];
+    const uint32_t K = uni(d.K), S = uni(d.S), S1 = S + 1, R = S - K, nU = (R + 1) * (R + 2) / 2;
+    const uint32_t flags = uni(d.flags);
+    // (every address an index from the workspace's base: a select between two LDS pointers would make them generic pointers)
+    double* const ws = cx.ws;
+    const uint32_t o_p = uni(d.panel), o_u = uni(d.upd), o_j = cx.l_jv;
+    double* const P = ws + o_p;
+    double* const U = ws + o_u;
+    for (uint32_t i = lane; i < S1 * K; i += 64) P[i] = 0.0;
+    if (R)
+        for (uint32_t i = lane; i < nU; i += 64) U[i] = 0.0;
+    wave_sync();
+    // ---- this front's own entries of JtJ + lambda I and of -Jt r ----------------------------------------------------------------------
+    {
+        const uint32_t* st = cx.stream + uni(d.asm_off);
+        const uint32_t n_e = uni(d.asm_n);
+        const uint32_t w4 = uni(*reinterpret_cast<const uint32_t*>(d.asm_w));
+        for (uint32_t e0 = 0, tr = 0; e0 < n_e; e0 += 64, ++tr) {
+            const uint32_t w = (w4 >> (8 * (tr < 3 ? tr : 3))) & 0xFFu;
+            const uint32_t hdr = st[lane];
+            const bool rhs = (hdr & FASM_RHS) != 0;
+            const uint32_t o_b = rhs ? l_r : o_j;
+            double acc0 = 0.0, acc1 = 0.0;
+            uint32_t q = 0;
+            for (; q + 4 <= w; q += 4) {
+                uint32_t op[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) op[i] = st[64 * (1 + q + i) + lane];
+                double va[4], vb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) va[i] = ws[o_j + (op[i] & 0xFFFFu)], vb[i] = ws[o_b + (op[i] >> 16)];
+                acc0 = __builtin_fma(va[0], vb[0], acc0);
+                acc1 = __builtin_fma(va[1], vb[1], acc1);
+                acc0 = __builtin_fma(va[2], vb[2], acc0);
+                acc1 = __builtin_fma(va[3], vb[3], acc1);
+            }
+            for (; q < w; ++q) {
+                const uint32_t op = st[64 * (1 + q) + lane];
+                acc0 = __builtin_fma(ws[o_j + (op & 0xFFFFu)], ws[o_b + (op >> 16)], acc0);
+            }
+            double acc = acc0 + acc1;
+            if (rhs) acc = -acc;
+            if (hdr & FASM_DIAG) acc += lambda;
+            if (!(hdr & FASM_NOP)) ws[((hdr & FASM_UPD) ? o_u : o_p) + (hdr & 0xFFFFu)] = acc;
+            st += 64 * (1 + w);
+        }
+    }
+    wave_sync();
+    // ---- extend-add: the children's update matrices, one child after the other ------------------------------------------------------------
+    const uint32_t n_child = uni(d.n_child), child0 = uni(d.child0);
+    for (uint32_t c = 0; c < n_child; ++c) {
+        const FrontChild& ch = cx.children[child0 + c];
+        const uint32_t rc1 = uni(ch.rows), n_c = rc1 * (rc1 + 1) / 2, upd = uni(ch.upd);
+        const bool remote = (uni(ch.flags) & FRONT_CHILD_REMOTE) != 0;
+        const uint8_t* const map = cx.maps + uni(ch.map);
+        for (uint32_t e = lane; e < n_c; e += 64) {
+            const uint32_t ab = cx.tri[e];
+            const uint32_t i = map[ab & 0xFFu], j = map[ab >> 8];
+            const double val = remote ? grid_wait(cx.chunks + upd + e, epoch, cx.dead) : ws[upd + e];
+            const uint32_t dst = j < K ? o_p + j * S1 + i : o_u + tri_index(i - K, j - K);
+            ws[dst] += val;
+        }
+        wave_sync();
+    }
+    // ---- the K pivot columns in registers ---------------------------------------------------------------------------------------------
+    bool bad;
+    if (K <= 4)
+        bad = front_pivots<4>(P, K, S, lane);
+    else if (K <= 8)
+        bad = front_pivots<8>(P, K, S, lane);
+    else
+        bad = front_pivots<16>(P, K, S, lane);
+    wave_sync();
+    // ---- Schur complement of the rows below (row R = right-hand side) -------------------------------------------------------------------
+    if (R) {
+        const bool remote_parent = (flags & FRONT_REMOTE_PARENT) != 0;
+        const uint32_t up_chunk = uni(d.up_chunk);
+        for (uint32_t e = lane; e < nU; e += 64) {
+            const uint32_t ab = cx.tri[e];
+            const double* pa = P + K + (ab & 0xFFu);
+            const double* pb = P + K + (ab >> 8);
+            double acc0 = 0.0, acc1 = 0.0;
+            uint32_t kk = 0;
+            for (; kk + 4 <= K; kk += 4) {
+                double va[4], vb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) va[i] = pa[(kk + i) * S1], vb[i] = pb[(kk + i) * S1];
+                acc0 = __builtin_fma(va[0], vb[0], acc0);
+                acc1 = __builtin_fma(va[1], vb[1], acc1);
+                acc0 = __builtin_fma(va[2], vb[2], acc0);
+                acc1 = __builtin_fma(va[3], vb[3], acc1);
+            }
+            for (; kk < K; ++kk) acc0 = __builtin_fma(pa[kk * S1], pb[kk * S1], acc0);
+            const double v = U[e] - (acc0 + acc1);
+            if (remote_parent)
+                grid_store(cx.chunks + up_chunk + e, v, epoch);
+            else
+                U[e] = v;
+        }
+    }
+    return bad;
+}
+
+// Backward substitution of front k: its K unknowns from y (row S of the panel), the steps of the rows below and the panel.
+template <int KMAX>
+__device__ __forceinline__ double front_bwd_body(const Ctx& cx, const FrontDesc& d, uint32_t K, uint32_t S, int lane, unsigned int epoch,
+                                                 double dmax) {
+    const uint32_t S1 = S + 1;
+    const double* const P = cx.ws + uni(d.panel);
+    double* const dv = cx.ws + cx.l_d;
+    const uint16_t* const frow = cx.rows + uni(d.rows);
+    const uint32_t r = (uint32_t)lane;
+    const double xr = (r >= K && r < S) ? dv[frow[r]] : 0.0;
+    const uint32_t kc = r < K ? r : K - 1;  // this lane's column
+    const double* const col = P + kc * S1;
+    double t = col[S];
+    for (uint32_t rr = K; rr < S; ++rr) t = __builtin_fma(-col[rr], readlane_f64(xr, rr), t);
+    double lcol[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) lcol[j] = (uint32_t)j < K ? col[j] : 0.0;  // (row j of column kc; its diagonal holds 1 / d)
+    const double rinv = col[kc];
+    double xown = 0.0;
+#pragma unroll
+    for (int j = KMAX - 1; j >= 0; --j) {
+        if ((uint32_t)j < K) {
+            const double xj = readlane_f64(t * rinv, j);
+            if (r < (uint32_t)j) t = __builtin_fma(-lcol[j], xj, t);
+            if (r == (uint32_t)j) xown = xj;
+        }
+    }
+    if (r < K) {
+        dv[frow[r]] = xown;
+        dmax = fmax_abs(dmax, xown);
+        if (uni(d.flags) & FRONT_EXPORTS) {
+            const uint32_t ch = cx.exports[uni(d.exp0) + r];
+            if (ch != 0xFFFFFFFFu) grid_store(cx.chunks + ch, xown, epoch);
+        }
+    }
+    return dmax;
+}
+__device__ __forceinline__ double front_bwd(const Ctx& cx, uint32_t k, int lane, unsigned int epoch, double dmax) {
+    const FrontDesc& d = cx.descs[k];
+    const uint32_t K = uni(d.K), S = uni(d.S);
+    if (K <= 4) return front_bwd_body<4>(cx, d, K, S, lane, epoch, dmax);
+    if (K <= 8) return front_bwd_body<8>(cx, d, K, S, lane, epoch, dmax);
+    return front_bwd_body<16>(cx, d, K, S, lane, epoch, dmax);
+}
+
+// Four workgroup- (and, on several workgroups, system-) wide reductions for one rendezvous: a sum, two NaN-ignoring maxima, a
+// sum; every lane gets all four.  Fixed trees: deterministic.
+struct Red {
+    double* buf;  // LDS: 2 x 64 doubles
+    int flip;
+    unsigned char* scratch;  // the system's scratch (several workgroups), else null
+    uint32_t G, wg;
+    unsigned int seq;
+    int* dead;
+    __device__ __forceinline__ void reduce(double& v0, double& v1, double& v2, double& v3) {
+        const int tid = threadIdx.x, wave = tid >> 6, nwaves = (int)(blockDim.x >> 6);
+        v0 = reduce_wave_to_last_lane(v0, OpSum());
+        v1 = reduce_wave_to_last_lane(v1, OpMax());
+        v2 = reduce_wave_to_last_lane(v2, OpMax());
+        v3 = reduce_wave_to_last_lane(v3, OpSum());
+        double* b = buf + (flip ? 64 : 0);
+        flip ^= 1;
+        if ((tid & 63) == 63) b[wave] = v0, b[16 + wave] = v1, b[32 + wave] = v2, b[48 + wave] = v3;
+        __syncthreads();
+        v0 = b[0], v1 = b[16], v2 = b[32], v3 = b[48];
+        for (int w = 1; w < nwaves; ++w) {
+            v0 = v0 + b[w];
+            v1 = fmax_nc(v1, b[16 + w]);
+            v2 = fmax_nc(v2, b[32 + w]);
+            v3 = v3 + b[48 + w];
+        }
+        if (G > 1) {
+            const unsigned int s = ++seq, par = s & 1u;
+            gridchunk_t* const arr = reinterpret_cast<gridchunk_t*>(scratch + sizeof(FrontScratchHead)) + par * kFrontRedValues * kFrontMaxWgs;
+            gridchunk_t* const out = reinterpret_cast<gridchunk_t*>(scratch + sizeof(FrontScratchHead) + kFrontScratchRedBytes) +
+                                     par * kFrontMaxWgs * kFrontRedValues;
+            if (tid < 4) grid_store(arr + tid * kFrontMaxWgs + wg, tid == 0 ? v0 : tid == 1 ? v1 : tid == 2 ? v2 : v3, s);
+            double* b2 = buf + (flip ? 64 : 0);
+            flip ^= 1;
+            if (wg == 0) {
+                if (tid < 64) {
+                    double w0 = 0.0, w1 = __builtin_nan(""), w2 = __builtin_nan(""), w3 = 0.0;
+                    if ((uint32_t)tid < G) {
+                        w0 = grid_wait(arr + 0 * kFrontMaxWgs + tid, s, dead);
+                        w1 = grid_wait(arr + 1 * kFrontMaxWgs + tid, s, dead);
+                        w2 = grid_wait(arr + 2 * kFrontMaxWgs + tid, s, dead);
+                        w3 = grid_wait(arr + 3 * kFrontMaxWgs + tid, s, dead);
+                    }
+                    w0 = reduce_lanes<64>(w0, OpSum());
+                    w1 = reduce_lanes<64>(w1, OpMax());
+                    w2 = reduce_lanes<64>(w2, OpMax());
+                    w3 = reduce_lanes<64>(w3, OpSum());
+                    if ((uint32_t)tid < G && tid > 0) {
+                        grid_store(out + tid * kFrontRedValues + 0, w0, s);
+                        grid_store(out + tid * kFrontRedValues + 1, w1, s);
+                        grid_store(out + tid * kFrontRedValues + 2, w2, s);
+                        grid_store(out + tid * kFrontRedValues + 3, w3, s);
+                    }
+                    if (tid == 0) b2[0] = w0, b2[1] = w1, b2[2] = w2, b2[3] = w3;
+                }
+            } else {
+                if (tid < 4) b2[tid] = grid_wait(out + wg * kFrontRedValues + tid, s, dead);
+            }
+            __syncthreads();
+            v0 = b2[0], v1 = b2[1], v2 = b2[2], v3 = b2[3];
+        }
+    }
+};
+
+}  // namespace frontal
+
+#ifdef EZPZ_STAMPS
+#define FRONT_STAMP(id)                                                          \
+    do {                                                                         \
+        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 2000) { \
+            a.stamps[2 * stamp_n] = (id);                                        \
+            a.stamps[2 * stamp_n + 1] = __builtin_readcyclecounter();            \
+            ++stamp_n;                                                           \
+        }                                                                        \
+    } while (0)
+#else
+#define FRONT_STAMP(id) \
+    do {                \
+    } while (0)
+#endif
+
+template <bool LIN>
+__global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) {
+    using namespace frontal;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)tid >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t G = a.n_wgs, wg = blockIdx.x % G, slot = blockIdx.x / G, n_slots = gridDim.x / G;
+    const FrontWg& W = reinterpret_cast<const FrontWg*>(a.plan)[wg];
+    // ---- LDS: [staged tables][workspace][reduction scratch 128 doubles][triangle table 2080 x u16][ints] -------------------------------
+    unsigned char* const tab = reinterpret_cast<unsigned char*>(smem);
+    double* const ws = smem + a.tab_lds_bytes / 8;
+    double* const redbuf = ws + a.ws_doubles;
+    uint16_t* const tri = reinterpret_cast<uint16_t*>(redbuf + 128);
+    int* const ints = reinterpret_cast<int*>(tri + 2080);  // [0] warnings, [1] a pivot failed
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.plan + W.o_tables);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (uint32_t i = tid; i < W.tab_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t ra = tid; ra < 64; ra += blockDim.x)
+            for (uint32_t rb = 0; rb <= ra; ++rb) tri[tri_index(ra, rb)] = (uint16_t)(ra | (rb << 8));
+    }
+    Ctx cx;
+    cx.ws = ws;
+    cx.descs = reinterpret_cast<const FrontDesc*>(tab);
+    cx.level_ptr = reinterpret_cast<const uint32_t*>(tab + W.t_level_ptr);
+    cx.children = reinterpret_cast<const FrontChild*>(tab + W.t_children);
+    cx.rows = reinterpret_cast<const uint16_t*>(tab + W.t_rows);
+    cx.exports = reinterpret_cast<const uint32_t*>(tab + W.t_exports);
+    cx.maps = reinterpret_cast<const uint8_t*>(tab + W.t_maps);
+    cx.tri = tri;
+    cx.stream = reinterpret_cast<const uint32_t*>(a.plan + W.o_asm);
+    unsigned char* const scratch = G > 1 ? a.scratch + (size_t)slot * a.scratch_stride : nullptr;
+    FrontScratchHead* const head = reinterpret_cast<FrontScratchHead*>(scratch);
+    cx.chunks = G > 1 ? reinterpret_cast<gridchunk_t*>(scratch + sizeof(FrontScratchHead) + 2 * kFrontScratchRedBytes) : nullptr;
+    cx.dead = G > 1 ? &head->dead : nullptr;
+    cx.l_jv = W.l_jv;
+    cx.l_d = W.l_d;
+    Red red;
+    red.buf = redbuf;
+    red.flip = 0;
+    red.scratch = scratch;
+    red.G = G;
+    red.wg = wg;
+    red.seq = 0;
+    red.dead = cx.dead;
+    unsigned int epoch = 0;  // tag of the chunks of one linear solve (update matrices up, steps down)
+    if (G > 1) {             // continue the slot's sequence numbers where this workgroup's previous launch left them
+        epoch = __hip_atomic_load(&head->hop[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red.seq = __hip_atomic_load(&head->red[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t n_loc = W.n_loc, n_own = W.n_own, n_cons = W.n_cons, m = W.n_rows, zj = W.zj, nlev = W.n_levels;
+    const uint32_t* const var_glob = reinterpret_cast<const uint32_t*>(a.plan + W.o_var_glob);
+    const DevCon* const cons = reinterpret_cast<const DevCon*>(a.plan + W.o_cons);
+    const FrontGhost* const ghosts = reinterpret_cast<const FrontGhost*>(a.plan + W.o_ghosts);
+    double* const xs = ws + W.l_x;
+    double* const dv = ws + W.l_d;
+    double* const jvp = ws + W.l_jv;
+    uint32_t l_r = W.l_r, l_rn = W.l_rn;
+    if (tid == 0) {  // the operands of padding pairs
+        ws[W.l_r + m] = 0.0;
+        ws[W.l_rn + m] = 0.0;
+        jvp[zj] = 0.0;
+    }
+    const bool unit_w = a.unit_weights != 0;
+    uint32_t sys_parity = 0;
+    for (uint64_t sys = slot; sys < a.batch; sys += n_slots, sys_parity ^= 1u) {
+#ifdef EZPZ_STAMPS
+        int stamp_n = 0;
+#endif
+        FRONT_STAMP(1);
+        const double* const x0 = a.x0 + sys * a.n_vars;
+        for (uint32_t i = tid; i < n_loc; i += blockDim.x) xs[i] = x0[var_glob[i]];
+        int* const nwarn = G > 1 ? &head->nwarn[sys_parity] : &ints[0];
+        if (tid == 0 && G == 1) ints[0] = 0;
+        __syncthreads();
+        FRONT_STAMP(2);
+        enum { EVAL0 = 0, STEP = 1, FINAL = 2 };
+        int mode = EVAL0;
+        uint32_t pass = 0, it = 0;
+        double residual_sq = 0.0, largest = 0.0, unsat_cnt = 0.0;
+        bool r_is_at_x = true, all_satisfied = false;
+        double lambda = a.initial_lambda;
+        double step_inf_norm = 0.0;
+        uint32_t iterations = a.max_iterations, converged = 0;
+        double dmax = __builtin_nan("");  // (fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax))
+        for (;;) {
+            if (mode == STEP) {
+                if (it >= a.max_iterations) {  // newton.rs:141-144
+                    mode = FINAL;
+                } else if (largest <= a.residual_tolerance) {  // newton.rs:50-60
+                    iterations = it;
+                    converged = 1;
+                    mode = FINAL;
+                }
+            }
+            if (mode == STEP) {
+                // ---- (JtJ + lambda I) d = -Jt r: the fronts, level by level (newton.rs:73-102) ------------------------------------------
+                ++epoch;
+                if (tid == 0) ints[1] = 0;
+                __syncthreads();
+                bool bad_here = false;
+                for (uint32_t lv = 0; lv < nlev; ++lv) {
+                    const uint32_t k0 = uni(cx.level_ptr[lv]), k1 = uni(cx.level_ptr[lv + 1]);
+                    for (uint32_t k = k0 + uni(wave); k < k1; k += nwaves) bad_here |= front_factor(cx, k, lane, lambda, l_r, epoch);
+                    __syncthreads();
+                    FRONT_STAMP(1000 + lv);
+                }
+                if (bad_here && lane == 0) ints[1] = 1;
+                if (G > 1) {
+                    // a pivot failed somewhere?  every workgroup tells workgroup 0, whose verdict travels with the steps
+                    __syncthreads();
+                    if (wg != 0) {
+                        if (tid == 0) grid_store(cx.chunks + a.bad_chunk0 + wg, ints[1] ? 1.0 : 0.0, epoch);
+                    } else {
+                        if (tid > 0 && (uint32_t)tid < G && grid_wait(cx.chunks + a.bad_chunk0 + tid, epoch, cx.dead) != 0.0) ints[1] = 1;
+                        __syncthreads();
+                        if (tid == 0) grid_store(cx.chunks + a.verdict_chunk, ints[1] ? 1.0 : 0.0, epoch);
+                    }
+                    if (wg != 0) {
+                        if (tid == 0 && grid_wait(cx.chunks + a.verdict_chunk, epoch, cx.dead) != 0.0) ints[1] = 1;
+                    }
+                }
+                __syncthreads();
+                const bool bad = ints[1] != 0;
+                FRONT_STAMP(11);
+                if (bad) {  // numeric failure => lambda *= 10, burn the iteration (newton.rs:93-99)
+                    lambda *= LM_LAMBDA_INCR;
+                    ++it;
+                    __syncthreads();  // (ints[1] is reset at the top of the next trip)
+                    continue;
+                }
+                // ---- backward substitution, top down; the steps of variables other workgroups eliminate arrive as chunks -------------------
+                if (G > 1 && wg != 0) {
+                    for (uint32_t i = tid; i < W.n_ghost; i += blockDim.x) dv[ghosts[i].local] = grid_wait(cx.chunks + ghosts[i].chunk, epoch, cx.dead);
+                    __syncthreads();
+                }
+                dmax = __builtin_nan("");
+                for (uint32_t lv = nlev; lv-- > 0;) {
+                    const uint32_t k0 = uni(cx.level_ptr[lv]), k1 = uni(cx.level_ptr[lv + 1]);
+                    for (uint32_t k = k0 + uni(wave); k < k1; k += nwaves) dmax = front_bwd(cx, k, lane, epoch, dmax);
+                    __syncthreads();
+                }
+                FRONT_STAMP(12);
+                // ---- tentative step (newton.rs:111-114): own variables and ghosts alike (every workgroup moves its copy) -----------------
+                for (uint32_t i = tid; i < n_loc; i += blockDim.x) xs[i] = xs[i] + dv[i];
+                __syncthreads();
+                FRONT_STAMP(14);
+            }
+            if (mode == FINAL && r_is_at_x && unit_w) {
+                // r already holds the unweighted residuals at this x (lib.rs:305-327, :358-370; see lm_kernel.hip.hpp)
+                if (largest < EPS && !isnan(residual_sq)) {
+                    all_satisfied = true;
+                    if (a.unsat_mask && wg == 0)
+                        for (uint32_t i = tid; i < a.n_cons; i += blockDim.x) a.unsat_mask[sys * a.n_cons + i] = 0;
+                    break;
+                }
+                for (uint32_t ci = tid; ci < n_cons; ci += blockDim.x) {
+                    const DevCon c = load_con(cons + ci);
+                    bool sat = fabs(ws[l_r + c.row0]) < EPS;
+                    if (c.nrows > 1) sat = sat && (fabs(ws[l_r + c.row0 + 1]) < EPS);
+                    if (!sat) unsat_cnt += 1.0;
+                    if (a.unsat_mask) a.unsat_mask[sys * a.n_cons + c.pos] = sat ? 0 : 1;
+                }
+                break;
+            }
+            // ---- the residual sweep: EVAL0 -> r, STEP -> r_next, FINAL -> unsatisfied test on unweighted values ---------------------------
+            const uint32_t l_dst = (mode == EVAL0) ? l_r : l_rn;
+            double sq = 0.0, mx = __builtin_nan("");
+            for (uint32_t ci = tid; ci < n_cons; ci += blockDim.x) {
+                const DevCon c = load_con(cons + ci);
+                double r0, r1;
+                const bool deg = con_residual<LIN>(c, (const double*)xs, r0, r1);
+                if (mode == FINAL) {
+                    bool sat = fabs(r0) < EPS;
+                    if (c.nrows > 1) sat = sat && (fabs(r1) < EPS);
+                    if (!sat) unsat_cnt += 1.0;
+                    if (a.unsat_mask) a.unsat_mask[sys * a.n_cons + c.pos] = sat ? 0 : 1;
+                    continue;
+                }
+                const double wgt = unit_w ? 1.0 : c.weight;
+                const double w0 = wgt * r0;
+                ws[l_dst + c.row0] = w0;
+                sq += w0 * w0;
+                mx = fmax_abs(mx, w0);
+                if (c.nrows > 1) {
+                    const double w1 = wgt * r1;
+                    ws[l_dst + c.row0 + 1] = w1;
+                    sq += w1 * w1;
+                    mx = fmax_abs(mx, w1);
+                }
+                if (deg) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
+                    const int idx = atomicAdd(nwarn, 1);
+                    if (a.warn_log && (uint32_t)idx < a.warn_cap) a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
+                }
+                if constexpr (LIN) {  // constant partials: the one Jacobian sweep of a linear-only system rides in eval()
+                    if (mode == EVAL0) {
+                        JacWriter<double*> w;
+                        w.jv = jvp;
+                        w.jbase = c.jbase;
+                        const uint32_t* loc = reinterpret_cast<const uint32_t*>(c.jloc);
+                        w.loc[0] = loc[0], w.loc[1] = loc[1], w.loc[2] = loc[2], w.loc[3] = loc[3];
+                        w.weight = wgt;
+                        (void)con_jacobian<LIN>(c, (const double*)xs, w);
+                    }
+                }
+            }
+            ++pass;
+            __syncthreads();
+            FRONT_STAMP(20);
+            if (mode == FINAL) break;
+            double dm = dmax, zero = 0.0;
+            red.reduce(sq, mx, dm, zero);
+            FRONT_STAMP(21);
+            if (mode == STEP) step_inf_norm = a.n_vars > 0 ? dm : 0.0;  // newton.rs:108
+            const bool accept = (mode == EVAL0) || (sq < residual_sq);  // strict, newton.rs:118
+            if (accept) {
+                if (mode == STEP) {
+                    const uint32_t t = l_r;
+                    l_r = l_rn;
+                    l_rn = t;
+                    lambda *= LM_LAMBDA_DECR;
+                }
+                if constexpr (!LIN) {
+                    for (uint32_t ci = tid; ci < n_cons; ci += blockDim.x) {
+                        const DevCon c = load_con(cons + ci);
+                        JacWriter<double*> w;
+                        w.jv = jvp;
+                        w.jbase = c.jbase;
+                        const uint32_t* loc = reinterpret_cast<const uint32_t*>(c.jloc);
+                        w.loc[0] = loc[0], w.loc[1] = loc[1], w.loc[2] = loc[2], w.loc[3] = loc[3];
+                        w.weight = unit_w ? 1.0 : c.weight;
+                        const bool deg = con_jacobian<LIN>(c, (const double*)xs, w);
+                        if (deg) {
+                            const int idx = atomicAdd(nwarn, 1);
+                            if (a.warn_log && (uint32_t)idx < a.warn_cap) a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | c.pos;
+                        }
+                    }
+                }
+                ++pass;
+                residual_sq = sq;
+                largest = mx;
+                r_is_at_x = true;
+            } else {  // reject: revert, raise lambda (newton.rs:124-131)
+                r_is_at_x = false;
+                for (uint32_t i = tid; i < n_loc; i += blockDim.x) xs[i] = xs[i] - dv[i];
+                lambda *= LM_LAMBDA_INCR;
+            }
+            __syncthreads();
+            FRONT_STAMP(22);
+            if (mode == STEP) {
+                if (step_inf_norm <= a.step_tolerance) {  // newton.rs:134-139
+                    iterations = it;
+                    converged = 1;
+                    mode = FINAL;
+                    continue;
+                }
+                ++it;
+            }
+            if (mode == EVAL0) mode = STEP;
+        }
+        // ---- write-back -------------------------------------------------------------------------------------------------------------------
+        FRONT_STAMP(30);
+        double d1 = __builtin_nan(""), d2 = __builtin_nan(""), d3 = 0.0;
+        const bool skip_count = all_satisfied && (G == 1 || LIN);  // (several workgroups: the rendezvous also orders the warning counter)
+        if (!skip_count) red.reduce(unsat_cnt, d1, d2, d3);
+        double* const xo = a.x_out + sys * a.n_vars;
+        for (uint32_t i = tid; i < n_own; i += blockDim.x) xo[var_glob[i]] = xs[i];
+        if (tid == 0 && wg == 0) {
+            EzpzStatus st;
+            st.iterations = iterations;
+            st.converged = converged;
+            st.n_unsatisfied = (uint32_t)unsat_cnt;
+            st.n_warnings = G > 1 ? (uint32_t)__hip_atomic_load(nwarn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)*nwarn;
+            st.final_residual_inf = largest;  // (a planned system has rows)
+            st.final_lambda = lambda;
+            if (G > 1 && __hip_atomic_load(cx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                st.iterations = EZPZ_ITERATIONS_TEAM_TIMEOUT;
+                st.converged = 0;
+            }
+            a.status[sys] = st;
+            // (several workgroups: this counter serves the slot's system after next; every workgroup passes a reduction of the
+            // next system, which this thread joins only after the store, before it can get there)
+            if (G > 1) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        FRONT_STAMP(32);
+    }
+    if (G > 1 && tid == 0) {
+        __hip_atomic_store(&head->hop[wg], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&head->red[wg], red.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    publish_done(a.done);
+}
+
+}  // namespace ezpz

@@ -1,0 +1,132 @@
+// Plain-data types shared by the host planner (fronts.cpp) and the kernel (front_kernel.hip.hpp) of the FRONTAL launch shape:
+// the linear solve of one connected sketch as a multifrontal supernodal Cholesky factorisation.
+//
+// Where the reference hands every pattern to faer's symbolic + numeric LLT -- simplicial or supernodal as the pattern
+// demands (ezpz/src/solver.rs:289-300, solver/newton.rs:87-102) -- the list / record walks of lm_kernel.hip.hpp eliminate
+// one COLUMN per synchronisation.  Here the unit is a FRONT: a supernode of K <= 16 consecutive columns of the elimination
+// order with the S - K later rows they touch, held as a dense panel; a wavefront owns a front (lane = row), children hand
+// their Schur complements to the parent (extend-add), independent subtrees run side by side on the wavefronts of a
+// workgroup -- and, for large systems, on different workgroups that meet at the top of the tree.
+#pragma once
+#include <cstdint>
+
+#include "dev_types.hpp"
+
+namespace ezpz {
+
+constexpr uint32_t kFrontMaxRows = 63;    // S: rows of a front (lane r = row r; lane S = the right-hand side's row)
+constexpr uint32_t kFrontMaxPivots = 16;  // K: columns eliminated in one front
+constexpr uint32_t kFrontMaxWgs = 64;     // workgroups that share one system
+constexpr uint32_t kFrontRedValues = 4;   // values per grid reduction
+
+// One front.  Panel: column-major (S + 1) x K doubles at `panel` (row S = right-hand side: b, then y); update matrix: the
+// packed lower triangle of the (R + 1) x (R + 1) trailing block (R = S - K; entry (a, b), a >= b, at a (a + 1) / 2 + b;
+// row R = right-hand side) at `upd`.  Offsets count doubles from the workgroup's workspace.
+struct alignas(16) FrontDesc {
+    uint16_t K, S;
+    uint16_t n_child;
+    uint16_t flags;        // FRONT_*
+    uint32_t panel;        // workspace offset of the panel
+    uint32_t upd;          // workspace offset of the update matrix (unused when R == 0)
+    uint32_t rows;         // index into the rows table: S local variable indices (pivots first)
+    uint32_t child0;       // index of the first FrontChild
+    uint32_t asm_off;      // word offset of the assembly stream (fronts.cpp: emit_assembly)
+    uint16_t asm_n;        // entries in the stream
+    uint16_t pad0;
+    uint8_t asm_w[4];      // operand pairs per entry in trip 0, 1, 2 and >= 3 of 64 entries (4-byte aligned: read as one word)
+    uint32_t up_chunk;     // FRONT_REMOTE_PARENT: first chunk of the update matrix in the system's scratch
+    uint32_t exp0;         // FRONT_EXPORTS: index into the export table: K entries (chunk of pivot k's step, or ~0)
+    uint32_t pad1;
+};
+static_assert(sizeof(FrontDesc) == 48, "FrontDesc layout");
+constexpr uint16_t FRONT_REMOTE_PARENT = 1, FRONT_EXPORTS = 2;
+
+// One child of a front: where its update matrix lies, and for each of its R_c + 1 rows the parent's row (the right-hand
+// side's row maps to the parent's row S).
+struct alignas(16) FrontChild {
+    uint32_t upd;      // workspace offset (doubles), or the first chunk in the system's scratch (FRONT_CHILD_REMOTE)
+    uint16_t rows;     // R_c + 1
+    uint16_t flags;
+    uint32_t map;      // byte offset into the map table
+    uint32_t pad;
+};
+static_assert(sizeof(FrontChild) == 16, "FrontChild layout");
+constexpr uint16_t FRONT_CHILD_REMOTE = 1;
+
+// A ghost variable of a workgroup: a later (ancestor) variable that one of its fronts or constraints touches and another
+// workgroup eliminates; its step arrives as a chunk.
+struct FrontGhost {
+    uint32_t local;  // local variable index (>= n_own)
+    uint32_t chunk;  // chunk of the system's scratch that carries its step
+};
+
+// One workgroup's share of a system.  Byte offsets count from the plan blob's start, `l_*` doubles from the workspace's.
+struct alignas(16) FrontWg {
+    uint32_t n_loc, n_own, n_ghost;   // local variables: own pivots first, ghosts behind
+    uint32_t n_cons, n_rows, zj;      // constraints evaluated here, their residual rows, their Jacobian slots
+    uint32_t n_fronts, n_levels;
+    uint32_t o_var_glob;              // uint32[n_loc]: caller's variable id
+    uint32_t o_cons;                  // DevCon[n_cons] (ids = local variables, row0 / jbase local)
+    uint32_t o_tables;                // start of the tables staged into LDS once per workgroup: tab_bytes of
+    uint32_t tab_bytes;               //   FrontDesc[n_fronts] | level_ptr | FrontChild[] | rows | exports | maps
+    uint32_t t_level_ptr, t_children, t_rows, t_exports, t_maps;  // byte offsets inside the staged tables
+    uint32_t o_asm;                   // uint32 words: the fronts' assembly streams
+    uint32_t o_ghosts;                // FrontGhost[n_ghost]
+    uint32_t l_x, l_d, l_r, l_rn, l_jv, l_panels, l_upool;  // workspace carve-up (doubles)
+    uint32_t ws_doubles;              // workspace doubles (state), tables excluded
+    uint32_t n_remote_children;       // fronts of this workgroup that wait for chunks of other workgroups
+    uint32_t pad[4];
+};
+static_assert(sizeof(FrontWg) % 16 == 0, "FrontWg layout");
+
+// Assembly stream of a front: per trip of 64 entries, 64 header words then w x 64 operand words (w = asm_w[trip]).
+// header: destination (doubles from the front's panel, or from its update matrix with FASM_UPD) | flags; operand word =
+// a | b << 16: Jacobian slots (entry of JtJ: += jv[a] * jv[b]), or with FASM_RHS slot a and residual row b (+= jv[a] * -r[b]).
+// Padding operands are (zj, zj) / (zj, n_rows): a Jacobian slot and a residual row that hold zero.
+constexpr uint32_t FASM_UPD = 1u << 16, FASM_DIAG = 1u << 17, FASM_RHS = 1u << 18, FASM_NOP = 1u << 19;
+
+// The scratch of one system in flight on several workgroups (all values travel as self-validating 16-byte chunks, see
+// lm_kernel.hip.hpp: grid_store / grid_wait).  chunks[]: update matrices of fronts whose parent lives in another workgroup,
+// then the steps of exported variables.
+struct FrontScratchHead {
+    int nwarn[2];
+    int dead;
+    int pad0;
+    unsigned int hop[kFrontMaxWgs];  // per workgroup: the last hop / reduction sequence number of its previous launch on this slot
+    unsigned int red[kFrontMaxWgs];
+    unsigned int pad1[60];
+};
+static_assert(sizeof(FrontScratchHead) == 768, "FrontScratchHead layout");
+// behind the head: reduction partials [2 parities][kFrontRedValues][kFrontMaxWgs] chunks, results [2][kFrontMaxWgs][kFrontRedValues]
+// chunks (one 64-byte line per workgroup), then the plan's n_chunks chunks
+constexpr uint32_t kFrontScratchRedBytes = 2u * kFrontRedValues * kFrontMaxWgs * 16u;
+inline constexpr uint32_t front_scratch_bytes(uint32_t n_chunks) {
+    return (uint32_t)sizeof(FrontScratchHead) + 2u * kFrontScratchRedBytes + ((n_chunks * 16u + 255u) & ~255u);
+}
+
+// The kernel's argument block (front.hip fills it from the launch's SolveArgs and the system's plan).
+struct FrontArgs {
+    const unsigned char* plan;  // FrontPlan::blob on the device
+    uint32_t n_wgs;             // workgroups per system
+    uint32_t n_vars, n_cons;    // of the whole system: row length of x0 / x_out, of the unsatisfied mask
+    const double* x0;
+    double* x_out;
+    EzpzStatus* status;
+    uint8_t* unsat_mask;
+    uint64_t* warn_log;
+    uint32_t warn_cap;
+    uint32_t max_iterations;
+    uint64_t batch;
+    double residual_tolerance, step_tolerance, initial_lambda;
+    uint32_t unit_weights;
+    uint32_t tab_lds_bytes;     // LDS reserved for the staged tables (largest workgroup's, a multiple of 16)
+    uint32_t ws_doubles;        // ... and for the workspace
+    uint32_t n_chunks, bad_chunk0, verdict_chunk;
+    unsigned char* scratch;     // n_wgs > 1: one FrontScratch per system in flight
+    uint32_t scratch_stride;
+    uint32_t pad;
+    unsigned long long* stamps;  // diagnostic builds
+    DoneWord done;
+};
+
+}  // namespace ezpz

@@ -1,0 +1,920 @@
+// Symbolic phase of the FRONTAL launch shape (fronts.hpp, front_types.hpp): elimination order, supernodes, the tree of
+// fronts, what each front assembles from the Jacobian, which workgroup owns which subtree, and the workspace carve-up.
+// The reference's counterpart is faer's SymbolicLlt (ezpz/src/solver.rs:289-300: ordering, elimination tree, column counts,
+// supernodal partition); nothing here is taken from it -- the structures are this kernel's own.  Host code, no device code.
+#include "fronts.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <queue>
+
+#include "kinds.hpp"
+
+namespace ezpz {
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+using UVec = std::vector<uint32_t>;
+
+// What the planner believes a front costs on one wavefront, in cycles: its fixed part (descriptor, zeroing, assembly stream,
+// stores), the K dependent pivot steps, the pivot block's updates, and the Schur complement / the children's extend-add by
+// trips of 64 entries.  Only ratios matter: it decides which supernodes are merged and how subtrees are dealt to workgroups.
+double front_cost(uint32_t K, uint32_t S) {
+    const uint32_t R = S - K, nU = (R + 1) * (R + 2) / 2;
+    const double trips = (double)((nU + 63) / 64);
+    return 1100.0 + 110.0 * K + 6.0 * K * K + trips * (40.0 + 14.0 * K) + trips * 90.0;
+}
+double front_bwd_cost(uint32_t K, uint32_t S) { return 350.0 + 30.0 * K + 8.0 * (S - K); }
+
+// Nested dissection of one connected component by breadth-first level structures: the separator is the level that best
+// balances the two sides by vertex count (thin levels preferred), sides are ordered first (recursively), the separator last;
+// pieces of at most `leaf` vertices, or too compact to cut, are leaves in breadth-first order (a band stays a band).
+void dissect(const UVec& verts, const std::vector<UVec>& adj, uint32_t leaf, UVec& out) {
+    const uint32_t n_all = (uint32_t)adj.size();
+    static thread_local UVec region, level, mark;
+    region.assign(n_all, NONE);
+    level.assign(n_all, 0);
+    mark.assign(n_all, 0);
+    for (uint32_t v : verts) region[v] = 0;
+    uint32_t next_region = 1, stamp = 0;
+    struct Task {
+        uint32_t region;
+        bool emit;
+        UVec members;
+    };
+    std::vector<Task> stack;
+    stack.push_back(Task{0, false, verts});
+    UVec queue;
+    auto bfs = [&](uint32_t start, uint32_t reg) {
+        ++stamp;
+        queue.clear();
+        queue.push_back(start);
+        level[start] = 0;
+        mark[start] = stamp;
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const uint32_t v = queue[h];
+            for (uint32_t w : adj[v])
+                if (region[w] == reg && mark[w] != stamp) {
+                    mark[w] = stamp;
+                    level[w] = level[v] + 1;
+                    queue.push_back(w);
+                }
+        }
+    };
+    while (!stack.empty()) {
+        Task t = std::move(stack.back());
+        stack.pop_back();
+        if (t.emit) {
+            out.insert(out.end(), t.members.begin(), t.members.end());
+            continue;
+        }
+        for (uint32_t s0 : t.members) {
+            if (region[s0] != t.region) continue;
+            bfs(s0, t.region);
+            bfs(queue.back(), t.region);  // pseudo-peripheral restart
+            const uint32_t depth = level[queue.back()];
+            if (queue.size() <= leaf || depth < 2) {
+                for (uint32_t v : queue) {
+                    out.push_back(v);
+                    region[v] = NONE;
+                }
+                continue;
+            }
+            UVec width(depth + 1, 0);
+            for (uint32_t v : queue) ++width[level[v]];
+            // the cut: |left - right| + 2 x |separator|, levels 1 .. depth - 1
+            uint32_t best = 1;
+            uint64_t best_score = ~0ull;
+            uint32_t below = width[0];
+            const uint32_t total = (uint32_t)queue.size();
+            for (uint32_t l = 1; l < depth; ++l) {
+                const uint32_t above = total - below - width[l];
+                const uint64_t score = (uint64_t)(below > above ? below - above : above - below) + 2ull * width[l];
+                if (score < best_score) best_score = score, best = l;
+                below += width[l];
+            }
+            Task sep{0, true, {}}, lo{next_region, false, {}}, hi{next_region + 1, false, {}};
+            next_region += 2;
+            for (uint32_t v : queue) {
+                if (level[v] == best) {
+                    sep.members.push_back(v);
+                    region[v] = NONE;
+                } else if (level[v] < best) {
+                    lo.members.push_back(v);
+                    region[v] = lo.region;
+                } else {
+                    hi.members.push_back(v);
+                    region[v] = hi.region;
+                }
+            }
+            stack.push_back(std::move(sep));
+            stack.push_back(std::move(hi));
+            stack.push_back(std::move(lo));
+        }
+    }
+}
+
+struct Blob {
+    std::vector<unsigned char>& b;
+    template <class T>
+    uint32_t put(const std::vector<T>& v) {
+        const size_t off = (b.size() + 15) & ~size_t(15);
+        b.resize(off + std::max<size_t>(v.size() * sizeof(T), 16), 0);
+        if (!v.empty()) std::memcpy(b.data() + off, v.data(), v.size() * sizeof(T));
+        return (uint32_t)off;
+    }
+};
+
+bool fail(const char** why, const char* msg) {
+    if (why) *why = msg;
+    return false;
+}
+
+}  // namespace
+
+bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const FrontOptions& opt, FrontPlan& out,
+                      const char** why) {
+    out = FrontPlan();
+    if (n_cs == 0 || n_vars == 0 || n_cs > 0x3FFFFFFFu || n_vars > 0x3FFFFFFFu) return fail(why, "empty or oversized system");
+    const uint32_t n = (uint32_t)n_vars, C = (uint32_t)n_cs;
+    static const bool debug = std::getenv("EZPZ_FRONT_DEBUG") != nullptr;
+
+    // ---- rows and Jacobian slots, numbered as build_program numbers them (constraint order; equal columns of a row share a
+    //      slot: solver.rs:255-260, :418) ---------------------------------------------------------------------------------
+    struct ConInfo {
+        uint32_t row0, jbase;
+        uint8_t nslots, jloc[16];
+    };
+    std::vector<ConInfo> cinfo(C);
+    UVec row_ptr(1, 0), row_col, row_slot, row_con;
+    std::vector<UVec> cvars(C);  // the variables a constraint's rows touch (sorted, unique)
+    {
+        uint32_t row_num = 0, jslot = 0;
+        for (uint32_t i = 0; i < C; ++i) {
+            if (cs[i].kind >= EZPZ_NUM_KINDS) return fail(why, "unknown kind");
+            const KindInfo& K = kKinds[cs[i].kind];
+            ConInfo& ci = cinfo[i];
+            std::memset(&ci, 0, sizeof(ci));
+            ci.row0 = row_num;
+            ci.jbase = jslot;
+            uint32_t local = 0;
+            int e_global = 0;
+            for (int r = 0; r < K.n_rows; ++r) {
+                for (int e = 0; e < K.n_emit[r]; ++e, ++e_global) {
+                    const uint32_t col = cs[i].ids[K.emit[r][e]];
+                    if (col >= n) return fail(why, "variable id out of range");
+                    int dup = -1;
+                    for (int e2 = 0; e2 < e; ++e2)
+                        if (cs[i].ids[K.emit[r][e2]] == col) {
+                            dup = e2;
+                            break;
+                        }
+                    if (dup >= 0) {
+                        ci.jloc[e_global] = (uint8_t)((ci.jloc[e_global - e + dup] & 0x7F) | 0x80);
+                    } else {
+                        ci.jloc[e_global] = (uint8_t)local;
+                        row_col.push_back(col);
+                        row_slot.push_back(jslot + local);
+                        ++local;
+                    }
+                    cvars[i].push_back(col);
+                }
+                for (int e = 0; e < K.n_nz[r]; ++e) {
+                    const uint32_t col = cs[i].ids[K.nz[r][e]];
+                    if (col >= n) return fail(why, "variable id out of range");
+                    cvars[i].push_back(col);
+                }
+                ++row_num;
+                row_ptr.push_back((uint32_t)row_col.size());
+                row_con.push_back(i);
+            }
+            ci.nslots = (uint8_t)local;
+            jslot += local;
+            std::sort(cvars[i].begin(), cvars[i].end());
+            cvars[i].erase(std::unique(cvars[i].begin(), cvars[i].end()), cvars[i].end());
+            if (cs[i].weight != 1.0) out.unit_weights = false;
+            if (!kind_is_linear(cs[i].kind)) out.linear_only = false;
+        }
+        out.n_rows = row_num;
+        out.zj = jslot;
+    }
+    out.n_vars = n;
+    out.n_cons = C;
+
+    // ---- the graph: every constraint a clique of all the variables it touches (one home front per constraint: whoever
+    //      evaluates it owns all its rows) ---------------------------------------------------------------------------------
+    std::vector<UVec> adj(n);
+    for (uint32_t i = 0; i < C; ++i)
+        for (uint32_t a : cvars[i])
+            for (uint32_t b : cvars[i])
+                if (a != b) adj[a].push_back(b);
+    for (uint32_t v = 0; v < n; ++v) {
+        std::sort(adj[v].begin(), adj[v].end());
+        adj[v].erase(std::unique(adj[v].begin(), adj[v].end()), adj[v].end());
+    }
+
+    // ---- elimination order: nested dissection per connected component -------------------------------------------------------
+    UVec order;
+    order.reserve(n);
+    {
+        std::vector<char> seen(n, 0);
+        UVec verts, stack;
+        static const uint32_t leaf = [] {
+            const char* e = std::getenv("EZPZ_FRONT_LEAF");
+            return e ? (uint32_t)std::atoi(e) : 10u;
+        }();
+        for (uint32_t s = 0; s < n; ++s) {
+            if (seen[s]) continue;
+            verts.clear();
+            stack.assign(1, s);
+            seen[s] = 1;
+            while (!stack.empty()) {
+                const uint32_t v = stack.back();
+                stack.pop_back();
+                verts.push_back(v);
+                for (uint32_t w : adj[v])
+                    if (!seen[w]) seen[w] = 1, stack.push_back(w);
+            }
+            std::sort(verts.begin(), verts.end());
+            if (verts.size() <= leaf)
+                order.insert(order.end(), verts.begin(), verts.end());
+            else
+                dissect(verts, adj, leaf, order);
+        }
+        if (order.size() != n) return fail(why, "ordering lost a variable");
+    }
+    UVec pos(n);
+    for (uint32_t k = 0; k < n; ++k) pos[order[k]] = k;
+
+    // ---- column structures and the elimination tree (positions) -------------------------------------------------------------
+    std::vector<UVec> cstruct(n);  // rows > j of column j of L, ascending
+    UVec parent(n, NONE);
+    auto symbolic = [&]() {
+        std::vector<UVec> kids(n);
+        for (uint32_t j = 0; j < n; ++j) {
+            UVec& s = cstruct[j];
+            s.clear();
+            for (uint32_t w : adj[order[j]])
+                if (pos[w] > j) s.push_back(pos[w]);
+            for (uint32_t c : kids[j])
+                for (uint32_t i : cstruct[c])
+                    if (i != j) s.push_back(i);
+            std::sort(s.begin(), s.end());
+            s.erase(std::unique(s.begin(), s.end()), s.end());
+            parent[j] = s.empty() ? NONE : s[0];
+            if (parent[j] != NONE) kids[parent[j]].push_back(j);
+        }
+    };
+    symbolic();
+    // ---- postorder (the tallest child last, next to its parent), then the same again in the new numbering -------------------
+    {
+        std::vector<UVec> kids(n);
+        UVec height(n, 1);
+        for (uint32_t j = 0; j < n; ++j)
+            if (parent[j] != NONE) {
+                kids[parent[j]].push_back(j);
+                height[parent[j]] = std::max(height[parent[j]], height[j] + 1);
+            }
+        UVec post;
+        post.reserve(n);
+        std::vector<std::pair<uint32_t, uint32_t>> st;  // (node, next child)
+        for (uint32_t r = 0; r < n; ++r) {
+            if (parent[r] != NONE) continue;
+            st.push_back({r, 0});
+            while (!st.empty()) {
+                auto& [v, k] = st.back();
+                if (k == 0) std::stable_sort(kids[v].begin(), kids[v].end(), [&](uint32_t a, uint32_t b) { return height[a] < height[b]; });
+                if (k < kids[v].size()) {
+                    const uint32_t c = kids[v][k++];
+                    st.push_back({c, 0});
+                } else {
+                    post.push_back(v);
+                    st.pop_back();
+                }
+            }
+        }
+        UVec order2(n);
+        for (uint32_t k = 0; k < n; ++k) order2[k] = order[post[k]];
+        order.swap(order2);
+        for (uint32_t k = 0; k < n; ++k) pos[order[k]] = k;
+        symbolic();
+    }
+
+    // ---- supernodes: fundamental ones first, then a child is merged into the parent it immediately precedes while the merged
+    //      front is cheaper than the two (front_cost: a front's fixed cost is most of a small front) ----------------------------
+    const uint32_t KMAX = kFrontMaxPivots, SMAX = kFrontMaxRows;
+    UVec nkids(n, 0);
+    for (uint32_t j = 0; j < n; ++j)
+        if (parent[j] != NONE) ++nkids[parent[j]];
+    struct Block {
+        uint32_t c0, c1;  // columns [c0, c1)
+    };
+    std::vector<Block> blocks;
+    for (uint32_t j = 0; j < n; ++j) {
+        const bool chain = j > 0 && parent[j - 1] == j && nkids[j] == 1 && cstruct[j - 1].size() == cstruct[j].size() + 1 &&
+                           !blocks.empty() && j - blocks.back().c0 < KMAX;
+        if (chain)
+            blocks.back().c1 = j + 1;
+        else
+            blocks.push_back(Block{j, j + 1});
+    }
+    {
+        static const bool relax = [] {
+            const char* e = std::getenv("EZPZ_FRONT_RELAX");
+            return !(e && e[0] == '0');
+        }();
+        // rows of a block = its columns + the structure of its last column (a block's columns chain: each column's structure
+        // is the next one's plus itself) -- until blocks are merged: then the structure of the merged block is that of the
+        // parent, its rows the child's columns + the parent's rows
+        std::vector<Block> merged;
+        std::vector<uint32_t> srows;  // S of each merged block
+        for (const Block& b : blocks) {
+            Block cur = b;
+            uint32_t S = (cur.c1 - cur.c0) + (uint32_t)cstruct[cur.c1 - 1].size();
+            while (relax && !merged.empty()) {
+                const Block& c = merged.back();
+                if (c.c1 != cur.c0 || parent[c.c1 - 1] == NONE || parent[c.c1 - 1] < cur.c0 || parent[c.c1 - 1] >= cur.c1) break;
+                const uint32_t Kc = c.c1 - c.c0, Sc = srows.back(), K2 = Kc + (cur.c1 - cur.c0), S2 = Kc + S;
+                if (K2 > KMAX || S2 > SMAX) break;
+                const double apart = front_cost(Kc, Sc) + front_bwd_cost(Kc, Sc) + front_cost(cur.c1 - cur.c0, S) + front_bwd_cost(cur.c1 - cur.c0, S);
+                const double joined = front_cost(K2, S2) + front_bwd_cost(K2, S2);
+                if (joined > apart) break;
+                cur.c0 = c.c0;
+                S = S2;
+                merged.pop_back();
+                srows.pop_back();
+            }
+            merged.push_back(cur);
+            srows.push_back(S);
+        }
+        blocks.swap(merged);
+    }
+    const uint32_t F = (uint32_t)blocks.size();
+    UVec block_of(n);
+    for (uint32_t f = 0; f < F; ++f)
+        for (uint32_t j = blocks[f].c0; j < blocks[f].c1; ++j) block_of[j] = f;
+
+    // ---- the fronts: rows, parents, children, levels --------------------------------------------------------------------------
+    struct Front {
+        uint32_t c0, K, S;
+        UVec below;  // rows beyond the pivots (positions, ascending)
+        uint32_t parent = NONE, level = 0, wg = 0, local = 0;
+        UVec kids;
+        UVec cons;  // constraints assembled here
+        double cost = 0.0, subtree = 0.0;
+    };
+    std::vector<Front> fr(F);
+    for (uint32_t f = 0; f < F; ++f) {
+        Front& t = fr[f];
+        t.c0 = blocks[f].c0;
+        t.K = blocks[f].c1 - blocks[f].c0;
+        for (uint32_t j = blocks[f].c0; j < blocks[f].c1; ++j)
+            for (uint32_t i : cstruct[j])
+                if (i >= blocks[f].c1) t.below.push_back(i);
+        std::sort(t.below.begin(), t.below.end());
+        t.below.erase(std::unique(t.below.begin(), t.below.end()), t.below.end());
+        t.S = t.K + (uint32_t)t.below.size();
+        if (t.S > SMAX) return fail(why, "a front has more than 63 rows");
+        t.parent = t.below.empty() ? NONE : block_of[t.below[0]];
+        t.cost = front_cost(t.K, t.S) + front_bwd_cost(t.K, t.S);
+        out.max_rows = std::max(out.max_rows, t.S);
+        out.max_pivots = std::max(out.max_pivots, t.K);
+    }
+    for (uint32_t f = 0; f < F; ++f) {
+        if (fr[f].parent == NONE) continue;
+        Front& p = fr[fr[f].parent];
+        p.kids.push_back(f);
+        p.level = std::max(p.level, fr[f].level + 1);  // (children precede parents)
+        // every row of the child beyond its pivots is a row of the parent
+        for (uint32_t i : fr[f].below) {
+            const bool in_p = (i >= p.c0 && i < p.c0 + p.K) || std::binary_search(p.below.begin(), p.below.end(), i);
+            if (!in_p) return fail(why, "internal: a child's row is missing from its parent");
+        }
+    }
+    for (uint32_t f = 0; f < F; ++f) {
+        fr[f].subtree += fr[f].cost;
+        if (fr[f].parent != NONE) fr[fr[f].parent].subtree += fr[f].subtree;
+    }
+    // ---- home fronts of the constraints: where their earliest variable is eliminated ---------------------------------------------
+    for (uint32_t i = 0; i < C; ++i) {
+        uint32_t first = NONE;
+        for (uint32_t v : cvars[i]) first = std::min(first, pos[v]);
+        if (first == NONE) return fail(why, "a constraint without variables");
+        Front& h = fr[block_of[first]];
+        for (uint32_t v : cvars[i]) {
+            const uint32_t p = pos[v];
+            const bool in_h = (p >= h.c0 && p < h.c0 + h.K) || std::binary_search(h.below.begin(), h.below.end(), p);
+            if (!in_h) return fail(why, "internal: a constraint's variable is missing from its home front");
+        }
+        h.cons.push_back(i);
+    }
+
+    // ---- workgroups: the top of the tree on workgroup 0, whole subtrees dealt to the others ------------------------------------
+    uint32_t G = opt.wgs;
+    double total_cost = 0.0;
+    for (uint32_t f = 0; f < F; ++f) total_cost += fr[f].cost;
+    if (G == 0) {
+        const uint32_t per_wg = std::max(16u, opt.vars_per_wg);
+        G = n <= 2 * per_wg ? 1u : std::min<uint32_t>(opt.max_wgs, (n + per_wg - 1) / per_wg + 1);
+    }
+    G = std::max(1u, std::min<uint32_t>(G, std::min<uint32_t>(opt.max_wgs, kFrontMaxWgs)));
+    if (G > 1) {
+        // open subtrees, heaviest first; a subtree's root moves to the top (workgroup 0) and its children open while the
+        // heaviest open subtree is more than its fair share of what is not yet on top
+        using Item = std::pair<double, uint32_t>;
+        std::priority_queue<Item> open;
+        for (uint32_t f = 0; f < F; ++f)
+            if (fr[f].parent == NONE) open.push(Item{fr[f].subtree, f});
+        std::vector<char> on_top(F, 0);
+        double top_cost = 0.0;
+        uint32_t top_vars = 0;
+        static const double share = [] {
+            const char* e = std::getenv("EZPZ_FRONT_SHARE");
+            return e ? std::atof(e) : 0.75;
+        }();
+        while (!open.empty()) {
+            const Item it = open.top();
+            const double rest = total_cost - top_cost;
+            if (open.size() >= G - 1 && it.first <= share * rest / (G - 1)) break;
+            if (fr[it.second].kids.empty()) break;  // a leaf front cannot be split
+            open.pop();
+            on_top[it.second] = 1;
+            top_cost += fr[it.second].cost;
+            top_vars += fr[it.second].K;
+            for (uint32_t c : fr[it.second].kids) open.push(Item{fr[c].subtree, c});
+        }
+        // longest-processing-time first into G - 1 bins
+        std::vector<Item> subs;
+        while (!open.empty()) subs.push_back(open.top()), open.pop();
+        std::vector<double> load(G, 0.0);
+        std::vector<uint32_t> owner(F, 0);
+        UVec root_wg(F, 0);
+        for (const Item& it : subs) {
+            uint32_t best = 1;
+            for (uint32_t g = 2; g < G; ++g)
+                if (load[g] < load[best]) best = g;
+            load[best] += it.first;
+            root_wg[it.second] = best;
+        }
+        // propagate: a front not on top belongs to its subtree root's workgroup (parents come later: walk down from the roots)
+        for (uint32_t f = F; f-- > 0;) {
+            if (on_top[f]) {
+                fr[f].wg = 0;
+            } else if (fr[f].parent == NONE || on_top[fr[f].parent]) {
+                fr[f].wg = root_wg[f];
+            } else {
+                fr[f].wg = fr[fr[f].parent].wg;
+            }
+        }
+        // workgroups that received nothing: renumber densely (workgroup 0 stays the top even when it is empty of subtrees)
+        std::vector<char> used(G, 0);
+        used[0] = 1;
+        for (uint32_t f = 0; f < F; ++f) used[fr[f].wg] = 1;
+        UVec renum(G, 0);
+        uint32_t g2 = 0;
+        for (uint32_t g = 0; g < G; ++g)
+            if (used[g]) renum[g] = g2++;
+        for (uint32_t f = 0; f < F; ++f) fr[f].wg = renum[fr[f].wg];
+        G = g2;
+        bool any_top = false;
+        for (uint32_t f = 0; f < F; ++f) any_top = any_top || fr[f].wg == 0;
+        if (!any_top || G < 2) {  // nothing to split: one workgroup
+            for (uint32_t f = 0; f < F; ++f) fr[f].wg = 0;
+            G = 1;
+        }
+        (void)top_vars;
+    }
+    out.n_wgs = G;
+
+    // ---- per workgroup: fronts by (level within the workgroup, cost), local variables, constraints ------------------------------
+    // Levels are per workgroup: a front's level = 1 + the highest level of its children IN THE SAME workgroup (children in other
+    // workgroups arrive as chunks and are waited for).
+    for (uint32_t f = 0; f < F; ++f) {
+        fr[f].level = 0;
+    }
+    for (uint32_t f = 0; f < F; ++f)
+        if (fr[f].parent != NONE && fr[fr[f].parent].wg == fr[f].wg)
+            fr[fr[f].parent].level = std::max(fr[fr[f].parent].level, fr[f].level + 1);
+    std::vector<UVec> wg_fronts(G);
+    for (uint32_t f = 0; f < F; ++f) wg_fronts[fr[f].wg].push_back(f);
+    // exported variables: pivots of workgroup 0 that another workgroup sees as a ghost (decided below); chunk layout of a system's
+    // scratch: [update matrices of fronts with a remote parent][one flag per workgroup: a pivot failed][steps of the exported
+    // variables][the verdict on the factorisation]
+    uint32_t n_chunks = 0;
+    UVec up_chunk(F, NONE);
+    for (uint32_t f = 0; f < F; ++f)
+        if (fr[f].parent != NONE && fr[fr[f].parent].wg != fr[f].wg) {
+            const uint32_t R = fr[f].S - fr[f].K;
+            up_chunk[f] = n_chunks;
+            n_chunks += (R + 1) * (R + 2) / 2;
+        }
+    const uint32_t bad_chunk0 = n_chunks;
+    if (G > 1) n_chunks += G;
+    UVec export_chunk(n, NONE);  // by position
+    const uint32_t exp_chunk0 = n_chunks;
+    (void)exp_chunk0;
+    // ghosts first (they decide the exports)
+    std::vector<UVec> wg_ghost(G);  // positions
+    std::vector<UVec> wg_cons(G);
+    for (uint32_t g = 0; g < G; ++g) {
+        UVec& gh = wg_ghost[g];
+        for (uint32_t f : wg_fronts[g]) {
+            for (uint32_t i : fr[f].below)
+                if (fr[block_of[i]].wg != g) gh.push_back(i);
+            for (uint32_t c : fr[f].cons) wg_cons[g].push_back(c);
+        }
+        std::sort(gh.begin(), gh.end());
+        gh.erase(std::unique(gh.begin(), gh.end()), gh.end());
+        for (uint32_t i : gh) {
+            if (fr[block_of[i]].wg != 0) return fail(why, "internal: a ghost that is not eliminated on workgroup 0");
+            if (export_chunk[i] == NONE) export_chunk[i] = 0;  // marked; numbered below
+        }
+    }
+    for (uint32_t j = 0; j < n; ++j)
+        if (export_chunk[j] != NONE) export_chunk[j] = n_chunks++;
+    const uint32_t verdict_chunk = n_chunks;
+    if (G > 1) ++n_chunks;
+    out.n_chunks = n_chunks;
+
+    // ---- emit -----------------------------------------------------------------------------------------------------------------
+    std::vector<FrontWg> wgs(G);
+    Blob B{out.blob};
+    out.blob.assign(((size_t)G * sizeof(FrontWg) + 15) & ~size_t(15), 0);
+    const uint32_t waves = std::max(1u, opt.threads / 64);
+    double model_top = 0.0, model_sub = 0.0;
+    for (uint32_t g = 0; g < G; ++g) {
+        FrontWg& W = wgs[g];
+        std::memset(&W, 0, sizeof(W));
+        UVec& fl = wg_fronts[g];
+        std::stable_sort(fl.begin(), fl.end(), [&](uint32_t a, uint32_t b) {
+            if (fr[a].level != fr[b].level) return fr[a].level < fr[b].level;
+            return fr[a].cost > fr[b].cost;
+        });
+        uint32_t nlev = 0;
+        for (uint32_t f : fl) nlev = std::max(nlev, fr[f].level + 1);
+        UVec level_ptr(nlev + 1, 0);
+        for (uint32_t f : fl) ++level_ptr[fr[f].level + 1];
+        for (uint32_t l = 0; l < nlev; ++l) level_ptr[l + 1] += level_ptr[l];
+        // model: per level the busiest wavefront
+        {
+            double up = 0.0;
+            for (uint32_t l = 0; l < nlev; ++l) {
+                std::vector<double> w(waves, 0.0);
+                for (uint32_t k = level_ptr[l]; k < level_ptr[l + 1]; ++k) w[(k - level_ptr[l]) % waves] += fr[fl[k]].cost;
+                up += *std::max_element(w.begin(), w.end()) + 150.0;
+            }
+            if (g == 0)
+                model_top = up;  // (workgroup 0 runs after the others)
+            else
+                model_sub = std::max(model_sub, up);
+        }
+        // local variables: own pivots in front order, ghosts behind
+        UVec local_of(n, NONE);  // position -> local index
+        UVec var_glob;
+        for (uint32_t k = 0; k < fl.size(); ++k) {
+            Front& t = fr[fl[k]];
+            t.local = k;
+            for (uint32_t j = t.c0; j < t.c0 + t.K; ++j) {
+                local_of[j] = (uint32_t)var_glob.size();
+                var_glob.push_back(order[j]);
+            }
+        }
+        W.n_own = (uint32_t)var_glob.size();
+        std::vector<FrontGhost> ghosts;
+        for (uint32_t i : wg_ghost[g]) {
+            local_of[i] = (uint32_t)var_glob.size();
+            ghosts.push_back(FrontGhost{local_of[i], export_chunk[i]});
+            var_glob.push_back(order[i]);
+        }
+        W.n_ghost = (uint32_t)ghosts.size();
+        W.n_loc = (uint32_t)var_glob.size();
+        if (W.n_loc >= 65535) return fail(why, "a workgroup's variables do not fit 16-bit indices");
+        // constraints: by kind (the sweeps' lanes then mostly run the same evaluator), rows and slots renumbered
+        UVec& cl = wg_cons[g];
+        std::stable_sort(cl.begin(), cl.end(), [&](uint32_t a, uint32_t b) { return cs[a].kind < cs[b].kind; });
+        std::vector<DevCon> dcons(cl.size());
+        UVec lrow0(C, NONE), ljbase(C, NONE);
+        uint32_t lrows = 0, lslots = 0;
+        for (uint32_t k = 0; k < cl.size(); ++k) {
+            const uint32_t i = cl[k];
+            const KindInfo& K = kKinds[cs[i].kind];
+            DevCon& d = dcons[k];
+            std::memset(&d, 0, sizeof(d));
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t v = e < K.n_ids ? cs[i].ids[e] : NONE;
+                // (ids a kind lists but neither differentiates nor reads -- a circle's centre for CircleRadius -- may lie outside
+                // this workgroup's variables: any valid index serves)
+                d.ids[e] = (v != NONE && v < n && local_of[pos[v]] != NONE) ? local_of[pos[v]] : 0u;
+            }
+            d.param = cs[i].param;
+            d.weight = cs[i].weight;
+            d.row0 = lrows;
+            d.jbase = lslots;
+            d.pos = i;
+            d.kind = (uint8_t)cs[i].kind;
+            d.tag = cs[i].tag;
+            d.nrows = K.n_rows;
+            d.nslots = cinfo[i].nslots;
+            std::memcpy(d.jloc, cinfo[i].jloc, 16);
+            lrow0[i] = lrows;
+            ljbase[i] = lslots;
+            lrows += K.n_rows;
+            lslots += cinfo[i].nslots;
+        }
+        W.n_cons = (uint32_t)cl.size();
+        W.n_rows = lrows;
+        W.zj = lslots;
+        if (lslots >= 65535 || lrows >= 65535) return fail(why, "a workgroup's Jacobian does not fit 16-bit indices");
+        // ---- workspace carve-up ------------------------------------------------------------------------------------------------
+        uint32_t off = 0;
+        auto take = [&](uint32_t doubles) {
+            const uint32_t o = off;
+            off += (doubles + 1) & ~1u;
+            return o;
+        };
+        W.l_x = take(W.n_loc);
+        W.l_d = take(W.n_loc);
+        W.l_r = take(lrows + 1);   // (+ the zero row padding operands read)
+        W.l_rn = take(lrows + 1);
+        W.l_jv = take(lslots + 1);  // (+ the zero slot)
+        W.l_panels = off;
+        std::vector<FrontDesc> descs(fl.size());
+        std::vector<FrontChild> children;
+        std::vector<uint16_t> rows;
+        UVec exports;
+        std::vector<uint8_t> maps;
+        UVec asm_words;
+        for (uint32_t k = 0; k < fl.size(); ++k) {
+            const Front& t = fr[fl[k]];
+            FrontDesc& d = descs[k];
+            std::memset(&d, 0, sizeof(d));
+            d.K = (uint16_t)t.K;
+            d.S = (uint16_t)t.S;
+            d.panel = take((t.S + 1) * t.K);
+            out.panel_doubles += (uint64_t)(t.S + 1) * t.K;
+        }
+        W.l_upool = off;
+        // update matrices: alive from their front's level to their parent's (first fit over the levels of this workgroup); fronts
+        // whose parent lives elsewhere keep theirs to the end of the factorisation (it is only scratch for the chunks)
+        {
+            struct Free {
+                uint32_t off, len;
+            };
+            std::vector<Free> free_list;
+            uint32_t pool_end = 0;
+            auto alloc = [&](uint32_t len) {
+                len = (len + 1) & ~1u;
+                for (size_t i = 0; i < free_list.size(); ++i)
+                    if (free_list[i].len >= len) {
+                        const uint32_t o = free_list[i].off;
+                        free_list[i].off += len;
+                        free_list[i].len -= len;
+                        if (!free_list[i].len) free_list.erase(free_list.begin() + (long)i);
+                        return o;
+                    }
+                const uint32_t o = pool_end;
+                pool_end += len;
+                return o;
+            };
+            auto release = [&](uint32_t o, uint32_t len) {
+                len = (len + 1) & ~1u;
+                free_list.push_back(Free{o, len});
+                std::sort(free_list.begin(), free_list.end(), [](const Free& a, const Free& b) { return a.off < b.off; });
+                for (size_t i = 0; i + 1 < free_list.size();)
+                    if (free_list[i].off + free_list[i].len == free_list[i + 1].off) {
+                        free_list[i].len += free_list[i + 1].len;
+                        free_list.erase(free_list.begin() + (long)i + 1);
+                    } else {
+                        ++i;
+                    }
+            };
+            std::vector<std::vector<std::pair<uint32_t, uint32_t>>> dies(nlev + 1);  // by level: (offset, length) freed AFTER it
+            for (uint32_t l = 0; l < nlev; ++l) {
+                for (uint32_t k = level_ptr[l]; k < level_ptr[l + 1]; ++k) {
+                    const Front& t = fr[fl[k]];
+                    const uint32_t R = t.S - t.K;
+                    if (R == 0) continue;
+                    const uint32_t len = (R + 1) * (R + 2) / 2;
+                    const uint32_t o = alloc(len);
+                    descs[k].upd = W.l_upool + o;
+                    out.update_doubles += len;
+                    const bool local_parent = t.parent != NONE && fr[t.parent].wg == g;
+                    dies[local_parent ? fr[t.parent].level : nlev - 1].push_back({o, len});
+                }
+                for (auto& [o, len] : dies[l]) release(o, len);
+            }
+            off = W.l_upool + ((pool_end + 1) & ~1u);
+        }
+        W.ws_doubles = off;
+        // ---- per front: rows, children + maps, exports, the assembly stream ---------------------------------------------------------
+        for (uint32_t k = 0; k < fl.size(); ++k) {
+            const Front& t = fr[fl[k]];
+            FrontDesc& d = descs[k];
+            d.rows = (uint32_t)rows.size();
+            UVec frow;  // positions of the front's rows
+            for (uint32_t j = t.c0; j < t.c0 + t.K; ++j) frow.push_back(j);
+            frow.insert(frow.end(), t.below.begin(), t.below.end());
+            for (uint32_t p : frow) {
+                if (local_of[p] == NONE) return fail(why, "internal: a front row without a local variable");
+                rows.push_back((uint16_t)local_of[p]);
+            }
+            auto row_in_front = [&](uint32_t p) -> uint32_t {  // position -> row of this front
+                if (p >= t.c0 && p < t.c0 + t.K) return p - t.c0;
+                const auto it = std::lower_bound(t.below.begin(), t.below.end(), p);
+                return (it != t.below.end() && *it == p) ? t.K + (uint32_t)(it - t.below.begin()) : NONE;
+            };
+            // children (this workgroup's first, in their order; then remote ones)
+            d.child0 = (uint32_t)children.size();
+            UVec kid_order = t.kids;
+            std::stable_sort(kid_order.begin(), kid_order.end(), [&](uint32_t a, uint32_t b) { return (fr[a].wg != g) < (fr[b].wg != g); });
+            for (uint32_t c : kid_order) {
+                const Front& ch = fr[c];
+                FrontChild fc;
+                std::memset(&fc, 0, sizeof(fc));
+                const bool remote = ch.wg != g;
+                fc.flags = remote ? FRONT_CHILD_REMOTE : 0;
+                fc.rows = (uint16_t)(ch.S - ch.K + 1);
+                fc.map = (uint32_t)maps.size();
+                for (uint32_t i : ch.below) {
+                    const uint32_t r = row_in_front(i);
+                    if (r == NONE) return fail(why, "internal: extend-add map");
+                    maps.push_back((uint8_t)r);
+                }
+                maps.push_back((uint8_t)t.S);  // the right-hand side's row
+                if (remote) {
+                    fc.upd = up_chunk[c];
+                    ++W.n_remote_children;
+                }
+                // (local children: filled in below, once every front of this workgroup has its update matrix)
+                children.push_back(fc);
+                ++d.n_child;
+            }
+            if (t.parent != NONE && fr[t.parent].wg != g) {
+                d.flags |= FRONT_REMOTE_PARENT;
+                d.up_chunk = up_chunk[fl[k]];
+            }
+            bool exp_any = false;
+            for (uint32_t j = t.c0; j < t.c0 + t.K; ++j) exp_any = exp_any || export_chunk[j] != NONE;
+            if (exp_any) {
+                d.flags |= FRONT_EXPORTS;
+                d.exp0 = (uint32_t)exports.size();
+                for (uint32_t j = t.c0; j < t.c0 + t.K; ++j) exports.push_back(export_chunk[j]);
+            }
+            // ---- assembly stream: every entry (row i, row j), i >= j, and every right-hand-side entry the front's own constraints
+            //      contribute to, with its operand pairs; sorted by pairs (most first) so that a trip's width fits its entries
+            struct Entry {
+                uint32_t hdr;
+                UVec ops;
+            };
+            std::vector<Entry> entries;
+            {
+                // (row i, row j) -> entry index, via a small dense table over the front
+                const uint32_t S1 = t.S + 1;
+                std::vector<int32_t> at((size_t)S1 * S1, -1);
+                auto entry = [&](uint32_t i, uint32_t j, uint32_t flags) -> Entry& {  // i >= j; i == S: right-hand side
+                    int32_t& e = at[(size_t)i * S1 + j];
+                    if (e < 0) {
+                        e = (int32_t)entries.size();
+                        uint32_t dest;
+                        if (j < t.K) {
+                            dest = j * S1 + i;  // panel, column-major
+                        } else {
+                            const uint32_t a = i - t.K, b = j - t.K;
+                            dest = (a * (a + 1) / 2 + b) | FASM_UPD;
+                        }
+                        entries.push_back(Entry{dest | flags, {}});
+                    }
+                    return entries[(size_t)e];
+                };
+                // the diagonal of every pivot exists even without a constraint (lambda)
+                for (uint32_t j = 0; j < t.K; ++j) entry(j, j, FASM_DIAG);
+                for (uint32_t c : t.cons) {
+                    const KindInfo& K = kKinds[cs[c].kind];
+                    for (int r = 0; r < K.n_rows; ++r) {
+                        const uint32_t grow = cinfo[c].row0 + (uint32_t)r;
+                        const uint32_t lrow = lrow0[c] + (uint32_t)r;
+                        for (uint32_t qa = row_ptr[grow]; qa < row_ptr[grow + 1]; ++qa) {
+                            const uint32_t ra = row_in_front(pos[row_col[qa]]);
+                            const uint32_t sa = row_slot[qa] - cinfo[c].jbase + ljbase[c];
+                            if (ra == NONE) return fail(why, "internal: assembly row");
+                            entry(t.S, ra, FASM_RHS).ops.push_back(sa | (lrow << 16));
+                            for (uint32_t qb = row_ptr[grow]; qb < row_ptr[grow + 1]; ++qb) {
+                                const uint32_t rb = row_in_front(pos[row_col[qb]]);
+                                if (rb == NONE || rb > ra) continue;
+                                if (rb == ra && qb != qa) continue;  // (one slot per column and row: cannot happen)
+                                const uint32_t sb = row_slot[qb] - cinfo[c].jbase + ljbase[c];
+                                entry(ra, rb, ra == rb && ra < t.K ? FASM_DIAG : 0u).ops.push_back(sa | (sb << 16));
+                            }
+                        }
+                    }
+                }
+            }
+            std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.ops.size() > b.ops.size(); });
+            if (entries.size() > 65535) return fail(why, "a front's assembly stream is too long");
+            d.asm_n = (uint16_t)entries.size();
+            d.asm_off = (uint32_t)asm_words.size();
+            const uint32_t trips = ((uint32_t)entries.size() + 63) / 64;
+            uint32_t tail_w = 0;
+            for (uint32_t tr = 3; tr < trips; ++tr) tail_w = std::max<uint32_t>(tail_w, (uint32_t)entries[tr * 64].ops.size());
+            for (uint32_t tr = 0; tr < trips; ++tr) {
+                uint32_t w = tr < 3 ? (uint32_t)entries[tr * 64].ops.size() : tail_w;
+                if (w > 255) return fail(why, "an entry with more than 255 operand pairs");
+                d.asm_w[std::min(tr, 3u)] = (uint8_t)w;
+                const size_t base = asm_words.size();
+                asm_words.resize(base + 64 * (1 + (size_t)w), 0);
+                for (uint32_t l = 0; l < 64; ++l) {
+                    const uint32_t e = tr * 64 + l;
+                    if (e >= entries.size()) {
+                        asm_words[base + l] = FASM_NOP;
+                        for (uint32_t q = 0; q < w; ++q) asm_words[base + 64 * (1 + q) + l] = lslots | (lslots << 16);
+                        continue;
+                    }
+                    const Entry& en = entries[e];
+                    asm_words[base + l] = en.hdr;
+                    const uint32_t padw = (en.hdr & FASM_RHS) ? (lslots | (lrows << 16)) : (lslots | (lslots << 16));
+                    for (uint32_t q = 0; q < w; ++q)
+                        asm_words[base + 64 * (1 + q) + l] = q < en.ops.size() ? en.ops[q] : padw;
+                }
+            }
+        }
+        // local children: their update matrices' offsets
+        for (uint32_t k = 0; k < fl.size(); ++k) {
+            const Front& t = fr[fl[k]];
+            UVec kid_order = t.kids;
+            std::stable_sort(kid_order.begin(), kid_order.end(), [&](uint32_t a, uint32_t b) { return (fr[a].wg != g) < (fr[b].wg != g); });
+            for (uint32_t q = 0; q < kid_order.size(); ++q)
+                if (fr[kid_order[q]].wg == g) children[descs[k].child0 + q].upd = descs[fr[kid_order[q]].local].upd;
+        }
+        // ---- serialise ----------------------------------------------------------------------------------------------------------------
+        W.n_fronts = (uint32_t)fl.size();
+        W.n_levels = nlev;
+        W.o_var_glob = B.put(var_glob);
+        W.o_cons = B.put(dcons);
+        // the staged tables, one block
+        {
+            std::vector<unsigned char> tab;
+            Blob T{tab};
+            T.put(descs);
+            W.t_level_ptr = T.put(level_ptr);
+            W.t_children = T.put(children);
+            W.t_rows = T.put(rows);
+            W.t_exports = T.put(exports);
+            W.t_maps = T.put(maps);
+            tab.resize((tab.size() + 15) & ~size_t(15), 0);
+            W.o_tables = B.put(tab);
+            W.tab_bytes = (uint32_t)tab.size();
+        }
+        W.o_asm = B.put(asm_words);
+        W.o_ghosts = B.put(ghosts);
+        out.n_fronts += W.n_fronts;
+        out.n_levels = std::max(out.n_levels, nlev);
+        out.ws_doubles_max = std::max(out.ws_doubles_max, W.ws_doubles);
+        out.tab_bytes_max = std::max(out.tab_bytes_max, W.tab_bytes);
+        if (debug)
+            std::fprintf(stderr, "front plan: wg %u: %u fronts in %u levels, %u own + %u ghost variables, %u constraints, workspace %u doubles, tables %u B, stream %zu words\n",
+                         g, W.n_fronts, nlev, W.n_own, W.n_ghost, W.n_cons, W.ws_doubles, W.tab_bytes, asm_words.size());
+    }
+    out.bad_chunk0 = bad_chunk0;
+    out.verdict_chunk = verdict_chunk;
+    std::memcpy(out.blob.data(), wgs.data(), (size_t)G * sizeof(FrontWg));
+    out.threads = opt.threads;
+    const double model = model_top + model_sub;
+    out.model_cycles = model;
+    // dynamic LDS: [tables][workspace][reduction scratch: 2 x 4 x 16 doubles][tri table 2080 x u16][small ints]
+    out.lds_bytes = ((size_t)out.tab_bytes_max + 15) / 16 * 16 + (size_t)out.ws_doubles_max * 8 + 2 * 4 * 16 * 8 + 2080 * 2 + 64;
+    if (out.lds_bytes > opt.lds_bytes) return fail(why, "a workgroup's share does not fit the LDS");
+    if (debug)
+        std::fprintf(stderr, "front plan: %u variables, %u fronts (largest %u x %u), %u levels, %u workgroups, LDS %zu B, model %.0f cycles, chunks %u\n",
+                     n, out.n_fronts, out.max_rows, out.max_pivots, out.n_levels, G, out.lds_bytes, model, out.n_chunks);
+    return true;
+}
+
+}  // namespace ezpz
+
+extern "C" long ezpz_debug_front_plan(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t wgs, uint32_t max_wgs,
+                                      uint64_t lds_bytes, unsigned char* buf, size_t cap, uint64_t* info) {
+    if (!cs && n_cs) return EZPZ_ERR_INVALID_ARGUMENT;
+    ezpz::FrontOptions opt;
+    opt.wgs = wgs;
+    if (max_wgs) opt.max_wgs = max_wgs;
+    if (lds_bytes) opt.lds_bytes = (size_t)lds_bytes;
+    ezpz::FrontPlan plan;
+    const char* why = nullptr;
+    if (!ezpz::front_plan_build(cs, n_cs, n_vars, opt, plan, &why)) {
+        if (std::getenv("EZPZ_FRONT_DEBUG")) std::fprintf(stderr, "front plan: not applicable: %s\n", why ? why : "?");
+        return 0;
+    }
+    if (info) {
+        const uint64_t v[16] = {plan.n_wgs, plan.n_chunks, plan.bad_chunk0, plan.verdict_chunk, plan.lds_bytes, plan.n_fronts,
+                                plan.n_levels, plan.max_rows, plan.max_pivots, plan.threads, (uint64_t)plan.model_cycles,
+                                plan.panel_doubles, plan.update_doubles, 0, 0, 0};
+        std::memcpy(info, v, sizeof(v));
+    }
+    if (buf && cap) std::memcpy(buf, plan.blob.data(), std::min(cap, plan.blob.size()));
+    return (long)plan.blob.size();
+}

@@ -44,8 +44,12 @@ int launch_sub(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t 
                          : launch_variant<TEAM, MODE_SUB, true, false>(s, args, grid, stream);
 }
 
+}  // namespace
+namespace ezpz {
 std::mutex g_grid_mu;
-hipEvent_t g_grid_event[16] = {};  // per device: completion of the last grid-team launch of this process
+hipEvent_t g_grid_event[16] = {};  // per device: completion of the last grid-team launch of this process (front.hip's too)
+}  // namespace ezpz
+namespace {
 
 // Grid team: G workgroups per system, all of a launch's workgroups resident at once, as many systems in flight as
 // the device holds.
@@ -281,6 +285,8 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             }
         }
     }
+    // one connected sketch as a tree of dense fronts (fronts.cpp): whenever the system has the plan
+    if (s.fronts && !args.resume && !args.sys_list) return front_launch(s, args, stream);
     if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
     if (s.lane && s.wave_jit && args.batch <= (uint64_t)s.lim.cus) {
         // one solve (or a few) of a small system built for latency: one wavefront per system, sweeps and assembly across its

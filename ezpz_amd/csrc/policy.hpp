@@ -56,6 +56,11 @@ inline EzpzLaunchPolicy launch_policy_for(int compute_units) {
     p.h2h_pieces_per_call = 16;
     p.one_call_host_mask_max_constraints = 256;  // ezpz_solve: unsatisfied mask / warning log straight to mapped host memory up to here
     p.one_call_host_log_max_entries = 8192;
+    // the frontal shape (fronts.cpp): one solve of a connected sketch from 48 variables; batches not yet (0)
+    p.front_min_vars_one_solve = 48;
+    p.front_min_vars_batch = 0;
+    p.front_vars_per_workgroup = 160;
+    p.front_max_workgroups = 32;
     return p;
 }
 

@@ -157,6 +157,8 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             return EZPZ_OK;
         }
     }
+    const bool force_fronts = team_size == EZPZ_TEAM_FRONTS;  // the frontal shape whatever the size; the latency shape behind it
+    if (force_fronts) team_size = EZPZ_TEAM_AUTO_LATENCY;
     const uint32_t width = (uint32_t)std::max<size_t>(1, std::max(n_cs, n_vars));
     auto fail = [&]() {
         if (err_constraint) *err_constraint = be.constraint;
@@ -652,6 +654,53 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
     if (auto_shape && lanes_enabled && !s.comp && !s.lane && s.grid_wgs == 1 && P.c.n_parts == 1 && n_vars > 20) {
         std::unique_ptr<BatchPlan> bp(new BatchPlan());
         if (batch_plan_build(cs, n_cs, n_vars, *bp)) s.lanes = std::move(bp);
+    }
+    // ---- the frontal shape: one connected sketch as a tree of dense fronts (fronts.cpp), one solve from front_min_vars_one_solve
+    //      variables on as many workgroups as its size asks for; the shapes above stay behind it (stragglers of the lanes, systems
+    //      whose fronts would exceed a wavefront's rows).  EZPZ_FRONTS=0: never; =2: batches like one solve (A/B runs);
+    //      EZPZ_FRONT_WGS: workgroups per system.
+    s.fronts.reset();
+    {
+        const char* fe = std::getenv("EZPZ_FRONTS");
+        const int fronts_env = fe ? std::atoi(fe) : 1;
+        const EzpzLaunchPolicy& pol = s.lim.policy;
+        uint32_t min_vars = for_latency ? pol.front_min_vars_one_solve : (fronts_env >= 2 ? pol.front_min_vars_one_solve : pol.front_min_vars_batch);
+        if (fronts_env == 0) min_vars = 0;
+        const bool connected = s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents;
+        const bool want = force_fronts || (auto_shape && min_vars && n_vars >= min_vars && connected && !s.comp && !s.lane && !keep_comp);
+        if (want && n_cs > 0) {
+            FrontOptions fo;
+            fo.wgs = (for_latency || force_fronts) ? 0u : 1u;
+            if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
+            fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
+            fo.vars_per_wg = pol.front_vars_per_workgroup;
+            if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
+            fo.lds_bytes = s.lim.lds_bytes;
+            std::unique_ptr<FrontPlan> plan(new FrontPlan());
+            const char* why = nullptr;
+            bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
+            // (a share that does not fit one CU's LDS: more workgroups, while there are any)
+            while (!ok && (for_latency || force_fronts) && fo.wgs != 1 && why && std::strstr(why, "LDS")) {
+                fo.vars_per_wg = fo.vars_per_wg * 3 / 4;
+                if (fo.vars_per_wg < 32) break;
+                fo.wgs = 0;
+                ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
+            }
+            if (ok) {
+                info.team_mode = 5;
+                info.team_size = plan->threads;
+                info.grid_workgroups = plan->n_wgs;
+                info.n_partitions = plan->n_fronts;
+                info.n_levels = plan->n_levels;
+                info.workspace_bytes = (uint64_t)plan->ws_doubles_max * 8;
+                info.workspace_in_lds = 1;
+                info.program_in_lds = 0;
+                info.program_bytes += plan->blob.size();
+                s.fronts = std::move(plan);
+            } else if (std::getenv("EZPZ_FRONT_DEBUG")) {
+                std::fprintf(stderr, "front plan: not taken: %s\n", why ? why : "?");
+            }
+        }
     }
     return EZPZ_OK;
 }

@@ -28,6 +28,7 @@
 #include "../../include/ezpz_amd.h"
 #include "call_trace.hpp"
 #include "comp_program.hpp"
+#include "fronts.hpp"
 #include "kinds.hpp"
 #include "launch_types.hpp"
 #include "one_call.hpp"
@@ -168,6 +169,12 @@ struct EzpzSystem {
                                       // kernel, list walk with the workspace in global memory): the next one, on any stream, waits for it
     uint64_t lanes_min = ~0ull;  // systems per call from which `lanes` serves the call
     std::atomic<uint32_t> launches{0};  // a topology solved again and again (an interactive sketch) earns its specialised kernel
+    // frontal launch shape (fronts.hpp, front_kernel.hip.hpp): the plan, its device copy, the scratch of systems that several
+    // workgroups share, and how many of the kernel's workgroups the device holds at once
+    std::unique_ptr<FrontPlan> fronts;
+    void* dev_fronts = nullptr;
+    DevBuf<unsigned char> front_scratch;
+    uint64_t front_capacity = 0;
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
     DevBuf<GridScratch> grid_scratch;
@@ -235,6 +242,7 @@ struct EzpzSystem {
         if (dev_grid_blob) (void)hipFree(dev_grid_blob);
         if (dev_comp) (void)hipFree(dev_comp);
         if (dev_lanes) (void)hipFree(dev_lanes);
+        if (dev_fronts) (void)hipFree(dev_fronts);
         if (lanes_done) (void)hipEventDestroy(lanes_done);
         comp_jit_destroy(jit);
         comp_jit_destroy(wave_jit);
@@ -308,6 +316,8 @@ extern unsigned long long* g_stamps;  // diagnostic builds only (tools/stamps.py
 int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch, const EzpzConfig* cfg, double* x_out_dev,
                             EzpzStatus* status_dev, uint8_t* unsat_mask_dev, uint64_t* warn_log_dev, uint32_t warn_cap, void* stream,
                             const DoneWord& done, bool* resident = nullptr);
+
+int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream);  // front.hip: the frontal shape (EzpzSystem::fronts)
 
 void launch_eval(EzpzSystem* sys, const double* x_int_dev, size_t batch, double* r_out_dev, double* jv_out_dev, uint32_t* deg_out_dev,
                  uint32_t grid, hipStream_t stream);  // the evaluation-only kernel (values in internal numbering)

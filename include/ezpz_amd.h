@@ -162,7 +162,9 @@ typedef struct EzpzSystemInfo {
     uint32_t team_mode;     /* 0 sub-wavefront teams, 1 wavefront-partitioned workgroup, 2 barrier workgroup,
                              * 3 component-resident (one lane per connected component; n_partitions = chunks of <= 64
                              * components of one isomorphism class), 4 barrier workgroup whose linear solve is a record
-                             * walk (one connected sketch, or a system of up to 127 components: the automatic shapes) */
+                             * walk (one connected sketch, or a system of up to 127 components: the automatic shapes),
+                             * 5 frontal: a tree of dense fronts, one wavefront per front (grid_workgroups = workgroups that
+                             * share one system, n_partitions = fronts, n_levels = levels of the tree per workgroup) */
     uint32_t n_partitions;  /* partitions (balanced unions of components), one per wavefront in mode 1 */
     uint32_t program_in_lds;
     uint32_t grid_workgroups; /* workgroups that share one system (grid team: one large system on many CUs), else 1 */
@@ -201,6 +203,10 @@ const char* ezpz_error_string(int err);
  * constraints of the non-linear kinds: `square` 47 -> 40 us of kernel, `two rectangles dependent` 63 -> 53; a 4-variable
  * linear system loses 12 -> 16) (A/B runs and tests) */
 #define EZPZ_TEAM_LATENCY_WAVE 0xFFFFFFFBu
+/* the FRONTAL shape (team_mode 5: multifrontal supernodal Cholesky on dense fronts, csrc/fronts.cpp) whatever the size of the
+ * system, with the automatic latency shape behind it where the shape does not apply (a front of more than 63 rows ...);
+ * EZPZ_TEAM_AUTO_LATENCY takes it from a size on its own (EzpzLaunchPolicy.front_min_vars_one_solve) */
+#define EZPZ_TEAM_FRONTS 0xFFFFFFFAu
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);
 void ezpz_system_destroy(EzpzSystem* sys);
@@ -404,6 +410,9 @@ typedef struct EzpzLaunchPolicy {
     uint64_t zero_copy_max_bytes, h2h_piece_min_bytes, h2h_piece_max_bytes;
     uint32_t h2h_pieces_per_call;
     uint32_t one_call_host_mask_max_constraints, one_call_host_log_max_entries;
+    /* the frontal shape (team_mode 5): one solve of a connected sketch takes it from this many variables, batches from that
+     * many (0 = never); one workgroup per system up to front_vars_per_workgroup x 2 variables, then one more per that many */
+    uint32_t front_min_vars_one_solve, front_min_vars_batch, front_vars_per_workgroup, front_max_workgroups;
 } EzpzLaunchPolicy;
 int ezpz_launch_policy(int compute_units, EzpzLaunchPolicy* out);
 
@@ -412,6 +421,15 @@ int ezpz_launch_policy(int compute_units, EzpzLaunchPolicy* out);
  * words; buf == NULL turns it off.  Returns the number of words written since the previous call
  * (tools/solve_call_breakdown.py -> profiles/r04_solve_call_breakdown.txt). */
 size_t ezpz_debug_call_trace(uint64_t* buf, size_t cap);
+
+/* Diagnostic (host only, no device needed): the symbolic phase of the FRONTAL launch shape (team_mode 5, csrc/fronts.cpp:
+ * the supernodal counterpart of faer's SymbolicLlt, solver.rs:289-300) for `wgs` workgroups per system (0 = automatic) on
+ * workgroups of `lds_bytes` of LDS.  Copies the plan's device blob into buf (up to cap bytes) and fills info[0..15] =
+ * workgroups, scratch chunks, first pivot-flag chunk, verdict chunk, LDS bytes, fronts, levels, largest front's rows /
+ * pivots, lanes per workgroup, modelled cycles, panel doubles, update doubles, 0...; returns the blob's size, 0 when the
+ * shape does not apply to the system, or a negative EZPZ_ERR_*.  tests/front_ref.py executes the blob in numpy. */
+long ezpz_debug_front_plan(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t wgs, uint32_t max_wgs,
+                           uint64_t lds_bytes, unsigned char* buf, size_t cap, uint64_t* info);
 
 /* ---- textual front end, ezpz/src/textual.rs:43-49 (Problem: FromStr) + executor.rs:40-445 ------------ */
 typedef struct EzpzProblem EzpzProblem; /* opaque: parsed + lowered problem text */
