@@ -68,11 +68,30 @@ struct Ctx {
     const uint32_t* exports;
     const uint8_t* maps;
     const uint16_t* tri;         // entry -> (a | b << 8) of a packed lower triangle
-    const uint32_t* stream;      // assembly streams (global)
+    const uint32_t* stream;      // assembly streams (staged tables, LDS)
     gridchunk_t* chunks;         // the system's scratch chunks (null on one workgroup)
     int* dead;
-    uint32_t l_jv, l_d;
+    uint32_t l_jv, l_d, l_upool;
+#ifdef EZPZ_STAMPS
+    unsigned long long* stamps;  // diagnostic builds: (id, cycle) pairs of workgroup 0, thread 0
+    int* stamp_n;
+#endif
 };
+
+#ifdef EZPZ_STAMPS
+#define FRONT_CX_STAMP(cx, id)                                                               \
+    do {                                                                                     \
+        if ((cx).stamps && blockIdx.x == 0 && threadIdx.x == 0 && *(cx).stamp_n < 2000) {     \
+            (cx).stamps[2 * *(cx).stamp_n] = (id);                                           \
+            (cx).stamps[2 * *(cx).stamp_n + 1] = __builtin_readcyclecounter();               \
+            ++*(cx).stamp_n;                                                                 \
+        }                                                                                    \
+    } while (0)
+#else
+#define FRONT_CX_STAMP(cx, id) \
+    do {                       \
+    } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t tri_index(uint32_t a, uint32_t b) { return a * (a + 1) / 2 + b; }
 
@@ -106,118 +125,223 @@ __device__ __forceinline__ bool front_pivots(double* P, uint32_t K, uint32_t S, 
     return bad;
 }
 
-__device__ __forceinline__ bool front_factor(const Ctx& cx, uint32_t k, int lane, double lambda, uint32_t l_r, unsigned int epoch) {
-    const FrontDesc& d = cx.descs[k];
-    const uint32_t K = uni(d.K), S = uni(d.S), S1 = S + 1, R = S - K, nU = (R + 1) * (R + 2) / 2;
-    const uint32_t flags = uni(d.flags);
-    // (every address an index from the workspace's base: a select between two LDS pointers would make them generic pointers)
+// A front's descriptor from the staged tables: three 16-byte LDS reads, then every field in a scalar register.
+struct DescRegs {
+    uint32_t K, S, n_child, flags, panel, upd, rows, child0, src_off, src_n, src_v, up_chunk, exp0;
+};
+__device__ __forceinline__ DescRegs load_desc(const FrontDesc* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+    DescRegs d;
+    d.K = uni(q0.x) & 0xFFFFu;
+    d.S = uni(q0.x) >> 16;
+    d.n_child = uni(q0.y) & 0xFFFFu;
+    d.flags = uni(q0.y) >> 16;
+    d.panel = uni(q0.z);
+    d.upd = uni(q0.w);
+    d.rows = uni(q1.x);
+    d.child0 = uni(q1.y);
+    d.src_off = uni(q1.z);
+    d.src_n = uni(q1.w) & 0xFFFFu;
+    d.src_v = uni(q2.x);
+    d.up_chunk = uni(q2.y);
+    d.exp0 = uni(q2.z);
+    return d;
+}
+
+// Schur complement of the rows below the pivots: U[e] -= sum_k L[a][k] L[b][k], every operand of an entry in flight at once.
+template <int KMAX>
+__device__ __forceinline__ void front_schur(const Ctx& cx, const DescRegs& d, int lane, unsigned int epoch) {
+    const uint32_t K = d.K, S1 = d.S + 1, R = d.S - K, nU = (R + 1) * (R + 2) / 2;
     double* const ws = cx.ws;
-    const uint32_t o_p = uni(d.panel), o_u = uni(d.upd), o_j = cx.l_jv;
-    double* const P = ws + o_p;
-    double* const U = ws + o_u;
-    for (uint32_t i = lane; i < S1 * K; i += 64) P[i] = 0.0;
-    if (R)
-        for (uint32_t i = lane; i < nU; i += 64) U[i] = 0.0;
-    wave_sync();
-    // ---- this front's own entries of JtJ + lambda I and of -Jt r ----------------------------------------------------------------------
+    const uint32_t o_pk = d.panel + K, o_u = d.upd;
+    const bool remote_parent = (d.flags & FRONT_REMOTE_PARENT) != 0;
+    for (uint32_t e = lane; e + 1 < nU; e += 64) {  // (the last entry pairs the right-hand side's row with itself: not needed)
+        const uint32_t ab = cx.tri[e];
+        const uint32_t ia = o_pk + (ab & 0xFFu), ib = o_pk + (ab >> 8);
+        double va[KMAX], vb[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const bool in = (uint32_t)k < K;
+            va[k] = in ? ws[ia + k * S1] : 0.0;
+            vb[k] = in ? ws[ib + k * S1] : 0.0;
+        }
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < KMAX; k += 2) {
+            acc0 = __builtin_fma(va[k], vb[k], acc0);
+            if (k + 1 < KMAX) acc1 = __builtin_fma(va[k + 1], vb[k + 1], acc1);
+        }
+        const double v = ws[o_u + e] - (acc0 + acc1);
+        if (remote_parent)
+            grid_store(cx.chunks + d.up_chunk + e, v, epoch);
+        else
+            ws[o_u + e] = v;
+    }
+}
+
+// One trip of the workgroup's assembly stream with W operand words per entry: every load in flight at once.
+template <int W>
+__device__ __forceinline__ void asm_trip(double* ws, const uint32_t* st, int lane, uint32_t hdr, uint32_t o_j, uint32_t l_r, uint32_t o_pan,
+                                         double lambda) {
+    uint32_t op[W > 0 ? W : 1];
+#pragma unroll
+    for (int q = 0; q < W; ++q) op[q] = st[64 * (1 + q) + lane];
+    const bool rhs = (hdr & FASM_RHS) != 0;
+    const uint32_t o_b = rhs ? l_r : o_j;
+    double va[W > 0 ? W : 1], vb[W > 0 ? W : 1];
+#pragma unroll
+    for (int q = 0; q < W; ++q) va[q] = ws[o_j + (op[q] & 0xFFFFu)], vb[q] = ws[o_b + (op[q] >> 16)];
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < W; q += 2) {
+        acc0 = __builtin_fma(va[q], vb[q], acc0);
+        if (q + 1 < W) acc1 = __builtin_fma(va[q + 1], vb[q + 1], acc1);
+    }
+    double acc = acc0 + acc1;
+    if (rhs) acc = -acc;
+    if (hdr & FASM_DIAG) acc += lambda;
+    if (!(hdr & FASM_NOP)) ws[o_pan + (hdr & 0xFFFFu)] = acc;
+}
+// The assembly of a linear solve (newton.rs:73-84: JtJ + lambda I and -Jt r), all wavefronts of the workgroup: panels and
+// update matrices zeroed, then every element the workgroup's constraints contribute to, one lane per element.
+__device__ __forceinline__ void assemble(const Ctx& cx, const FrontWg& W, double lambda, uint32_t l_r) {
+    double* const ws = cx.ws;
     {
-        const uint32_t* st = cx.stream + uni(d.asm_off);
-        const uint32_t n_e = uni(d.asm_n);
-        const uint32_t w4 = uni(*reinterpret_cast<const uint32_t*>(d.asm_w));
-        for (uint32_t e0 = 0, tr = 0; e0 < n_e; e0 += 64, ++tr) {
-            const uint32_t w = (w4 >> (8 * (tr < 3 ? tr : 3))) & 0xFFu;
-            const uint32_t hdr = st[lane];
+        double2* const Z = reinterpret_cast<double2*>(ws + W.l_panels);
+        const uint32_t n2 = (W.ws_doubles - W.l_panels) / 2;
+        const double2 z = {0.0, 0.0};
+        for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) Z[i] = z;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t nwaves = blockDim.x >> 6, o_j = cx.l_jv, o_pan = W.l_panels;
+    const uint32_t* const offs = cx.stream + W.asm_word0;
+    for (uint32_t t = uni(threadIdx.x >> 6); t < W.asm_trips; t += nwaves) {
+        const uint32_t* st = cx.stream + uni(offs[t]);
+        const uint32_t hdr = st[lane];
+        const uint32_t w = uni(hdr >> 24);
+        switch (w) {
+        case 0: asm_trip<0>(ws, st, lane, hdr, o_j, l_r, o_pan, lambda); break;
+        case 1: asm_trip<1>(ws, st, lane, hdr, o_j, l_r, o_pan, lambda); break;
+        case 2: asm_trip<2>(ws, st, lane, hdr, o_j, l_r, o_pan, lambda); break;
+        case 3: asm_trip<3>(ws, st, lane, hdr, o_j, l_r, o_pan, lambda); break;
+        case 4: asm_trip<4>(ws, st, lane, hdr, o_j, l_r, o_pan, lambda); break;
+        case 5: asm_trip<5>(ws, st, lane, hdr, o_j, l_r, o_pan, lambda); break;
+        case 6: asm_trip<6>(ws, st, lane, hdr, o_j, l_r, o_pan, lambda); break;
+        default: {
             const bool rhs = (hdr & FASM_RHS) != 0;
             const uint32_t o_b = rhs ? l_r : o_j;
-            double acc0 = 0.0, acc1 = 0.0;
-            uint32_t q = 0;
-            for (; q + 4 <= w; q += 4) {
-                uint32_t op[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) op[i] = st[64 * (1 + q + i) + lane];
-                double va[4], vb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) va[i] = ws[o_j + (op[i] & 0xFFFFu)], vb[i] = ws[o_b + (op[i] >> 16)];
-                acc0 = __builtin_fma(va[0], vb[0], acc0);
-                acc1 = __builtin_fma(va[1], vb[1], acc1);
-                acc0 = __builtin_fma(va[2], vb[2], acc0);
-                acc1 = __builtin_fma(va[3], vb[3], acc1);
-            }
-            for (; q < w; ++q) {
+            double acc = 0.0;
+            for (uint32_t q = 0; q < w; ++q) {
                 const uint32_t op = st[64 * (1 + q) + lane];
-                acc0 = __builtin_fma(ws[o_j + (op & 0xFFFFu)], ws[o_b + (op >> 16)], acc0);
+                acc = __builtin_fma(ws[o_j + (op & 0xFFFFu)], ws[o_b + (op >> 16)], acc);
             }
-            double acc = acc0 + acc1;
             if (rhs) acc = -acc;
             if (hdr & FASM_DIAG) acc += lambda;
-            if (!(hdr & FASM_NOP)) ws[((hdr & FASM_UPD) ? o_u : o_p) + (hdr & 0xFFFFu)] = acc;
-            st += 64 * (1 + w);
+            if (!(hdr & FASM_NOP)) ws[o_pan + (hdr & 0xFFFFu)] = acc;
+        }
+        }
+    }
+    __syncthreads();
+}
+
+// One trip of a front's source stream with V source words (2 V sources) per entry.
+template <int V>
+__device__ __forceinline__ void src_trip(double* ws, const uint32_t* st, int lane, uint32_t hdr, uint32_t o_pan) {
+    uint32_t x[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) x[q] = st[64 * (1 + q) + lane];
+    const uint32_t dst = o_pan + (hdr & 0xFFFFu);
+    double v0[V], v1[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) v0[q] = ws[o_pan + (x[q] & 0xFFFFu)], v1[q] = ws[o_pan + (x[q] >> 16)];
+    double acc = ws[dst];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc += v0[q] + v1[q];
+    if (!(hdr & FASM_NOP)) ws[dst] = acc;
+}
+
+__device__ __forceinline__ bool front_factor(const Ctx& cx, uint32_t k, int lane, uint32_t o_pan, unsigned int epoch) {
+    const DescRegs d = load_desc(cx.descs + k);
+    const uint32_t K = d.K, S = d.S, S1 = S + 1, R = S - K;
+    // (every address an index from the workspace's base: a select between two LDS pointers would make them generic pointers)
+    double* const ws = cx.ws;
+    const uint32_t o_p = d.panel, o_u = d.upd;
+    FRONT_CX_STAMP(cx, 100);
+    // ---- extend-add: the elements of this workgroup's own children's update matrices, gathered by destination -----------------------
+    {
+        const uint32_t* st = cx.stream + d.src_off;
+        for (uint32_t e0 = 0, tr = 0; e0 < d.src_n; e0 += 64, ++tr) {
+            const uint32_t v = (d.src_v >> (8 * (tr < 3 ? tr : 3))) & 0xFFu;
+            const uint32_t hdr = st[lane];
+            switch (v) {
+            case 1: src_trip<1>(ws, st, lane, hdr, o_pan); break;
+            case 2: src_trip<2>(ws, st, lane, hdr, o_pan); break;
+            case 3: src_trip<3>(ws, st, lane, hdr, o_pan); break;
+            case 4: src_trip<4>(ws, st, lane, hdr, o_pan); break;
+            default: {
+                const uint32_t dst = o_pan + (hdr & 0xFFFFu);
+                double acc = ws[dst];
+                for (uint32_t q = 0; q < v; ++q) {
+                    const uint32_t x = st[64 * (1 + q) + lane];
+                    acc += ws[o_pan + (x & 0xFFFFu)] + ws[o_pan + (x >> 16)];
+                }
+                if (!(hdr & FASM_NOP)) ws[dst] = acc;
+            }
+            }
+            st += 64 * (1 + v);
         }
     }
     wave_sync();
-    // ---- extend-add: the children's update matrices, one child after the other ------------------------------------------------------------
-    const uint32_t n_child = uni(d.n_child), child0 = uni(d.child0);
-    for (uint32_t c = 0; c < n_child; ++c) {
-        const FrontChild& ch = cx.children[child0 + c];
-        const uint32_t rc1 = uni(ch.rows), n_c = rc1 * (rc1 + 1) / 2, upd = uni(ch.upd);
-        const bool remote = (uni(ch.flags) & FRONT_CHILD_REMOTE) != 0;
-        const uint8_t* const map = cx.maps + uni(ch.map);
+    FRONT_CX_STAMP(cx, 101);
+    // ---- children in other workgroups: their update matrices arrive as chunks, one child after the other -------------------------------
+    for (uint32_t c = 0; c < d.n_child; ++c) {
+        const uint4 q = *reinterpret_cast<const uint4*>(cx.children + d.child0 + c);
+        // (without the last entry: the right-hand side's row against itself is nobody's)
+        const uint32_t upd = uni(q.x), rc1 = uni(q.y) & 0xFFFFu, n_c = rc1 * (rc1 + 1) / 2 - 1;
+        const uint8_t* const map = cx.maps + uni(q.z);
         for (uint32_t e = lane; e < n_c; e += 64) {
             const uint32_t ab = cx.tri[e];
             const uint32_t i = map[ab & 0xFFu], j = map[ab >> 8];
-            const double val = remote ? grid_wait(cx.chunks + upd + e, epoch, cx.dead) : ws[upd + e];
+            const double val = grid_wait(cx.chunks + upd + e, epoch, cx.dead);
             const uint32_t dst = j < K ? o_p + j * S1 + i : o_u + tri_index(i - K, j - K);
             ws[dst] += val;
         }
         wave_sync();
     }
+    FRONT_CX_STAMP(cx, 102);
     // ---- the K pivot columns in registers ---------------------------------------------------------------------------------------------
     bool bad;
     if (K <= 4)
-        bad = front_pivots<4>(P, K, S, lane);
+        bad = front_pivots<4>(ws + o_p, K, S, lane);
     else if (K <= 8)
-        bad = front_pivots<8>(P, K, S, lane);
+        bad = front_pivots<8>(ws + o_p, K, S, lane);
     else
-        bad = front_pivots<16>(P, K, S, lane);
+        bad = front_pivots<16>(ws + o_p, K, S, lane);
     wave_sync();
+    FRONT_CX_STAMP(cx, 103);
     // ---- Schur complement of the rows below (row R = right-hand side) -------------------------------------------------------------------
     if (R) {
-        const bool remote_parent = (flags & FRONT_REMOTE_PARENT) != 0;
-        const uint32_t up_chunk = uni(d.up_chunk);
-        for (uint32_t e = lane; e < nU; e += 64) {
-            const uint32_t ab = cx.tri[e];
-            const double* pa = P + K + (ab & 0xFFu);
-            const double* pb = P + K + (ab >> 8);
-            double acc0 = 0.0, acc1 = 0.0;
-            uint32_t kk = 0;
-            for (; kk + 4 <= K; kk += 4) {
-                double va[4], vb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) va[i] = pa[(kk + i) * S1], vb[i] = pb[(kk + i) * S1];
-                acc0 = __builtin_fma(va[0], vb[0], acc0);
-                acc1 = __builtin_fma(va[1], vb[1], acc1);
-                acc0 = __builtin_fma(va[2], vb[2], acc0);
-                acc1 = __builtin_fma(va[3], vb[3], acc1);
-            }
-            for (; kk < K; ++kk) acc0 = __builtin_fma(pa[kk * S1], pb[kk * S1], acc0);
-            const double v = U[e] - (acc0 + acc1);
-            if (remote_parent)
-                grid_store(cx.chunks + up_chunk + e, v, epoch);
-            else
-                U[e] = v;
-        }
+        if (K <= 4)
+            front_schur<4>(cx, d, lane, epoch);
+        else if (K <= 8)
+            front_schur<8>(cx, d, lane, epoch);
+        else
+            front_schur<16>(cx, d, lane, epoch);
     }
+    FRONT_CX_STAMP(cx, 104);
     return bad;
 }
 
 // Backward substitution of front k: its K unknowns from y (row S of the panel), the steps of the rows below and the panel.
 template <int KMAX>
-__device__ __forceinline__ double front_bwd_body(const Ctx& cx, const FrontDesc& d, uint32_t K, uint32_t S, int lane, unsigned int epoch,
+__device__ __forceinline__ double front_bwd_body(const Ctx& cx, const DescRegs& d, uint32_t K, uint32_t S, int lane, unsigned int epoch,
                                                  double dmax) {
     const uint32_t S1 = S + 1;
-    const double* const P = cx.ws + uni(d.panel);
+    const double* const P = cx.ws + d.panel;
     double* const dv = cx.ws + cx.l_d;
-    const uint16_t* const frow = cx.rows + uni(d.rows);
+    const uint16_t* const frow = cx.rows + d.rows;
     const uint32_t r = (uint32_t)lane;
     const double xr = (r >= K && r < S) ? dv[frow[r]] : 0.0;
     const uint32_t kc = r < K ? r : K - 1;  // this lane's column
@@ -240,16 +364,16 @@ __device__ __forceinline__ double front_bwd_body(const Ctx& cx, const FrontDesc&
     if (r < K) {
         dv[frow[r]] = xown;
         dmax = fmax_abs(dmax, xown);
-        if (uni(d.flags) & FRONT_EXPORTS) {
-            const uint32_t ch = cx.exports[uni(d.exp0) + r];
+        if (d.flags & FRONT_EXPORTS) {
+            const uint32_t ch = cx.exports[d.exp0 + r];
             if (ch != 0xFFFFFFFFu) grid_store(cx.chunks + ch, xown, epoch);
         }
     }
     return dmax;
 }
 __device__ __forceinline__ double front_bwd(const Ctx& cx, uint32_t k, int lane, unsigned int epoch, double dmax) {
-    const FrontDesc& d = cx.descs[k];
-    const uint32_t K = uni(d.K), S = uni(d.S);
+    const DescRegs d = load_desc(cx.descs + k);
+    const uint32_t K = d.K, S = d.S;
     if (K <= 4) return front_bwd_body<4>(cx, d, K, S, lane, epoch, dmax);
     if (K <= 8) return front_bwd_body<8>(cx, d, K, S, lane, epoch, dmax);
     return front_bwd_body<16>(cx, d, K, S, lane, epoch, dmax);
@@ -336,8 +460,10 @@ struct Red {
     } while (0)
 #endif
 
-template <bool LIN>
-__global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) {
+// THREADS: 512 (two wavefronts per SIMD: up to 256 registers per lane) or 1024 (four: 128 -- the non-linear evaluators then spill a
+// little in the sweeps, and twice as many fronts of a level run side by side)
+template <bool LIN, int THREADS>
+__global__ void __launch_bounds__(THREADS, 1) front_solve_kernel(const FrontArgs a) {
     using namespace frontal;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -366,13 +492,14 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
     cx.exports = reinterpret_cast<const uint32_t*>(tab + W.t_exports);
     cx.maps = reinterpret_cast<const uint8_t*>(tab + W.t_maps);
     cx.tri = tri;
-    cx.stream = reinterpret_cast<const uint32_t*>(a.plan + W.o_asm);
+    cx.stream = reinterpret_cast<const uint32_t*>(tab + W.t_stream);
     unsigned char* const scratch = G > 1 ? a.scratch + (size_t)slot * a.scratch_stride : nullptr;
     FrontScratchHead* const head = reinterpret_cast<FrontScratchHead*>(scratch);
     cx.chunks = G > 1 ? reinterpret_cast<gridchunk_t*>(scratch + sizeof(FrontScratchHead) + 2 * kFrontScratchRedBytes) : nullptr;
     cx.dead = G > 1 ? &head->dead : nullptr;
     cx.l_jv = W.l_jv;
     cx.l_d = W.l_d;
+    cx.l_upool = W.l_upool;
     Red red;
     red.buf = redbuf;
     red.flip = 0;
@@ -398,12 +525,15 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
         ws[W.l_r + m] = 0.0;
         ws[W.l_rn + m] = 0.0;
         jvp[zj] = 0.0;
+        ws[W.l_panels] = 0.0;  // ... and of padding sources
     }
     const bool unit_w = a.unit_weights != 0;
     uint32_t sys_parity = 0;
     for (uint64_t sys = slot; sys < a.batch; sys += n_slots, sys_parity ^= 1u) {
 #ifdef EZPZ_STAMPS
         int stamp_n = 0;
+        cx.stamps = a.stamps;
+        cx.stamp_n = &stamp_n;
 #endif
         FRONT_STAMP(1);
         const double* const x0 = a.x0 + sys * a.n_vars;
@@ -436,10 +566,12 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 ++epoch;
                 if (tid == 0) ints[1] = 0;
                 __syncthreads();
+                assemble(cx, W, lambda, l_r);
+                FRONT_STAMP(10);
                 bool bad_here = false;
                 for (uint32_t lv = 0; lv < nlev; ++lv) {
                     const uint32_t k0 = uni(cx.level_ptr[lv]), k1 = uni(cx.level_ptr[lv + 1]);
-                    for (uint32_t k = k0 + uni(wave); k < k1; k += nwaves) bad_here |= front_factor(cx, k, lane, lambda, l_r, epoch);
+                    for (uint32_t k = k0 + uni(wave); k < k1; k += nwaves) bad_here |= front_factor(cx, k, lane, W.l_panels, epoch);
                     __syncthreads();
                     FRONT_STAMP(1000 + lv);
                 }
@@ -477,6 +609,7 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                     const uint32_t k0 = uni(cx.level_ptr[lv]), k1 = uni(cx.level_ptr[lv + 1]);
                     for (uint32_t k = k0 + uni(wave); k < k1; k += nwaves) dmax = front_bwd(cx, k, lane, epoch, dmax);
                     __syncthreads();
+                    FRONT_STAMP(2000 + lv);
                 }
                 FRONT_STAMP(12);
                 // ---- tentative step (newton.rs:111-114): own variables and ghosts alike (every workgroup moves its copy) -----------------

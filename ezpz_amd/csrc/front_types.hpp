@@ -24,16 +24,17 @@ constexpr uint32_t kFrontRedValues = 4;   // values per grid reduction
 // row R = right-hand side) at `upd`.  Offsets count doubles from the workgroup's workspace.
 struct alignas(16) FrontDesc {
     uint16_t K, S;
-    uint16_t n_child;
+    uint16_t n_child;      // children in OTHER workgroups (their update matrices arrive as chunks; this workgroup's own children
+                           // are sources of the front's source stream)
     uint16_t flags;        // FRONT_*
     uint32_t panel;        // workspace offset of the panel
     uint32_t upd;          // workspace offset of the update matrix (unused when R == 0)
     uint32_t rows;         // index into the rows table: S local variable indices (pivots first)
     uint32_t child0;       // index of the first FrontChild
-    uint32_t asm_off;      // word offset of the assembly stream (fronts.cpp: emit_assembly)
-    uint16_t asm_n;        // entries in the stream
+    uint32_t src_off;      // word offset of the front's source stream in the staged tables
+    uint16_t src_n;        // entries in it
     uint16_t pad0;
-    uint8_t asm_w[4];      // operand pairs per entry in trip 0, 1, 2 and >= 3 of 64 entries (4-byte aligned: read as one word)
+    uint8_t src_v[4];      // source words per entry in trip 0, 1, 2 and >= 3 of 64 entries (4-byte aligned: read as one word)
     uint32_t up_chunk;     // FRONT_REMOTE_PARENT: first chunk of the update matrix in the system's scratch
     uint32_t exp0;         // FRONT_EXPORTS: index into the export table: K entries (chunk of pivot k's step, or ~0)
     uint32_t pad1;
@@ -68,22 +69,30 @@ struct alignas(16) FrontWg {
     uint32_t o_var_glob;              // uint32[n_loc]: caller's variable id
     uint32_t o_cons;                  // DevCon[n_cons] (ids = local variables, row0 / jbase local)
     uint32_t o_tables;                // start of the tables staged into LDS once per workgroup: tab_bytes of
-    uint32_t tab_bytes;               //   FrontDesc[n_fronts] | level_ptr | FrontChild[] | rows | exports | maps
+    uint32_t tab_bytes;               //   FrontDesc[n_fronts] | level_ptr | FrontChild[] | rows | exports | maps | streams
     uint32_t t_level_ptr, t_children, t_rows, t_exports, t_maps;  // byte offsets inside the staged tables
-    uint32_t o_asm;                   // uint32 words: the fronts' assembly streams
+    uint32_t t_stream;                // ... of the streams (uint32 words): the fronts' source streams, then the assembly stream
+    uint32_t asm_word0, asm_trips;    // the assembly stream: its first word in the streams, its trips of 64 entries
     uint32_t o_ghosts;                // FrontGhost[n_ghost]
     uint32_t l_x, l_d, l_r, l_rn, l_jv, l_panels, l_upool;  // workspace carve-up (doubles)
     uint32_t ws_doubles;              // workspace doubles (state), tables excluded
     uint32_t n_remote_children;       // fronts of this workgroup that wait for chunks of other workgroups
-    uint32_t pad[4];
+    uint32_t pad[2];
 };
 static_assert(sizeof(FrontWg) % 16 == 0, "FrontWg layout");
 
-// Assembly stream of a front: per trip of 64 entries, 64 header words then w x 64 operand words (w = asm_w[trip]).
-// header: destination (doubles from the front's panel, or from its update matrix with FASM_UPD) | flags; operand word =
-// a | b << 16: Jacobian slots (entry of JtJ: += jv[a] * jv[b]), or with FASM_RHS slot a and residual row b (+= jv[a] * -r[b]).
-// Padding operands are (zj, zj) / (zj, n_rows): a Jacobian slot and a residual row that hold zero.
-constexpr uint32_t FASM_UPD = 1u << 16, FASM_DIAG = 1u << 17, FASM_RHS = 1u << 18, FASM_NOP = 1u << 19;
+// The ASSEMBLY stream of a workgroup (once per linear solve, all lanes, no order among entries): per trip of 64 entries, 64
+// header words, then w x 64 operand words, w = header >> 24 (the same in all 64 headers of a trip; trips are sorted by it).  An
+// entry is one element of one front -- of its panel or of its update matrix -- that the workgroup's constraints contribute to:
+// header = destination (doubles from l_panels) | flags | w << 24; operand word = a | b << 16: Jacobian slots (element of JtJ:
+// += jv[a] * jv[b]), or with FASM_RHS slot a and residual row b (element of -Jt r: -= jv[a] * r[b]); FASM_DIAG adds lambda.
+// Padding operands are (zj, zj) / (zj, n_rows): a Jacobian slot and a residual row that hold zero.  Elements no entry names stay
+// zero (the fill of merged supernodes, elements that only children contribute to): the panels and update matrices are zeroed first.
+// The SOURCE stream of a front (before its factorisation, by its wavefront): per trip of 64 entries, 64 header words (the
+// destination, doubles from l_panels), then v x 64 source words (v = src_v[trip]): s0 | s1 << 16, two elements of update matrices of
+// this workgroup's own children (doubles from l_panels) that the extend-add sends to the destination; padding sources are 0: the
+// first double at l_panels stays zero.
+constexpr uint32_t FASM_DIAG = 1u << 17, FASM_RHS = 1u << 18, FASM_NOP = 1u << 19;
 
 // The scratch of one system in flight on several workgroups (all values travel as self-validating 16-byte chunks, see
 // lm_kernel.hip.hpp: grid_store / grid_wait).  chunks[]: update matrices of fronts whose parent lives in another workgroup,

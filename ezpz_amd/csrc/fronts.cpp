@@ -21,15 +21,17 @@ namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 using UVec = std::vector<uint32_t>;
 
-// What the planner believes a front costs on one wavefront, in cycles: its fixed part (descriptor, zeroing, assembly stream,
-// stores), the K dependent pivot steps, the pivot block's updates, and the Schur complement / the children's extend-add by
-// trips of 64 entries.  Only ratios matter: it decides which supernodes are merged and how subtrees are dealt to workgroups.
-double front_cost(uint32_t K, uint32_t S) {
+// What a front costs its wavefront, in cycles, from the stamps of front_kernel.hip.hpp on an MI355X (tools/front_stamps.py, K = 2 ...
+// 16): the descriptor, the gather of the children's update matrices (a trip of 64 destinations ~ 300 cycles + ~500 of latency),
+// the K dependent pivot steps (~150 cycles each: broadcast, 1 / sqrt by two Newton steps, scale) with the pivot block's K^2 / 2
+// register updates (two v_readlane, a wait state, an fma each), and the Schur complement by trips of 64 entries (2 K operands
+// each).  It decides which supernodes are merged and how subtrees are dealt to workgroups; only ratios matter.
+double front_cost(uint32_t K, uint32_t S, bool children = true) {
     const uint32_t R = S - K, nU = (R + 1) * (R + 2) / 2;
     const double trips = (double)((nU + 63) / 64);
-    return 1100.0 + 110.0 * K + 6.0 * K * K + trips * (40.0 + 14.0 * K) + trips * 90.0;
+    return 180.0 + (children ? 800.0 : 0.0) + 700.0 + 40.0 * K + 17.0 * K * K + (R ? 500.0 + trips * (300.0 + 40.0 * K) : 0.0);
 }
-double front_bwd_cost(uint32_t K, uint32_t S) { return 350.0 + 30.0 * K + 8.0 * (S - K); }
+double front_bwd_cost(uint32_t K, uint32_t S) { return 900.0 + 60.0 * K + 15.0 * (S - K); }
 
 // Nested dissection of one connected component by breadth-first level structures: the separator is the level that best
 // balances the two sides by vertex count (thin levels preferred), sides are ordered first (recursively), the separator last;
@@ -137,8 +139,7 @@ bool fail(const char** why, const char* msg) {
 
 }  // namespace
 
-bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const FrontOptions& opt, FrontPlan& out,
-                      const char** why) {
+static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const FrontOptions& opt, FrontPlan& out, const char** why) {
     out = FrontPlan();
     if (n_cs == 0 || n_vars == 0 || n_cs > 0x3FFFFFFFu || n_vars > 0x3FFFFFFFu) return fail(why, "empty or oversized system");
     const uint32_t n = (uint32_t)n_vars, C = (uint32_t)n_cs;
@@ -307,7 +308,13 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
 
     // ---- supernodes: fundamental ones first, then a child is merged into the parent it immediately precedes while the merged
     //      front is cheaper than the two (front_cost: a front's fixed cost is most of a small front) ----------------------------
-    const uint32_t KMAX = kFrontMaxPivots, SMAX = kFrontMaxRows;
+    static const uint32_t kmax_env = [] {
+        const char* e = std::getenv("EZPZ_FRONT_KMAX");  // (A/B runs: the widest supernode)
+        // (measured, one solve of 800 / 2000 / 5000 variables with supernodes of at most 6 / 8 / 16 columns: 2.09 / 2.08 / 2.35 ms,
+        // 0.52 / 0.52 / 0.62 ms, 3.24 / 3.16 / 4.06 ms: the pivot block's register updates grow with K^2)
+        return e ? std::max(1u, std::min<uint32_t>(kFrontMaxPivots, (uint32_t)std::atoi(e))) : 8u;
+    }();
+    const uint32_t KMAX = kmax_env, SMAX = kFrontMaxRows;
     UVec nkids(n, 0);
     for (uint32_t j = 0; j < n; ++j)
         if (parent[j] != NONE) ++nkids[parent[j]];
@@ -643,12 +650,13 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
         W.l_rn = take(lrows + 1);
         W.l_jv = take(lslots + 1);  // (+ the zero slot)
         W.l_panels = off;
+        (void)take(2);  // (the first double of the region stays zero: the padding source of the source streams)
         std::vector<FrontDesc> descs(fl.size());
         std::vector<FrontChild> children;
         std::vector<uint16_t> rows;
         UVec exports;
         std::vector<uint8_t> maps;
-        UVec asm_words;
+        UVec stream_words;
         for (uint32_t k = 0; k < fl.size(); ++k) {
             const Front& t = fr[fl[k]];
             FrontDesc& d = descs[k];
@@ -659,59 +667,24 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             out.panel_doubles += (uint64_t)(t.S + 1) * t.K;
         }
         W.l_upool = off;
-        // update matrices: alive from their front's level to their parent's (first fit over the levels of this workgroup); fronts
-        // whose parent lives elsewhere keep theirs to the end of the factorisation (it is only scratch for the chunks)
-        {
-            struct Free {
-                uint32_t off, len;
-            };
-            std::vector<Free> free_list;
-            uint32_t pool_end = 0;
-            auto alloc = [&](uint32_t len) {
-                len = (len + 1) & ~1u;
-                for (size_t i = 0; i < free_list.size(); ++i)
-                    if (free_list[i].len >= len) {
-                        const uint32_t o = free_list[i].off;
-                        free_list[i].off += len;
-                        free_list[i].len -= len;
-                        if (!free_list[i].len) free_list.erase(free_list.begin() + (long)i);
-                        return o;
-                    }
-                const uint32_t o = pool_end;
-                pool_end += len;
-                return o;
-            };
-            auto release = [&](uint32_t o, uint32_t len) {
-                len = (len + 1) & ~1u;
-                free_list.push_back(Free{o, len});
-                std::sort(free_list.begin(), free_list.end(), [](const Free& a, const Free& b) { return a.off < b.off; });
-                for (size_t i = 0; i + 1 < free_list.size();)
-                    if (free_list[i].off + free_list[i].len == free_list[i + 1].off) {
-                        free_list[i].len += free_list[i + 1].len;
-                        free_list.erase(free_list.begin() + (long)i + 1);
-                    } else {
-                        ++i;
-                    }
-            };
-            std::vector<std::vector<std::pair<uint32_t, uint32_t>>> dies(nlev + 1);  // by level: (offset, length) freed AFTER it
-            for (uint32_t l = 0; l < nlev; ++l) {
-                for (uint32_t k = level_ptr[l]; k < level_ptr[l + 1]; ++k) {
-                    const Front& t = fr[fl[k]];
-                    const uint32_t R = t.S - t.K;
-                    if (R == 0) continue;
-                    const uint32_t len = (R + 1) * (R + 2) / 2;
-                    const uint32_t o = alloc(len);
-                    descs[k].upd = W.l_upool + o;
-                    out.update_doubles += len;
-                    const bool local_parent = t.parent != NONE && fr[t.parent].wg == g;
-                    dies[local_parent ? fr[t.parent].level : nlev - 1].push_back({o, len});
-                }
-                for (auto& [o, len] : dies[l]) release(o, len);
-            }
-            off = W.l_upool + ((pool_end + 1) & ~1u);
+        // update matrices: every front keeps its own for the whole solve (they are small: all of them together about a third of
+        // the panels), so that the assembly stream can fill them all at once
+        for (uint32_t k = 0; k < fl.size(); ++k) {
+            const Front& t = fr[fl[k]];
+            const uint32_t R = t.S - t.K;
+            if (R == 0) continue;
+            const uint32_t len = (R + 1) * (R + 2) / 2;
+            descs[k].upd = take(len);
+            out.update_doubles += len;
         }
+        if (off - W.l_panels >= 65536) return fail(why, "a workgroup's fronts do not fit 16-bit offsets");
         W.ws_doubles = off;
-        // ---- per front: rows, children + maps, exports, the assembly stream ---------------------------------------------------------
+        struct FlatEntry {
+            uint32_t hdr;
+            UVec ops;
+        };
+        std::vector<FlatEntry> flat;
+        // ---- per front: rows, children + maps, exports, the source stream ----------------------------------------------------------------
         for (uint32_t k = 0; k < fl.size(); ++k) {
             const Front& t = fr[fl[k]];
             FrontDesc& d = descs[k];
@@ -728,16 +701,15 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
                 const auto it = std::lower_bound(t.below.begin(), t.below.end(), p);
                 return (it != t.below.end() && *it == p) ? t.K + (uint32_t)(it - t.below.begin()) : NONE;
             };
-            // children (this workgroup's first, in their order; then remote ones)
+            // children in other workgroups: their update matrices arrive as chunks and are added through row maps; this workgroup's
+            // own children are sources of the assembly stream below
             d.child0 = (uint32_t)children.size();
-            UVec kid_order = t.kids;
-            std::stable_sort(kid_order.begin(), kid_order.end(), [&](uint32_t a, uint32_t b) { return (fr[a].wg != g) < (fr[b].wg != g); });
-            for (uint32_t c : kid_order) {
+            for (uint32_t c : t.kids) {
                 const Front& ch = fr[c];
+                if (ch.wg == g) continue;
                 FrontChild fc;
                 std::memset(&fc, 0, sizeof(fc));
-                const bool remote = ch.wg != g;
-                fc.flags = remote ? FRONT_CHILD_REMOTE : 0;
+                fc.flags = FRONT_CHILD_REMOTE;
                 fc.rows = (uint16_t)(ch.S - ch.K + 1);
                 fc.map = (uint32_t)maps.size();
                 for (uint32_t i : ch.below) {
@@ -746,11 +718,8 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
                     maps.push_back((uint8_t)r);
                 }
                 maps.push_back((uint8_t)t.S);  // the right-hand side's row
-                if (remote) {
-                    fc.upd = up_chunk[c];
-                    ++W.n_remote_children;
-                }
-                // (local children: filled in below, once every front of this workgroup has its update matrix)
+                fc.upd = up_chunk[c];
+                ++W.n_remote_children;
                 children.push_back(fc);
                 ++d.n_child;
             }
@@ -765,15 +734,15 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
                 d.exp0 = (uint32_t)exports.size();
                 for (uint32_t j = t.c0; j < t.c0 + t.K; ++j) exports.push_back(export_chunk[j]);
             }
-            // ---- assembly stream: every entry (row i, row j), i >= j, and every right-hand-side entry the front's own constraints
-            //      contribute to, with its operand pairs; sorted by pairs (most first) so that a trip's width fits its entries
+            // ---- what the front's elements receive: operand pairs of this workgroup's constraints (-> the workgroup's assembly
+            //      stream) and elements of its local children's update matrices (-> the front's source stream) -------------------------
             struct Entry {
-                uint32_t hdr;
-                UVec ops;
+                uint32_t dest;  // doubles from l_panels
+                uint32_t flags;
+                UVec ops, srcs;
             };
             std::vector<Entry> entries;
             {
-                // (row i, row j) -> entry index, via a small dense table over the front
                 const uint32_t S1 = t.S + 1;
                 std::vector<int32_t> at((size_t)S1 * S1, -1);
                 auto entry = [&](uint32_t i, uint32_t j, uint32_t flags) -> Entry& {  // i >= j; i == S: right-hand side
@@ -782,12 +751,12 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
                         e = (int32_t)entries.size();
                         uint32_t dest;
                         if (j < t.K) {
-                            dest = j * S1 + i;  // panel, column-major
+                            dest = d.panel - W.l_panels + j * S1 + i;  // panel, column-major
                         } else {
                             const uint32_t a = i - t.K, b = j - t.K;
-                            dest = (a * (a + 1) / 2 + b) | FASM_UPD;
+                            dest = d.upd - W.l_panels + a * (a + 1) / 2 + b;
                         }
-                        entries.push_back(Entry{dest | flags, {}});
+                        entries.push_back(Entry{dest, flags, {}, {}});
                     }
                     return entries[(size_t)e];
                 };
@@ -813,42 +782,91 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
                         }
                     }
                 }
-            }
-            std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.ops.size() > b.ops.size(); });
-            if (entries.size() > 65535) return fail(why, "a front's assembly stream is too long");
-            d.asm_n = (uint16_t)entries.size();
-            d.asm_off = (uint32_t)asm_words.size();
-            const uint32_t trips = ((uint32_t)entries.size() + 63) / 64;
-            uint32_t tail_w = 0;
-            for (uint32_t tr = 3; tr < trips; ++tr) tail_w = std::max<uint32_t>(tail_w, (uint32_t)entries[tr * 64].ops.size());
-            for (uint32_t tr = 0; tr < trips; ++tr) {
-                uint32_t w = tr < 3 ? (uint32_t)entries[tr * 64].ops.size() : tail_w;
-                if (w > 255) return fail(why, "an entry with more than 255 operand pairs");
-                d.asm_w[std::min(tr, 3u)] = (uint8_t)w;
-                const size_t base = asm_words.size();
-                asm_words.resize(base + 64 * (1 + (size_t)w), 0);
-                for (uint32_t l = 0; l < 64; ++l) {
-                    const uint32_t e = tr * 64 + l;
-                    if (e >= entries.size()) {
-                        asm_words[base + l] = FASM_NOP;
-                        for (uint32_t q = 0; q < w; ++q) asm_words[base + 64 * (1 + q) + l] = lslots | (lslots << 16);
-                        continue;
+                // extend-add: every element of a local child's update matrix is a source of the element its rows map to
+                for (uint32_t c : t.kids) {
+                    const Front& ch = fr[c];
+                    if (ch.wg != g) continue;
+                    const uint32_t Rc = ch.S - ch.K;
+                    const uint32_t base = descs[ch.local].upd - W.l_panels;
+                    UVec prow(Rc + 1);
+                    for (uint32_t a = 0; a < Rc; ++a) {
+                        prow[a] = row_in_front(ch.below[a]);
+                        if (prow[a] == NONE) return fail(why, "internal: extend-add map");
                     }
-                    const Entry& en = entries[e];
-                    asm_words[base + l] = en.hdr;
-                    const uint32_t padw = (en.hdr & FASM_RHS) ? (lslots | (lrows << 16)) : (lslots | (lslots << 16));
-                    for (uint32_t q = 0; q < w; ++q)
-                        asm_words[base + 64 * (1 + q) + l] = q < en.ops.size() ? en.ops[q] : padw;
+                    prow[Rc] = t.S;
+                    for (uint32_t a = 0; a <= Rc; ++a)
+                        for (uint32_t b = 0; b <= a; ++b) {
+                            if (a == Rc && b == Rc) continue;  // (the right-hand side's row against itself is nobody's)
+                            if (prow[a] < prow[b]) return fail(why, "internal: extend-add order");
+                            entry(prow[a], prow[b], 0u).srcs.push_back(base + a * (a + 1) / 2 + b);
+                        }
                 }
             }
+            // the front's source stream: the entries that have sources, widest first
+            {
+                std::vector<const Entry*> se;
+                for (const Entry& en : entries)
+                    if (!en.srcs.empty()) se.push_back(&en);
+                std::stable_sort(se.begin(), se.end(), [](const Entry* a, const Entry* b) { return a->srcs.size() > b->srcs.size(); });
+                if (se.size() > 65535) return fail(why, "a front's source stream is too long");
+                d.src_n = (uint16_t)se.size();
+                d.src_off = (uint32_t)stream_words.size();
+                const uint32_t trips = ((uint32_t)se.size() + 63) / 64;
+                uint32_t tv[4] = {0, 0, 0, 0};
+                for (uint32_t e = 0; e < se.size(); ++e) tv[std::min(e / 64, 3u)] = std::max<uint32_t>(tv[std::min(e / 64, 3u)], (uint32_t)(se[e]->srcs.size() + 1) / 2);
+                for (int q = 0; q < 4; ++q) {
+                    if (tv[q] > 255) return fail(why, "an element with more than 510 sources");
+                    d.src_v[q] = (uint8_t)tv[q];
+                }
+                for (uint32_t tr = 0; tr < trips; ++tr) {
+                    const uint32_t v = tv[std::min(tr, 3u)];
+                    const size_t base = stream_words.size();
+                    stream_words.resize(base + 64 * (1 + (size_t)v), 0);
+                    for (uint32_t l = 0; l < 64; ++l) {
+                        const uint32_t e = tr * 64 + l;
+                        if (e >= se.size()) {
+                            stream_words[base + l] = FASM_NOP;
+                            continue;  // (source words stay 0: the zero at l_panels)
+                        }
+                        stream_words[base + l] = se[e]->dest;
+                        for (uint32_t q = 0; q < v; ++q) {
+                            const UVec& sr = se[e]->srcs;
+                            const uint32_t s0 = 2 * q < sr.size() ? sr[2 * q] : 0u, s1 = 2 * q + 1 < sr.size() ? sr[2 * q + 1] : 0u;
+                            stream_words[base + 64 * (1 + q) + l] = s0 | (s1 << 16);
+                        }
+                    }
+                }
+            }
+            // ... and its share of the workgroup's assembly stream
+            for (Entry& en : entries)
+                if (!en.ops.empty() || (en.flags & FASM_DIAG)) flat.push_back(FlatEntry{en.dest | en.flags, std::move(en.ops)});
         }
-        // local children: their update matrices' offsets
-        for (uint32_t k = 0; k < fl.size(); ++k) {
-            const Front& t = fr[fl[k]];
-            UVec kid_order = t.kids;
-            std::stable_sort(kid_order.begin(), kid_order.end(), [&](uint32_t a, uint32_t b) { return (fr[a].wg != g) < (fr[b].wg != g); });
-            for (uint32_t q = 0; q < kid_order.size(); ++q)
-                if (fr[kid_order[q]].wg == g) children[descs[k].child0 + q].upd = descs[fr[kid_order[q]].local].upd;
+        // ---- the workgroup's assembly stream: entries by operand count (most first), trips of 64 -----------------------------------------
+        {
+            std::stable_sort(flat.begin(), flat.end(), [](const FlatEntry& a, const FlatEntry& b) { return a.ops.size() > b.ops.size(); });
+            W.asm_word0 = (uint32_t)stream_words.size();
+            W.asm_trips = ((uint32_t)flat.size() + 63) / 64;
+            // (first the trips' word offsets from the streams' start: a wavefront takes every n-th trip)
+            stream_words.resize(stream_words.size() + ((W.asm_trips + 3) & ~3u), 0);
+            for (uint32_t tr = 0; tr < W.asm_trips; ++tr) {
+                const uint32_t w = (uint32_t)flat[(size_t)tr * 64].ops.size();
+                if (w > 255) return fail(why, "an element with more than 255 operand pairs");
+                const size_t base = stream_words.size();
+                stream_words[W.asm_word0 + tr] = (uint32_t)base;
+                stream_words.resize(base + 64 * (1 + (size_t)w), 0);
+                for (uint32_t l = 0; l < 64; ++l) {
+                    const size_t e = (size_t)tr * 64 + l;
+                    if (e >= flat.size()) {
+                        stream_words[base + l] = FASM_NOP | (w << 24);
+                        for (uint32_t q = 0; q < w; ++q) stream_words[base + 64 * (1 + q) + l] = lslots | (lslots << 16);
+                        continue;
+                    }
+                    const FlatEntry& en = flat[e];
+                    stream_words[base + l] = en.hdr | (w << 24);
+                    const uint32_t padw = (en.hdr & FASM_RHS) ? (lslots | (lrows << 16)) : (lslots | (lslots << 16));
+                    for (uint32_t q = 0; q < w; ++q) stream_words[base + 64 * (1 + q) + l] = q < en.ops.size() ? en.ops[q] : padw;
+                }
+            }
         }
         // ---- serialise ----------------------------------------------------------------------------------------------------------------
         W.n_fronts = (uint32_t)fl.size();
@@ -865,19 +883,19 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             W.t_rows = T.put(rows);
             W.t_exports = T.put(exports);
             W.t_maps = T.put(maps);
+            W.t_stream = T.put(stream_words);
             tab.resize((tab.size() + 15) & ~size_t(15), 0);
             W.o_tables = B.put(tab);
             W.tab_bytes = (uint32_t)tab.size();
         }
-        W.o_asm = B.put(asm_words);
         W.o_ghosts = B.put(ghosts);
         out.n_fronts += W.n_fronts;
         out.n_levels = std::max(out.n_levels, nlev);
         out.ws_doubles_max = std::max(out.ws_doubles_max, W.ws_doubles);
         out.tab_bytes_max = std::max(out.tab_bytes_max, W.tab_bytes);
         if (debug)
-            std::fprintf(stderr, "front plan: wg %u: %u fronts in %u levels, %u own + %u ghost variables, %u constraints, workspace %u doubles, tables %u B, stream %zu words\n",
-                         g, W.n_fronts, nlev, W.n_own, W.n_ghost, W.n_cons, W.ws_doubles, W.tab_bytes, asm_words.size());
+            std::fprintf(stderr, "front plan: wg %u: %u fronts in %u levels, %u own + %u ghost variables, %u constraints, workspace %u doubles, tables %u B, streams %zu words\n",
+                         g, W.n_fronts, nlev, W.n_own, W.n_ghost, W.n_cons, W.ws_doubles, W.tab_bytes, stream_words.size());
     }
     out.bad_chunk0 = bad_chunk0;
     out.verdict_chunk = verdict_chunk;
@@ -894,6 +912,22 @@ bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
     return true;
 }
 
+}  // namespace ezpz
+
+namespace ezpz {
+bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const FrontOptions& opt, FrontPlan& out,
+                      const char** why) {
+    const char* w = nullptr;
+    FrontOptions o = opt;
+    for (;;) {
+        if (plan_once(cs, n_cs, n_vars, o, out, &w)) return true;
+        // the planner's own choice of workgroups: a share that does not fit one CU's LDS asks for more of them
+        if (opt.wgs != 0 || !w || !std::strstr(w, "LDS") || out.n_wgs >= std::min<uint32_t>(o.max_wgs, kFrontMaxWgs) || o.vars_per_wg <= 24) break;
+        o.vars_per_wg = o.vars_per_wg * 3 / 4;
+    }
+    if (why) *why = w;
+    return false;
+}
 }  // namespace ezpz
 
 extern "C" long ezpz_debug_front_plan(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t wgs, uint32_t max_wgs,

@@ -676,16 +676,10 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             fo.vars_per_wg = pol.front_vars_per_workgroup;
             if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
             fo.lds_bytes = s.lim.lds_bytes;
+            if (const char* e = std::getenv("EZPZ_FRONT_THREADS")) fo.threads = std::atoi(e) >= 1024 ? 1024u : 512u;
             std::unique_ptr<FrontPlan> plan(new FrontPlan());
             const char* why = nullptr;
-            bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
-            // (a share that does not fit one CU's LDS: more workgroups, while there are any)
-            while (!ok && (for_latency || force_fronts) && fo.wgs != 1 && why && std::strstr(why, "LDS")) {
-                fo.vars_per_wg = fo.vars_per_wg * 3 / 4;
-                if (fo.vars_per_wg < 32) break;
-                fo.wgs = 0;
-                ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
-            }
+            const bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
             if (ok) {
                 info.team_mode = 5;
                 info.team_size = plan->threads;

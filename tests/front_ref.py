@@ -12,21 +12,21 @@ import ezpz_amd as E
 from oracle import oracle as O
 
 FRONT_DESC = np.dtype([("K", "<u2"), ("S", "<u2"), ("n_child", "<u2"), ("flags", "<u2"), ("panel", "<u4"), ("upd", "<u4"),
-                       ("rows", "<u4"), ("child0", "<u4"), ("asm_off", "<u4"), ("asm_n", "<u2"), ("pad0", "<u2"),
-                       ("asm_w", "u1", (4,)), ("up_chunk", "<u4"), ("exp0", "<u4"), ("pad1", "<u4")])
+                       ("rows", "<u4"), ("child0", "<u4"), ("src_off", "<u4"), ("src_n", "<u2"), ("pad0", "<u2"),
+                       ("src_v", "u1", (4,)), ("up_chunk", "<u4"), ("exp0", "<u4"), ("pad1", "<u4")])
 assert FRONT_DESC.itemsize == 48
 FRONT_CHILD = np.dtype([("upd", "<u4"), ("rows", "<u2"), ("flags", "<u2"), ("map", "<u4"), ("pad", "<u4")])
 assert FRONT_CHILD.itemsize == 16
 FRONT_GHOST = np.dtype([("local", "<u4"), ("chunk", "<u4")])
 WG_FIELDS = ["n_loc", "n_own", "n_ghost", "n_cons", "n_rows", "zj", "n_fronts", "n_levels", "o_var_glob", "o_cons", "o_tables",
-             "tab_bytes", "t_level_ptr", "t_children", "t_rows", "t_exports", "t_maps", "o_asm", "o_ghosts", "l_x", "l_d", "l_r",
-             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "pad0", "pad1", "pad2", "pad3"]
+             "tab_bytes", "t_level_ptr", "t_children", "t_rows", "t_exports", "t_maps", "t_stream", "asm_word0", "asm_trips", "o_ghosts", "l_x", "l_d", "l_r",
+             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "pad0", "pad1"]
 FRONT_WG = np.dtype([(f, "<u4") for f in WG_FIELDS])
 assert FRONT_WG.itemsize == 128
 DEVCON = np.dtype([("ids", "<u4", (8,)), ("param", "<f8"), ("weight", "<f8"), ("row0", "<u4"), ("jbase", "<u4"), ("pos", "<u4"),
                    ("kind", "u1"), ("tag", "u1"), ("nrows", "u1"), ("nslots", "u1"), ("jloc", "u1", (16,))])
 assert DEVCON.itemsize == 80
-FASM_UPD, FASM_DIAG, FASM_RHS, FASM_NOP = 1 << 16, 1 << 17, 1 << 18, 1 << 19
+FASM_DIAG, FASM_RHS, FASM_NOP = 1 << 17, 1 << 18, 1 << 19
 FRONT_REMOTE_PARENT, FRONT_EXPORTS, FRONT_CHILD_REMOTE = 1, 2, 1
 
 
@@ -60,7 +60,7 @@ class Plan:
         children = self.arr(FRONT_CHILD, t0 + int(W["t_children"]), n_children)
         rows = self.arr("<u2", t0 + int(W["t_rows"]), (int(W["t_exports"]) - int(W["t_rows"])) // 2)
         exports = self.arr("<u4", t0 + int(W["t_exports"]), (int(W["t_maps"]) - int(W["t_exports"])) // 4)
-        maps = self.arr("u1", t0 + int(W["t_maps"]), int(W["tab_bytes"]) - int(W["t_maps"]))
+        maps = self.arr("u1", t0 + int(W["t_maps"]), int(W["t_stream"]) - int(W["t_maps"]))
         return descs, level_ptr, children, rows, exports, maps
 
 
@@ -106,7 +106,27 @@ def linear_step(plan, x_caller, lam):
         descs, level_ptr, children, rows, exports, maps = plan.wg_tables(g)
         w = ws[g]
         r, jv = evals[g]
-        stream = plan.arr("<u4", W["o_asm"], (len(plan.blob) - int(W["o_asm"])) // 4)
+        stream = plan.arr("<u4", int(W["o_tables"]) + int(W["t_stream"]), (int(W["tab_bytes"]) - int(W["t_stream"])) // 4)
+        pan = int(W["l_panels"])
+        # the assembly of the linear solve: panels and update matrices zeroed, then the workgroup's assembly stream
+        w[pan:] = 0.0
+        offs = stream[int(W["asm_word0"]): int(W["asm_word0"]) + int(W["asm_trips"])]
+        for tr in range(int(W["asm_trips"])):
+            base = int(offs[tr])
+            wdt = int(stream[base]) >> 24
+            for l in range(64):
+                hdr = int(stream[base + l])
+                assert hdr >> 24 == wdt
+                if hdr & FASM_NOP:
+                    continue
+                acc = 0.0
+                for q in range(wdt):
+                    op = int(stream[base + 64 * (1 + q) + l])
+                    a, b = op & 0xFFFF, op >> 16
+                    acc += jv[a] * (-r[b]) if hdr & FASM_RHS else jv[a] * jv[b]
+                if hdr & FASM_DIAG:
+                    acc += lam
+                w[pan + (hdr & 0xFFFF)] = acc
         for lv in range(int(W["n_levels"])):
             for k in range(int(level_ptr[lv]), int(level_ptr[lv + 1])):
                 d = descs[k]
@@ -114,39 +134,33 @@ def linear_step(plan, x_caller, lam):
                 S1, R = S + 1, S - K
                 nU = (R + 1) * (R + 2) // 2
                 P = w[int(d["panel"]): int(d["panel"]) + S1 * K]
-                U = w[int(d["upd"]): int(d["upd"]) + nU] if R else np.zeros(1)
-                P[:] = 0.0
-                U[:] = 0.0
-                # assembly stream
-                base = int(d["asm_off"])
-                n_e = int(d["asm_n"])
+                U = w[int(d["upd"]): int(d["upd"]) + nU] if R else w[0:0]  # (a root front has no update matrix: nothing may be written)
+                # the front's source stream: elements of its local children's update matrices, gathered by destination
+                base = int(d["src_off"])
+                n_e = int(d["src_n"])
                 for tr in range((n_e + 63) // 64):
-                    wdt = int(d["asm_w"][min(tr, 3)])
+                    vdt = int(d["src_v"][min(tr, 3)])
                     for l in range(64):
                         hdr = int(stream[base + l])
                         if hdr & FASM_NOP:
                             continue
-                        acc = 0.0
-                        for q in range(wdt):
-                            op = int(stream[base + 64 * (1 + q) + l])
-                            a, b = op & 0xFFFF, op >> 16
-                            acc += jv[a] * (-r[b]) if hdr & FASM_RHS else jv[a] * jv[b]
-                        if hdr & FASM_DIAG:
-                            acc += lam
-                        dest = hdr & 0xFFFF
-                        if hdr & FASM_UPD:
-                            U[dest] = acc
-                        else:
-                            P[dest] = acc
-                    base += 64 * (1 + wdt)
-                # extend-add
+                        acc = w[pan + (hdr & 0xFFFF)]
+                        for q in range(vdt):
+                            sw = int(stream[base + 64 * (1 + q) + l])
+                            acc += w[pan + (sw & 0xFFFF)] + w[pan + (sw >> 16)]
+                        w[pan + (hdr & 0xFFFF)] = acc
+                    base += 64 * (1 + vdt)
+                # children in other workgroups (this workgroup's own are sources of the stream)
                 for c in children[int(d["child0"]): int(d["child0"]) + int(d["n_child"])]:
                     Rc1 = int(c["rows"])
                     m = maps[int(c["map"]): int(c["map"]) + Rc1]
                     for a in range(Rc1):
                         for b in range(a + 1):
                             e = tri(a, b)
-                            val = chunks[int(c["upd"]) + e] if int(c["flags"]) & FRONT_CHILD_REMOTE else w[int(c["upd"]) + e]
+                            if e == Rc1 * (Rc1 + 1) // 2 - 1:
+                                continue  # the right-hand side's row against itself is nobody's
+                            assert int(c["flags"]) & FRONT_CHILD_REMOTE
+                            val = chunks[int(c["upd"]) + e]
                             i, j = int(m[a]), int(m[b])
                             assert i >= j, (i, j, a, b)
                             if j < K:
@@ -171,12 +185,14 @@ def linear_step(plan, x_caller, lam):
                 # Schur complement (row R = right-hand side)
                 for a in range(R + 1):
                     for b in range(a + 1):
+                        if a == R and b == R:
+                            continue
                         acc = 0.0
                         for kk in range(K):
                             acc += P[kk * S1 + K + a] * P[kk * S1 + K + b]
                         U[tri(a, b)] -= acc
                 if int(d["flags"]) & FRONT_REMOTE_PARENT:
-                    for e in range(nU):
+                    for e in range(nU - 1):
                         chunks[int(d["up_chunk"]) + e] = U[e]
 
     def backward(g):

@@ -52,7 +52,7 @@ def front_system(E, recs, n, wgs=None):
     return s, info
 
 
-@pytest.mark.parametrize("npts,wgs", [(4, 1), (8, 1), (25, 1), (75, 1), (75, 2), (150, 1), (150, 3), (400, None), (400, 1), (1000, None)])
+@pytest.mark.parametrize("npts,wgs", [(4, 1), (8, 1), (25, 1), (75, 1), (75, 2), (150, 1), (150, 3), (400, None), (400, 4), (1000, None)])
 def test_connected_sketch_on_fronts_equals_the_oracle(E, npts, wgs):
     """tests/gen.py:connected_sketch (fully determined, mixed kinds) from its own start and from jittered starts: iterations,
     flags, unsatisfied counts equal to the oracle's, coordinates at 1e-6; the batch is bitwise repeatable."""
