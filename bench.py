@@ -774,7 +774,7 @@ def main():
     checked = None
     if args.check and rank == 0:
         checked = w.oracle_check()
-        ok = ok and checked["max_rel_err"] <= 1e-6 and checked["max_rel_err_underconstrained"] <= 1e-3 and checked["iterations_equal"]
+        ok = ok and checked["max_rel_err"] <= 1e-6 and checked["max_rel_err_underconstrained"] <= 1e-4 and checked["iterations_equal"]
 
     # the other BASELINE configurations (outside `value`): every rank takes part in a leg's barriers; at N > 1 only the
     # mixed batch -- BASELINE configs[4], "batch-sharded across 8 x MI355X" -- runs, split over the ranks

@@ -643,6 +643,7 @@ TEAM_AUTO_LISTS = 0xFFFFFFFE  # `team_size`: automatic, list-walk shapes only (n
 TEAM_BATCH_LANES = 0xFFFFFFFD  # `team_size`: automatic, connected sketches one lane per system at every batch size
 TEAM_LATENCY_PHASES = 0xFFFFFFFC  # `team_size`: TEAM_AUTO_LATENCY without the record walk (dense phases instead)
 TEAM_LATENCY_WAVE = 0xFFFFFFFB  # `team_size`: TEAM_AUTO_LATENCY, a small system always on one wavefront per system where that form exists
+TEAM_LATENCY_RECORDS = 0xFFFFFFF9  # `team_size`: TEAM_AUTO_LATENCY without the frontal shape (the record walk, as before round 5)
 TEAM_FRONTS = 0xFFFFFFFA  # `team_size`: the frontal shape (team_mode 5) whatever the size of the system, TEAM_AUTO_LATENCY behind it
 TEAM_AUTO_LATENCY = 0xFFFFFFFF  # `team_size`: choose for the latency of one solve instead of batch throughput (ezpz_amd.h)
 

@@ -84,7 +84,7 @@ int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int
     call_stamp(COLD_ANALYSED);
     if (rc != EZPZ_OK) return rc;
     if (!have_device) return EZPZ_ERR_NO_DEVICE;
-    HIP_TRY(hipSetDevice(device));
+    EZPZ_ON_DEVICE(device);
     if (!s->program_deferred.load()) {
         HIP_TRY(hipMalloc(&s->dev_program, blob.size()));
         HIP_TRY(hipMemcpy(s->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -140,7 +140,7 @@ int ezpz::ensure_program(EzpzSystem* sys) {
                           nullptr, nullptr, false, /*keep_comp=*/true);
     if (rc != EZPZ_OK) return rc;
     if (sys->device >= 0) {
-        HIP_TRY(hipSetDevice(sys->device));
+        EZPZ_ON_DEVICE(sys->device);
         HIP_TRY(hipMalloc(&sys->dev_program, blob.size()));
         HIP_TRY(hipMemcpy(sys->dev_program, blob.data(), blob.size(), hipMemcpyHostToDevice));
         sys->view.base = static_cast<const unsigned char*>(sys->dev_program);

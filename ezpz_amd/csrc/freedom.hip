@@ -293,7 +293,7 @@ int ezpz_system_freedom_batch_device(EzpzSystem* sys, const double* x_dev, size_
     if (!sys || (batch && (!x_dev || !under_mask_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch == 0) return EZPZ_OK;
     std::lock_guard<std::mutex> lock(sys->mu);
-    HIP_TRY(hipSetDevice(sys->device));
+    EZPZ_ON_DEVICE(sys->device);
     return freedom_device(sys, x_dev, batch, under_mask_dev, participation_dev, n_under_dev, (hipStream_t)stream);
 }
 
@@ -305,7 +305,7 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
     // whatever this call puts on a stream would otherwise queue behind it until its lease runs out)
     release_thread_kernel(sys->device);
     std::lock_guard<std::mutex> lock(sys->mu);
-    HIP_TRY(hipSetDevice(sys->device));
+    EZPZ_ON_DEVICE(sys->device);
     auto& F = sys->freedom;
     const size_t n = sys->counts.n_vars;
     if (n == 0 || sys->counts.n_rows == 0) return EZPZ_ERR_EMPTY_SYSTEM;

@@ -355,7 +355,7 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
                                    void* stream, const DoneWord& done, bool* resident) {
     if (!sys || (batch && (!x_out_dev || !status_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch && sys->counts.n_vars && !x0_dev) return EZPZ_ERR_INVALID_ARGUMENT;
-    HIP_TRY(hipSetDevice(sys->device));
+    EZPZ_ON_DEVICE(sys->device);
     SolveArgs a{};
     a.p = sys->view;
     a.x0 = x0_dev;
@@ -437,17 +437,24 @@ int lane_indexed_launch(EzpzSystem* sys, const double* x_ragged, const uint64_t*
     return lane_jit_launch(sys->jit, *sys->lane, L, sys->device, sys->lim.cus, static_cast<hipStream_t>(stream)) == EZPZ_OK ? EZPZ_OK : 1;
 }
 
-// The pipelined host-to-host path's copy out, as a kernel (pipeline.cpp): `bytes` (a multiple of 16) from device memory
-// into registered host memory through its device address, 16 bytes per lane and store.  Which engine moves a
-// hipMemcpyAsync is the runtime's choice; this one is ours (tools/pcie_duplex.hip: a copy kernel out beside copies in
-// keeps 41-43 GB/s each way whatever moves the copies in).
-__global__ void __launch_bounds__(256) copy_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+// The pipelined host-to-host path's copy out, as a kernel (pipeline.cpp): `bytes` (a multiple of 8: rows of doubles, 32-byte
+// statuses) from device memory into registered host memory through its device address.  16 bytes per lane and store where both
+// addresses and the length allow it; a piece of an odd number of doubles, or one that starts on an odd double (odd n_vars and
+// an odd number of systems before it), goes 8 bytes at a time.  Which engine moves a hipMemcpyAsync is the runtime's choice;
+// this one is ours (tools/pcie_duplex.hip: a copy kernel out beside copies in keeps 41-43 GB/s each way whatever moves the
+// copies in).
+template <class T>
+__global__ void __launch_bounds__(256) copy_out_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 void launch_copy_out(void* dst_host_as_device, const void* src_dev, size_t bytes, void* stream) {
-    hipLaunchKernelGGL(copy_out_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(src_dev),
-                       static_cast<uint4*>(dst_host_as_device), bytes / 16);
+    const bool wide = ((reinterpret_cast<uintptr_t>(dst_host_as_device) | reinterpret_cast<uintptr_t>(src_dev) | bytes) & 15u) == 0;
+    if (wide)
+        hipLaunchKernelGGL(copy_out_kernel<uint4>, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(src_dev),
+                           static_cast<uint4*>(dst_host_as_device), bytes / 16);
+    else
+        hipLaunchKernelGGL(copy_out_kernel<uint2>, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint2*>(src_dev),
+                           static_cast<uint2*>(dst_host_as_device), bytes / 8);
 }
 
 // The evaluation-only kernel (K1: residuals and Jacobian values at given points, internal numbering) on `stream`.
@@ -482,7 +489,7 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
     release_thread_kernel(sys->device);
     if (int rc0 = ensure_program(sys)) return rc0;
     std::lock_guard<std::mutex> lock(sys->mu);
-    HIP_TRY(hipSetDevice(sys->device));
+    EZPZ_ON_DEVICE(sys->device);
     const size_t n = sys->counts.n_vars, m = sys->counts.n_rows, zj = sys->counts.zj;
     DevBuf<double> xd, rd, jd;
     DevBuf<uint32_t> dd;

@@ -78,7 +78,8 @@ struct EzpzMixedBatch {
     double* d_x = nullptr;
     EzpzStatus* d_st = nullptr;
     ~EzpzMixedBatch() {
-        if (device >= 0) (void)hipSetDevice(device);
+        // (freed with the batch's device current; the caller's own is put back)
+        ezpz::DeviceGuard on_device(device >= 0 ? device : 0);
         for (Group& g : groups) {
             if (g.stream) (void)hipStreamSynchronize(g.stream);
             for (void* p : {(void*)g.d_sys_of, (void*)g.d_offset, (void*)g.d_block, (void*)g.d_status})
@@ -99,11 +100,21 @@ int ezpz_mixed_create(EzpzSystem* const* handles, size_t n_handles, const uint32
     if (!out) return EZPZ_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if ((batch && (!handles || !n_handles || !topology_of_system)) || batch >= (1ull << 32)) return EZPZ_ERR_INVALID_ARGUMENT;
+    // the batch lives where its topologies live: one device for all of them (its streams, events and staging blocks are created
+    // there, whatever device the calling thread is on)
     int device = -1;
-    if (hipGetDevice(&device) != hipSuccess) {
-        (void)hipGetLastError();
-        return EZPZ_ERR_NO_DEVICE;
+    for (size_t t = 0; t < n_handles; ++t) {
+        if (!handles[t] || handles[t]->device < 0) return EZPZ_ERR_INVALID_ARGUMENT;
+        if (device < 0) device = handles[t]->device;
+        if (handles[t]->device != device) return EZPZ_ERR_INVALID_ARGUMENT;
     }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) {
+            (void)hipGetLastError();
+            return EZPZ_ERR_NO_DEVICE;
+        }
+    }
+    EZPZ_ON_DEVICE(device);
     std::vector<EzpzSystemInfo> info(n_handles);
     for (size_t t = 0; t < n_handles; ++t) {
         if (!handles[t]) return EZPZ_ERR_INVALID_ARGUMENT;
@@ -149,10 +160,11 @@ int ezpz_mixed_create(EzpzSystem* const* handles, size_t n_handles, const uint32
         g.contiguous = (uint64_t)g.sys_of.back() - g.sys_of.front() + 1 == g.count;
         HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
-        if (g.contiguous || g.n == 0) continue;
+        // (a scattered group of systems WITHOUT variables still has statuses to scatter: the same staging, an empty block)
+        if (g.contiguous) continue;
         HIP_TRY(hipMalloc((void**)&g.d_sys_of, g.count * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&g.d_offset, g.count * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void**)&g.d_block, g.count * g.n * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&g.d_block, std::max<size_t>(g.count * g.n, 1) * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&g.d_status, g.count * sizeof(EzpzStatus)));
         HIP_TRY(hipMemcpy(g.d_sys_of, g.sys_of.data(), g.count * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(g.d_offset, g.offset.data(), g.count * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -175,13 +187,13 @@ int ezpz_mixed_solve_device(EzpzMixedBatch* m, const double* x0_dev, const EzpzC
     if (m->batch == 0) return EZPZ_OK;
     if (!status_dev || (m->total && (!x0_dev || !x_out_dev))) return EZPZ_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(m->mu);
-    HIP_TRY(hipSetDevice(m->device));
+    EZPZ_ON_DEVICE(m->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipEventRecord(m->fork, stream));
     int rc = EZPZ_OK;
     for (Group& g : m->groups) {
         HIP_TRY(hipStreamWaitEvent(g.stream, m->fork, 0));
-        if (g.contiguous || g.n == 0) {
+        if (g.contiguous) {
             const int r = ezpz_system_solve_batch_device(g.sys, x0_dev + g.first_off, g.count, cfg, x_out_dev + g.first_off,
                                                          status_dev + g.first, nullptr, nullptr, 0, g.stream);
             if (rc == EZPZ_OK) rc = r;
@@ -211,9 +223,9 @@ int ezpz_mixed_solve(EzpzMixedBatch* m, const double* x0, const EzpzConfig* cfg,
     if (!m) return EZPZ_ERR_INVALID_ARGUMENT;
     if (m->batch == 0) return EZPZ_OK;
     if (!status || (m->total && (!x0 || !x_out))) return EZPZ_ERR_INVALID_ARGUMENT;
+    EZPZ_ON_DEVICE(m->device);  // (the copies below run on the batch's device too)
     {
         std::lock_guard<std::mutex> lock(m->mu);
-        HIP_TRY(hipSetDevice(m->device));
         if (!m->d_x) HIP_TRY(hipMalloc((void**)&m->d_x, std::max<uint64_t>(m->total, 1) * sizeof(double)));
         if (!m->d_st) HIP_TRY(hipMalloc((void**)&m->d_st, m->batch * sizeof(EzpzStatus)));
     }

@@ -42,7 +42,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     if (batch == 0) return EZPZ_OK;
     release_thread_kernel(sys->device);
     std::lock_guard<std::mutex> lock(sys->mu);
-    HIP_TRY(hipSetDevice(sys->device));
+    EZPZ_ON_DEVICE(sys->device);
     const size_t n = sys->counts.n_vars, C = sys->counts.n_cons;
     const bool want_log = warn_log && warn_cap;
     const size_t x_bytes = batch * std::max<size_t>(n, 1) * sizeof(double);
@@ -85,7 +85,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         }
         call_stamp(CALL_COMPLETE);
         std::memcpy(status, hst, st_bytes);
-        if (sys->grid_wgs > 1)
+        if (can_time_out(*sys))
             for (size_t b2 = 0; b2 < batch; ++b2)
                 if (status[b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
         if (n) std::memcpy(x_out, hx, batch * n * sizeof(double));
@@ -227,7 +227,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                          std::chrono::duration<double, std::micro>(t_enq1 - t_enq0).count(),
                          std::chrono::duration<double, std::micro>(t_enq2 - t_enq1).count(),
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq2).count());
-        if (sys->grid_wgs > 1 || (sys->comp && sys->comp->jit_wgs > 1))  // a system spread over several workgroups: its rendezvous can time out
+        if (can_time_out(*sys))
             for (size_t b2 = 0; b2 < batch; ++b2)
                 if (status[b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
         return EZPZ_OK;
@@ -250,7 +250,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
                                             warn_cap, nullptr);
         if (rc != EZPZ_OK) return rc;
         HIP_TRY(hipMemcpy(status + off, sys->st_dev.p, nb * sizeof(EzpzStatus), hipMemcpyDeviceToHost));
-        if (sys->grid_wgs > 1)
+        if (can_time_out(*sys))
             for (size_t b2 = 0; b2 < nb; ++b2)
                 if (status[off + b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
         if (n) HIP_TRY(hipMemcpy(x_out + off * n, sys->x_dev.p, nb * n * sizeof(double), hipMemcpyDeviceToHost));
@@ -358,7 +358,7 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
                            uint8_t* unsat_mask, uint64_t* warn_log, uint32_t warn_cap) {
     if (!sys || !status) return EZPZ_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(sys->mu);
-    HIP_TRY(hipSetDevice(sys->device));
+    EZPZ_ON_DEVICE(sys->device);
     call_stamp(CALL_LOCKED);
     const size_t n = sys->counts.n_vars, C = sys->counts.n_cons;
     if (n && (!x0 || !x_out)) return EZPZ_ERR_INVALID_ARGUMENT;
@@ -532,7 +532,7 @@ int ezpz::system_solve_one(EzpzSystem* sys, const double* x0, const EzpzConfig* 
     std::atomic_thread_fence(std::memory_order_acquire);
     call_stamp(CALL_COMPLETE);
     *status = *hst;
-    if (status->iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT && (sys->grid_wgs > 1 || (sys->comp && sys->comp->jit_wgs > 1))) return EZPZ_ERR_HIP;
+    if (status->iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT && can_time_out(*sys)) return EZPZ_ERR_HIP;
     if (n) std::memcpy(x_out, hx_out, n * sizeof(double));
     const bool fetch_mask = unsat_mask && C && status->n_unsatisfied > 0;
     const size_t n_log = want_log ? std::min<size_t>(status->n_warnings, warn_cap) : 0;

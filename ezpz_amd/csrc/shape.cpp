@@ -125,6 +125,10 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
                  Program& P, std::vector<unsigned char>& blob, int32_t* err_constraint, int64_t* err_variable, bool may_defer,
                  bool keep_comp) {
     BuildError be;
+    const bool no_fronts = team_size == EZPZ_TEAM_LATENCY_RECORDS;  // the automatic latency shape as it was before the fronts
+    if (no_fronts) team_size = EZPZ_TEAM_AUTO_LATENCY;
+    const bool latency_auto = team_size == EZPZ_TEAM_AUTO_LATENCY || team_size == EZPZ_TEAM_LATENCY_WAVE;
+    const bool batch_auto = team_size == 0;
     static const bool comp_enabled0 = [] {
         const char* e = std::getenv("EZPZ_COMP");
         return !(e && e[0] == '0');
@@ -664,8 +668,11 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
         const char* fe = std::getenv("EZPZ_FRONTS");
         const int fronts_env = fe ? std::atoi(fe) : 1;
         const EzpzLaunchPolicy& pol = s.lim.policy;
-        uint32_t min_vars = for_latency ? pol.front_min_vars_one_solve : (fronts_env >= 2 ? pol.front_min_vars_one_solve : pol.front_min_vars_batch);
-        if (fronts_env == 0) min_vars = 0;
+        // (one solve: the automatic latency shape only -- EZPZ_TEAM_LATENCY_PHASES / _RECORDS ask for the older ones; batches: the
+        // automatic shape)
+        uint32_t min_vars = latency_auto ? pol.front_min_vars_one_solve
+                            : batch_auto ? (fronts_env >= 2 ? pol.front_min_vars_one_solve : pol.front_min_vars_batch) : 0u;
+        if (fronts_env == 0 || no_fronts) min_vars = 0;
         const bool connected = s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents;
         const bool want = force_fronts || (auto_shape && min_vars && n_vars >= min_vars && connected && !s.comp && !s.lane && !keep_comp);
         if (want && n_cs > 0) {

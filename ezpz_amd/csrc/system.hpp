@@ -82,6 +82,34 @@ inline bool hip_debug() {
         }                                                                                                         \
     } while (0)
 
+// Makes `device` the calling thread's current HIP device for a scope and puts the caller's own back at its end: a host entry
+// point must not leave a torch caller on an 8-GPU node on another device than it was on (every entry that touches the runtime
+// on behalf of a system opens one).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+        if (prev == device) {
+            prev = -1;  // nothing to put back
+        } else if (hipSetDevice(device) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define EZPZ_ON_DEVICE(device)              \
+    ezpz::DeviceGuard device_guard_(device); \
+    if (!device_guard_.ok) return EZPZ_ERR_HIP
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -250,6 +278,13 @@ struct EzpzSystem {
 };
 
 namespace ezpz {
+
+// A system spread over several workgroups that wait for each other (a grid team, a multi-workgroup specialised kernel, fronts across
+// workgroups): its rendezvous can time out, and the status then says so (EZPZ_ITERATIONS_TEAM_TIMEOUT) -- every host entry turns
+// that into EZPZ_ERR_HIP.
+inline bool can_time_out(const EzpzSystem& s) {
+    return s.grid_wgs > 1 || (s.comp && s.comp->jit_wgs > 1) || (s.fronts && s.fronts->n_wgs > 1);
+}
 
 inline uint32_t pow2_ceil(uint32_t v) {
     uint32_t p = 1;

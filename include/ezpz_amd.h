@@ -207,6 +207,9 @@ const char* ezpz_error_string(int err);
  * system, with the automatic latency shape behind it where the shape does not apply (a front of more than 63 rows ...);
  * EZPZ_TEAM_AUTO_LATENCY takes it from a size on its own (EzpzLaunchPolicy.front_min_vars_one_solve) */
 #define EZPZ_TEAM_FRONTS 0xFFFFFFFAu
+/* EZPZ_TEAM_AUTO_LATENCY without the frontal shape: one connected sketch then walks records (team_mode 4), as every latency
+ * shape did before round 5 (A/B runs and tests) */
+#define EZPZ_TEAM_LATENCY_RECORDS 0xFFFFFFF9u
 int ezpz_system_create(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, int device, uint32_t team_size,
                        EzpzSystem** out, int32_t* err_constraint, int64_t* err_variable);
 void ezpz_system_destroy(EzpzSystem* sys);

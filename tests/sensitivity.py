@@ -16,7 +16,8 @@ when every start coordinate is moved by one ulp.  So the bar for a system is mea
                   excused but judged on what remains well defined -- its answer must satisfy the constraints as well as
                   the oracle's runs do (max |r| <= 10 x the worst of theirs, floor 1e-8 = residual_tolerance; the same
                   constraints unsatisfied at EPSILON) on top of the iteration and convergence checks, and still lie within
-                  20 x the oracle's own spread -- and is counted separately in the log ("beyond the ceiling")
+                  20 x the oracle's own spread AND within 1e-2 whatever that spread -- and is counted separately in the log
+                  ("beyond the ceiling"), with the coordinate error it was actually granted
     iterations    equal to the oracle's, or inside the range of counts those K + 1 oracle runs produce (the counts of a
                   chaotic path are samples -- comb 51 of the graph fuzz gives 18, 20, 22, 24, 28, 32 ... 50 over 96
                   perturbations -- so K grows 8 -> 32 -> 96 before a count is declared outside)
@@ -37,12 +38,16 @@ BAR_CEILING = 1e-4  # the reference's own test tolerance: the measured bar never
 _LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_bar.txt")
 
 
-def _log(what, total, needed, worst_err, widest_bar, iteration_exceptions, beyond):
+BEYOND_CEILING = 1e-2  # ... and what a system "beyond the ceiling" may differ by at most, whatever its oracle spread
+
+
+def _log(what, total, needed, worst_err, widest_bar, iteration_exceptions, beyond, beyond_err=0.0, beyond_bar=0.0):
     if os.path.isdir(os.path.dirname(_LOG)):
         with open(_LOG, "a") as f:
             f.write(f"{what!r} | systems {total} | measured bar needed {needed} | largest error among them {worst_err:.3e} | "
                     f"widest bar granted {widest_bar:.3e} | iteration counts inside the oracle's range only {iteration_exceptions} | "
-                    f"beyond the ceiling (oracle spread > {BAR_CEILING / 20:.0e}: judged by residual) {beyond}\n")
+                    f"beyond the ceiling (oracle spread > {BAR_CEILING / 20:.0e}: judged by residual) {beyond} | "
+                    f"largest coordinate error among those {beyond_err:.3e} (granted up to {beyond_bar:.3e}, never above {BEYOND_CEILING:.0e})\n")
 
 
 def residual_inf(recs, x):
@@ -105,14 +110,14 @@ def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, li
     if check_iterations:
         plain &= np.asarray(iterations).astype(np.int64) == np.asarray(it).astype(np.int64)
     needed = beyond = 0
-    worst_err = widest_bar = 0.0
+    worst_err = widest_bar = beyond_err = beyond_bar = 0.0
     iteration_exceptions = 0
     for b in np.nonzero(~plain)[0]:
         needed += 1
         for k in (K_PERTURBED, 32, 96):
             its, convs, spread, answers = oracle_spread(recs, x0[b], cfg, linsolve, k, answers=True)
             over = 20.0 * spread > BAR_CEILING  # the oracle's own answers are not reproducible to the reference's tolerance
-            bar = 20.0 * spread if over else max(rel, 20.0 * spread)
+            bar = min(20.0 * spread, BEYOND_CEILING) if over else max(rel, 20.0 * spread)
             inside = (not check_iterations or min(its) <= int(iterations[b]) <= max(its)) and bool(converged[b]) in convs and \
                 err[b] <= bar
             if inside:
@@ -124,6 +129,7 @@ def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, li
         assert err[b] <= bar, (what, int(b), float(err[b]), spread, bar)
         if over:  # judged by what is still well defined: the quality of the answer as a solution of the constraints
             beyond += 1
+            beyond_err, beyond_bar = max(beyond_err, float(err[b])), max(beyond_bar, bar)
             r_mine, unsat_mine = residual_inf(recs, x[b])
             theirs = [residual_inf(recs, a) for a in answers if not np.any(np.isnan(a))]
             r_theirs = max([r for r, _ in theirs] + [1e-8])
@@ -131,5 +137,5 @@ def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, li
             assert any(unsat_mine == u for _, u in theirs), (what, int(b), "unsatisfied", sorted(unsat_mine))
         else:
             worst_err, widest_bar = max(worst_err, float(err[b])), max(widest_bar, bar)
-    _log(what, len(x), needed, worst_err, widest_bar, iteration_exceptions, beyond)
+    _log(what, len(x), needed, worst_err, widest_bar, iteration_exceptions, beyond, beyond_err, beyond_bar)
     return needed

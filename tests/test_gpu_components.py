@@ -2,11 +2,15 @@
 component, class programs read through the scalar unit), through the C ABI, against the CPU oracle and against the
 list-walk kernels.  Same tolerances as test_gpu_parity.py; block systems are additionally bitwise equal to the oracle
 (every component is factorised in the same order with the same operations)."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 import gen
-from conftest import read_case
+from conftest import ROOT, read_case
 from oracle import oracle as O
 from oracle import textual as T
 
@@ -250,6 +254,40 @@ def test_registered_host_buffers_pipeline_gives_the_same_results(E):
         finally:
             E.host_unregister(xin)
             E.host_unregister(out)
+
+
+def test_registered_buffers_copy_out_kernel_with_odd_rows():
+    """The pipeline's copy out as a kernel (EZPZ_H2H_OUT=kernel: what a process on a HIP runtime older than 7.2 takes by itself)
+    on a system of an ODD number of variables and an odd number of systems: pieces then start and end on odd doubles, which the
+    16-byte copy kernel used to cut short (the last double of a piece stayed unwritten with a status of success).  In a process
+    of its own: the switch is read once."""
+    code = """
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import ezpz_amd as E, gen
+from oracle import oracle as O
+pts = 3
+cons = [O.fixed(0, 0.0), O.fixed(1, 0.0), O.distance((0, 1), (2, 3), 2.0), O.horizontal((0, 1), (2, 3)), O.distance((2, 3), (4, 5), 1.5),
+        O.vertical((2, 3), (4, 5)), O.fixed(6, 7.0)]
+recs, n = O.stack(cons), 7
+B = 200001
+x0 = np.ascontiguousarray(np.array([0.1, 0.1, 1.9, 0.2, 2.1, 1.4, 6.0])[None, :] + gen.keyed_uniform(7, B, n, -0.05, 0.05))
+s = E.System(recs, n)
+want_x, want_st, _ = s.solve_batch(x0)
+out = np.full_like(x0, np.nan)
+E.host_register(x0); E.host_register(out)
+st = np.zeros(B, dtype=E.STATUS_DTYPE)
+cfg = E.Config()._c()
+rc = E.lib().ezpz_system_solve_batch(s._h, x0.ctypes.data, B, C.byref(cfg), out.ctypes.data, st.ctypes.data, None, None, 0)
+E.host_unregister(x0); E.host_unregister(out)
+assert rc == 0
+assert not np.isnan(out).any(), int(np.isnan(out).sum())
+assert np.array_equal(out, want_x) and np.array_equal(st["iterations"], want_st["iterations"])
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, EZPZ_H2H_OUT="kernel", EZPZ_H2H_PIECE_MB="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("lines,over", [(12000, False), (12000, True), (3000, True)])

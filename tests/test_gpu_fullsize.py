@@ -74,7 +74,7 @@ def test_one_million_mixed_systems_full_size(E):
         free = sysobj.freedom_batch(x[sample])[0].astype(bool)
         rel = np.abs(x[sample] - xo) / np.maximum(1.0, np.abs(xo))
         assert np.max(np.where(free, 0.0, rel)) <= 1e-6, name
-        assert np.max(np.where(free, rel, 0.0)) <= 2e-4, name  # held by lambda only (tests.rs:630-637)
+        assert np.max(np.where(free, rel, 0.0)) <= 1e-4, name  # held by lambda only (tests.rs:630-637): the reference's EPSILON (lib.rs:43), measured worst 3e-5
         # the specialised lane kernel gives the same answers
         if sysobj.specialize(wait=True) == 2:
             x2, st2, _ = sysobj.solve_batch(x0)

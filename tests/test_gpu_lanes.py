@@ -95,7 +95,7 @@ def test_jittered_batches_match_the_oracle_and_the_list_walk_kernel(E, case):
     assert np.array_equal(mask, maskw) and np.array_equal(st["n_warnings"], stw["n_warnings"])
     free = sysobj.freedom_batch(x[:64])[0].astype(bool).any(axis=0)
     assert_x_close(x[:, ~free], xo[:, ~free])
-    assert_x_close(x[:, free], xo[:, free], 2e-4)
+    assert_x_close(x[:, free], xo[:, free], 1e-4)  # (the reference's own tolerance, lib.rs:43; measured worst 3e-5)
     assert np.max(np.abs(st["final_residual_inf"] - stw["final_residual_inf"])) <= 1e-9
     # ragged batch sizes: fewer systems than lanes, not a multiple of the wavefront
     for b in (1, 3, 65, 257):

@@ -1,14 +1,15 @@
 """profiles/rNN_parity_bar.txt from the raw log tests/sensitivity.py appends to gpurun_out/parity_bar.txt during a GPU run:
 totals first, then every call in which a system needed the measured bar (calls that needed none are only counted).
-usage: python tools/parity_bar_summary.py gpurun_out/parity_bar.txt "<what was run>" > profiles/r04_parity_bar.txt"""
+usage: python tools/parity_bar_summary.py gpurun_out/parity_bar.txt "<what was run>" > profiles/r05_parity_bar.txt"""
 import re
 import sys
 
 rx = re.compile(r"systems (\d+) \| measured bar needed (\d+) \| largest error among them ([\d.e+-]+) \| widest bar granted ([\d.e+-]+) \| "
-                r"iteration counts inside the oracle's range only (\d+) \| beyond the ceiling .*?\) (\d+)")
+                r"iteration counts inside the oracle's range only (\d+) \| beyond the ceiling .*?\) (\d+)"
+                r"(?: \| largest coordinate error among those ([\d.e+-]+) \(granted up to ([\d.e+-]+))?")
 lines = [l.rstrip("\n") for l in open(sys.argv[1]) if l.strip()]
 tot = need = beyond = its = clean = 0
-worst = widest = 0.0
+worst = widest = b_err = b_bar = 0.0
 listed = []
 for l in lines:
     m = rx.search(l)
@@ -17,6 +18,8 @@ for l in lines:
     t, n, e, w, i, b = int(m[1]), int(m[2]), float(m[3]), float(m[4]), int(m[5]), int(m[6])
     tot, need, beyond, its = tot + t, need + n, beyond + b, its + i
     worst, widest = max(worst, e), max(widest, w)
+    if m[7]:
+        b_err, b_bar = max(b_err, float(m[7])), max(b_bar, float(m[8]))
     if n:
         listed.append(l)
     else:
@@ -26,7 +29,8 @@ print(f"# {tot} systems checked in {len(lines)} calls; {need} ({100.0 * need / m
       f"to the measured one: coordinates within max(1e-6, 20 x the oracle's own spread under one-ulp moves of the start), never above "
       f"the reference's 1e-4.  {need - beyond} of them were judged by coordinates (largest error {worst:.2e}, widest bar granted {widest:.2e}); "
       f"{beyond} are (system, shape, start) checks of systems whose ORACLE answers differ among themselves by more than 5e-6: judged by "
-      f"residual and unsatisfied set instead (last column).  {its} iteration counts were inside the oracle's range rather than equal.")
+      f"residual and unsatisfied set instead, their coordinates within 20 x that spread and never above 1e-2 (largest coordinate error among "
+      f"them {b_err:.2e}, widest bar granted {b_bar:.2e}).  {its} iteration counts were inside the oracle's range rather than equal.")
 print(f"# calls in which no system needed the measured bar: {clean} (not listed); the other {len(listed)} follow.")
 for l in listed:
     print(l)
