@@ -47,15 +47,16 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t l) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// 1 / sqrt(p) from the hardware's estimate and two coupled Newton steps (as the record walk's rounds)
+// 1 / sqrt(p) from the hardware's estimate y0 (about 26 bits) and ONE third-order step: with e = 1 - p y0^2,
+// y1 = y0 (1 + e / 2 + 3 e^2 / 8) leaves an error of order e^3 -- below the last bit -- in four dependent operations where two
+// coupled Newton steps are seven; the pivot chain of a front is this sequence K times.
 __device__ __forceinline__ double rsqrt_newton(double p) {
     const double y0 = __builtin_amdgcn_rsq(p);
-    const double g0 = p * y0, h0 = 0.5 * y0;
-    const double r0 = __builtin_fma(-g0, h0, 0.5);
-    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
-    const double r1 = __builtin_fma(-g1, h1, 0.5);
-    const double h2 = __builtin_fma(h1, r1, h1);
-    return h2 + h2;
+    const double t = p * y0;
+    const double e = __builtin_fma(-t, y0, 1.0);
+    const double s = __builtin_fma(e, 0.375, 0.5);
+    const double u = y0 * e;
+    return __builtin_fma(u, s, y0);
 }
 
 // What a wavefront needs to work on a front of its workgroup.
@@ -515,7 +516,8 @@ __global__ void __launch_bounds__(THREADS, 1) front_solve_kernel(const FrontArgs
     }
     const uint32_t n_loc = W.n_loc, n_own = W.n_own, n_cons = W.n_cons, m = W.n_rows, zj = W.zj, nlev = W.n_levels;
     const uint32_t* const var_glob = reinterpret_cast<const uint32_t*>(a.plan + W.o_var_glob);
-    const DevCon* const cons = reinterpret_cast<const DevCon*>(a.plan + W.o_cons);
+    // (the constraint table: its copy in the staged tables when the planner found room for one, else global memory)
+    const DevCon* const cons = W.t_cons != 0xFFFFFFFFu ? reinterpret_cast<const DevCon*>(tab + W.t_cons) : reinterpret_cast<const DevCon*>(a.plan + W.o_cons);
     const FrontGhost* const ghosts = reinterpret_cast<const FrontGhost*>(a.plan + W.o_ghosts);
     double* const xs = ws + W.l_x;
     double* const dv = ws + W.l_d;

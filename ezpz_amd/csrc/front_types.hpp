@@ -73,11 +73,12 @@ struct alignas(16) FrontWg {
     uint32_t t_level_ptr, t_children, t_rows, t_exports, t_maps;  // byte offsets inside the staged tables
     uint32_t t_stream;                // ... of the streams (uint32 words): the fronts' source streams, then the assembly stream
     uint32_t asm_word0, asm_trips;    // the assembly stream: its first word in the streams, its trips of 64 entries
+    uint32_t t_cons;                  // byte offset of a copy of the constraint table inside the staged tables, or ~0: read it at o_cons
     uint32_t o_ghosts;                // FrontGhost[n_ghost]
     uint32_t l_x, l_d, l_r, l_rn, l_jv, l_panels, l_upool;  // workspace carve-up (doubles)
     uint32_t ws_doubles;              // workspace doubles (state), tables excluded
     uint32_t n_remote_children;       // fronts of this workgroup that wait for chunks of other workgroups
-    uint32_t pad[2];
+    uint32_t pad[1];
 };
 static_assert(sizeof(FrontWg) % 16 == 0, "FrontWg layout");
 

@@ -885,6 +885,14 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             W.t_maps = T.put(maps);
             W.t_stream = T.put(stream_words);
             tab.resize((tab.size() + 15) & ~size_t(15), 0);
+            // the constraint table rides along where the LDS has room to spare (the sweeps then read their 80-byte records from
+            // LDS instead of L2: two sweeps per iteration)
+            W.t_cons = 0xFFFFFFFFu;
+            const size_t extras = 2 * 4 * 16 * 8 + 2080 * 2 + 64;
+            if (!dcons.empty() && (tab.size() + dcons.size() * sizeof(DevCon) + (size_t)W.ws_doubles * 8 + extras) * 5 <= opt.lds_bytes * 4) {
+                W.t_cons = T.put(dcons);
+                tab.resize((tab.size() + 15) & ~size_t(15), 0);
+            }
             W.o_tables = B.put(tab);
             W.tab_bytes = (uint32_t)tab.size();
         }

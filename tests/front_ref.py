@@ -19,8 +19,8 @@ FRONT_CHILD = np.dtype([("upd", "<u4"), ("rows", "<u2"), ("flags", "<u2"), ("map
 assert FRONT_CHILD.itemsize == 16
 FRONT_GHOST = np.dtype([("local", "<u4"), ("chunk", "<u4")])
 WG_FIELDS = ["n_loc", "n_own", "n_ghost", "n_cons", "n_rows", "zj", "n_fronts", "n_levels", "o_var_glob", "o_cons", "o_tables",
-             "tab_bytes", "t_level_ptr", "t_children", "t_rows", "t_exports", "t_maps", "t_stream", "asm_word0", "asm_trips", "o_ghosts", "l_x", "l_d", "l_r",
-             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "pad0", "pad1"]
+             "tab_bytes", "t_level_ptr", "t_children", "t_rows", "t_exports", "t_maps", "t_stream", "asm_word0", "asm_trips", "t_cons", "o_ghosts", "l_x", "l_d", "l_r",
+             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "pad0"]
 FRONT_WG = np.dtype([(f, "<u4") for f in WG_FIELDS])
 assert FRONT_WG.itemsize == 128
 DEVCON = np.dtype([("ids", "<u4", (8,)), ("param", "<f8"), ("weight", "<f8"), ("row0", "<u4"), ("jbase", "<u4"), ("pos", "<u4"),
@@ -106,7 +106,8 @@ def linear_step(plan, x_caller, lam):
         descs, level_ptr, children, rows, exports, maps = plan.wg_tables(g)
         w = ws[g]
         r, jv = evals[g]
-        stream = plan.arr("<u4", int(W["o_tables"]) + int(W["t_stream"]), (int(W["tab_bytes"]) - int(W["t_stream"])) // 4)
+        t_end = int(W["t_cons"]) if int(W["t_cons"]) != 0xFFFFFFFF else int(W["tab_bytes"])
+        stream = plan.arr("<u4", int(W["o_tables"]) + int(W["t_stream"]), (t_end - int(W["t_stream"])) // 4)
         pan = int(W["l_panels"])
         # the assembly of the linear solve: panels and update matrices zeroed, then the workgroup's assembly stream
         w[pan:] = 0.0

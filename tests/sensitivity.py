@@ -16,7 +16,7 @@ when every start coordinate is moved by one ulp.  So the bar for a system is mea
                   excused but judged on what remains well defined -- its answer must satisfy the constraints as well as
                   the oracle's runs do (max |r| <= 10 x the worst of theirs, floor 1e-8 = residual_tolerance; the same
                   constraints unsatisfied at EPSILON) on top of the iteration and convergence checks, and still lie within
-                  20 x the oracle's own spread AND within 1e-2 whatever that spread -- and is counted separately in the log
+                  20 x the oracle's own spread AND within max(1e-2, twice that spread) -- and is counted separately in the log
                   ("beyond the ceiling"), with the coordinate error it was actually granted
     iterations    equal to the oracle's, or inside the range of counts those K + 1 oracle runs produce (the counts of a
                   chaotic path are samples -- comb 51 of the graph fuzz gives 18, 20, 22, 24, 28, 32 ... 50 over 96
@@ -38,7 +38,8 @@ BAR_CEILING = 1e-4  # the reference's own test tolerance: the measured bar never
 _LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_bar.txt")
 
 
-BEYOND_CEILING = 1e-2  # ... and what a system "beyond the ceiling" may differ by at most, whatever its oracle spread
+BEYOND_CEILING = 1e-2  # ... and what a system "beyond the ceiling" may differ by at most -- or twice its oracle's own spread where THAT
+                       # exceeds 5e-3 (comb 51: the oracle's answers differ among themselves by 1.2e-2 under one-ulp moves)
 
 
 def _log(what, total, needed, worst_err, widest_bar, iteration_exceptions, beyond, beyond_err=0.0, beyond_bar=0.0):
@@ -47,7 +48,7 @@ def _log(what, total, needed, worst_err, widest_bar, iteration_exceptions, beyon
             f.write(f"{what!r} | systems {total} | measured bar needed {needed} | largest error among them {worst_err:.3e} | "
                     f"widest bar granted {widest_bar:.3e} | iteration counts inside the oracle's range only {iteration_exceptions} | "
                     f"beyond the ceiling (oracle spread > {BAR_CEILING / 20:.0e}: judged by residual) {beyond} | "
-                    f"largest coordinate error among those {beyond_err:.3e} (granted up to {beyond_bar:.3e}, never above {BEYOND_CEILING:.0e})\n")
+                    f"largest coordinate error among those {beyond_err:.3e} (granted up to {beyond_bar:.3e}: min(20 x spread, max({BEYOND_CEILING:.0e}, 2 x spread)))\n")
 
 
 def residual_inf(recs, x):
@@ -117,7 +118,7 @@ def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, li
         for k in (K_PERTURBED, 32, 96):
             its, convs, spread, answers = oracle_spread(recs, x0[b], cfg, linsolve, k, answers=True)
             over = 20.0 * spread > BAR_CEILING  # the oracle's own answers are not reproducible to the reference's tolerance
-            bar = min(20.0 * spread, BEYOND_CEILING) if over else max(rel, 20.0 * spread)
+            bar = min(20.0 * spread, max(BEYOND_CEILING, 2.0 * spread)) if over else max(rel, 20.0 * spread)
             inside = (not check_iterations or min(its) <= int(iterations[b]) <= max(its)) and bool(converged[b]) in convs and \
                 err[b] <= bar
             if inside:

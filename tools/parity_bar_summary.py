@@ -29,7 +29,7 @@ print(f"# {tot} systems checked in {len(lines)} calls; {need} ({100.0 * need / m
       f"to the measured one: coordinates within max(1e-6, 20 x the oracle's own spread under one-ulp moves of the start), never above "
       f"the reference's 1e-4.  {need - beyond} of them were judged by coordinates (largest error {worst:.2e}, widest bar granted {widest:.2e}); "
       f"{beyond} are (system, shape, start) checks of systems whose ORACLE answers differ among themselves by more than 5e-6: judged by "
-      f"residual and unsatisfied set instead, their coordinates within 20 x that spread and never above 1e-2 (largest coordinate error among "
+      f"residual and unsatisfied set instead, their coordinates within min(20 x that spread, max(1e-2, 2 x that spread)) (largest coordinate error among "
       f"them {b_err:.2e}, widest bar granted {b_bar:.2e}).  {its} iteration counts were inside the oracle's range rather than equal.")
 print(f"# calls in which no system needed the measured bar: {clean} (not listed); the other {len(listed)} follow.")
 for l in listed:
