@@ -63,11 +63,14 @@ PMC_SETS = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
 ]
-SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel", "ezpz_jit_solve", "ezpz_jit_lane", "batch_lane_kernel")
+SOLVE_KERNELS = ("lm_solve_kernel", "comp_solve_kernel", "ezpz_jit_solve", "ezpz_jit_lane", "batch_lane_kernel", "front_solve_kernel")
 # The other BASELINE.json configurations, as (workload, systems per launch at N = 1): configs[2], [4], [3], and the
 # connected-sketch batches of DESIGN.md section 3 (one lane per system at 262 144 systems per launch; the per-system teams'
 # record walk at 32 768).  Short legs after the headline; the mixed batch is sharded over the ranks.
-LEGS = [("square", 65536), ("mixed", 1 << 20), ("massive50000", 64), ("sketch150", 262144), ("sketch150", 32768)]
+# ... and ONE solve of a 2000-variable connected sketch on the frontal shape (team 0xFFFFFFFF = the automatic latency shape:
+# a tree of dense fronts on several workgroups): a launch is one solve, its roofs are over the CUs it uses.
+LEGS = [("square", 65536, 0), ("mixed", 1 << 20, 0), ("massive50000", 64, 0), ("sketch150", 262144, 0), ("sketch150", 32768, 0),
+        ("sketch1000", 1, 0xFFFFFFFF)]
 
 
 def algorithmic_bytes(info: dict, k: int) -> int:
@@ -77,14 +80,15 @@ def algorithmic_bytes(info: dict, k: int) -> int:
     return (1 + k) * (56 * C + 8 * n + 8 * m + 8 * zj) + k * (12 * zj + 8 * m + 16 * za + 24 * zl + 48 * n)
 
 
-def cpu_baseline(records, guesses, budget_s: float):
+def cpu_baseline(records, guesses, budget_s: float, max_iterations: int = 0):
     """Oracle (`kind: port`) timed on one core with the CLI protocol (ezpz-cli/src/main.rs:86-100)."""
     from oracle import oracle as O
 
-    secs, iters = O.time_solves(records, guesses, repeats=20, linsolve=O.LINSOLVE_SPARSE)
+    ocfg = O.Config(max_iterations=max_iterations) if max_iterations else None
+    secs, iters = O.time_solves(records, guesses, repeats=20, config=ocfg, linsolve=O.LINSOLVE_SPARSE)
     per = max(secs / 20.0, 1e-7)
-    repeats = int(min(max(budget_s / per, 100), 200000))
-    secs, iters = O.time_solves(records, guesses, repeats=repeats, linsolve=O.LINSOLVE_SPARSE)
+    repeats = int(min(max(budget_s / per, 100 if per < 1e-3 else 5), 200000))
+    secs, iters = O.time_solves(records, guesses, repeats=repeats, config=ocfg, linsolve=O.LINSOLVE_SPARSE)
     out = {"value": repeats / secs, "unit": "solves/s", "cores": 1, "kind": "port",
            "sample": f"{repeats} back-to-back full solve() calls (setup + sparse LLT + LM, {iters} iterations each) "
                      f"of the same system on 1 core in {secs:.1f} s"}
@@ -96,7 +100,7 @@ def cpu_baseline(records, guesses, budget_s: float):
     nb = int(min(max(out["value"] * cores * min(budget_s, 4.0), 4 * cores), max(64, (256 << 20) // (8 * max(len(guesses), 1)))))
     x0 = np.tile(np.asarray(guesses, dtype=np.float64), (nb, 1))
     t0 = time.perf_counter()
-    O.solve_batch(records, x0, linsolve=O.LINSOLVE_SPARSE, nthreads=cores)
+    O.solve_batch(records, x0, ocfg, linsolve=O.LINSOLVE_SPARSE, nthreads=cores)
     out["all_cores"] = {"value": nb / (time.perf_counter() - t0), "unit": "solves/s", "cores": cores,
                         "sample": f"{nb} replicas, OpenMP over systems"}
     return out
@@ -111,7 +115,8 @@ def parse_args(argv=None):
                     help="systems per launch per GPU (the gap between launches and the partly empty last round of the 768 resident "
                          "workgroups are 2000 x 2000's 4096: 81.9, 16 384: 88.4, 32 768: 92.0, 65 536: 93.5, 131 072: 92.8 M solves/s)")
     ap.add_argument("--workload", default="massive500", help="massive<lines>[o] (o = over-constrained variant), sketch<points> (one connected sketch), a test_cases/ directory name, or mixed")
-    ap.add_argument("--team", type=int, default=0, help="override lanes per system (0 = auto)")
+    ap.add_argument("--team", type=lambda v: int(v, 0), default=0, help="override lanes per system (0 = auto; 0xFFFFFFFF = the automatic shape for one solve)")
+    ap.add_argument("--max-iterations", type=int, default=0, help="Config.max_iterations (0 = the reference's default, 35)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--check", type=int, default=1, help="verify the results of the last step against the oracle")
     ap.add_argument("--extras", type=int, default=1, help="also report the host-to-host rate, single-solve latency (and, "
@@ -182,7 +187,7 @@ def dry_run(args, world, rank) -> int:
     return 0
 
 
-def collect_pmc(args, workload=None, batch=None, sets=None) -> dict:
+def collect_pmc(args, workload=None, batch=None, sets=None, team=None) -> dict:
     """Per-launch means of the PMC counters of the solve kernel, from rocprofv3 child passes of this script with the
     same workload (one counter set per pass; the profiler's child is this interpreter running bench.py itself)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -193,7 +198,7 @@ def collect_pmc(args, workload=None, batch=None, sets=None) -> dict:
     env = dict(os.environ, TMPDIR="/tmp")
     # the interpreter that runs this script (a plain ELF placed directly after `--`: no env / shim hop under the profiler)
     child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--workload", workload or args.workload,
-             "--batch", str(batch or args.batch), "--team", str(args.team), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
+             "--batch", str(batch or args.batch), "--team", str(team if team is not None else args.team), "--max-iterations", str(args.max_iterations), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
              "--check", "0", "--extras", "0", "--pmc", "0", "--legs", "0", "--specialize", str(args.specialize)]
     counters, errors = {}, []
     for i, cset in enumerate(sets or PMC_SETS):
@@ -226,6 +231,11 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels, 
     units of the device the kernel ran on (4 SIMDs each)."""
     t = kernel_ms * 1e-3
     n_simds = 4 * n_cus
+    if n_kernels > 1 and pmc:
+        # a step of several kernels (the mixed batch: one per topology): collect_pmc returns the mean over DISPATCHES, every
+        # other figure here is per STEP -- round 4 compared one kernel's traffic with the whole step's compulsory bytes
+        # (traffic_over_compulsory 0.69); the counters of a step are the per-dispatch means times the kernels of a step
+        pmc = {k: (v * n_kernels if isinstance(v, float) and not k.startswith("_") else v) for k, v in pmc.items()}
     compulsory = sum((16 * p["info"]["n_vars"] + 32) * p["B"] for p in info_parts)  # bytes per launch
     hbm = {"achieved": compulsory / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "compulsory_bytes_per_solve": compulsory / B}
@@ -290,11 +300,12 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels, 
 class Workload:
     """One workload resident on this rank's device: systems (one per topology), jittered guesses in HBM, outputs."""
 
-    def __init__(self, E, torch, name, batch, device_index, dev, team, specialize, seed_rank):
+    def __init__(self, E, torch, name, batch, device_index, dev, team, specialize, seed_rank, max_iterations=0):
         # BASELINE configs[4] flavour: system i uses [circle_tangent, parallelogram, arc_radius][i mod 3]; the batch is
         # grouped by topology (one launch per topology per step).  Everything else is a single-topology batch.
         names = ["circle_tangent", "parallelogram", "arc_radius"] if name == "mixed" else [name]
         self.E, self.torch, self.dev, self.batch = E, torch, dev, batch
+        self.config = E.Config(max_iterations=max_iterations) if max_iterations else None
         self.stream = torch.cuda.current_stream(dev)
         self.parts = []
         for k, nm in enumerate(names):
@@ -340,7 +351,7 @@ class Workload:
             return
         for p in self.parts:
             p["system"].solve_batch_device(p["x0"].data_ptr(), p["B"], p["x_out"].data_ptr(), p["status"].data_ptr(), 0,
-                                           self.stream.cuda_stream)
+                                           self.stream.cuda_stream, self.config)
 
     def sync_parts(self):
         """The mixed batch's results, per topology (the checks below read the per-topology tensors)."""
@@ -359,7 +370,7 @@ class Workload:
         import numpy as np
 
         E = self.E
-        cfg = E.Config()._c()
+        cfg = (self.config or E.Config())._c()
         self.sync_parts()
         if self.mixed is not None:
             hx, hxo = np.ascontiguousarray(self.x0_ragged_host), np.empty_like(self.x0_ragged_host)
@@ -443,7 +454,8 @@ class Workload:
         for p in self.parts:
             Bp = p["B"]
             sample = np.arange(0, Bp, max(1, Bp // per_part))[:per_part]
-            rc, xo, it, conv, nun = O.solve_batch(p["records"], p["x0_host"][sample], linsolve=O.LINSOLVE_SPARSE)
+            ocfg = O.Config(max_iterations=self.config.max_iterations) if self.config else None
+            rc, xo, it, conv, nun = O.solve_batch(p["records"], p["x0_host"][sample], ocfg, linsolve=O.LINSOLVE_SPARSE)
             xg = p["x_out"][torch.from_numpy(sample).to(self.dev)].cpu().numpy()
             stp = p["status"].cpu().numpy().view(self.E.STATUS_DTYPE).reshape(-1)
             rel = np.abs(xg - xo) / np.maximum(1.0, np.abs(xo))
@@ -467,7 +479,7 @@ class Workload:
         return total
 
 
-def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, backend, n_cus):
+def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, backend, n_cus, team=0):
     """One short leg over another BASELINE configuration: steady-state warm-up, a few timed launches bracketed like the
     headline's (barrier + synchronize, max over ranks), iterations, oracle check, roofs (hbm always; issue from one PMC
     pass at N = 1)."""
@@ -477,7 +489,7 @@ def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, b
     # whether it is ready, and the leg runs only if all are)
     w, ran, failure = None, 0, None
     try:
-        w = Workload(E, torch, name, batch, device_index, dev, args.team, args.specialize, rank)
+        w = Workload(E, torch, name, batch, device_index, dev, team or args.team, args.specialize, rank, args.max_iterations)
         ran = w.warm_to_steady_state(2)
     except Exception as exc:  # noqa: BLE001
         failure = repr(exc)[:300]
@@ -531,10 +543,19 @@ def run_leg(E, torch, dist, args, name, batch, world, rank, device_index, dev, b
         # (the kernel that keeps its state in HBM -- lanes across the batch, sketch150 x 262 144 -- gets its traffic measured too:
         # its bound is read from the counters, not from the model)
         sets = [PMC_SETS[1]] + (PMC_SETS[2:] if name.startswith("sketch") and batch >= 65536 else [])
-        pmc = collect_pmc(args, workload=name, batch=batch, sets=sets) if (args.pmc and world == 1) else {}
+        pmc = collect_pmc(args, workload=name, batch=batch, sets=sets, team=team or None) if (args.pmc and world == 1) else {}
         r = roofline(w.parts, batch, kernel_ms, w.algorithmic_launch_bytes(), pmc, len(w.parts), n_cus)
         out["roofline"] = {"bound": r["bound"], "frac": r["frac"], "kernel_ms": kernel_ms,
                            "roofs": {k: v["frac"] for k, v in r["roofs"].items()}}
+        info0 = w.parts[0]["info"]
+        if info0.get("team_mode") == 5:
+            # the frontal shape: a launch of `batch` systems runs on batch x grid_workgroups workgroups, one per CU -- a single solve
+            # uses a few CUs of the chip, and the issue / LDS roofs that mean something are those of the CUs it runs on
+            active = min(n_cus, batch * int(info0["grid_workgroups"]))
+            out["roofline"]["active_cus"] = active
+            out["roofline"]["workgroups_per_system"] = int(info0["grid_workgroups"])
+            out["roofline"]["roofs_of_active_cus"] = {k: r["roofs"][k]["frac"] * n_cus / active for k in ("issue", "lds") if k in r["roofs"]}
+            out["roofline"]["fronts"] = int(info0["n_partitions"])
         if "wave_cycles_waiting_frac" in r["roofs"].get("issue", {}):
             out["roofline"]["wave_cycles_waiting_frac"] = r["roofs"]["issue"]["wave_cycles_waiting_frac"]
         if r["roofs"]["hbm"].get("state"):
@@ -675,7 +696,7 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    w = Workload(E, torch, args.workload, args.batch, device_index, dev, args.team, args.specialize, rank)
+    w = Workload(E, torch, args.workload, args.batch, device_index, dev, args.team, args.specialize, rank, args.max_iterations)
     parts, stream, B = w.parts, w.stream, args.batch
     p0 = parts[0]
     desc, records, guesses, jitter, expect_iters = w.desc, p0["records"], p0["guesses"], p0["jitter"], p0["expect"]
@@ -780,12 +801,12 @@ def main():
     # mixed batch -- BASELINE configs[4], "batch-sharded across 8 x MI355X" -- runs, split over the ranks
     legs = []
     if args.legs and args.workload == "massive500":
-        for name, lb in LEGS:
+        for name, lb, lteam in LEGS:
             if world > 1 and name != "mixed":
                 continue
             try:
                 # (the headline's tensors are small; a leg's go away with its Workload)
-                legs.append(run_leg(E, torch, dist, args, name, lb // world, world, rank, device_index, dev, backend, n_cus))
+                legs.append(run_leg(E, torch, dist, args, name, max(1, lb // world), world, rank, device_index, dev, backend, n_cus, team=lteam))
             except Exception as exc:  # noqa: BLE001  (a leg must not cost the run its headline)
                 legs.append({"workload": name, "error": repr(exc)[:300]})
             torch.cuda.empty_cache()
@@ -829,6 +850,11 @@ def main():
         }
         if pmc:
             line["pmc_per_launch"] = {k: v for k, v in pmc.items() if not k.startswith("_")}
+        if info.get("team_mode") == 5:  # the frontal shape: the roofs of the CUs a launch runs on (see run_leg)
+            active = min(n_cus, B * int(info["grid_workgroups"]))
+            r_ = line["roofline"]
+            r_["active_cus"], r_["workgroups_per_system"], r_["fronts"] = active, int(info["grid_workgroups"]), int(info["n_partitions"])
+            r_["roofs_of_active_cus"] = {k: r_["roofs"][k]["frac"] * n_cus / active for k in ("issue", "lds") if k in r_["roofs"]}
         if checked:
             line["oracle_check"] = checked
         if legs:
@@ -836,7 +862,7 @@ def main():
         if extras:
             line["extras"] = extras
         if args.cpu_seconds > 0 and world == 1:
-            line["cpu_baseline"] = cpu_baseline(records, guesses, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(records, guesses, args.cpu_seconds, args.max_iterations)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if distributed:
