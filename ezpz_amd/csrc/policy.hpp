@@ -60,7 +60,7 @@ inline EzpzLaunchPolicy launch_policy_for(int compute_units) {
     p.front_min_vars_one_solve = 48;
     p.front_min_vars_batch = 0;
     p.front_vars_per_workgroup = 160;
-    p.front_max_workgroups = 32;
+    p.front_max_workgroups = 64;  // (20 000 variables need 48 to fit their shares into the LDS)
     return p;
 }
 

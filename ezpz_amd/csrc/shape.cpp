@@ -680,6 +680,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             fo.wgs = (for_latency || force_fronts) ? 0u : 1u;
             if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
             fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
+            if (const char* e = std::getenv("EZPZ_FRONT_MAX_WGS")) fo.max_wgs = std::max(1, std::atoi(e));  // (A/B runs)
             fo.vars_per_wg = pol.front_vars_per_workgroup;
             if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
             fo.lds_bytes = s.lim.lds_bytes;

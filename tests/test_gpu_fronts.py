@@ -147,6 +147,26 @@ def test_failed_pivots_limits_and_nan_starts_on_fronts(E, wgs):
             assert np.nanmax(err, initial=0.0) <= 1e-6, (cfg, b, float(np.nanmax(err, initial=0.0)))
 
 
+@pytest.mark.parametrize("npts", [2500, 10000])
+def test_large_connected_sketches_on_many_workgroups(E, npts):
+    """5000 and 20 000 variables: the planner's own choice of workgroups (22 and 64: the shares must fit one CU's LDS each), the
+    top of the tree on workgroup 0, update matrices and steps between workgroups as chunks.  Two starts against the oracle."""
+    recs, g = gen.connected_sketch(npts, 1000 + npts)
+    n = len(g)
+    s, info = front_system(E, recs, n)
+    assert info["grid_workgroups"] >= 16 and info["workspace_in_lds"] == 1, info
+    x0 = np.stack([g, g + gen.keyed_uniform(npts, 1, n, -0.01, 0.01)[0]])
+    cfg = dict(max_iterations=60)
+    x, st, _ = s.solve_batch(x0, E.Config(**cfg))
+    x2, st2, _ = s.solve_batch(x0, E.Config(**cfg))
+    assert np.array_equal(x, x2) and np.array_equal(st["iterations"], st2["iterations"])
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0
+    assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg), oracle_result=(xo, it, conv),
+                                what=("fronts", npts, "auto"))
+    assert np.array_equal(st["n_unsatisfied"], nun)
+
+
 def test_one_solve_call_takes_the_fronts_and_equals_the_oracle(E):
     """ezpz_solve (the reference's protocol, one call per solve: ezpz-cli/src/main.rs:96-98) of a 300-variable connected sketch:
     the automatic latency shape is the frontal one from EzpzLaunchPolicy.front_min_vars_one_solve variables."""
