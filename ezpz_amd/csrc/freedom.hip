@@ -120,10 +120,16 @@ int build_freedom(EzpzSystem* sys) {
 }
 
 // x_dev: final values, caller order.  Everything on `stream`.
+// `done_flag` (optional): a word of mapped host memory; when the call fits ONE launch of one workgroup -- a small system's
+// analysis: values gathered, Jacobian evaluated and analysed by the same kernel -- the kernel stores `done_seq` there at its end and
+// *flagged says so (the caller polls the word instead of the stream: a stream query costs more than this kernel runs).
 int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* mask_dev, double* part_dev,
-                   uint32_t* count_dev, hipStream_t stream) {
+                   uint32_t* count_dev, hipStream_t stream, unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0,
+                   bool* flagged = nullptr) {
     auto& F = sys->freedom;
-    release_thread_kernel(sys->device);
+    // (a kernel of the calling thread's one-call path that waits on the device for its next request holds hipStreamPerThread: work
+    // put there would queue behind it until its lease runs out, so it is told to leave -- unless this call has a stream of its own)
+    if (!done_flag) release_thread_kernel(sys->device);
     int rc = ensure_program(sys);
     if (rc != EZPZ_OK) return rc;
     const size_t n = sys->counts.n_vars, zj = sys->counts.zj;
@@ -136,12 +142,30 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
         if ((rc = F.part.ensure(batch * n)) != EZPZ_OK) return rc;
         part_dev = F.part.p;
     }
-    const uint32_t* var_of = reinterpret_cast<const uint32_t*>(sys->view.base + sys->view.o_var_of);
-    const uint64_t total = (uint64_t)batch * n;
-    hipLaunchKernelGGL(gather_values_kernel, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0,
-                       stream, x_dev, var_of, F.x_int.p, (uint32_t)n, total);
-    launch_eval(sys, F.x_int.p, batch, nullptr, F.jv.p, nullptr, (uint32_t)std::min<size_t>(batch, 8192), stream);
+    // Small calls whose components fit the LDS layouts (LANE, or TEAM with its workspace in LDS) are ONE launch: the kernel gathers
+    // and evaluates itself (FreedomArgs::x_caller).  EZPZ_FREEDOM_FUSE=0: the three launches (A/B runs).
+    static const bool fuse_enabled = [] {
+        const char* e = std::getenv("EZPZ_FREEDOM_FUSE");
+        return !(e && e[0] == '0');
+    }();
+    const size_t head0 = (2 * (size_t)F.group + (F.group + 1) / 2 + 16) * sizeof(double);
+    const bool in_lds = F.lane || head0 + (size_t)F.ws * sizeof(double) <= 128 * 1024;
+    const bool fused = fuse_enabled && in_lds && batch <= 64 && (uint64_t)batch * sys->counts.n_cons <= 4096;
+    if (flagged) *flagged = false;
+    if (!fused) {
+        const uint32_t* var_of = reinterpret_cast<const uint32_t*>(sys->view.base + sys->view.o_var_of);
+        const uint64_t total = (uint64_t)batch * n;
+        hipLaunchKernelGGL(gather_values_kernel, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0,
+                           stream, x_dev, var_of, F.x_int.p, (uint32_t)n, total);
+        launch_eval(sys, F.x_int.p, batch, nullptr, F.jv.p, nullptr, (uint32_t)std::min<size_t>(batch, 8192), stream);
+    }
     FreedomArgs a{};
+    if (fused) {
+        a.x_caller = x_dev;
+        a.x_int = F.x_int.p;
+        a.jv_out = F.jv.p;
+        a.prog = sys->view;
+    }
     a.jv = F.jv.p;
     a.comps = F.comps.p;
     a.items = F.lists.p;
@@ -161,8 +185,16 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
     if (F.lane) {
         const size_t lds = head + (size_t)F.threads * F.ws * sizeof(double);
         const uint32_t grid = (uint32_t)std::min<size_t>((batch + F.group - 1) / F.group, 1u << 16);
-        HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+        static std::atomic<size_t> raised_lane[16];  // (the attribute belongs to the kernel: raised once per device and size)
+        if (raised_lane[sys->device & 15].load(std::memory_order_relaxed) < lds) {
+            HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised_lane[sys->device & 15].store(lds, std::memory_order_relaxed);
+        }
+        if (fused && grid == 1 && done_flag) {
+            a.done_flag = done_flag;
+            a.done_seq = done_seq;
+            if (flagged) *flagged = true;
+        }
         hipLaunchKernelGGL(freedom_kernel<true>, dim3(grid), dim3(F.threads), lds, stream, a);
     } else {
         size_t lds = head + (size_t)F.ws * sizeof(double);
@@ -276,8 +308,16 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                 return EZPZ_OK;
             }
         }
-        HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+        static std::atomic<size_t> raised_team[16];
+        if (raised_team[sys->device & 15].load(std::memory_order_relaxed) < lds) {
+            HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised_team[sys->device & 15].store(lds, std::memory_order_relaxed);
+        }
+        if (fused && grid == 1 && done_flag && !a.gws) {
+            a.done_flag = done_flag;
+            a.done_seq = done_seq;
+            if (flagged) *flagged = true;
+        }
         hipLaunchKernelGGL(freedom_kernel<false>, dim3(grid), dim3(F.threads), lds, stream, a);
     }
     HIP_TRY(hipGetLastError());
@@ -301,9 +341,6 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
                               double* participation) {
     if (!sys || (batch && (!x || !under_mask))) return EZPZ_ERR_INVALID_ARGUMENT;
     if (batch == 0) return EZPZ_OK;
-    // (the calling thread's one-call kernel, if one is waiting on the device for its next request, is told to leave first:
-    // whatever this call puts on a stream would otherwise queue behind it until its lease runs out)
-    release_thread_kernel(sys->device);
     std::lock_guard<std::mutex> lock(sys->mu);
     EZPZ_ON_DEVICE(sys->device);
     auto& F = sys->freedom;
@@ -318,17 +355,34 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
         // was 270 us through a per-call hipMalloc, three blocking copies on the null stream and a hipFree.)
         static thread_local PinnedBuf t_buf[16];
         PinnedBuf& pinned = t_buf[sys->device & 15];
-        if ((rc = pinned.ensure(x_bytes + mask_bytes + part_bytes)) != EZPZ_OK) return rc;
+        // a stream of the thread's own for these calls: the analysis then runs BESIDE a resident one-call kernel of the same thread
+        // (solve_analysis = solve, then this: the solve's kernel keeps waiting for the next solve, no relaunch per call)
+        static thread_local hipStream_t t_stream[16] = {};
+        hipStream_t& fstream = t_stream[sys->device & 15];
+        if (!fstream) HIP_TRY(hipStreamCreateWithFlags(&fstream, hipStreamNonBlocking));
+        if ((rc = pinned.ensure(x_bytes + mask_bytes + part_bytes + 16)) != EZPZ_OK) return rc;
         unsigned char* h = pinned.p;
         std::memcpy(h, x, x_bytes);
         uint8_t* hmask = h + x_bytes;
         double* hpart = participation ? reinterpret_cast<double*>(h + x_bytes + mask_bytes) : nullptr;
-        if ((rc = freedom_device(sys, reinterpret_cast<const double*>(h), batch, hmask, hpart, nullptr, hipStreamPerThread)) != EZPZ_OK) return rc;
-        hipError_t q;
+        // (the completion word behind the buffers: the one-launch form stores the call's sequence number there at its end)
+        unsigned long long* const flag = reinterpret_cast<unsigned long long*>(h + ((x_bytes + mask_bytes + part_bytes + 7) & ~size_t(7)));
+        static thread_local unsigned long long t_seq = 0;
+        const unsigned long long seq = ++t_seq;
+        bool flagged = false;
+        if ((rc = freedom_device(sys, reinterpret_cast<const double*>(h), batch, hmask, hpart, nullptr, fstream, flag, seq, &flagged)) != EZPZ_OK) return rc;
+        hipError_t q = hipSuccess;
         int spins = 0;
-        while ((q = hipStreamQuery(hipStreamPerThread)) == hipErrorNotReady)
+        if (flagged) {
+            // ~6 us launch-to-flag against ~13 us launch-to-hipStreamQuery (tools/launch_floor.hip); a kernel that never signals
+            // (a fault) is caught by the stream after a while
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+                if ((++spins & 0xFFFF) == 0 && hipStreamQuery(fstream) != hipErrorNotReady) break;
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) q = hipStreamSynchronize(fstream);
+        } else
+        while ((q = hipStreamQuery(fstream)) == hipErrorNotReady)
             if (++spins > 4000) {  // (long analyses -- a large component -- block instead of burning a core)
-                q = hipStreamSynchronize(hipStreamPerThread);
+                q = hipStreamSynchronize(fstream);
                 break;
             }
         if (q != hipSuccess) {

@@ -20,6 +20,7 @@
 #include <cstdint>
 
 #include "launch_types.hpp"
+#include "lm_kernel.hip.hpp"  // (the fused form evaluates the Jacobian itself: Prog, load_con / load_packed, the evaluators)
 
 namespace ezpz {
 
@@ -39,6 +40,14 @@ struct FreedomArgs {
     uint32_t ws;     // workspace doubles of the largest component
     uint32_t group;  // LANE: systems per workgroup
     uint32_t qr_done;  // TEAM, global workspace: 1 + the component whose pivoted QR is already in the workspace (step kernels below), 0 = none
+    // FUSED small calls (solve_analysis of one sketch: one launch instead of gather_values + eval + this kernel, round 5): the kernel
+    // gathers the caller-ordered values into the program's order and evaluates the weighted Jacobian there itself
+    const double* x_caller;  // non-null: fused
+    double* x_int;           // [batch][n] scratch
+    double* jv_out;          // = jv
+    ProgramView prog;
+    unsigned long long* done_flag;  // a word of mapped host memory the caller polls (one-workgroup launches), or null
+    unsigned long long done_seq;
 };
 
 constexpr double kFreedomRankTol = 1e-8;  // find_dof.rs:12
@@ -329,6 +338,35 @@ __global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
             under[g] = 0;
         }
         __syncthreads();
+        if (a.x_caller) {  // fused: this workgroup's systems gathered and evaluated here (what gather_values_kernel + eval_kernel do)
+            const Prog<uint32_t> P = make_prog<uint32_t>(a.prog, a.prog.base, a.prog.base);
+            for (uint32_t idx = tid; idx < nsys * a.n; idx += nthr) {
+                const uint32_t g = idx / a.n, v = idx - g * a.n;
+                a.x_int[(base + g) * a.n + v] = a.x_caller[(base + g) * a.n + P.var_of[v]];
+            }
+            __threadfence_block();
+            __syncthreads();
+            const uint32_t n_cons = a.prog.n_cons;
+            for (uint32_t idx = tid; idx < nsys * n_cons; idx += nthr) {
+                const uint32_t g = idx / n_cons, ci = idx - g * n_cons;
+                DevCon c;
+                if (a.prog.packed) {
+                    c = load_packed(P.pcons, P.con_weight, ci, false);
+                    *reinterpret_cast<uint4*>(c.jloc) = P.patterns[c.nslots];
+                } else {
+                    c = load_con(P.cons + ci);
+                }
+                dev::JacWriter<double*> w;
+                w.jv = a.jv_out + (base + g) * a.zj;
+                w.jbase = c.jbase;
+                const uint32_t* loc = reinterpret_cast<const uint32_t*>(c.jloc);
+                w.loc[0] = loc[0], w.loc[1] = loc[1], w.loc[2] = loc[2], w.loc[3] = loc[3];
+                w.weight = c.weight;
+                (void)dev::con_jacobian<false>(c, (const double*)(a.x_int + (base + g) * a.n), w);
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
         // largest |R_ii| of the pivoted QR = largest column norm; a variable in no row is a null vector by itself
         for (uint32_t idx = tid; idx < nsys * a.n; idx += nthr) {
             const uint32_t g = idx / a.n, v = idx - g * a.n;
@@ -379,6 +417,10 @@ __global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
         if (a.n_under)
             for (uint32_t g = tid; g < nsys; g += nthr) a.n_under[base + g] = under[g];
         __syncthreads();
+    }
+    if (a.done_flag && gridDim.x == 1) {  // (every thread's stores are issued; the release store publishes them to the host)
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

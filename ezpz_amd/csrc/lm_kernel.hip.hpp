@@ -1713,7 +1713,8 @@ struct EvalArgs {
     uint64_t batch;
 };
 
-__global__ void __launch_bounds__(256) eval_kernel(const EvalArgs e) {
+// (static: launch.hip and freedom.hip each take their own copy)
+static __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs e) {
     using namespace dev;
     __shared__ int nwarn;
     const Prog<uint32_t> P = make_prog<uint32_t>(e.p, e.p.base, e.p.base);
