@@ -775,8 +775,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             // One workgroup cannot hold the system: G workgroups of 4 wavefronts share it (grid reductions, see
             // jit_kernel.hip.hpp).  A wavefront takes slots of every class in proportion to the class's chunks, ~112
             // VGPRs of state in all.
-            static const char* env_g = std::getenv("EZPZ_JIT_GRID_WAVES");
-            T = env_g && std::atoi(env_g) > 0 ? (uint32_t)std::atoi(env_g) : 4;
+            T = 4;
             uint64_t weight = 0;
             for (size_t k = 0; k < classes.size(); ++k) weight += (uint64_t)nchunk[k] * per_slot(k);
             uint32_t waves = 0;
@@ -819,12 +818,8 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             // 2000 x 2000 (four wavefronts per system, three per SIMD) 96.0 -> 101.9 M solves/s, 800 x 800 (two, three) 195.8 ->
             // 214.2, 2400 x 2400 (four, two per SIMD: eight slots per lane) 65.3 -> 60.1, the over-constrained variant (non-linear
             // classes) 24.8 -> 23.8: taken for linear systems compiled for three or more wavefronts per SIMD;
-            // EZPZ_JIT_FUSE=1 / 0 forces it on / off (A/B runs).  One workgroup per system only.
-            static const int fuse_env = [] {
-                const char* e = std::getenv("EZPZ_JIT_FUSE");
-                return !e ? -1 : e[0] == '1' ? 1 : 0;
-            }();
-            const bool fuse = fuse_env < 0 ? (!any_nonlinear && min_waves >= 3) : fuse_env == 1;
+            // One workgroup per system only.
+            const bool fuse = !any_nonlinear && min_waves >= 3;
             // two entries: batches, and (`_one`) one-call launches that stay resident for the caller's next request
             for (int one = 0; one < 2; ++one) {
                 o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve" + (one ? "_one" : "") + "(const ezpz::jit::JitArgs a) {\n";
@@ -888,11 +883,7 @@ WaveRows wave_row_structure(const Class& cl) {
     };
     const Program& Q = cl.Q;
     const uint32_t nv = Q.c.n_vars, zlo = Q.c.zlo;
-    static const bool off = [] {
-        const char* e = std::getenv("EZPZ_JIT_WAVE_TAIL");
-        return e && e[0] == '0';
-    }();
-    if (off || nv < 2 || nv > 64) return why(1);
+    if (nv < 2 || nv > 64) return why(1);
     w.col.assign(nv, {});
     w.slot_row.assign(zlo, ~0u);
     std::vector<std::vector<uint32_t>> slot_of(nv, std::vector<uint32_t>(nv, ~0u));
@@ -1204,9 +1195,8 @@ bool lane_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, LaneP
     emit_class(cls, 0, cl, true, cs);
     std::string& o = plan.jit_source;
     o = cls;
-    static const char* env_lb = std::getenv("EZPZ_JIT_LANE_BOUNDS");  // e.g. "256, 2" -- for measurements
     for (int one = 0; one < 2; ++one) {  // (batches; `_one`: one-call launches that stay resident, jit_kernel.hip.hpp)
-        o += std::string("extern \"C\" __global__ void __launch_bounds__(") + (env_lb ? env_lb : "256") + ") ezpz_jit_lane" + (one ? "_one" : "") + "(const ezpz::jit::LaneArgs a) {\n";
+        o += std::string("extern \"C\" __global__ void __launch_bounds__(") + "256" + ") ezpz_jit_lane" + (one ? "_one" : "") + "(const ezpz::jit::LaneArgs a) {\n";
         o += std::string("    ezpz::jit::lane_kernel<Cls0, ") + (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ">(a);\n}\n";
     }
     plan.n_vars = (uint32_t)n_vars;

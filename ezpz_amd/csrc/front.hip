@@ -11,10 +11,10 @@ namespace ezpz {
 extern std::mutex g_grid_mu;          // launch.hip: launches whose workgroups wait for each other are chained per device
 extern hipEvent_t g_grid_event[16];
 
-template <bool LIN, int THREADS>
+template <bool LIN>
 static int front_launch_kernel(EzpzSystem& s, FrontArgs& fa, hipStream_t stream) {
     const FrontPlan& plan = *s.fronts;
-    auto kernel = front_solve_kernel<LIN, THREADS>;
+    auto kernel = front_solve_kernel<LIN>;
     const uint32_t G = plan.n_wgs;
     if (s.front_capacity == 0) {  // once per system: these runtime calls cost more than a small solve
         if (plan.lds_bytes > 48 * 1024)
@@ -86,8 +86,7 @@ int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     fa.done = args.done;
     fa.done.request = nullptr;  // (this kernel does not stay resident between calls)
     args.done.request = nullptr;
-    if (plan.threads == 1024) return plan.linear_only ? front_launch_kernel<true, 1024>(s, fa, stream) : front_launch_kernel<false, 1024>(s, fa, stream);
-    return plan.linear_only ? front_launch_kernel<true, 512>(s, fa, stream) : front_launch_kernel<false, 512>(s, fa, stream);
+    return plan.linear_only ? front_launch_kernel<true>(s, fa, stream) : front_launch_kernel<false>(s, fa, stream);
 }
 
 }  // namespace ezpz

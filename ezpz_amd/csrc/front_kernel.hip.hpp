@@ -461,10 +461,10 @@ struct Red {
     } while (0)
 #endif
 
-// THREADS: 512 (two wavefronts per SIMD: up to 256 registers per lane) or 1024 (four: 128 -- the non-linear evaluators then spill a
-// little in the sweeps, and twice as many fronts of a level run side by side)
-template <bool LIN, int THREADS>
-__global__ void __launch_bounds__(THREADS, 1) front_solve_kernel(const FrontArgs a) {
+// (512 lanes: two wavefronts per SIMD.  1024 -- four per SIMD at 128 registers, the non-linear evaluators spilling a little -- was
+// measured and not kept: one solve of 300 variables 191 -> 193 us, 800: 2.09 -> 2.30 ms)
+template <bool LIN>
+__global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) {
     using namespace frontal;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;

@@ -225,10 +225,7 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
     {
         std::vector<char> seen(n, 0);
         UVec verts, stack;
-        static const uint32_t leaf = [] {
-            const char* e = std::getenv("EZPZ_FRONT_LEAF");
-            return e ? (uint32_t)std::atoi(e) : 10u;
-        }();
+        constexpr uint32_t leaf = 10;  // (pieces of at most this many variables are not dissected further)
         for (uint32_t s = 0; s < n; ++s) {
             if (seen[s]) continue;
             verts.clear();
@@ -308,13 +305,10 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
 
     // ---- supernodes: fundamental ones first, then a child is merged into the parent it immediately precedes while the merged
     //      front is cheaper than the two (front_cost: a front's fixed cost is most of a small front) ----------------------------
-    static const uint32_t kmax_env = [] {
-        const char* e = std::getenv("EZPZ_FRONT_KMAX");  // (A/B runs: the widest supernode)
-        // (measured, one solve of 800 / 2000 / 5000 variables with supernodes of at most 6 / 8 / 16 columns: 2.09 / 2.08 / 2.35 ms,
-        // 0.52 / 0.52 / 0.62 ms, 3.24 / 3.16 / 4.06 ms: the pivot block's register updates grow with K^2)
-        return e ? std::max(1u, std::min<uint32_t>(kFrontMaxPivots, (uint32_t)std::atoi(e))) : 8u;
-    }();
-    const uint32_t KMAX = kmax_env, SMAX = kFrontMaxRows;
+    // the widest supernode: 8 columns (measured, one solve of 800 / 2000 / 5000 variables with supernodes of at most 6 / 8 / 16
+    // columns: 2.09 / 2.08 / 2.35 ms, 0.52 / 0.52 / 0.62 ms, 3.24 / 3.16 / 4.06 ms: the pivot block's register updates grow with K^2;
+    // the kernel itself takes up to kFrontMaxPivots)
+    const uint32_t KMAX = 8, SMAX = kFrontMaxRows;
     UVec nkids(n, 0);
     for (uint32_t j = 0; j < n; ++j)
         if (parent[j] != NONE) ++nkids[parent[j]];
@@ -331,10 +325,7 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             blocks.push_back(Block{j, j + 1});
     }
     {
-        static const bool relax = [] {
-            const char* e = std::getenv("EZPZ_FRONT_RELAX");
-            return !(e && e[0] == '0');
-        }();
+        constexpr bool relax = true;
         // rows of a block = its columns + the structure of its last column (a block's columns chain: each column's structure
         // is the next one's plus itself) -- until blocks are merged: then the structure of the merged block is that of the
         // parent, its rows the child's columns + the parent's rows
@@ -443,10 +434,7 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
         std::vector<char> on_top(F, 0);
         double top_cost = 0.0;
         uint32_t top_vars = 0;
-        static const double share = [] {
-            const char* e = std::getenv("EZPZ_FRONT_SHARE");
-            return e ? std::atof(e) : 0.75;
-        }();
+        constexpr double share = 0.75;
         while (!open.empty()) {
             const Item it = open.top();
             const double rest = total_cost - top_cost;

@@ -390,11 +390,7 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
         a.rec_chunks = reinterpret_cast<const uint4*>(base + sys->rec_chunks_off);
         a.rec_rounds = sys->rec_rounds;
         a.rec_desc_off = sys->rec_desc_lds_off;
-        static const bool packed = [] {  // (A/B runs)
-            const char* e = std::getenv("EZPZ_REC_ASM");
-            return !(e && e[0] == '0');
-        }();
-        if ((packed || sys->rec_jglobal) && sys->rec_asm_kc) {
+        if (sys->rec_asm_kc) {
             a.rec_asm_cols = reinterpret_cast<const uint4*>(base + sys->rec_asm_cols_off);
             a.rec_asm_slots = reinterpret_cast<const uint4*>(base + sys->rec_asm_slots_off);
             a.rec_asm_kc = sys->rec_asm_kc;

@@ -271,11 +271,8 @@ bool pack_grid_slices(EzpzSystem& s, const Program& P, uint32_t G, uint32_t W) {
 // backward), first chunk; chunks[((chunk + c) x 64 + lane of the wavefront) x 4]: chunk 0 = target | diagonal << 16, destination
 // | lane flags, two (a | b << 16) pairs; chunks 1 and 2 = four pairs each (REC_* in lm_kernel.hip.hpp).  Only a wavefront that
 // has an item in a round has chunks for it, as many as its longest share needs.
-// (analyze_into: up to this many components walk records as one partition; EZPZ_REC_MAX_COMPONENTS for A/B runs)
-extern const uint32_t kRecMaxComponents = [] {
-    const char* e = std::getenv("EZPZ_REC_MAX_COMPONENTS");
-    return e ? (uint32_t)std::atol(e) : launch_policy_for(256).rec_max_components;  // (from 128 the component-resident shape may take the system)
-}();
+// (analyze_into: up to this many components walk records as one partition; from 128 the component-resident shape may take the system)
+extern const uint32_t kRecMaxComponents = launch_policy_for(256).rec_max_components;
 // `wide`: the workspace lives in global memory -- 32-bit addresses counted from its start (lds_base = 0), chunk 0 = target,
 // diagonal, destination, lane flags, then up to four chunks of two (a, b) pairs; no packed assembly.
 // `jglobal` (LDS form): the Jacobian's values live in global memory (SolveArgs::rec_jglobal): no room for them in the workspace, and
@@ -583,10 +580,7 @@ bool make_dense_phases(Program& P, uint32_t n_waves, size_t lds_room_bytes) {
         if (lds_used > lds_room_bytes) return false;
         phases.push_back(std::move(root));
     }
-    static const uint32_t max_phases = [] {
-        const char* e = std::getenv("EZPZ_DENSE_PHASES");
-        return e ? std::min<uint32_t>(4u, (uint32_t)std::atoi(e)) : 4u;
-    }();
+    constexpr uint32_t max_phases = 4;
     while (phases.size() < max_phases) {
         const uint32_t lb = phases.back().la;
         // How far down?  A walked level costs ~4.1 k cycles (2.9 k in the factorisation, 1.2 k in the backward substitution).

@@ -133,11 +133,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
         const char* e = std::getenv("EZPZ_COMP");
         return !(e && e[0] == '0');
     }();
-    static const bool defer_enabled = [] {
-        const char* e = std::getenv("EZPZ_DEFER");  // EZPZ_DEFER=0: every system is analysed whole at creation (A/B runs)
-        return !(e && e[0] == '0');
-    }();
-    if (may_defer && (team_size == EZPZ_TEAM_AUTO_LATENCY || team_size == EZPZ_TEAM_LATENCY_WAVE) && comp_enabled0 && defer_enabled && !keep_comp) {
+    if (may_defer && (team_size == EZPZ_TEAM_AUTO_LATENCY || team_size == EZPZ_TEAM_LATENCY_WAVE) && comp_enabled0 && !keep_comp) {
         std::unique_ptr<CompPlan> plan(new CompPlan());
         CompLimits cl;
         cl.lds_bytes = s.lim.lds_bytes;
@@ -204,13 +200,8 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
         // One connected system walks records (build_records) from 25 variables for one solve and from 57 in batches, on one
         // wavefront: one solve of 32 / 50 / 64 variables 61 -> 54, 142 -> 112, 119 -> 82 us; batches of 64 variables 17.0 -> 23.1 M
         // solves/s, but of 50 variables 19.2 -> 16.8 M and of 32 variables 60 -> 37 M (two to four systems share a wavefront
-        // there).  EZPZ_REC_SMALL = that bound for both (A/B runs), 0 = the sub-wavefront teams always.
-        static const int rec_small_env = [] {
-            const char* e = std::getenv("EZPZ_REC_SMALL");
-            return e ? std::atoi(e) : -1;
-        }();
-        const int rec_small = rec_small_env >= 0 ? rec_small_env
-                                                 : (int)(for_latency ? s.lim.policy.rec_min_vars_one_solve : s.lim.policy.rec_min_vars_batch) - 1;
+        // there).
+        const int rec_small = (int)(for_latency ? s.lim.policy.rec_min_vars_one_solve : s.lim.policy.rec_min_vars_batch) - 1;
         static const bool rec_on = [] {
             const char* e = std::getenv("EZPZ_REC");
             return !(e && e[0] == '0');
@@ -311,16 +302,12 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             // A FEW components (a document of several sketches) are one partition for the record walk, which needs levels, not
             // connectivity: batches of 4 x 150 / 8 x 80 / 3 x 300 variables 0.64 -> 1.73, 0.68 -> 1.63, 0.57 -> 1.28 M solves/s against a
             // wavefront per balanced share of the components.  (Many small components are the component-resident shape's.)
-            static const bool rec_multi = [] {
-                const char* e = std::getenv("EZPZ_REC_MULTI");
-                return !(e && e[0] == '0');
-            }();
             static const bool rec_on2 = [] {
                 const char* e = std::getenv("EZPZ_REC");
                 return !(e && e[0] == '0');
             }();
             // (one solve of such a system too: 4 x 150 / 8 x 80 / 6 x 40 variables 790 -> 237, 727 -> 237, 224 -> 109 us)
-            const bool few = rec_on2 && rec_multi && !team_size && !latency_phases && !lists_only && n_pieces >= 2 &&
+            const bool few = rec_on2 && !team_size && !latency_phases && !lists_only && n_pieces >= 2 &&
                              n_pieces <= kRecMaxComponents;
             if (!build_program(cs, n_cs, n_vars, P, be, few ? 1u : W)) return fail();
             if (!team_size && (size_t)workspace_doubles(P.c) * 8 + 4096 > s.lim.lds_bytes && grid_wgs_for() > 1) {
@@ -403,22 +390,15 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
     // Batches of one connected sketch on the per-system teams take the record walk as well -- one wavefront up to 160 variables,
     // then 128 / 256 / 512 lanes as four / two or three / one workgroup fit a CU -- instead of one wavefront / a lean workgroup walking level lists
     // with dense phases on top: 100 / 150 / 200 / 300 / 500 / 800 variables 10.5 -> 23.0, 4.3 -> 8.7, 4.0 -> 7.5, 1.49 -> 3.10,
-    // 0.33 -> 0.61 M solves/s, 57 -> 86 k (EZPZ_REC_BATCH = lanes for A/B runs, 0 = the shapes above).
-    static const int rec_batch_lanes = [] {
-        const char* e = std::getenv("EZPZ_REC_BATCH");
-        return e ? std::atoi(e) : -1;
-    }();
+    // 0.33 -> 0.61 M solves/s, 57 -> 86 k.
     const int saved_mode = s.mode;
     const uint32_t saved_team = s.team_size;
     const bool saved_lean = s.lean_lds;
-    const bool rec_batch = rec_enabled && rec_batch_lanes != 0 && auto_shape && team_size == 0 && !for_latency && !want_sub &&
+    const bool rec_batch = rec_enabled && auto_shape && team_size == 0 && !for_latency && !want_sub &&
                            s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents && !P.c.dense;
     // Batches keep the Jacobian's values in global memory (SolveArgs::rec_jglobal) when the assembly can read them from packed
-    // pairs (no list of more than twelve): a fifth of a system's LDS, one more workgroup per CU.  EZPZ_REC_JGLOBAL=0: in the LDS.
-    static const bool jglobal_enabled = [] {
-        const char* e = std::getenv("EZPZ_REC_JGLOBAL");
-        return !(e && e[0] == '0');
-    }();
+    // pairs (no list of more than twelve): a fifth of a system's LDS, one more workgroup per CU.
+    constexpr bool jglobal_enabled = true;
     bool jglobal = rec_batch && jglobal_enabled && P.c.zj < 65535 && !P.parts.empty();
     if (jglobal) {
         const uint32_t l0 = P.parts[0].lvl0, nl = P.parts[0].nlev;
@@ -444,7 +424,6 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             jglobal = P.c.n_vars > 160 && (wj > w || (wj == w && per_cu_j > per_cu));
             if (jglobal) t = tj;
         }
-        if (rec_batch_lanes >= 64 && rec_batch_lanes <= 512 && rec_batch_lanes % 64 == 0) t = (uint32_t)rec_batch_lanes;
         s.mode = MODE_WGB;
         s.team_size = t;
         s.lean_lds = true;  // (its lists stay in L2: the LDS is for as many systems as fit)
@@ -457,30 +436,20 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
 #ifdef EZPZ_REC_TIMES
         s.rec_extra += 6 * 128;  // (diagnostic build: six cycle stamps per round of the second iteration's walk, behind the zero)
 #endif
-        if (const char* e = std::getenv("EZPZ_REC_LANES")) {  // (A/B runs)
-            const uint32_t t = (uint32_t)std::atoi(e);
-            if (t >= 64 && t <= 512 && t % 64 == 0) s.team_size = t;
-        }
     }
     pack_and_shape(true);
     bool rec_wide = false;
     if (rec_try && !s.lds_ws) {
         // no room in the LDS with the walk's extra doubles: if the state fits without them the list walk keeps it there (with its dense
         // phases); a state that lives in global memory anyway walks records in the wide form
-        static const bool wide_enabled = [] {
-            const char* e = std::getenv("EZPZ_REC_WIDE");
-            return !(e && e[0] == '0');
-        }();
+        constexpr bool wide_enabled = true;
         const uint32_t extra = s.rec_extra;
         s.rec_extra = 0;
         s.rec_jglobal = false;  // (J in global memory is for states that fit the LDS with it)
         pack_and_shape(true);
         // (batches: 4194 systems of 2000 variables 106 -> 114 k solves/s, 1677 of 5000 variables 6.3 -> 8.4 k; a round through
         // global memory is a store's acknowledgement, a rendezvous and a trip to L2)
-        static const uint32_t wide_one_solve_max = [] {  // (A/B runs: one solve walks wide records up to this many variables)
-            const char* e = std::getenv("EZPZ_REC_WIDE_LATENCY");
-            return e ? (uint32_t)std::atol(e) : launch_policy_for(256).rec_wide_one_solve_max_vars;
-        }();
+        const uint32_t wide_one_solve_max = s.lim.policy.rec_wide_one_solve_max_vars;
         // (one solve of 1600 / 2000 / 3000 / 4000 / 5000 variables: 1.23 -> 1.16, 2.02 -> 1.82, 1.77 -> 1.49, 2.47 -> 2.47, 25.0 -> 26.9 ms)
         if (!s.lds_ws && wide_enabled && (rec_batch || P.c.n_vars <= wide_one_solve_max)) {
             rec_wide = true;
@@ -680,11 +649,9 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             fo.wgs = (for_latency || force_fronts) ? 0u : 1u;
             if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
             fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
-            if (const char* e = std::getenv("EZPZ_FRONT_MAX_WGS")) fo.max_wgs = std::max(1, std::atoi(e));  // (A/B runs)
             fo.vars_per_wg = pol.front_vars_per_workgroup;
             if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
             fo.lds_bytes = s.lim.lds_bytes;
-            if (const char* e = std::getenv("EZPZ_FRONT_THREADS")) fo.threads = std::atoi(e) >= 1024 ? 1024u : 512u;
             std::unique_ptr<FrontPlan> plan(new FrontPlan());
             const char* why = nullptr;
             const bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
