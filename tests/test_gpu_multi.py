@@ -290,3 +290,33 @@ def test_registered_buffers_on_a_system_that_always_runs_lanes_across_the_batch(
     assert np.array_equal(xo, want) and np.array_equal(st["iterations"], wst["iterations"])
     rc, xr, it, conv, _ = O.solve_batch(recs, x0[:64], linsolve=O.LINSOLVE_SPARSE)
     assert rc == 0 and np.all(np.abs(xo[:64] - xr) <= 1e-6 * np.maximum(1.0, np.abs(xr)))
+
+
+def test_host_entries_leave_the_callers_device_as_it_was(E):
+    """Every host entry that works on a system of device 1 -- create, batch solve between host buffers and on device pointers,
+    evaluation, FreedomAnalysis, the heterogeneous batch and its destructor, destroy -- puts the calling thread's current HIP device
+    back (the library's own runtime: a caller on an 8-GPU node must not find itself on another device after a call).  Needs two
+    devices; the single-GPU boxes of the build skip it."""
+    if E.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")  # (the runtime the library itself is linked against: already loaded)
+    recs, g = gen.connected_sketch(30, 5)
+    n = len(g)
+    assert hip.hipSetDevice(0) == 0 and E.lib().ezpz_current_device() == 0
+    s = E.System(recs, n, device=1)
+    assert E.lib().ezpz_current_device() == 0
+    x0 = np.tile(g, (4, 1))
+    x, st, _ = s.solve_batch(x0)
+    assert E.lib().ezpz_current_device() == 0 and np.all(st["converged"] == 1)
+    s.eval_batch(x)
+    assert E.lib().ezpz_current_device() == 0
+    s.freedom_batch(x)
+    assert E.lib().ezpz_current_device() == 0
+    mixed = E.MixedBatch([s], np.zeros(4, np.uint32))
+    assert E.lib().ezpz_current_device() == 0
+    del mixed
+    assert E.lib().ezpz_current_device() == 0
+    del s
+    assert E.lib().ezpz_current_device() == 0
