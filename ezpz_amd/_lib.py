@@ -39,7 +39,8 @@ class CSystemInfo(C.Structure):
                 ("nnz_a", C.c_uint64), ("nnz_l", C.c_uint64), ("n_levels", C.c_uint64), ("n_components", C.c_uint64),
                 ("program_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("team_size", C.c_uint32),
                 ("workspace_in_lds", C.c_uint32), ("team_mode", C.c_uint32), ("n_partitions", C.c_uint32),
-                ("program_in_lds", C.c_uint32), ("grid_workgroups", C.c_uint32)]
+                ("program_in_lds", C.c_uint32), ("grid_workgroups", C.c_uint32), ("front_workgroups", C.c_uint32),
+                ("front_max_batch", C.c_uint32)]
 
 
 class CLaunchPolicy(C.Structure):
@@ -53,7 +54,8 @@ class CLaunchPolicy(C.Structure):
                 ("zero_copy_max_bytes", C.c_uint64), ("h2h_piece_min_bytes", C.c_uint64), ("h2h_piece_max_bytes", C.c_uint64),
                 ("h2h_pieces_per_call", C.c_uint32), ("one_call_host_mask_max_constraints", C.c_uint32),
                 ("one_call_host_log_max_entries", C.c_uint32), ("front_min_vars_one_solve", C.c_uint32),
-                ("front_min_vars_batch", C.c_uint32), ("front_vars_per_workgroup", C.c_uint32), ("front_max_workgroups", C.c_uint32)]
+                ("front_min_vars_batch", C.c_uint32), ("front_vars_per_workgroup", C.c_uint32), ("front_max_workgroups", C.c_uint32),
+                ("front_small_call_fill", C.c_uint32)]
 
 
 # every symbol include/ezpz_amd.h declares

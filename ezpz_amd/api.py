@@ -920,7 +920,8 @@ def device_count() -> int:
 
 def launch_policy(compute_units: int = 0):
     """The table of launch-shape thresholds (include/ezpz_amd.h: EzpzLaunchPolicy) for a device of `compute_units` CUs
-    (0 = the current device)."""
+    (0 = the full 256-CU MI355X, as the header says -- NOT the current device: a caller on a CPX/DPX partition or a CU-masked
+    device passes its own count, e.g. torch.cuda.get_device_properties(i).multi_processor_count)."""
     from ._lib import CLaunchPolicy
 
     p = CLaunchPolicy()

@@ -257,13 +257,13 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                     hipLaunchKernelGGL(fr_init_kernel, dim3(bl_mn, nb), dim3(256), 0, stream, sa);
                     hipLaunchKernelGGL(fr_scatter_kernel, dim3(bl_it, nb), dim3(256), 0, stream, sa);
                     hipLaunchKernelGGL(fr_norms_kernel, dim3((nc + 255) / 256, nb), dim3(256), 0, stream, sa);
-                    bool cooperative = false;
+                    bool cooperative = false, resident = false;
                     if (res_cper) {
                         uint32_t nd = ndiag, cper = res_cper;
                         void* params[] = {&sa, &nd, &cper};
                         if (hip_debug()) std::fprintf(stderr, "[ezpz hip] resident QR: m %u n %u, %u workgroups x %u columns, %u systems\n", m, nc, res_G, cper, nb);
                         const hipError_t ce = hipLaunchCooperativeKernel((const void*)fr_qrc_kernel, dim3(res_G, nb), dim3(1024), params, 0, stream);
-                        cooperative = ce == hipSuccess;
+                        cooperative = resident = ce == hipSuccess;
                         if (!cooperative && hip_debug()) std::fprintf(stderr, "[ezpz hip] resident QR launch -> %s\n", hipGetErrorString(ce));
                         (void)hipGetLastError();
                     }
@@ -299,6 +299,7 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                     fa.n_under = a.n_under ? a.n_under + base : nullptr;
                     fa.batch = nb;
                     fa.qr_done = F.big + 1;
+                    fa.qr_timed_out = resident ? F.step_done.p : nullptr;  // (the chain uses these words for something else)
                     hipLaunchKernelGGL(freedom_kernel<false>, dim3(nb), dim3(F.threads), lds, stream, fa);
                 }
                 HIP_TRY(hipGetLastError());
@@ -319,6 +320,13 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
     }
     HIP_TRY(hipGetLastError());
     return EZPZ_OK;
+}
+
+// A system whose resident QR timed out (FreedomArgs::qr_timed_out) carries kFreedomPoisonedMask in every byte of its mask.
+bool mask_poisoned(const uint8_t* mask, size_t batch, size_t n) {
+    for (size_t b = 0; b < batch; ++b)
+        if (mask[b * n] == kFreedomPoisonedMask) return true;
+    return false;
 }
 
 }  // namespace
@@ -388,7 +396,7 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
         }
         std::memcpy(under_mask, hmask, batch * n);
         if (participation) std::memcpy(participation, hpart, x_bytes);
-        return EZPZ_OK;
+        return mask_poisoned(under_mask, batch, n) ? EZPZ_ERR_HIP : EZPZ_OK;
     }
     if ((rc = F.x_in.ensure(batch * n)) != EZPZ_OK) return rc;
     if ((rc = F.mask.ensure(batch * n)) != EZPZ_OK) return rc;
@@ -397,6 +405,7 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
     if ((rc = freedom_device(sys, F.x_in.p, batch, F.mask.p, F.part.p, nullptr, nullptr)) != EZPZ_OK) return rc;
     HIP_TRY(hipMemcpy(under_mask, F.mask.p, batch * n, hipMemcpyDeviceToHost));
     if (participation) HIP_TRY(hipMemcpy(participation, F.part.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (mask_poisoned(under_mask, batch, n)) return EZPZ_ERR_HIP;
     return EZPZ_OK;
 }
 

@@ -40,6 +40,10 @@ struct FreedomArgs {
     uint32_t ws;     // workspace doubles of the largest component
     uint32_t group;  // LANE: systems per workgroup
     uint32_t qr_done;  // TEAM, global workspace: 1 + the component whose pivoted QR is already in the workspace (step kernels below), 0 = none
+    // [systems of this launch] or null: non-zero = the resident QR (fr_qrc_kernel) gave up waiting for another workgroup's chunk.
+    // The factorisation in the workspace is then not one: the system's mask becomes kFreedomPoisonedMask in every byte and its
+    // count 0xFFFFFFFF (the host entry returns EZPZ_ERR_HIP), as the LM grid teams report EZPZ_ITERATIONS_TEAM_TIMEOUT.
+    const uint32_t* qr_timed_out;
     // FUSED small calls (solve_analysis of one sketch: one launch instead of gather_values + eval + this kernel, round 5): the kernel
     // gathers the caller-ordered values into the program's order and evaluates the weighted Jacobian there itself
     const double* x_caller;  // non-null: fused
@@ -51,6 +55,7 @@ struct FreedomArgs {
 };
 
 constexpr double kFreedomRankTol = 1e-8;  // find_dof.rs:12
+constexpr uint8_t kFreedomPoisonedMask = 0xFF;
 constexpr double kFreedomVarTol = 1e-3;   // find_dof.rs:98
 
 // Gathers caller-ordered values into the program's internal variable order for eval_kernel.
@@ -410,12 +415,14 @@ __global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
             const uint32_t g = idx / a.n;
             const double var_tol = kFreedomVarTol * __longlong_as_double((long long)partmax[g]);
             const bool free_var = a.part[base * a.n + idx] > var_tol * var_tol;
-            a.mask[base * a.n + idx] = free_var ? 1 : 0;
+            const bool poisoned = a.qr_timed_out && a.qr_timed_out[base + g] != 0;
+            a.mask[base * a.n + idx] = poisoned ? kFreedomPoisonedMask : free_var ? 1 : 0;
             if (free_var) atomicAdd(&under[g], 1u);
         }
         __syncthreads();
         if (a.n_under)
-            for (uint32_t g = tid; g < nsys; g += nthr) a.n_under[base + g] = under[g];
+            for (uint32_t g = tid; g < nsys; g += nthr)
+                a.n_under[base + g] = a.qr_timed_out && a.qr_timed_out[base + g] != 0 ? 0xFFFFFFFFu : under[g];
         __syncthreads();
     }
     if (a.done_flag && gridDim.x == 1) {  // (every thread's stores are issued; the release store publishes them to the host)
@@ -852,7 +859,9 @@ __global__ void __launch_bounds__(1024) fr_qrc_kernel(const FreedomStepArgs a, c
     qc_chunk_t* const area = reinterpret_cast<qc_chunk_t*>(W + oNS + ((reinterpret_cast<uintptr_t>(W + oNS) >> 3) & 1u));
     qc_chunk_t* const candc = area;                              // [workgroup]: its candidate
     qc_chunk_t* const resc = candc + kQcMaxWgs;                  // [workgroup][4]: the winner, a 64-byte line each
-    unsigned int* const dead = reinterpret_cast<unsigned int*>(resc + 4 * kQcMaxWgs);
+    // "somebody gave up waiting": the system's word of FreedomStepArgs::done (zeroed by fr_init_kernel, not otherwise used on this
+    // route) -- it outlives the kernel, freedom_kernel reads it as FreedomArgs::qr_timed_out
+    unsigned int* const dead = a.done + blockIdx.y;
     // [parity of the step][workgroup][row]: the reflector every workgroup forms from ITS candidate column while the winner is
     // being decided (tau at row k) -- the winner's is then already on its way when the others learn who won.  Two sets: a
     // workgroup overwrites its slot two steps later, which it only reaches after everybody has sent the next step's candidate,

@@ -46,6 +46,7 @@ int launch_sub(EzpzSystem& s, const SolveArgs& args, uint32_t grid, hipStream_t 
 
 }  // namespace
 namespace ezpz {
+thread_local uint64_t t_call_batch = 0;
 std::mutex g_grid_mu;
 hipEvent_t g_grid_event[16] = {};  // per device: completion of the last grid-team launch of this process (front.hip's too)
 }  // namespace ezpz
@@ -285,8 +286,10 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             }
         }
     }
-    // one connected sketch as a tree of dense fronts (fronts.cpp): whenever the system has the plan
-    if (s.fronts && !args.resume && !args.sys_list) return front_launch(s, args, stream);
+    // one connected sketch as a tree of dense fronts (fronts.cpp): every call of a system created for one solve, the small calls
+    // of a system created for batches
+    if (s.fronts && !args.resume && !args.sys_list && (t_call_batch ? t_call_batch : args.batch) <= s.front_max_batch)
+        return front_launch(s, args, stream);
     if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
     if (s.lane && s.wave_jit && args.batch <= (uint64_t)s.lim.cus) {
         // one solve (or a few) of a small system built for latency: one wavefront per system, sweeps and assembly across its

@@ -43,6 +43,11 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     release_thread_kernel(sys->device);
     std::lock_guard<std::mutex> lock(sys->mu);
     EZPZ_ON_DEVICE(sys->device);
+    // (the launch shape is chosen for the call, not for each of the pieces it may be fed to the device in)
+    struct CallBatch {
+        explicit CallBatch(size_t b) { t_call_batch = b; }
+        ~CallBatch() { t_call_batch = 0; }
+    } call_batch(batch);
     const size_t n = sys->counts.n_vars, C = sys->counts.n_cons;
     const bool want_log = warn_log && warn_cap;
     const size_t x_bytes = batch * std::max<size_t>(n, 1) * sizeof(double);

@@ -630,23 +630,26 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
     }
     // ---- the frontal shape: one connected sketch as a tree of dense fronts (fronts.cpp), one solve from front_min_vars_one_solve
     //      variables on as many workgroups as its size asks for; the shapes above stay behind it (stragglers of the lanes, systems
-    //      whose fronts would exceed a wavefront's rows).  EZPZ_FRONTS=0: never; =2: batches like one solve (A/B runs);
-    //      EZPZ_FRONT_WGS: workgroups per system.
+    //      whose fronts would exceed a wavefront's rows).  A system created for batches carries the plan too and takes it for
+    //      calls that would leave most of the device idle at one workgroup per system (EzpzSystem::front_max_batch); its
+    //      EzpzSystemInfo keeps describing the shape of its large calls.  EZPZ_FRONTS=0: never; EZPZ_FRONT_WGS: workgroups per system.
     s.fronts.reset();
+    s.front_max_batch = 0;
+    info.front_workgroups = 0;
+    info.front_max_batch = 0;
     {
         const char* fe = std::getenv("EZPZ_FRONTS");
         const int fronts_env = fe ? std::atoi(fe) : 1;
         const EzpzLaunchPolicy& pol = s.lim.policy;
         // (one solve: the automatic latency shape only -- EZPZ_TEAM_LATENCY_PHASES / _RECORDS ask for the older ones; batches: the
         // automatic shape)
-        uint32_t min_vars = latency_auto ? pol.front_min_vars_one_solve
-                            : batch_auto ? (fronts_env >= 2 ? pol.front_min_vars_one_solve : pol.front_min_vars_batch) : 0u;
+        uint32_t min_vars = latency_auto ? pol.front_min_vars_one_solve : batch_auto ? pol.front_min_vars_batch : 0u;
         if (fronts_env == 0 || no_fronts) min_vars = 0;
         const bool connected = s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents;
         const bool want = force_fronts || (auto_shape && min_vars && n_vars >= min_vars && connected && !s.comp && !s.lane && !keep_comp);
         if (want && n_cs > 0) {
             FrontOptions fo;
-            fo.wgs = (for_latency || force_fronts) ? 0u : 1u;
+            fo.wgs = 0;
             if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
             fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
             fo.vars_per_wg = pol.front_vars_per_workgroup;
@@ -656,14 +659,25 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             const char* why = nullptr;
             const bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
             if (ok) {
-                info.team_mode = 5;
-                info.team_size = plan->threads;
-                info.grid_workgroups = plan->n_wgs;
-                info.n_partitions = plan->n_fronts;
-                info.n_levels = plan->n_levels;
-                info.workspace_bytes = (uint64_t)plan->ws_doubles_max * 8;
-                info.workspace_in_lds = 1;
-                info.program_in_lds = 0;
+                info.front_workgroups = plan->n_wgs;
+                if (for_latency || force_fronts) {
+                    s.front_max_batch = ~0ull;
+                    info.front_max_batch = 0xFFFFFFFFu;
+                    info.team_mode = 5;
+                    info.team_size = plan->threads;
+                    info.grid_workgroups = plan->n_wgs;
+                    info.n_partitions = plan->n_fronts;
+                    info.n_levels = plan->n_levels;
+                    info.workspace_bytes = (uint64_t)plan->ws_doubles_max * 8;
+                    info.workspace_in_lds = 1;
+                    info.program_in_lds = 0;
+                } else {
+                    // batches: the calls whose systems x workgroups the device holds `front_small_call_fill` times over (one
+                    // workgroup per system: once -- four 128-lane teams of the record walk share a CU from there)
+                    const uint64_t cus = (uint64_t)std::max(1, s.lim.cus);
+                    s.front_max_batch = plan->n_wgs > 1 ? std::max<uint64_t>(1, pol.front_small_call_fill * cus / plan->n_wgs) : cus;
+                    info.front_max_batch = (uint32_t)std::min<uint64_t>(s.front_max_batch, 0xFFFFFFFEu);
+                }
                 info.program_bytes += plan->blob.size();
                 s.fronts = std::move(plan);
             } else if (std::getenv("EZPZ_FRONT_DEBUG")) {

@@ -203,6 +203,7 @@ struct EzpzSystem {
     void* dev_fronts = nullptr;
     DevBuf<unsigned char> front_scratch;
     uint64_t front_capacity = 0;
+    uint64_t front_max_batch = 0;  // calls of up to this many systems take the fronts (~0: every call; shape.cpp)
     uint32_t grid_wgs = 1;     // grid team: workgroups that share one system (each keeps its share of the state in LDS)
     uint32_t grid_ws_doubles = 0;
     DevBuf<GridScratch> grid_scratch;
@@ -352,6 +353,9 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
                             EzpzStatus* status_dev, uint8_t* unsat_mask_dev, uint64_t* warn_log_dev, uint32_t warn_cap, void* stream,
                             const DoneWord& done, bool* resident = nullptr);
 
+// The whole call's systems while a host entry of this thread feeds them to launch() in pieces (pipeline.cpp): the launch shape is
+// chosen once per call, not per piece -- a short last piece does not change shape (0: the piece is the call).
+extern thread_local uint64_t t_call_batch;
 int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream);  // front.hip: the frontal shape (EzpzSystem::fronts)
 
 void launch_eval(EzpzSystem* sys, const double* x_int_dev, size_t batch, double* r_out_dev, double* jv_out_dev, uint32_t* deg_out_dev,

@@ -168,6 +168,11 @@ typedef struct EzpzSystemInfo {
     uint32_t n_partitions;  /* partitions (balanced unions of components), one per wavefront in mode 1 */
     uint32_t program_in_lds;
     uint32_t grid_workgroups; /* workgroups that share one system (grid team: one large system on many CUs), else 1 */
+    /* A system created for batches (team_size 0) of one connected sketch also carries the frontal plan (team_mode 5's) and
+     * takes it for calls of at most front_max_batch systems -- calls too small to fill the device with one workgroup per
+     * system; the fields above then describe the shape of its larger calls.  front_workgroups = workgroups that share one
+     * system on that plan (0: no such plan); 0xFFFFFFFF in front_max_batch: every call (the latency shapes). */
+    uint32_t front_workgroups, front_max_batch;
 } EzpzSystemInfo;
 
 typedef struct EzpzSystem EzpzSystem; /* opaque: one analysed topology, resident on one device */
@@ -279,7 +284,10 @@ int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_id
  * batch solve): under_mask [batch][n_vars] gets 1 where the variable is underconstrained, participation
  * [batch][n_vars] (optional) the squared row norms of the orthonormal null-space basis (find_dof.rs:90-95).  The
  * Jacobian is re-evaluated at the values given (the reference reuses the LM loop's last refresh, which is the
- * Jacobian at the final values). */
+ * Jacobian at the final values).  A large component's QR runs on many workgroups that wait for each other's chunks; should one
+ * of them give up waiting (a device fault), the host entries return EZPZ_ERR_HIP and the asynchronous _device entry marks the
+ * system: 0xFF in every byte of its mask, 0xFFFFFFFF as its count -- as a timed-out grid team's solve reports
+ * EZPZ_ITERATIONS_TEAM_TIMEOUT. */
 int ezpz_solve_analysis(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
                         size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids,
                         EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out, uint32_t* under_out,
@@ -413,9 +421,12 @@ typedef struct EzpzLaunchPolicy {
     uint64_t zero_copy_max_bytes, h2h_piece_min_bytes, h2h_piece_max_bytes;
     uint32_t h2h_pieces_per_call;
     uint32_t one_call_host_mask_max_constraints, one_call_host_log_max_entries;
-    /* the frontal shape (team_mode 5): one solve of a connected sketch takes it from this many variables, batches from that
-     * many (0 = never); one workgroup per system up to front_vars_per_workgroup x 2 variables, then one more per that many */
+    /* the frontal shape (team_mode 5): one solve of a connected sketch takes it from this many variables; a system created for
+     * batches (team_size 0) carries the plan from that many (0 = never) and takes it for calls of up to
+     * EzpzSystemInfo.front_max_batch systems (= front_small_call_fill x compute units / workgroups per system; one workgroup per
+     * system: compute units); one workgroup per system up to front_vars_per_workgroup x 2 variables, then one more per that many */
     uint32_t front_min_vars_one_solve, front_min_vars_batch, front_vars_per_workgroup, front_max_workgroups;
+    uint32_t front_small_call_fill;
 } EzpzLaunchPolicy;
 int ezpz_launch_policy(int compute_units, EzpzLaunchPolicy* out);
 

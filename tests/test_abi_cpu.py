@@ -75,7 +75,7 @@ def test_struct_layouts_match_the_header():
     assert E.CONSTRAINT_DTYPE.itemsize == 56 and O.CONSTRAINT_DTYPE == E.CONSTRAINT_DTYPE
     assert E.STATUS_DTYPE.itemsize == 32
     assert C.sizeof(CConfig) == 32 and C.sizeof(CWarning) == 8 and C.sizeof(COutcome) == 80
-    assert C.sizeof(CSystemInfo) == 104
+    assert C.sizeof(CSystemInfo) == 112
 
 
 def test_default_config():

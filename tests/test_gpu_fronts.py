@@ -179,3 +179,41 @@ def test_one_solve_call_takes_the_fronts_and_equals_the_oracle(E):
         assert (got.iterations, got.converged, list(got.unsatisfied)) == (want.iterations, want.converged, list(want.unsatisfied))
         err = np.abs(got.final_values - want.final_values) / np.maximum(1.0, np.abs(want.final_values))
         assert float(err.max()) <= 1e-6
+
+
+@pytest.mark.parametrize("npts", [150, 1000])
+def test_small_calls_of_a_batch_system_take_the_fronts(E, npts):
+    """A system created for batches (team_size 0) carries the frontal plan and takes it for calls too small to fill the device at one
+    workgroup per system (EzpzSystemInfo.front_max_batch): those calls are bit for bit the frontal system's, one system more is bit
+    for bit the record walk's (a system created with EZPZ_FRONTS=0), both equal to the oracle; its info describes the large calls."""
+    import torch
+
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    recs, g = gen.connected_sketch(npts, 1000 + npts)
+    n = len(g)
+    auto = E.System(recs, n)
+    info = auto.info()
+    fronts, finfo = front_system(E, recs, n)
+    with env(EZPZ_FRONTS=0):
+        records = E.System(recs, n)
+    G = finfo["grid_workgroups"]
+    assert info["team_mode"] != 5 and info["front_workgroups"] == G, info
+    assert info["front_max_batch"] == (cus if G == 1 else max(1, 2 * cus // G)), (info, G, cus)
+    assert finfo["front_max_batch"] == 0xFFFFFFFF and records.info()["front_workgroups"] == 0
+    most = info["front_max_batch"]
+    x0 = g[None, :] + gen.keyed_uniform(npts, most + 1, n, -0.01, 0.01)
+    x0[0] = g
+    cfg = E.Config(max_iterations=60)
+    for B, same_as in ((1, fronts), (most, fronts), (most + 1, records)):
+        x, st, _ = auto.solve_batch(x0[:B], cfg)
+        xw, stw, _ = same_as.solve_batch(x0[:B], cfg)
+        assert np.array_equal(x, xw) and np.array_equal(st, stw), B
+        # ... and on the device-resident entry, whose call is one piece by construction
+        xin = torch.from_numpy(x0[:B]).cuda()
+        xd = torch.empty_like(xin)
+        std = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+        auto.solve_batch_device(xin.data_ptr(), B, xd.data_ptr(), std.data_ptr(), 0, torch.cuda.current_stream().cuda_stream, cfg)
+        torch.cuda.synchronize()
+        assert np.array_equal(xd.cpu().numpy(), x), B
+    x, st, _ = auto.solve_batch(x0[:4], cfg)
+    assert_batch_matches_oracle(recs, x0[:4], x, st["iterations"], st["converged"], O.Config(max_iterations=60), what=("auto small call", npts))

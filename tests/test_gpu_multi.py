@@ -165,7 +165,9 @@ OVERSUBSCRIBED = textwrap.dedent("""
     # whole-batch call to rounding (iteration counts, flags, coordinates at 1e-9 on this well-conditioned sketch)
     recs, g = gen.connected_sketch(12, 1005)
     n = len(g)
-    pol = E.launch_policy(0)
+    import torch
+
+    pol = E.launch_policy(torch.cuda.get_device_properties(0).multi_processor_count)  # (0 would be the 256-CU table)
     B = int(pol.lanes_min_systems_small) + 300
     x0 = g[None, :] + gen.keyed_uniform(77, B, n, -0.02, 0.02)
     single = E.System(recs, n)
