@@ -55,7 +55,7 @@ class CLaunchPolicy(C.Structure):
                 ("h2h_pieces_per_call", C.c_uint32), ("one_call_host_mask_max_constraints", C.c_uint32),
                 ("one_call_host_log_max_entries", C.c_uint32), ("front_min_vars_one_solve", C.c_uint32),
                 ("front_min_vars_batch", C.c_uint32), ("front_vars_per_workgroup", C.c_uint32), ("front_max_workgroups", C.c_uint32),
-                ("front_small_call_fill", C.c_uint32)]
+                ("front_small_call_wgs_per_round", C.c_uint32)]
 
 
 # every symbol include/ezpz_amd.h declares

@@ -129,6 +129,9 @@ struct CompLaunch {
     // lane-per-system kernel only: the systems of one topology inside a ragged batch, in place (jit_kernel.hip.hpp: LaneArgs)
     const uint64_t* row_offset = nullptr;
     const uint32_t* sys_of = nullptr;
+    // the specialised kernels' work counters (jit_kernel.hip.hpp: JitArgs::ticket) and where each of the eight stands
+    unsigned int* ticket = nullptr;
+    const unsigned int* ticket_base = nullptr;
 };
 int comp_launch(const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus,
                 size_t lds_limit, void* stream);

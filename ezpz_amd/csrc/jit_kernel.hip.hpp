@@ -40,8 +40,20 @@ struct JitArgs {
     uint32_t grid_wgs;         // workgroups that share a system (1 = the ordinary case)
     uint32_t pad;
     DoneWord done;             // one-call launches: the completion word (dev_types.hpp)
+    // Batches larger than the launch (one workgroup per system): after its first system (its own index) a workgroup DRAWS the
+    // next one from this counter -- system = workgroups of the launch + (drawn value - ticket_base) -- instead of striding.  The
+    // launch holds as many workgroups as the device has room for; when something else occupies one of those places (another
+    // stream's kernel, a resident one-call kernel of this library) the workgroup that does not fit starts when the others END,
+    // and with a fixed share of the batch it then ran alone for as long again: 100.9 -> 53.7 M solves/s beside one resident
+    // one-call kernel (profiles/r05_resident_cost.txt).  Drawn, its share is one system.  Null: strides.
+    // Eight counters, kTicketStride words apart, workgroup b on counter b % 8 (its XCD's, as workgroups are dealt out), value t of
+    // counter c = system `workgroups + 8 t + c`: ONE counter answered 768 workgroups 84 M times a second and no faster -- 100.5 ->
+    // 83.7 M solves/s.  (32 bits, modular: a launch draws fewer than 2^32 values.)
+    unsigned int* ticket;
+    unsigned int ticket_base[8];
 };
-static_assert(sizeof(JitArgs) == 176, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
+constexpr unsigned int kTicketStride = 1024;  // words between two counters (4 KB: another channel)
+static_assert(sizeof(JitArgs) == 216, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
 
 // One system on several workgroups ("grid team", as in lm_kernel.hip.hpp): every workgroup owns its wavefronts' slots;
 // the reductions of the LM control cross workgroups through this per-system scratch.  Every workgroup publishes its
@@ -600,8 +612,16 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     // (a resident launch -- DoneWord::request, one workgroup -- serves one request after the other on the same buffers)
     const unsigned long long born = wall_clock64();
     DoneWord done = a.done;
+    // (tickets: JitArgs::ticket.  Thread 0 asks the counter right ahead of its wavefront's loads of the guesses -- the answer takes
+    // no longer than they do -- and leaves the drawn system in LDS when eval() is through, two words by parity: every system has
+    // a rendezvous after that point, everybody reads the word after the system's last.)
+    const bool tickets = !GRID && !RESIDENT && a.ticket != nullptr;
+    unsigned int* const drawn_lds = reinterpret_cast<unsigned int*>(smem + kRedDoubles + 10);
+    const uint32_t ticket_c = blockIdx.x & 7u;
     do {
-    for (uint64_t sys = grid_slot; sys < a.batch; sys += n_slots, parity ^= 1u) {
+    uint64_t sys_next = 0;
+    for (uint64_t sys = grid_slot; sys < a.batch; sys = sys_next, parity ^= 1u) {
+        unsigned int drawn = 0;
         const double* x0 = a.x0 + sys * a.n_row;
         // (Pulling the NEXT system's guesses towards L2 while this one is solved -- one 4-byte load per 64 bytes of its row
         // into a register nothing reads -- was measured and not kept: 2000 x 2000, 16 384 systems per launch, 75.0 -> 70.4 M
@@ -624,8 +644,12 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
 
         // ---- load the initial values; eval() (newton.rs:45, :232-236) ------------------------------------------------------------
         double sq = 0.0, mx = __builtin_nan("");
-        seq.each([&](auto& s, auto* cls, int) {
+        seq.each([&](auto& s, auto* cls, int index) {
             using C = typename class_of<decltype(cls)>::type;
+            // (by hand: the compiler's atomicAdd waits for the answer on the spot -- it folds the lanes of a wavefront into one
+            // request and hands every lane its share)
+            if (index == 0 && tickets && tid == 0)
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
 #pragma unroll
             for (int k = 0; k < C::NV; ++k) s.x[k] = x0[s.ids[k]];
             unsigned long long wm = 0;
@@ -642,6 +666,10 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
                 log_mask(s, cls, wm, 1);
             }
         });
+        if (tickets && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn)::"memory");
+            drawn_lds[parity] = (drawn - a.ticket_base[ticket_c]) * 8u + ticket_c;
+        }
         // FUSE: eval()'s sums do not get a rendezvous of their own -- the wavefront's totals wait in scalar registers and ride in
         // the first iteration's exchange (Red::step5; the first step is computed before anybody knows whether the system had
         // converged already: x only moves after the rendezvous).  Every iteration runs the same five-value exchange: ONE loop
@@ -821,6 +849,10 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             // serves the system after next of this workgroup / slot (every wavefront passes a rendezvous of the next
             // system, which this thread joins only after the store, before it can touch the counter again)
             if (ANY_NONLINEAR) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sys_next = sys + n_slots;
+        if (tickets) {
+            sys_next = (uint64_t)n_slots + __builtin_amdgcn_readfirstlane(drawn_lds[parity]);
         }
     }
     if constexpr (RESIDENT) publish_done(done);

@@ -181,7 +181,16 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     }
     const uint32_t per_cu = s.lds_ws ? (uint32_t)std::max<size_t>(1, s.lim.lds_bytes / std::max<size_t>(s.lds_bytes, 1))
                                      : 2048u / s.block_threads;
-    grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)s.lim.cus * std::min<uint32_t>(per_cu, 8) * 2);
+    // Workgroups: twice what the device holds at once where a workgroup serves several systems side by side (sub-wavefront teams)
+    // or owns a workspace in global memory; a workgroup per system -- up to 32 times what the device holds -- where it solves one
+    // system at a time in its LDS: the dispatcher then hands a free place the next system, whatever the systems before it took
+    // (a jittered batch's systems take 4 to 10 iterations) and whoever else occupies places on the device -- sketch150 x 32 768
+    // at x1 / x2 / x4 / x8 / x32: 3.58 / 3.62 / 3.70 / 3.82 / 3.91 M solves/s; starting a workgroup costs a few microseconds
+    // against the ~250 of a system.
+    const uint32_t rounds = (s.lds_ws && s.mode != MODE_SUB) ? 32u : 2u;
+    grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)s.lim.cus * std::min<uint32_t>(per_cu, 8) * rounds);
+    if (s.rec && s.rec_jglobal)  // (a workgroup's Jacobian values in global memory: at most 1 GiB of them)
+        grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (1ull << 27) / ((s.counts.zj + 2) & ~1ull)));
     if (!s.lds_ws) {
         int rc = s.gws_dev.ensure((size_t)grid * s.ws_doubles);
         if (rc != EZPZ_OK) return rc;
@@ -317,7 +326,37 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             if (st == 0 && (big || sync || s.launches.fetch_add(1) >= pol.jit_after_launches)) st = comp_jit_request(s.jit, sync);
             if (st == 2) {
                 if (s.comp->jit_wgs <= 1) {
-                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream) == EZPZ_OK) return EZPZ_OK;
+                    // a batch beyond the launch's workgroups: the workgroups draw their systems from the system's counter, and
+                    // launches that share the counter are chained
+                    const uint64_t capacity = L.done.flag ? 0 : comp_jit_capacity(s.jit, *s.comp, s.device, s.lim.cus);
+                    CompLaunch Lt = L;
+                    static const bool tickets_enabled = [] {  // EZPZ_TICKETS=0: fixed shares (A/B runs: 101.1 -> 110.0 M solves/s with them)
+                        const char* e = std::getenv("EZPZ_TICKETS");
+                        return !(e && e[0] == '0');
+                    }();
+                    if (tickets_enabled && capacity && L.batch > capacity && L.batch < (1ull << 32)) {
+                        bool ok = s.ticket.p != nullptr;
+                        if (!ok && s.ticket.ensure(8 * 1024) == EZPZ_OK) {  // (jit_kernel.hip.hpp: kTicketStride words apart)
+                            ok = hipMemset(s.ticket.p, 0, 8 * 1024 * sizeof(unsigned int)) == hipSuccess;
+                            for (unsigned int& b : s.ticket_base) b = 0;
+                        }
+                        if (ok && !s.ticket_done) ok = hipEventCreateWithFlags(&s.ticket_done, hipEventDisableTiming) == hipSuccess;
+                        else if (ok) ok = hipStreamWaitEvent(stream, s.ticket_done, 0) == hipSuccess;
+                        if (ok) Lt.ticket = s.ticket.p, Lt.ticket_base = s.ticket_base;
+                        else (void)hipGetLastError();
+                    }
+                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, Lt, s.device, s.lim.cus, stream) == EZPZ_OK) {
+                        if (Lt.ticket) {
+                            // every workgroup draws once per system it solves, the last time in vain: counter c hands out its share of
+                            // the systems beyond the workgroups' own, and one value more to each of its workgroups
+                            for (uint64_t c = 0; c < 8; ++c) {
+                                const uint64_t wgs_c = (capacity + 7 - c) / 8, beyond = L.batch - capacity;
+                                s.ticket_base[c] += (unsigned int)(wgs_c + (beyond > c ? (beyond - c + 7) / 8 : 0));
+                            }
+                            HIP_TRY(hipEventRecord(s.ticket_done, stream));
+                        }
+                        return EZPZ_OK;
+                    }
                 } else {
                     CompLaunch Lg = L;
                     Lg.done.request = nullptr;  // (several workgroups per system: never resident)

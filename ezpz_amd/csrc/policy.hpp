@@ -57,12 +57,14 @@ inline EzpzLaunchPolicy launch_policy_for(int compute_units) {
     p.one_call_host_mask_max_constraints = 256;  // ezpz_solve: unsatisfied mask / warning log straight to mapped host memory up to here
     p.one_call_host_log_max_entries = 8192;
     // the frontal shape (fronts.cpp): one solve of a connected sketch from 48 variables; a system created for batches carries
-    // the plan from the same size and takes it for SMALL calls -- those whose workgroups (systems x workgroups per system) the
-    // device holds front_small_call_fill times over (profiles/r05_sketch_scaling_small_calls.txt); device-filling batches stay
-    // on the record walk / the lanes, which need half the instructions per solve
+    // the plan from the same size and takes it for SMALL calls: as many systems as the device holds at once (CUs / workgroups per
+    // system), times one ROUND per front_small_call_wgs_per_round workgroups per system -- the more workgroups a system is spread
+    // over, the further ahead of the record walk its solve is (one solve, fronts vs records: 6 workgroups x1.9, 14 x3.6, 22 x9.4;
+    // profiles/r05_small_calls.txt); device-filling batches stay on the record walk / the lanes, which need half the
+    // instructions per solve
     p.front_min_vars_one_solve = 48;
     p.front_min_vars_batch = 48;
-    p.front_small_call_fill = 2;
+    p.front_small_call_wgs_per_round = 4;
     p.front_vars_per_workgroup = 160;
     p.front_max_workgroups = 64;  // (20 000 variables need 48 to fit their shares into the LDS)
     return p;

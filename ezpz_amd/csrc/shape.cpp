@@ -672,10 +672,11 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
                     info.workspace_in_lds = 1;
                     info.program_in_lds = 0;
                 } else {
-                    // batches: the calls whose systems x workgroups the device holds `front_small_call_fill` times over (one
-                    // workgroup per system: once -- four 128-lane teams of the record walk share a CU from there)
-                    const uint64_t cus = (uint64_t)std::max(1, s.lim.cus);
-                    s.front_max_batch = plan->n_wgs > 1 ? std::max<uint64_t>(1, pol.front_small_call_fill * cus / plan->n_wgs) : cus;
+                    // batches: as many systems as the device holds at once, times a round per `front_small_call_wgs_per_round`
+                    // workgroups per system (policy.hpp)
+                    const uint64_t cus = (uint64_t)std::max(1, s.lim.cus), G = plan->n_wgs;
+                    const uint64_t rounds = std::max<uint64_t>(1, G / std::max<uint32_t>(1, pol.front_small_call_wgs_per_round));
+                    s.front_max_batch = std::max<uint64_t>(1, cus / G) * rounds;
                     info.front_max_batch = (uint32_t)std::min<uint64_t>(s.front_max_batch, 0xFFFFFFFEu);
                 }
                 info.program_bytes += plan->blob.size();

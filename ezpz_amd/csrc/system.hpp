@@ -193,6 +193,12 @@ struct EzpzSystem {
     DevBuf<uint32_t> strag_list, strag_count;  // the systems a lanes launch hands over to the teams (device-side list + count)
     DevBuf<LmResume> strag_state;              // ... and the LM state each had reached
     uint64_t lanes_ws_waves = 0;
+    // the specialised kernels' work counters (JitArgs::ticket): never reset -- what a launch draws from each follows from its batch and
+    // its workgroups, the host keeps the running totals -- so launches that use them are chained on `ticket_done` whatever their
+    // streams (under launch_mu)
+    DevBuf<unsigned int> ticket;
+    unsigned int ticket_base[8] = {};
+    hipEvent_t ticket_done = nullptr;
     hipEvent_t lanes_done = nullptr;  // completion of this system's last launch that used its global-memory workspace (lanes
                                       // kernel, list walk with the workspace in global memory): the next one, on any stream, waits for it
     uint64_t lanes_min = ~0ull;  // systems per call from which `lanes` serves the call
@@ -273,6 +279,7 @@ struct EzpzSystem {
         if (dev_lanes) (void)hipFree(dev_lanes);
         if (dev_fronts) (void)hipFree(dev_fronts);
         if (lanes_done) (void)hipEventDestroy(lanes_done);
+        if (ticket_done) (void)hipEventDestroy(ticket_done);
         comp_jit_destroy(jit);
         comp_jit_destroy(wave_jit);
     }

@@ -423,10 +423,11 @@ typedef struct EzpzLaunchPolicy {
     uint32_t one_call_host_mask_max_constraints, one_call_host_log_max_entries;
     /* the frontal shape (team_mode 5): one solve of a connected sketch takes it from this many variables; a system created for
      * batches (team_size 0) carries the plan from that many (0 = never) and takes it for calls of up to
-     * EzpzSystemInfo.front_max_batch systems (= front_small_call_fill x compute units / workgroups per system; one workgroup per
-     * system: compute units); one workgroup per system up to front_vars_per_workgroup x 2 variables, then one more per that many */
+     * EzpzSystemInfo.front_max_batch systems (= the systems the device holds at once, compute units / workgroups per system, times
+     * max(1, workgroups per system / front_small_call_wgs_per_round) rounds); one workgroup per system up to
+     * front_vars_per_workgroup x 2 variables, then one more per that many */
     uint32_t front_min_vars_one_solve, front_min_vars_batch, front_vars_per_workgroup, front_max_workgroups;
-    uint32_t front_small_call_fill;
+    uint32_t front_small_call_wgs_per_round;
 } EzpzLaunchPolicy;
 int ezpz_launch_policy(int compute_units, EzpzLaunchPolicy* out);
 

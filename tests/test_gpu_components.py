@@ -351,3 +351,35 @@ def test_random_classes_interpreter_and_specialised_kernel_agree_bitwise(E):
         assert want.error == 0 and np.array_equal(np.isnan(x[0]), np.isnan(want.final_values)), trial
         assert int(st["n_warnings"][0]) == len(want.warnings) or not want.converged, trial
     assert len(kinds_seen) >= 20
+
+
+@pytest.mark.parametrize("lines,over", [(50, False), (500, True)])
+def test_batches_beyond_the_launchs_workgroups_draw_their_systems(E, lines, over):
+    """The specialised kernel's workgroups draw their systems from eight counters once a batch exceeds the workgroups the device
+    holds (jit_kernel.hip.hpp: JitArgs::ticket; the host keeps the counters' running totals from launch to launch): odd batch
+    sizes, one launch after the other, every system of every launch bit for bit what calls that FIT the launch give (fixed
+    shares: no counter), statuses included -- a system solved twice, skipped, or handed to two workgroups would show."""
+    import torch
+
+    ref = T.load(T.gen_big_problem(lines, over))
+    n = ref.num_vars
+    sysobj = E.System(ref.constraints, n)
+    assert sysobj.specialize(wait=True) == 2
+    B = 9001
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(5, B, n, -0.25, 0.25)
+    want_x = np.empty_like(x0)
+    want_st = np.zeros(B, dtype=E.STATUS_DTYPE)
+    for lo in range(0, B, 256):  # 256 systems: fewer than the device holds workgroups
+        xs, sts, _ = sysobj.solve_batch(x0[lo:lo + 256])
+        want_x[lo:lo + 256], want_st[lo:lo + 256] = xs, sts
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0[:64], linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0 and np.array_equal(want_st["iterations"][:64], it)
+    assert_x_close(want_x[:64], xo)
+    xin = torch.from_numpy(x0).cuda()
+    for count in (B, 4099, 8191, 300, B, 7777):  # (300: a call that fits between two that do not)
+        xd = torch.full((count, n), float("nan"), dtype=torch.float64, device="cuda")
+        std = torch.zeros((count, 32), dtype=torch.uint8, device="cuda")
+        sysobj.solve_batch_device(xin.data_ptr(), count, xd.data_ptr(), std.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(xd.cpu().numpy(), want_x[:count]), count
+        assert np.array_equal(std.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1), want_st[:count]), count

@@ -198,7 +198,7 @@ def test_small_calls_of_a_batch_system_take_the_fronts(E, npts):
         records = E.System(recs, n)
     G = finfo["grid_workgroups"]
     assert info["team_mode"] != 5 and info["front_workgroups"] == G, info
-    assert info["front_max_batch"] == (cus if G == 1 else max(1, 2 * cus // G)), (info, G, cus)
+    assert info["front_max_batch"] == max(1, cus // G) * max(1, G // 4), (info, G, cus)
     assert finfo["front_max_batch"] == 0xFFFFFFFF and records.info()["front_workgroups"] == 0
     most = info["front_max_batch"]
     x0 = g[None, :] + gen.keyed_uniform(npts, most + 1, n, -0.01, 0.01)
