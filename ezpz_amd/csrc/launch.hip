@@ -187,7 +187,8 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     // (a jittered batch's systems take 4 to 10 iterations) and whoever else occupies places on the device -- sketch150 x 32 768
     // at x1 / x2 / x4 / x8 / x32: 3.58 / 3.62 / 3.70 / 3.82 / 3.91 M solves/s; starting a workgroup costs a few microseconds
     // against the ~250 of a system.
-    const uint32_t rounds = (s.lds_ws && s.mode != MODE_SUB) ? 32u : 2u;
+    // (a list of systems on the device -- the lanes' stragglers: `batch` is the list's capacity, the systems are a few hundred)
+    const uint32_t rounds = (s.lds_ws && s.mode != MODE_SUB && !args.sys_list) ? 32u : 2u;
     grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)s.lim.cus * std::min<uint32_t>(per_cu, 8) * rounds);
     if (s.rec && s.rec_jglobal)  // (a workgroup's Jacobian values in global memory: at most 1 GiB of them)
         grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (1ull << 27) / ((s.counts.zj + 2) & ~1ull)));
