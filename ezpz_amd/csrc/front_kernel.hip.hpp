@@ -8,8 +8,9 @@
 //     update matrices through their row maps (extend-add), factors the K pivot columns in registers (lane = row, pivots and
 //     multipliers by v_readlane, the right-hand side as row S so that the forward substitution rides along), and leaves the
 //     Schur complement of the rows below as its own update matrix;
-//   * the fronts of one level of the tree run side by side on the wavefronts of the workgroup, one barrier per level; the
-//     backward substitution walks the levels top down, a front solving its K unknowns from its panel;
+//   * every wavefront of the workgroup runs its own list of fronts (the planner's schedule: list scheduling on the cost model) and
+//     waits only for what its next front needs -- a counter in LDS that the front's children sign in on; the backward substitution
+//     runs the same way top down (a front waits for its parent's stamp), a front solving its K unknowns from its panel;
 //   * a system too large for one CU's LDS -- or too slow on one CU -- is cut at the top of the tree: whole subtrees go to
 //     workgroups 1 .. G-1, the top to workgroup 0; update matrices and steps cross workgroups as self-validating 16-byte chunks
 //     (grid_ops.hip.hpp), the LM control's sums gather at workgroup 0 and scatter.
@@ -462,7 +463,9 @@ struct Red {
 #endif
 
 // (512 lanes: two wavefronts per SIMD.  1024 -- four per SIMD at 128 registers, the non-linear evaluators spilling a little -- was
-// measured and not kept: one solve of 300 variables 191 -> 193 us, 800: 2.09 -> 2.30 ms)
+// measured twice and not kept: with a barrier per level of the tree, one solve of 300 variables 191 -> 193 us, 800: 2.09 -> 2.30 ms;
+// with the wavefronts' schedules 50 / 150 / 300 / 500 / 800 / 2000 / 5000 / 10 000 variables 84 -> 107, 96 -> 114, 179 -> 171, 347 ->
+// 413, 1844 -> 2038, 451 -> 509, 2659 -> 2703, 919 -> 798 us)
 template <bool LIN>
 __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) {
     using namespace frontal;
@@ -477,6 +480,12 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
     double* const redbuf = ws + a.ws_doubles;
     uint16_t* const tri = reinterpret_cast<uint16_t*>(redbuf + 128);
     int* const ints = reinterpret_cast<int*>(tri + 2080);  // [0] warnings, [1] a pivot failed
+    // per front: how many of its children (in this workgroup) have been factorised, all factorisations of this launch counted
+    // together (never reset: a front starts at children x the number of the factorisation); the number of the factorisation whose
+    // backward substitution the front has been through
+    unsigned int* const arrived = reinterpret_cast<unsigned int*>(ints + 16);
+    unsigned int* const bdone = arrived + W.n_fronts;
+    for (uint32_t i = tid; i < 2 * W.n_fronts; i += blockDim.x) arrived[i] = 0;
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.plan + W.o_tables);
         uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -509,12 +518,14 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
     red.wg = wg;
     red.seq = 0;
     red.dead = cx.dead;
+    const uint16_t* const sched = reinterpret_cast<const uint16_t*>(tab + W.t_sched);  // (FrontWg::t_sched)
+    unsigned int fact_no = 0;  // factorisations of this launch so far
     unsigned int epoch = 0;  // tag of the chunks of one linear solve (update matrices up, steps down)
     if (G > 1) {             // continue the slot's sequence numbers where this workgroup's previous launch left them
         epoch = __hip_atomic_load(&head->hop[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         red.seq = __hip_atomic_load(&head->red[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const uint32_t n_loc = W.n_loc, n_own = W.n_own, n_cons = W.n_cons, m = W.n_rows, zj = W.zj, nlev = W.n_levels;
+    const uint32_t n_loc = W.n_loc, n_own = W.n_own, n_cons = W.n_cons, m = W.n_rows, zj = W.zj;
     const uint32_t* const var_glob = reinterpret_cast<const uint32_t*>(a.plan + W.o_var_glob);
     // (the constraint table: its copy in the staged tables when the planner found room for one, else global memory)
     const DevCon* const cons = W.t_cons != 0xFFFFFFFFu ? reinterpret_cast<const DevCon*>(tab + W.t_cons) : reinterpret_cast<const DevCon*>(a.plan + W.o_cons);
@@ -571,12 +582,22 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 assemble(cx, W, lambda, l_r);
                 FRONT_STAMP(10);
                 bool bad_here = false;
-                for (uint32_t lv = 0; lv < nlev; ++lv) {
-                    const uint32_t k0 = uni(cx.level_ptr[lv]), k1 = uni(cx.level_ptr[lv + 1]);
-                    for (uint32_t k = k0 + uni(wave); k < k1; k += nwaves) bad_here |= front_factor(cx, k, lane, W.l_panels, epoch);
-                    __syncthreads();
-                    FRONT_STAMP(1000 + lv);
+                ++fact_no;
+                for (uint32_t i = uni(sched[wave]), i1 = uni(sched[wave + 1]); i < i1; ++i) {
+                    const uint32_t k = uni(sched[i]);
+                    const uint32_t kids = uni(cx.descs[k].n_kids_local), parent = uni(cx.descs[k].parent_local);
+                    if (kids) {
+                        const unsigned int want = kids * fact_no;
+                        while (uni(__hip_atomic_load(&arrived[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != want) __builtin_amdgcn_s_sleep(1);
+                    }
+                    bad_here |= front_factor(cx, k, lane, W.l_panels, epoch);
+                    if (parent != 0xFFFFFFFFu) {
+                        wave_sync();
+                        if (lane == 0) __hip_atomic_fetch_add(&arrived[parent], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
+                __syncthreads();
+                FRONT_STAMP(1000);
                 if (bad_here && lane == 0) ints[1] = 1;
                 if (G > 1) {
                     // a pivot failed somewhere?  every workgroup tells workgroup 0, whose verdict travels with the steps
@@ -607,12 +628,17 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                     __syncthreads();
                 }
                 dmax = __builtin_nan("");
-                for (uint32_t lv = nlev; lv-- > 0;) {
-                    const uint32_t k0 = uni(cx.level_ptr[lv]), k1 = uni(cx.level_ptr[lv + 1]);
-                    for (uint32_t k = k0 + uni(wave); k < k1; k += nwaves) dmax = front_bwd(cx, k, lane, epoch, dmax);
-                    __syncthreads();
-                    FRONT_STAMP(2000 + lv);
+                for (uint32_t i = uni(sched[nwaves + 1 + wave]), i1 = uni(sched[nwaves + 2 + wave]); i < i1; ++i) {
+                    const uint32_t k = uni(sched[i]);
+                    const uint32_t parent = uni(cx.descs[k].parent_local);
+                    if (parent != 0xFFFFFFFFu)
+                        while (uni(__hip_atomic_load(&bdone[parent], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != fact_no) __builtin_amdgcn_s_sleep(1);
+                    dmax = front_bwd(cx, k, lane, epoch, dmax);
+                    wave_sync();
+                    if (lane == 0) __hip_atomic_store(&bdone[k], fact_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                __syncthreads();
+                FRONT_STAMP(2000);
                 FRONT_STAMP(12);
                 // ---- tentative step (newton.rs:111-114): own variables and ghosts alike (every workgroup moves its copy) -----------------
                 for (uint32_t i = tid; i < n_loc; i += blockDim.x) xs[i] = xs[i] + dv[i];

@@ -33,11 +33,11 @@ struct alignas(16) FrontDesc {
     uint32_t child0;       // index of the first FrontChild
     uint32_t src_off;      // word offset of the front's source stream in the staged tables
     uint16_t src_n;        // entries in it
-    uint16_t pad0;
+    uint16_t n_kids_local; // children in THIS workgroup: the front starts when that many have signed in (front_kernel.hip.hpp)
     uint8_t src_v[4];      // source words per entry in trip 0, 1, 2 and >= 3 of 64 entries (4-byte aligned: read as one word)
     uint32_t up_chunk;     // FRONT_REMOTE_PARENT: first chunk of the update matrix in the system's scratch
     uint32_t exp0;         // FRONT_EXPORTS: index into the export table: K entries (chunk of pivot k's step, or ~0)
-    uint32_t pad1;
+    uint32_t parent_local; // the parent's index among this workgroup's fronts, or ~0 (a root of the workgroup's share)
 };
 static_assert(sizeof(FrontDesc) == 48, "FrontDesc layout");
 constexpr uint16_t FRONT_REMOTE_PARENT = 1, FRONT_EXPORTS = 2;
@@ -78,7 +78,12 @@ struct alignas(16) FrontWg {
     uint32_t l_x, l_d, l_r, l_rn, l_jv, l_panels, l_upool;  // workspace carve-up (doubles)
     uint32_t ws_doubles;              // workspace doubles (state), tables excluded
     uint32_t n_remote_children;       // fronts of this workgroup that wait for chunks of other workgroups
-    uint32_t pad[1];
+    // The wavefronts' SCHEDULES (byte offset inside the staged tables; uint16 words): [threads / 64 + 1] starts of the forward lists,
+    // [threads / 64 + 1] starts of the backward lists (in words from the table's start), then the lists -- the fronts a wavefront
+    // factorises, in order (a front starts when its local children have signed in), and the fronts it substitutes back, in order
+    // (a front starts when its local parent is through).  Made by list scheduling on the cost model (fronts.cpp): no barrier
+    // between the levels of the tree, a wavefront waits for exactly what its next front needs.
+    uint32_t t_sched;
 };
 static_assert(sizeof(FrontWg) % 16 == 0, "FrontWg layout");
 

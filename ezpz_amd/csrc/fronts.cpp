@@ -545,10 +545,12 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
     out.blob.assign(((size_t)G * sizeof(FrontWg) + 15) & ~size_t(15), 0);
     const uint32_t waves = std::max(1u, opt.threads / 64);
     double model_top = 0.0, model_sub = 0.0;
+    size_t max_fronts_wg = 0;
     for (uint32_t g = 0; g < G; ++g) {
         FrontWg& W = wgs[g];
         std::memset(&W, 0, sizeof(W));
         UVec& fl = wg_fronts[g];
+        UVec sched_par, sched_nkids;
         std::stable_sort(fl.begin(), fl.end(), [&](uint32_t a, uint32_t b) {
             if (fr[a].level != fr[b].level) return fr[a].level < fr[b].level;
             return fr[a].cost > fr[b].cost;
@@ -570,6 +572,114 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
                 model_top = up;  // (workgroup 0 runs after the others)
             else
                 model_sub = std::max(model_sub, up);
+        }
+        // ---- the wavefronts' schedules: list scheduling of the workgroup's fronts on `waves` wavefronts by the cost model -- forward:
+        //      a front is ready when its children in this workgroup are done (children elsewhere arrive as chunks, whenever), the
+        //      ready front with the longest way up to the top goes to the wavefront that is free first; backward: ready when the
+        //      parent is done, the longest way down first.  A wavefront runs its list in order and waits only for what its next
+        //      front needs (front_kernel.hip.hpp): the per-level barriers cost the 300-variable sketch 11 rounds of fronts where
+        //      the tree's critical path is 6.  (Deadlock-free: a front's dependencies start earlier in the simulated time than it
+        //      does, on whatever wavefront, and every list is in simulated start order.)
+        std::vector<uint16_t> sched;
+        {
+            const uint32_t nf = (uint32_t)fl.size();
+            UVec loc_of(F, NONE);
+            for (uint32_t k = 0; k < nf; ++k) loc_of[fl[k]] = k;
+            UVec par(nf, NONE), nkids(nf, 0);
+            std::vector<UVec> kid_list(nf);
+            for (uint32_t k = 0; k < nf; ++k) {
+                const uint32_t p = fr[fl[k]].parent;
+                if (p != NONE && fr[p].wg == g) {
+                    par[k] = loc_of[p];
+                    ++nkids[par[k]];
+                    kid_list[par[k]].push_back(k);
+                }
+            }
+            std::vector<double> cf(nf), cb(nf), up(nf, 0.0), down(nf, 0.0);
+            for (uint32_t k = 0; k < nf; ++k) {
+                cf[k] = front_cost(fr[fl[k]].K, fr[fl[k]].S, !fr[fl[k]].kids.empty());
+                cb[k] = front_bwd_cost(fr[fl[k]].K, fr[fl[k]].S);
+            }
+            // (fl is sorted by level: parents behind their children)
+            for (uint32_t k = nf; k-- > 0;) up[k] = cf[k] + (par[k] != NONE ? up[par[k]] : 0.0);
+            for (uint32_t k = 0; k < nf; ++k) {
+                down[k] += cb[k];
+                if (par[k] != NONE) down[par[k]] = std::max(down[par[k]], down[k]);
+            }
+            // (down[k] so far = cb[k] + the longest way below: recompute top-down as a priority = longest way down including itself)
+            auto run = [&](bool forward, std::vector<UVec>& lists) -> double {
+                lists.assign(waves, UVec());
+                std::vector<double> free_at(waves, 0.0), done_at(nf, 0.0);
+                UVec waiting(nf, 0);
+                std::vector<uint32_t> ready;
+                for (uint32_t k = 0; k < nf; ++k) {
+                    waiting[k] = forward ? nkids[k] : (par[k] != NONE ? 1u : 0u);
+                    if (!waiting[k]) ready.push_back(k);
+                }
+                std::vector<double> ready_at(nf, 0.0);
+                uint32_t left = nf;
+                double makespan = 0.0;
+                while (left) {
+                    // the wavefront that is free first takes, of the fronts ready by then (or the one ready soonest), the one with
+                    // the highest priority
+                    uint32_t w = 0;
+                    for (uint32_t i = 1; i < waves; ++i)
+                        if (free_at[i] < free_at[w]) w = i;
+                    double soonest = 1e300;
+                    for (uint32_t k : ready) soonest = std::min(soonest, ready_at[k]);
+                    const double now = std::max(free_at[w], soonest);
+                    size_t best = ready.size();
+                    for (size_t i = 0; i < ready.size(); ++i) {
+                        const uint32_t k = ready[i];
+                        if (ready_at[k] > now) continue;
+                        const double pr = forward ? up[k] : down[k];
+                        if (best == ready.size() || pr > (forward ? up[ready[best]] : down[ready[best]])) best = i;
+                    }
+                    const uint32_t k = ready[best];
+                    ready.erase(ready.begin() + (long)best);
+                    const double end = now + (forward ? cf[k] : cb[k]) + 60.0;
+                    free_at[w] = end;
+                    done_at[k] = end;
+                    makespan = std::max(makespan, end);
+                    lists[w].push_back(k);
+                    --left;
+                    if (forward) {
+                        if (par[k] != NONE) {
+                            ready_at[par[k]] = std::max(ready_at[par[k]], end);
+                            if (--waiting[par[k]] == 0) ready.push_back(par[k]);
+                        }
+                    } else {
+                        for (uint32_t c : kid_list[k]) {
+                            ready_at[c] = end;
+                            waiting[c] = 0;
+                            ready.push_back(c);
+                        }
+                    }
+                }
+                return makespan;
+            };
+            std::vector<UVec> fwd, bwd;
+            const double span_f = run(true, fwd), span_b = run(false, bwd);
+            sched.assign(2 * (waves + 1), 0);
+            for (int pass = 0; pass < 2; ++pass) {
+                const std::vector<UVec>& L = pass ? bwd : fwd;
+                for (uint32_t w = 0; w < waves; ++w) {
+                    sched[(size_t)pass * (waves + 1) + w] = (uint16_t)sched.size();
+                    for (uint32_t k : L[w]) sched.push_back((uint16_t)k);
+                }
+                sched[(size_t)pass * (waves + 1) + waves] = (uint16_t)sched.size();
+            }
+            if (sched.size() >= 65535) return fail(why, "a workgroup's schedule does not fit 16-bit offsets");
+            if (sched.size() & 1) sched.push_back(0);
+            for (uint32_t k = 0; k < nf; ++k) {
+                sched_par.push_back(par[k]);
+                sched_nkids.push_back(nkids[k]);
+            }
+            // the model: the schedules' makespans instead of the levels' busiest wavefronts
+            if (g == 0)
+                model_top = span_f + span_b;
+            else
+                model_sub = std::max(model_sub, span_f + span_b);
         }
         // local variables: own pivots in front order, ghosts behind
         UVec local_of(n, NONE);  // position -> local index
@@ -654,6 +764,8 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             std::memset(&d, 0, sizeof(d));
             d.K = (uint16_t)t.K;
             d.S = (uint16_t)t.S;
+            d.n_kids_local = (uint16_t)sched_nkids[k];
+            d.parent_local = sched_par[k];
             d.panel = take((t.S + 1) * t.K);
             out.panel_doubles += (uint64_t)(t.S + 1) * t.K;
         }
@@ -875,11 +987,12 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             W.t_exports = T.put(exports);
             W.t_maps = T.put(maps);
             W.t_stream = T.put(stream_words);
+            W.t_sched = T.put(sched);
             tab.resize((tab.size() + 15) & ~size_t(15), 0);
             // the constraint table rides along where the LDS has room to spare (the sweeps then read their 80-byte records from
             // LDS instead of L2: two sweeps per iteration)
             W.t_cons = 0xFFFFFFFFu;
-            const size_t extras = 2 * 4 * 16 * 8 + 2080 * 2 + 64;
+            const size_t extras = 2 * 4 * 16 * 8 + 2080 * 2 + 64 + 8 * fl.size();
             if (!dcons.empty() && (tab.size() + dcons.size() * sizeof(DevCon) + (size_t)W.ws_doubles * 8 + extras) * 5 <= opt.lds_bytes * 4) {
                 W.t_cons = T.put(dcons);
                 tab.resize((tab.size() + 15) & ~size_t(15), 0);
@@ -892,6 +1005,7 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
         out.n_levels = std::max(out.n_levels, nlev);
         out.ws_doubles_max = std::max(out.ws_doubles_max, W.ws_doubles);
         out.tab_bytes_max = std::max(out.tab_bytes_max, W.tab_bytes);
+        max_fronts_wg = std::max<size_t>(max_fronts_wg, fl.size());
         if (debug)
             std::fprintf(stderr, "front plan: wg %u: %u fronts in %u levels, %u own + %u ghost variables, %u constraints, workspace %u doubles, tables %u B, streams %zu words\n",
                          g, W.n_fronts, nlev, W.n_own, W.n_ghost, W.n_cons, W.ws_doubles, W.tab_bytes, stream_words.size());
@@ -903,7 +1017,8 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
     const double model = model_top + model_sub;
     out.model_cycles = model;
     // dynamic LDS: [tables][workspace][reduction scratch: 2 x 4 x 16 doubles][tri table 2080 x u16][small ints]
-    out.lds_bytes = ((size_t)out.tab_bytes_max + 15) / 16 * 16 + (size_t)out.ws_doubles_max * 8 + 2 * 4 * 16 * 8 + 2080 * 2 + 64;
+    // ... [per front: children signed in, substituted-back stamp: 2 x u32]
+    out.lds_bytes = ((size_t)out.tab_bytes_max + 15) / 16 * 16 + (size_t)out.ws_doubles_max * 8 + 2 * 4 * 16 * 8 + 2080 * 2 + 64 + 8 * max_fronts_wg;
     if (out.lds_bytes > opt.lds_bytes) return fail(why, "a workgroup's share does not fit the LDS");
     if (debug)
         std::fprintf(stderr, "front plan: %u variables, %u fronts (largest %u x %u), %u levels, %u workgroups, LDS %zu B, model %.0f cycles, chunks %u\n",

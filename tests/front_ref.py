@@ -12,15 +12,15 @@ import ezpz_amd as E
 from oracle import oracle as O
 
 FRONT_DESC = np.dtype([("K", "<u2"), ("S", "<u2"), ("n_child", "<u2"), ("flags", "<u2"), ("panel", "<u4"), ("upd", "<u4"),
-                       ("rows", "<u4"), ("child0", "<u4"), ("src_off", "<u4"), ("src_n", "<u2"), ("pad0", "<u2"),
-                       ("src_v", "u1", (4,)), ("up_chunk", "<u4"), ("exp0", "<u4"), ("pad1", "<u4")])
+                       ("rows", "<u4"), ("child0", "<u4"), ("src_off", "<u4"), ("src_n", "<u2"), ("n_kids_local", "<u2"),
+                       ("src_v", "u1", (4,)), ("up_chunk", "<u4"), ("exp0", "<u4"), ("parent_local", "<u4")])
 assert FRONT_DESC.itemsize == 48
 FRONT_CHILD = np.dtype([("upd", "<u4"), ("rows", "<u2"), ("flags", "<u2"), ("map", "<u4"), ("pad", "<u4")])
 assert FRONT_CHILD.itemsize == 16
 FRONT_GHOST = np.dtype([("local", "<u4"), ("chunk", "<u4")])
 WG_FIELDS = ["n_loc", "n_own", "n_ghost", "n_cons", "n_rows", "zj", "n_fronts", "n_levels", "o_var_glob", "o_cons", "o_tables",
              "tab_bytes", "t_level_ptr", "t_children", "t_rows", "t_exports", "t_maps", "t_stream", "asm_word0", "asm_trips", "t_cons", "o_ghosts", "l_x", "l_d", "l_r",
-             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "pad0"]
+             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "t_sched"]
 FRONT_WG = np.dtype([(f, "<u4") for f in WG_FIELDS])
 assert FRONT_WG.itemsize == 128
 DEVCON = np.dtype([("ids", "<u4", (8,)), ("param", "<f8"), ("weight", "<f8"), ("row0", "<u4"), ("jbase", "<u4"), ("pos", "<u4"),

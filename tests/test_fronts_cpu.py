@@ -74,3 +74,51 @@ def test_workgroup_shares_fit_the_lds_they_are_given():
     p = FR.Plan(recs, len(g), wgs=0, lds_bytes=64 * 1024)
     assert p.ok and p.lds_bytes <= 64 * 1024 and p.n_wgs >= 4
     assert not FR.Plan(recs, len(g), wgs=1, lds_bytes=64 * 1024).ok  # 800 variables do not fit 64 KB on one workgroup
+
+
+@pytest.mark.parametrize("npts,wgs", [(25, 1), (150, 1), (400, 0), (1000, 0)])
+def test_wavefront_schedules_cover_every_front_once_and_cannot_deadlock(npts, wgs):
+    """FrontWg::t_sched: eight forward and eight backward lists per workgroup.  Every front of the workgroup is on exactly one list of
+    each kind; parents and child counts of the descriptors agree; and the wavefronts, each running its list IN ORDER and waiting for
+    what its next front needs (forward: the children of this workgroup, backward: the parent), all get through -- whatever the
+    timing: stepped here with the slowest possible interleaving (one front of one wavefront at a time, lowest wavefront first)."""
+    recs, g = gen.connected_sketch(npts, 1000 + npts)
+    plan = FR.Plan(recs, len(g), wgs=wgs)
+    waves = 8
+    for gi in range(plan.n_wgs):
+        W = plan.wgs[gi]
+        descs = plan.wg_tables(gi)[0]
+        nf = len(descs)
+        t0 = int(W["o_tables"]) + int(W["t_sched"])
+        head = plan.arr("<u2", t0, 2 * (waves + 1))
+        total = int(head[2 * waves + 1])
+        words = plan.arr("<u2", t0, total)
+        lists = [[[int(k) for k in words[int(head[p * (waves + 1) + w]):int(head[p * (waves + 1) + w + 1])]] for w in range(waves)] for p in range(2)]
+        parent = [int(d["parent_local"]) for d in descs]
+        kids = [0] * nf
+        for k in range(nf):
+            if parent[k] != 0xFFFFFFFF:
+                assert parent[k] < nf and parent[k] != k
+                kids[parent[k]] += 1
+        assert kids == [int(d["n_kids_local"]) for d in descs]
+        for p in range(2):
+            assert sorted(k for l in lists[p] for k in l) == list(range(nf)), (gi, p)
+            done = [False] * nf
+            signed = [0] * nf
+            at = [0] * waves
+            progressed = True
+            while progressed:
+                progressed = False
+                for w in range(waves):
+                    if at[w] == len(lists[p][w]):
+                        continue
+                    k = lists[p][w][at[w]]
+                    ready = signed[k] == kids[k] if p == 0 else (parent[k] == 0xFFFFFFFF or done[parent[k]])
+                    if ready:
+                        done[k] = True
+                        if p == 0 and parent[k] != 0xFFFFFFFF:
+                            signed[parent[k]] += 1
+                        at[w] += 1
+                        progressed = True
+                        break
+            assert all(done), (gi, p, [k for k in range(nf) if not done[k]][:8])

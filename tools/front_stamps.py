@@ -1,5 +1,5 @@
 """Diagnostic: cycle stamps of workgroup 0 / thread 0 over one solve on the frontal shape (front_kernel.hip.hpp, FRONT_STAMP): where an LM
-iteration's time goes -- per level of the tree, inside wavefront 0's fronts (zero, assembly stream, extend-add, pivots, Schur complement),
+iteration's time goes -- inside wavefront 0's fronts (extend-add, pivots, Schur complement; the other wavefronts run their own lists),
 the backward substitution, the sweeps and the reductions.  Needs the stamped build:
 python -c "import ezpz_amd.build as b; b.build(extra_flags=['-DEZPZ_STAMPS'], lib_path=b.LIB.replace('.so', '_stamps.so'))"
 usage (GPU box): python tools/front_stamps.py <points> [workgroups] [iteration to print]"""
@@ -35,7 +35,7 @@ print(f"total cycles {b[-1, 1] - b[0, 1]} over {int((b[:, 0] == 22).sum())} trip
 for i, t in b:
     i = int(i)
     if it == which:
-        nm = names.get(i, f"level {i - 1000} factorised" if 1000 <= i < 2000 else f"level {i - 2000} substituted" if i >= 2000 else str(i))
+        nm = names.get(i, "every wavefront's fronts factorised" if i == 1000 else "... substituted back" if i == 2000 else str(i))
         print(f"{nm:>34}: +{(t - prev) if prev is not None else 0:7d}")
     if i == 22: it += 1
     prev = t
