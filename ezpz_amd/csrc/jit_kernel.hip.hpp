@@ -87,13 +87,19 @@ __device__ __forceinline__ gridchunk_t grid_peek(const gridchunk_t* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(c) : "v"(p) : "memory");
     return c;
 }
+// When a wait gives up: every 1024th look, after 2^21 looks or as soon as anybody else has given up (the caller then raises the flag
+// itself, which makes the whole system's status EZPZ_ITERATIONS_TEAM_TIMEOUT).  A macro, and the spin loops stay written out where
+// they are (they differ in how many chunks they request together): this kernel's schedule notices helper functions -- the same test
+// as an inline function with the store inside, and the chunk's value through one, cost the ladder 1 % on one box (428.5-429.9 vs
+// 423.7-426.1 k solves/s); a generalised form of the reductions 8 % (DESIGN_HISTORY.md).
+#define EZPZ_GRID_TIMED_OUT(spins, dead) \
+    (((spins) & 1023u) == 1023u && ((spins) >= (1u << 21) || __hip_atomic_load((dead), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
 __device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int seq, int* dead) {
     gridchunk_t c;
     for (unsigned int spins = 0;; ++spins) {
         c = grid_peek(p);
         if (c.z == seq) break;
-        if ((spins & 1023u) == 1023u &&
-            (spins >= (1u << 21) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (EZPZ_GRID_TIMED_OUT(spins, dead)) {
             __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return __builtin_nan("");
         }
@@ -101,36 +107,6 @@ __device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int s
     }
     return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x);
 }
-// Four chunks at once (the four partials of one workgroup): the four loads are in flight together, one round trip to
-// the memory side instead of four.
-__device__ __forceinline__ void grid_wait4(const gridchunk_t* p0, const gridchunk_t* p1, const gridchunk_t* p2, const gridchunk_t* p3,
-                                           unsigned int seq, int* dead, double (&v)[4]) {
-    gridchunk_t c0, c1, c2, c3;
-    for (unsigned int spins = 0;; ++spins) {
-        asm volatile(
-            "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
-            "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-            "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
-            "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
-            : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-            : "memory");
-        if (c0.z == seq && c1.z == seq && c2.z == seq && c3.z == seq) break;
-        if ((spins & 1023u) == 1023u &&
-            (spins >= (1u << 21) || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v[0] = v[1] = v[2] = v[3] = __builtin_nan("");
-            return;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    v[0] = __builtin_bit_cast(double, ((unsigned long long)c0.y << 32) | c0.x);
-    v[1] = __builtin_bit_cast(double, ((unsigned long long)c1.y << 32) | c1.x);
-    v[2] = __builtin_bit_cast(double, ((unsigned long long)c2.y << 32) | c2.x);
-    v[3] = __builtin_bit_cast(double, ((unsigned long long)c3.y << 32) | c3.x);
-}
-
 // One component per lane of one class: everything in registers (every index below is a literal after inlining).
 template <class C>
 struct Slot {
@@ -230,62 +206,9 @@ struct Red {
     GridScratch* grid;  // null: the workgroup owns its system alone
     uint32_t grid_wgs, grid_wg;
     unsigned int grid_seq;
-    // (sum, max, max, max) over the workgroups of a system; every thread passes the workgroup's values, every thread
-    // gets the system's
-    __device__ __forceinline__ void across_workgroups(double& s0, double& m1, double& m2, double& m3, int lane, uint32_t wave, uint32_t nwaves) {
-        using namespace ezpz::dev;
-        const int tid = threadIdx.x;
-        const unsigned int seq = ++grid_seq;
-        const unsigned int par = seq & 1u;
-        // (a workgroup publishes sequence number s+1 only after it has consumed the result of s, and workgroup 0 writes
-        // the result of s+2 only after every arrival for s+2: parities never collide)
-        if (tid < 4) grid_store(&grid->arr[par][tid][grid_wg], tid == 0 ? s0 : tid == 1 ? m1 : tid == 2 ? m2 : m3, seq);
-        double* b = buf + (flip ? 48 : 0);
-        flip ^= 1;
-        if (grid_wg == 0) {
-            double a0 = 0.0, a1 = __builtin_nan(""), a2 = a1, a3 = a1;
-            for (uint32_t g = tid; g < grid_wgs; g += blockDim.x) {
-                double v[4];
-                grid_wait4(&grid->arr[par][0][g], &grid->arr[par][1][g], &grid->arr[par][2][g], &grid->arr[par][3][g], seq, &grid->dead, v);
-                a0 = a0 + v[0];
-                a1 = fmax_nc(a1, v[1]);
-                a2 = fmax_nc(a2, v[2]);
-                a3 = fmax_nc(a3, v[3]);
-            }
-            a0 = reduce_wave_to_last_lane(a0, OpSum());
-            a1 = reduce_wave_to_last_lane(a1, OpMax());
-            a2 = reduce_wave_to_last_lane(a2, OpMax());
-            a3 = reduce_wave_to_last_lane(a3, OpMax());
-            if (lane == 63) {
-                b[wave] = a0;
-                b[12 + wave] = a1;
-                b[24 + wave] = a2;
-                b[36 + wave] = a3;
-            }
-            __syncthreads();
-            const bool in = (uint32_t)lane < nwaves;
-            const int l = lane & 15;
-            s0 = uniform(reduce_lanes<16>(in ? b[l] : 0.0, OpSum()));
-            m1 = uniform(reduce_lanes<16>(in ? b[12 + l] : __builtin_nan(""), OpMax()));
-            m2 = uniform(reduce_lanes<16>(in ? b[24 + l] : __builtin_nan(""), OpMax()));
-            m3 = uniform(reduce_lanes<16>(in ? b[36 + l] : __builtin_nan(""), OpMax()));
-            for (uint32_t g = 1 + tid; g < grid_wgs; g += blockDim.x) {  // one line per workgroup
-                grid_store(&grid->out[par][g][0], s0, seq);
-                grid_store(&grid->out[par][g][1], m1, seq);
-                grid_store(&grid->out[par][g][2], m2, seq);
-                grid_store(&grid->out[par][g][3], m3, seq);
-            }
-        } else {
-            if (tid < 4) b[tid] = grid_wait(&grid->out[par][grid_wg][tid], seq, &grid->dead);
-            __syncthreads();
-            s0 = uniform(b[0]);
-            m1 = uniform(b[1]);
-            m2 = uniform(b[2]);
-            m3 = uniform(b[3]);
-        }
-    }
-    // across_workgroups for step()'s three values with its flag riding in the spare word of the first chunk: three chunks per
-    // workgroup to publish, gather and scatter instead of four
+    // step()'s three values (a sum, two maxima) over the workgroups of a system, its flag riding in the spare word of the first chunk:
+    // every thread passes the workgroup's values, every thread gets the system's.  Three chunks per workgroup to publish, gather and
+    // scatter (a grid reduction costs by the lines it touches)
     __device__ __forceinline__ bool across_workgroups3(double& s0, double& m1, double& m2, bool flag, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
         const int tid = threadIdx.x;
@@ -315,8 +238,7 @@ struct Red {
                         : "v"(&grid->arr[par][0][g]), "v"(&grid->arr[par][1][g]), "v"(&grid->arr[par][2][g])
                         : "memory");
                     if (c0.z == seq && c1.z == seq && c2.z == seq) break;
-                    if ((spins & 1023u) == 1023u &&
-                        (spins >= (1u << 21) || __hip_atomic_load(&grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (EZPZ_GRID_TIMED_OUT(spins, &grid->dead)) {
                         __hip_atomic_store(&grid->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
                         c0.x = c1.x = c2.x = (unsigned int)nan, c0.y = c1.y = c2.y = (unsigned int)(nan >> 32);
@@ -358,8 +280,7 @@ struct Red {
                 for (unsigned int spins = 0;; ++spins) {
                     c = grid_peek(&grid->out[par][grid_wg][tid]);
                     if (c.z == seq) break;
-                    if ((spins & 1023u) == 1023u &&
-                        (spins >= (1u << 21) || __hip_atomic_load(&grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (EZPZ_GRID_TIMED_OUT(spins, &grid->dead)) {
                         __hip_atomic_store(&grid->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
                         c.x = (unsigned int)nan, c.y = (unsigned int)(nan >> 32), c.w = 0;
@@ -378,8 +299,7 @@ struct Red {
         }
         return failed;
     }
-    // across_workgroups for eval()'s two values alone (a sum, a maximum): two chunks per workgroup to publish, gather and
-    // scatter instead of four with two of them padding (a grid reduction costs by the lines it touches)
+    // ... and eval()'s two values alone (a sum, a maximum): two chunks per workgroup
     __device__ __forceinline__ void across_workgroups2(double& s0, double& m1, int lane, uint32_t wave, uint32_t nwaves) {
         using namespace ezpz::dev;
         const int tid = threadIdx.x;
@@ -401,8 +321,7 @@ struct Red {
                         : "v"(&grid->arr[par][0][g]), "v"(&grid->arr[par][1][g])
                         : "memory");
                     if (c0.z == seq && c1.z == seq) break;
-                    if ((spins & 1023u) == 1023u &&
-                        (spins >= (1u << 21) || __hip_atomic_load(&grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (EZPZ_GRID_TIMED_OUT(spins, &grid->dead)) {
                         __hip_atomic_store(&grid->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long nan = __builtin_bit_cast(unsigned long long, __builtin_nan(""));
                         c0.x = c1.x = (unsigned int)nan, c0.y = c1.y = (unsigned int)(nan >> 32);
