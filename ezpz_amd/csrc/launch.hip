@@ -335,7 +335,13 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                         const char* e = std::getenv("EZPZ_TICKETS");
                         return !(e && e[0] == '0');
                     }();
-                    if (tickets_enabled && capacity && L.batch > capacity && L.batch < (1ull << 32)) {
+                    // (a launch that is being recorded into a graph keeps fixed shares: a replay would find the counters elsewhere)
+                    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+                    if (stream && hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
+                        (void)hipGetLastError();
+                        capturing = hipStreamCaptureStatusNone;
+                    }
+                    if (tickets_enabled && capturing == hipStreamCaptureStatusNone && capacity && L.batch > capacity && L.batch < (1ull << 32)) {
                         bool ok = s.ticket.p != nullptr;
                         if (!ok && s.ticket.ensure(8 * 1024) == EZPZ_OK) {  // (jit_kernel.hip.hpp: kTicketStride words apart)
                             ok = hipMemset(s.ticket.p, 0, 8 * 1024 * sizeof(unsigned int)) == hipSuccess;

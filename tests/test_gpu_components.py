@@ -383,3 +383,39 @@ def test_batches_beyond_the_launchs_workgroups_draw_their_systems(E, lines, over
         torch.cuda.synchronize()
         assert np.array_equal(xd.cpu().numpy(), want_x[:count]), count
         assert np.array_equal(std.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1), want_st[:count]), count
+
+
+def test_a_batch_launch_recorded_into_a_graph_replays_on_new_guesses(E):
+    """A launch that is being recorded into a HIP graph (here: torch.cuda.graph) keeps fixed shares of the batch -- a replay would find
+    the counters of `test_batches_beyond_the_launchs_workgroups_draw_their_systems` elsewhere (launch.hip): replays on new guesses, with
+    direct calls (which draw) between them, all equal the direct call's results bit for bit."""
+    import torch
+
+    ref = T.load(T.gen_big_problem(50))
+    n = ref.num_vars
+    s = E.System(ref.constraints, n)
+    assert s.specialize(wait=True) == 2
+    B = 9001
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(5, B, n, -0.25, 0.25)
+    xin = torch.from_numpy(x0).cuda()
+    xo = torch.empty_like(xin)
+    st = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):  # warm: everything the call creates on first use exists before the recording
+            s.solve_batch_device(xin.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, side.cuda_stream)
+    torch.cuda.synchronize()
+    want = xo.cpu().numpy().copy()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        s.solve_batch_device(xin.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        flip = rep % 2 == 1
+        xin.copy_(torch.from_numpy(x0[::-1].copy() if flip else x0).cuda())
+        xo.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(xo.cpu().numpy(), want[::-1] if flip else want), rep
+        s.solve_batch_device(xin.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(xo.cpu().numpy(), want[::-1] if flip else want), ("direct", rep)
