@@ -3,6 +3,8 @@ tests/sensitivity.py and NO exclusions: every (system, start, launch shape) must
 convergence flag -- or one of those the oracle itself produces from one-ulp perturbations of the start -- and its
 coordinates within max(1e-6, 20 x the oracle's own spread).  These were diagnostic tools in round 2 (tools/fuzz_graphs.py,
 tools/fuzz_sketch.py) whose "MISMATCH" lines had to be argued about; the argument is now the measured bar."""
+import os
+
 import numpy as np
 import pytest
 
@@ -22,6 +24,20 @@ def E():
     return ezpz_amd
 
 
+def batch_records_system(E, recs, n):
+    """The automatic batch shape as LARGE calls get it -- the record walk on 64 / 128 lanes per system: since round 5 a team_size 0
+    system takes the frontal plan for calls as small as these tests', so the shape is asked for by creating the system without one."""
+    old = os.environ.get("EZPZ_FRONTS")
+    os.environ["EZPZ_FRONTS"] = "0"
+    try:
+        return E.System(recs, n, team_size=0)
+    finally:
+        if old is None:
+            del os.environ["EZPZ_FRONTS"]
+        else:
+            os.environ["EZPZ_FRONTS"] = old
+
+
 # seeds 0..47 plus the three of round 2's list beyond them whose oracle answers move the most under one-ulp perturbations
 # (comb 51, band 153, band 189; band 29 and tree 8 are below 48)
 GRAPH_SEEDS = list(range(48)) + [51, 153, 189]
@@ -29,8 +45,9 @@ GRAPH_SEEDS = list(range(48)) + [51, 153, 189]
 # (profiles/r04_parity_bar.txt): comb 51, band 153, tree 8, hub 38, band 189, comb 11, band 29 -- systems whose oracle
 # answers move by more than 5e-6 under one-ulp moves of the start, on all five shapes -- and hub 26 (bar 3.7e-5).  The
 # assertion is that count plus a margin of three, not "half of them".  (Round 5: six shapes -- the frontal one is what
-# TEAM_AUTO_LATENCY now takes, the record walk runs as TEAM_LATENCY_RECORDS -- so the same systems count six times.)
-GRAPH_NEEDED = [12, 12, 30, 0, 0, 12]
+# TEAM_AUTO_LATENCY now takes, the record walk runs as TEAM_LATENCY_RECORDS -- and a seventh, the batch record walk that small calls
+# of a team_size 0 system no longer reach -- so the same systems count seven times.)
+GRAPH_NEEDED = [14, 14, 35, 0, 0, 14]
 
 
 @pytest.mark.parametrize("chunk", range(6))
@@ -48,8 +65,9 @@ def test_graph_families_on_every_launch_shape(E, chunk):
         cfg = dict(max_iterations=50)
         rc, xo, it, conv, _ = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
         assert rc == 0
-        for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_RECORDS, E.TEAM_LATENCY_PHASES, E.TEAM_BATCH_LANES, 512):
-            x, st, _ = E.System(recs, n, team_size=team).solve_batch(x0, E.Config(**cfg))
+        for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_RECORDS, E.TEAM_LATENCY_PHASES, E.TEAM_BATCH_LANES, 512, "batch records"):
+            sysobj = batch_records_system(E, recs, n) if team == "batch records" else E.System(recs, n, team_size=team)
+            x, st, _ = sysobj.solve_batch(x0, E.Config(**cfg))
             needed += assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg),
                                                   oracle_result=(xo, it, conv), what=(family, seed, npts, team))
             total += 2
@@ -71,8 +89,9 @@ def test_connected_sketches_on_the_team_shapes(E, chunk):
         cfg = dict(max_iterations=60)
         rc, xo, it, conv, _ = O.solve_batch(recs, x0, O.Config(**cfg), linsolve=O.LINSOLVE_SPARSE)
         assert rc == 0
-        for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_RECORDS, E.TEAM_LATENCY_PHASES, 128):
-            x, st, _ = E.System(recs, n, team_size=team).solve_batch(x0, E.Config(**cfg))
+        for team in (0, E.TEAM_AUTO_LATENCY, E.TEAM_LATENCY_RECORDS, E.TEAM_LATENCY_PHASES, 128, "batch records"):
+            sysobj = batch_records_system(E, recs, n) if team == "batch records" else E.System(recs, n, team_size=team)
+            x, st, _ = sysobj.solve_batch(x0, E.Config(**cfg))
             needed += assert_batch_matches_oracle(recs, x0, x, st["iterations"], st["converged"], O.Config(**cfg),
                                                   oracle_result=(xo, it, conv), what=(seed, npts, team))
             total += 3
