@@ -362,6 +362,58 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
                               P.c.n_apairs < 65536 && P.c.n_lpairs < 65536 && P.c.n_cons < 65536;
     ProgramView& v = s.view;
     size_t stage_bytes = 0;
+    // ---- the frontal shape: one connected sketch as a tree of dense fronts (fronts.cpp), one solve from front_min_vars_one_solve
+    //      variables on as many workgroups as its size asks for; the shapes above stay behind it (stragglers of the lanes, systems
+    //      whose fronts would exceed a wavefront's rows).  A system created for batches carries the plan too and takes it for
+    //      calls that would leave most of the device idle at one workgroup per system (EzpzSystem::front_max_batch); its
+    //      EzpzSystemInfo keeps describing the shape of its large calls.  EZPZ_FRONTS=0: never; EZPZ_FRONT_WGS: workgroups per system.
+    s.fronts.reset();
+    s.front_max_batch = 0;
+    bool fronts_tried = false;
+    auto build_fronts = [&]() {
+        fronts_tried = true;
+        const char* fe = std::getenv("EZPZ_FRONTS");
+        const int fronts_env = fe ? std::atoi(fe) : 1;
+        const EzpzLaunchPolicy& pol = s.lim.policy;
+        // (one solve: the automatic latency shape only -- EZPZ_TEAM_LATENCY_PHASES / _RECORDS ask for the older ones; batches: the
+        // automatic shape)
+        uint32_t min_vars = latency_auto ? pol.front_min_vars_one_solve : batch_auto ? pol.front_min_vars_batch : 0u;
+        if (fronts_env == 0 || no_fronts) min_vars = 0;
+        const bool connected = s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents;
+        const bool want = force_fronts || (auto_shape && min_vars && n_vars >= min_vars && connected && !s.comp && !s.lane && !keep_comp);
+        if (want && n_cs > 0) {
+            FrontOptions fo;
+            fo.wgs = 0;
+            if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
+            fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
+            fo.vars_per_wg = pol.front_vars_per_workgroup;
+            if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
+            fo.lds_bytes = s.lim.lds_bytes;
+            std::unique_ptr<FrontPlan> plan(new FrontPlan());
+            const char* why = nullptr;
+            const bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
+            if (ok) {
+                if (for_latency || force_fronts) {
+                    s.front_max_batch = ~0ull;
+                } else {
+                    // batches: as many systems as the device holds at once, times a round per `front_small_call_wgs_per_round`
+                    // workgroups per system (policy.hpp)
+                    const uint64_t cus = (uint64_t)std::max(1, s.lim.cus), G = plan->n_wgs;
+                    const uint64_t rounds = std::max<uint64_t>(1, G / std::max<uint32_t>(1, pol.front_small_call_wgs_per_round));
+                    s.front_max_batch = std::min<uint64_t>(std::max<uint64_t>(1, cus / G) * rounds, 0xFFFFFFFEull);
+                }
+                s.fronts = std::move(plan);
+            } else if (std::getenv("EZPZ_FRONT_DEBUG")) {
+                std::fprintf(stderr, "front plan: not taken: %s\n", why ? why : "?");
+            }
+        }
+    };
+    // Where the fronts serve EVERY call of the system (one solve: the automatic latency shape, or asked for) and the system is one the
+    // later plans would not take over (no component plan, not a sub-wavefront system), the plan is built now and the plans nobody would
+    // run are skipped -- the record walk's rounds, the dense phases, the lanes across the batch: half of the symbolic phase of a
+    // 2000-variable sketch (records 5.1 + dense phases 2.0 + lanes 3.8 of 21.8 ms on the build container's CPU).
+    if ((latency_auto || force_fronts) && !s.comp && s.mode != MODE_SUB) build_fronts();
+    const bool fronts_serve_all = s.fronts && s.front_max_batch == ~0ull;
     auto pack_and_shape = [&](bool may_stage, size_t panel_bytes = 0) {
         stage_bytes = 0;
         if (small_counts && may_stage) {
@@ -428,7 +480,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
         s.team_size = t;
         s.lean_lds = true;  // (its lists stay in L2: the LDS is for as many systems as fit)
     }
-    const bool rec_try = rec_enabled && auto_shape && ((for_latency && !latency_phases) || rec_batch) && s.mode == MODE_WGB &&
+    const bool rec_try = rec_enabled && !fronts_serve_all && auto_shape && ((for_latency && !latency_phases) || rec_batch) && s.mode == MODE_WGB &&
                          s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents && !P.c.dense;
     if (rec_try) {
         s.rec_jglobal = jglobal;
@@ -501,7 +553,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
     } else if (s.lds_bytes + 4096 * teams_now <= s.lim.lds_bytes) {  // (one solve: occupancy does not matter)
         dense_room = std::min<size_t>((s.lim.lds_bytes - s.lds_bytes - 1024) / teams_now, 48 * 1024);
     }
-    if (root_enabled && (auto_shape || lists_only) && s.grid_wgs == 1 && !s.rec &&
+    if (root_enabled && !fronts_serve_all && (auto_shape || lists_only) && s.grid_wgs == 1 && !s.rec &&
         ((s.mode == MODE_WGB && (for_latency || s.team_size >= 128)) || wave_teams) && dense_room >= 1024 &&
         make_dense_phases(P, wave_teams ? 1 : s.team_size / 64, dense_room)) {
         const int mode_before = s.mode;
@@ -624,67 +676,27 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
         const char* e = std::getenv("EZPZ_LANES");
         return !(e && e[0] == '0');
     }();
-    if (auto_shape && lanes_enabled && !s.comp && !s.lane && s.grid_wgs == 1 && P.c.n_parts == 1 && n_vars > 20) {
+    if (auto_shape && lanes_enabled && !fronts_serve_all && !s.comp && !s.lane && s.grid_wgs == 1 && P.c.n_parts == 1 && n_vars > 20) {
         std::unique_ptr<BatchPlan> bp(new BatchPlan());
         if (batch_plan_build(cs, n_cs, n_vars, *bp)) s.lanes = std::move(bp);
     }
-    // ---- the frontal shape: one connected sketch as a tree of dense fronts (fronts.cpp), one solve from front_min_vars_one_solve
-    //      variables on as many workgroups as its size asks for; the shapes above stay behind it (stragglers of the lanes, systems
-    //      whose fronts would exceed a wavefront's rows).  A system created for batches carries the plan too and takes it for
-    //      calls that would leave most of the device idle at one workgroup per system (EzpzSystem::front_max_batch); its
-    //      EzpzSystemInfo keeps describing the shape of its large calls.  EZPZ_FRONTS=0: never; EZPZ_FRONT_WGS: workgroups per system.
-    s.fronts.reset();
-    s.front_max_batch = 0;
-    info.front_workgroups = 0;
-    info.front_max_batch = 0;
-    {
-        const char* fe = std::getenv("EZPZ_FRONTS");
-        const int fronts_env = fe ? std::atoi(fe) : 1;
-        const EzpzLaunchPolicy& pol = s.lim.policy;
-        // (one solve: the automatic latency shape only -- EZPZ_TEAM_LATENCY_PHASES / _RECORDS ask for the older ones; batches: the
-        // automatic shape)
-        uint32_t min_vars = latency_auto ? pol.front_min_vars_one_solve : batch_auto ? pol.front_min_vars_batch : 0u;
-        if (fronts_env == 0 || no_fronts) min_vars = 0;
-        const bool connected = s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents;
-        const bool want = force_fronts || (auto_shape && min_vars && n_vars >= min_vars && connected && !s.comp && !s.lane && !keep_comp);
-        if (want && n_cs > 0) {
-            FrontOptions fo;
-            fo.wgs = 0;
-            if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
-            fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
-            fo.vars_per_wg = pol.front_vars_per_workgroup;
-            if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
-            fo.lds_bytes = s.lim.lds_bytes;
-            std::unique_ptr<FrontPlan> plan(new FrontPlan());
-            const char* why = nullptr;
-            const bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
-            if (ok) {
-                info.front_workgroups = plan->n_wgs;
-                if (for_latency || force_fronts) {
-                    s.front_max_batch = ~0ull;
-                    info.front_max_batch = 0xFFFFFFFFu;
-                    info.team_mode = 5;
-                    info.team_size = plan->threads;
-                    info.grid_workgroups = plan->n_wgs;
-                    info.n_partitions = plan->n_fronts;
-                    info.n_levels = plan->n_levels;
-                    info.workspace_bytes = (uint64_t)plan->ws_doubles_max * 8;
-                    info.workspace_in_lds = 1;
-                    info.program_in_lds = 0;
-                } else {
-                    // batches: as many systems as the device holds at once, times a round per `front_small_call_wgs_per_round`
-                    // workgroups per system (policy.hpp)
-                    const uint64_t cus = (uint64_t)std::max(1, s.lim.cus), G = plan->n_wgs;
-                    const uint64_t rounds = std::max<uint64_t>(1, G / std::max<uint32_t>(1, pol.front_small_call_wgs_per_round));
-                    s.front_max_batch = std::max<uint64_t>(1, cus / G) * rounds;
-                    info.front_max_batch = (uint32_t)std::min<uint64_t>(s.front_max_batch, 0xFFFFFFFEu);
-                }
-                info.program_bytes += plan->blob.size();
-                s.fronts = std::move(plan);
-            } else if (std::getenv("EZPZ_FRONT_DEBUG")) {
-                std::fprintf(stderr, "front plan: not taken: %s\n", why ? why : "?");
-            }
+    // ---- the frontal shape (built ahead of the plans above where it serves every call, else here) -------------------------------------------
+    if (!fronts_tried) build_fronts();
+    if (s.fronts) {
+        const FrontPlan& plan = *s.fronts;
+        info.front_workgroups = plan.n_wgs;
+        info.front_max_batch = (uint32_t)std::min<uint64_t>(s.front_max_batch, 0xFFFFFFFFull);
+        if (s.front_max_batch == ~0ull) {
+            info.team_mode = 5;
+            info.team_size = plan.threads;
+            info.grid_workgroups = plan.n_wgs;
+            info.n_partitions = plan.n_fronts;
+            info.n_levels = plan.n_levels;
+            info.workspace_bytes = (uint64_t)plan.ws_doubles_max * 8;
+            info.workspace_in_lds = 1;
+            info.program_in_lds = 0;
         }
+        info.program_bytes += plan.blob.size();
     }
     return EZPZ_OK;
 }
