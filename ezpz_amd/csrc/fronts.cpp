@@ -36,6 +36,50 @@ double front_bwd_cost(uint32_t K, uint32_t S) { return 900.0 + 60.0 * K + 15.0 *
 // Nested dissection of one connected component by breadth-first level structures: the separator is the level that best
 // balances the two sides by vertex count (thin levels preferred), sides are ordered first (recursively), the separator last;
 // pieces of at most `leaf` vertices, or too compact to cut, are leaves in breadth-first order (a band stays a band).
+// Minimum-degree ordering of one connected component (exact degrees on the explicit elimination graph, smallest (degree, id) first;
+// lazily updated heap).  A random tree with chords, a comb: breadth-first levels there hold a third of the vertices and nested
+// dissection by level structures makes fronts of hundreds of rows, while eliminating leaves first keeps them at the size of the
+// cycles.  (The same rule as program.cpp's order_component, on this file's own graph.)
+void min_degree(const UVec& verts, const std::vector<UVec>& adj, UVec& out) {
+    const uint32_t k = (uint32_t)verts.size();
+    static thread_local UVec local;
+    uint32_t top = 0;
+    for (uint32_t v : verts) top = std::max(top, v + 1);
+    if (local.size() < top) local.resize(top);
+    for (uint32_t i = 0; i < k; ++i) local[verts[i]] = i;
+    std::vector<UVec> g(k);
+    for (uint32_t i = 0; i < k; ++i) {
+        for (uint32_t w : adj[verts[i]]) g[i].push_back(local[w]);
+        std::sort(g[i].begin(), g[i].end());
+    }
+    std::vector<char> gone(k, 0);
+    typedef std::pair<uint32_t, uint32_t> DegIdx;
+    std::priority_queue<DegIdx, std::vector<DegIdx>, std::greater<DegIdx>> heap;
+    for (uint32_t i = 0; i < k; ++i) heap.push(DegIdx((uint32_t)g[i].size(), i));
+    UVec nb, merged;
+    for (uint32_t step = 0; step < k; ++step) {
+        uint32_t best = k;
+        while (best == k) {
+            const DegIdx t = heap.top();
+            heap.pop();
+            if (!gone[t.second] && g[t.second].size() == t.first) best = t.second;
+        }
+        gone[best] = 1;
+        out.push_back(verts[best]);
+        nb = g[best];
+        for (uint32_t u : nb) {  // g[u] = (g[u] \ {best}) U (nb \ {u})
+            merged.clear();
+            std::set_union(g[u].begin(), g[u].end(), nb.begin(), nb.end(), std::back_inserter(merged));
+            UVec& gu = g[u];
+            gu.clear();
+            for (uint32_t w : merged)
+                if (w != u && w != best) gu.push_back(w);
+            heap.push(DegIdx((uint32_t)gu.size(), u));
+        }
+        UVec().swap(g[best]);
+    }
+}
+
 void dissect(const UVec& verts, const std::vector<UVec>& adj, uint32_t leaf, UVec& out) {
     const uint32_t n_all = (uint32_t)adj.size();
     static thread_local UVec region, level, mark;
@@ -241,6 +285,8 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             std::sort(verts.begin(), verts.end());
             if (verts.size() <= leaf)
                 order.insert(order.end(), verts.begin(), verts.end());
+            else if (opt.ordering == 1)
+                min_degree(verts, adj, order);
             else
                 dissect(verts, adj, leaf, order);
         }
@@ -1035,12 +1081,17 @@ namespace ezpz {
 bool front_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const FrontOptions& opt, FrontPlan& out,
                       const char** why) {
     const char* w = nullptr;
-    FrontOptions o = opt;
-    for (;;) {
-        if (plan_once(cs, n_cs, n_vars, o, out, &w)) return true;
-        // the planner's own choice of workgroups: a share that does not fit one CU's LDS asks for more of them
-        if (opt.wgs != 0 || !w || !std::strstr(w, "LDS") || out.n_wgs >= std::min<uint32_t>(o.max_wgs, kFrontMaxWgs) || o.vars_per_wg <= 24) break;
-        o.vars_per_wg = o.vars_per_wg * 3 / 4;
+    // nested dissection first (balanced trees); where its separators make a front of more than a wavefront's rows, minimum degree
+    for (uint32_t ordering = opt.ordering; ordering <= 1; ++ordering) {
+        FrontOptions o = opt;
+        o.ordering = ordering;
+        for (;;) {
+            if (plan_once(cs, n_cs, n_vars, o, out, &w)) return true;
+            // the planner's own choice of workgroups: a share that does not fit one CU's LDS asks for more of them
+            if (opt.wgs != 0 || !w || !std::strstr(w, "LDS") || out.n_wgs >= std::min<uint32_t>(o.max_wgs, kFrontMaxWgs) || o.vars_per_wg <= 24) break;
+            o.vars_per_wg = o.vars_per_wg * 3 / 4;
+        }
+        if (!w || !std::strstr(w, "63 rows")) break;
     }
     if (why) *why = w;
     return false;

@@ -17,6 +17,9 @@ struct FrontOptions {
     uint32_t vars_per_wg = 160;     // ... one workgroup up to twice this many variables, then one more per this many
     size_t lds_bytes = 160 * 1024;  // LDS one workgroup may take (tables + workspace)
     uint32_t threads = 512;         // lanes per workgroup
+    // elimination order per connected component: 0 = nested dissection (balanced trees: parallel fronts, workgroups), 1 = minimum
+    // degree (small fronts on bushy graphs whose breadth-first levels make wide separators); front_plan_build tries 0, then 1
+    uint32_t ordering = 0;
 };
 
 struct FrontPlan {

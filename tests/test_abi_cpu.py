@@ -45,6 +45,8 @@ def test_launch_policy_table_and_its_scaling():
     assert (full.rec_min_vars_one_solve, full.rec_min_vars_batch, full.rec_one_wavefront_max_vars, full.rec_max_components) == (25, 57, 160, 127)
     assert (full.lane_max_vars, full.lane_max_constraints, full.comp_min_components) == (20, 40, 128)
     assert (full.zero_copy_max_bytes, full.h2h_piece_min_bytes, full.h2h_piece_max_bytes, full.h2h_pieces_per_call) == (1 << 20, 4 << 20, 16 << 20, 16)
+    assert (full.front_min_vars_one_solve, full.front_min_vars_batch, full.front_vars_per_workgroup, full.front_max_workgroups,
+            full.front_small_call_wgs_per_round) == (48, 48, 160, 64, 4)
     zero = policy(0)  # 0 = the full chip
     assert all(getattr(zero, f) == getattr(full, f) for f, _ in CLaunchPolicy._fields_)
     for cus in (32, 64, 128, 304):
