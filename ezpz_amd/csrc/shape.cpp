@@ -391,7 +391,22 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             fo.lds_bytes = s.lim.lds_bytes;
             std::unique_ptr<FrontPlan> plan(new FrontPlan());
             const char* why = nullptr;
-            const bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
+            bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
+            // Wide fronts (a band of ten points, a comb: 40-63 rows, update matrices of a thousand entries and more) can cost more
+            // than the record walk's rounds: one solve of a system the record walk holds in LDS is then left to it.  Both sides
+            // estimated in cycles per LM iteration from what the symbolic phase has at this point -- fronts: 1.65 x the planner's
+            // model (the model leaves out the sweeps, the assembly and the sums); record walk: 28 k + 1.75 k per level of its
+            // elimination tree + 5 per entry of L -- fitted on the graph families of tests/gen.py (profiles/r05_graph_families.txt: of
+            // 33 systems the fronts lost five by 12-25 %; with a margin of 5 % for the fronts the rule moves three of them to the
+            // record walk -- the other two are within its error -- and none of the 28 winners).
+            if (ok && !force_fronts && n_vars <= 1200 && s.grid_wgs == 1 && P.c.n_parts == 1) {
+                const double fronts_est = 1.65 * plan->model_cycles;
+                const double rec_est = 28000.0 + 1750.0 * (double)P.c.n_levels + 5.0 * (double)((uint64_t)P.c.zlo + P.c.n_vars);
+                if (fronts_est > 1.05 * rec_est) {
+                    ok = false;
+                    why = "the record walk is estimated faster";
+                }
+            }
             if (ok) {
                 if (for_latency || force_fronts) {
                     s.front_max_batch = ~0ull;

@@ -4,7 +4,7 @@ import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 import ezpz_amd as E
-import gen
+import gen, front_ref as FR
 
 dev = torch.device('cuda', 0)
 cfg = E.Config(max_iterations=50)
@@ -18,7 +18,7 @@ def one_solve(s, g):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(10): s.solve_batch_device(x0.data_ptr(), 1, xo.data_ptr(), st.data_ptr(), 0, stream, cfg)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t) / 10
+    return (time.perf_counter() - t) / 10, int(st.cpu().numpy().view(E.STATUS_DTYPE)["iterations"][0])
 
 
 seeds = [int(a) for a in sys.argv[1:]] or (list(range(48)) + [51, 153, 189])
@@ -33,7 +33,10 @@ for seed in seeds:
     x0 = true + rng.uniform(-0.01, 0.01, n)
     a = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY); ia = a.info()
     r = E.System(recs, n, team_size=E.TEAM_LATENCY_RECORDS); ir = r.info()
-    ta, tr = one_solve(a, x0), one_solve(r, x0)
+    (ta, it), (tr, _) = one_solve(a, x0), one_solve(r, x0)
     taken += ia['team_mode'] == 5
-    print(f"{family:5s} seed {seed:3d} n={n:4d}: automatic team_mode {ia['team_mode']} ({ia['grid_workgroups']} workgroups) {ta*1e6:9.1f} us | record walk (mode {ir['team_mode']}, nnzL/nnzA {ir['nnz_l']/max(1,ir['nnz_a']):.1f}) {tr*1e6:9.1f} us | x{tr/ta:5.2f}")
+    plan = FR.Plan(recs, n, wgs=0, max_wgs=64)
+    model = f"fronts model {plan.model_cycles:7d} cycles, largest front {plan.max_rows:2d} rows" if plan.ok else "no frontal plan"
+    print(f"{family:5s} seed {seed:3d} n={n:4d} {it:2d} iterations: automatic team_mode {ia['team_mode']} ({ia['grid_workgroups']:2d} workgroups) {ta*1e6:9.1f} us = {ta*2.1e9/max(it,1):8.0f} cycles/iteration | "
+          f"record walk (mode {ir['team_mode']}, levels {ir['n_levels']:3d}, nnzL {ir['nnz_l']:6d}) {tr*1e6:9.1f} us = {tr*2.1e9/max(it,1):8.0f} | x{tr/ta:5.2f} | {model}")
 print(f"{taken} of these systems take the frontal plan")

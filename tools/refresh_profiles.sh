@@ -67,6 +67,7 @@ hipcc --offload-arch=gfx950 -O2 -o tools/pcie_duplex.bin tools/pcie_duplex.hip 2
 # what a resident one-call kernel costs a batch on another stream (with the residency switched off as the control)
 (echo "# EZPZ_TICKETS=<0|1> python bench.py --steps 20 --warmup 5 --legs 0 --cpu-seconds 0 --extras 0 --pmc 0  (0 = fixed shares of the batch per workgroup, 1 = the default: workgroups draw their systems from eight counters)"; for t in 0 1 0 1; do EZPZ_TICKETS=$t python bench.py --steps 20 --warmup 5 --legs 0 --cpu-seconds 0 --extras 0 --pmc 0 2>/dev/null | $PY -c "import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('EZPZ_TICKETS=$t:', round(l['value']/1e6,2), 'M solves/s,', round(l['ms_per_step'],4), 'ms per launch of', l['config']['systems_per_launch_per_gpu'], 'systems; oracle check', l['oracle_check']['bitwise_equal'])"; done) > $out/tickets_ab.txt
 (echo "# python tools/small_calls.py; BATCHES=1,8,24,42,54,55,64 python tools/small_calls.py 400 1000 2500"; python tools/small_calls.py 2>&1 | grep -v amdgpu.ids; BATCHES=1,8,24,42,54,55,64 python tools/small_calls.py 400 1000 2500 2>&1 | grep -v amdgpu.ids) > $out/small_calls.txt
+(echo "# python tools/graph_families.py  (the graph families and seeds of tests/test_gpu_fuzz.py, one solve: the automatic latency shape against the record walk)"; python tools/graph_families.py 2>&1 | grep -v amdgpu.ids) > $out/graph_families.txt
 (python tools/resident_cost.py 2>&1 | grep -v amdgpu.ids) > $out/resident_cost.txt
 (EZPZ_RESIDENT_US=0 python tools/resident_cost.py 2>&1 | grep -v amdgpu.ids) > $out/resident_cost_no_residency.txt
 (EZPZ_TICKETS=0 python tools/resident_cost.py 2>&1 | grep -v amdgpu.ids) > $out/resident_cost_fixed_shares.txt
