@@ -270,8 +270,10 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
         std::vector<char> seen(n, 0);
         UVec verts, stack;
         constexpr uint32_t leaf = 10;  // (pieces of at most this many variables are not dissected further)
+        out.n_components = 0;
         for (uint32_t s = 0; s < n; ++s) {
             if (seen[s]) continue;
+            ++out.n_components;
             verts.clear();
             stack.assign(1, s);
             seen[s] = 1;

@@ -38,6 +38,7 @@ struct FrontPlan {
     size_t lds_bytes = 0;         // dynamic LDS of the launch: tables + workspace + reduction scratch
     // statistics (EzpzSystemInfo, tools)
     uint32_t n_fronts = 0, n_levels = 0, max_rows = 0, max_pivots = 0;
+    uint32_t n_components = 0;  // connected components of the variable graph
     uint64_t panel_doubles = 0, update_doubles = 0, fill_zeros = 0;
     double model_cycles = 0.0;  // the planner's own estimate of one factorisation + substitution on the critical path
 };

@@ -157,6 +157,62 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             return EZPZ_OK;
         }
     }
+    auto front_options = [&]() {
+        const EzpzLaunchPolicy& pol = s.lim.policy;
+        FrontOptions fo;
+        fo.wgs = 0;
+        if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
+        fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
+        fo.vars_per_wg = pol.front_vars_per_workgroup;
+        if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
+        fo.lds_bytes = s.lim.lds_bytes;
+        return fo;
+    };
+    // One solve of a connected sketch with narrow fronts (at most 32 rows: no question of the record walk being cheaper): the frontal
+    // plan is ALL a solve needs -- the kernel reads nothing of the program -- so the system returns with it alone, like a block
+    // system with its component plan above, and the program (FreedomAnalysis, eval, the info) is analysed when somebody asks
+    // (ensure_program).  A new topology's first solve is mostly its symbolic phase (300 variables: 1.2 ms against 0.18 ms of
+    // kernel), and an edited sketch is a new topology: 300 / 2000 variables 1.16 -> 0.45, 6.4 -> 2.4 ms.
+    if (may_defer && latency_auto && !no_fronts && !keep_comp && n_cs > 0 && n_vars >= s.lim.policy.front_min_vars_one_solve) {
+        const char* fe = std::getenv("EZPZ_FRONTS");
+        if (!(fe && std::atoi(fe) == 0)) {
+            std::unique_ptr<FrontPlan> plan(new FrontPlan());
+            const char* why = nullptr;
+            if (front_plan_build(cs, n_cs, n_vars, front_options(), *plan, &why) && plan->n_components == 1 && plan->max_rows <= 32) {
+                s.counts = ProgramCounts();
+                s.counts.n_cons = plan->n_cons;
+                s.counts.n_vars = plan->n_vars;
+                s.counts.n_rows = plan->n_rows;
+                s.counts.zj = plan->zj;
+                s.unit_weights = plan->unit_weights;
+                EzpzSystemInfo& info = s.info;
+                std::memset(&info, 0, sizeof(info));
+                info.n_constraints = plan->n_cons;
+                info.n_vars = plan->n_vars;
+                info.n_rows = plan->n_rows;
+                info.nnz_j = plan->zj;
+                info.n_components = 1;
+                info.program_bytes = plan->blob.size();
+                info.team_mode = 5;
+                info.team_size = plan->threads;
+                info.grid_workgroups = info.front_workgroups = plan->n_wgs;
+                info.front_max_batch = 0xFFFFFFFFu;
+                info.n_partitions = plan->n_fronts;
+                info.n_levels = plan->n_levels;
+                info.workspace_bytes = (uint64_t)plan->ws_doubles_max * 8;
+                info.workspace_in_lds = 1;
+                s.comp.reset();
+                s.lane.reset();
+                s.lanes.reset();
+                s.fronts = std::move(plan);
+                s.front_max_batch = ~0ull;
+                s.deferred_cs.assign(cs, cs + n_cs);
+                s.program_deferred.store(true);
+                blob.clear();
+                return EZPZ_OK;
+            }
+        }
+    }
     const bool force_fronts = team_size == EZPZ_TEAM_FRONTS;  // the frontal shape whatever the size; the latency shape behind it
     if (force_fronts) team_size = EZPZ_TEAM_AUTO_LATENCY;
     const uint32_t width = (uint32_t)std::max<size_t>(1, std::max(n_cs, n_vars));
@@ -367,11 +423,16 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
     //      whose fronts would exceed a wavefront's rows).  A system created for batches carries the plan too and takes it for
     //      calls that would leave most of the device idle at one workgroup per system (EzpzSystem::front_max_batch); its
     //      EzpzSystemInfo keeps describing the shape of its large calls.  EZPZ_FRONTS=0: never; EZPZ_FRONT_WGS: workgroups per system.
-    s.fronts.reset();
-    s.front_max_batch = 0;
-    bool fronts_tried = false;
+    // (the rest of a deferred analysis keeps the plan the system has been solving on)
+    const bool keep_fronts = keep_comp && s.fronts && s.front_max_batch == ~0ull;
+    if (!keep_fronts) {
+        s.fronts.reset();
+        s.front_max_batch = 0;
+    }
+    bool fronts_tried = keep_fronts;
     auto build_fronts = [&]() {
         fronts_tried = true;
+        if (keep_fronts) return;
         const char* fe = std::getenv("EZPZ_FRONTS");
         const int fronts_env = fe ? std::atoi(fe) : 1;
         const EzpzLaunchPolicy& pol = s.lim.policy;
@@ -382,13 +443,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
         const bool connected = s.grid_wgs == 1 && P.c.n_parts == 1 && P.c.n_components >= 1 && P.c.n_components <= kRecMaxComponents;
         const bool want = force_fronts || (auto_shape && min_vars && n_vars >= min_vars && connected && !s.comp && !s.lane && !keep_comp);
         if (want && n_cs > 0) {
-            FrontOptions fo;
-            fo.wgs = 0;
-            if (const char* e = std::getenv("EZPZ_FRONT_WGS")) fo.wgs = (uint32_t)std::atoi(e);
-            fo.max_wgs = std::min<uint32_t>(pol.front_max_workgroups, (uint32_t)std::max(1, s.lim.cus));
-            fo.vars_per_wg = pol.front_vars_per_workgroup;
-            if (const char* e = std::getenv("EZPZ_FRONT_VARS_PER_WG")) fo.vars_per_wg = (uint32_t)std::atoi(e);
-            fo.lds_bytes = s.lim.lds_bytes;
+            const FrontOptions fo = front_options();
             std::unique_ptr<FrontPlan> plan(new FrontPlan());
             const char* why = nullptr;
             bool ok = front_plan_build(cs, n_cs, n_vars, fo, *plan, &why);
