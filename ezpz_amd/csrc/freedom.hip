@@ -322,6 +322,216 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
     return EZPZ_OK;
 }
 
+// ---- FreedomAnalysis of a system the FRONTS serve, without the pivoted QR --------------------------------------------------------------
+// The reference factorises the dense Jacobian with column pivoting and reads the null space off R (find_dof.rs:31-103): for one
+// connected sketch that is the unblocked QR of a 300 ... 2000-column matrix over the whole device, 2.6 ... 19 ms, fourteen to forty
+// times the solve it follows.  What the analysis reports is basis-independent -- a variable's participation is the diagonal entry of
+// the orthogonal projector P onto null(J) (the squared row norm of ANY orthonormal basis) -- and the frontal factorisation gives P
+// applied to a vector for the price of one linear solve: lambda (JtJ + lambda I)^-1 w -> P w as lambda -> 0 (front_kernel.hip.hpp,
+// FrontArgs::probe_m; lambda = 1e-11 x J's largest squared entry; what rounding adds to the answer lies along the small eigenvectors,
+// i.e. INSIDE the null space).  m pseudo-random sign vectors w_j give Y = P W (n x m), whose range is null(J) as soon as m exceeds
+// its dimension: the eigenvalues of the m x m matrix Yt Y split into a cluster of order m (one per degree of freedom) and values of
+// order m (lambda / sigma^2)^2 for everything else, and participation_i = sum over the cluster of (y_i . q_t)^2 / e_t.  A fully
+// constrained sketch -- the common case -- is Y = 0 after the first eight solves.  Otherwise the directions of Y that stand out are
+// refined by subspace iteration with the same operator (V <- orthonormalised Op V): its Ritz values on span(V) are lambda /
+// (sigma^2 + lambda) themselves -- 1 for a null vector, below one half for anything whose singular value exceeds 3e-6 x J's
+// largest entry, which is dropped -- and what is left of other directions in the kept vectors shrinks by that factor per round.
+// Eight or more candidates, a Ritz value that stays between 0.5 and 0.999 after six rounds (a singular value of J within 1e-7 ...
+// 3e-6 of its largest entry: where the reference's rank decision, 1e-8 on R's diagonal, and lambda's may disagree), a failed
+// pivot, more than 64 systems, a system without a frontal plan: the pivoted QR.
+namespace {
+
+// Eigenvalues (ascending is not needed) and eigenvectors of a small symmetric matrix by cyclic Jacobi rotations: a[m][m] -> its
+// diagonal holds the eigenvalues, q[m][m] the eigenvectors as columns.
+void jacobi_eigen(std::vector<double>& a, std::vector<double>& q, uint32_t m) {
+    q.assign((size_t)m * m, 0.0);
+    for (uint32_t i = 0; i < m; ++i) q[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (uint32_t i = 0; i < m; ++i)
+            for (uint32_t j = 0; j < m; ++j) (i == j ? diag : off) += a[(size_t)i * m + j] * a[(size_t)i * m + j];
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (uint32_t p = 0; p + 1 < m; ++p)
+            for (uint32_t r = p + 1; r < m; ++r) {
+                const double apr = a[(size_t)p * m + r];
+                if (apr == 0.0) continue;
+                const double theta = (a[(size_t)r * m + r] - a[(size_t)p * m + p]) / (2.0 * apr);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (uint32_t k = 0; k < m; ++k) {
+                    const double akp = a[(size_t)k * m + p], akr = a[(size_t)k * m + r];
+                    a[(size_t)k * m + p] = c * akp - sn * akr;
+                    a[(size_t)k * m + r] = sn * akp + c * akr;
+                }
+                for (uint32_t k = 0; k < m; ++k) {
+                    const double apk = a[(size_t)p * m + k], ark = a[(size_t)r * m + k];
+                    a[(size_t)p * m + k] = c * apk - sn * ark;
+                    a[(size_t)r * m + k] = sn * apk + c * ark;
+                }
+                for (uint32_t k = 0; k < m; ++k) {
+                    const double qkp = q[(size_t)k * m + p], qkr = q[(size_t)k * m + r];
+                    q[(size_t)k * m + p] = c * qkp - sn * qkr;
+                    q[(size_t)k * m + r] = sn * qkp + c * qkr;
+                }
+            }
+    }
+}
+
+// 0: done (mask / participation written); 1: not decided here -- the caller runs the pivoted QR; negative: an error.
+int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* under_mask, double* participation) {
+    const char* const env = std::getenv("EZPZ_FREEDOM_PROBES");  // =0: the pivoted QR for every system (read per call: tests switch it)
+    const bool enabled = !(env && env[0] == '0');
+    if (!enabled || !sys->fronts || !sys->dev_fronts || batch > 64) return 1;
+    auto give_up = [&](const char* why2) {
+        if (hip_debug()) std::fprintf(stderr, "[ezpz hip] null-space probes: %s -> the pivoted QR\n", why2);
+        return 1;
+    };
+    auto& F = sys->freedom;
+    const size_t n = sys->counts.n_vars;
+    constexpr uint32_t m = 8;
+    int rc;
+    if ((rc = F.x_in.ensure(batch * n)) != EZPZ_OK) return rc;
+    if ((rc = F.probe.ensure(batch * m * n)) != EZPZ_OK) return rc;
+    if ((rc = F.probe_w.ensure(batch * m * n)) != EZPZ_OK) return rc;
+    HIP_TRY(hipMemcpy(F.x_in.p, x, batch * n * sizeof(double), hipMemcpyHostToDevice));
+    // ---- eight random probes: Y = Op W, Op = lambda (JtJ + lambda I)^-1 (symmetric; eigenvalue 1 on null(J), lambda / sigma^2 off it)
+    if ((rc = front_launch_probe(*sys, F.x_in.p, batch, F.probe.p, m, nullptr)) != EZPZ_OK) return rc;
+    std::vector<double> Y(batch * m * n), V(batch * m * n, 0.0), G, Q, H;
+    HIP_TRY(hipMemcpy(Y.data(), F.probe.p, Y.size() * sizeof(double), hipMemcpyDeviceToHost));
+    auto gram = [&](const double* A, const double* B2, uint32_t k, std::vector<double>& out) {  // out[j][t] = A_j . B_t
+        out.assign((size_t)k * k, 0.0);
+        for (uint32_t j2 = 0; j2 < k; ++j2)
+            for (uint32_t t = 0; t < k; ++t) {
+                double sum = 0.0;
+                for (size_t i2 = 0; i2 < n; ++i2) sum += A[j2 * n + i2] * B2[t * n + i2];
+                out[(size_t)j2 * k + t] = sum;
+            }
+    };
+    // per system: the subspace that may hold null vectors -- the eigenvectors of Yt Y that stand out of the (lambda / sigma^2)^2 floor
+    std::vector<uint32_t> kdim(batch, 0);
+    bool any = false;
+    for (size_t b = 0; b < batch; ++b) {
+        const double* Yb = Y.data() + b * m * n;
+        gram(Yb, Yb, m, G);
+        for (double g : G)
+            if (!(std::fabs(g) < 1e300)) return give_up("a probe's answer is not finite (a pivot failed)");
+        for (uint32_t a2 = 0; a2 < m; ++a2)
+            for (uint32_t b2 = a2 + 1; b2 < m; ++b2) G[(size_t)b2 * m + a2] = G[(size_t)a2 * m + b2] = 0.5 * (G[(size_t)a2 * m + b2] + G[(size_t)b2 * m + a2]);
+        jacobi_eigen(G, Q, m);
+        double* Vb = V.data() + b * m * n;
+        uint32_t k = 0;
+        for (uint32_t t = 0; t < m; ++t) {
+            const double e = G[(size_t)t * m + t];
+            // (a null vector's eigenvalue is a chi-square of eight: of order m; a direction answered by a tenth of itself or less
+            // is not one)
+            if (!(e > 0.005 * m)) continue;
+            const double inv = 1.0 / std::sqrt(e);
+            for (size_t i2 = 0; i2 < n; ++i2) {
+                double d = 0.0;
+                for (uint32_t j2 = 0; j2 < m; ++j2) d += Q[(size_t)j2 * m + t] * Yb[j2 * n + i2];
+                Vb[k * n + i2] = d * inv;
+            }
+            ++k;
+        }
+        if (k >= 5) return give_up("five or more candidate directions from eight probes");
+        kdim[b] = k;
+        any = any || k;
+    }
+    // ---- subspace iteration on the candidates: V <- orthonormalised Op V, until every Ritz value of Op on span(V) is 1 (a null
+    //      vector) or below 1e-4 (not one).  The Ritz values ARE lambda / (sigma^2 + lambda): no threshold on magnitudes of J.
+    std::vector<std::vector<double>> ritz(batch);
+    for (int round = 0; any && round < 6; ++round) {
+        // (as many probes as the system with the most candidates has; rows of `mk` vectors per system)
+        uint32_t mk = 0;
+        for (size_t b = 0; b < batch; ++b) mk = std::max(mk, kdim[b]);
+        any = mk != 0;
+        if (!any) break;
+        for (size_t b = 0; b < batch; ++b)
+            HIP_TRY(hipMemcpy(F.probe_w.p + b * mk * n, V.data() + b * m * n, (size_t)mk * n * sizeof(double), hipMemcpyHostToDevice));
+        if ((rc = front_launch_probe(*sys, F.x_in.p, batch, F.probe.p, mk, nullptr, F.probe_w.p)) != EZPZ_OK) return rc;
+        for (size_t b = 0; b < batch; ++b)
+            HIP_TRY(hipMemcpy(Y.data() + b * m * n, F.probe.p + b * mk * n, (size_t)mk * n * sizeof(double), hipMemcpyDeviceToHost));
+        bool settled = true;
+        for (size_t b = 0; b < batch; ++b) {
+            const uint32_t k = kdim[b];
+            if (!k) continue;
+            const double* Zb = Y.data() + b * m * n;
+            double* Vb = V.data() + b * m * n;
+            gram(Vb, Zb, k, H);  // Vt Op V
+            for (double g : H)
+                if (!(std::fabs(g) < 1e300)) return give_up("a refinement's answer is not finite");
+            for (uint32_t a2 = 0; a2 < k; ++a2)
+                for (uint32_t b2 = a2 + 1; b2 < k; ++b2) H[(size_t)b2 * k + a2] = H[(size_t)a2 * k + b2] = 0.5 * (H[(size_t)a2 * k + b2] + H[(size_t)b2 * k + a2]);
+            jacobi_eigen(H, Q, k);
+            ritz[b].assign(k, 0.0);
+            // the Ritz vectors' images, orthonormalised (modified Gram-Schmidt, largest Ritz value first), become the next V
+            std::vector<uint32_t> order(k);
+            for (uint32_t t = 0; t < k; ++t) order[t] = t;
+            std::sort(order.begin(), order.end(), [&](uint32_t a2, uint32_t b2) { return H[(size_t)a2 * k + a2] > H[(size_t)b2 * k + b2]; });
+            std::vector<double> next((size_t)k * n, 0.0);
+            uint32_t kept = 0;
+            for (uint32_t o = 0; o < k; ++o) {
+                const uint32_t t = order[o];
+                const double f = H[(size_t)t * k + t];
+                double* u = next.data() + (size_t)kept * n;
+                for (size_t i2 = 0; i2 < n; ++i2) {
+                    double d = 0.0;
+                    for (uint32_t j2 = 0; j2 < k; ++j2) d += Q[(size_t)j2 * k + t] * Zb[j2 * n + i2];
+                    u[i2] = d;
+                }
+                for (uint32_t q2 = 0; q2 < kept; ++q2) {
+                    const double* w2 = next.data() + (size_t)q2 * n;
+                    double dot = 0.0;
+                    for (size_t i2 = 0; i2 < n; ++i2) dot += u[i2] * w2[i2];
+                    for (size_t i2 = 0; i2 < n; ++i2) u[i2] -= dot * w2[i2];
+                }
+                double nrm = 0.0;
+                for (size_t i2 = 0; i2 < n; ++i2) nrm += u[i2] * u[i2];
+                // (a null vector is answered by itself -- f = 1 up to the rounding of J w, ~1e-5 at this lambda; a direction answered
+                // by less than half of itself has sigma^2 > lambda: not one, and out of the candidates)
+                if (!(f >= 0.5) || !(nrm > 1e-28)) continue;
+                const double inv = 1.0 / std::sqrt(nrm);
+                for (size_t i2 = 0; i2 < n; ++i2) u[i2] *= inv;
+                ritz[b][kept] = f;
+                ++kept;
+            }
+            ritz[b].resize(kept);
+            std::fill(Vb, Vb + (size_t)m * n, 0.0);
+            std::copy(next.begin(), next.begin() + (size_t)kept * n, Vb);
+            kdim[b] = kept;
+            for (double f : ritz[b])
+                if (f < 0.999) settled = false;
+        }
+        // (three rounds at least: what is not a null vector leaves the kept ones at lambda / sigma^2 per round)
+        if (settled && round >= 2) break;
+        if (round == 5) return give_up("a Ritz value stays between 0.5 and 0.999 (a singular value of J within 1e-7 ... 3e-6 of its largest entry)");
+    }
+    // ---- participation = squared row norms of the null vectors (find_dof.rs:90-103) ---------------------------------------------------
+    std::vector<double> proj(n);
+    for (size_t b = 0; b < batch; ++b) {
+        const double* Vb = V.data() + b * m * n;
+        std::fill(proj.begin(), proj.end(), 0.0);
+        uint32_t nullity = 0;
+        for (uint32_t t = 0; t < kdim[b]; ++t) {
+            if (!(ritz[b][t] >= 0.999)) return give_up("an unsettled direction");
+            ++nullity;
+            for (size_t i2 = 0; i2 < n; ++i2) proj[i2] += Vb[t * n + i2] * Vb[t * n + i2];
+        }
+        double most_part = 0.0;
+        for (size_t i2 = 0; i2 < n; ++i2) most_part = std::max(most_part, proj[i2]);
+        const double var_tol = kFreedomVarTol * most_part, squared_tol = var_tol * var_tol;
+        uint8_t* mk = under_mask + b * n;
+        double* pt = participation ? participation + b * n : nullptr;
+        for (size_t i2 = 0; i2 < n; ++i2) {
+            mk[i2] = nullity && proj[i2] > squared_tol ? 1 : 0;
+            if (pt) pt[i2] = proj[i2];
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
 // A system whose resident QR timed out (FreedomArgs::qr_timed_out) carries kFreedomPoisonedMask in every byte of its mask.
 bool mask_poisoned(const uint8_t* mask, size_t batch, size_t n) {
     for (size_t b = 0; b < batch; ++b)
@@ -352,6 +562,7 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
     const size_t n = sys->counts.n_vars;
     if (n == 0 || sys->counts.n_rows == 0) return EZPZ_ERR_EMPTY_SYSTEM;
     int rc;
+    if ((rc = freedom_by_probes(sys, x, batch, under_mask, participation)) <= 0) return rc;  // (a system on the fronts: no QR)
     const size_t x_bytes = batch * n * sizeof(double), mask_bytes = (batch * n + 15) & ~size_t(15), part_bytes = participation ? x_bytes : 0;
     if (x_bytes + mask_bytes + part_bytes <= sys->lim.policy.zero_copy_max_bytes) {
         // Small call (solve_analysis of one sketch): no copies and no allocation.  The kernels read the values from, and

@@ -11,6 +11,10 @@ namespace ezpz {
 extern std::mutex g_grid_mu;          // launch.hip: launches whose workgroups wait for each other are chained per device
 extern hipEvent_t g_grid_event[16];
 
+static thread_local uint32_t g_probe_m = 0;
+static thread_local double* g_probe_out = nullptr;
+static thread_local const double* g_probe_in = nullptr;
+
 template <bool LIN>
 static int front_launch_kernel(EzpzSystem& s, FrontArgs& fa, hipStream_t stream) {
     const FrontPlan& plan = *s.fronts;
@@ -82,11 +86,35 @@ int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     fa.verdict_chunk = plan.verdict_chunk;
     fa.scratch = nullptr;
     fa.scratch_stride = 0;
+    fa.probe_m = g_probe_m;  // (front_launch_probe, this thread)
+    fa.probe_out = g_probe_out;
+    fa.probe_in = g_probe_in;
     fa.stamps = args.stamps;
     fa.done = args.done;
     fa.done.request = nullptr;  // (this kernel does not stay resident between calls)
     args.done.request = nullptr;
     return plan.linear_only ? front_launch_kernel<true>(s, fa, stream) : front_launch_kernel<false>(s, fa, stream);
+}
+
+// The null-space probes of FreedomAnalysis (FrontArgs::probe_m): `m` probes of `batch` systems at the values x_dev ([batch][n_vars],
+// caller order), answers to y_dev ([batch][m][n_vars]); w_dev: the probes' vectors ([batch][m][n_vars]), or null = pseudo-random signs.
+int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double* y_dev, uint32_t m, hipStream_t stream, const double* w_dev) {
+    if (!s.fronts || !s.dev_fronts || !m) return EZPZ_ERR_INVALID_ARGUMENT;
+    SolveArgs args{};
+    args.x0 = x_dev;
+    args.batch = batch;
+    args.max_iterations = 0;
+    args.residual_tolerance = 0.0;
+    args.step_tolerance = 0.0;
+    args.initial_lambda = 0.0;
+    g_probe_m = m;
+    g_probe_out = y_dev;
+    g_probe_in = w_dev;
+    const int rc = front_launch(s, args, stream);
+    g_probe_m = 0;
+    g_probe_out = nullptr;
+    g_probe_in = nullptr;
+    return rc;
 }
 
 }  // namespace ezpz

@@ -541,6 +541,9 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
         ws[W.l_panels] = 0.0;  // ... and of padding sources
     }
     const bool unit_w = a.unit_weights != 0;
+    // null-space probes instead of the LM loop (FrontArgs::probe_m)
+    const bool probing = a.probe_m != 0;
+    const uint16_t* const slotmap = reinterpret_cast<const uint16_t*>(a.plan + W.o_slotmap);
     uint32_t sys_parity = 0;
     for (uint64_t sys = slot; sys < a.batch; sys += n_slots, sys_parity ^= 1u) {
 #ifdef EZPZ_STAMPS
@@ -564,8 +567,49 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
         double step_inf_norm = 0.0;
         uint32_t iterations = a.max_iterations, converged = 0;
         double dmax = __builtin_nan("");  // (fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax))
+        uint32_t probe_j = 0;
+        double lambda_probe = 0.0;
         for (;;) {
-            if (mode == STEP) {
+            if (mode == STEP && probing) {
+                // ---- probe j: w = pseudo-random signs (in x's place: the Jacobian is evaluated, x is not needed again), the
+                //      right-hand side's residual vector J w (in r_next's place), lambda_p from J's largest entry ---------------------
+                if (probe_j == 0) {
+                    double m2 = __builtin_nan(""), z0 = 0.0, z1 = __builtin_nan(""), z2 = 0.0;
+                    for (uint32_t i = tid; i < zj; i += blockDim.x) m2 = fmax_abs(m2, jvp[i]);
+                    red.reduce(z0, m2, z1, z2);
+                    lambda_probe = 1e-11 * m2 * m2;
+                }
+                for (uint32_t i = tid; i < n_loc; i += blockDim.x) {
+                    if (a.probe_in) {
+                        xs[i] = a.probe_in[(sys * a.probe_m + probe_j) * a.n_vars + var_glob[i]];
+                        continue;
+                    }
+                    uint32_t h = var_glob[i] * 2654435761u ^ (probe_j * 0x9E3779B9u + 0x7F4A7C15u);
+                    h ^= h >> 15;
+                    h *= 0x2C1B3C6Du;
+                    h ^= h >> 12;
+                    h *= 0x297A2D39u;
+                    h ^= h >> 15;
+                    xs[i] = (h & 0x10000u) ? 1.0 : -1.0;
+                }
+                __syncthreads();
+                for (uint32_t ci = tid; ci < n_cons; ci += blockDim.x) {
+                    const DevCon c = load_con(cons + ci);
+                    double r0 = 0.0, r1 = 0.0;
+                    for (uint32_t q = 0; q < c.nslots; ++q) {
+                        const uint32_t e = slotmap[c.jbase + q];
+                        const double t = jvp[c.jbase + q] * xs[e & 0x7FFFu];
+                        if (e >> 15)
+                            r1 += t;
+                        else
+                            r0 += t;
+                    }
+                    ws[l_rn + c.row0] = r0;
+                    if (c.nrows > 1) ws[l_rn + c.row0 + 1] = r1;
+                }
+                __syncthreads();
+            }
+            if (mode == STEP && !probing) {
                 if (it >= a.max_iterations) {  // newton.rs:141-144
                     mode = FINAL;
                 } else if (largest <= a.residual_tolerance) {  // newton.rs:50-60
@@ -579,7 +623,7 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 ++epoch;
                 if (tid == 0) ints[1] = 0;
                 __syncthreads();
-                assemble(cx, W, lambda, l_r);
+                assemble(cx, W, probing ? lambda_probe : lambda, probing ? l_rn : l_r);
                 FRONT_STAMP(10);
                 bool bad_here = false;
                 ++fact_no;
@@ -616,6 +660,12 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 __syncthreads();
                 const bool bad = ints[1] != 0;
                 FRONT_STAMP(11);
+                if (bad && probing) {  // (the host falls back to the pivoted QR)
+                    for (uint32_t q = probe_j; q < a.probe_m; ++q)
+                        for (uint32_t i = tid; i < n_own; i += blockDim.x) a.probe_out[(sys * a.probe_m + q) * a.n_vars + var_glob[i]] = __builtin_nan("");
+                    __syncthreads();
+                    break;
+                }
                 if (bad) {  // numeric failure => lambda *= 10, burn the iteration (newton.rs:93-99)
                     lambda *= LM_LAMBDA_INCR;
                     ++it;
@@ -644,6 +694,12 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 for (uint32_t i = tid; i < n_loc; i += blockDim.x) xs[i] = xs[i] + dv[i];
                 __syncthreads();
                 FRONT_STAMP(14);
+                if (probing) {  // y = w + d: the probe's answer for this workgroup's own variables
+                    for (uint32_t i = tid; i < n_own; i += blockDim.x) a.probe_out[(sys * a.probe_m + probe_j) * a.n_vars + var_glob[i]] = xs[i];
+                    __syncthreads();
+                    if (++probe_j == a.probe_m) break;
+                    continue;
+                }
             }
             if (mode == FINAL && r_is_at_x && unit_w) {
                 // r already holds the unweighted residuals at this x (lib.rs:305-327, :358-370; see lm_kernel.hip.hpp)
@@ -756,6 +812,14 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 ++it;
             }
             if (mode == EVAL0) mode = STEP;
+        }
+        if (probing) {  // (the probes' answers are written; nothing else is)
+            if (G > 1 && tid == 0 && wg == 0) {
+                if (__hip_atomic_load(cx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) a.probe_out[sys * a.probe_m * a.n_vars] = __builtin_nan("");
+                __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            continue;
         }
         // ---- write-back -------------------------------------------------------------------------------------------------------------------
         FRONT_STAMP(30);

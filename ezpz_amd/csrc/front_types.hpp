@@ -84,6 +84,11 @@ struct alignas(16) FrontWg {
     // (a front starts when its local parent is through).  Made by list scheduling on the cost model (fronts.cpp): no barrier
     // between the levels of the tree, a wavefront waits for exactly what its next front needs.
     uint32_t t_sched;
+    // Which entry of the Jacobian a slot is (byte offset from the plan blob's start; uint16 per slot of this workgroup: the
+    // local variable of its column | the row inside its constraint << 15): what J times a vector needs (the null-space probes of
+    // FreedomAnalysis, front_kernel.hip.hpp); read from global memory, not staged.
+    uint32_t o_slotmap;
+    uint32_t pad[3];
 };
 static_assert(sizeof(FrontWg) % 16 == 0, "FrontWg layout");
 
@@ -139,7 +144,14 @@ struct FrontArgs {
     uint32_t n_chunks, bad_chunk0, verdict_chunk;
     unsigned char* scratch;     // n_wgs > 1: one FrontScratch per system in flight
     uint32_t scratch_stride;
-    uint32_t pad;
+    // NULL-SPACE PROBES (FreedomAnalysis of a system the fronts serve; freedom.hip): probe_m > 0 -- no LM loop; at x0 the kernel
+    // evaluates J and, for j < probe_m, solves (JtJ + lambda_p I) d = -JtJ w_j for the pseudo-random sign vector w_j (a hash of j and
+    // the variable's id; or the caller's own vectors, probe_in) and writes y_j = w_j + d = lambda_p (JtJ + lambda_p I)^-1 w_j to probe_out[(system x probe_m + j) x n_vars +
+    // variable]: the projection of w_j onto J's null space up to lambda_p / sigma^2 (lambda_p = 1e-11 x the largest squared entry
+    // of J).  A failed pivot writes NaN.  x_out / status / masks are not written.
+    uint32_t probe_m;
+    double* probe_out;
+    const double* probe_in;  // [batch][probe_m][n_vars] the vectors w_j themselves instead of the pseudo-random signs, or null
     unsigned long long* stamps;  // diagnostic builds
     DoneWord done;
 };

@@ -788,6 +788,19 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
         W.n_cons = (uint32_t)cl.size();
         W.n_rows = lrows;
         W.zj = lslots;
+        // which entry of J a slot is (FrontWg::o_slotmap)
+        std::vector<uint16_t> slotmap(lslots, 0);
+        for (uint32_t k = 0; k < cl.size(); ++k) {
+            const uint32_t i = cl[k];
+            for (int r = 0; r < kKinds[cs[i].kind].n_rows; ++r) {
+                const uint32_t grow = cinfo[i].row0 + (uint32_t)r;
+                for (uint32_t q = row_ptr[grow]; q < row_ptr[grow + 1]; ++q) {
+                    const uint32_t lv = local_of[pos[row_col[q]]];
+                    if (lv == NONE || lv >= 0x8000u) return fail(why, "internal: a Jacobian column without a local variable");
+                    slotmap[row_slot[q] - cinfo[i].jbase + ljbase[i]] = (uint16_t)(lv | ((uint32_t)r << 15));
+                }
+            }
+        }
         if (lslots >= 65535 || lrows >= 65535) return fail(why, "a workgroup's Jacobian does not fit 16-bit indices");
         // ---- workspace carve-up ------------------------------------------------------------------------------------------------
         uint32_t off = 0;
@@ -1052,6 +1065,7 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
             W.tab_bytes = (uint32_t)tab.size();
         }
         W.o_ghosts = B.put(ghosts);
+        W.o_slotmap = B.put(slotmap);
         out.n_fronts += W.n_fronts;
         out.n_levels = std::max(out.n_levels, nlev);
         out.ws_doubles_max = std::max(out.ws_doubles_max, W.ws_doubles);

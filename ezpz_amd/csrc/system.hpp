@@ -265,7 +265,7 @@ struct EzpzSystem {
         DevBuf<FreedomComp> comps;
         DevBuf<uint32_t> lists;  // items | comp_vars | col_ptr | col_slots
         uint32_t o_vars = 0, o_col_ptr = 0, o_col_slots = 0;
-        DevBuf<double> x_in, x_int, jv, part, gws, step_tau;
+        DevBuf<double> x_in, x_int, jv, part, gws, step_tau, probe, probe_w;
         DevBuf<uint32_t> step_done;
         FreedomComp comp0{};  // host copy of the largest component (the wide QR path factorises it over the whole device)
         uint32_t big = 0;     // ... and its index
@@ -363,7 +363,9 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
 // The whole call's systems while a host entry of this thread feeds them to launch() in pieces (pipeline.cpp): the launch shape is
 // chosen once per call, not per piece -- a short last piece does not change shape (0: the piece is the call).
 extern thread_local uint64_t t_call_batch;
-int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream);  // front.hip: the frontal shape (EzpzSystem::fronts)
+int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream);
+int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double* y_dev, uint32_t m, hipStream_t stream,
+                       const double* w_dev = nullptr);  // front.hip  // front.hip: the frontal shape (EzpzSystem::fronts)
 
 void launch_eval(EzpzSystem* sys, const double* x_int_dev, size_t batch, double* r_out_dev, double* jv_out_dev, uint32_t* deg_out_dev,
                  uint32_t grid, hipStream_t stream);  // the evaluation-only kernel (values in internal numbering)

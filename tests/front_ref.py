@@ -20,9 +20,9 @@ assert FRONT_CHILD.itemsize == 16
 FRONT_GHOST = np.dtype([("local", "<u4"), ("chunk", "<u4")])
 WG_FIELDS = ["n_loc", "n_own", "n_ghost", "n_cons", "n_rows", "zj", "n_fronts", "n_levels", "o_var_glob", "o_cons", "o_tables",
              "tab_bytes", "t_level_ptr", "t_children", "t_rows", "t_exports", "t_maps", "t_stream", "asm_word0", "asm_trips", "t_cons", "o_ghosts", "l_x", "l_d", "l_r",
-             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "t_sched"]
+             "l_rn", "l_jv", "l_panels", "l_upool", "ws_doubles", "n_remote_children", "t_sched", "o_slotmap", "pad0", "pad1", "pad2"]
 FRONT_WG = np.dtype([(f, "<u4") for f in WG_FIELDS])
-assert FRONT_WG.itemsize == 128
+assert FRONT_WG.itemsize == 144
 DEVCON = np.dtype([("ids", "<u4", (8,)), ("param", "<f8"), ("weight", "<f8"), ("row0", "<u4"), ("jbase", "<u4"), ("pos", "<u4"),
                    ("kind", "u1"), ("tag", "u1"), ("nrows", "u1"), ("nslots", "u1"), ("jloc", "u1", (16,))])
 assert DEVCON.itemsize == 80

@@ -980,7 +980,14 @@ def test_freedom_lane_mode_on_block_systems(E):
     assert not mask.any() and np.all(part == 0.0)
 
 
-def test_freedom_workgroup_mode_with_global_workspace(E):
+@pytest.fixture
+def pivoted_qr(monkeypatch):
+    """The tests of the pivoted QR's layouts: systems the fronts serve would be analysed by null-space probes (freedom.hip:
+    freedom_by_probes, tested below) and never reach them."""
+    monkeypatch.setenv("EZPZ_FREEDOM_PROBES", "0")
+
+
+def test_freedom_workgroup_mode_with_global_workspace(E, pivoted_qr):
     """One 240-variable component: the dense workspace (1.4 MB) lives in global memory, lanes work on columns."""
     recs, g = _chain_system(120)
     recs = recs[:-1]  # drop the last direction constraint: the last point may swing on its circle
@@ -992,7 +999,7 @@ def test_freedom_workgroup_mode_with_global_workspace(E):
     assert np.all(mask[:, -2:].any(axis=1)) and np.all(mask[:, :-2] == 0)  # only the last point is free
 
 
-def test_freedom_of_one_large_component_spread_over_the_device(E):
+def test_freedom_of_one_large_component_spread_over_the_device(E, pivoted_qr):
     """A 300-variable connected sketch that lost its last three constraints: one component, so its pivoted QR runs over the
     whole device (one cooperative launch for all Householder steps, freedom.hip.hpp:fr_qr_kernel) before the ordinary
     kernel takes rank, null space and participation; three systems side by side.  Against the oracle's dense QR."""
@@ -1009,7 +1016,7 @@ def test_freedom_of_one_large_component_spread_over_the_device(E):
 
 
 @pytest.mark.parametrize("points,repeated", [(150, 0), (400, 0), (200, 60)])
-def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, repeated, monkeypatch):
+def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, repeated, monkeypatch, pivoted_qr):
     """The three routes of the WIDE layout -- the matrix resident in the workgroups' registers for the whole factorisation
     (fr_qrc_kernel, the default up to 2048 rows), the trailing matrix streamed once per step inside one cooperative launch
     (fr_qr_kernel, EZPZ_FREEDOM_CHAIN=2), and the chain of one launch pair per step they fall back to when the device
@@ -1033,7 +1040,7 @@ def test_freedom_wide_cooperative_launch_and_launch_chain_agree(E, points, repea
         assert np.allclose(part_other, part, atol=1e-10), route
 
 
-def test_freedom_two_large_components_on_one_workgroup(E):
+def test_freedom_two_large_components_on_one_workgroup(E, pivoted_qr):
     """Two 120-variable chains in one system: the larger workspace of the two is factorised over the whole device (its QR
     left in the global workspace for the ordinary kernel, which takes that component first), the other in sequence by one
     workgroup out of the same workspace (rows contiguous, norms summed during the update)."""
@@ -1047,6 +1054,53 @@ def test_freedom_two_large_components_on_one_workgroup(E):
     x, st, _ = sysobj.solve_batch(X)
     _, mask, _ = _freedom_vs_oracle(E, both, len(gg), x, atol=1e-8)
     assert mask[:, len(g) - 2:len(g)].any() and mask[:, -2:].any()
+
+
+@pytest.mark.parametrize("npts,drop,team", [(40, 0, 0), (40, 3, 0), (150, 0, 0), (150, 1, 0), (150, 3, "latency"), (400, 2, 0), (400, 4, "latency"),
+                                             (1000, 0, "latency"), (1000, 3, 0)])
+def test_freedom_by_null_space_probes_equals_the_oracle(E, npts, drop, team, monkeypatch):
+    """FreedomAnalysis of a system the fronts serve (freedom.hip: freedom_by_probes): no pivoted QR -- the projector onto null(J)
+    applied to pseudo-random vectors by the frontal factorisation, the candidates refined by subspace iteration, participation from
+    the null vectors found.  Fully constrained sketches and sketches that lost their last 1 ... 4 constraints, 80 ... 2000
+    variables on 1 ... 14 workgroups, systems created for batches and for one solve: the underconstrained set equal to the oracle's
+    dense pivoted QR of the same Jacobian (find_dof.rs:31-103), participation within 1e-9, and equal to the device's own QR."""
+    recs, g = gen.connected_sketch(npts, 4242)
+    if drop:
+        recs = recs[:-drop]
+    n = len(g)
+    sysobj = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY if team == "latency" else team)
+    assert sysobj.info()["front_workgroups"] >= 1
+    X = g[None, :] + gen.keyed_uniform(61, 2, n, -0.01, 0.01)
+    x, st, _ = sysobj.solve_batch(X, E.Config(max_iterations=60))
+    monkeypatch.delenv("EZPZ_FREEDOM_PROBES", raising=False)
+    mask, part = sysobj.freedom_batch(x)
+    _, J, _ = sysobj.eval_batch(x)
+    for b in range(len(x)):
+        under, want = O.freedom_analysis_dense(J[b])
+        assert np.nonzero(mask[b])[0].tolist() == under, (b, int(mask[b].sum()), len(under))
+        assert np.allclose(part[b], want, atol=1e-9), (b, float(np.abs(part[b] - want).max()))
+        assert bool(under) == bool(drop)
+    monkeypatch.setenv("EZPZ_FREEDOM_PROBES", "0")
+    mask_qr, part_qr = sysobj.freedom_batch(x)
+    assert np.array_equal(mask_qr, mask) and np.allclose(part_qr, part, atol=1e-8)
+
+
+def test_freedom_probes_leave_many_degrees_of_freedom_to_the_qr(E, monkeypatch):
+    """Eight probes are trusted with up to four candidate directions: a sketch that lost twelve constraints goes to the pivoted QR
+    (the same answer as with the probes switched off, equal to the oracle's)."""
+    recs, g = gen.connected_sketch(150, 4242)
+    recs = recs[:-12]
+    n = len(g)
+    sysobj = E.System(recs, n)
+    x, st, _ = sysobj.solve_batch(g[None, :], E.Config(max_iterations=60))
+    monkeypatch.delenv("EZPZ_FREEDOM_PROBES", raising=False)
+    mask, part = sysobj.freedom_batch(x)
+    monkeypatch.setenv("EZPZ_FREEDOM_PROBES", "0")
+    mask_qr, part_qr = sysobj.freedom_batch(x)
+    assert np.array_equal(mask, mask_qr) and np.array_equal(part, part_qr)
+    _, J, _ = sysobj.eval_batch(x)
+    under, want = O.freedom_analysis_dense(J[0])
+    assert np.nonzero(mask[0])[0].tolist() == under and len(under) >= 5
 
 
 def test_freedom_random_systems(E):
