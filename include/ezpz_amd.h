@@ -284,7 +284,11 @@ int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_id
  * batch solve): under_mask [batch][n_vars] gets 1 where the variable is underconstrained, participation
  * [batch][n_vars] (optional) the squared row norms of the orthonormal null-space basis (find_dof.rs:90-95).  The
  * Jacobian is re-evaluated at the values given (the reference reuses the LM loop's last refresh, which is the
- * Jacobian at the final values).  A large component's QR runs on many workgroups that wait for each other's chunks; should one
+ * Jacobian at the final values).  Where the system has a frontal plan (EzpzSystemInfo.front_workgroups) the host entries do not
+ * factorise J at all: the projector onto its null space is applied to a few probe vectors by the frontal factorisation and the
+ * null vectors are refined by subspace iteration -- the same sets, participation equal to rounding; more
+ * than four degrees of freedom, a singular value within 1e-7 ... 3e-6 of J's largest entry, or more than 64 systems per call go
+ * to the pivoted QR, like every call of the _device entry.  A large component's QR runs on many workgroups that wait for each other's chunks; should one
  * of them give up waiting (a device fault), the host entries return EZPZ_ERR_HIP and the asynchronous _device entry marks the
  * system: 0xFF in every byte of its mask, 0xFFFFFFFF as its count -- as a timed-out grid team's solve reports
  * EZPZ_ITERATIONS_TEAM_TIMEOUT. */
