@@ -329,8 +329,8 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
 // the orthogonal projector P onto null(J) (the squared row norm of ANY orthonormal basis) -- and the frontal factorisation gives P
 // applied to a vector for the price of one linear solve: lambda (JtJ + lambda I)^-1 w -> P w as lambda -> 0 (front_kernel.hip.hpp,
 // FrontArgs::probe_m; lambda = 1e-11 x J's largest squared entry; what rounding adds to the answer lies along the small eigenvectors,
-// i.e. INSIDE the null space).  m pseudo-random sign vectors w_j give Y = P W (n x m), whose range is null(J) as soon as m exceeds
-// its dimension: the eigenvalues of the m x m matrix Yt Y split into a cluster of order m (one per degree of freedom) and values of
+// i.e. INSIDE the null space).  m pseudo-random vectors w_j (entries uniform in [-1, 1)) give Y = P W (n x m), whose range is null(J) as soon as m exceeds
+// its dimension: the eigenvalues of the m x m matrix Yt Y split into a cluster of order m / 3 (one per degree of freedom) and values of
 // order m (lambda / sigma^2)^2 for everything else, and participation_i = sum over the cluster of (y_i . q_t)^2 / e_t.  A fully
 // constrained sketch -- the common case -- is Y = 0 after the first eight solves.  Otherwise the directions of Y that stand out are
 // refined by subspace iteration with the same operator (V <- orthonormalised Op V): its Ritz values on span(V) are lambda /
@@ -422,8 +422,8 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
         uint32_t k = 0;
         for (uint32_t t = 0; t < m; ++t) {
             const double e = G[(size_t)t * m + t];
-            // (a null vector's eigenvalue is a chi-square of eight: of order m; a direction answered by a tenth of itself or less
-            // is not one)
+            // (a null vector's eigenvalue is a sum of eight squares of variance 1/3: of order m / 3; a direction answered by a tenth of
+            // itself or less is not one)
             if (!(e > 0.005 * m)) continue;
             const double inv = 1.0 / std::sqrt(e);
             for (size_t i2 = 0; i2 < n; ++i2) {

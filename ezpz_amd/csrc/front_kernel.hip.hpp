@@ -590,7 +590,9 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                     h ^= h >> 12;
                     h *= 0x297A2D39u;
                     h ^= h >> 15;
-                    xs[i] = (h & 0x10000u) ? 1.0 : -1.0;
+                    // (uniform in [-1, 1), not signs: a null vector like (1, -1) / sqrt 2 is orthogonal to every sign vector that gives
+                    // its two variables the same sign -- all eight of them once in 256)
+                    xs[i] = (double)h * (1.0 / 2147483648.0) - 1.0;
                 }
                 __syncthreads();
                 for (uint32_t ci = tid; ci < n_cons; ci += blockDim.x) {
