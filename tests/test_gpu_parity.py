@@ -1085,6 +1085,31 @@ def test_freedom_by_null_space_probes_equals_the_oracle(E, npts, drop, team, mon
     assert np.array_equal(mask_qr, mask) and np.allclose(part_qr, part, atol=1e-8)
 
 
+@pytest.mark.parametrize("drop", [0, 1, 2])
+def test_freedom_probes_on_a_linear_only_sketch(E, drop, monkeypatch):
+    """A chain of points tied by horizontal and vertical distances only (the frontal kernel's linear-only build, whose one Jacobian
+    sweep rides in eval()): fully constrained, and with its last one or two constraints gone (the last point free along y, then
+    along both)."""
+    npts = 60
+    cons = [O.fixed(0, 0.0), O.fixed(1, 0.0)]
+    for i in range(1, npts):
+        cons += [O.horizontal_distance((2 * i, 2 * i + 1), (2 * i - 2, 2 * i - 1), 1.0 + 0.01 * i),
+                 O.vertical_distance((2 * i, 2 * i + 1), (2 * i - 2, 2 * i - 1), 0.5)]
+    recs = O.stack(cons)
+    if drop:
+        recs = recs[:-drop]
+    n = 2 * npts
+    sysobj = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY)
+    assert sysobj.info()["team_mode"] == 5
+    x, st, _ = sysobj.solve_batch(np.zeros((1, n)), E.Config(max_iterations=20))
+    monkeypatch.delenv("EZPZ_FREEDOM_PROBES", raising=False)
+    mask, part = sysobj.freedom_batch(x)
+    _, J, _ = sysobj.eval_batch(x)
+    under, want = O.freedom_analysis_dense(J[0])
+    assert np.nonzero(mask[0])[0].tolist() == under and len(under) == drop
+    assert np.allclose(part[0], want, atol=1e-9)
+
+
 def test_freedom_probes_leave_many_degrees_of_freedom_to_the_qr(E, monkeypatch):
     """Eight probes are trusted with up to four candidate directions: a sketch that lost twelve constraints goes to the pivoted QR
     (the same answer as with the probes switched off, equal to the oracle's)."""
