@@ -102,7 +102,7 @@ int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double*
     if (!s.fronts || !s.dev_fronts || !m) return EZPZ_ERR_INVALID_ARGUMENT;
     SolveArgs args{};
     args.x0 = x_dev;
-    args.batch = batch;
+    args.batch = batch * m;  // (a work item is one probe of one system: front_kernel.hip.hpp)
     args.max_iterations = 0;
     args.residual_tolerance = 0.0;
     args.step_tolerance = 0.0;

@@ -552,7 +552,9 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
         cx.stamp_n = &stamp_n;
 #endif
         FRONT_STAMP(1);
-        const double* const x0 = a.x0 + sys * a.n_vars;
+        // (probes: a work item is ONE probe of one system -- item = system x probe_m + probe -- so that a system's probes run side by
+        // side on as many workgroups)
+        const double* const x0 = a.x0 + (probing ? sys / a.probe_m : sys) * a.n_vars;
         for (uint32_t i = tid; i < n_loc; i += blockDim.x) xs[i] = x0[var_glob[i]];
         int* const nwarn = G > 1 ? &head->nwarn[sys_parity] : &ints[0];
         if (tid == 0 && G == 1) ints[0] = 0;
@@ -567,21 +569,21 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
         double step_inf_norm = 0.0;
         uint32_t iterations = a.max_iterations, converged = 0;
         double dmax = __builtin_nan("");  // (fmax drops NaN seeds; an all-NaN d stays NaN like reduce(fmax))
-        uint32_t probe_j = 0;
         double lambda_probe = 0.0;
         for (;;) {
             if (mode == STEP && probing) {
                 // ---- probe j: w = pseudo-random signs (in x's place: the Jacobian is evaluated, x is not needed again), the
                 //      right-hand side's residual vector J w (in r_next's place), lambda_p from J's largest entry ---------------------
-                if (probe_j == 0) {
+                {
                     double m2 = __builtin_nan(""), z0 = 0.0, z1 = __builtin_nan(""), z2 = 0.0;
                     for (uint32_t i = tid; i < zj; i += blockDim.x) m2 = fmax_abs(m2, jvp[i]);
                     red.reduce(z0, m2, z1, z2);
                     lambda_probe = 1e-11 * m2 * m2;
                 }
+                const uint32_t probe_j = (uint32_t)(sys % a.probe_m);
                 for (uint32_t i = tid; i < n_loc; i += blockDim.x) {
                     if (a.probe_in) {
-                        xs[i] = a.probe_in[(sys * a.probe_m + probe_j) * a.n_vars + var_glob[i]];
+                        xs[i] = a.probe_in[sys * a.n_vars + var_glob[i]];
                         continue;
                     }
                     uint32_t h = var_glob[i] * 2654435761u ^ (probe_j * 0x9E3779B9u + 0x7F4A7C15u);
@@ -663,8 +665,7 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 const bool bad = ints[1] != 0;
                 FRONT_STAMP(11);
                 if (bad && probing) {  // (the host falls back to the pivoted QR)
-                    for (uint32_t q = probe_j; q < a.probe_m; ++q)
-                        for (uint32_t i = tid; i < n_own; i += blockDim.x) a.probe_out[(sys * a.probe_m + q) * a.n_vars + var_glob[i]] = __builtin_nan("");
+                    for (uint32_t i = tid; i < n_own; i += blockDim.x) a.probe_out[sys * a.n_vars + var_glob[i]] = __builtin_nan("");
                     __syncthreads();
                     break;
                 }
@@ -697,10 +698,9 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 __syncthreads();
                 FRONT_STAMP(14);
                 if (probing) {  // y = w + d: the probe's answer for this workgroup's own variables
-                    for (uint32_t i = tid; i < n_own; i += blockDim.x) a.probe_out[(sys * a.probe_m + probe_j) * a.n_vars + var_glob[i]] = xs[i];
+                    for (uint32_t i = tid; i < n_own; i += blockDim.x) a.probe_out[sys * a.n_vars + var_glob[i]] = xs[i];
                     __syncthreads();
-                    if (++probe_j == a.probe_m) break;
-                    continue;
+                    break;
                 }
             }
             if (mode == FINAL && r_is_at_x && unit_w) {
@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
         }
         if (probing) {  // (the probes' answers are written; nothing else is)
             if (G > 1 && tid == 0 && wg == 0) {
-                if (__hip_atomic_load(cx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) a.probe_out[sys * a.probe_m * a.n_vars] = __builtin_nan("");
+                if (__hip_atomic_load(cx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) a.probe_out[sys * a.n_vars] = __builtin_nan("");
                 __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();

@@ -144,7 +144,8 @@ struct FrontArgs {
     uint32_t n_chunks, bad_chunk0, verdict_chunk;
     unsigned char* scratch;     // n_wgs > 1: one FrontScratch per system in flight
     uint32_t scratch_stride;
-    // NULL-SPACE PROBES (FreedomAnalysis of a system the fronts serve; freedom.hip): probe_m > 0 -- no LM loop; at x0 the kernel
+    // NULL-SPACE PROBES (FreedomAnalysis of a system the fronts serve; freedom.hip): probe_m > 0 -- no LM loop; `batch` counts work items =
+    // systems x probe_m, item i = probe i % probe_m of system i / probe_m (a system's probes side by side on as many workgroups); at x0 the kernel
     // evaluates J and, for j < probe_m, solves (JtJ + lambda_p I) d = -JtJ w_j for the pseudo-random vector w_j (uniform in [-1, 1): a hash of j and
     // the variable's id; or the caller's own vectors, probe_in) and writes y_j = w_j + d = lambda_p (JtJ + lambda_p I)^-1 w_j to probe_out[(system x probe_m + j) x n_vars +
     // variable]: the projection of w_j onto J's null space up to lambda_p / sigma^2 (lambda_p = 1e-11 x the largest squared entry
