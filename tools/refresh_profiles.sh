@@ -62,7 +62,7 @@ python tools/ab_microbench.py $out > /dev/null 2>&1
 hipcc --offload-arch=gfx950 -O2 -o tools/launch_floor.bin tools/launch_floor.hip 2>/dev/null && (echo "# tools/launch_floor.bin  (host -> device -> host round trips by completion method)"; ./tools/launch_floor.bin 2>&1) > $out/launch_floor.txt
 hipcc --offload-arch=gfx950 -O2 -o tools/pcie_duplex.bin tools/pcie_duplex.hip 2>/dev/null && (echo "# tools/pcie_duplex.bin  (both directions of the host link at once: queues and piece sizes)"; ./tools/pcie_duplex.bin 2>&1) > $out/pcie_duplex.txt
 (echo "# python tools/h2h_rate.py [lines batch]  (ezpz_system_solve_batch between host buffers: pageable, then registered = the pipelined path)"; python tools/h2h_rate.py 2>&1 | tail -1; python tools/h2h_rate.py 600 16384 2>&1 | tail -1; python tools/h2h_rate.py 200 65536 2>&1 | tail -1) > $out/h2h_rate.txt
-(echo "# python tools/freedom_wide.py 150 400 850 1000  (FreedomAnalysis of one large connected component: null-space probes on the frontal factorisation -- round 5, no QR --, then EZPZ_FREEDOM_PROBES=0: the pivoted QR with the matrix resident in registers, then on top EZPZ_FREEDOM_CHAIN=2: one cooperative launch streaming the trailing matrix, then EZPZ_FREEDOM_CHAIN=1: round 3's chain of a launch pair per Householder step)"; python tools/freedom_wide.py 150 400 850 1000 2500 10000 2>&1 | grep variables; EZPZ_FREEDOM_PROBES=0 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables; EZPZ_FREEDOM_PROBES=0 EZPZ_FREEDOM_CHAIN=2 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables; EZPZ_FREEDOM_PROBES=0 EZPZ_FREEDOM_CHAIN=1 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables) > $out/freedom_wide.txt
+(echo "# python tools/freedom_wide.py 150 400 850 1000  (FreedomAnalysis of one large connected component: null-space probes on the frontal factorisation -- round 5, no QR --, then EZPZ_FREEDOM_PROBES=0: the pivoted QR with the matrix resident in registers, then on top EZPZ_FREEDOM_CHAIN=2: one cooperative launch streaming the trailing matrix, then EZPZ_FREEDOM_CHAIN=1: round 3's chain of a launch pair per Householder step)"; python tools/freedom_wide.py 150 400 850 1000 2500 2>&1 | grep variables; EZPZ_FREEDOM_PROBES=0 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables; EZPZ_FREEDOM_PROBES=0 EZPZ_FREEDOM_CHAIN=2 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables; EZPZ_FREEDOM_PROBES=0 EZPZ_FREEDOM_CHAIN=1 python tools/freedom_wide.py 150 400 850 1000 2>&1 | grep variables) > $out/freedom_wide.txt
 # round 5: who solves which system -- the headline with drawn systems against fixed shares (same build), small calls of batch systems, and
 # what a resident one-call kernel costs a batch on another stream (with the residency switched off as the control)
 (echo "# EZPZ_TICKETS=<0|1> python bench.py --steps 20 --warmup 5 --legs 0 --cpu-seconds 0 --extras 0 --pmc 0  (0 = fixed shares of the batch per workgroup, 1 = the default: workgroups draw their systems from eight counters)"; for t in 0 1 0 1; do EZPZ_TICKETS=$t python bench.py --steps 20 --warmup 5 --legs 0 --cpu-seconds 0 --extras 0 --pmc 0 2>/dev/null | $PY -c "import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('EZPZ_TICKETS=$t:', round(l['value']/1e6,2), 'M solves/s,', round(l['ms_per_step'],4), 'ms per launch of', l['config']['systems_per_launch_per_gpu'], 'systems; oracle check', l['oracle_check']['bitwise_equal'])"; done) > $out/tickets_ab.txt
