@@ -190,8 +190,8 @@ int launch_list_walk(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     // (a list of systems on the device -- the lanes' stragglers: `batch` is the list's capacity, the systems are a few hundred)
     const uint32_t rounds = (s.lds_ws && s.mode != MODE_SUB && !args.sys_list) ? 32u : 2u;
     grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)s.lim.cus * std::min<uint32_t>(per_cu, 8) * rounds);
-    if (s.rec && s.rec_jglobal)  // (a workgroup's Jacobian values in global memory: at most 1 GiB of them)
-        grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (1ull << 27) / ((s.counts.zj + 2) & ~1ull)));
+    if (s.rec && s.rec_jglobal)  // (a workgroup's Jacobian values in global memory: at most 256 MiB of them per system object)
+        grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (1ull << 25) / ((s.counts.zj + 2) & ~1ull)));
     if (!s.lds_ws) {
         int rc = s.gws_dev.ensure((size_t)grid * s.ws_doubles);
         if (rc != EZPZ_OK) return rc;
