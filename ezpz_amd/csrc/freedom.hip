@@ -504,7 +504,41 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
         }
         // (three rounds at least: what is not a null vector leaves the kept ones at lambda / sigma^2 per round)
         if (settled && round >= 2) break;
-        if (round == 5) return give_up("a Ritz value stays between 0.5 and 0.999 (a singular value of J within 1e-7 ... 3e-6 of its largest entry)");
+        if (round == 5) {
+            // A Ritz value stays between 0.5 and 0.999: a singular value of J within 1e-7 ... 3e-6 of its largest entry, which the
+            // reference's rank decision (1e-8 on R's diagonal) counts as non-zero.  A second opinion at lambda_p / 1000: what it
+            // answers by less than half of itself there is NOT a null vector and leaves; the null vectors' own answers are noisier
+            // (the rounding of J w over a smaller lambda: 1e-2), so they only have to stay above 0.9.  Anything between, or a failed
+            // pivot at that lambda: the pivoted QR.
+            uint32_t mk2 = 0;
+            for (size_t b = 0; b < batch; ++b) mk2 = std::max(mk2, kdim[b]);
+            for (size_t b = 0; b < batch; ++b)
+                HIP_TRY(hipMemcpy(F.probe_w.p + b * mk2 * n, V.data() + b * m * n, (size_t)mk2 * n * sizeof(double), hipMemcpyHostToDevice));
+            if ((rc = front_launch_probe(*sys, F.x_in.p, batch, F.probe.p, mk2, nullptr, F.probe_w.p, 1e-14)) != EZPZ_OK) return rc;
+            for (size_t b = 0; b < batch; ++b)
+                HIP_TRY(hipMemcpy(Y.data() + b * m * n, F.probe.p + b * mk2 * n, (size_t)mk2 * n * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t b = 0; b < batch; ++b) {
+                const uint32_t k = kdim[b];
+                const double* Zb = Y.data() + b * m * n;
+                double* Vb = V.data() + b * m * n;
+                uint32_t kept = 0;
+                for (uint32_t t = 0; t < k; ++t) {
+                    double f2 = 0.0;
+                    for (size_t i2 = 0; i2 < n; ++i2) f2 += Vb[t * n + i2] * Zb[t * n + i2];
+                    if (!(std::fabs(f2) < 1e300)) return give_up("a pivot failed at the second opinion's lambda");
+                    if (ritz[b][t] >= 0.999 || f2 > 0.9) {  // a null vector (kept as it is)
+                        if (kept != t) std::copy(Vb + (size_t)t * n, Vb + (size_t)(t + 1) * n, Vb + (size_t)kept * n);
+                        ritz[b][kept] = 1.0;
+                        ++kept;
+                    } else if (f2 >= 0.5) {
+                        return give_up("a direction answered by 0.5 ... 0.9 of itself at both lambdas (a singular value of J within 3e-9 ... 1e-7 of its largest entry)");
+                    }
+                }
+                ritz[b].resize(kept);
+                kdim[b] = kept;
+            }
+            break;
+        }
     }
     // ---- participation = squared row norms of the null vectors (find_dof.rs:90-103) ---------------------------------------------------
     std::vector<double> proj(n);

@@ -14,6 +14,7 @@ extern hipEvent_t g_grid_event[16];
 static thread_local uint32_t g_probe_m = 0;
 static thread_local double* g_probe_out = nullptr;
 static thread_local const double* g_probe_in = nullptr;
+static thread_local double g_probe_scale = 1e-11;
 
 template <bool LIN>
 static int front_launch_kernel(EzpzSystem& s, FrontArgs& fa, hipStream_t stream) {
@@ -89,6 +90,7 @@ int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     fa.probe_m = g_probe_m;  // (front_launch_probe, this thread)
     fa.probe_out = g_probe_out;
     fa.probe_in = g_probe_in;
+    fa.probe_scale = g_probe_scale;
     fa.stamps = args.stamps;
     fa.done = args.done;
     fa.done.request = nullptr;  // (this kernel does not stay resident between calls)
@@ -98,7 +100,8 @@ int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
 
 // The null-space probes of FreedomAnalysis (FrontArgs::probe_m): `m` probes of `batch` systems at the values x_dev ([batch][n_vars],
 // caller order), answers to y_dev ([batch][m][n_vars]); w_dev: the probes' vectors ([batch][m][n_vars]), or null = pseudo-random signs.
-int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double* y_dev, uint32_t m, hipStream_t stream, const double* w_dev) {
+int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double* y_dev, uint32_t m, hipStream_t stream, const double* w_dev,
+                       double lambda_scale) {
     if (!s.fronts || !s.dev_fronts || !m) return EZPZ_ERR_INVALID_ARGUMENT;
     SolveArgs args{};
     args.x0 = x_dev;
@@ -110,6 +113,7 @@ int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double*
     g_probe_m = m;
     g_probe_out = y_dev;
     g_probe_in = w_dev;
+    g_probe_scale = lambda_scale;
     const int rc = front_launch(s, args, stream);
     g_probe_m = 0;
     g_probe_out = nullptr;

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                     double m2 = __builtin_nan(""), z0 = 0.0, z1 = __builtin_nan(""), z2 = 0.0;
                     for (uint32_t i = tid; i < zj; i += blockDim.x) m2 = fmax_abs(m2, jvp[i]);
                     red.reduce(z0, m2, z1, z2);
-                    lambda_probe = 1e-11 * m2 * m2;
+                    lambda_probe = a.probe_scale * m2 * m2;
                 }
                 const uint32_t probe_j = (uint32_t)(sys % a.probe_m);
                 for (uint32_t i = tid; i < n_loc; i += blockDim.x) {

@@ -365,7 +365,7 @@ int solve_batch_device_impl(EzpzSystem* sys, const double* x0_dev, size_t batch,
 extern thread_local uint64_t t_call_batch;
 int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream);
 int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double* y_dev, uint32_t m, hipStream_t stream,
-                       const double* w_dev = nullptr);  // front.hip  // front.hip: the frontal shape (EzpzSystem::fronts)
+                       const double* w_dev = nullptr, double lambda_scale = 1e-11);  // front.hip  // front.hip: the frontal shape (EzpzSystem::fronts)
 
 void launch_eval(EzpzSystem* sys, const double* x_int_dev, size_t batch, double* r_out_dev, double* jv_out_dev, uint32_t* deg_out_dev,
                  uint32_t grid, hipStream_t stream);  // the evaluation-only kernel (values in internal numbering)

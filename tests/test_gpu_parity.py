@@ -1057,13 +1057,15 @@ def test_freedom_two_large_components_on_one_workgroup(E, pivoted_qr):
 
 
 @pytest.mark.parametrize("npts,drop,team", [(40, 0, 0), (40, 3, 0), (150, 0, 0), (150, 1, 0), (150, 3, "latency"), (400, 2, 0), (400, 4, "latency"),
-                                             (1000, 0, "latency"), (1000, 3, 0)])
+                                             (850, 0, 0), (850, 3, "latency"), (1000, 0, "latency"), (1000, 3, 0)])
 def test_freedom_by_null_space_probes_equals_the_oracle(E, npts, drop, team, monkeypatch):
     """FreedomAnalysis of a system the fronts serve (freedom.hip: freedom_by_probes): no pivoted QR -- the projector onto null(J)
     applied to pseudo-random vectors by the frontal factorisation, the candidates refined by subspace iteration, participation from
     the null vectors found.  Fully constrained sketches and sketches that lost their last 1 ... 4 constraints, 80 ... 2000
     variables on 1 ... 14 workgroups, systems created for batches and for one solve: the underconstrained set equal to the oracle's
-    dense pivoted QR of the same Jacobian (find_dof.rs:31-103), participation within 1e-9, and equal to the device's own QR."""
+    dense pivoted QR of the same Jacobian (find_dof.rs:31-103), participation within 1e-9, and equal to the device's own QR.  (The
+    1700-variable sketch has a singular value ~1e-6 of the largest entry: a Ritz value stays undecided at the first lambda and the
+    second opinion at lambda / 1000 settles it.)"""
     recs, g = gen.connected_sketch(npts, 4242)
     if drop:
         recs = recs[:-drop]
