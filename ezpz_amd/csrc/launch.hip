@@ -348,7 +348,15 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                             for (unsigned int& b : s.ticket_base) b = 0;
                         }
                         if (ok && !s.ticket_done) ok = hipEventCreateWithFlags(&s.ticket_done, hipEventDisableTiming) == hipSuccess;
-                        else if (ok) ok = hipStreamWaitEvent(stream, s.ticket_done, 0) == hipSuccess;
+                        if (ok && s.ticket_used && s.ticket_stream != stream) {
+                            // another stream than last time: everything enqueued on the old one first (an event per launch instead
+                            // cost the back-to-back launches of one stream two runtime calls and a barrier packet each)
+                            ok = hipEventRecord(s.ticket_done, s.ticket_stream) == hipSuccess && hipStreamWaitEvent(stream, s.ticket_done, 0) == hipSuccess;
+                            if (!ok) {  // (the old stream is gone: whatever ran on it is awaited the blunt way)
+                                (void)hipGetLastError();
+                                ok = hipDeviceSynchronize() == hipSuccess;
+                            }
+                        }
                         if (ok) Lt.ticket = s.ticket.p, Lt.ticket_base = s.ticket_base;
                         else (void)hipGetLastError();
                     }
@@ -360,7 +368,8 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                                 const uint64_t wgs_c = (capacity + 7 - c) / 8, beyond = L.batch - capacity;
                                 s.ticket_base[c] += (unsigned int)(wgs_c + (beyond > c ? (beyond - c + 7) / 8 : 0));
                             }
-                            HIP_TRY(hipEventRecord(s.ticket_done, stream));
+                            s.ticket_stream = stream;
+                            s.ticket_used = true;
                         }
                         return EZPZ_OK;
                     }

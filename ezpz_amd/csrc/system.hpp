@@ -194,11 +194,13 @@ struct EzpzSystem {
     DevBuf<LmResume> strag_state;              // ... and the LM state each had reached
     uint64_t lanes_ws_waves = 0;
     // the specialised kernels' work counters (JitArgs::ticket): never reset -- what a launch draws from each follows from its batch and
-    // its workgroups, the host keeps the running totals -- so launches that use them are chained on `ticket_done` whatever their
-    // streams (under launch_mu)
+    // its workgroups, the host keeps the running totals -- so launches that use them must not overlap: on one stream they do not
+    // anyway; when the stream CHANGES, an event recorded on the old one is waited for on the new one (under launch_mu)
     DevBuf<unsigned int> ticket;
     unsigned int ticket_base[8] = {};
     hipEvent_t ticket_done = nullptr;
+    hipStream_t ticket_stream = nullptr;  // the stream of the last launch that drew from the counters
+    bool ticket_used = false;
     hipEvent_t lanes_done = nullptr;  // completion of this system's last launch that used its global-memory workspace (lanes
                                       // kernel, list walk with the workspace in global memory): the next one, on any stream, waits for it
     uint64_t lanes_min = ~0ull;  // systems per call from which `lanes` serves the call
