@@ -64,7 +64,6 @@ __device__ __forceinline__ double rsqrt_newton(double p) {
 struct Ctx {
     double* ws;                  // workspace (LDS)
     const FrontDesc* descs;      // staged tables (LDS)
-    const uint32_t* level_ptr;
     const FrontChild* children;
     const uint16_t* rows;
     const uint32_t* exports;
@@ -496,7 +495,6 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
     Ctx cx;
     cx.ws = ws;
     cx.descs = reinterpret_cast<const FrontDesc*>(tab);
-    cx.level_ptr = reinterpret_cast<const uint32_t*>(tab + W.t_level_ptr);
     cx.children = reinterpret_cast<const FrontChild*>(tab + W.t_children);
     cx.rows = reinterpret_cast<const uint16_t*>(tab + W.t_rows);
     cx.exports = reinterpret_cast<const uint32_t*>(tab + W.t_exports);
@@ -623,7 +621,7 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
                 }
             }
             if (mode == STEP) {
-                // ---- (JtJ + lambda I) d = -Jt r: the fronts, level by level (newton.rs:73-102) ------------------------------------------
+                // ---- (JtJ + lambda I) d = -Jt r: every wavefront its list of fronts (newton.rs:73-102) ---------------------------------
                 ++epoch;
                 if (tid == 0) ints[1] = 0;
                 __syncthreads();

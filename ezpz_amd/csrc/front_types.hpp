@@ -69,7 +69,7 @@ struct alignas(16) FrontWg {
     uint32_t o_var_glob;              // uint32[n_loc]: caller's variable id
     uint32_t o_cons;                  // DevCon[n_cons] (ids = local variables, row0 / jbase local)
     uint32_t o_tables;                // start of the tables staged into LDS once per workgroup: tab_bytes of
-    uint32_t tab_bytes;               //   FrontDesc[n_fronts] | level_ptr | FrontChild[] | rows | exports | maps | streams
+    uint32_t tab_bytes;               //   FrontDesc[n_fronts] | level_ptr (the planner's levels: tests/front_ref.py walks them) | FrontChild[] | rows | exports | maps | streams | schedules
     uint32_t t_level_ptr, t_children, t_rows, t_exports, t_maps;  // byte offsets inside the staged tables
     uint32_t t_stream;                // ... of the streams (uint32 words): the fronts' source streams, then the assembly stream
     uint32_t asm_word0, asm_trips;    // the assembly stream: its first word in the streams, its trips of 64 entries
