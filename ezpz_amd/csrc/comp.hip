@@ -27,9 +27,11 @@ int launch_build(const CompPlan& plan, const CompArgs& args, int device, int cus
         raised[device & 15].store(true, std::memory_order_release);
     }
     const uint32_t threads = plan.n_waves * 64;
-    // persistent workgroups: as many as the device holds at once (LDS and the 2048 lanes of a CU), each walks the batch
+    // workgroups: eight times what the device holds at once (LDS and the 2048 lanes of a CU), each walks the batch with the grid's
+    // stride -- the dispatcher hands a free place to the next one, whatever the systems before it took: 2000 x 2000 on the
+    // interpreter at x1 / x2 / x8: 18.7 / 19.2 / 20.2 M solves/s
     const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(lds_limit / std::max<uint32_t>(plan.lds_bytes, 1), 2048 / threads));  // (a CU holds 2048 lanes)
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)cus * per_cu);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(args.batch, (uint64_t)cus * per_cu * 8u);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), plan.lds_bytes, stream, args);
     if (hipGetLastError() != hipSuccess) return EZPZ_ERR_HIP;
     return EZPZ_OK;
