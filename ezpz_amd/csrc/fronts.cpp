@@ -271,6 +271,7 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
         UVec verts, stack;
         constexpr uint32_t leaf = 10;  // (pieces of at most this many variables are not dissected further)
         out.n_components = 0;
+        out.ordering = opt.ordering;
         for (uint32_t s = 0; s < n; ++s) {
             if (seen[s]) continue;
             ++out.n_components;
@@ -1130,7 +1131,7 @@ extern "C" long ezpz_debug_front_plan(const EzpzConstraint* cs, size_t n_cs, siz
     if (info) {
         const uint64_t v[16] = {plan.n_wgs, plan.n_chunks, plan.bad_chunk0, plan.verdict_chunk, plan.lds_bytes, plan.n_fronts,
                                 plan.n_levels, plan.max_rows, plan.max_pivots, plan.threads, (uint64_t)plan.model_cycles,
-                                plan.panel_doubles, plan.update_doubles, 0, 0, 0};
+                                plan.panel_doubles, plan.update_doubles, plan.ordering, plan.n_components, 0};
         std::memcpy(info, v, sizeof(v));
     }
     if (buf && cap) std::memcpy(buf, plan.blob.data(), std::min(cap, plan.blob.size()));

@@ -39,6 +39,7 @@ struct FrontPlan {
     // statistics (EzpzSystemInfo, tools)
     uint32_t n_fronts = 0, n_levels = 0, max_rows = 0, max_pivots = 0;
     uint32_t n_components = 0;  // connected components of the variable graph
+    uint32_t ordering = 0;      // the elimination order the plan was made with (FrontOptions::ordering)
     uint64_t panel_doubles = 0, update_doubles = 0, fill_zeros = 0;
     double model_cycles = 0.0;  // the planner's own estimate of one factorisation + substitution on the critical path
 };

@@ -44,7 +44,7 @@ class Plan:
         L.ezpz_debug_front_plan(recs.ctypes.data, len(recs), n_vars, wgs, max_wgs, lds_bytes, buf.ctypes.data, size, info.ctypes.data)
         self.blob = buf
         (self.n_wgs, self.n_chunks, self.bad_chunk0, self.verdict_chunk, self.lds_bytes, self.n_fronts, self.n_levels, self.max_rows,
-         self.max_pivots, self.threads, self.model_cycles, self.panel_doubles, self.update_doubles) = [int(v) for v in info[:13]]
+         self.max_pivots, self.threads, self.model_cycles, self.panel_doubles, self.update_doubles, self.ordering, self.n_components) = [int(v) for v in info[:15]]
         self.wgs = np.frombuffer(buf, FRONT_WG, self.n_wgs, 0)
 
     def arr(self, dtype, off, count):

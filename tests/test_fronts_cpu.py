@@ -122,3 +122,28 @@ def test_wavefront_schedules_cover_every_front_once_and_cannot_deadlock(npts, wg
                         progressed = True
                         break
             assert all(done), (gi, p, [k for k in range(nf) if not done[k]][:8])
+
+
+def test_minimum_degree_serves_graphs_whose_level_separators_are_too_wide():
+    """The planner orders by nested dissection and, where that makes a front of more than a wavefront's 63 rows, by minimum degree
+    (FrontPlan::ordering 1): among the graph families of the GPU fuzz (tests/gen.py:graph_sketch, the seeds of test_gpu_fuzz.py) some
+    take the second -- their plans' steps equal the dense solve like any other -- and some have no plan at all under either."""
+    used = {0: 0, 1: 0, None: 0}
+    checked = 0
+    for seed in range(48):
+        rng = np.random.default_rng(7000 + seed)
+        family = ["tree", "band", "hub", "comb"][seed % 4]
+        npts = int(rng.integers(20, 500))
+        recs, true = gen.graph_sketch(family, npts, rng)
+        n = len(true)
+        if n < 48 or n > 300:
+            continue  # (the numpy executor is slow: the small ones)
+        p = FR.Plan(recs, n, wgs=0)
+        used[p.ordering if p.ok else None] += 1
+        if p.ok and p.ordering == 1:
+            assert p.max_rows <= 63 and p.n_components == 1
+            d, bad = FR.linear_step(p, true, 1e-3)
+            want = FR.dense_step(recs, n, true, 1e-3)
+            assert not bad and np.max(np.abs(d - want)) <= 1e-9 * max(1.0, np.max(np.abs(want)))
+            checked += 1
+    assert used[0] >= 5 and checked >= 1, used
