@@ -419,3 +419,31 @@ def test_a_batch_launch_recorded_into_a_graph_replays_on_new_guesses(E):
         s.solve_batch_device(xin.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(xo.cpu().numpy(), want[::-1] if flip else want), ("direct", rep)
+
+
+def test_drawn_systems_on_two_streams_of_one_system_object(E):
+    """Launches that draw from one system object's counters must not overlap: on one stream they do not anyway, and when the stream
+    changes the new one waits for an event recorded on the old (launch.hip).  Two streams taking turns, and then both loaded before
+    either is waited for: every result bit for bit the reference run's."""
+    import torch
+
+    ref = T.load(T.gen_big_problem(50))
+    n = ref.num_vars
+    s = E.System(ref.constraints, n)
+    assert s.specialize(wait=True) == 2
+    B = 6001
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(9, B, n, -0.25, 0.25)
+    xin = torch.from_numpy(x0).cuda()
+    want = torch.empty_like(xin)
+    st = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+    s.solve_batch_device(xin.data_ptr(), B, want.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.full_like(xin, float("nan")) for _ in range(6)]
+    sts = [torch.zeros((B, 32), dtype=torch.uint8, device="cuda") for _ in range(6)]
+    for i, out in enumerate(outs):  # six launches, alternating streams, nothing waited for in between
+        s.solve_batch_device(xin.data_ptr(), B, out.data_ptr(), sts[i].data_ptr(), 0, streams[i % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for i, out in enumerate(outs):
+        assert torch.equal(out, want), i
+        assert torch.equal(sts[i], st), i
