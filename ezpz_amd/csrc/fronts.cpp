@@ -356,7 +356,8 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
     //      front is cheaper than the two (front_cost: a front's fixed cost is most of a small front) ----------------------------
     // the widest supernode: 8 columns (measured, one solve of 800 / 2000 / 5000 variables with supernodes of at most 6 / 8 / 16
     // columns: 2.09 / 2.08 / 2.35 ms, 0.52 / 0.52 / 0.62 ms, 3.24 / 3.16 / 4.06 ms: the pivot block's register updates grow with K^2;
-    // the kernel itself takes up to kFrontMaxPivots)
+    // the kernel itself takes up to kFrontMaxPivots; up to 12 or 16 columns where the parent has ONE child -- a chain, no parallelism
+    // to lose -- with the wavefronts' schedules: 500 / 800 / 2000 / 5000 variables 343 -> 359, 1798 -> 1750, 450 -> 462, 2649 -> 2743 us)
     const uint32_t KMAX = 8, SMAX = kFrontMaxRows;
     UVec nkids(n, 0);
     for (uint32_t j = 0; j < n; ++j)
