@@ -78,17 +78,30 @@ def perturbed_starts(x0_row, k=K_PERTURBED, seed=0):
     return np.stack(out[:k])
 
 
+_SPREADS = {}  # (system, start, configuration, k) -> the oracle's runs: the same for every launch shape a test walks through
+
+
 def oracle_spread(recs, x0_row, cfg=None, linsolve=O.LINSOLVE_SPARSE, k=K_PERTURBED, answers=False):
     """(iteration counts, converged flags, largest relative difference of the answers) over the oracle's runs from the
-    start and from its k one-ulp perturbations (answers=True: and the answers themselves)."""
-    starts = np.concatenate([x0_row[None, :], perturbed_starts(x0_row, k)])
-    rc, xo, it, conv, nun = O.solve_batch(recs, starts, cfg, linsolve=linsolve)
-    assert rc == 0
-    with np.errstate(invalid="ignore"):
-        diff = np.abs(xo[1:] - xo[0]) / np.maximum(1.0, np.abs(xo[0]))
-    spread = float(np.nanmax(diff)) if np.any(~np.isnan(diff)) else 0.0
-    out = (set(int(v) for v in it), set(bool(v) for v in conv), spread)
-    return out + (xo,) if answers else out
+    start and from its k one-ulp perturbations (answers=True: and the answers themselves).  Remembered per (system, start,
+    configuration, k): the fuzz asks for the same runs once per launch shape -- seven times, and a 1000-variable system's 97 oracle
+    solves were most of the GPU suite's wall clock."""
+    import hashlib
+
+    key = (hashlib.sha1(np.ascontiguousarray(recs).tobytes()).hexdigest(), hashlib.sha1(np.ascontiguousarray(x0_row).tobytes()).hexdigest(),
+           repr(cfg), int(linsolve), int(k))
+    if key not in _SPREADS:
+        starts = np.concatenate([x0_row[None, :], perturbed_starts(x0_row, k)])
+        rc, xo, it, conv, nun = O.solve_batch(recs, starts, cfg, linsolve=linsolve)
+        assert rc == 0
+        with np.errstate(invalid="ignore"):
+            diff = np.abs(xo[1:] - xo[0]) / np.maximum(1.0, np.abs(xo[0]))
+        spread = float(np.nanmax(diff)) if np.any(~np.isnan(diff)) else 0.0
+        if len(_SPREADS) > 64:
+            _SPREADS.clear()
+        _SPREADS[key] = (set(int(v) for v in it), set(bool(v) for v in conv), spread, xo)
+    out = _SPREADS[key]
+    return out if answers else out[:3]
 
 
 def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, linsolve=O.LINSOLVE_SPARSE, rel=1e-6,
