@@ -26,7 +26,7 @@ when every start coordinate is moved by one ulp.  So the bar for a system is mea
 and every system of a test is checked -- none is excluded.  The K extra oracle runs are only made for the systems that
 miss the plain bar (1e-6, equal iterations), which keeps the tests fast.  Every call appends one line to
 gpurun_out/parity_bar.txt (when that directory exists): what was checked, how many systems needed the measured bar, the
-largest error among them and the widest bar granted -- profiles/r04_parity_bar.txt is that file from the round's GPU run."""
+largest error among them and the widest bar granted -- profiles/r05_parity_bar.txt (r04_... for round 4) is that file from the round's GPU run."""
 import os
 
 import numpy as np
