@@ -110,6 +110,8 @@ int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double*
     args.residual_tolerance = 0.0;
     args.step_tolerance = 0.0;
     args.initial_lambda = 0.0;
+    // (like launch(): what a launch creates on first use -- the occupancy figure, the scratch of several workgroups -- under the lock)
+    std::lock_guard<std::mutex> launch_lock(s.launch_mu);
     g_probe_m = m;
     g_probe_out = y_dev;
     g_probe_in = w_dev;
