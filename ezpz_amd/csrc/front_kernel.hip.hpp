@@ -3,9 +3,10 @@
 // (JtJ + lambda I) d = -Jt r (newton.rs:73-102: faer's sparse matmul, Llt::try_new_with_symbolic, solve) as a MULTIFRONTAL
 // supernodal Cholesky factorisation on dense fronts (front_types.hpp, fronts.cpp):
 //
-//   * a wavefront owns a front: it assembles the front's entries of JtJ and -Jt r from the Jacobian values of the constraints
-//     whose earliest variable is eliminated there (one lane per entry, operand pairs streamed from the plan), adds its children's
-//     update matrices through their row maps (extend-add), factors the K pivot columns in registers (lane = row, pivots and
+//   * once per linear solve all lanes of the workgroup assemble every front's entries of JtJ and -Jt r from the Jacobian values of
+//     the constraints whose earliest variable is eliminated there (one lane per entry, operand pairs streamed from the plan);
+//   * a wavefront owns a front: it adds its children's update matrices, gathered by destination from the front's source stream
+//     (extend-add; children in other workgroups through row maps, as chunks), factors the K pivot columns in registers (lane = row, pivots and
 //     multipliers by v_readlane, the right-hand side as row S so that the forward substitution rides along), and leaves the
 //     Schur complement of the rows below as its own update matrix;
 //   * every wavefront of the workgroup runs its own list of fronts (the planner's schedule: list scheduling on the cost model) and
@@ -15,7 +16,11 @@
 //     workgroups 1 .. G-1, the top to workgroup 0; update matrices and steps cross workgroups as self-validating 16-byte chunks
 //     (grid_ops.hip.hpp), the LM control's sums gather at workgroup 0 and scatter.
 //
-// State per workgroup (LDS): x, d, r, r_next, Jacobian values, the fronts' panels (the factor), a pool of update matrices.
+// The same factorisation answers FreedomAnalysis (find_dof.rs:31-103) for the systems it serves: in PROBE mode (FrontArgs::probe_m)
+// the kernel applies lambda (JtJ + lambda I)^-1 -- the projector onto null(J) as lambda -> 0 -- to vectors instead of running the
+// LM loop (freedom.hip: freedom_by_probes).
+//
+// State per workgroup (LDS): x, d, r, r_next, Jacobian values, the fronts' panels (the factor), every front's update matrix.
 // Results are those of a valid Cholesky factorisation in another elimination order than the list walks': coordinates at the
 // 1e-6 bar of connected sketches, not bitwise.
 #pragma once
