@@ -217,3 +217,25 @@ def test_small_calls_of_a_batch_system_take_the_fronts(E, npts):
         assert np.array_equal(xd.cpu().numpy(), x), B
     x, st, _ = auto.solve_batch(x0[:4], cfg)
     assert_batch_matches_oracle(recs, x0[:4], x, st["iterations"], st["converged"], O.Config(max_iterations=60), what=("auto small call", npts))
+
+
+@pytest.mark.parametrize("drop", [0, 2])
+def test_solve_analysis_call_of_a_connected_sketch(E, drop):
+    """ezpz_solve_analysis (lib.rs:134-146) of a 300-variable connected sketch through the one-call entry: the solve on the fronts,
+    the analysis by null-space probes on the same factorisation -- and with a deferred program (the symbolic phase returned with the
+    frontal plan alone) nothing else of the system is ever analysed.  Outcome and underconstrained ids equal to the oracle's."""
+    import time
+
+    recs, g = gen.connected_sketch(150, 4242)
+    if drop:
+        recs = recs[:-drop]
+    guesses = list(enumerate(g.tolist()))
+    want = O.solve(recs, guesses, O.Config(max_iterations=60), linsolve=O.LINSOLVE_SPARSE, analysis=True)
+    for _ in range(3):  # cold, then warm calls on the request's plan
+        got = E.solve_records(recs, guesses, E.Config(max_iterations=60), analysis=True)
+        assert (got.error, got.iterations, got.converged) == (0, want.iterations, want.converged)
+        assert sorted(got.underconstrained) == sorted(want.underconstrained) and bool(got.underconstrained) == bool(drop)
+        err = np.abs(got.final_values - want.final_values) / np.maximum(1.0, np.abs(want.final_values))
+        free = np.zeros(len(g), bool)
+        free[list(want.underconstrained)] = True
+        assert float(err[~free].max()) <= 1e-6
