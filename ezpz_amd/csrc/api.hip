@@ -244,9 +244,9 @@ long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_var
     return rc;
 }
 
-#ifdef EZPZ_STAMPS
+// Diagnostic: a device buffer for in-kernel time stamps (the -DEZPZ_STAMPS builds of the list-walk and frontal kernels:
+// tools/front_stamps.py; the run-time compiled kernel of a system on several workgroups in every build: tools/ladder_stamps.py).
 void ezpz_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = dev_buf; }
-#endif
 
 
 }  // extern "C"

@@ -420,6 +420,79 @@ void emit_class(std::string& o, size_t k, const Class& cl, bool lane = false, co
         emit_elimination(o, cl, fast != 0, fastdiv);
         o += std::string("        (void)J; (void)r;") + (fast ? " (void)ok;" : "") + "\n        return bad;\n    }\n";
     }
+    // A linear class's matrix J^T J + lambda I is the same for every instance and every system: `factor` is the part of `solve` that
+    // depends on lambda alone (diagonals, their refined reciprocals, the entries of L), `solve_f` the rest (right-hand side, the
+    // two substitutions) on a factorisation the caller keeps -- in scalar registers, once per lambda and launch
+    // (jit_kernel.hip.hpp: solve_kernel_grid_fast).  Every quantity receives exactly `solve`'s operations in `solve`'s order.
+    // F: D<v> at 2 v, Y<v> at 2 v + 1, L<s> at 2 NV + s.
+    o += "    static constexpr int NF = " + S(lin && !lane ? 2 * nv + zlo : 1) + ";\n";
+    if (lin && !lane) {
+        auto div = [&](const std::string& num, uint32_t col) {
+            return fastdiv ? "ezpz::jit::div_by(" + num + ", D" + S(col) + ", Y" + S(col) + ", ok)" : num + " / D" + S(col);
+        };
+        auto jv = [&](uint32_t slot) { return hexf(cl.jconst[slot]); };
+        const PartDesc part = Q.parts.empty() ? PartDesc{0, 0, 0, 0} : Q.parts[0];
+        o += "    static __device__ __forceinline__ bool factor(double lambda, double (&F)[NF], bool& ok) {\n        bool bad = false;\n";
+        for (uint32_t v = 0; v < nv; ++v) {
+            o += "        double D" + S(v) + " = 0.0;\n";
+            for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q) {
+                const std::string j = jv(Q.colj_items[2 * q]);
+                o += "        D" + S(v) + " += " + j + " * " + j + ";\n";
+            }
+            o += "        D" + S(v) + " = D" + S(v) + " + lambda;\n";
+        }
+        for (uint32_t s2 = 0; s2 < zlo; ++s2) {
+            o += "        double L" + S(s2) + " = 0.0;\n";
+            for (uint32_t q = Q.apair_ptr[s2]; q < Q.apair_ptr[s2 + 1]; ++q)
+                o += "        L" + S(s2) + " += " + jv(Q.apairs[2 * q]) + " * " + jv(Q.apairs[2 * q + 1]) + ";\n";
+        }
+        for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+            const uint32_t s0 = Q.lvl_sptr[part.lvl0 + lv], s1 = Q.lvl_sptr[part.lvl0 + lv + 1];
+            for (uint32_t v = c0; v < c1; ++v) {
+                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q) {
+                    const std::string l = "L" + S(Q.fwd_items[2 * q]);
+                    o += "        D" + S(v) + " -= " + l + " * " + l + ";\n";
+                }
+                o += "        if (!(D" + S(v) + " > 0.0)) bad = true;\n";
+                o += "        D" + S(v) + " = sqrt(D" + S(v) + ");";
+                o += fastdiv ? " const double Y" + S(v) + " = ezpz::jit::recip_of(D" + S(v) + ", ok);" : " const double Y" + S(v) + " = 0.0;";
+                o += " F[" + S(2 * v) + "] = D" + S(v) + "; F[" + S(2 * v + 1) + "] = Y" + S(v) + ";\n";
+            }
+            for (uint32_t s2 = s0; s2 < s1; ++s2) {
+                for (uint32_t q = Q.lpair_ptr[s2]; q < Q.lpair_ptr[s2 + 1]; ++q)
+                    o += "        L" + S(s2) + " -= L" + S(Q.lpairs[2 * q]) + " * L" + S(Q.lpairs[2 * q + 1]) + ";\n";
+                o += "        L" + S(s2) + " = " + div("L" + S(s2), Q.l_col[s2]) + "; F[" + S(2 * nv + s2) + "] = L" + S(s2) + ";\n";
+            }
+        }
+        o += "        (void)ok;\n        return bad;\n    }\n";
+        o += "    static __device__ __forceinline__ void solve_f(const double (&F)[NF], const double (&r)[" + S(std::max(m, 1u)) + "], double (&d)[" + S(nv) +
+             "], double& dmax, bool& ok) {\n";
+        for (uint32_t v = 0; v < nv; ++v) o += "        const double D" + S(v) + " = F[" + S(2 * v) + "], Y" + S(v) + " = F[" + S(2 * v + 1) + "]; (void)Y" + S(v) + ";\n";
+        for (uint32_t s2 = 0; s2 < zlo; ++s2) o += "        const double L" + S(s2) + " = F[" + S(2 * nv + s2) + "];\n";
+        for (uint32_t v = 0; v < nv; ++v) {
+            o += "        double V" + S(v) + " = 0.0;\n";
+            for (uint32_t q = Q.colj_ptr[v]; q < Q.colj_ptr[v + 1]; ++q)
+                o += "        V" + S(v) + " += " + jv(Q.colj_items[2 * q]) + " * -r[" + S(Q.colj_items[2 * q + 1]) + "];\n";
+        }
+        for (uint32_t lv = 0; lv < part.nlev; ++lv) {
+            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+            for (uint32_t v = c0; v < c1; ++v) {
+                for (uint32_t q = Q.fwd_ptr[v]; q < Q.fwd_ptr[v + 1]; ++q)
+                    o += "        V" + S(v) + " -= L" + S(Q.fwd_items[2 * q]) + " * V" + S(Q.fwd_items[2 * q + 1]) + ";\n";
+                o += "        V" + S(v) + " = " + div("V" + S(v), v) + ";\n";
+            }
+        }
+        for (uint32_t lv = part.nlev; lv-- > 0;) {
+            const uint32_t c0 = Q.lvl_cptr[part.lvl0 + lv], c1 = Q.lvl_cptr[part.lvl0 + lv + 1];
+            for (uint32_t v = c0; v < c1; ++v) {
+                for (uint32_t q = Q.bwd_ptr[v]; q < Q.bwd_ptr[v + 1]; ++q)
+                    o += "        V" + S(v) + " -= L" + S(Q.bwd_items[2 * q]) + " * V" + S(Q.bwd_items[2 * q + 1]) + ";\n";
+                o += "        V" + S(v) + " = " + div("V" + S(v), v) + "; d[" + S(v) + "] = V" + S(v) + "; dmax = ezpz::dev::fmax_abs(dmax, V" + S(v) + ");\n";
+            }
+        }
+        o += "        (void)r; (void)ok;\n    }\n";
+    }
     // unsatisfied check (lib.rs:305-327, :358-370)
     o += "    static __device__ __forceinline__ void unsatisfied(" + xs + ", bool active, double& unsat, uint8_t* mask, const uint32_t* pos) {\n";
     for (uint32_t ci = 0; ci < nc; ++ci) {
@@ -824,8 +897,27 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             for (int one = 0; one < 2; ++one) {
                 o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve" + (one ? "_one" : "") + "(const ezpz::jit::JitArgs a) {\n";
                 o += "    __shared__ double smem[ezpz::jit::kRedDoubles + 16];\n";
-                o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
-                     (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse && G == 1 ? "true" : "false") + ", " + (G > 1 ? "true" : "false") + ">(a, smem);\n}\n";
+                if (G > 1)  // a system on several workgroups: the kernel with the reductions' grid stage (jit_kernel.hip.hpp: solve_kernel_grid)
+                    o += "    ezpz::jit::solve_kernel_grid<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
+                         (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ">(a, smem);\n}\n";
+                else
+                    o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
+                         (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse ? "true" : "false") + ", false>(a, smem);\n}\n";
+            }
+            // a LINEAR system with unit weights on several workgroups: the kernel that does not wait for the verdicts of the LM control
+            // (jit_kernel.hip.hpp: solve_kernel_grid_fast; the entry above then solves what it could not finish).  A third of the
+            // loop's registers: compiled for four wavefronts per SIMD while its state fits
+            if (G > 1 && !any_nonlinear && plan.unit_weights) {
+                uint64_t fast_vg = 0;  // x, the next system's x, d, r (doubles), parameters, ids
+                for (size_t k = 0; k < classes.size(); ++k) {
+                    const ClassLayout& H = classes[k].H;
+                    fast_vg += (2ull * (3 * H.nv + H.m + H.ncons) + H.nv) * slots_k[k];
+                }
+                static const char* env_fw = std::getenv("EZPZ_JIT_FAST_MINWAVES");  // occupancy hint, for measurements
+                const int fast_waves = env_fw ? std::atoi(env_fw) : (fast_vg + 40 <= 128 ? 4 : fast_vg + 40 <= 168 ? 3 : 2);
+                o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ", " + std::to_string(fast_waves) +
+                     ") ezpz_jit_solve_fast(const ezpz::jit::JitArgs a) {\n";
+                o += "    ezpz::jit::solve_kernel_grid_fast<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ">(a);\n}\n";
             }
             align4(blob);
             plan.o_jit_slots = (uint32_t)blob.size();

@@ -98,7 +98,7 @@ struct CompPlan {
     bool interpretable = true;   // the state fits one CU's LDS: comp_solve_kernel can run the plan (else specialised only)
 };
 
-constexpr size_t kJitGridScratchBytes = 65600;  // sizeof(ezpz::jit::GridScratch), one per system in flight
+constexpr size_t kJitGridScratchBytes = 197184;  // sizeof(ezpz::jit::GridScratch), one per system in flight
 
 struct CompLimits {
     size_t lds_bytes = 160 * 1024;
@@ -181,10 +181,17 @@ void comp_jit_destroy(CompJit* jit);
 int comp_jit_request(CompJit* jit, bool wait);
 int comp_jit_state(const CompJit* jit);
 const char* comp_jit_log(const CompJit* jit);
+// (a system on several workgroups: `grid_slots` systems in flight on `grid_scratch`; fast_slots / redo: the same for the kernel
+// that does not wait for its verdicts, and the device list -- 1 + batch words, count zero -- of the systems it leaves to the loop;
+// redo_next: the list of the system's next call, whose count this call zeroes; redo_seen_dev / _host: a word of mapped host memory
+// the loop's launch leaves its count in, the hint for the width of the next one.  0 / null: the loop alone)
 int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob, const CompLaunch& launch, int device, int cus, void* stream,
-                    void* grid_scratch = nullptr, uint32_t grid_slots = 0);
+                    void* grid_scratch = nullptr, uint32_t grid_slots = 0, uint32_t fast_slots = 0, unsigned int* redo = nullptr,
+                    unsigned int* redo_next = nullptr, unsigned int* redo_seen_dev = nullptr, const unsigned int* redo_seen_host = nullptr);
 // workgroups of the specialised kernel the device holds at once (loads the code object on first use); 0 on failure
 uint64_t comp_jit_capacity(CompJit* jit, const CompPlan& plan, int device, int cus);
+// ... of its `_fast` entry (0: the kernel has none)
+uint64_t comp_jit_capacity_fast(CompJit* jit, const CompPlan& plan, int device, int cus);
 // (through the on-disk cache of code objects; _uncached always compiles; comp_jit_cached: is it in the cache?)
 int comp_jit_compile(const std::string& source, std::vector<char>& code, std::string& log);
 int comp_jit_compile_uncached(const std::string& source, std::vector<char>& code, std::string& log);

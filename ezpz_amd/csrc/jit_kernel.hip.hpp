@@ -51,9 +51,20 @@ struct JitArgs {
     // 83.7 M solves/s.  (32 bits, modular: a launch draws fewer than 2^32 values.)
     unsigned int* ticket;
     unsigned int ticket_base[8];
+    // diagnostic (tools/ladder_stamps.py; null otherwise): solve_kernel_grid leaves wall-clock stamps of thread 0 of every
+    // workgroup here, 16 per (system, workgroup)
+    unsigned long long* stamps;
+    // a system on several workgroups: the systems solve_kernel_grid_fast could not finish -- redo[0] of them, redo[1], ... -- which it
+    // appends to and the launch of solve_kernel_grid behind it solves (null: that kernel solves the whole batch)
+    unsigned int* redo;
+    // ... and the list of the system's NEXT call (the host alternates between two), whose count the launch of solve_kernel_grid
+    // zeroes: it was read for the last time by the call before this one (a memset per call was a 5 us kernel of its own).
+    // redo_seen: a word of mapped host memory that launch leaves its count in -- the host's hint for how wide to launch it next time
+    unsigned int* redo_next;
+    unsigned int* redo_seen;
 };
 constexpr unsigned int kTicketStride = 1024;  // words between two counters (4 KB: another channel)
-static_assert(sizeof(JitArgs) == 216, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
+static_assert(sizeof(JitArgs) == 248, "JitArgs is restated on the host (jit.cpp: JitArgsHost)");
 
 // One system on several workgroups ("grid team", as in lm_kernel.hip.hpp): every workgroup owns its wavefronts' slots;
 // the reductions of the LM control cross workgroups through this per-system scratch.  Every workgroup publishes its
@@ -70,8 +81,11 @@ struct GridScratch {
     int pad[13];
     gridchunk_t arr[2][4][kGridMaxWgs];  // [parity of the sequence number][value][workgroup]: partials
     gridchunk_t out[2][kGridMaxWgs][4];  // [parity][workgroup]: the four results in one 64-byte line
+    // systems whose verdicts are not waited for (solve_kernel_grid): a ring of four systems in flight per slot
+    gridchunk_t ring_p[4][kGridMaxWgs][8];  // [sequence number & 3][workgroup][value]: a workgroup's eight partials, one 128-byte line
+    gridchunk_t ring_v[4][8];               // [sequence number & 3][0]: workgroup 0's verdict on that system (a line each)
 };
-static_assert(sizeof(GridScratch) == 65600, "GridScratch is sized on the host (comp_program.hpp: kJitGridScratchBytes)");
+static_assert(sizeof(GridScratch) == 197184, "GridScratch is sized on the host (comp_program.hpp: kJitGridScratchBytes)");
 
 __device__ __forceinline__ void grid_store(gridchunk_t* p, double v, unsigned int seq) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -111,6 +125,9 @@ __device__ __forceinline__ double grid_wait(const gridchunk_t* p, unsigned int s
 template <class C>
 struct Slot {
     double x[C::NV], d[C::NV];
+    double xn[C::NV];                     // (solve_kernel_grid_fast: the NEXT system's guesses, on their way while this one is solved)
+    double F[2][C::NF];                   // (solve_kernel_grid_fast: a linear class's factorisation at the two lambdas, wave-uniform)
+    bool fbad[2], fok[2];
     double r[C::M > 0 ? C::M : 1], rn[C::M > 0 ? C::M : 1];
     double J[C::ZJS > 0 ? C::ZJS : 1];    // Jacobian values (classes with a non-linear member; constant otherwise)
     double par[C::NC > 0 ? C::NC : 1];    // constraint parameters of this lane's instance
@@ -137,11 +154,26 @@ struct Slots<> {
     template <class F>
     __device__ __forceinline__ void each(F&&, int = 0) {}
 };
+template <class A, class B>
+struct same_class {
+    static constexpr bool value = false;
+};
+template <class A>
+struct same_class<A, A> {
+    static constexpr bool value = true;
+};
 template <class C, class... Rest>
 struct Slots<C, Rest...> {
     static constexpr int N = 1 + sizeof...(Rest);
     Slot<C> head;
     Slots<Rest...> tail;
+    template <class X>
+    __device__ __forceinline__ Slot<X>& first() {  // the first slot of class X (what a class's slots share lives there)
+        if constexpr (same_class<X, C>::value)
+            return head;
+        else
+            return tail.template first<X>();
+    }
     template <class F>
     __device__ __forceinline__ void each(F&& f, int index = 0) {
         f(head, static_cast<C*>(nullptr), index);
@@ -776,6 +808,588 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
     }
     if constexpr (RESIDENT) publish_done(done);
     } while (RESIDENT && resident_next(done, born, reinterpret_cast<unsigned long long*>(smem + kRedDoubles + 8)));
+}
+
+// The same kernel for a system spread over SEVERAL workgroups (the generator names it when CompPlan::jit_wgs > 1: the 200 000-variable
+// ladder on ~100 workgroups of 4 wavefronts): solve_kernel's loop with the reductions' grid stage.  A function of its own so that
+// nothing done here moves an instruction of the one-workgroup kernel above (at 168 of 168 registers that one notices code it never
+// runs).  Every verdict of the LM control (eval(), each step) is a trip to workgroup 0 and back, ~3.5 us each
+// (two hops through memory), during which nobody has anything to do: the ladder spent 11 of its 18 us per solve there
+// (profiles/r06_ladder_stamps_before.txt) -- which is why linear systems go through solve_kernel_grid_fast first and come here only
+// when that kernel says so: JitArgs::redo != null, the launch solves the systems LISTED there (redo[0] of them: redo[1], ...).
+template <class SEQ, int NWAVES, bool ANY_NONLINEAR, bool UNIT_W, bool RESIDENT = false>
+__device__ __forceinline__ void solve_kernel_grid(const JitArgs& a, double* smem) {
+    using namespace ezpz::dev;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    Red red;
+    red.buf = smem;
+    red.flags = reinterpret_cast<int*>(smem + kRedDoubles);
+    red.flip = 0;
+    red.turn = 0;
+    int* nwarn2 = red.flags + 4;
+    if (tid < 8) red.flags[tid] = 0;
+    if (NWAVES > 1) __syncthreads();
+    // workgroup g of the G that share a system, slot = which system in flight
+    const uint32_t grid_wgs = a.grid ? a.grid_wgs : 1u;
+    const uint32_t grid_wg = blockIdx.x % grid_wgs, grid_slot = blockIdx.x / grid_wgs, n_slots = gridDim.x / grid_wgs;
+    const uint64_t n_systems = a.redo ? (uint64_t)a.redo[0] : a.batch;
+    if (a.redo && blockIdx.x == 0 && tid == 0) {
+        a.redo_next[0] = 0;
+        if (a.redo_seen) *a.redo_seen = (unsigned int)n_systems;
+    }
+    if (a.redo && n_systems == 0 && !RESIDENT) return;  // (the usual case of a launch behind solve_kernel_grid_fast: nothing to do)
+    red.grid = a.grid ? a.grid + grid_slot : nullptr;
+    red.grid_wgs = grid_wgs;
+    red.grid_wg = grid_wg;
+    red.grid_seq = 0;
+    if (red.grid) {  // continue the slot's sequence numbers where the previous launch left them (this workgroup's own)
+        const gridchunk_t c0 = grid_peek(&red.grid->arr[0][0][grid_wg]), c1 = grid_peek(&red.grid->arr[1][0][grid_wg]);
+        red.grid_seq = c0.z > c1.z ? c0.z : c1.z;
+    }
+    const uint32_t wave_global = grid_wg * NWAVES + wave;
+    constexpr int W = NWAVES <= 2 ? 2 : NWAVES <= 4 ? 4 : NWAVES <= 8 ? 8 : 16;
+
+    // ---- this wavefront's slots: what never changes from system to system lives in registers for the whole launch ----
+    SEQ seq;
+    seq.each([&](auto& s, auto* cls, int index) {
+        using C = typename class_of<decltype(cls)>::type;
+        const uint32_t* t = a.blob + a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index);
+        const uint32_t ids_off = t[0], par_off = t[1], pos_off = t[2], count = t[3];
+        s.active = (uint32_t)lane < count;
+#pragma unroll
+        for (int k = 0; k < C::NV; ++k) s.ids[k] = a.blob[ids_off + (size_t)k * C::STRIDE + lane];
+        const double* par = reinterpret_cast<const double*>(a.blob + par_off) + lane;
+#pragma unroll
+        for (int k = 0; k < C::NC; ++k) s.par[k] = par[(size_t)k * C::STRIDE];
+        s.pos = a.blob + pos_off + lane;
+        s.wmask = 0;
+    });
+
+    uint32_t parity = 0;
+    DoneWord done = a.done;
+    for (uint64_t item = grid_slot; item < n_systems; item += n_slots, parity ^= 1u) {
+        const uint64_t sys = a.redo ? (uint64_t)a.redo[1 + item] : item;
+        const double* x0 = a.x0 + sys * a.n_row;
+        // (several workgroups: the counter is the scratch's, zeroed by workgroup 0 two systems ago)
+        int* nwarn = red.grid ? &red.grid->nwarn[parity] : nwarn2 + parity;
+        auto log_warning = [&](uint32_t pass, uint32_t pos) {  // Warning::Degenerate, every evaluation (solver.rs:340-346)
+            const int idx = atomicAdd(nwarn, 1);
+            if (a.warn_log && (uint32_t)idx < a.warn_cap) a.warn_log[sys * a.warn_cap + idx] = ((uint64_t)pass << 32) | pos;
+        };
+        auto log_mask = [&](auto& s, auto* cls, unsigned long long m, uint32_t pass) {
+            using C = typename class_of<decltype(cls)>::type;
+            if (!s.active) m = 0;
+            while (m) {
+                const int ci = __builtin_ctzll(m);
+                m &= m - 1;
+                log_warning(pass, s.pos[(size_t)ci * C::STRIDE]);
+            }
+        };
+
+        // ---- load the initial values; eval() (newton.rs:45, :232-236) ------------------------------------------------------------
+        double sq = 0.0, mx = __builtin_nan("");
+        seq.each([&](auto& s, auto* cls, int index) {
+            using C = typename class_of<decltype(cls)>::type;
+#pragma unroll
+            for (int k = 0; k < C::NV; ++k) s.x[k] = x0[s.ids[k]];
+            unsigned long long wm = 0;
+            double sq_s = sq, mx_s = mx;
+            C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
+            if (s.active) {
+                sq = sq_s;
+                mx = mx_s;
+            }
+            if constexpr (!C::LINEAR) {
+                log_mask(s, cls, wm, 0);
+                wm = 0;
+                C::jacobian(s.x, s.par, s.J, wm);
+                log_mask(s, cls, wm, 1);
+            }
+        });
+        red.template sum_max<W>(sq, mx, lane, wave, NWAVES);
+        double residual_sq = sq, largest = mx;
+        uint32_t pass = 2;
+        double lambda = a.initial_lambda;
+        uint32_t it = 0, iterations = a.max_iterations, converged = 0;
+        bool r_is_at_x = true;
+
+        // ---- the LM loop (newton.rs:47-139) ------------------------------------------------------------------------------------------
+        for (;;) {
+            if (it >= a.max_iterations) break;            // newton.rs:141-144
+            if (largest <= a.residual_tolerance) {  // newton.rs:50-60
+                iterations = it;
+                converged = 1;
+                break;
+            }
+            bool lane_bad = false;
+            double dmax = __builtin_nan("");
+            sq = 0.0;
+            mx = __builtin_nan("");
+            // Pass 1 -- normal equations, Cholesky, substitutions of every lane's components (newton.rs:73-102), on every lane,
+            // active or not, in one basic block: what depends on lambda alone (all of the factorisation of a linear
+            // class) is formed once for all the slots of the wavefront, and the slots' dependent chains interleave.
+            bool need_exact = false;
+            seq.each([&](auto& s, auto* cls, int) {
+                using C = typename class_of<decltype(cls)>::type;
+                double cd = __builtin_nan("");
+                bool ok = true;
+                const bool cb = C::solve(s.J, s.r, lambda, s.d, cd, ok);
+                s.exact = s.active && !ok && !cb;  // an operand outside the short division's range
+                const bool take = s.active && !s.exact;  // (selects, not a branch: the slots stay one basic block)
+                const double dm = fmax_nc(dmax, cd);
+                dmax = take ? dm : dmax;
+                lane_bad = lane_bad || (take && cb);
+                need_exact = need_exact || s.exact;
+            });
+            if (need_exact) {  // (almost never: the same solves with plain divisions for the lanes that asked)
+                seq.each([&](auto& s, auto* cls, int) {
+                    using C = typename class_of<decltype(cls)>::type;
+                    if (s.exact) {
+                        double cd = __builtin_nan("");
+                        double J2[C::ZJS > 0 ? C::ZJS : 1], r2[C::M > 0 ? C::M : 1];
+                        opaque_copy(s.J, J2);
+                        opaque_copy(s.r, r2);
+                        const bool cb = C::solve_exact(J2, r2, lambda, s.d, cd);
+                        lane_bad = lane_bad || cb;
+                        dmax = fmax_nc(dmax, cd);
+                    }
+                });
+            }
+            // Pass 2 -- residual at the tentative values (newton.rs:111-116), speculative: x moves only after the rendezvous.
+            // The sums continue the lane's running values and are taken over by one select per slot.
+            seq.each([&](auto& s, auto* cls, int) {
+                using C = typename class_of<decltype(cls)>::type;
+                double xt[C::NV];
+#pragma unroll
+                for (int k = 0; k < C::NV; ++k) xt[k] = s.x[k] + s.d[k];
+                s.wmask = 0;
+                double sq_s = sq, mx_s = mx;
+                C::residuals(xt, s.par, s.rn, true, sq_s, mx_s, s.wmask);
+                if (s.active) {
+                    sq = sq_s;
+                    mx = mx_s;
+                }
+            });
+            const bool bad = red.template step<W>(sq, mx, dmax, lane_bad, lane, wave, NWAVES);
+            if (bad) {  // numeric failure anywhere in the system => lambda *= 10, burn the iteration, x untouched
+                lambda *= LM_LAMBDA_INCR;
+                ++it;
+                continue;
+            }
+            const double step_inf_norm = (a.n_row > 0) ? dmax : 0.0;
+            const bool accept = sq < residual_sq;  // strict, newton.rs:118
+            const uint32_t pass_res = pass++;
+            const uint32_t pass_jac = pass;
+            if (accept) ++pass;
+            seq.each([&](auto& s, auto* cls, int) {
+                using C = typename class_of<decltype(cls)>::type;
+                if constexpr (!C::LINEAR) log_mask(s, cls, s.wmask, pass_res);
+                if (accept) {
+#pragma unroll
+                    for (int k = 0; k < C::NV; ++k) s.x[k] = s.x[k] + s.d[k];
+#pragma unroll
+                    for (int k = 0; k < C::M; ++k) s.r[k] = s.rn[k];
+                    if constexpr (!C::LINEAR) {
+                        unsigned long long wm = 0;
+                        C::jacobian(s.x, s.par, s.J, wm);
+                        log_mask(s, cls, wm, pass_jac);
+                    }
+                } else {  // reject: x += d, x -= d like the reference (newton.rs:111-114,:124-131), not a copy
+#pragma unroll
+                    for (int k = 0; k < C::NV; ++k) s.x[k] = (s.x[k] + s.d[k]) - s.d[k];
+                }
+            });
+            if (accept) {
+                lambda *= LM_LAMBDA_DECR;
+                residual_sq = sq;
+                largest = mx;
+                r_is_at_x = true;
+            } else {
+                r_is_at_x = false;  // x is now (x + d) - d, which may differ from the x of r in the last bit
+                lambda *= LM_LAMBDA_INCR;
+            }
+            if (step_inf_norm <= a.step_tolerance) {  // newton.rs:134-139
+                iterations = it;
+                converged = 1;
+                break;
+            }
+            ++it;
+        }
+
+        // ---- unsatisfied check (lib.rs:305-327, :358-370) and write-back -----------------------------------------------------------------
+        const bool use_r = r_is_at_x && UNIT_W;
+        const bool all_satisfied = use_r && largest < EPS && !isnan(residual_sq);
+        double unsat_cnt = 0.0;
+        double* xo = a.x_out + sys * a.n_row;
+        uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
+        seq.each([&](auto& s, auto* cls, int) {
+            using C = typename class_of<decltype(cls)>::type;
+            if (all_satisfied) {
+                if (mask && s.active)
+#pragma unroll
+                    for (int ci = 0; ci < C::NC; ++ci) mask[s.pos[(size_t)ci * C::STRIDE]] = 0;
+            } else if (use_r) {
+                C::unsatisfied_from_r(s.r, s.active, unsat_cnt, mask, s.pos);
+            } else {
+                C::unsatisfied(s.x, s.par, s.active, unsat_cnt, mask, s.pos);
+            }
+            if (s.active) {
+#pragma unroll
+                for (int k = 0; k < C::NV; ++k) xo[s.ids[k]] = s.x[k];
+            }
+        });
+        if (!all_satisfied || ANY_NONLINEAR) {
+            double none = __builtin_nan("");
+            red.template sum_max<W>(unsat_cnt, none, lane, wave, NWAVES);
+        }
+        if (tid == 0 && grid_wg == 0) {
+            EzpzStatus st;
+            st.iterations = iterations;
+            st.converged = converged;
+            st.n_unsatisfied = (uint32_t)unsat_cnt;
+            st.n_warnings = ANY_NONLINEAR ? (uint32_t)__hip_atomic_load(nwarn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            st.final_residual_inf = (a.n_rows_total > 0) ? largest : 0.0;
+            st.final_lambda = lambda;
+            if (red.grid && __hip_atomic_load(&red.grid->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                st.iterations = EZPZ_ITERATIONS_TEAM_TIMEOUT;
+                st.converged = 0;
+            }
+            a.status[sys] = st;
+            // serves the system after next of this workgroup / slot (every wavefront passes a rendezvous of the next
+            // system, which this thread joins only after the store, before it can touch the counter again)
+            if (ANY_NONLINEAR) __hip_atomic_store(nwarn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (RESIDENT) publish_done(done);  // (several workgroups per system: a completion word, never resident)
+}
+
+// A value at a uniform base + a lane's 32-bit byte offset, as a buffer access: four scalar registers for the row's descriptor and ONE
+// vector register per value for the offset.  (`base[index]` with a 64-bit index becomes a 64-bit address per value and use in vector
+// registers -- recurrences over the systems of the launch: 48 registers for the ladder's loads, prefetches and stores.)
+typedef int bufword2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_at(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);  // raw, no swizzle, 4 GB
+}
+__device__ __forceinline__ double load_at(__amdgpu_buffer_rsrc_t row, uint32_t byte_offset) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(row, (int)byte_offset, 0, 0));
+}
+__device__ __forceinline__ void store_at(__amdgpu_buffer_rsrc_t row, uint32_t byte_offset, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufword2_t, v), row, (int)byte_offset, 0, 0);
+}
+
+// VERDICTS NOT WAITED FOR -- a LINEAR system with unit weights on several workgroups (the ladder).  What the verdicts of such a system
+// decide is almost always the same -- not converged at the start, pivots fine, step accepted, not converged, step accepted,
+// converged: 2 iterations (README.md:36-38) -- and a step needs nothing of the SYSTEM but lambda, which those verdicts fix
+// (newton.rs:118-123: x 0.1 per accepted step).  So every workgroup takes both steps on its own share, STORES the values that
+// result, publishes its eight partial sums / maxima (eval(), and per step: sum of squares, largest residual, step norm, failed
+// pivot) as one 128-byte line of self-validating chunks, and goes on to the next system with empty hands.  One system later (the
+// lines are all there by then: no wait) ONE workgroup -- they take turns: sequence number mod G -- gathers the lines, makes the
+// reference's decisions in the reference's order on the system's totals (newton.rs:50-60, :93-99, :118-139, lib.rs:305-327) and,
+// if they are the expected ones, writes the status: iterations 2, converged, nothing unsatisfied.  Any other outcome (converged
+// earlier, a failed pivot, a rejected step, the step tolerance met, not converged after two, a residual at or above EPSILON) puts
+// the system on the launch's REDO LIST (JitArgs::redo), which the launch of solve_kernel_grid that follows on the stream solves
+// from the caller's guesses with every verdict waited for -- so x0 must not be the buffer the values were stored to (the host
+// runs that kernel alone when they overlap), and the arithmetic of the expected path is that kernel's operation for operation:
+// the same bits (tests/test_gpu_components.py: every exit, mixed in one launch).
+// Nothing waits in the steady state: a system costs a workgroup its loads (asked for a system ahead), ~600 vector instructions per
+// wavefront, one barrier, its stores, and every G-th time a turn at the totals.  A kernel of its own because it needs a third of
+// the registers of the loop (no r_next, no step kept across a rendezvous, nothing of the general evaluators): more systems in
+// flight.  The only wait left is flow control: a workgroup may be four systems ahead of the totals (the ring's depth).
+template <class SEQ, int NWAVES>
+__device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
+    using namespace ezpz::dev;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    const uint32_t grid_wgs = a.grid_wgs;
+    const uint32_t grid_wg = blockIdx.x % grid_wgs, grid_slot = blockIdx.x / grid_wgs, n_slots = gridDim.x / grid_wgs;
+    GridScratch* const gs = a.grid + grid_slot;
+    // sequence number of the last system this workgroup published (continues from launch to launch): the largest in its four ring
+    // places, looked at by four lanes at once (asked for here, read after the setup below)
+    gridchunk_t ring_c;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(ring_c) : "v"(&gs->ring_p[lane & 3][grid_wg][0]) : "memory");
+    const uint32_t wave_global = grid_wg * NWAVES + wave;
+    SEQ seq;
+    seq.each([&](auto& s, auto* cls, int index) {
+        using C = typename class_of<decltype(cls)>::type;
+        const uint32_t* t = a.blob + a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index);
+        const uint32_t ids_off = t[0], par_off = t[1], count = t[3];
+        s.active = (uint32_t)lane < count;
+#pragma unroll
+        for (int k = 0; k < C::NV; ++k) s.ids[k] = a.blob[ids_off + (size_t)k * C::STRIDE + lane] * 8u;  // BYTE offsets (n_row < 2^29: the host)
+        const double* par = reinterpret_cast<const double*>(a.blob + par_off) + lane;
+#pragma unroll
+        for (int k = 0; k < C::NC; ++k) s.par[k] = par[(size_t)k * C::STRIDE];
+    });
+    // Slot::xn: the guesses of the system at hand -- asked for a whole system ahead of their use (below), the first ones here
+    if (grid_slot < a.batch) {
+        const __amdgpu_buffer_rsrc_t x0 = row_at(a.x0 + (uint64_t)grid_slot * a.n_row);
+        seq.each([&](auto& s, auto* cls, int) {
+            using C = typename class_of<decltype(cls)>::type;
+#pragma unroll
+            for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0, s.ids[i]);
+        });
+    }
+    const double lambda1 = a.initial_lambda * LM_LAMBDA_DECR, lambda2 = lambda1 * LM_LAMBDA_DECR;
+    // J^T J + lambda I of a linear class is the same matrix for every instance of every system: factorised here, once per lambda
+    // (newton.rs:73-99 -- the operations of C::solve that do not involve the right-hand side, in its order), kept in scalar
+    // registers
+    seq.each([&](auto& s, auto* cls, int) {
+        using C = typename class_of<decltype(cls)>::type;
+        if (&s != &seq.template first<C>()) return;  // (once per class: its other slots read the first one's)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            double F[C::NF];
+            bool ok = true;
+            const bool bad = C::factor(st == 0 ? a.initial_lambda : lambda1, F, ok);
+#pragma unroll
+            for (int i = 0; i < C::NF; ++i) s.F[st][i] = uniform(F[i]);
+            s.fbad[st] = __builtin_amdgcn_readfirstlane((int)bad) != 0;
+            s.fok[st] = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+        }
+    });
+    constexpr int GROUPS = NWAVES * 8;       // a turn at the totals: thread = (value tid & 7, group tid >> 3)
+    __shared__ double fast_part[2][8 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
+    __shared__ int fast_pflag[2][16];
+    __shared__ double fast_gath[NWAVES * 64];  // the gather's first fold
+    __shared__ int fast_gflag[NWAVES * 64];
+    auto put = [&](gridchunk_t* p, double x, unsigned int w, unsigned int q) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+        gridchunk_t c;
+        c.x = (unsigned int)u, c.y = (unsigned int)(u >> 32), c.z = q, c.w = w;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(c) : "memory");
+    };
+    auto val = [](const gridchunk_t& c) { return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x); };
+    unsigned int ring_q;
+    {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring_c)::"memory");
+        const unsigned int z0 = __builtin_amdgcn_readlane(ring_c.z, 0), z1 = __builtin_amdgcn_readlane(ring_c.z, 1);
+        const unsigned int z2 = __builtin_amdgcn_readlane(ring_c.z, 2), z3 = __builtin_amdgcn_readlane(ring_c.z, 3);
+        const unsigned int m0 = z0 > z1 ? z0 : z1, m1 = z2 > z3 ? z2 : z3;
+        ring_q = m0 > m1 ? m0 : m1;
+    }
+    bool f1 = false, f2 = false;  // systems k - 1 / k - 2 of this slot were published: k - 1's totals may be this workgroup's turn
+    uint64_t sys1 = 0;
+    unsigned int q1 = 0, q2 = 0;
+    for (uint64_t k = 0;; ++k) {
+        const uint64_t sys = grid_slot + k * (uint64_t)n_slots;
+        const bool have = sys < a.batch;
+        // (past its last system a workgroup stays for its turn at the totals of that one, if it is its turn, and for nothing else)
+        if (!have && !(f1 && q1 % grid_wgs == grid_wg)) break;
+        const unsigned int kp = (unsigned int)k & 1u;
+        unsigned int q0 = 0;
+        unsigned long long* const stamps = a.stamps && tid == 0 && have ? a.stamps + (sys * grid_wgs + grid_wg) * 16 : nullptr;
+        int stamp_n = 0;
+        auto stamp = [&]() {
+            if (stamps && stamp_n < 16) stamps[stamp_n++] = (unsigned long long)wall_clock64();
+        };
+        stamp();  // 0: start
+        if (have) {
+            const uint64_t sys_n = sys + n_slots;
+            const bool next = sys_n < a.batch;
+            const __amdgpu_buffer_rsrc_t xo = row_at(a.x_out + sys * a.n_row);
+            const __amdgpu_buffer_rsrc_t x0n = row_at(a.x0 + (next ? sys_n : sys) * a.n_row);
+            uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
+            const __amdgpu_buffer_rsrc_t table = row_at(a.blob);
+            // this lane's share of: sum r0^2, sum r1^2, sum r2^2 | max|r0|, max|r1|, |d1|, max|r2|, |d2| -- accumulated over its slots
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = i < 3 ? 0.0 : __builtin_nan("");
+            bool lane_bad1 = false, lane_bad2 = false, lane_redo = false;
+            // SLOT BY SLOT, each from the guesses to the stored values (the phases in step: eval() (newton.rs:45, :232-236), then
+            // two iterations taken for accepted -- the loop's two passes (newton.rs:73-116), x += d, r = r_next): one slot's x, d and
+            // r are live at a time, and the place of a slot's guesses is free for the NEXT system's, asked for a whole system ahead
+            // of their use, as soon as it has read them.  The sums run over the slots in the loop's order: the same bits.
+            seq.each([&](auto& s, auto* cls, int index) {
+                using C = typename class_of<decltype(cls)>::type;
+                auto& f = seq.template first<C>();
+#pragma unroll
+                for (int i = 0; i < C::NV; ++i) s.x[i] = s.xn[i];
+                if (next) {
+#pragma unroll
+                    for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0n, s.ids[i]);
+                }
+                unsigned long long wm = 0;
+                {
+                    double sq_s = v[0], mx_s = v[3];
+                    C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
+                    v[0] = s.active ? sq_s : v[0];
+                    v[3] = s.active ? mx_s : v[3];
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    double cd = __builtin_nan("");
+                    bool ok = f.fok[st];
+                    C::solve_f(f.F[st], s.r, s.d, cd, ok);
+                    const bool cb = f.fbad[st];
+                    // (an operand outside the short division's range -- almost never: the system goes on the redo list, where
+                    // C::solve_exact divides plainly)
+                    lane_redo = lane_redo || (s.active && !ok && !cb);
+                    double& dmax = v[st == 0 ? 5 : 7];
+                    const double dm = fmax_nc(dmax, cd);
+                    dmax = s.active ? dm : dmax;
+                    if (st == 0)
+                        lane_bad1 = lane_bad1 || (s.active && cb);
+                    else
+                        lane_bad2 = lane_bad2 || (s.active && cb);
+#pragma unroll
+                    for (int i = 0; i < C::NV; ++i) s.x[i] = s.x[i] + s.d[i];
+                    double sq_s = v[1 + st], mx_s = v[st == 0 ? 4 : 6];
+                    C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
+                    v[1 + st] = s.active ? sq_s : v[1 + st];
+                    v[st == 0 ? 4 : 6] = s.active ? mx_s : v[st == 0 ? 4 : 6];
+                }
+                // the values this leads to, and "every constraint satisfied" (lib.rs:305-327; largest < EPS is part of the verdict)
+                if (s.active) {
+#pragma unroll
+                    for (int i = 0; i < C::NV; ++i) store_at(xo, s.ids[i], s.x[i]);
+                }
+                if (mask) {
+                    const uint32_t pos_off = __builtin_amdgcn_readfirstlane(a.blob[a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index) + 2]);
+#pragma unroll
+                    for (int ci = 0; ci < C::NC; ++ci) {
+                        const uint32_t at = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(table, lane * 4, (int)((pos_off + (uint32_t)ci * C::STRIDE) * 4u), 0);
+                        if (s.active) mask[at] = 0;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            stamp();  // 2: both steps taken, stores issued
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = i < 3 ? reduce_wave_to_last_lane(v[i], OpSum()) : reduce_wave_to_last_lane(v[i], OpMax());
+            const unsigned int wave_flags = (__ballot(lane_bad1) != 0 ? 1u : 0u) | (__ballot(lane_bad2) != 0 ? 2u : 0u) | (__ballot(lane_redo) != 0 ? 4u : 0u);
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fast_part[kp][16 * i + wave] = v[i];
+                fast_pflag[kp][wave] = (int)wave_flags;
+            }
+        }
+        // flow control: system k's line takes the ring place of system k - 4's, whose totals were taken three systems ago (k - 2's
+        // "taken" mark is looked for: there at the first look, and it implies every earlier one)
+        if (have && f2 && tid == 0 && q2 % grid_wgs != grid_wg) {
+            for (unsigned int spins = 0;; ++spins) {
+                const gridchunk_t c = grid_peek(&gs->ring_v[q2 & 3u][0]);
+                if (c.z == q2) break;
+                if (EZPZ_GRID_TIMED_OUT(spins, &gs->dead)) {
+                    __hip_atomic_store(&gs->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (have) __syncthreads();
+        stamp();  // 3: the barrier
+        if (have) {  // wavefront 0 folds the wavefronts' partials (lane = value) and publishes them
+            q0 = ++ring_q;
+            if (wave == 0) {
+                const int i = lane & 7;
+                double t = fast_part[kp][16 * i];
+                unsigned int fl = (unsigned int)fast_pflag[kp][0];
+#pragma unroll
+                for (int w2 = 1; w2 < NWAVES; ++w2) {
+                    const double o = fast_part[kp][16 * i + w2];
+                    const double sum = t + o, mxm = fmax_nc(t, o);
+                    t = i < 3 ? sum : mxm;
+                    fl |= (unsigned int)fast_pflag[kp][w2];
+                }
+                if (lane < 8) put(&gs->ring_p[q0 & 3u][grid_wg][lane], t, lane == 0 ? fl : 0u, q0);
+            }
+        }
+        stamp();  // 4: published
+        // ---- this workgroup's turn: the totals of system k - 1 and the reference's verdict on them ------------------------------------
+        if (f1 && q1 % grid_wgs == grid_wg) {
+            const int i = tid & 7, j = tid >> 3;
+            double acc = i < 3 ? 0.0 : __builtin_nan("");
+            unsigned int fl = 0;
+            bool dead = false;
+            for (uint32_t g0 = (uint32_t)j; g0 < grid_wgs; g0 += 4u * GROUPS) {
+                gridchunk_t c[4];
+                const gridchunk_t* src = &gs->ring_p[q1 & 3u][g0][i];
+                const bool in1 = g0 + GROUPS < grid_wgs, in2 = g0 + 2u * GROUPS < grid_wgs, in3 = g0 + 3u * GROUPS < grid_wgs;
+                const gridchunk_t* s1 = in1 ? src + 8 * GROUPS : src;
+                const gridchunk_t* s2 = in2 ? src + 16 * GROUPS : src;
+                const gridchunk_t* s3 = in3 ? src + 24 * GROUPS : src;
+                for (unsigned int spins = 0;; ++spins) {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                        "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                        "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+                        "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                        : "v"(src), "v"(s1), "v"(s2), "v"(s3)
+                        : "memory");
+                    if (c[0].z == q1 && c[1].z == q1 && c[2].z == q1 && c[3].z == q1) break;
+                    if (EZPZ_GRID_TIMED_OUT(spins, &gs->dead)) {
+                        __hip_atomic_store(&gs->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const bool in[4] = {true, in1, in2, in3};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const double o = val(c[h]);
+                    const double sum = acc + o, mxm = fmax_nc(acc, o);
+                    acc = in[h] ? (i < 3 ? sum : mxm) : acc;
+                    fl |= in[h] ? c[h].w : 0u;
+                }
+            }
+            fast_gath[tid] = acc;
+            fast_gflag[tid] = (int)(fl | (dead ? 4u : 0u));
+            __syncthreads();
+            if (wave == 0) {
+                double t = fast_gath[i];
+                unsigned int fl2 = (unsigned int)fast_gflag[i];
+                for (int jj = 1; jj < GROUPS; ++jj) {
+                    const double o = fast_gath[i + 8 * jj];
+                    const double sum = t + o, mxm = fmax_nc(t, o);
+                    t = i < 3 ? sum : mxm;
+                    fl2 |= (unsigned int)fast_gflag[i + 8 * jj];
+                }
+                auto at = [&](int src_lane) {
+                    const unsigned long long u = __builtin_bit_cast(unsigned long long, t);
+                    const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, src_lane), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), src_lane);
+                    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                };
+                const double sq_0 = at(0), sq_1 = at(1), sq_2 = at(2), mx_0 = at(3), mx_1 = at(4), dm_1 = at(5), mx_2 = at(6), dm_2 = at(7);
+                unsigned int flags = 0;
+#pragma unroll
+                for (int l2 = 0; l2 < 8; ++l2) flags |= (unsigned int)__builtin_amdgcn_readlane((int)fl2, l2);
+                // the reference's decisions in the reference's order: eval() and the top of iteration 0 (newton.rs:45-60), its step
+                // (:93-99, :118-139), the top of iteration 1, its step, the top of iteration 2 (max_iterations >= 3, says the host:
+                // the limit is not what ends it), every constraint satisfied (lib.rs:305-327: unit weights, r is at x)
+                const double step1 = (a.n_row > 0) ? dm_1 : 0.0, step2 = (a.n_row > 0) ? dm_2 : 0.0;
+                const bool stands = !(flags & 4u) && !(mx_0 <= a.residual_tolerance) && !(flags & 1u) && sq_1 < sq_0 &&
+                                    !(step1 <= a.step_tolerance) && !(mx_1 <= a.residual_tolerance) && !(flags & 2u) && sq_2 < sq_1 &&
+                                    !(step2 <= a.step_tolerance) && mx_2 <= a.residual_tolerance && mx_2 < EPS && !isnan(sq_2);
+                if (lane == 0) {
+                    if (stands) {
+                        EzpzStatus st;
+                        st.iterations = 2;
+                        st.converged = 1;
+                        st.n_unsatisfied = 0;
+                        st.n_warnings = 0;
+                        st.final_residual_inf = (a.n_rows_total > 0) ? mx_2 : 0.0;
+                        st.final_lambda = lambda2;
+                        a.status[sys1] = st;
+                    } else {
+                        const unsigned int at_list = __hip_atomic_fetch_add(a.redo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.redo[1 + at_list] = (unsigned int)sys1;
+                    }
+                    gridchunk_t c;
+                    c.x = stands ? 1u : 2u, c.y = 0, c.z = q1, c.w = 0;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&gs->ring_v[q1 & 3u][0]), "v"(c) : "memory");
+                }
+            }
+        }
+        stamp();  // 5: (its turn: the totals of k - 1 taken)
+        f2 = f1, q2 = q1;
+        f1 = have, sys1 = sys, q1 = q0;
+    }
 }
 
 // ---- one LANE per system ------------------------------------------------------------------------------------------------------

@@ -117,10 +117,30 @@ int launch_jit_grid(EzpzSystem& s, const CompLaunch& L, hipStream_t stream) {
     const uint64_t capacity = comp_jit_capacity(s.jit, *s.comp, s.device, s.lim.cus);
     if (capacity < G) return EZPZ_ERR_TOO_LARGE;
     const uint32_t slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(L.batch, capacity / G));
-    if (s.jit_scratch.cap < (size_t)slots * kJitGridScratchBytes) {
-        int rc = s.jit_scratch.ensure((size_t)slots * kJitGridScratchBytes);
+    // (a linear system: the kernel that does not wait for its verdicts goes first -- leaner, so more systems in flight -- and the
+    // loop solves what it lists)
+    const uint32_t fast_slots = (uint32_t)(comp_jit_capacity_fast(s.jit, *s.comp, s.device, s.lim.cus) / G);
+    const uint32_t most = std::max(slots, fast_slots);
+    if (s.jit_scratch.cap < (size_t)most * kJitGridScratchBytes) {
+        // (sized for the device, not the call: a later, larger call must find the sequence numbers the slots have reached)
+        const uint32_t all = (uint32_t)std::max<uint64_t>(most, std::max<uint64_t>(capacity / G, fast_slots));
+        int rc = s.jit_scratch.ensure((size_t)all * kJitGridScratchBytes);
         if (rc != EZPZ_OK) return rc;
         HIP_TRY(hipMemsetAsync(s.jit_scratch.p, 0, s.jit_scratch.cap, stream));
+    }
+    const bool lists = fast_slots && L.batch < (1ull << 32);
+    if (lists) {
+        for (auto& list : s.jit_redo)
+            if (list.cap < L.batch + 1) {
+                int rc = list.ensure(L.batch + 1);  // (synchronises the device: nobody reads the old one any more)
+                if (rc != EZPZ_OK) return rc;
+                HIP_TRY(hipMemsetAsync(list.p, 0, sizeof(unsigned int), stream));
+            }
+        if (!s.jit_redo_seen) {
+            HIP_TRY(hipHostMalloc((void**)&s.jit_redo_seen, sizeof(unsigned int), hipHostMallocMapped));
+            *s.jit_redo_seen = 0;
+            HIP_TRY(hipHostGetDevicePointer((void**)&s.jit_redo_seen_dev, s.jit_redo_seen, 0));
+        }
     }
     std::lock_guard<std::mutex> lock(g_grid_mu);
     hipEvent_t& ev = g_grid_event[s.device & 15];
@@ -128,7 +148,11 @@ int launch_jit_grid(EzpzSystem& s, const CompLaunch& L, hipStream_t stream) {
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     else
         HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
-    int rc = comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream, s.jit_scratch.p, slots);
+    const unsigned int turn = s.jit_redo_turn;
+    int rc = comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream, s.jit_scratch.p, slots, lists ? fast_slots : 0,
+                             lists ? s.jit_redo[turn].p : nullptr, lists ? s.jit_redo[turn ^ 1u].p : nullptr, s.jit_redo_seen_dev,
+                             s.jit_redo_seen);
+    if (lists) s.jit_redo_turn = turn ^ 1u;
     if (rc != EZPZ_OK) return rc;
     HIP_TRY(hipEventRecord(ev, stream));
     return EZPZ_OK;

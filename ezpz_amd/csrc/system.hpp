@@ -184,6 +184,11 @@ struct EzpzSystem {
     std::mutex defer_mu;
     CompJit* jit = nullptr;  // the plan's class-specialised kernel (run-time compiled), when it has one
     DevBuf<unsigned char> jit_scratch;  // ... and, when it spreads a system over several workgroups, their reduction scratch
+    DevBuf<unsigned int> jit_redo[2];   // ... and the lists of systems its `_fast` entry leaves to the loop (count, then systems):
+                                        // calls alternate between the two, each zeroes the other's count (launch.hip)
+    unsigned int jit_redo_turn = 0;
+    unsigned int* jit_redo_seen = nullptr;      // mapped host memory: the count the loop's last launch found (a hint, jit.cpp)
+    unsigned int* jit_redo_seen_dev = nullptr;  // ... its device address
     std::unique_ptr<LanePlan> lane;  // small systems: one lane per system, run-time compiled (jit stands for it then)
     CompJit* wave_jit = nullptr;     // ... and, for the latency of one solve, the same class on one wavefront per system
     // connected sketches in large batches: one lane per system, uniform program, state in global memory (batch_kernel.hip.hpp)
@@ -282,6 +287,7 @@ struct EzpzSystem {
         if (dev_fronts) (void)hipFree(dev_fronts);
         if (lanes_done) (void)hipEventDestroy(lanes_done);
         if (ticket_done) (void)hipEventDestroy(ticket_done);
+        if (jit_redo_seen) (void)hipHostFree(jit_redo_seen);
         comp_jit_destroy(jit);
         comp_jit_destroy(wave_jit);
     }

@@ -317,6 +317,63 @@ def test_specialised_kernel_on_several_workgroups(E, lines, over):
         assert np.array_equal(st["final_lambda"], stw["final_lambda"]) and np.array_equal(st["n_warnings"], stw["n_warnings"])
 
 
+@pytest.mark.parametrize("over", [False, True])
+def test_several_workgroups_verdicts_not_waited_for_every_exit(E, over):
+    """A linear system on several workgroups does not wait for the verdicts of the LM control (jit_kernel.hip.hpp:
+    solve_kernel_grid): both iterations are taken and the values stored before anybody knows whether the steps stand, and
+    whatever the verdicts turn out to be the system must end on the reference's path (newton.rs:47-139) -- converged at the
+    start, converged after one iteration, a failed pivot (a NaN guess: every iteration burnt), a rejected first step, the step
+    tolerance met by the first step, iteration limits of 0 ... 3 -- with such systems at the start, in the middle and at the
+    end of a slot's sequence of ordinary ones (a re-solve, then verdicts waited for, while two later systems' verdicts are
+    still pending).  Against the list-walk kernel in every output, and the oracle.  (over: the non-linear variant, which
+    always waits -- the same cases on the loop alone.)"""
+    lines = 12000 if not over else 3000
+    ref = T.load(T.gen_big_problem(lines, over))
+    n = ref.num_vars
+    sysobj = E.System(ref.constraints, n)
+    exact = np.zeros(n)
+    exact[0::4] = exact[2::4] = np.arange(lines)
+    exact[3::4] = 4.0
+    B = 33
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(78, B, n, -0.25, 0.25)
+    cfgs = [E.Config(), E.Config(max_iterations=0), E.Config(max_iterations=1), E.Config(max_iterations=2), E.Config(max_iterations=3),
+            E.Config(residual_tolerance=-1.0),                       # exact start: step 0, rejected (0 < 0 is false), step test ends it
+            E.Config(residual_tolerance=-1.0, step_tolerance=-1.0, max_iterations=6),  # ... and nothing ends it: six rejected steps
+            E.Config(step_tolerance=1e3)]                            # the first step meets the step tolerance
+    seen = set()
+    for variant in range(2):
+        if variant == 0:  # special systems scattered among ordinary ones
+            x0[1] = exact                                                    # converged before the first iteration
+            x0[10] = exact + gen.keyed_uniform(79, 1, n, -1e-4, 1e-4)[0]     # one iteration is enough
+            x0[18, 5] = np.nan                                               # a pivot fails in every iteration
+            x0[27] = exact
+            x0[27, 2 * (lines // 2)] += 1e-6                                  # one component away from the solution, barely
+            x0[32] = exact                                                   # the last system of its slot
+        else:  # ... and every system special (every verdict a re-solve from the first on)
+            x0[:] = exact[None, :] + gen.keyed_uniform(80, B, n, -1e-5, 1e-5)
+            x0[::3] = exact
+        fresh = E.System(ref.constraints, n)
+        want = [fresh.solve_batch(x0, cfg, want_mask=True) for cfg in cfgs]  # list-walk
+        assert sysobj.specialize(wait=True) == 2
+        for cfg, (xw, stw, maskw) in zip(cfgs, want):
+            ocfg = O.Config(cfg.max_iterations, cfg.residual_tolerance, cfg.step_tolerance, cfg.initial_lambda)
+            rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0, ocfg, linsolve=O.LINSOLVE_SPARSE)
+            assert rc == 0
+            for rep in range(2):
+                x, st, mask = sysobj.solve_batch(x0, cfg, want_mask=rep == 0)
+                for f in st.dtype.names:
+                    assert np.array_equal(st[f], stw[f], equal_nan=True), (cfg, f, st[f], stw[f])
+                assert np.array_equal(x, xw, equal_nan=True) and (rep or np.array_equal(mask, maskw)), cfg
+                assert np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv) and np.array_equal(st["n_unsatisfied"], nun), cfg
+                fin = ~np.isnan(xo).any(axis=1)
+                assert_x_close(x[fin], xo[fin])
+                if not over:
+                    assert np.array_equal(x, xo, equal_nan=True), cfg
+            seen.update((int(i), int(c)) for i, c in zip(st["iterations"], st["converged"]))
+    # the exits were really taken
+    assert {(0, 1), (1, 1), (2, 1), (6, 0)} <= seen and any(c == 0 and i > 6 for i, c in seen), str(sorted(seen))
+
+
 def test_random_classes_interpreter_and_specialised_kernel_agree_bitwise(E):
     """Random little systems of all 25 kinds (the fuzz generator's), each replicated 130 times with jittered guesses into
     a block system: the component interpreter and the run-time compiled kernel give the same bits in every output
