@@ -209,16 +209,21 @@ def collect_pmc(args, workload=None, batch=None, sets=None, team=None) -> dict:
         except (subprocess.SubprocessError, OSError) as exc:
             errors.append(f"set{i}: {type(exc).__name__}: {str(getattr(exc, 'stderr', b'') or exc)[-200:]}")
             continue
+        # a step may be several kernels of DIFFERENT names (a linear system on several workgroups: ezpz_jit_solve_fast, then the
+        # loop kernel for what it lists -- usually nothing): a counter's value per step is the sum over the names of its mean per
+        # dispatch of that name (kernels of one name launched several times per step -- the mixed batch -- are roofline()'s n_kernels)
         acc = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if any(k in row["Kernel_Name"] for k in SOLVE_KERNELS):
-                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                    acc.setdefault(row["Counter_Name"], {}).setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
                     if "batch_lane_kernel" in row["Kernel_Name"]:
                         counters["_state_in_hbm"] = 1.0
-        for k, v in acc.items():
-            counters[k] = sum(v) / len(v)
-            counters.setdefault("_dispatches", len(v))
+        for k, by_name in acc.items():
+            counters[k] = sum(sum(v) / len(v) for v in by_name.values())
+            counters.setdefault("_dispatches", max(len(v) for v in by_name.values()))
+            if len(by_name) > 1:
+                counters["_kernels"] = sorted(n.split("(")[0][:48] for n in by_name)
     shutil.rmtree(outdir, ignore_errors=True)
     if errors:
         counters["errors"] = errors
