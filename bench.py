@@ -695,6 +695,8 @@ def main():
     n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (only when something other than this script or torch.distributed.run set RANK / WORLD_SIZE without a port: the ranks
+        # cannot agree on a free one without it; both launchers above choose the port themselves)
         os.environ.setdefault("MASTER_PORT", "29577")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)

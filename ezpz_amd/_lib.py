@@ -77,7 +77,7 @@ EXPORTS = [
     "ezpz_specialized_source",
     "ezpz_multi_create", "ezpz_multi_destroy", "ezpz_multi_device_count", "ezpz_multi_device", "ezpz_multi_shard",
     "ezpz_multi_specialize", "ezpz_multi_solve_batch", "ezpz_system_solve_batch_multi",
-    "ezpz_debug_call_trace", "ezpz_launch_policy", "ezpz_debug_front_plan",
+    "ezpz_debug_call_trace", "ezpz_launch_policy", "ezpz_debug_front_plan", "ezpz_debug_set_stamps", "ezpz_debug_jit_compilations", "ezpz_debug_freedom_exits",
     "ezpz_mixed_create", "ezpz_mixed_destroy", "ezpz_mixed_total_values", "ezpz_mixed_offsets", "ezpz_mixed_solve_device",
     "ezpz_mixed_solve", "ezpz_system_solve_batch_mixed", "ezpz_multi_solve_batch_mixed",
 ]
@@ -164,6 +164,12 @@ def lib():
     L.ezpz_launch_policy.argtypes = [C.c_int, C.POINTER(CLaunchPolicy)]
     L.ezpz_debug_call_trace.restype = sz
     L.ezpz_debug_call_trace.argtypes = [vp, sz]
+    L.ezpz_debug_set_stamps.restype = None
+    L.ezpz_debug_set_stamps.argtypes = [vp]
+    L.ezpz_debug_freedom_exits.restype = None
+    L.ezpz_debug_freedom_exits.argtypes = [vp]
+    L.ezpz_debug_jit_compilations.restype = C.c_uint64
+    L.ezpz_debug_jit_compilations.argtypes = []
     L.ezpz_debug_front_plan.restype = C.c_long
     L.ezpz_debug_front_plan.argtypes = [vp, sz, sz, u32, u32, C.c_uint64, vp, sz, vp]
     L.ezpz_cache_clear.restype = None

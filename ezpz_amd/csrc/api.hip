@@ -248,5 +248,7 @@ long ezpz_specialized_source(const EzpzConstraint* cs, size_t n_cs, size_t n_var
 // tools/front_stamps.py; the run-time compiled kernel of a system on several workgroups in every build: tools/ladder_stamps.py).
 void ezpz_debug_set_stamps(unsigned long long* dev_buf) { g_stamps = dev_buf; }
 
+unsigned long long ezpz_debug_jit_compilations(void) { return comp_jit_compilations(); }
+
 
 }  // extern "C"

@@ -904,20 +904,33 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                     o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
                          (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse ? "true" : "false") + ", false>(a, smem);\n}\n";
             }
-            // a LINEAR system with unit weights on several workgroups: the kernel that does not wait for the verdicts of the LM control
-            // (jit_kernel.hip.hpp: solve_kernel_grid_fast; the entry above then solves what it could not finish).  A third of the
-            // loop's registers: compiled for four wavefronts per SIMD while its state fits
-            if (G > 1 && !any_nonlinear && plan.unit_weights) {
-                uint64_t fast_vg = 0;  // x, the next system's x, d, r (doubles), parameters, ids
+            // a LINEAR system with unit weights: the kernel that does not wait for the verdicts of the LM control (jit_kernel.hip.hpp:
+            // solve_kernel_fast / solve_kernel_grid_fast) and, for a system on one workgroup, the loop over the systems that kernel
+            // lists (`_list`; several workgroups: the first entry reads the list itself).  The first needs far fewer registers than the
+            // loop: compiled for four wavefronts per SIMD while its state fits
+            if (!any_nonlinear && plan.unit_weights) {
+                uint64_t fast_vg = 0;  // the next system's x, parameters (doubles), ids; one slot's x, d, r; the eight partials
+                uint64_t widest = 0;
                 for (size_t k = 0; k < classes.size(); ++k) {
                     const ClassLayout& H = classes[k].H;
-                    fast_vg += (2ull * (3 * H.nv + H.m + H.ncons) + H.nv) * slots_k[k];
+                    fast_vg += (2ull * (H.nv + H.ncons) + H.nv) * slots_k[k];
+                    widest = std::max<uint64_t>(widest, 2ull * (2 * H.nv + H.m));
                 }
+                fast_vg += widest + 16;
                 static const char* env_fw = std::getenv("EZPZ_JIT_FAST_MINWAVES");  // occupancy hint, for measurements
                 const int fast_waves = env_fw ? std::atoi(env_fw) : (fast_vg + 40 <= 128 ? 4 : fast_vg + 40 <= 168 ? 3 : 2);
-                o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ", " + std::to_string(fast_waves) +
-                     ") ezpz_jit_solve_fast(const ezpz::jit::JitArgs a) {\n";
-                o += "    ezpz::jit::solve_kernel_grid_fast<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ">(a);\n}\n";
+                // (twice: for the estimated occupancy and for one wavefront per SIMD less -- the loader takes the first that keeps its
+                // registers out of scratch memory, jit.cpp: ensure_loaded)
+                for (int variant = 0; variant < (fast_waves > 2 && !env_fw ? 2 : 1); ++variant) {
+                    o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ", " + std::to_string(fast_waves - variant) +
+                         ") ezpz_jit_solve_fast" + (variant ? "_b" : "") + "(const ezpz::jit::JitArgs a) {\n";
+                    o += std::string("    ezpz::jit::") + (G > 1 ? "solve_kernel_grid_fast" : "solve_kernel_fast") + "<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ">(a);\n}\n";
+                }
+                if (G == 1) {
+                    o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve_list(const ezpz::jit::JitArgs a) {\n";
+                    o += "    __shared__ double smem[ezpz::jit::kRedDoubles + 16];\n";
+                    o += "    ezpz::jit::solve_kernel_grid<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", false, true, false>(a, smem);\n}\n";
+                }
             }
             align4(blob);
             plan.o_jit_slots = (uint32_t)blob.size();

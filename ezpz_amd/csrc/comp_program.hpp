@@ -192,10 +192,13 @@ int comp_jit_launch(CompJit* jit, const CompPlan& plan, const uint32_t* dev_blob
 uint64_t comp_jit_capacity(CompJit* jit, const CompPlan& plan, int device, int cus);
 // ... of its `_fast` entry (0: the kernel has none)
 uint64_t comp_jit_capacity_fast(CompJit* jit, const CompPlan& plan, int device, int cus);
+// whether this launch may take the `_fast` entry (then: fast_slots, redo, redo_next to comp_jit_launch)
+bool comp_jit_fast_ok(CompJit* jit, const CompPlan& plan, const CompLaunch& launch, int device, int cus);
 // (through the on-disk cache of code objects; _uncached always compiles; comp_jit_cached: is it in the cache?)
 int comp_jit_compile(const std::string& source, std::vector<char>& code, std::string& log);
 int comp_jit_compile_uncached(const std::string& source, std::vector<char>& code, std::string& log);
 bool comp_jit_cached(const std::string& source);
+unsigned long long comp_jit_compilations();  // hiprtc compilations of this process so far (cache hits do not count)
 // asks the on-disk cache for the kernel in the background, once (a system's first launch does this)
 void comp_jit_probe(CompJit* jit);
 // comp_jit_request when the process already holds its budget of resident specialised kernels (512: code objects are

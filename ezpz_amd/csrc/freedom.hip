@@ -377,13 +377,23 @@ void jacobi_eigen(std::vector<double>& a, std::vector<double>& q, uint32_t m) {
     }
 }
 
+// How the calls of freedom_by_probes ended, per process (ezpz_debug_freedom_exits; tests/test_gpu_freedom_fuzz.py logs them):
+// [0] systems decided fully constrained by the first eight probes, [1] decided with null vectors found, [2] calls that took the
+// second opinion; calls handed to the pivoted QR because: [3] an answer was not finite, [4] five or more candidates, [5] a direction
+// undecided at both lambdas, [6] an unsettled direction at the end, [7] not applicable (switched off, no frontal plan, > 64 systems).
+std::atomic<unsigned long long> g_probe_exits[8];
+
 // 0: done (mask / participation written); 1: not decided here -- the caller runs the pivoted QR; negative: an error.
 int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* under_mask, double* participation) {
     const char* const env = std::getenv("EZPZ_FREEDOM_PROBES");  // =0: the pivoted QR for every system (read per call: tests switch it)
     const bool enabled = !(env && env[0] == '0');
-    if (!enabled || !sys->fronts || !sys->dev_fronts || batch > 64) return 1;
-    auto give_up = [&](const char* why2) {
+    if (!enabled || !sys->fronts || !sys->dev_fronts || batch > 64) {
+        g_probe_exits[7].fetch_add(1);
+        return 1;
+    }
+    auto give_up = [&](const char* why2, int reason) {
         if (hip_debug()) std::fprintf(stderr, "[ezpz hip] null-space probes: %s -> the pivoted QR\n", why2);
+        g_probe_exits[reason].fetch_add(1);
         return 1;
     };
     auto& F = sys->freedom;
@@ -414,7 +424,7 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
         const double* Yb = Y.data() + b * m * n;
         gram(Yb, Yb, m, G);
         for (double g : G)
-            if (!(std::fabs(g) < 1e300)) return give_up("a probe's answer is not finite (a pivot failed)");
+            if (!(std::fabs(g) < 1e300)) return give_up("a probe's answer is not finite (a pivot failed)", 3);
         for (uint32_t a2 = 0; a2 < m; ++a2)
             for (uint32_t b2 = a2 + 1; b2 < m; ++b2) G[(size_t)b2 * m + a2] = G[(size_t)a2 * m + b2] = 0.5 * (G[(size_t)a2 * m + b2] + G[(size_t)b2 * m + a2]);
         jacobi_eigen(G, Q, m);
@@ -433,7 +443,7 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
             }
             ++k;
         }
-        if (k >= 5) return give_up("five or more candidate directions from eight probes");
+        if (k >= 5) return give_up("five or more candidate directions from eight probes", 4);
         kdim[b] = k;
         any = any || k;
     }
@@ -459,7 +469,7 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
             double* Vb = V.data() + b * m * n;
             gram(Vb, Zb, k, H);  // Vt Op V
             for (double g : H)
-                if (!(std::fabs(g) < 1e300)) return give_up("a refinement's answer is not finite");
+                if (!(std::fabs(g) < 1e300)) return give_up("a refinement's answer is not finite", 3);
             for (uint32_t a2 = 0; a2 < k; ++a2)
                 for (uint32_t b2 = a2 + 1; b2 < k; ++b2) H[(size_t)b2 * k + a2] = H[(size_t)a2 * k + b2] = 0.5 * (H[(size_t)a2 * k + b2] + H[(size_t)b2 * k + a2]);
             jacobi_eigen(H, Q, k);
@@ -505,6 +515,7 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
         // (three rounds at least: what is not a null vector leaves the kept ones at lambda / sigma^2 per round)
         if (settled && round >= 2) break;
         if (round == 5) {
+            g_probe_exits[2].fetch_add(1);
             // A Ritz value stays between 0.5 and 0.999: a singular value of J within 1e-7 ... 3e-6 of its largest entry, which the
             // reference's rank decision (1e-8 on R's diagonal) counts as non-zero.  A second opinion at lambda_p / 1000: what it
             // answers by less than half of itself there is NOT a null vector and leaves; the null vectors' own answers are noisier
@@ -525,13 +536,13 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
                 for (uint32_t t = 0; t < k; ++t) {
                     double f2 = 0.0;
                     for (size_t i2 = 0; i2 < n; ++i2) f2 += Vb[t * n + i2] * Zb[t * n + i2];
-                    if (!(std::fabs(f2) < 1e300)) return give_up("a pivot failed at the second opinion's lambda");
+                    if (!(std::fabs(f2) < 1e300)) return give_up("a pivot failed at the second opinion's lambda", 3);
                     if (ritz[b][t] >= 0.999 || f2 > 0.9) {  // a null vector (kept as it is)
                         if (kept != t) std::copy(Vb + (size_t)t * n, Vb + (size_t)(t + 1) * n, Vb + (size_t)kept * n);
                         ritz[b][kept] = 1.0;
                         ++kept;
                     } else if (f2 >= 0.5) {
-                        return give_up("a direction answered by 0.5 ... 0.9 of itself at both lambdas (a singular value of J within 3e-9 ... 1e-7 of its largest entry)");
+                        return give_up("a direction answered by 0.5 ... 0.9 of itself at both lambdas (a singular value of J within 3e-9 ... 1e-7 of its largest entry)", 5);
                     }
                 }
                 ritz[b].resize(kept);
@@ -547,7 +558,7 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
         std::fill(proj.begin(), proj.end(), 0.0);
         uint32_t nullity = 0;
         for (uint32_t t = 0; t < kdim[b]; ++t) {
-            if (!(ritz[b][t] >= 0.999)) return give_up("an unsettled direction");
+            if (!(ritz[b][t] >= 0.999)) return give_up("an unsettled direction", 6);
             ++nullity;
             for (size_t i2 = 0; i2 < n; ++i2) proj[i2] += Vb[t * n + i2] * Vb[t * n + i2];
         }
@@ -560,11 +571,16 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
             mk[i2] = nullity && proj[i2] > squared_tol ? 1 : 0;
             if (pt) pt[i2] = proj[i2];
         }
+        g_probe_exits[nullity ? 1 : 0].fetch_add(1);
     }
     return 0;
 }
 
 }  // namespace
+
+extern "C" void ezpz_debug_freedom_exits(unsigned long long* out8) {
+    for (int i = 0; i < 8; ++i) out8[i] = g_probe_exits[i].load();
+}
 
 // A system whose resident QR timed out (FreedomArgs::qr_timed_out) carries kFreedomPoisonedMask in every byte of its mask.
 bool mask_poisoned(const uint8_t* mask, size_t batch, size_t n) {

@@ -51,8 +51,8 @@ struct JitArgs {
     // 83.7 M solves/s.  (32 bits, modular: a launch draws fewer than 2^32 values.)
     unsigned int* ticket;
     unsigned int ticket_base[8];
-    // diagnostic (tools/ladder_stamps.py; null otherwise): solve_kernel_grid leaves wall-clock stamps of thread 0 of every
-    // workgroup here, 16 per (system, workgroup)
+    // diagnostic (tools/ladder_stamps.py; null otherwise): a solve_kernel_grid_fast compiled with EZPZ_JIT_STAMPS leaves wall-clock
+    // stamps of thread 0 of every workgroup here, 16 per (system, workgroup)
     unsigned long long* stamps;
     // a system on several workgroups: the systems solve_kernel_grid_fast could not finish -- redo[0] of them, redo[1], ... -- which it
     // appends to and the launch of solve_kernel_grid behind it solves (null: that kernel solves the whole batch)
@@ -151,6 +151,7 @@ struct Slots;
 template <>
 struct Slots<> {
     static constexpr int N = 0;
+    static constexpr int NVS = 0;
     template <class F>
     __device__ __forceinline__ void each(F&&, int = 0) {}
 };
@@ -165,6 +166,7 @@ struct same_class<A, A> {
 template <class C, class... Rest>
 struct Slots<C, Rest...> {
     static constexpr int N = 1 + sizeof...(Rest);
+    static constexpr int NVS = C::NV + Slots<Rest...>::NVS;  // variables per lane over all the slots
     Slot<C> head;
     Slots<Rest...> tail;
     template <class X>
@@ -1097,45 +1099,37 @@ __device__ __forceinline__ void store_at(__amdgpu_buffer_rsrc_t row, uint32_t by
 // wavefront, one barrier, its stores, and every G-th time a turn at the totals.  A kernel of its own because it needs a third of
 // the registers of the loop (no r_next, no step kept across a rendezvous, nothing of the general evaluators): more systems in
 // flight.  The only wait left is flow control: a workgroup may be four systems ahead of the totals (the ring's depth).
-template <class SEQ, int NWAVES>
-__device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
-    using namespace ezpz::dev;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
-    const uint32_t grid_wgs = a.grid_wgs;
-    const uint32_t grid_wg = blockIdx.x % grid_wgs, grid_slot = blockIdx.x / grid_wgs, n_slots = gridDim.x / grid_wgs;
-    GridScratch* const gs = a.grid + grid_slot;
-    // sequence number of the last system this workgroup published (continues from launch to launch): the largest in its four ring
-    // places, looked at by four lanes at once (asked for here, read after the setup below)
-    gridchunk_t ring_c;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(ring_c) : "v"(&gs->ring_p[lane & 3][grid_wg][0]) : "memory");
-    const uint32_t wave_global = grid_wg * NWAVES + wave;
-    SEQ seq;
+// ---- what the kernels that do not wait for the LM control's verdicts share (solve_kernel_fast, solve_kernel_grid_fast) -----------
+// A wavefront's slots for those kernels: the caller's variable ids as BYTE offsets (n_row < 2^29: the host), the instances'
+// parameters, and the factorisation of every class at the two lambdas of the expected path -- J^T J + lambda I of a linear class is
+// the same matrix for every instance of every system: factorised once per launch (newton.rs:73-99: the operations of C::solve
+// that do not involve the right-hand side, in its order), kept in scalar registers by the class's first slot.
+template <class SEQ>
+__device__ __forceinline__ void fast_setup(SEQ& seq, const JitArgs& a, const uint32_t wave_global, const int lane) {
     seq.each([&](auto& s, auto* cls, int index) {
         using C = typename class_of<decltype(cls)>::type;
         const uint32_t* t = a.blob + a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index);
         const uint32_t ids_off = t[0], par_off = t[1], count = t[3];
         s.active = (uint32_t)lane < count;
 #pragma unroll
-        for (int k = 0; k < C::NV; ++k) s.ids[k] = a.blob[ids_off + (size_t)k * C::STRIDE + lane] * 8u;  // BYTE offsets (n_row < 2^29: the host)
+        for (int k = 0; k < C::NV; ++k) s.ids[k] = a.blob[ids_off + (size_t)k * C::STRIDE + lane] * 8u;
         const double* par = reinterpret_cast<const double*>(a.blob + par_off) + lane;
 #pragma unroll
         for (int k = 0; k < C::NC; ++k) s.par[k] = par[(size_t)k * C::STRIDE];
     });
-    // Slot::xn: the guesses of the system at hand -- asked for a whole system ahead of their use (below), the first ones here
-    if (grid_slot < a.batch) {
-        const __amdgpu_buffer_rsrc_t x0 = row_at(a.x0 + (uint64_t)grid_slot * a.n_row);
-        seq.each([&](auto& s, auto* cls, int) {
-            using C = typename class_of<decltype(cls)>::type;
+}
+template <class SEQ>
+__device__ __forceinline__ void fast_fetch(SEQ& seq, const JitArgs& a, const uint64_t sys) {  // Slot::xn <- the guesses of `sys`
+    const __amdgpu_buffer_rsrc_t x0 = row_at(a.x0 + sys * a.n_row);
+    seq.each([&](auto& s, auto* cls, int) {
+        using C = typename class_of<decltype(cls)>::type;
 #pragma unroll
-            for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0, s.ids[i]);
-        });
-    }
-    const double lambda1 = a.initial_lambda * LM_LAMBDA_DECR, lambda2 = lambda1 * LM_LAMBDA_DECR;
-    // J^T J + lambda I of a linear class is the same matrix for every instance of every system: factorised here, once per lambda
-    // (newton.rs:73-99 -- the operations of C::solve that do not involve the right-hand side, in its order), kept in scalar
-    // registers
+        for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0, s.ids[i]);
+    });
+}
+template <class SEQ>
+__device__ __forceinline__ void fast_factor(SEQ& seq, const JitArgs& a) {
+    const double lambda1 = a.initial_lambda * ezpz::dev::LM_LAMBDA_DECR;
     seq.each([&](auto& s, auto* cls, int) {
         using C = typename class_of<decltype(cls)>::type;
         if (&s != &seq.template first<C>()) return;  // (once per class: its other slots read the first one's)
@@ -1150,6 +1144,212 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
             s.fok[st] = __builtin_amdgcn_readfirstlane((int)ok) != 0;
         }
     });
+}
+// One wavefront's share of system `sys` from the guesses in Slot::xn to the stored values: eval() (newton.rs:45, :232-236), then two
+// iterations taken for accepted -- the loop's two passes (newton.rs:73-116), x += d, r = r_next.  SLOT BY SLOT: one slot's x, d and
+// r are live at a time, and the place of a slot's guesses is free for those of the wavefront's NEXT system (`sys_n`, if `next`),
+// asked for a whole system ahead of their use, as soon as it has read them.  The sums run over the slots in the loop's order:
+// the same bits.  Leaves in v[], in the wavefront's last lane: sum r0^2, sum r1^2, sum r2^2 | max|r0|, max|r1|, |d1|, max|r2|, |d2|;
+// returns bit 0 / 1: a pivot failed in the first / second step, bit 2: an operand outside the short division's range (almost
+// never: the system goes on the redo list, where C::solve_exact divides plainly).
+template <bool STAGE, class SEQ>
+__device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, const uint64_t sys, const uint64_t sys_n, const bool next,
+                                                  const uint32_t wave_global, const int lane, double (&v)[8], double* const out_lds) {
+    using namespace ezpz::dev;
+    const __amdgpu_buffer_rsrc_t xo = row_at(a.x_out + sys * a.n_row);
+    const __amdgpu_buffer_rsrc_t x0n = row_at(a.x0 + (next ? sys_n : sys) * a.n_row);
+    uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
+    const __amdgpu_buffer_rsrc_t table = row_at(a.blob);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = i < 3 ? 0.0 : __builtin_nan("");
+    bool lane_bad1 = false, lane_bad2 = false, lane_redo = false;
+    int var0 = 0;
+    seq.each([&](auto& s, auto* cls, int index) {
+        using C = typename class_of<decltype(cls)>::type;
+        auto& f = seq.template first<C>();
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) s.x[i] = s.xn[i];
+        if (next) {
+#pragma unroll
+            for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0n, s.ids[i]);
+        }
+        unsigned long long wm = 0;
+        {
+            double sq_s = v[0], mx_s = v[3];
+            C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
+            v[0] = s.active ? sq_s : v[0];
+            v[3] = s.active ? mx_s : v[3];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            double cd = __builtin_nan("");
+            bool ok = f.fok[st];
+            C::solve_f(f.F[st], s.r, s.d, cd, ok);
+            const bool cb = f.fbad[st];
+            lane_redo = lane_redo || (s.active && !ok && !cb);
+            double& dmax = v[st == 0 ? 5 : 7];
+            const double dm = fmax_nc(dmax, cd);
+            dmax = s.active ? dm : dmax;
+            if (st == 0)
+                lane_bad1 = lane_bad1 || (s.active && cb);
+            else
+                lane_bad2 = lane_bad2 || (s.active && cb);
+#pragma unroll
+            for (int i = 0; i < C::NV; ++i) s.x[i] = s.x[i] + s.d[i];
+            double sq_s = v[1 + st], mx_s = v[st == 0 ? 4 : 6];
+            C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
+            v[1 + st] = s.active ? sq_s : v[1 + st];
+            v[st == 0 ? 4 : 6] = s.active ? mx_s : v[st == 0 ? 4 : 6];
+        }
+        if (mask) {
+            const uint32_t pos_off = __builtin_amdgcn_readfirstlane(a.blob[a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index) + 2]);
+#pragma unroll
+            for (int ci = 0; ci < C::NC; ++ci) {
+                const uint32_t at = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(table, lane * 4, (int)((pos_off + (uint32_t)ci * C::STRIDE) * 4u), 0);
+                if (s.active) mask[at] = 0;
+            }
+        }
+        if constexpr (STAGE) {  // (the values wait in LDS -- this lane's own words, `out_lds` is the wavefront's -- for the stores below)
+#pragma unroll
+            for (int i = 0; i < C::NV; ++i) out_lds[(var0 + i) * 64 + lane] = s.x[i];
+            var0 += C::NV;
+        } else {
+            if (s.active) {
+#pragma unroll
+                for (int i = 0; i < C::NV; ++i) store_at(xo, s.ids[i], s.x[i]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // the values this leads to ("every constraint satisfied", lib.rs:305-327: largest < EPS is part of the verdict) -- the
+    // wavefront's stores BACK TO BACK: a 128-byte line of the row is shared by three or four of them, and stored slot by slot, as
+    // the values came, the pieces reached memory apart: 23.8 KB written and 18 KB read per 16 KB row of the 2000 x 2000 system,
+    // 4.8 TB/s for 113.9 M solves/s; together 16.0 / 16.0 KB and 129 M (profiles/r06_fast_stores.txt).  STAGE false: stored as
+    // they come (a system on several workgroups: 15 registers less let a fourth wavefront onto the SIMD, worth more to the
+    // ladder -- issue-bound at 0.37 of the memory roof -- than 20 % of traffic)
+    var0 = 0;
+    if constexpr (STAGE) seq.each([&](auto& s, auto* cls, int) {
+        using C = typename class_of<decltype(cls)>::type;
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            const double x = out_lds[(var0 + i) * 64 + lane];
+            if (s.active) store_at(xo, s.ids[i], x);
+        }
+        var0 += C::NV;
+    });
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = i < 3 ? reduce_wave_to_last_lane(v[i], OpSum()) : reduce_wave_to_last_lane(v[i], OpMax());
+    return (__ballot(lane_bad1) != 0 ? 1u : 0u) | (__ballot(lane_bad2) != 0 ? 2u : 0u) | (__ballot(lane_redo) != 0 ? 4u : 0u);
+}
+// The reference's decisions in the reference's order on a system's totals -- lane i < 8 of the calling wavefront holds value i of
+// fast_wave's list, `flags` its bits for the system (bit 2 also: a workgroup's line never came) -- : eval() and the top of iteration 0
+// (newton.rs:45-60), its step (:93-99, :118-139), the top of iteration 1, its step, the top of iteration 2 (max_iterations >= 3, says
+// the host: the limit is not what ends it), every constraint satisfied (lib.rs:305-327: unit weights, r is at x).  If they are the
+// expected ones, lane 0 writes the status; if not, it puts the system on the redo list.  Returns whether they were.
+__device__ __forceinline__ bool fast_verdict(const JitArgs& a, const uint64_t sys, const double t, const unsigned int flags, const int lane) {
+    using namespace ezpz::dev;
+    auto at = [&](int src_lane) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, t);
+        const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, src_lane), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), src_lane);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    const double sq_0 = at(0), sq_1 = at(1), sq_2 = at(2), mx_0 = at(3), mx_1 = at(4), dm_1 = at(5), mx_2 = at(6), dm_2 = at(7);
+    const double step1 = (a.n_row > 0) ? dm_1 : 0.0, step2 = (a.n_row > 0) ? dm_2 : 0.0;
+    const bool stands = !(flags & 4u) && !(mx_0 <= a.residual_tolerance) && !(flags & 1u) && sq_1 < sq_0 && !(step1 <= a.step_tolerance) &&
+                        !(mx_1 <= a.residual_tolerance) && !(flags & 2u) && sq_2 < sq_1 && !(step2 <= a.step_tolerance) &&
+                        mx_2 <= a.residual_tolerance && mx_2 < EPS && !isnan(sq_2);
+    if (lane == 0) {
+        if (stands) {
+            EzpzStatus st;
+            st.iterations = 2;
+            st.converged = 1;
+            st.n_unsatisfied = 0;
+            st.n_warnings = 0;
+            st.final_residual_inf = (a.n_rows_total > 0) ? mx_2 : 0.0;
+            st.final_lambda = (a.initial_lambda * LM_LAMBDA_DECR) * LM_LAMBDA_DECR;
+            a.status[sys] = st;
+        } else {
+            const unsigned int at_list = __hip_atomic_fetch_add(a.redo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.redo[1 + at_list] = (unsigned int)sys;
+        }
+    }
+    return stands;
+}
+
+// VERDICTS NOT WAITED FOR, one workgroup per system (the 2000 x 2000 headline).  The same idea as solve_kernel_grid_fast below, where
+// it is explained, without anything crossing workgroups: a wavefront takes its slots through eval() and both iterations (fast_wave),
+// the wavefronts' partials meet in LDS at the ONE barrier a system costs, wavefront 0 makes the reference's decisions on the totals
+// (fast_verdict) while the others are on the next system already.  solve_kernel spends three rendezvous per system on the LM
+// control, each with every wavefront's state held in registers across it (168 of them, three wavefronts per SIMD, 43 % of wave
+// cycles parked: profiles/r05_bench_massive.json); here nothing is live across the barrier but the next system's guesses.
+// Systems are dealt to the workgroups with the stride of the launch.
+template <class SEQ, int NWAVES>
+__device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
+    using namespace ezpz::dev;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    SEQ seq;
+    fast_setup(seq, a, wave, lane);
+    if (blockIdx.x < a.batch) fast_fetch(seq, a, blockIdx.x);
+    fast_factor(seq, a);
+    __shared__ double fast_part[2][8 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
+    __shared__ int fast_pflag[2][16];
+    __shared__ double fast_out[NWAVES * SEQ::NVS * 64];  // per wavefront: a system's values on their way out (fast_wave)
+    unsigned int kp = 0;
+    for (uint64_t sys = blockIdx.x; sys < a.batch; sys += gridDim.x, kp ^= 1u) {
+        const uint64_t sys_n = sys + gridDim.x;
+        double v[8];
+        const unsigned int wave_flags = fast_wave<true>(seq, a, sys, sys_n, sys_n < a.batch, wave, lane, v, fast_out + wave * (SEQ::NVS * 64));
+        if constexpr (NWAVES == 1) {
+            // (lane i <- value i from the last lane)
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned long long u = __builtin_bit_cast(unsigned long long, v[i]);
+                const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, 63), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), 63);
+                const double x = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                t = lane == i ? x : t;
+            }
+            fast_verdict(a, sys, t, wave_flags, lane);
+        } else {
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fast_part[kp][16 * i + wave] = v[i];
+                fast_pflag[kp][wave] = (int)wave_flags;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int i = lane & 7;
+                double t = fast_part[kp][16 * i];
+                unsigned int fl = (unsigned int)fast_pflag[kp][0];
+#pragma unroll
+                for (int w2 = 1; w2 < NWAVES; ++w2) {
+                    const double o = fast_part[kp][16 * i + w2];
+                    const double sum = t + o, mxm = fmax_nc(t, o);
+                    t = i < 3 ? sum : mxm;
+                    fl |= (unsigned int)fast_pflag[kp][w2];
+                }
+                fast_verdict(a, sys, t, fl, lane);
+            }
+        }
+    }
+}
+
+template <class SEQ, int NWAVES>
+__device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
+    using namespace ezpz::dev;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    const uint32_t grid_wgs = a.grid_wgs;
+    const uint32_t grid_wg = blockIdx.x % grid_wgs, grid_slot = blockIdx.x / grid_wgs, n_slots = gridDim.x / grid_wgs;
+    GridScratch* const gs0 = a.grid + grid_slot;
+    const uint32_t wave_global = grid_wg * NWAVES + wave;
+    SEQ seq;
+    fast_setup(seq, a, wave_global, lane);
+    if (grid_slot < a.batch) fast_fetch(seq, a, grid_slot);  // (the guesses of the first system; every later one's a system ahead)
+    fast_factor(seq, a);
     constexpr int GROUPS = NWAVES * 8;       // a turn at the totals: thread = (value tid & 7, group tid >> 3)
     __shared__ double fast_part[2][8 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
     __shared__ int fast_pflag[2][16];
@@ -1162,9 +1362,12 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(c) : "memory");
     };
     auto val = [](const gridchunk_t& c) { return __builtin_bit_cast(double, ((unsigned long long)c.y << 32) | c.x); };
+    // sequence number of the last system this workgroup published (continues from launch to launch): the largest in its four ring
+    // places, looked at by four lanes at once
     unsigned int ring_q;
     {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring_c)::"memory");
+        gridchunk_t ring_c;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(ring_c) : "v"(&gs0->ring_p[lane & 3][grid_wg][0]) : "memory");
         const unsigned int z0 = __builtin_amdgcn_readlane(ring_c.z, 0), z1 = __builtin_amdgcn_readlane(ring_c.z, 1);
         const unsigned int z2 = __builtin_amdgcn_readlane(ring_c.z, 2), z3 = __builtin_amdgcn_readlane(ring_c.z, 3);
         const unsigned int m0 = z0 > z1 ? z0 : z1, m1 = z2 > z3 ? z2 : z3;
@@ -1180,86 +1383,25 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
         if (!have && !(f1 && q1 % grid_wgs == grid_wg)) break;
         const unsigned int kp = (unsigned int)k & 1u;
         unsigned int q0 = 0;
+#ifdef EZPZ_JIT_STAMPS  // (diagnostic compilations only, tools/ladder_stamps.py: the pointer and the counter are registers the kernel has no room for)
         unsigned long long* const stamps = a.stamps && tid == 0 && have ? a.stamps + (sys * grid_wgs + grid_wg) * 16 : nullptr;
         int stamp_n = 0;
         auto stamp = [&]() {
             if (stamps && stamp_n < 16) stamps[stamp_n++] = (unsigned long long)wall_clock64();
         };
+#else
+        auto stamp = [] {};
+#endif
         stamp();  // 0: start
+        // (opaque, every time round: what the lanes' addresses into the scratch have in common would otherwise be computed once,
+        // ahead of the loop, and held in vector registers across the slots -- 15 registers too many for four wavefronts per SIMD)
+        GridScratch* gs = gs0;
+        asm volatile("" : "+s"(gs));
         if (have) {
             const uint64_t sys_n = sys + n_slots;
-            const bool next = sys_n < a.batch;
-            const __amdgpu_buffer_rsrc_t xo = row_at(a.x_out + sys * a.n_row);
-            const __amdgpu_buffer_rsrc_t x0n = row_at(a.x0 + (next ? sys_n : sys) * a.n_row);
-            uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
-            const __amdgpu_buffer_rsrc_t table = row_at(a.blob);
-            // this lane's share of: sum r0^2, sum r1^2, sum r2^2 | max|r0|, max|r1|, |d1|, max|r2|, |d2| -- accumulated over its slots
             double v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = i < 3 ? 0.0 : __builtin_nan("");
-            bool lane_bad1 = false, lane_bad2 = false, lane_redo = false;
-            // SLOT BY SLOT, each from the guesses to the stored values (the phases in step: eval() (newton.rs:45, :232-236), then
-            // two iterations taken for accepted -- the loop's two passes (newton.rs:73-116), x += d, r = r_next): one slot's x, d and
-            // r are live at a time, and the place of a slot's guesses is free for the NEXT system's, asked for a whole system ahead
-            // of their use, as soon as it has read them.  The sums run over the slots in the loop's order: the same bits.
-            seq.each([&](auto& s, auto* cls, int index) {
-                using C = typename class_of<decltype(cls)>::type;
-                auto& f = seq.template first<C>();
-#pragma unroll
-                for (int i = 0; i < C::NV; ++i) s.x[i] = s.xn[i];
-                if (next) {
-#pragma unroll
-                    for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0n, s.ids[i]);
-                }
-                unsigned long long wm = 0;
-                {
-                    double sq_s = v[0], mx_s = v[3];
-                    C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
-                    v[0] = s.active ? sq_s : v[0];
-                    v[3] = s.active ? mx_s : v[3];
-                }
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    double cd = __builtin_nan("");
-                    bool ok = f.fok[st];
-                    C::solve_f(f.F[st], s.r, s.d, cd, ok);
-                    const bool cb = f.fbad[st];
-                    // (an operand outside the short division's range -- almost never: the system goes on the redo list, where
-                    // C::solve_exact divides plainly)
-                    lane_redo = lane_redo || (s.active && !ok && !cb);
-                    double& dmax = v[st == 0 ? 5 : 7];
-                    const double dm = fmax_nc(dmax, cd);
-                    dmax = s.active ? dm : dmax;
-                    if (st == 0)
-                        lane_bad1 = lane_bad1 || (s.active && cb);
-                    else
-                        lane_bad2 = lane_bad2 || (s.active && cb);
-#pragma unroll
-                    for (int i = 0; i < C::NV; ++i) s.x[i] = s.x[i] + s.d[i];
-                    double sq_s = v[1 + st], mx_s = v[st == 0 ? 4 : 6];
-                    C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
-                    v[1 + st] = s.active ? sq_s : v[1 + st];
-                    v[st == 0 ? 4 : 6] = s.active ? mx_s : v[st == 0 ? 4 : 6];
-                }
-                // the values this leads to, and "every constraint satisfied" (lib.rs:305-327; largest < EPS is part of the verdict)
-                if (s.active) {
-#pragma unroll
-                    for (int i = 0; i < C::NV; ++i) store_at(xo, s.ids[i], s.x[i]);
-                }
-                if (mask) {
-                    const uint32_t pos_off = __builtin_amdgcn_readfirstlane(a.blob[a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index) + 2]);
-#pragma unroll
-                    for (int ci = 0; ci < C::NC; ++ci) {
-                        const uint32_t at = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(table, lane * 4, (int)((pos_off + (uint32_t)ci * C::STRIDE) * 4u), 0);
-                        if (s.active) mask[at] = 0;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            stamp();  // 2: both steps taken, stores issued
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = i < 3 ? reduce_wave_to_last_lane(v[i], OpSum()) : reduce_wave_to_last_lane(v[i], OpMax());
-            const unsigned int wave_flags = (__ballot(lane_bad1) != 0 ? 1u : 0u) | (__ballot(lane_bad2) != 0 ? 2u : 0u) | (__ballot(lane_redo) != 0 ? 4u : 0u);
+            const unsigned int wave_flags = fast_wave<false>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, nullptr);
+            stamp();  // 1: both steps taken, stores issued
             if (lane == 63) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) fast_part[kp][16 * i + wave] = v[i];
@@ -1280,7 +1422,7 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
             }
         }
         if (have) __syncthreads();
-        stamp();  // 3: the barrier
+        stamp();  // 2: the barrier
         if (have) {  // wavefront 0 folds the wavefronts' partials (lane = value) and publishes them
             q0 = ++ring_q;
             if (wave == 0) {
@@ -1297,7 +1439,7 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
                 if (lane < 8) put(&gs->ring_p[q0 & 3u][grid_wg][lane], t, lane == 0 ? fl : 0u, q0);
             }
         }
-        stamp();  // 4: published
+        stamp();  // 3: published
         // ---- this workgroup's turn: the totals of system k - 1 and the reference's verdict on them ------------------------------------
         if (f1 && q1 % grid_wgs == grid_wg) {
             const int i = tid & 7, j = tid >> 3;
@@ -1350,43 +1492,18 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
                     t = i < 3 ? sum : mxm;
                     fl2 |= (unsigned int)fast_gflag[i + 8 * jj];
                 }
-                auto at = [&](int src_lane) {
-                    const unsigned long long u = __builtin_bit_cast(unsigned long long, t);
-                    const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, src_lane), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), src_lane);
-                    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-                };
-                const double sq_0 = at(0), sq_1 = at(1), sq_2 = at(2), mx_0 = at(3), mx_1 = at(4), dm_1 = at(5), mx_2 = at(6), dm_2 = at(7);
                 unsigned int flags = 0;
 #pragma unroll
                 for (int l2 = 0; l2 < 8; ++l2) flags |= (unsigned int)__builtin_amdgcn_readlane((int)fl2, l2);
-                // the reference's decisions in the reference's order: eval() and the top of iteration 0 (newton.rs:45-60), its step
-                // (:93-99, :118-139), the top of iteration 1, its step, the top of iteration 2 (max_iterations >= 3, says the host:
-                // the limit is not what ends it), every constraint satisfied (lib.rs:305-327: unit weights, r is at x)
-                const double step1 = (a.n_row > 0) ? dm_1 : 0.0, step2 = (a.n_row > 0) ? dm_2 : 0.0;
-                const bool stands = !(flags & 4u) && !(mx_0 <= a.residual_tolerance) && !(flags & 1u) && sq_1 < sq_0 &&
-                                    !(step1 <= a.step_tolerance) && !(mx_1 <= a.residual_tolerance) && !(flags & 2u) && sq_2 < sq_1 &&
-                                    !(step2 <= a.step_tolerance) && mx_2 <= a.residual_tolerance && mx_2 < EPS && !isnan(sq_2);
+                const bool stands = fast_verdict(a, sys1, t, flags, lane);
                 if (lane == 0) {
-                    if (stands) {
-                        EzpzStatus st;
-                        st.iterations = 2;
-                        st.converged = 1;
-                        st.n_unsatisfied = 0;
-                        st.n_warnings = 0;
-                        st.final_residual_inf = (a.n_rows_total > 0) ? mx_2 : 0.0;
-                        st.final_lambda = lambda2;
-                        a.status[sys1] = st;
-                    } else {
-                        const unsigned int at_list = __hip_atomic_fetch_add(a.redo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a.redo[1 + at_list] = (unsigned int)sys1;
-                    }
                     gridchunk_t c;
                     c.x = stands ? 1u : 2u, c.y = 0, c.z = q1, c.w = 0;
                     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&gs->ring_v[q1 & 3u][0]), "v"(c) : "memory");
                 }
             }
         }
-        stamp();  // 5: (its turn: the totals of k - 1 taken)
+        stamp();  // 4: (its turn: the totals of k - 1 taken)
         f2 = f1, q2 = q1;
         f1 = have, sys1 = sys, q1 = q0;
     }

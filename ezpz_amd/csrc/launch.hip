@@ -109,6 +109,34 @@ int launch_grid_team(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     return s.linear_only ? launch_grid_kernel<true>(s, args, stream) : launch_grid_kernel<false>(s, args, stream);
 }
 
+// (a launch that is being recorded into a graph never takes the `_fast` entry: its redo list is zeroed by the NEXT call's launches,
+// which a replay does not run)
+bool stream_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
+        (void)hipGetLastError();
+        capturing = hipStreamCaptureStatusNone;
+    }
+    return capturing != hipStreamCaptureStatusNone;
+}
+
+// The two redo lists of a system whose specialised kernel has a `_fast` entry (system.hpp: jit_redo), for `batch` systems, and the
+// mapped word the loop's launch leaves its count in.
+int jit_redo_lists(EzpzSystem& s, uint64_t batch, hipStream_t stream) {
+    for (auto& list : s.jit_redo)
+        if (list.cap < batch + 1) {
+            int rc = list.ensure(batch + 1);  // (synchronises the device: nobody reads the old one any more)
+            if (rc != EZPZ_OK) return rc;
+            HIP_TRY(hipMemsetAsync(list.p, 0, sizeof(unsigned int), stream));
+        }
+    if (!s.jit_redo_seen) {
+        HIP_TRY(hipHostMalloc((void**)&s.jit_redo_seen, sizeof(unsigned int), hipHostMallocMapped));
+        *s.jit_redo_seen = 0;
+        HIP_TRY(hipHostGetDevicePointer((void**)&s.jit_redo_seen_dev, s.jit_redo_seen, 0));
+    }
+    return EZPZ_OK;
+}
+
 // The class-specialised kernel of a system spread over several workgroups (CompPlan::jit_wgs > 1): as many systems in
 // flight as the device holds whole teams of; every workgroup of the launch must be resident (they wait for each other),
 // so launches of this kind are chained like the list-walk grid teams' (launch_grid_kernel).
@@ -128,19 +156,10 @@ int launch_jit_grid(EzpzSystem& s, const CompLaunch& L, hipStream_t stream) {
         if (rc != EZPZ_OK) return rc;
         HIP_TRY(hipMemsetAsync(s.jit_scratch.p, 0, s.jit_scratch.cap, stream));
     }
-    const bool lists = fast_slots && L.batch < (1ull << 32);
+    const bool lists = fast_slots && comp_jit_fast_ok(s.jit, *s.comp, L, s.device, s.lim.cus) && !stream_capturing(stream);
     if (lists) {
-        for (auto& list : s.jit_redo)
-            if (list.cap < L.batch + 1) {
-                int rc = list.ensure(L.batch + 1);  // (synchronises the device: nobody reads the old one any more)
-                if (rc != EZPZ_OK) return rc;
-                HIP_TRY(hipMemsetAsync(list.p, 0, sizeof(unsigned int), stream));
-            }
-        if (!s.jit_redo_seen) {
-            HIP_TRY(hipHostMalloc((void**)&s.jit_redo_seen, sizeof(unsigned int), hipHostMallocMapped));
-            *s.jit_redo_seen = 0;
-            HIP_TRY(hipHostGetDevicePointer((void**)&s.jit_redo_seen_dev, s.jit_redo_seen, 0));
-        }
+        int rc = jit_redo_lists(s, L.batch, stream);
+        if (rc != EZPZ_OK) return rc;
     }
     std::lock_guard<std::mutex> lock(g_grid_mu);
     hipEvent_t& ev = g_grid_event[s.device & 15];
@@ -350,7 +369,18 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             const bool big = args.batch >= pol.jit_comp_min_batch || args.batch * (uint64_t)s.counts.n_vars >= pol.jit_comp_min_values;
             if (st == 0 && (big || sync || s.launches.fetch_add(1) >= pol.jit_after_launches)) st = comp_jit_request(s.jit, sync);
             if (st == 2) {
-                if (s.comp->jit_wgs <= 1) {
+                if (s.comp->jit_wgs <= 1 && comp_jit_fast_ok(s.jit, *s.comp, L, s.device, s.lim.cus) && !stream_capturing(stream) &&
+                    jit_redo_lists(s, L.batch, stream) == EZPZ_OK) {
+                    // a linear system: the kernel that does not wait for the LM control's verdicts, then the loop over the systems it
+                    // lists (jit_kernel.hip.hpp: solve_kernel_fast)
+                    const unsigned int turn = s.jit_redo_turn;
+                    const uint32_t fast_wgs = (uint32_t)std::min<uint64_t>(comp_jit_capacity_fast(s.jit, *s.comp, s.device, s.lim.cus), 0xFFFFFFFFull);
+                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream, nullptr, 0, fast_wgs, s.jit_redo[turn].p,
+                                        s.jit_redo[turn ^ 1u].p, s.jit_redo_seen_dev, s.jit_redo_seen) == EZPZ_OK) {
+                        s.jit_redo_turn = turn ^ 1u;
+                        return EZPZ_OK;
+                    }
+                } else if (s.comp->jit_wgs <= 1) {
                     // a batch beyond the launch's workgroups: the workgroups draw their systems from the system's counter, and
                     // launches that share the counter are chained
                     const uint64_t capacity = L.done.flag ? 0 : comp_jit_capacity(s.jit, *s.comp, s.device, s.lim.cus);

@@ -441,6 +441,21 @@ int ezpz_launch_policy(int compute_units, EzpzLaunchPolicy* out);
  * (tools/solve_call_breakdown.py -> profiles/r04_solve_call_breakdown.txt). */
 size_t ezpz_debug_call_trace(uint64_t* buf, size_t cap);
 
+/* Diagnostic: a device buffer for in-kernel time stamps, NULL to stop (the -DEZPZ_STAMPS builds of the list-walk and frontal
+ * kernels: tools/front_stamps.py; the run-time compiled kernel of a system on several workgroups when the process runs with
+ * EZPZ_JIT_STAMPS=1: tools/ladder_stamps.py).  Not for production callers. */
+void ezpz_debug_set_stamps(unsigned long long* dev_buf);
+
+/* Diagnostic: how this process's FreedomAnalysis calls by null-space probes ended (csrc/freedom.hip: freedom_by_probes): out8[0]
+ * systems decided fully constrained by the first eight probes, [1] decided with null vectors found, [2] calls that took the
+ * second opinion at lambda / 1000; calls handed to the pivoted QR because [3] an answer was not finite, [4] five or more
+ * candidate directions, [5] a direction undecided at both lambdas, [6] an unsettled direction, [7] probes not applicable. */
+void ezpz_debug_freedom_exits(unsigned long long* out8);
+
+/* Diagnostic: run-time compilations (hiprtc) this process has performed so far -- a kernel found in the on-disk cache of code
+ * objects does not count (tests/test_abi_cpu.py::test_code_object_cache_on_disk). */
+unsigned long long ezpz_debug_jit_compilations(void);
+
 /* Diagnostic (host only, no device needed): the symbolic phase of the FRONTAL launch shape (team_mode 5, csrc/fronts.cpp:
  * the supernodal counterpart of faer's SymbolicLlt, solver.rs:289-300) for `wgs` workgroups per system (0 = automatic) on
  * workgroups of `lds_bytes` of LDS.  Copies the plan's device blob into buf (up to cap bytes) and fills info[0..15] =

@@ -390,7 +390,7 @@ def test_code_object_cache_on_disk(tmp_path):
         b = E.textual.Problem.from_str(E.textual.gen_big_problem(lines)).to_constraint_system()
         t = time.perf_counter()
         assert "ezpz_jit_solve" in E.specialized_source(b.records, b.num_vars, compile="cached")
-        print("seconds", time.perf_counter() - t)
+        print("compilations", E.lib().ezpz_debug_jit_compilations())
     """ % ROOT)
     cache = tmp_path / "cache"
 
@@ -398,24 +398,22 @@ def test_code_object_cache_on_disk(tmp_path):
         r = subprocess.run([sys.executable, "-c", script, str(lines)], env=dict(os.environ, EZPZ_JIT_CACHE_DIR=str(cache), **env),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        return float(r.stdout.split()[-1])
+        return int(r.stdout.split()[-1])  # hiprtc compilations of that process (not wall-clock: a loaded machine compiles slowly)
 
-    cold = run(200)
+    assert run(200) == 1  # cold
     files = sorted(os.listdir(cache))
     assert len(files) == 1 and files[0].endswith(".co") and os.path.getsize(cache / files[0]) > 4096
-    warm = run(200)
-    assert sorted(os.listdir(cache)) == files and warm < cold / 4, (cold, warm)
+    assert run(200) == 0 and sorted(os.listdir(cache)) == files  # warm: the kernel comes from the file
     # a damaged file (a flipped byte in the code) is a miss, and the kernel is compiled and stored again
     path = cache / files[0]
     blob = bytearray(path.read_bytes())
     blob[-100] ^= 0xFF
     path.write_bytes(bytes(blob))
-    again = run(200)
-    assert again > 4 * warm and path.read_bytes() != bytes(blob)
+    assert run(200) == 1 and path.read_bytes() != bytes(blob)
     path.write_bytes(bytes(blob[: len(blob) // 2]))  # and a truncated one
-    run(200)
+    assert run(200) == 1
     assert os.path.getsize(path) == len(blob)
-    run(240)  # another topology: its own file
+    assert run(240) == 1  # another topology: its own file
     assert len(os.listdir(cache)) == 2
     off = tmp_path / "off"
     subprocess.run([sys.executable, "-c", script, "200"], env=dict(os.environ, EZPZ_JIT_CACHE_DIR=str(off), EZPZ_JIT_CACHE="0"), check=True,

@@ -38,8 +38,13 @@ def test_launcher_invocation_world_2():
     env = dict(os.environ, EZPZ_BENCH_DRY="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
+    import socket
+
+    with socket.socket() as s:  # a port that is free now (two test sessions on one host used to collide on a fixed one)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29631", BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

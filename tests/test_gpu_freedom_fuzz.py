@@ -1,0 +1,103 @@
+"""FreedomAnalysis by null-space probes (csrc/freedom.hip: freedom_by_probes) is another algorithm than the reference's -- the
+projector onto null(J) applied to random vectors by the frontal factorisation instead of a column-pivoted QR with the rank rule
+|R_ii| > 1e-8 max |R_ii| (find_dof.rs:36-49) -- behind heuristic thresholds (Ritz values, a second opinion at lambda / 1000).  Round
+5's review: pinned by one generator seed.  This fuzz sweeps what could make the two disagree: four graph families x 24 ... 1000
+points x 0 ... 6 constraints dropped x constraints DUPLICATED or NEARLY DEPENDENT (a copy of a constraint with its parameter and
+the point it ties moved by 1e-4 ... 1e-11: a singular value of J swept through the rank decision) x coordinates scaled by 1e-3 ... 1e3.
+Every system: the underconstrained id list equal to the oracle's dense pivoted QR of the same Jacobian (freedom_analysis_dense) --
+whether the probes decided or handed the system to the device's own QR; the exits taken are counted and logged
+(gpurun_out/freedom_probes_fuzz.txt when that directory exists: profiles/r06_freedom_probes_fuzz.txt is that file from the round's
+GPU run)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import gen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FAMILIES = ["tree", "band", "hub", "comb"]
+
+
+@pytest.fixture(scope="module")
+def E():
+    import ezpz_amd
+
+    if ezpz_amd.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device: the product path has no CPU fallback")
+    return ezpz_amd
+
+
+def exits(E):
+    out = (C.c_ulonglong * 8)()
+    E.lib().ezpz_debug_freedom_exits(out)
+    return np.array(list(out), dtype=np.int64)
+
+
+def variant(rng, family, npts, scale, drop, weak, dup, eps):
+    """records, true values: a graph sketch scaled by `scale`; its last `drop` constraints gone, `weak` of them back with weight
+    `eps` -- a degree of freedom held by a row of norm ~eps: a singular value of J swept through the reference's rank decision --
+    and `dup` constraints repeated with weight 1 + eps (dependent rows: the rank must not notice)."""
+    recs, true = gen.graph_sketch(family, npts, rng)
+    recs = recs.copy()
+    recs["param"] *= scale  # (every parameter of these sketches is a length or a coordinate)
+    true = true * scale
+    kept, gone = (recs[:-drop], recs[-drop:]) if drop else (recs, recs[:0])
+    extra = []
+    for c in gone[:weak]:
+        d = c.copy()
+        d["weight"] = eps
+        extra.append(d)
+    for _ in range(dup):
+        d = kept[int(rng.integers(2, len(kept)))].copy()
+        d["weight"] = 1.0 + eps
+        extra.append(d)
+    if extra:
+        kept = np.concatenate([kept, np.array(extra, dtype=recs.dtype)])
+    return kept, true
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_probes_equal_the_pivoted_qr_over_the_fuzz(E, family):
+    rng = np.random.default_rng({"tree": 11, "band": 12, "hub": 13, "comb": 14}[family])
+    before = exits(E)
+    checked = mismatch = 0
+    log = []
+    for npts in (24, 60, 150, 400, 1000):
+        reps = {24: 12, 60: 10, 150: 8, 400: 4, 1000: 2}[npts]
+        for rep in range(reps):
+            scale = float(10.0 ** rng.uniform(-3, 3))
+            drop = int(rng.integers(0, 7))
+            weak = int(rng.integers(0, drop + 1))
+            dup = int(rng.integers(0, 3))
+            eps = float(rng.choice([1e-11, 1e-10, 1e-9, 3e-9, 1e-8, 3e-8, 1e-7, 1e-6, 1e-5, 1e-4]))
+            recs, true = variant(rng, family, npts, scale, drop, weak, dup, eps)
+            n = len(true)
+            sysobj = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY)
+            # at the true layout (consistent: every residual ~0) and at two jittered, re-solved starts
+            X = np.stack([true, true + scale * rng.uniform(-0.01, 0.01, n), true + scale * rng.uniform(-0.01, 0.01, n)])
+            x, st, _ = sysobj.solve_batch(X, E.Config(max_iterations=60))
+            x[0] = true
+            mask, part = sysobj.freedom_batch(x)
+            _, J, _ = sysobj.eval_batch(x)
+            for b in range(len(x)):
+                under, want = O.freedom_analysis_dense(J[b])
+                got = np.nonzero(mask[b])[0].tolist()
+                checked += 1
+                if got != under:
+                    mismatch += 1
+                    log.append(f"MISMATCH {family} npts {npts} rep {rep} system {b}: scale {scale:.3g} drop {drop} weak {weak} dup {dup} eps {eps:g}: "
+                               f"{len(got)} vs oracle {len(under)} underconstrained; fronts {sysobj.info()['front_workgroups']}")
+    took = exits(E) - before
+    names = ["fully constrained by 8 probes", "null vectors found", "second opinions", "QR: not finite", "QR: >= 5 candidates",
+             "QR: undecided at both lambdas", "QR: unsettled", "QR: probes not applicable"]
+    line = f"{family}: {checked} systems, {mismatch} mismatches; exits: " + ", ".join(f"{n} {int(t)}" for n, t in zip(names, took))
+    print(line)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "freedom_probes_fuzz.txt"), "a") as f:
+            f.write(line + "\n" + "".join(l + "\n" for l in log))
+    assert mismatch == 0, "\n".join(log[:10])
+    assert checked >= 100

@@ -7,6 +7,7 @@ stores issued, 3 the barrier, 4 partials published, 5 (workgroup 0) verdict on t
 none (the stamps are the fast path's).
 usage (GPU box): python tools/ladder_stamps.py [lines=50000] [systems=14]"""
 import ctypes as C, os, sys
+os.environ["EZPZ_JIT_STAMPS"] = "1"  # (the kernels compiled with their time stamps)
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 import ezpz_amd as E, gen
