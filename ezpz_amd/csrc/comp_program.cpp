@@ -525,10 +525,10 @@ void emit_class(std::string& o, size_t k, const Class& cl, bool lane = false, co
 
 }  // namespace
 
-// EZPZ_COMP_DEBUG=1 in the environment: say on stderr why a system did not get a component plan.
+// EZPZ_DEBUG=comp in the environment: say on stderr why a system did not get a component plan.
 #define COMP_REJECT(...)                                                            \
     do {                                                                            \
-        static const bool dbg_ = std::getenv("EZPZ_COMP_DEBUG") != nullptr;        \
+        static const bool dbg_ = debug_topic("comp");        \
         if (dbg_) std::fprintf(stderr, "[ezpz comp] no plan: " __VA_ARGS__), std::fputc('\n', stderr); \
         return false;                                                               \
     } while (0)
@@ -982,7 +982,7 @@ struct WaveRows {
 WaveRows wave_row_structure(const Class& cl) {
     WaveRows w;
     auto why = [&](int code) {
-        static const bool dbg = std::getenv("EZPZ_JIT_DEBUG") != nullptr;
+        static const bool dbg = debug_topic("jit");
         if (dbg) std::fprintf(stderr, "[ezpz jit] wave: elimination across lanes not used (check %d)\n", code);
         return w;
     };
@@ -1345,7 +1345,7 @@ bool batch_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, Batc
     plan.o_dg = plan.o_j + plan.zj;
     plan.o_l = plan.o_dg + plan.nv;
     plan.rows = plan.o_l + plan.zlo;
-    if (std::getenv("EZPZ_LANES_DEBUG")) {  // the operation stream by kind: records and items (an item is two loads)
+    if (debug_topic("lanes")) {  // the operation stream by kind: records and items (an item is two loads)
         uint64_t recs[8] = {}, items[8] = {};
         for (uint32_t io = 0; io < plan.n_ops; ++io) {
             const uint32_t w = plan.blob[plan.ops_off + io * kCompRecWords];

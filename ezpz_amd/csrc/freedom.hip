@@ -400,6 +400,9 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
     const size_t n = sys->counts.n_vars;
     constexpr uint32_t m = 8;
     int rc;
+    // (the copies and probe launches below run on the null stream, which waits for hipStreamPerThread: a kernel of the calling
+    // thread's one-call path that sits there waiting for its next request is told to leave first)
+    release_thread_kernel(sys->device);
     if ((rc = F.x_in.ensure(batch * n)) != EZPZ_OK) return rc;
     if ((rc = F.probe.ensure(batch * m * n)) != EZPZ_OK) return rc;
     if ((rc = F.probe_w.ensure(batch * m * n)) != EZPZ_OK) return rc;
@@ -549,6 +552,40 @@ int freedom_by_probes(EzpzSystem* sys, const double* x, size_t batch, uint8_t* u
                 kdim[b] = kept;
             }
             break;
+        }
+    }
+    // ---- what the probes call a null vector must be one by the REFERENCE's measure -------------------------------------------------
+    // The probes tell sigma = 0 from sigma > 3e-6 x J's largest entry; a direction held by a WEAK row -- a singular value within
+    // ~1e-10 ... 3e-6 of the largest -- is answered like a null vector (the operator's own rounding is 1e-5), while the reference
+    // counts it as rank whenever its pivot exceeds 1e-8 of the largest (find_dof.rs:36-49): tests/test_gpu_freedom_fuzz.py found
+    // every such disagreement at weights 3e-8 ... 1e-6.  ||J v|| is exact to ~1e-16 x ||J||: a kept direction with ||J v|| above
+    // 1e-10 of J's largest column norm (the reference's scale: its first pivot) hands the system to the pivoted QR, which makes the
+    // reference's decision the reference's way; below, every pivot of that direction is a hundred times under its threshold.
+    {
+        bool any_kept = false;
+        for (size_t b = 0; b < batch; ++b) any_kept = any_kept || kdim[b] != 0;
+        if (any_kept) {
+            if ((rc = ensure_program(sys)) != EZPZ_OK) return rc;
+            const size_t zj = sys->counts.zj, mrows = sys->counts.n_rows;
+            std::vector<double> rr(batch * std::max<size_t>(mrows, 1)), jv(batch * std::max<size_t>(zj, 1)), y(mrows), col2(n);
+            if ((rc = eval_batch_locked(sys, x, batch, rr.data(), jv.data(), nullptr)) != EZPZ_OK) return rc;
+            for (size_t b = 0; b < batch; ++b) {
+                if (!kdim[b]) continue;
+                const double* jb = jv.data() + b * zj;
+                std::fill(col2.begin(), col2.end(), 0.0);
+                for (size_t s2 = 0; s2 < zj; ++s2) col2[sys->host_slot_col[s2]] += jb[s2] * jb[s2];
+                double scale2 = 0.0;
+                for (double c : col2) scale2 = std::max(scale2, c);
+                for (uint32_t t = 0; t < kdim[b]; ++t) {
+                    const double* v = V.data() + b * m * n + (size_t)t * n;
+                    std::fill(y.begin(), y.end(), 0.0);
+                    for (size_t s2 = 0; s2 < zj; ++s2) y[sys->host_slot_row[s2]] += jb[s2] * v[sys->host_slot_col[s2]];
+                    double jv2 = 0.0;
+                    for (double e : y) jv2 += e * e;
+                    if (!(jv2 <= 1e-20 * scale2))
+                        return give_up("a kept direction is held by a singular value above 1e-10 of J's largest column norm: the reference's rank rule decides", 5);
+                }
+            }
         }
     }
     // ---- participation = squared row norms of the null vectors (find_dof.rs:90-103) ---------------------------------------------------

@@ -13,6 +13,7 @@
 #include <queue>
 
 #include "kinds.hpp"
+#include "policy.hpp"
 
 namespace ezpz {
 
@@ -187,7 +188,7 @@ static bool plan_once(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, cons
     out = FrontPlan();
     if (n_cs == 0 || n_vars == 0 || n_cs > 0x3FFFFFFFu || n_vars > 0x3FFFFFFFu) return fail(why, "empty or oversized system");
     const uint32_t n = (uint32_t)n_vars, C = (uint32_t)n_cs;
-    static const bool debug = std::getenv("EZPZ_FRONT_DEBUG") != nullptr;
+    static const bool debug = debug_topic("front");
 
     // ---- rows and Jacobian slots, numbered as build_program numbers them (constraint order; equal columns of a row share a
     //      slot: solver.rs:255-260, :418) ---------------------------------------------------------------------------------
@@ -1126,7 +1127,7 @@ extern "C" long ezpz_debug_front_plan(const EzpzConstraint* cs, size_t n_cs, siz
     ezpz::FrontPlan plan;
     const char* why = nullptr;
     if (!ezpz::front_plan_build(cs, n_cs, n_vars, opt, plan, &why)) {
-        if (std::getenv("EZPZ_FRONT_DEBUG")) std::fprintf(stderr, "front plan: not applicable: %s\n", why ? why : "?");
+        if (ezpz::debug_topic("front")) std::fprintf(stderr, "front plan: not applicable: %s\n", why ? why : "?");
         return 0;
     }
     if (info) {

@@ -1081,24 +1081,6 @@ __device__ __forceinline__ void store_at(__amdgpu_buffer_rsrc_t row, uint32_t by
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufword2_t, v), row, (int)byte_offset, 0, 0);
 }
 
-// VERDICTS NOT WAITED FOR -- a LINEAR system with unit weights on several workgroups (the ladder).  What the verdicts of such a system
-// decide is almost always the same -- not converged at the start, pivots fine, step accepted, not converged, step accepted,
-// converged: 2 iterations (README.md:36-38) -- and a step needs nothing of the SYSTEM but lambda, which those verdicts fix
-// (newton.rs:118-123: x 0.1 per accepted step).  So every workgroup takes both steps on its own share, STORES the values that
-// result, publishes its eight partial sums / maxima (eval(), and per step: sum of squares, largest residual, step norm, failed
-// pivot) as one 128-byte line of self-validating chunks, and goes on to the next system with empty hands.  One system later (the
-// lines are all there by then: no wait) ONE workgroup -- they take turns: sequence number mod G -- gathers the lines, makes the
-// reference's decisions in the reference's order on the system's totals (newton.rs:50-60, :93-99, :118-139, lib.rs:305-327) and,
-// if they are the expected ones, writes the status: iterations 2, converged, nothing unsatisfied.  Any other outcome (converged
-// earlier, a failed pivot, a rejected step, the step tolerance met, not converged after two, a residual at or above EPSILON) puts
-// the system on the launch's REDO LIST (JitArgs::redo), which the launch of solve_kernel_grid that follows on the stream solves
-// from the caller's guesses with every verdict waited for -- so x0 must not be the buffer the values were stored to (the host
-// runs that kernel alone when they overlap), and the arithmetic of the expected path is that kernel's operation for operation:
-// the same bits (tests/test_gpu_components.py: every exit, mixed in one launch).
-// Nothing waits in the steady state: a system costs a workgroup its loads (asked for a system ahead), ~600 vector instructions per
-// wavefront, one barrier, its stores, and every G-th time a turn at the totals.  A kernel of its own because it needs a third of
-// the registers of the loop (no r_next, no step kept across a rendezvous, nothing of the general evaluators): more systems in
-// flight.  The only wait left is flow control: a workgroup may be four systems ahead of the totals (the ring's depth).
 // ---- what the kernels that do not wait for the LM control's verdicts share (solve_kernel_fast, solve_kernel_grid_fast) -----------
 // A wavefront's slots for those kernels: the caller's variable ids as BYTE offsets (n_row < 2^29: the host), the instances'
 // parameters, and the factorisation of every class at the two lambdas of the expected path -- J^T J + lambda I of a linear class is
@@ -1149,19 +1131,29 @@ __device__ __forceinline__ void fast_factor(SEQ& seq, const JitArgs& a) {
 // iterations taken for accepted -- the loop's two passes (newton.rs:73-116), x += d, r = r_next.  SLOT BY SLOT: one slot's x, d and
 // r are live at a time, and the place of a slot's guesses is free for those of the wavefront's NEXT system (`sys_n`, if `next`),
 // asked for a whole system ahead of their use, as soon as it has read them.  The sums run over the slots in the loop's order:
-// the same bits.  Leaves in v[], in the wavefront's last lane: sum r0^2, sum r1^2, sum r2^2 | max|r0|, max|r1|, |d1|, max|r2|, |d2|;
-// returns bit 0 / 1: a pivot failed in the first / second step, bit 2: an operand outside the short division's range (almost
-// never: the system goes on the redo list, where C::solve_exact divides plainly).
+// the same bits.  Leaves in v[], in the wavefront's last lane: sum r0^2, sum r1^2, sum r2^2, max|r2| -- what the verdict needs as
+// NUMBERS (the accept tests compare sums, the status reports max|r2|).  The other four maxima of the LM control (max|r0|, |d1|,
+// max|r1|, |d2|) are only ever compared with a tolerance (newton.rs:50-60, :134-139), and `max > tol` is `any lane's > tol`: they
+// travel as two bits each instead of a cross-lane reduction of a double (20 instructions apiece, a fifth of the kernel's):
+// kFastGt << 2 k: some value exceeded the tolerance, kFastFin << 2 k: some value was not NaN (the maxima ignore NaNs:
+// newton.rs:53,:108 -- a maximum of NaNs only is NaN, and NaN <= tol is false).  Bits 0 / 1: a pivot failed in the first / second
+// step, bit 2: an operand outside the short division's range (almost never: the system goes on the redo list, where
+// C::solve_exact divides plainly).
+constexpr unsigned int kFastGt = 8u, kFastFin = 16u;  // (k = 0: max|r0|, 1: |d1|, 2: max|r1|, 3: |d2|)
+__device__ __forceinline__ bool fast_exceeds(unsigned int flags, int k) {  // !(maximum k <= its tolerance), as the loop tests it
+    return (flags & (kFastGt << (2 * k))) != 0 || (flags & (kFastFin << (2 * k))) == 0;
+}
 template <bool STAGE, class SEQ>
 __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, const uint64_t sys, const uint64_t sys_n, const bool next,
-                                                  const uint32_t wave_global, const int lane, double (&v)[8], double* const out_lds) {
+                                                  const uint32_t wave_global, const int lane, double (&v)[4], double* const out_lds) {
     using namespace ezpz::dev;
     const __amdgpu_buffer_rsrc_t xo = row_at(a.x_out + sys * a.n_row);
     const __amdgpu_buffer_rsrc_t x0n = row_at(a.x0 + (next ? sys_n : sys) * a.n_row);
     uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
     const __amdgpu_buffer_rsrc_t table = row_at(a.blob);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = i < 3 ? 0.0 : __builtin_nan("");
+    v[0] = v[1] = v[2] = 0.0;
+    v[3] = __builtin_nan("");
+    double m[4] = {__builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};  // this lane's max|r0|, |d1|, max|r1|, |d2|
     bool lane_bad1 = false, lane_bad2 = false, lane_redo = false;
     int var0 = 0;
     seq.each([&](auto& s, auto* cls, int index) {
@@ -1175,10 +1167,10 @@ __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, co
         }
         unsigned long long wm = 0;
         {
-            double sq_s = v[0], mx_s = v[3];
+            double sq_s = v[0], mx_s = m[0];
             C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
             v[0] = s.active ? sq_s : v[0];
-            v[3] = s.active ? mx_s : v[3];
+            m[0] = s.active ? mx_s : m[0];
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -1187,7 +1179,7 @@ __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, co
             C::solve_f(f.F[st], s.r, s.d, cd, ok);
             const bool cb = f.fbad[st];
             lane_redo = lane_redo || (s.active && !ok && !cb);
-            double& dmax = v[st == 0 ? 5 : 7];
+            double& dmax = m[1 + 2 * st];
             const double dm = fmax_nc(dmax, cd);
             dmax = s.active ? dm : dmax;
             if (st == 0)
@@ -1196,10 +1188,11 @@ __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, co
                 lane_bad2 = lane_bad2 || (s.active && cb);
 #pragma unroll
             for (int i = 0; i < C::NV; ++i) s.x[i] = s.x[i] + s.d[i];
-            double sq_s = v[1 + st], mx_s = v[st == 0 ? 4 : 6];
+            double& mx = st == 0 ? m[2] : v[3];
+            double sq_s = v[1 + st], mx_s = mx;
             C::residuals(s.x, s.par, s.r, true, sq_s, mx_s, wm);
             v[1 + st] = s.active ? sq_s : v[1 + st];
-            v[st == 0 ? 4 : 6] = s.active ? mx_s : v[st == 0 ? 4 : 6];
+            mx = s.active ? mx_s : mx;
         }
         if (mask) {
             const uint32_t pos_off = __builtin_amdgcn_readfirstlane(a.blob[a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index) + 2]);
@@ -1238,14 +1231,21 @@ __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, co
         var0 += C::NV;
     });
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = i < 3 ? reduce_wave_to_last_lane(v[i], OpSum()) : reduce_wave_to_last_lane(v[i], OpMax());
-    return (__ballot(lane_bad1) != 0 ? 1u : 0u) | (__ballot(lane_bad2) != 0 ? 2u : 0u) | (__ballot(lane_redo) != 0 ? 4u : 0u);
+    for (int i = 0; i < 4; ++i) v[i] = i < 3 ? reduce_wave_to_last_lane(v[i], OpSum()) : reduce_wave_to_last_lane(v[i], OpMax());
+    unsigned int flags = (__ballot(lane_bad1) != 0 ? 1u : 0u) | (__ballot(lane_bad2) != 0 ? 2u : 0u) | (__ballot(lane_redo) != 0 ? 4u : 0u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double tol = (k & 1) ? a.step_tolerance : a.residual_tolerance;
+        flags |= (__ballot(m[k] > tol) != 0 ? kFastGt << (2 * k) : 0u) | (__ballot(m[k] == m[k]) != 0 ? kFastFin << (2 * k) : 0u);
+    }
+    return flags;
 }
-// The reference's decisions in the reference's order on a system's totals -- lane i < 8 of the calling wavefront holds value i of
-// fast_wave's list, `flags` its bits for the system (bit 2 also: a workgroup's line never came) -- : eval() and the top of iteration 0
-// (newton.rs:45-60), its step (:93-99, :118-139), the top of iteration 1, its step, the top of iteration 2 (max_iterations >= 3, says
-// the host: the limit is not what ends it), every constraint satisfied (lib.rs:305-327: unit weights, r is at x).  If they are the
-// expected ones, lane 0 writes the status; if not, it puts the system on the redo list.  Returns whether they were.
+// The reference's decisions in the reference's order on a system's totals -- lane i < 4 of the calling wavefront holds value i of
+// fast_wave's list, `flags` the OR of its bits over the system (bit 2 also: a workgroup's line never came) -- : eval() and the top of
+// iteration 0 (newton.rs:45-60), its step (:93-99, :118-139), the top of iteration 1, its step, the top of iteration 2
+// (max_iterations >= 3, says the host: the limit is not what ends it), every constraint satisfied (lib.rs:305-327: unit weights,
+// r is at x).  If they are the expected ones, lane 0 writes the status; if not, it puts the system on the redo list.  Returns
+// whether they were.
 __device__ __forceinline__ bool fast_verdict(const JitArgs& a, const uint64_t sys, const double t, const unsigned int flags, const int lane) {
     using namespace ezpz::dev;
     auto at = [&](int src_lane) {
@@ -1253,11 +1253,11 @@ __device__ __forceinline__ bool fast_verdict(const JitArgs& a, const uint64_t sy
         const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, src_lane), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), src_lane);
         return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     };
-    const double sq_0 = at(0), sq_1 = at(1), sq_2 = at(2), mx_0 = at(3), mx_1 = at(4), dm_1 = at(5), mx_2 = at(6), dm_2 = at(7);
-    const double step1 = (a.n_row > 0) ? dm_1 : 0.0, step2 = (a.n_row > 0) ? dm_2 : 0.0;
-    const bool stands = !(flags & 4u) && !(mx_0 <= a.residual_tolerance) && !(flags & 1u) && sq_1 < sq_0 && !(step1 <= a.step_tolerance) &&
-                        !(mx_1 <= a.residual_tolerance) && !(flags & 2u) && sq_2 < sq_1 && !(step2 <= a.step_tolerance) &&
-                        mx_2 <= a.residual_tolerance && mx_2 < EPS && !isnan(sq_2);
+    const double sq_0 = at(0), sq_1 = at(1), sq_2 = at(2), mx_2 = at(3);
+    // (a system without variables has step norm 0 <= any tolerance in the loop: n_row > 0 here, a plan has variables)
+    const bool stands = !(flags & 4u) && fast_exceeds(flags, 0) && !(flags & 1u) && sq_1 < sq_0 && fast_exceeds(flags, 1) &&
+                        fast_exceeds(flags, 2) && !(flags & 2u) && sq_2 < sq_1 && fast_exceeds(flags, 3) &&
+                        mx_2 <= a.residual_tolerance && mx_2 < EPS && !isnan(sq_2) && a.n_row > 0;
     if (lane == 0) {
         if (stands) {
             EzpzStatus st;
@@ -1293,19 +1293,19 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     fast_setup(seq, a, wave, lane);
     if (blockIdx.x < a.batch) fast_fetch(seq, a, blockIdx.x);
     fast_factor(seq, a);
-    __shared__ double fast_part[2][8 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
+    __shared__ double fast_part[2][4 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
     __shared__ int fast_pflag[2][16];
     __shared__ double fast_out[NWAVES * SEQ::NVS * 64];  // per wavefront: a system's values on their way out (fast_wave)
     unsigned int kp = 0;
     for (uint64_t sys = blockIdx.x; sys < a.batch; sys += gridDim.x, kp ^= 1u) {
         const uint64_t sys_n = sys + gridDim.x;
-        double v[8];
+        double v[4];
         const unsigned int wave_flags = fast_wave<true>(seq, a, sys, sys_n, sys_n < a.batch, wave, lane, v, fast_out + wave * (SEQ::NVS * 64));
         if constexpr (NWAVES == 1) {
             // (lane i <- value i from the last lane)
             double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const unsigned long long u = __builtin_bit_cast(unsigned long long, v[i]);
                 const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)u, 63), hi = __builtin_amdgcn_readlane((unsigned int)(u >> 32), 63);
                 const double x = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
@@ -1315,12 +1315,12 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
         } else {
             if (lane == 63) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) fast_part[kp][16 * i + wave] = v[i];
+                for (int i = 0; i < 4; ++i) fast_part[kp][16 * i + wave] = v[i];
                 fast_pflag[kp][wave] = (int)wave_flags;
             }
             __syncthreads();
             if (wave == 0) {
-                const int i = lane & 7;
+                const int i = lane & 3;
                 double t = fast_part[kp][16 * i];
                 unsigned int fl = (unsigned int)fast_pflag[kp][0];
 #pragma unroll
@@ -1336,6 +1336,24 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     }
 }
 
+// VERDICTS NOT WAITED FOR -- a LINEAR system with unit weights on several workgroups (the ladder).  What the verdicts of such a system
+// decide is almost always the same -- not converged at the start, pivots fine, step accepted, not converged, step accepted,
+// converged: 2 iterations (README.md:36-38) -- and a step needs nothing of the SYSTEM but lambda, which those verdicts fix
+// (newton.rs:118-123: x 0.1 per accepted step).  So every workgroup takes both steps on its own share, STORES the values that
+// result, publishes what the verdict needs of it (fast_wave: three sums of squares, the last maximum, and the other maxima and
+// flags as bits) as four self-validating chunks of one line, and goes on to the next system with empty hands.  One system later (the
+// lines are all there by then: no wait) ONE workgroup -- they take turns: sequence number mod G -- gathers the lines, makes the
+// reference's decisions in the reference's order on the system's totals (newton.rs:50-60, :93-99, :118-139, lib.rs:305-327) and,
+// if they are the expected ones, writes the status: iterations 2, converged, nothing unsatisfied.  Any other outcome (converged
+// earlier, a failed pivot, a rejected step, the step tolerance met, not converged after two, a residual at or above EPSILON) puts
+// the system on the launch's REDO LIST (JitArgs::redo), which the launch of solve_kernel_grid that follows on the stream solves
+// from the caller's guesses with every verdict waited for -- so x0 must not be the buffer the values were stored to (the host
+// runs that kernel alone when they overlap), and the arithmetic of the expected path is that kernel's operation for operation:
+// the same bits (tests/test_gpu_components.py: every exit, mixed in one launch).
+// Nothing waits in the steady state: a system costs a workgroup its loads (asked for a system ahead), ~600 vector instructions per
+// wavefront, one barrier, its stores, and every G-th time a turn at the totals.  A kernel of its own because it needs a third of
+// the registers of the loop (no r_next, no step kept across a rendezvous, nothing of the general evaluators): more systems in
+// flight.  The only wait left is flow control: a workgroup may be four systems ahead of the totals (the ring's depth).
 template <class SEQ, int NWAVES>
 __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
     using namespace ezpz::dev;
@@ -1350,8 +1368,8 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
     fast_setup(seq, a, wave_global, lane);
     if (grid_slot < a.batch) fast_fetch(seq, a, grid_slot);  // (the guesses of the first system; every later one's a system ahead)
     fast_factor(seq, a);
-    constexpr int GROUPS = NWAVES * 8;       // a turn at the totals: thread = (value tid & 7, group tid >> 3)
-    __shared__ double fast_part[2][8 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
+    constexpr int GROUPS = NWAVES * 16;      // a turn at the totals: thread = (value tid & 3, group tid >> 2)
+    __shared__ double fast_part[2][4 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
     __shared__ int fast_pflag[2][16];
     __shared__ double fast_gath[NWAVES * 64];  // the gather's first fold
     __shared__ int fast_gflag[NWAVES * 64];
@@ -1399,12 +1417,12 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
         asm volatile("" : "+s"(gs));
         if (have) {
             const uint64_t sys_n = sys + n_slots;
-            double v[8];
+            double v[4];
             const unsigned int wave_flags = fast_wave<false>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, nullptr);
             stamp();  // 1: both steps taken, stores issued
             if (lane == 63) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) fast_part[kp][16 * i + wave] = v[i];
+                for (int i = 0; i < 4; ++i) fast_part[kp][16 * i + wave] = v[i];
                 fast_pflag[kp][wave] = (int)wave_flags;
             }
         }
@@ -1426,7 +1444,7 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
         if (have) {  // wavefront 0 folds the wavefronts' partials (lane = value) and publishes them
             q0 = ++ring_q;
             if (wave == 0) {
-                const int i = lane & 7;
+                const int i = lane & 3;
                 double t = fast_part[kp][16 * i];
                 unsigned int fl = (unsigned int)fast_pflag[kp][0];
 #pragma unroll
@@ -1436,13 +1454,13 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
                     t = i < 3 ? sum : mxm;
                     fl |= (unsigned int)fast_pflag[kp][w2];
                 }
-                if (lane < 8) put(&gs->ring_p[q0 & 3u][grid_wg][lane], t, lane == 0 ? fl : 0u, q0);
+                if (lane < 4) put(&gs->ring_p[q0 & 3u][grid_wg][lane], t, lane == 0 ? fl : 0u, q0);
             }
         }
         stamp();  // 3: published
         // ---- this workgroup's turn: the totals of system k - 1 and the reference's verdict on them ------------------------------------
         if (f1 && q1 % grid_wgs == grid_wg) {
-            const int i = tid & 7, j = tid >> 3;
+            const int i = tid & 3, j = tid >> 2;
             double acc = i < 3 ? 0.0 : __builtin_nan("");
             unsigned int fl = 0;
             bool dead = false;
@@ -1487,14 +1505,14 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
                 double t = fast_gath[i];
                 unsigned int fl2 = (unsigned int)fast_gflag[i];
                 for (int jj = 1; jj < GROUPS; ++jj) {
-                    const double o = fast_gath[i + 8 * jj];
+                    const double o = fast_gath[i + 4 * jj];
                     const double sum = t + o, mxm = fmax_nc(t, o);
                     t = i < 3 ? sum : mxm;
-                    fl2 |= (unsigned int)fast_gflag[i + 8 * jj];
+                    fl2 |= (unsigned int)fast_gflag[i + 4 * jj];
                 }
                 unsigned int flags = 0;
 #pragma unroll
-                for (int l2 = 0; l2 < 8; ++l2) flags |= (unsigned int)__builtin_amdgcn_readlane((int)fl2, l2);
+                for (int l2 = 0; l2 < 4; ++l2) flags |= (unsigned int)__builtin_amdgcn_readlane((int)fl2, l2);
                 const bool stands = fast_verdict(a, sys1, t, flags, lane);
                 if (lane == 0) {
                     gridchunk_t c;

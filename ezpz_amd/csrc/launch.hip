@@ -598,6 +598,13 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
     if (int rc0 = ensure_program(sys)) return rc0;
     std::lock_guard<std::mutex> lock(sys->mu);
     EZPZ_ON_DEVICE(sys->device);
+    return ezpz::eval_batch_locked(sys, x, batch, r_out, jv_out, degenerate_count_out);
+}
+
+}  // extern "C"
+
+// (the caller holds sys->mu, the system's device is current and its program is there: ensure_program)
+int ezpz::eval_batch_locked(EzpzSystem* sys, const double* x, size_t batch, double* r_out, double* jv_out, uint32_t* degenerate_count_out) {
     const size_t n = sys->counts.n_vars, m = sys->counts.n_rows, zj = sys->counts.zj;
     DevBuf<double> xd, rd, jd;
     DevBuf<uint32_t> dd;
@@ -629,6 +636,8 @@ int ezpz_system_eval_batch(EzpzSystem* sys, const double* x, size_t batch, doubl
         HIP_TRY(hipMemcpy(degenerate_count_out, dd.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return EZPZ_OK;
 }
+
+extern "C" {
 
 
 }  // extern "C"

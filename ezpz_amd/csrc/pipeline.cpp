@@ -168,7 +168,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
             }
             return result;
         };
-        static const bool h2h_debug = std::getenv("EZPZ_H2H_DEBUG") != nullptr;
+        static const bool h2h_debug = debug_topic("h2h");
         // How the results leave: copies by the runtime (hipMemcpyAsync), or a copy kernel of ours into the registered buffer's
         // device address (EZPZ_H2H_OUT=dma / kernel).  Both directions as runtime copies is the fastest pair where the
         // runtime gives each direction an SDMA engine (46-48 GB/s each way, ROCm 7.2); the runtime PyTorch bundles (7.0)
@@ -244,13 +244,14 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
     const size_t row_bytes = std::max<size_t>(n, 1) * sizeof(double);
     const size_t piece = std::max<size_t>(1, std::min<size_t>(batch, (16u << 20) / row_bytes));
     if ((rc = sys->x_dev.ensure(piece * std::max<size_t>(n, 1))) != EZPZ_OK) return rc;
+    if ((rc = sys->xo_dev.ensure(piece * std::max<size_t>(n, 1))) != EZPZ_OK) return rc;
     if ((rc = sys->st_dev.ensure(piece)) != EZPZ_OK) return rc;
     if (unsat_mask && (rc = sys->mask_dev.ensure(piece * std::max<size_t>(C, 1))) != EZPZ_OK) return rc;
     if (want_log && (rc = sys->log_dev.ensure(piece * (size_t)warn_cap)) != EZPZ_OK) return rc;
     for (size_t off = 0; off < batch; off += piece) {
         const size_t nb = std::min(piece, batch - off);
         if (n) HIP_TRY(hipMemcpy(sys->x_dev.p, x0 + off * n, nb * n * sizeof(double), hipMemcpyHostToDevice));
-        rc = ezpz_system_solve_batch_device(sys, sys->x_dev.p, nb, cfg, sys->x_dev.p, sys->st_dev.p,
+        rc = ezpz_system_solve_batch_device(sys, sys->x_dev.p, nb, cfg, sys->xo_dev.p, sys->st_dev.p,
                                             unsat_mask ? sys->mask_dev.p : nullptr, want_log ? sys->log_dev.p : nullptr,
                                             warn_cap, nullptr);
         if (rc != EZPZ_OK) return rc;
@@ -258,7 +259,7 @@ int ezpz_system_solve_batch(EzpzSystem* sys, const double* x0, size_t batch, con
         if (can_time_out(*sys))
             for (size_t b2 = 0; b2 < nb; ++b2)
                 if (status[off + b2].iterations == EZPZ_ITERATIONS_TEAM_TIMEOUT) return EZPZ_ERR_HIP;
-        if (n) HIP_TRY(hipMemcpy(x_out + off * n, sys->x_dev.p, nb * n * sizeof(double), hipMemcpyDeviceToHost));
+        if (n) HIP_TRY(hipMemcpy(x_out + off * n, sys->xo_dev.p, nb * n * sizeof(double), hipMemcpyDeviceToHost));
         if (unsat_mask && C) HIP_TRY(hipMemcpy(unsat_mask + off * C, sys->mask_dev.p, nb * C, hipMemcpyDeviceToHost));
         if (want_log) {
             // the log's capacity is sized for the worst case (every constraint warning in every sweep): bring back only

@@ -6,12 +6,29 @@
 // -- CPX / DPX -- or a CU-masked process sees fewer), the others are properties of one workgroup / one CU's LDS and do not
 // scale.  tests/test_abi_cpu.py pins the table (the 256-CU values and the scaling).
 #pragma once
+#include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <cstdint>
 
 #include "../../include/ezpz_amd.h"
 
 namespace ezpz {
+
+// Diagnostics on stderr, one switch for all of them: EZPZ_DEBUG=<topic>[,<topic>...] or EZPZ_DEBUG=all -- topics: hip (failing
+// runtime calls), comp (why a system got no component plan), jit (compilation logs, the wavefront kernel's elimination), lanes
+// (the lanes-across-the-batch operation stream), front (the frontal plan), dense (dense phases), rec (the record walk), h2h (the
+// host-to-host pipeline).  (Round 5 had eight environment switches for this.)
+inline bool debug_topic(const char* topic) {
+    const char* e = std::getenv("EZPZ_DEBUG");
+    if (!e || !*e) return false;
+    if (!std::strcmp(e, "all") || !std::strcmp(e, "1")) return true;
+    const size_t n = std::strlen(topic);
+    for (const char* p = e; (p = std::strstr(p, topic)) != nullptr; p += n)
+        if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+    return false;
+}
+
 
 inline EzpzLaunchPolicy launch_policy_for(int compute_units) {
     const uint64_t cus = (uint64_t)std::max(compute_units, 1);

@@ -608,7 +608,7 @@ bool make_dense_phases(Program& P, uint32_t n_waves, size_t lds_room_bytes) {
         phases.push_back(Phase{la, lb, std::move(best)});
     }
     std::reverse(phases.begin(), phases.end());  // in the order they run
-    if (std::getenv("EZPZ_DENSE_DEBUG")) {
+    if (debug_topic("dense")) {
         for (const Phase& ph : phases) {
             std::fprintf(stderr, "dense phase: levels [%u, %u) of %u:", ph.la, ph.lb, nlev);
             for (const Block& b : ph.blocks) std::fprintf(stderr, " %zu cols + %zu rows below;", b.cols.size(), b.below.size());

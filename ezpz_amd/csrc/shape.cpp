@@ -473,7 +473,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
                     s.front_max_batch = std::min<uint64_t>(std::max<uint64_t>(1, cus / G) * rounds, 0xFFFFFFFEull);
                 }
                 s.fronts = std::move(plan);
-            } else if (std::getenv("EZPZ_FRONT_DEBUG")) {
+            } else if (debug_topic("front")) {
                 std::fprintf(stderr, "front plan: not taken: %s\n", why ? why : "?");
             }
         }
@@ -653,7 +653,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             s.dense_lds_off = (uint32_t)((s.lds_bytes + 15) / 16 * 2);
             s.lds_bytes = (size_t)s.dense_lds_off * 8 + (size_t)P.dense_lds_doubles * 8 * teams;
         } else {
-            if (std::getenv("EZPZ_DENSE_DEBUG"))
+            if (debug_topic("dense"))
                 std::fprintf(stderr, "dense phases: mode %d -> %d, threads %u, lds %zu + %zu x %u of %zu\n", mode_before, (int)s.mode,
                              s.block_threads, s.lds_bytes, (size_t)P.dense_lds_doubles * 8, teams, s.lim.lds_bytes);
             be.code = EZPZ_ERR_TOO_LARGE;  // cannot happen: the same program with shorter lists
@@ -669,7 +669,7 @@ int analyze_into(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, uint32_t 
             s.rec_asm_cols_off = append(blob, rec.asm_cols);
             s.rec_asm_slots_off = append(blob, rec.asm_slots);
         }
-        if (std::getenv("EZPZ_REC_DEBUG"))
+        if (debug_topic("rec"))
             std::fprintf(stderr, "record walk: %u rounds on %u lanes, %zu KB of descriptors, %zu KB of records\n", rec.rounds, s.team_size,
                          rec.desc.size() * 4 / 1024, rec.chunks.size() * 4 / 1024);
     }

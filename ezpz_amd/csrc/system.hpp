@@ -67,9 +67,9 @@ inline const DeviceLimits& device_limits(int device) {
     return cache[device];
 }
 
-// (EZPZ_HIP_DEBUG=1: the failing call and the runtime's message on stderr)
+// (EZPZ_DEBUG=hip: the failing call and the runtime's message on stderr)
 inline bool hip_debug() {
-    static const bool on = std::getenv("EZPZ_HIP_DEBUG") != nullptr;
+    static const bool on = debug_topic("hip");
     return on;
 }
 #define HIP_TRY(expr)                                                                                             \
@@ -244,6 +244,8 @@ struct EzpzSystem {
     // grow-only scratch for the host-pointer entry points
     std::mutex mu;
     DevBuf<double> x_dev;
+    DevBuf<double> xo_dev;  // ... and their results (pageable host buffers: out of place, so that a linear block system's call may take
+                            // the kernel that stores its values before the LM control's verdicts are in, jit_kernel.hip.hpp)
     DevBuf<EzpzStatus> st_dev;
     DevBuf<uint8_t> mask_dev;
     DevBuf<uint64_t> log_dev;
@@ -384,6 +386,9 @@ void launch_copy_out(void* dst_host_as_device, const void* src_dev, size_t bytes
 
 // ---- api.hip ----------------------------------------------------------------------------------------------------------------
 int ensure_program(EzpzSystem* sys);  // the rest of a deferred analysis (EzpzSystem::program_deferred)
+// ezpz_system_eval_batch for a caller that holds sys->mu already (launch.hip; FreedomAnalysis by probes checks its null vectors
+// against the Jacobian)
+int eval_batch_locked(EzpzSystem* sys, const double* x, size_t batch, double* r_out, double* jv_out, uint32_t* degenerate_count_out);
 
 // ---- pipeline.cpp -----------------------------------------------------------------------------------------------------------
 bool host_range_registered(const void* p, size_t bytes);  // inside a range the caller registered (ezpz_host_register)

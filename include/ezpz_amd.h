@@ -235,9 +235,17 @@ int ezpz_system_jacobian_pattern(const EzpzSystem* sys, uint32_t* rows, uint32_t
 /* ---- numeric phase -------------------------------------------------------------------------------
  * Replaces Model::solve_levenberg_marquardt (ezpz/src/solver/newton.rs:29-145) followed by the
  * unsatisfied check of solve_inner (ezpz/src/lib.rs:305-327), for `batch` independent systems that
- * share the analysed topology.  x0 / x_out are AoS [batch][n_vars] and may alias.  unsat_mask is
- * optional ([batch][n_cs] bytes, 1 = unsatisfied, indexed by position in `cs`); warn_log is optional
+ * share the analysed topology.  x0 / x_out are AoS [batch][n_vars] and may alias -- but a block system of linear constraints
+ * with unit weights (massive_parallel_system) is solved ~20 % faster when they do not overlap: its kernel stores a system's
+ * values before the verdicts of the LM control are in and re-solves the few systems whose verdicts are not the expected ones
+ * from x0 (csrc/jit_kernel.hip.hpp: solve_kernel_fast); with overlapping buffers the loop kernel serves, same results.
+ * unsat_mask is optional ([batch][n_cs] bytes, 1 = unsatisfied, indexed by position in `cs`); warn_log is optional
  * ([batch][warn_cap] entries (pass << 32 | position), chronological once sorted).
+ * Which kernel serves a call may depend on the call's size (EzpzSystemInfo.front_max_batch: small calls of a connected
+ * sketch take the frontal elimination order, larger ones the record walk or the lanes): integer and flag outputs are the
+ * reference's either way, coordinates of connected sketches agree to rounding (1e-6 relative on determined coordinates), not
+ * bit for bit across call sizes -- a caller who chunks a batch itself and needs identical bits per chunk size creates the system
+ * with one shape (team_size: EZPZ_TEAM_*).  Block systems are bitwise the same on every path.
  * The _device form takes device pointers and only enqueues on `stream` (a hipStream_t; NULL = default);
  * the host form copies in, runs, copies out and synchronises.  Launches on one EzpzSystem must not overlap in time
  * when the system uses per-system device scratch (a global workspace or a grid team, see EzpzSystemInfo): enqueue

@@ -42,13 +42,30 @@ BEYOND_CEILING = 1e-2  # ... and what a system "beyond the ceiling" may differ b
                        # exceeds 5e-3 (comb 51: the oracle's answers differ among themselves by 1.2e-2 under one-ulp moves)
 
 
-def _log(what, total, needed, worst_err, widest_bar, iteration_exceptions, beyond, beyond_err=0.0, beyond_bar=0.0):
+def _log(what, total, needed, worst_err, widest_bar, iteration_exceptions, beyond, beyond_err=0.0, beyond_bar=0.0, restart_moves=()):
     if os.path.isdir(os.path.dirname(_LOG)):
+        fixed = sum(1 for m in restart_moves if m == 0.0)
         with open(_LOG, "a") as f:
             f.write(f"{what!r} | systems {total} | measured bar needed {needed} | largest error among them {worst_err:.3e} | "
                     f"widest bar granted {widest_bar:.3e} | iteration counts inside the oracle's range only {iteration_exceptions} | "
                     f"beyond the ceiling (oracle spread > {BAR_CEILING / 20:.0e}: judged by residual) {beyond} | "
-                    f"largest coordinate error among those {beyond_err:.3e} (granted up to {beyond_bar:.3e}: min(20 x spread, max({BEYOND_CEILING:.0e}, 2 x spread)))\n")
+                    f"largest coordinate error among those {beyond_err:.3e} (granted up to {beyond_bar:.3e}: min(20 x spread, max({BEYOND_CEILING:.0e}, 2 x spread))) | "
+                    f"of those, the oracle restarted at the device's answer stays there bit for bit {fixed}, moves by at most "
+                    f"{max([m for m in restart_moves] + [0.0]):.3e} otherwise\n")
+
+
+def restart_check(recs, x_row, converged, cfg, linsolve, what, b):
+    """The oracle started at the device's answer `x_row` (idempotence).  Returns how far it moves (relative; 0.0: not a bit)."""
+    rc, xr, itr, convr, _ = O.solve_batch(recs, np.ascontiguousarray(x_row)[None, :], cfg, linsolve=linsolve)
+    assert rc == 0
+    tol = (cfg.residual_tolerance if cfg is not None else 1e-8)
+    worst, _ = residual_inf(recs, x_row)
+    with np.errstate(invalid="ignore"):
+        move = float(np.nanmax(np.abs(xr[0] - x_row) / np.maximum(1.0, np.abs(x_row)))) if len(x_row) else 0.0
+    if converged and worst <= 0.5 * tol and all(float(r["weight"]) == 1.0 for r in np.ascontiguousarray(recs)):
+        # (unit weights: the loop's test is on the weighted residuals, residual_inf's on the unweighted ones)
+        assert int(itr[0]) == 0 and bool(convr[0]) and np.array_equal(xr[0], x_row), (what, b, "restart", int(itr[0]), move)
+    return move
 
 
 def residual_inf(recs, x):
@@ -124,6 +141,7 @@ def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, li
     if check_iterations:
         plain &= np.asarray(iterations).astype(np.int64) == np.asarray(it).astype(np.int64)
     needed = beyond = 0
+    restart_moves = []
     worst_err = widest_bar = beyond_err = beyond_bar = 0.0
     iteration_exceptions = 0
     for b in np.nonzero(~plain)[0]:
@@ -149,7 +167,12 @@ def assert_batch_matches_oracle(recs, x0, x, iterations, converged, cfg=None, li
             r_theirs = max([r for r, _ in theirs] + [1e-8])
             assert r_mine <= 10.0 * r_theirs, (what, int(b), "residual", r_mine, r_theirs)
             assert any(unsat_mine == u for _, u in theirs), (what, int(b), "unsatisfied", sorted(unsat_mine))
+            # ... and as a FIXED POINT of the reference's algorithm (idempotence): the oracle started at the device's answer.  Where
+            # the answer meets the residual tolerance the reference's loop ends before its first iteration (newton.rs:50-60): zero
+            # iterations, the values untouched, bit for bit; elsewhere (the step test ended the solve, or the limit did) it may move,
+            # and how far is logged -- a same-answer check at 1e-9 for systems whose oracle runs differ among themselves by 1e-2
+            restart_moves.append(restart_check(recs, x[b], bool(converged[b]), cfg, linsolve, what, int(b)))
         else:
             worst_err, widest_bar = max(worst_err, float(err[b])), max(widest_bar, bar)
-    _log(what, len(x), needed, worst_err, widest_bar, iteration_exceptions, beyond, beyond_err, beyond_bar)
+    _log(what, len(x), needed, worst_err, widest_bar, iteration_exceptions, beyond, beyond_err, beyond_bar, restart_moves)
     return needed

@@ -317,24 +317,24 @@ def test_specialised_kernel_on_several_workgroups(E, lines, over):
         assert np.array_equal(st["final_lambda"], stw["final_lambda"]) and np.array_equal(st["n_warnings"], stw["n_warnings"])
 
 
-@pytest.mark.parametrize("over", [False, True])
-def test_several_workgroups_verdicts_not_waited_for_every_exit(E, over):
-    """A linear system on several workgroups does not wait for the verdicts of the LM control (jit_kernel.hip.hpp:
-    solve_kernel_grid): both iterations are taken and the values stored before anybody knows whether the steps stand, and
+@pytest.mark.parametrize("lines,over,B", [(12000, False, 33), (3000, True, 33), (500, False, 80), (500, True, 80)])
+def test_verdicts_not_waited_for_every_exit(E, lines, over, B):
+    """A linear block system does not wait for the verdicts of the LM control (jit_kernel.hip.hpp: solve_kernel_fast for a
+    system on one workgroup -- 500 lines: the 2000 x 2000 headline --, solve_kernel_grid_fast on several -- 12 000 lines; calls of
+    more than 1 MB through the host entry run out of place, which those kernels need):
+    both iterations are taken and the values stored before anybody knows whether the steps stand, and
     whatever the verdicts turn out to be the system must end on the reference's path (newton.rs:47-139) -- converged at the
     start, converged after one iteration, a failed pivot (a NaN guess: every iteration burnt), a rejected first step, the step
     tolerance met by the first step, iteration limits of 0 ... 3 -- with such systems at the start, in the middle and at the
     end of a slot's sequence of ordinary ones (a re-solve, then verdicts waited for, while two later systems' verdicts are
     still pending).  Against the list-walk kernel in every output, and the oracle.  (over: the non-linear variant, which
     always waits -- the same cases on the loop alone.)"""
-    lines = 12000 if not over else 3000
     ref = T.load(T.gen_big_problem(lines, over))
     n = ref.num_vars
     sysobj = E.System(ref.constraints, n)
     exact = np.zeros(n)
     exact[0::4] = exact[2::4] = np.arange(lines)
     exact[3::4] = 4.0
-    B = 33
     x0 = ref.guesses[None, :] + gen.keyed_uniform(78, B, n, -0.25, 0.25)
     cfgs = [E.Config(), E.Config(max_iterations=0), E.Config(max_iterations=1), E.Config(max_iterations=2), E.Config(max_iterations=3),
             E.Config(residual_tolerance=-1.0),                       # exact start: step 0, rejected (0 < 0 is false), step test ends it
@@ -348,7 +348,7 @@ def test_several_workgroups_verdicts_not_waited_for_every_exit(E, over):
             x0[18, 5] = np.nan                                               # a pivot fails in every iteration
             x0[27] = exact
             x0[27, 2 * (lines // 2)] += 1e-6                                  # one component away from the solution, barely
-            x0[32] = exact                                                   # the last system of its slot
+            x0[B - 1] = exact                                                # the last system of its slot
         else:  # ... and every system special (every verdict a re-solve from the first on)
             x0[:] = exact[None, :] + gen.keyed_uniform(80, B, n, -1e-5, 1e-5)
             x0[::3] = exact
