@@ -1282,13 +1282,23 @@ __device__ __forceinline__ bool fast_verdict(const JitArgs& a, const uint64_t sy
 // (fast_verdict) while the others are on the next system already.  solve_kernel spends three rendezvous per system on the LM
 // control, each with every wavefront's state held in registers across it (168 of them, three wavefronts per SIMD, 43 % of wave
 // cycles parked: profiles/r05_bench_massive.json); here nothing is live across the barrier but the next system's guesses.
-// Systems are dealt to the workgroups with the stride of the launch.
 template <class SEQ, int NWAVES>
 __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     using namespace ezpz::dev;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    // Who solves which system: a workgroup's first is its own index; every further one is DRAWN (JitArgs::ticket, as in solve_kernel:
+    // a workgroup that starts late -- a co-tenant held its place -- then has one system to catch up on, not a fixed share of the
+    // batch: 100.9 -> 53.7 M solves/s beside one resident one-call kernel with fixed shares, DESIGN_HISTORY.md C.2) -- and drawn TWO
+    // systems ahead, because the guesses are asked for one ahead: thread 0 asks the counter at the top of a system and leaves the
+    // answer in LDS ahead of that system's barrier.  (Two draws per workgroup are in vain: the host counts on it.)
+    const bool tickets = a.ticket != nullptr;
+    const uint32_t ticket_c = blockIdx.x & 7u;
+    __shared__ unsigned int fast_drawn[2];
+    unsigned int drawn = 0;
+    if (tickets && tid == 0)
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
     SEQ seq;
     fast_setup(seq, a, wave, lane);
     if (blockIdx.x < a.batch) fast_fetch(seq, a, blockIdx.x);
@@ -1296,12 +1306,29 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     __shared__ double fast_part[2][4 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
     __shared__ int fast_pflag[2][16];
     __shared__ double fast_out[NWAVES * SEQ::NVS * 64];  // per wavefront: a system's values on their way out (fast_wave)
+    auto drawn_system = [&](unsigned int d) { return (uint64_t)gridDim.x + (uint64_t)(d - a.ticket_base[ticket_c]) * 8u + ticket_c; };
+    uint64_t sys = blockIdx.x, sys_n = sys + gridDim.x;
+    if (tickets) {
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn)::"memory");
+            fast_drawn[1] = drawn;
+        }
+        __syncthreads();
+        sys_n = drawn_system(__builtin_amdgcn_readfirstlane(fast_drawn[1]));
+    }
     unsigned int kp = 0;
-    for (uint64_t sys = blockIdx.x; sys < a.batch; sys += gridDim.x, kp ^= 1u) {
-        const uint64_t sys_n = sys + gridDim.x;
+    for (; sys < a.batch; kp ^= 1u) {
+        if (tickets && tid == 0)
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
         double v[4];
         const unsigned int wave_flags = fast_wave<true>(seq, a, sys, sys_n, sys_n < a.batch, wave, lane, v, fast_out + wave * (SEQ::NVS * 64));
+        uint64_t sys_nn = sys_n + gridDim.x;
+        if (tickets && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn)::"memory");
+            if (NWAVES > 1) fast_drawn[kp] = drawn;
+        }
         if constexpr (NWAVES == 1) {
+            if (tickets) sys_nn = drawn_system(__builtin_amdgcn_readfirstlane(drawn));
             // (lane i <- value i from the last lane)
             double t = 0.0;
 #pragma unroll
@@ -1319,6 +1346,7 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
                 fast_pflag[kp][wave] = (int)wave_flags;
             }
             __syncthreads();
+            if (tickets) sys_nn = drawn_system(__builtin_amdgcn_readfirstlane(fast_drawn[kp]));
             if (wave == 0) {
                 const int i = lane & 3;
                 double t = fast_part[kp][16 * i];
@@ -1333,6 +1361,8 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
                 fast_verdict(a, sys, t, fl, lane);
             }
         }
+        sys = sys_n;
+        sys_n = sys_nn;
     }
 }
 

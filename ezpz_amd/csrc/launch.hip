@@ -120,6 +120,45 @@ bool stream_capturing(hipStream_t stream) {
     return capturing != hipStreamCaptureStatusNone;
 }
 
+// The counters a specialised kernel's workgroups draw their systems from (jit_kernel.hip.hpp: JitArgs::ticket), for a launch on
+// `stream`: created on first use; launches that share them are chained.  False: the launch keeps fixed shares.
+bool prepare_tickets(EzpzSystem& s, hipStream_t stream) {
+    static const bool tickets_enabled = [] {  // EZPZ_TICKETS=0: fixed shares (A/B runs: 101.1 -> 110.0 M solves/s with them)
+        const char* e = std::getenv("EZPZ_TICKETS");
+        return !(e && e[0] == '0');
+    }();
+    // (a launch that is being recorded into a graph keeps fixed shares: a replay would find the counters elsewhere)
+    if (!tickets_enabled || stream_capturing(stream)) return false;
+    bool ok = s.ticket.p != nullptr;
+    if (!ok && s.ticket.ensure(8 * 1024) == EZPZ_OK) {  // (jit_kernel.hip.hpp: kTicketStride words apart)
+        ok = hipMemset(s.ticket.p, 0, 8 * 1024 * sizeof(unsigned int)) == hipSuccess;
+        for (unsigned int& b : s.ticket_base) b = 0;
+    }
+    if (ok && !s.ticket_done) ok = hipEventCreateWithFlags(&s.ticket_done, hipEventDisableTiming) == hipSuccess;
+    if (ok && s.ticket_used && s.ticket_stream != stream) {
+        // another stream than last time: everything enqueued on the old one first (an event per launch instead
+        // cost the back-to-back launches of one stream two runtime calls and a barrier packet each)
+        ok = hipEventRecord(s.ticket_done, s.ticket_stream) == hipSuccess && hipStreamWaitEvent(stream, s.ticket_done, 0) == hipSuccess;
+        if (!ok) {  // (the old stream is gone: whatever ran on it is awaited the blunt way)
+            (void)hipGetLastError();
+            ok = hipDeviceSynchronize() == hipSuccess;
+        }
+    }
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+// ... and what a launch of `workgroups` workgroups over `batch` systems has drawn from each: counter c hands out its share of the
+// systems beyond the workgroups' own, and `in_vain` values more to each of its workgroups (the loop kernel draws once per system
+// it solves, the last time in vain; the kernel that asks for its guesses a system ahead draws a system ahead: twice in vain)
+void advance_tickets(EzpzSystem& s, hipStream_t stream, uint64_t workgroups, uint64_t batch, unsigned int in_vain) {
+    for (uint64_t c = 0; c < 8; ++c) {
+        const uint64_t wgs_c = (workgroups + 7 - c) / 8, beyond = batch - workgroups;
+        s.ticket_base[c] += (unsigned int)(in_vain * wgs_c + (beyond > c ? (beyond - c + 7) / 8 : 0));
+    }
+    s.ticket_stream = stream;
+    s.ticket_used = true;
+}
+
 // The two redo lists of a system whose specialised kernel has a `_fast` entry (system.hpp: jit_redo), for `batch` systems, and the
 // mapped word the loop's launch leaves its count in.
 int jit_redo_lists(EzpzSystem& s, uint64_t batch, hipStream_t stream) {
@@ -375,8 +414,11 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                     // lists (jit_kernel.hip.hpp: solve_kernel_fast)
                     const unsigned int turn = s.jit_redo_turn;
                     const uint32_t fast_wgs = (uint32_t)std::min<uint64_t>(comp_jit_capacity_fast(s.jit, *s.comp, s.device, s.lim.cus), 0xFFFFFFFFull);
-                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream, nullptr, 0, fast_wgs, s.jit_redo[turn].p,
+                    CompLaunch Lt = L;
+                    if (L.batch > fast_wgs && prepare_tickets(s, stream)) Lt.ticket = s.ticket.p, Lt.ticket_base = s.ticket_base;
+                    if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, Lt, s.device, s.lim.cus, stream, nullptr, 0, fast_wgs, s.jit_redo[turn].p,
                                         s.jit_redo[turn ^ 1u].p, s.jit_redo_seen_dev, s.jit_redo_seen) == EZPZ_OK) {
+                        if (Lt.ticket) advance_tickets(s, stream, fast_wgs, L.batch, 2);
                         s.jit_redo_turn = turn ^ 1u;
                         return EZPZ_OK;
                     }
@@ -385,46 +427,9 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                     // launches that share the counter are chained
                     const uint64_t capacity = L.done.flag ? 0 : comp_jit_capacity(s.jit, *s.comp, s.device, s.lim.cus);
                     CompLaunch Lt = L;
-                    static const bool tickets_enabled = [] {  // EZPZ_TICKETS=0: fixed shares (A/B runs: 101.1 -> 110.0 M solves/s with them)
-                        const char* e = std::getenv("EZPZ_TICKETS");
-                        return !(e && e[0] == '0');
-                    }();
-                    // (a launch that is being recorded into a graph keeps fixed shares: a replay would find the counters elsewhere)
-                    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-                    if (stream && hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
-                        (void)hipGetLastError();
-                        capturing = hipStreamCaptureStatusNone;
-                    }
-                    if (tickets_enabled && capturing == hipStreamCaptureStatusNone && capacity && L.batch > capacity && L.batch < (1ull << 32)) {
-                        bool ok = s.ticket.p != nullptr;
-                        if (!ok && s.ticket.ensure(8 * 1024) == EZPZ_OK) {  // (jit_kernel.hip.hpp: kTicketStride words apart)
-                            ok = hipMemset(s.ticket.p, 0, 8 * 1024 * sizeof(unsigned int)) == hipSuccess;
-                            for (unsigned int& b : s.ticket_base) b = 0;
-                        }
-                        if (ok && !s.ticket_done) ok = hipEventCreateWithFlags(&s.ticket_done, hipEventDisableTiming) == hipSuccess;
-                        if (ok && s.ticket_used && s.ticket_stream != stream) {
-                            // another stream than last time: everything enqueued on the old one first (an event per launch instead
-                            // cost the back-to-back launches of one stream two runtime calls and a barrier packet each)
-                            ok = hipEventRecord(s.ticket_done, s.ticket_stream) == hipSuccess && hipStreamWaitEvent(stream, s.ticket_done, 0) == hipSuccess;
-                            if (!ok) {  // (the old stream is gone: whatever ran on it is awaited the blunt way)
-                                (void)hipGetLastError();
-                                ok = hipDeviceSynchronize() == hipSuccess;
-                            }
-                        }
-                        if (ok) Lt.ticket = s.ticket.p, Lt.ticket_base = s.ticket_base;
-                        else (void)hipGetLastError();
-                    }
+                    if (capacity && L.batch > capacity && L.batch < (1ull << 32) && prepare_tickets(s, stream)) Lt.ticket = s.ticket.p, Lt.ticket_base = s.ticket_base;
                     if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, Lt, s.device, s.lim.cus, stream) == EZPZ_OK) {
-                        if (Lt.ticket) {
-                            // every workgroup draws once per system it solves, the last time in vain: counter c hands out its share of
-                            // the systems beyond the workgroups' own, and one value more to each of its workgroups
-                            for (uint64_t c = 0; c < 8; ++c) {
-                                const uint64_t wgs_c = (capacity + 7 - c) / 8, beyond = L.batch - capacity;
-                                s.ticket_base[c] += (unsigned int)(wgs_c + (beyond > c ? (beyond - c + 7) / 8 : 0));
-                            }
-                            s.ticket_stream = stream;
-                            s.ticket_used = true;
-                        }
+                        if (Lt.ticket) advance_tickets(s, stream, capacity, L.batch, 1);
                         return EZPZ_OK;
                     }
                 } else {
