@@ -904,6 +904,27 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                     o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
                          (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse ? "true" : "false") + ", false>(a, smem);\n}\n";
             }
+            // the caller's variables of every wavefront (of the G * T that share a system): one contiguous run?  Then the kernels below
+            // move a wavefront's piece of a row as full lines (jit_kernel.hip.hpp: fast_wave, IO 2)
+            std::vector<uint32_t> wave_lo(G * T, 0), wave_n(G * T, 0);
+            bool contiguous = true;
+            for (uint32_t w = 0; w < G * T && contiguous; ++w) {
+                uint32_t lo = ~0u, hi = 0, cnt = 0;
+                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                    const uint32_t k = slot_of[sl].first;
+                    const Class& cl = classes[k];
+                    const uint32_t chunk = w * slots_k[k] + slot_of[sl].second, ninst = (uint32_t)cl.instances.size();
+                    for (uint32_t i = chunk * 64; i < ninst && i < chunk * 64 + 64; ++i)
+                        for (uint32_t kv = 0; kv < cl.H.nv; ++kv) {
+                            const uint32_t id = comps[cl.instances[i]].verts[cl.Q.var_of[kv]];
+                            lo = std::min(lo, id), hi = std::max(hi, id), ++cnt;
+                        }
+                }
+                if (cnt == 0) continue;  // (a wavefront beyond the system's last chunk)
+                // (every variable belongs to one instance: as many variables as the run is long means exactly the run)
+                contiguous = hi - lo + 1 == cnt;
+                wave_lo[w] = lo, wave_n[w] = cnt;
+            }
             // a LINEAR system with unit weights: the kernel that does not wait for the verdicts of the LM control (jit_kernel.hip.hpp:
             // solve_kernel_fast / solve_kernel_grid_fast) and, for a system on one workgroup, the loop over the systems that kernel
             // lists (`_list`; several workgroups: the first entry reads the list itself).  The first needs far fewer registers than the
@@ -924,7 +945,8 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                 for (int variant = 0; variant < (fast_waves > 2 && !env_fw ? 2 : 1); ++variant) {
                     o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ", " + std::to_string(fast_waves - variant) +
                          ") ezpz_jit_solve_fast" + (variant ? "_b" : "") + "(const ezpz::jit::JitArgs a) {\n";
-                    o += std::string("    ezpz::jit::") + (G > 1 ? "solve_kernel_grid_fast" : "solve_kernel_fast") + "<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ">(a);\n}\n";
+                    o += std::string("    ezpz::jit::") + (G > 1 ? "solve_kernel_grid_fast" : "solve_kernel_fast") + "<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) +
+                         (G == 1 ? (contiguous ? ", true" : ", false") : "") + ">(a);\n}\n";
                 }
                 if (G == 1) {
                     o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve_list(const ezpz::jit::JitArgs a) {\n";
@@ -948,6 +970,12 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                     blob.push_back(count);
                 }
             blob.resize(blob.size() + 16, 0);
+            plan.o_jit_ranges = 0;
+            if (contiguous) {  // [wave] {first variable, count}
+                plan.o_jit_ranges = (uint32_t)blob.size();
+                for (uint32_t w = 0; w < G * T; ++w) blob.push_back(wave_lo[w]), blob.push_back(wave_n[w]);
+                blob.resize(blob.size() + 16, 0);
+            }
             plan.jit_waves = T;
             plan.jit_slots = nslots;
             plan.jit_wgs = G;

@@ -94,6 +94,7 @@ struct CompPlan {
     // `jit_slots` slots; blob[o_jit_slots ...] = [wave][slot] {ids_off, par_off, pos_off, count}.  Empty = none.
     std::string jit_source;
     uint32_t jit_waves = 0, jit_slots = 0, o_jit_slots = 0;
+    uint32_t o_jit_ranges = 0;  // blob[...] = [wave] {first variable, count} when every wavefront's variables are one contiguous run (else 0)
     uint32_t jit_wgs = 1;        // workgroups that share one system in the specialised kernel (grid reductions when > 1)
     bool interpretable = true;   // the state fits one CU's LDS: comp_solve_kernel can run the plan (else specialised only)
 };

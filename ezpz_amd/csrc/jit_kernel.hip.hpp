@@ -38,7 +38,7 @@ struct JitArgs {
     double residual_tolerance, step_tolerance, initial_lambda;
     struct GridScratch* grid;  // systems too large for one workgroup: one scratch per system in flight (else null)
     uint32_t grid_wgs;         // workgroups that share a system (1 = the ordinary case)
-    uint32_t pad;
+    uint32_t o_ranges;         // (the `_fast` entries of a plan whose wavefronts own contiguous pieces of a row: word offset of [wave] {first variable, count}; else 0)
     DoneWord done;             // one-call launches: the completion word (dev_types.hpp)
     // Batches larger than the launch (one workgroup per system): after its first system (its own index) a workgroup DRAWS the
     // next one from this counter -- system = workgroups of the launch + (drawn value - ticket_base) -- instead of striding.  The
@@ -1087,14 +1087,15 @@ __device__ __forceinline__ void store_at(__amdgpu_buffer_rsrc_t row, uint32_t by
 // the same matrix for every instance of every system: factorised once per launch (newton.rs:73-99: the operations of C::solve
 // that do not involve the right-hand side, in its order), kept in scalar registers by the class's first slot.
 template <class SEQ>
-__device__ __forceinline__ void fast_setup(SEQ& seq, const JitArgs& a, const uint32_t wave_global, const int lane) {
+__device__ __forceinline__ void fast_setup(SEQ& seq, const JitArgs& a, const uint32_t wave_global, const int lane, const uint32_t first_byte = 0) {
     seq.each([&](auto& s, auto* cls, int index) {
         using C = typename class_of<decltype(cls)>::type;
         const uint32_t* t = a.blob + a.o_slots + 4 * ((size_t)wave_global * SEQ::N + index);
         const uint32_t ids_off = t[0], par_off = t[1], count = t[3];
         s.active = (uint32_t)lane < count;
+        // (first_byte: the wavefront's piece of the row starts there -- offsets into the piece; a lane without an instance reads its start)
 #pragma unroll
-        for (int k = 0; k < C::NV; ++k) s.ids[k] = a.blob[ids_off + (size_t)k * C::STRIDE + lane] * 8u;
+        for (int k = 0; k < C::NV; ++k) s.ids[k] = s.active ? a.blob[ids_off + (size_t)k * C::STRIDE + lane] * 8u - first_byte : 0u;
         const double* par = reinterpret_cast<const double*>(a.blob + par_off) + lane;
 #pragma unroll
         for (int k = 0; k < C::NC; ++k) s.par[k] = par[(size_t)k * C::STRIDE];
@@ -1108,6 +1109,45 @@ __device__ __forceinline__ void fast_fetch(SEQ& seq, const JitArgs& a, const uin
 #pragma unroll
         for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0, s.ids[i]);
     });
+}
+// A wavefront's CONTIGUOUS piece of a row -- `bytes` from `first_byte` on: the generator found that the variables of the wavefront's
+// instances are exactly those (comp_program.cpp: wave ranges) -- moved as FULL LINES: lane l takes 16 bytes at 1024 p + 16 l, p = 0 ...
+// PIECES - 1, consecutive lanes on consecutive bytes, instead of eight 8-byte accesses per lane at strides of 16 / 32 bytes in which a
+// 128-byte line is shared by three or four instructions (tools/row_copy_bench.hip: 165 against 150 M rows/s of 16 KB is what memory
+// allows the two patterns).  The slots read and write their values in an LDS copy of the piece (`buf`: the wavefront's own).
+typedef int bufword4_t __attribute__((ext_vector_type(4)));
+typedef bufword4_t __attribute__((may_alias)) lds_b128_t;  // (the piece is written as 16-byte words and read as doubles, and the other way round)
+typedef double __attribute__((may_alias)) lds_f64_t;
+template <int PIECES>
+__device__ __forceinline__ void piece_load(bufword4_t (&q)[PIECES], const __amdgpu_buffer_rsrc_t row, const uint32_t first_byte, const uint32_t bytes, const int lane) {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const uint32_t at = 1024u * p + 16u * lane;
+        q[p] = bufword4_t{0, 0, 0, 0};
+        if (at + 16u <= bytes) {
+            q[p] = __builtin_amdgcn_raw_buffer_load_b128(row, (int)(first_byte + at), 0, 0);
+        } else if (at + 8u <= bytes) {
+            const bufword2_t h = __builtin_amdgcn_raw_buffer_load_b64(row, (int)(first_byte + at), 0, 0);
+            q[p].x = h.x, q[p].y = h.y;
+        }
+    }
+}
+template <int PIECES>
+__device__ __forceinline__ void piece_to_lds(const bufword4_t (&q)[PIECES], double* buf, const int lane) {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) *reinterpret_cast<lds_b128_t*>(reinterpret_cast<char*>(buf) + 1024 * p + 16 * lane) = q[p];
+}
+template <int PIECES>
+__device__ __forceinline__ void piece_store(const double* buf, const __amdgpu_buffer_rsrc_t row, const uint32_t first_byte, const uint32_t bytes, const int lane) {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const uint32_t at = 1024u * p + 16u * lane;
+        const bufword4_t q = *reinterpret_cast<const lds_b128_t*>(reinterpret_cast<const char*>(buf) + at);
+        if (at + 16u <= bytes)
+            __builtin_amdgcn_raw_buffer_store_b128(q, row, (int)(first_byte + at), 0, 0);
+        else if (at + 8u <= bytes)
+            __builtin_amdgcn_raw_buffer_store_b64(bufword2_t{q.x, q.y}, row, (int)(first_byte + at), 0, 0);
+    }
 }
 template <class SEQ>
 __device__ __forceinline__ void fast_factor(SEQ& seq, const JitArgs& a) {
@@ -1143,12 +1183,23 @@ constexpr unsigned int kFastGt = 8u, kFastFin = 16u;  // (k = 0: max|r0|, 1: |d1
 __device__ __forceinline__ bool fast_exceeds(unsigned int flags, int k) {  // !(maximum k <= its tolerance), as the loop tests it
     return (flags & (kFastGt << (2 * k))) != 0 || (flags & (kFastFin << (2 * k))) == 0;
 }
-template <bool STAGE, class SEQ>
+// IO: how the values travel -- 0: every slot loads the next system's guesses and stores its values itself; 1: the values wait in LDS
+// (`out_lds`) and are stored back to back; 2: the wavefront owns a contiguous piece of the row (`first_byte`, `bytes`): this
+// system's values are in `out_lds`, the slots read and write them there, the next system's piece is loaded as full lines at the top
+// and put into `next_lds` at the end, this one's is stored as full lines.
+template <int IO, class SEQ>
 __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, const uint64_t sys, const uint64_t sys_n, const bool next,
-                                                  const uint32_t wave_global, const int lane, double (&v)[4], double* const out_lds) {
+                                                  const uint32_t wave_global, const int lane, double (&v)[4], double* const out_lds,
+                                                  double* const next_lds = nullptr, const uint32_t first_byte = 0, const uint32_t bytes = 0) {
     using namespace ezpz::dev;
+    constexpr bool STAGE = IO == 1;
+    constexpr int PIECES = (SEQ::NVS + 1) / 2;
     const __amdgpu_buffer_rsrc_t xo = row_at(a.x_out + sys * a.n_row);
     const __amdgpu_buffer_rsrc_t x0n = row_at(a.x0 + (next ? sys_n : sys) * a.n_row);
+    bufword4_t ahead[IO == 2 ? PIECES : 1];
+    if constexpr (IO == 2) {
+        if (next) piece_load<PIECES>(ahead, x0n, first_byte, bytes, lane);
+    }
     uint8_t* mask = a.unsat_mask ? a.unsat_mask + sys * a.n_cons : nullptr;
     const __amdgpu_buffer_rsrc_t table = row_at(a.blob);
     v[0] = v[1] = v[2] = 0.0;
@@ -1159,11 +1210,16 @@ __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, co
     seq.each([&](auto& s, auto* cls, int index) {
         using C = typename class_of<decltype(cls)>::type;
         auto& f = seq.template first<C>();
+        if constexpr (IO == 2) {
 #pragma unroll
-        for (int i = 0; i < C::NV; ++i) s.x[i] = s.xn[i];
-        if (next) {
+            for (int i = 0; i < C::NV; ++i) s.x[i] = *reinterpret_cast<const lds_f64_t*>(reinterpret_cast<const char*>(out_lds) + s.ids[i]);
+        } else {
 #pragma unroll
-            for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0n, s.ids[i]);
+            for (int i = 0; i < C::NV; ++i) s.x[i] = s.xn[i];
+            if (next) {
+#pragma unroll
+                for (int i = 0; i < C::NV; ++i) s.xn[i] = load_at(x0n, s.ids[i]);
+            }
         }
         unsigned long long wm = 0;
         {
@@ -1202,7 +1258,12 @@ __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, co
                 if (s.active) mask[at] = 0;
             }
         }
-        if constexpr (STAGE) {  // (the values wait in LDS -- this lane's own words, `out_lds` is the wavefront's -- for the stores below)
+        if constexpr (IO == 2) {
+            if (s.active) {
+#pragma unroll
+                for (int i = 0; i < C::NV; ++i) *reinterpret_cast<lds_f64_t*>(reinterpret_cast<char*>(out_lds) + s.ids[i]) = s.x[i];
+            }
+        } else if constexpr (STAGE) {  // (the values wait in LDS -- this lane's own words, `out_lds` is the wavefront's -- for the stores below)
 #pragma unroll
             for (int i = 0; i < C::NV; ++i) out_lds[(var0 + i) * 64 + lane] = s.x[i];
             var0 += C::NV;
@@ -1230,6 +1291,10 @@ __device__ __forceinline__ unsigned int fast_wave(SEQ& seq, const JitArgs& a, co
         }
         var0 += C::NV;
     });
+    if constexpr (IO == 2) {
+        piece_store<PIECES>(out_lds, xo, first_byte, bytes, lane);
+        if (next) piece_to_lds<PIECES>(ahead, next_lds, lane);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = i < 3 ? reduce_wave_to_last_lane(v[i], OpSum()) : reduce_wave_to_last_lane(v[i], OpMax());
     unsigned int flags = (__ballot(lane_bad1) != 0 ? 1u : 0u) | (__ballot(lane_bad2) != 0 ? 2u : 0u) | (__ballot(lane_redo) != 0 ? 4u : 0u);
@@ -1282,7 +1347,8 @@ __device__ __forceinline__ bool fast_verdict(const JitArgs& a, const uint64_t sy
 // (fast_verdict) while the others are on the next system already.  solve_kernel spends three rendezvous per system on the LM
 // control, each with every wavefront's state held in registers across it (168 of them, three wavefronts per SIMD, 43 % of wave
 // cycles parked: profiles/r05_bench_massive.json); here nothing is live across the barrier but the next system's guesses.
-template <class SEQ, int NWAVES>
+// CONTIG (says the generator): every wavefront's variables are one contiguous piece of the row -- moved as full lines (fast_wave, IO 2).
+template <class SEQ, int NWAVES, bool CONTIG = false>
 __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     using namespace ezpz::dev;
     const int tid = threadIdx.x;
@@ -1300,12 +1366,29 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     if (tickets && tid == 0)
         asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
     SEQ seq;
-    fast_setup(seq, a, wave, lane);
-    if (blockIdx.x < a.batch) fast_fetch(seq, a, blockIdx.x);
-    fast_factor(seq, a);
     __shared__ double fast_part[2][4 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
     __shared__ int fast_pflag[2][16];
-    __shared__ double fast_out[NWAVES * SEQ::NVS * 64];  // per wavefront: a system's values on their way out (fast_wave)
+    // per wavefront: a system's values on their way out (fast_wave, IO 1) -- or, CONTIG, the wavefront's piece of the row: this
+    // system's and the next one's (IO 2; a piece of NVS x 64 doubles, rounded up to whole 16-byte accesses of the 64 lanes)
+    constexpr int PIECE = ((SEQ::NVS + 1) / 2) * 128;
+    __shared__ __attribute__((aligned(16))) double fast_out[NWAVES * (CONTIG ? 2 * PIECE : SEQ::NVS * 64)];
+    uint32_t first_byte = 0, piece_bytes = 0;
+    if constexpr (CONTIG) {
+        first_byte = a.blob[a.o_ranges + 2 * wave] * 8u;
+        piece_bytes = a.blob[a.o_ranges + 2 * wave + 1] * 8u;
+    }
+    double* const row_lds = fast_out + wave * (CONTIG ? 2 * PIECE : SEQ::NVS * 64);
+    fast_setup(seq, a, wave, lane, first_byte);
+    if constexpr (CONTIG) {
+        if (blockIdx.x < a.batch) {
+            bufword4_t q[(SEQ::NVS + 1) / 2];
+            piece_load<(SEQ::NVS + 1) / 2>(q, row_at(a.x0 + (uint64_t)blockIdx.x * a.n_row), first_byte, piece_bytes, lane);
+            piece_to_lds<(SEQ::NVS + 1) / 2>(q, row_lds, lane);
+        }
+    } else {
+        if (blockIdx.x < a.batch) fast_fetch(seq, a, blockIdx.x);
+    }
+    fast_factor(seq, a);
     auto drawn_system = [&](unsigned int d) { return (uint64_t)gridDim.x + (uint64_t)(d - a.ticket_base[ticket_c]) * 8u + ticket_c; };
     uint64_t sys = blockIdx.x, sys_n = sys + gridDim.x;
     if (tickets) {
@@ -1321,7 +1404,11 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
         if (tickets && tid == 0)
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
         double v[4];
-        const unsigned int wave_flags = fast_wave<true>(seq, a, sys, sys_n, sys_n < a.batch, wave, lane, v, fast_out + wave * (SEQ::NVS * 64));
+        unsigned int wave_flags;
+        if constexpr (CONTIG)
+            wave_flags = fast_wave<2>(seq, a, sys, sys_n, sys_n < a.batch, wave, lane, v, row_lds + kp * PIECE, row_lds + (kp ^ 1u) * PIECE, first_byte, piece_bytes);
+        else
+            wave_flags = fast_wave<1>(seq, a, sys, sys_n, sys_n < a.batch, wave, lane, v, row_lds);
         uint64_t sys_nn = sys_n + gridDim.x;
         if (tickets && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn)::"memory");
@@ -1448,7 +1535,7 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
         if (have) {
             const uint64_t sys_n = sys + n_slots;
             double v[4];
-            const unsigned int wave_flags = fast_wave<false>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, nullptr);
+            const unsigned int wave_flags = fast_wave<0>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, nullptr);
             stamp();  // 1: both steps taken, stores issued
             if (lane == 63) {
 #pragma unroll

@@ -380,8 +380,17 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     }
     // one connected sketch as a tree of dense fronts (fronts.cpp): every call of a system created for one solve, the small calls
     // of a system created for batches
-    if (s.fronts && !args.resume && !args.sys_list && (t_call_batch ? t_call_batch : args.batch) <= s.front_max_batch)
-        return front_launch(s, args, stream);
+    if (s.fronts && !args.resume && !args.sys_list && (t_call_batch ? t_call_batch : args.batch) <= s.front_max_batch) {
+        // (a launch that is being recorded into a graph: fronts on several workgroups allocate and zero their scratch on first use and
+        // chain their launches on the process-wide event of the grid teams -- neither may end up inside a capture, which would also
+        // leave that event unusable for the launches after it.  A system created for batches has its other shapes and takes them; a
+        // system the fronts alone serve says so)
+        if (s.fronts->n_wgs > 1 && stream_capturing(stream)) {
+            if (s.front_max_batch == 0xFFFFFFFFu) return EZPZ_ERR_INVALID_ARGUMENT;
+        } else {
+            return front_launch(s, args, stream);
+        }
+    }
     if (s.jit && s.launches.load(std::memory_order_relaxed) == 0) comp_jit_probe(s.jit);  // the kernel may be in the on-disk cache
     if (s.lane && s.wave_jit && args.batch <= (uint64_t)s.lim.cus) {
         // one solve (or a few) of a small system built for latency: one wavefront per system, sweeps and assembly across its

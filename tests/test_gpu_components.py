@@ -374,6 +374,35 @@ def test_verdicts_not_waited_for_every_exit(E, lines, over, B):
     assert {(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (6, 0)} <= seen, str(sorted(seen))
 
 
+@pytest.mark.parametrize("lines,permute", [(333, False), (500, True), (97, False), (1000, True)])
+def test_verdicts_not_waited_for_row_layouts(E, lines, permute):
+    """How the kernel of a linear block system moves its rows (jit_kernel.hip.hpp: fast_wave): where every wavefront's variables
+    are one contiguous piece of the row -- gen_big_problem.py's numbering -- as full 16-byte accesses through an LDS copy of the
+    piece, its last wavefront's piece shorter, odd lengths included (333, 97 lines); where they are not -- the same systems with
+    their variables renumbered at random -- value by value.  Calls above 1 MB (out of place); bitwise against the oracle."""
+    ref = T.load(T.gen_big_problem(lines))
+    n = ref.num_vars
+    recs = O.stack(ref.constraints).copy()
+    guesses = ref.guesses.copy()
+    if permute:
+        perm = np.random.default_rng(lines).permutation(n).astype(np.uint32)
+        for i in range(len(recs)):
+            k = O.KIND_NUM_IDS[int(recs["kind"][i])]
+            recs["ids"][i, :k] = perm[recs["ids"][i, :k]]
+        g2 = np.empty(n)
+        g2[perm] = guesses
+        guesses = g2
+    B = max(40, (1 << 20) // (8 * n) + 8)
+    x0 = guesses[None, :] + gen.keyed_uniform(5 + lines, B, n, -0.25, 0.25)
+    sysobj = E.System(recs, n)
+    assert sysobj.specialize(wait=True) == 2
+    rc, xo, it, conv, nun = O.solve_batch(recs, x0, linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0 and np.all(it == 2)
+    for _ in range(2):
+        x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+        assert np.array_equal(x, xo) and np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv) and not mask.any()
+
+
 def test_random_classes_interpreter_and_specialised_kernel_agree_bitwise(E):
     """Random little systems of all 25 kinds (the fuzz generator's), each replicated 130 times with jittered guesses into
     a block system: the component interpreter and the run-time compiled kernel give the same bits in every output

@@ -31,6 +31,18 @@ print(f"# {tot} systems checked in {len(lines)} calls; {need} ({100.0 * need / m
       f"{beyond} are (system, shape, start) checks of systems whose ORACLE answers differ among themselves by more than 5e-6: judged by "
       f"residual and unsatisfied set instead, their coordinates within min(20 x that spread, max(1e-2, 2 x that spread)) (largest coordinate error among "
       f"them {b_err:.2e}, widest bar granted {b_bar:.2e}).  {its} iteration counts were inside the oracle's range rather than equal.")
+rx2 = re.compile(r"stays there bit for bit (\d+), moves by at most ([\d.e+-]+) otherwise")
+fixed = 0
+moved = 0.0
+for l in lines:
+    m2 = rx2.search(l)
+    if m2:
+        fixed += int(m2[1])
+        moved = max(moved, float(m2[2]))
+print(f"# Round 6: every one of those {beyond} checks also restarts the ORACLE at the device's answer (idempotence: the reference's algorithm started "
+      f"where the device ended).  Where the answer meets the residual tolerance the reference's loop must end before its first iteration and leave "
+      f"the values untouched, bit for bit: {fixed} of {beyond}; the others (solves the step test or the iteration limit ended) move by at most {moved:.2e} "
+      f"relative -- a same-answer check far below 1e-4 for systems whose oracle runs differ among themselves by up to 1e-2.")
 print(f"# calls in which no system needed the measured bar: {clean} (not listed); the other {len(listed)} follow.")
 for l in listed:
     print(l)
