@@ -904,8 +904,10 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                     o += "    ezpz::jit::solve_kernel<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) + ", " + (any_nonlinear ? "true" : "false") + ", " +
                          (plan.unit_weights ? "true" : "false") + ", " + (one ? "true" : "false") + ", " + (fuse ? "true" : "false") + ", false>(a, smem);\n}\n";
             }
-            // the caller's variables of every wavefront (of the G * T that share a system): one contiguous run?  Then the kernels below
-            // move a wavefront's piece of a row as full lines (jit_kernel.hip.hpp: fast_wave, IO 2)
+            // the caller's variables of every wavefront (of the G * T that share a system): one contiguous run?  Then the one-workgroup
+            // kernel below moves a wavefront's piece of a row as full lines (jit_kernel.hip.hpp: fast_wave, IO 2) -- for systems of four
+            // wavefronts or more: same box, previous build / this one, M solves/s: 2000 x 2000 134.8 -> 142.0, 2400 x 2400 113.1 ->
+            // 111.5, but 800 x 800 (two wavefronts per system) 289 -> 274
             std::vector<uint32_t> wave_lo(G * T, 0), wave_n(G * T, 0);
             bool contiguous = true;
             for (uint32_t w = 0; w < G * T && contiguous; ++w) {
@@ -946,7 +948,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                     o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ", " + std::to_string(fast_waves - variant) +
                          ") ezpz_jit_solve_fast" + (variant ? "_b" : "") + "(const ezpz::jit::JitArgs a) {\n";
                     o += std::string("    ezpz::jit::") + (G > 1 ? "solve_kernel_grid_fast" : "solve_kernel_fast") + "<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) +
-                         (G == 1 ? (contiguous ? ", true" : ", false") : "") + ">(a);\n}\n";
+                         (G == 1 ? (contiguous && T >= 4 ? ", true" : ", false") : "") + ">(a);\n}\n";
                 }
                 if (G == 1) {
                     o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve_list(const ezpz::jit::JitArgs a) {\n";
