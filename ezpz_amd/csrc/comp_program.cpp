@@ -907,7 +907,9 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
             // the caller's variables of every wavefront (of the G * T that share a system): one contiguous run?  Then the one-workgroup
             // kernel below moves a wavefront's piece of a row as full lines (jit_kernel.hip.hpp: fast_wave, IO 2) -- for systems of four
             // wavefronts or more: same box, previous build / this one, M solves/s: 2000 x 2000 134.8 -> 142.0, 2400 x 2400 113.1 ->
-            // 111.5, but 800 x 800 (two wavefronts per system) 289 -> 274
+            // 111.5, but 800 x 800 (two wavefronts per system) 289 -> 274; and not for a system on several workgroups (the ladder, same
+            // box: 256 systems per launch 0.93 -> 0.99 M, but the 64-system launches of the bench leg 0.87 -> 0.81 M: the first system's
+            // piece goes through LDS before anything starts)
             std::vector<uint32_t> wave_lo(G * T, 0), wave_n(G * T, 0);
             bool contiguous = true;
             for (uint32_t w = 0; w < G * T && contiguous; ++w) {
@@ -948,7 +950,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                     o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ", " + std::to_string(fast_waves - variant) +
                          ") ezpz_jit_solve_fast" + (variant ? "_b" : "") + "(const ezpz::jit::JitArgs a) {\n";
                     o += std::string("    ezpz::jit::") + (G > 1 ? "solve_kernel_grid_fast" : "solve_kernel_fast") + "<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) +
-                         (G == 1 ? (contiguous && T >= 4 ? ", true" : ", false") : "") + ">(a);\n}\n";
+                         (contiguous && T >= 4 && G == 1 ? ", true" : ", false") + ">(a);\n}\n";
                 }
                 if (G == 1) {
                     o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve_list(const ezpz::jit::JitArgs a) {\n";

@@ -1471,7 +1471,7 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
 // wavefront, one barrier, its stores, and every G-th time a turn at the totals.  A kernel of its own because it needs a third of
 // the registers of the loop (no r_next, no step kept across a rendezvous, nothing of the general evaluators): more systems in
 // flight.  The only wait left is flow control: a workgroup may be four systems ahead of the totals (the ring's depth).
-template <class SEQ, int NWAVES>
+template <class SEQ, int NWAVES, bool CONTIG = false>
 __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
     using namespace ezpz::dev;
     const int tid = threadIdx.x;
@@ -1482,8 +1482,25 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
     GridScratch* const gs0 = a.grid + grid_slot;
     const uint32_t wave_global = grid_wg * NWAVES + wave;
     SEQ seq;
-    fast_setup(seq, a, wave_global, lane);
-    if (grid_slot < a.batch) fast_fetch(seq, a, grid_slot);  // (the guesses of the first system; every later one's a system ahead)
+    // (CONTIG: a wavefront's variables are one contiguous piece of the row -- moved as full lines through an LDS copy, fast_wave IO 2)
+    constexpr int PIECE = ((SEQ::NVS + 1) / 2) * 128;
+    __shared__ __attribute__((aligned(16))) double fast_row[CONTIG ? NWAVES * 2 * PIECE : 2];
+    uint32_t first_byte = 0, piece_bytes = 0;
+    if constexpr (CONTIG) {
+        first_byte = a.blob[a.o_ranges + 2 * wave_global] * 8u;
+        piece_bytes = a.blob[a.o_ranges + 2 * wave_global + 1] * 8u;
+    }
+    double* const row_lds = fast_row + (CONTIG ? wave * 2 * PIECE : 0);
+    fast_setup(seq, a, wave_global, lane, first_byte);
+    if (grid_slot < a.batch) {  // (the guesses of the first system; every later one's a system ahead)
+        if constexpr (CONTIG) {
+            bufword4_t q[(SEQ::NVS + 1) / 2];
+            piece_load<(SEQ::NVS + 1) / 2>(q, row_at(a.x0 + (uint64_t)grid_slot * a.n_row), first_byte, piece_bytes, lane);
+            piece_to_lds<(SEQ::NVS + 1) / 2>(q, row_lds, lane);
+        } else {
+            fast_fetch(seq, a, grid_slot);
+        }
+    }
     fast_factor(seq, a);
     constexpr int GROUPS = NWAVES * 16;      // a turn at the totals: thread = (value tid & 3, group tid >> 2)
     __shared__ double fast_part[2][4 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
@@ -1535,7 +1552,11 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
         if (have) {
             const uint64_t sys_n = sys + n_slots;
             double v[4];
-            const unsigned int wave_flags = fast_wave<0>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, nullptr);
+            unsigned int wave_flags;
+            if constexpr (CONTIG)
+                wave_flags = fast_wave<2>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, row_lds + kp * PIECE, row_lds + (kp ^ 1u) * PIECE, first_byte, piece_bytes);
+            else
+                wave_flags = fast_wave<0>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, nullptr);
             stamp();  // 1: both steps taken, stores issued
             if (lane == 63) {
 #pragma unroll
