@@ -120,6 +120,23 @@ bool stream_capturing(hipStream_t stream) {
     return capturing != hipStreamCaptureStatusNone;
 }
 
+// Launches of one system that share device state between them -- the counters its workgroups draw their systems from, the redo lists of
+// its `_fast` entry, whose count a call's last launch zeroes for the NEXT call -- run one after the other whatever streams they are
+// enqueued on: a launch on another stream than the last one waits for everything enqueued there.  (An event per launch instead cost the
+// back-to-back launches of one stream two runtime calls and a barrier packet each.)  False: could not be arranged.
+bool chain_launches(EzpzSystem& s, hipStream_t stream) {
+    bool ok = true;
+    if (!s.ticket_done) ok = hipEventCreateWithFlags(&s.ticket_done, hipEventDisableTiming) == hipSuccess;
+    if (ok && s.ticket_used && s.ticket_stream != stream) {
+        ok = hipEventRecord(s.ticket_done, s.ticket_stream) == hipSuccess && hipStreamWaitEvent(stream, s.ticket_done, 0) == hipSuccess;
+        if (!ok) {  // (the old stream is gone: whatever ran on it is awaited the blunt way)
+            (void)hipGetLastError();
+            ok = hipDeviceSynchronize() == hipSuccess;
+        }
+    }
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
 // The counters a specialised kernel's workgroups draw their systems from (jit_kernel.hip.hpp: JitArgs::ticket), for a launch on
 // `stream`: created on first use; launches that share them are chained.  False: the launch keeps fixed shares.
 bool prepare_tickets(EzpzSystem& s, hipStream_t stream) {
@@ -134,16 +151,7 @@ bool prepare_tickets(EzpzSystem& s, hipStream_t stream) {
         ok = hipMemset(s.ticket.p, 0, 8 * 1024 * sizeof(unsigned int)) == hipSuccess;
         for (unsigned int& b : s.ticket_base) b = 0;
     }
-    if (ok && !s.ticket_done) ok = hipEventCreateWithFlags(&s.ticket_done, hipEventDisableTiming) == hipSuccess;
-    if (ok && s.ticket_used && s.ticket_stream != stream) {
-        // another stream than last time: everything enqueued on the old one first (an event per launch instead
-        // cost the back-to-back launches of one stream two runtime calls and a barrier packet each)
-        ok = hipEventRecord(s.ticket_done, s.ticket_stream) == hipSuccess && hipStreamWaitEvent(stream, s.ticket_done, 0) == hipSuccess;
-        if (!ok) {  // (the old stream is gone: whatever ran on it is awaited the blunt way)
-            (void)hipGetLastError();
-            ok = hipDeviceSynchronize() == hipSuccess;
-        }
-    }
+    ok = ok && chain_launches(s, stream);
     if (!ok) (void)hipGetLastError();
     return ok;
 }
@@ -418,7 +426,7 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
             if (st == 0 && (big || sync || s.launches.fetch_add(1) >= pol.jit_after_launches)) st = comp_jit_request(s.jit, sync);
             if (st == 2) {
                 if (s.comp->jit_wgs <= 1 && comp_jit_fast_ok(s.jit, *s.comp, L, s.device, s.lim.cus) && !stream_capturing(stream) &&
-                    jit_redo_lists(s, L.batch, stream) == EZPZ_OK) {
+                    jit_redo_lists(s, L.batch, stream) == EZPZ_OK && chain_launches(s, stream)) {
                     // a linear system: the kernel that does not wait for the LM control's verdicts, then the loop over the systems it
                     // lists (jit_kernel.hip.hpp: solve_kernel_fast)
                     const unsigned int turn = s.jit_redo_turn;
@@ -428,6 +436,8 @@ int launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
                     if (comp_jit_launch(s.jit, *s.comp, s.dev_comp, Lt, s.device, s.lim.cus, stream, nullptr, 0, fast_wgs, s.jit_redo[turn].p,
                                         s.jit_redo[turn ^ 1u].p, s.jit_redo_seen_dev, s.jit_redo_seen) == EZPZ_OK) {
                         if (Lt.ticket) advance_tickets(s, stream, fast_wgs, L.batch, 2);
+                        s.ticket_stream = stream;  // (the redo lists are shared with the next call: chain_launches)
+                        s.ticket_used = true;
                         s.jit_redo_turn = turn ^ 1u;
                         return EZPZ_OK;
                     }

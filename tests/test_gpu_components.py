@@ -403,6 +403,89 @@ def test_verdicts_not_waited_for_row_layouts(E, lines, permute):
         assert np.array_equal(x, xo) and np.array_equal(st["iterations"], it) and np.array_equal(st["converged"], conv) and not mask.any()
 
 
+def test_verdicts_not_waited_for_on_two_streams(E):
+    """The `_device` entry may be called on one EzpzSystem from several streams.  The kernels that do not wait for verdicts share two
+    redo lists per system between consecutive calls (each call's last launch zeroes the other list's count): calls on another
+    stream than the last one are chained behind it (launch.hip: chain_launches).  Twelve calls alternating between two streams, every
+    third system of every call one that needs the loop kernel: every call's results equal the host entry's."""
+    import torch
+
+    ref = T.load(T.gen_big_problem(500))
+    n = ref.num_vars
+    sysobj = E.System(ref.constraints, n)
+    assert sysobj.specialize(wait=True) == 2
+    exact = np.zeros(n)
+    exact[0::4] = exact[2::4] = np.arange(500)
+    exact[3::4] = 4.0
+    B = 96
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    calls = []
+    for c in range(12):
+        x0 = ref.guesses[None, :] + gen.keyed_uniform(900 + c, B, n, -0.25, 0.25)
+        x0[c % 3::3] = exact + gen.keyed_uniform(950 + c, 1, n, -1e-5, 1e-5)[0]  # (one iteration is enough: not the expected verdicts)
+        st = streams[c % 2]
+        with torch.cuda.stream(st):
+            xd = torch.from_numpy(x0).to(dev, non_blocking=False)
+            xo = torch.empty_like(xd)
+            sd = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
+            sysobj.solve_batch_device(xd.data_ptr(), B, xo.data_ptr(), sd.data_ptr(), 0, st.cuda_stream, E.Config())
+        calls.append((x0, xd, xo, sd))
+    torch.cuda.synchronize(dev)
+    for x0, xd, xo, sd in calls:
+        x, st, _ = sysobj.solve_batch(x0)
+        assert np.array_equal(xo.cpu().numpy(), x)
+        got = np.frombuffer(sd.cpu().numpy().tobytes(), dtype=E.STATUS_DTYPE)
+        assert np.array_equal(got["iterations"], st["iterations"]) and np.array_equal(got["converged"], st["converged"])
+        assert set(int(i) for i in st["iterations"]) == {1, 2}
+
+
+def test_random_linear_classes_on_the_kernels_that_do_not_wait(E):
+    """The generator splits a linear class's `solve` into the factorisation of J^T J + lambda I (lambda only: once per launch, in
+    scalar registers) and the substitutions (comp_program.cpp: factor / solve_f) for the kernels that do not wait for the LM
+    control's verdicts.  gen_big_problem.py's two classes are a 2 x 2 and a 1 x 1 matrix; here: random little systems of the nine
+    LINEAR kinds (3 ... 8 variables, 2 ... 7 constraints: several elimination levels, fill, free variables, duplicated and
+    contradictory constraints -- whose systems do not converge in two iterations and go through the redo list), each replicated 130 ...
+    400 times with jittered guesses into a block system, calls above 1 MB (out of place: those kernels), twice (the redo lists of
+    consecutive calls alternate).  Every output against the component interpreter of a fresh system, bit for bit, and the oracle."""
+    rng = np.random.default_rng(2468)
+    linear = [O.FIXED, O.SCALAR_EQUAL, O.VERTICAL, O.HORIZONTAL, O.VERTICAL_DISTANCE, O.HORIZONTAL_DISTANCE, O.CIRCLE_RADIUS,
+              O.POINTS_COINCIDENT, O.MIDPOINT]
+    took_fast = redone = 0
+    for trial in range(12):
+        nv = int(rng.integers(3, 9))
+        cons = [gen.arb_constraint(rng, int(rng.choice(linear)), hi=nv) for _ in range(int(rng.integers(2, 8)))]
+        base = rng.uniform(-6.0, 6.0, nv)
+        copies = int(rng.integers(130, 401))
+        recs, g = replicate(cons, base, copies, seed=trial, jitter=0.05)
+        n = len(g)
+        B = (1 << 20) // (8 * n) + 9  # (just above the zero-copy limit of the host entry)
+        x0 = g[None, :] + gen.keyed_uniform(300 + trial, B, n, -0.5, 0.5)
+        x0[B // 2] = g  # (and an unjittered one)
+        fresh = E.System(recs, n)
+        if fresh.info()["team_mode"] != 3:
+            continue
+        xw, stw, maskw = fresh.solve_batch(x0, want_mask=True)  # the component interpreter
+        sysobj = E.System(recs, n)
+        assert sysobj.specialize(wait=True) == 2
+        src = E.specialized_source(recs, n)
+        took_fast += "ezpz_jit_solve_fast" in src
+        for rep in range(2):
+            x, st, mask = sysobj.solve_batch(x0, want_mask=True)
+            assert np.array_equal(x, xw, equal_nan=True) and np.array_equal(mask, maskw), trial
+            for f in st.dtype.names:
+                assert np.array_equal(st[f], stw[f], equal_nan=True), (trial, f)
+        redone += int(np.any(st["iterations"] != 2))
+        want = O.solve(recs, x0[0], linsolve=O.LINSOLVE_SPARSE)
+        assert want.error == 0 and np.array_equal(np.isnan(x[0]), np.isnan(want.final_values)), trial
+        if want.converged and want.final_residual_inf <= 1e-8:
+            # (consistent constraints: the residual test ends the solve.  Contradictory ones end on the step test at the least-squares
+            # minimum, after as many iterations as the noise in |d| takes to drop below 1e-12 -- the kernels agree with each other
+            # on that count bit for bit, the oracle's summation order gives another)
+            assert want.iterations == int(st["iterations"][0]) and bool(st["converged"][0]), trial
+    assert took_fast >= 8 and redone >= 2, (took_fast, redone)
+
+
 def test_random_classes_interpreter_and_specialised_kernel_agree_bitwise(E):
     """Random little systems of all 25 kinds (the fuzz generator's), each replicated 130 times with jittered guesses into
     a block system: the component interpreter and the run-time compiled kernel give the same bits in every output
