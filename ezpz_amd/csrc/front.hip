@@ -11,10 +11,13 @@ namespace ezpz {
 extern std::mutex g_grid_mu;          // launch.hip: launches whose workgroups wait for each other are chained per device
 extern hipEvent_t g_grid_event[16];
 
-static thread_local uint32_t g_probe_m = 0;
-static thread_local double* g_probe_out = nullptr;
-static thread_local const double* g_probe_in = nullptr;
-static thread_local double g_probe_scale = 1e-11;
+// What a probe launch adds to a solve launch (FrontArgs::probe_*).
+struct FrontProbe {
+    uint32_t m = 0;
+    double* out = nullptr;
+    const double* in = nullptr;
+    double scale = 1e-11;
+};
 
 template <bool LIN>
 static int front_launch_kernel(EzpzSystem& s, FrontArgs& fa, hipStream_t stream) {
@@ -60,7 +63,7 @@ static int front_launch_kernel(EzpzSystem& s, FrontArgs& fa, hipStream_t stream)
     return EZPZ_OK;
 }
 
-int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
+static int front_launch_with(EzpzSystem& s, SolveArgs& args, hipStream_t stream, const FrontProbe& probe) {
     const FrontPlan& plan = *s.fronts;
     if (!s.dev_fronts) return EZPZ_ERR_INVALID_ARGUMENT;
     FrontArgs fa{};
@@ -87,16 +90,18 @@ int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
     fa.verdict_chunk = plan.verdict_chunk;
     fa.scratch = nullptr;
     fa.scratch_stride = 0;
-    fa.probe_m = g_probe_m;  // (front_launch_probe, this thread)
-    fa.probe_out = g_probe_out;
-    fa.probe_in = g_probe_in;
-    fa.probe_scale = g_probe_scale;
+    fa.probe_m = probe.m;  // (front_launch_probe)
+    fa.probe_out = probe.out;
+    fa.probe_in = probe.in;
+    fa.probe_scale = probe.scale;
     fa.stamps = args.stamps;
     fa.done = args.done;
     fa.done.request = nullptr;  // (this kernel does not stay resident between calls)
     args.done.request = nullptr;
     return plan.linear_only ? front_launch_kernel<true>(s, fa, stream) : front_launch_kernel<false>(s, fa, stream);
 }
+
+int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) { return front_launch_with(s, args, stream, FrontProbe{}); }
 
 // The null-space probes of FreedomAnalysis (FrontArgs::probe_m): `m` probes of `batch` systems at the values x_dev ([batch][n_vars],
 // caller order), answers to y_dev ([batch][m][n_vars]); w_dev: the probes' vectors ([batch][m][n_vars]), or null = pseudo-random signs.
@@ -112,15 +117,12 @@ int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double*
     args.initial_lambda = 0.0;
     // (like launch(): what a launch creates on first use -- the occupancy figure, the scratch of several workgroups -- under the lock)
     std::lock_guard<std::mutex> launch_lock(s.launch_mu);
-    g_probe_m = m;
-    g_probe_out = y_dev;
-    g_probe_in = w_dev;
-    g_probe_scale = lambda_scale;
-    const int rc = front_launch(s, args, stream);
-    g_probe_m = 0;
-    g_probe_out = nullptr;
-    g_probe_in = nullptr;
-    return rc;
+    FrontProbe probe;
+    probe.m = m;
+    probe.out = y_dev;
+    probe.in = w_dev;
+    probe.scale = lambda_scale;
+    return front_launch_with(s, args, stream, probe);
 }
 
 }  // namespace ezpz
