@@ -425,7 +425,8 @@ __global__ void __launch_bounds__(256) freedom_kernel(const FreedomArgs a) {
                 a.n_under[base + g] = a.qr_timed_out && a.qr_timed_out[base + g] != 0 ? 0xFFFFFFFFu : under[g];
         __syncthreads();
     }
-    if (a.done_flag && gridDim.x == 1) {  // (every thread's stores are issued; the release store publishes them to the host)
+    if (a.done_flag && gridDim.x == 1) {  // (every thread's stores are acknowledged; the release store publishes them to the host)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -593,7 +594,12 @@ constexpr uint32_t kQrCols = 16, kQrChunks = 64, kQrKeep = 32;
 // its agent-scope fences publish the workgroup's stores (they sit in the XCD's L2, which the write-back covers) and drop
 // stale lines before anybody reads on.  (cooperative groups' grid.sync() does the same for the whole grid and took ~20 us
 // with 125 workgroups of 1024 lanes: two of them were 40 of a step's 50 us.)
+// Every lane first waits for its own stores to be acknowledged: the workgroup barrier does not (a barrier orders a workgroup's
+// accesses among its own wavefronts, which share an L1), and lane 0's release only waits for lane 0's wavefront -- a store of
+// another wavefront still on its way to the L2 when lane 0 writes the L2 back would stay there, unseen by the other XCDs, until
+// somebody's next write-back.
 __device__ __forceinline__ void qr_rendezvous(unsigned int* counter, unsigned int& target, unsigned int workgroups) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         target += workgroups;
@@ -675,11 +681,12 @@ __global__ void __launch_bounds__(1024) fr_qr_kernel(const FreedomStepArgs a, co
                     if (i > k) nk /= denom;
                     W[(size_t)i * n + k] = nk;
                 }
+                // (the chain also moves column k's norm to position bj; here that store would race with the other workgroups' pivot
+                // searches of this step, and nobody needs it: the apply phase writes the norm of every column right of k anew)
                 if (wg == 0 && tid == 0 && bj != k) {
                     const double t = W[oPerm + k];
                     W[oPerm + k] = W[oPerm + bj];
                     W[oPerm + bj] = t;
-                    W[oTau + bj] = W[oTau + k];
                 }
             }
         }

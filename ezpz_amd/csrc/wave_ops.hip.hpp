@@ -11,10 +11,12 @@ namespace ezpz {
 namespace dev {
 
 // The last thing a kernel does when its launch carries a completion word (DoneWord, dev_types.hpp): every thread of the
-// workgroup has issued its stores; one thread per workgroup counts it in, and the last workgroup's release store at
-// system scope publishes everything the launch wrote before the word itself.
+// workgroup waits until its stores are acknowledged (the workgroup barrier does not wait for them, and the release below only
+// waits for its own wavefront's); one thread per workgroup counts it in, and the last workgroup's release store at system scope
+// publishes everything the launch wrote before the word itself.
 __device__ __forceinline__ void publish_done(const DoneWord& w) {
     if (!w.flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         bool last = true;
