@@ -134,3 +134,30 @@ def test_probes_equal_the_pivoted_qr_over_the_fuzz(E, family, monkeypatch):
             f.write(line + "\n" + "".join(l + "\n" for l in log))
     assert mismatch == 0, "\n".join(log[:10])
     assert checked >= 120 and clear >= 40
+
+
+def test_pivoted_qr_on_several_workgroups_is_repeatable(E, monkeypatch):
+    """The device's pivoted QR of systems too large for one workgroup has three routes (freedom.hip: the matrix resident in
+    registers, one cooperative launch streaming it, a chain of launches per step).  Each must give the same bits on the same
+    input every time -- round 6's fuzz caught the cooperative one, three 1400-variable systems side by side, differing from call
+    to call (a store still on its way when the rendezvous wrote the L2 back; a store racing with the pivot search) -- and all
+    three the same id lists where no pivot sits at the rank rule's threshold."""
+    rng = np.random.default_rng(5)
+    recs, true = variant(rng, "tree", 700, 7.66, 6, 1, 1, 1e-5)
+    n = len(true)
+    sysobj = E.System(recs, n, team_size=E.TEAM_AUTO_LATENCY)
+    X = np.stack([true, true + 0.05 * rng.uniform(-1, 1, n), true + 0.05 * rng.uniform(-1, 1, n)])
+    x, st, _ = sysobj.solve_batch(X, E.Config(max_iterations=60))
+    x[0] = true
+    monkeypatch.setenv("EZPZ_FREEDOM_PROBES", "0")
+    masks = {}
+    for chain in ("1", "2", ""):
+        monkeypatch.setenv("EZPZ_FREEDOM_CHAIN", chain)
+        for xs in (x, x[1:2]):  # three systems side by side; one (the resident route where it fits)
+            runs = [sysobj.freedom_batch(xs) for _ in range(6)]
+            for m, p in runs[1:]:
+                assert np.array_equal(m, runs[0][0]) and np.array_equal(p, runs[0][1]), f"route {chain!r}, {len(xs)} systems: not repeatable"
+            masks[(chain, len(xs))] = runs[0][0]
+    for key, m in masks.items():
+        assert np.array_equal(m, masks[("1", 3)][-len(m):] if len(m) == 3 else masks[("1", 3)][1:2]), key
+    assert masks[("1", 3)].sum(axis=1).min() >= 5  # (five constraints dropped for good: the degrees of freedom are there)
