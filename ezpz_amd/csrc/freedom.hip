@@ -210,6 +210,56 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                 HIP_TRY(hipFuncSetAttribute((const void*)freedom_kernel<false>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 const uint32_t m = F.comp0.m, nc = F.comp0.n, ndiag = std::min(m, nc);
+                // The route of the QR, decided before the initialisation (which zeroes the resident route's chunk area):
+                //   * the matrix resident in the workgroups' registers for the whole factorisation (fr_qrc_kernel: up to 2048 rows,
+                //     8 columns per workgroup, its reflector slots inside the null-space and Q blocks), as many systems side by side
+                //     as the device holds that way (one at 1400 variables, two at 800) -- 7.9 / 15 / 23 ms per round at 800 / 1400 /
+                //     2000 variables;
+                //   * the chain of one launch pair per step: 24 / 65 / 126 ms, and a dozen systems side by side cost it little more
+                //     -- so a call of more systems than a few resident rounds hold goes there;
+                //   * one cooperative launch streaming the trailing matrix (fr_qr_kernel): 16 / 39 / 76 ms for ONE system, slower
+                //     than the chain from two (its workgroups are dealt among the systems) -- one system the resident route
+                //     cannot take.
+                // EZPZ_FREEDOM_CHAIN=2 / 1 (read per call: tests switch it): not the first / only the last.
+                const char* const chain_env = std::getenv("EZPZ_FREEDOM_CHAIN");
+                const bool chain_only = chain_env && chain_env[0] == '1', no_resident = chain_env && chain_env[0] == '2';
+                int coop = 0;
+                (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
+                uint64_t cap_resident = 0, cap_streaming = 0;
+                if (coop && !chain_only) {
+                    int per_cu = 0;
+                    if (!no_resident && m <= kQcRows && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fr_qrc_kernel, 1024, 0) == hipSuccess && per_cu > 0)
+                        cap_resident = (uint64_t)sys->lim.cus * (uint64_t)per_cu;
+                    per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fr_qr_kernel, 1024, 0) == hipSuccess && per_cu > 0)
+                        cap_streaming = (uint64_t)sys->lim.cus * (uint64_t)per_cu;
+                    (void)hipGetLastError();
+                }
+                // (workgroups x columns per workgroup of the resident route for `nb` systems side by side; 0 columns: does not fit)
+                auto resident_shape = [&](uint32_t nb, uint32_t& cper_out, uint32_t& G_out, uint32_t& chunk_doubles) {
+                    cper_out = G_out = chunk_doubles = 0;
+                    if (!cap_resident || !nb) return;
+                    const uint32_t g_max = (uint32_t)std::min<uint64_t>(kQcMaxWgs, cap_resident / nb);
+                    const uint64_t m_slot = ((uint64_t)m + 3) & ~3ull, room = 2ull * nc * nc;  // doubles of the two blocks
+                    for (uint32_t cper = g_max ? std::max(1u, (nc + g_max - 1) / g_max) : kQcCols + 1; cper <= kQcCols; ++cper) {
+                        const uint32_t G = (nc + cper - 1) / cper;
+                        const uint64_t need = kQcSmallDoubles + 4ull * G * m_slot;  // two sets of slots, two doubles a chunk
+                        if (need <= room && need < 0xFFFFFFFFull) {
+                            cper_out = cper, G_out = G, chunk_doubles = (uint32_t)need;
+                            return;
+                        }
+                    }
+                };
+                uint32_t resident_side_by_side = 0;
+                for (uint32_t nb = 1, cper, G, chunk; nb <= grid; ++nb) {
+                    resident_shape(nb, cper, G, chunk);
+                    if (!cper) break;
+                    resident_side_by_side = nb;
+                }
+                // (a resident round is 10-12 us per Householder step, a step of the chain 29 / 46 / 63 us at 800 / 1400 / 2000 columns)
+                const uint32_t resident_rounds_max = nc >= 1800 ? 5 : nc >= 1200 ? 4 : 2;
+                const bool by_resident_rounds = resident_side_by_side && (batch + resident_side_by_side - 1) / resident_side_by_side <= resident_rounds_max;
+                if (by_resident_rounds) grid = std::min(grid, resident_side_by_side);
                 for (size_t base = 0; base < batch; base += grid) {
                     const uint32_t nb = (uint32_t)std::min<size_t>(grid, batch - base);
                     FreedomStepArgs sa{};
@@ -226,34 +276,9 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                     sa.item1 = F.comp0.item1;
                     const uint32_t bl_mn = (uint32_t)std::min<uint64_t>(((uint64_t)m * nc + 255) / 256, 4096);
                     const uint32_t bl_it = std::max<uint32_t>(1, std::min<uint32_t>((sa.item1 - sa.item0 + 255) / 256, 1024));
-                    // The route of the QR, decided before the initialisation (which zeroes the resident route's chunk area):
-                    // first choice the matrix resident in the workgroups' registers for the whole factorisation (fr_qrc_kernel: up
-                    // to 2048 rows, 8 columns per workgroup, its reflector slots inside the null-space and Q blocks); then one
-                    // cooperative launch streaming the trailing matrix (fr_qr_kernel); then the chain of one launch pair per step.
-                    // EZPZ_FREEDOM_CHAIN=2 / 1 (read per call: tests switch it): not the first / only the last.
-                    const char* const chain_env = std::getenv("EZPZ_FREEDOM_CHAIN");
-                    const bool chain_only = chain_env && chain_env[0] == '1';
                     uint32_t res_cper = 0, res_G = 0;
                     sa.k = 0;
-                    if (!chain_only && !(chain_env && chain_env[0] == '2') && m <= kQcRows) {
-                        int per_cu = 0, coop = 0;
-                        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
-                        if (coop && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fr_qrc_kernel, 1024, 0) == hipSuccess && per_cu > 0) {
-                            const uint64_t capacity = (uint64_t)sys->lim.cus * (uint64_t)per_cu;
-                            const uint32_t g_max = (uint32_t)std::min<uint64_t>(kQcMaxWgs, capacity / nb);
-                            const uint64_t m_slot = ((uint64_t)m + 3) & ~3ull, room = 2ull * nc * nc;  // doubles of the two blocks
-                            for (uint32_t cper = g_max ? std::max(1u, (nc + g_max - 1) / g_max) : kQcCols + 1; cper <= kQcCols; ++cper) {
-                                const uint32_t G = (nc + cper - 1) / cper;
-                                const uint64_t need = kQcSmallDoubles + 4ull * G * m_slot;  // two sets of slots, two doubles a chunk
-                                if (need <= room && need < 0xFFFFFFFFull) {
-                                    res_cper = cper, res_G = G;
-                                    sa.k = (uint32_t)need;
-                                    break;
-                                }
-                            }
-                        }
-                        (void)hipGetLastError();
-                    }
+                    if (by_resident_rounds) resident_shape(nb, res_cper, res_G, sa.k);
                     hipLaunchKernelGGL(fr_init_kernel, dim3(bl_mn, nb), dim3(256), 0, stream, sa);
                     hipLaunchKernelGGL(fr_scatter_kernel, dim3(bl_it, nb), dim3(256), 0, stream, sa);
                     hipLaunchKernelGGL(fr_norms_kernel, dim3((nc + 255) / 256, nb), dim3(256), 0, stream, sa);
@@ -267,23 +292,14 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                         if (!cooperative && hip_debug()) std::fprintf(stderr, "[ezpz hip] resident QR launch -> %s\n", hipGetErrorString(ce));
                         (void)hipGetLastError();
                     }
-                    if (!chain_only && !cooperative) {
-                        int per_cu = 0, coop = 0;
-                        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
-                        if (hip_debug()) std::fprintf(stderr, "[ezpz hip] cooperative launch attribute %d\n", coop);
-                        if (coop && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fr_qr_kernel, 1024, 0) == hipSuccess && per_cu > 0) {
-                            const uint64_t capacity = (uint64_t)sys->lim.cus * (uint64_t)per_cu;
-                            const uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1, (nc + kQrCols - 1) / kQrCols), capacity / nb);
-                            if (G >= 1 && (uint64_t)G * nb <= capacity) {
-                                uint32_t nd = ndiag;
-                                void* params[] = {&sa, &nd};
-                                const hipError_t ce = hipLaunchCooperativeKernel((const void*)fr_qr_kernel, dim3(G, nb), dim3(1024), params, 0, stream);
-                                cooperative = ce == hipSuccess;
-                                if (!cooperative && hip_debug())
-                                    std::fprintf(stderr, "[ezpz hip] cooperative QR launch (%u x %u workgroups of %llu) -> %s\n", G, nb,
-                                                 (unsigned long long)capacity, hipGetErrorString(ce));
-                            }
-                        }
+                    if (!cooperative && cap_streaming && batch == 1) {
+                        const uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1, (nc + kQrCols - 1) / kQrCols), cap_streaming);
+                        uint32_t nd = ndiag;
+                        void* params[] = {&sa, &nd};
+                        const hipError_t ce = hipLaunchCooperativeKernel((const void*)fr_qr_kernel, dim3(G, nb), dim3(1024), params, 0, stream);
+                        cooperative = ce == hipSuccess;
+                        if (!cooperative && hip_debug())
+                            std::fprintf(stderr, "[ezpz hip] cooperative QR launch (%u workgroups of %llu) -> %s\n", G, (unsigned long long)cap_streaming, hipGetErrorString(ce));
                         (void)hipGetLastError();
                     }
                     for (uint32_t k = 0; k < ndiag && !cooperative; ++k) {
