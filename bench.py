@@ -55,6 +55,7 @@ from ezpz_amd.synthetic import keyed_uniform, make_workload  # noqa: E402  (re-e
 METRIC = "solves/sec on 2000-row massive_parallel_system @1/2/4/8 GPU; iters-to-converge"
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # HBM3E peak BW 8.0 TB/s (spec)
+STREAMING_COPY_GBS = 5400.0  # measured, not a datasheet figure: tools/row_copy_bench.hip (full-line accesses, 768-2048 workgroups)
 PMC_SETS = [
     ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
      "SQ_INSTS_VALU", "SQ_INSTS_SALU"],
@@ -252,6 +253,10 @@ def roofline(info_parts, B, kernel_ms, solves_per_launch_iters, pmc, n_kernels, 
         traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         hbm["traffic_over_compulsory"] = traffic / compulsory
         hbm["measured_gbs"] = traffic / t / 1e9
+        # what a kernel that only copies 16 KB rows in and out with whole-line accesses reaches on this device at the solve kernels'
+        # occupancy (tools/row_copy_bench.hip, profiles/r06_row_copy_bench.txt: 5.2-5.45 TB/s; 4.9-5.0 with 8-byte strided accesses)
+        hbm["streaming_copy_gbs"] = STREAMING_COPY_GBS
+        hbm["frac_of_streaming_copy"] = hbm["measured_gbs"] / STREAMING_COPY_GBS
     if pmc.get("_state_in_hbm"):
         # lanes across the batch (batch_kernel.hip.hpp) keep the solver state in global memory by design.  SURVEY 8(d)'s BYTES
         # formula is the MODEL of that traffic (every access priced as if it reached HBM); the roof itself is what the counters
