@@ -1471,8 +1471,11 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
 // wavefront, one barrier, its stores, and every G-th time a turn at the totals.  A kernel of its own because it needs a third of
 // the registers of the loop (no r_next, no step kept across a rendezvous, nothing of the general evaluators): more systems in
 // flight.  The only wait left is flow control: a workgroup may be four systems ahead of the totals (the ring's depth).
-template <class SEQ, int NWAVES, bool CONTIG = false>
+// IO (fast_wave): 0 = values stored slot by slot; 1 = they wait in LDS and a wavefront's stores go out back to back (the pieces of a
+// 128-byte line reach the L2 together: written once); 2 = the wavefront's contiguous piece of the row as whole lines through LDS.
+template <class SEQ, int NWAVES, int IO = 0>
 __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
+    constexpr bool CONTIG = IO == 2;
     using namespace ezpz::dev;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1484,13 +1487,13 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
     SEQ seq;
     // (CONTIG: a wavefront's variables are one contiguous piece of the row -- moved as full lines through an LDS copy, fast_wave IO 2)
     constexpr int PIECE = ((SEQ::NVS + 1) / 2) * 128;
-    __shared__ __attribute__((aligned(16))) double fast_row[CONTIG ? NWAVES * 2 * PIECE : 2];
+    __shared__ __attribute__((aligned(16))) double fast_row[CONTIG ? NWAVES * 2 * PIECE : IO == 1 ? NWAVES * SEQ::NVS * 64 : 2];
     uint32_t first_byte = 0, piece_bytes = 0;
     if constexpr (CONTIG) {
         first_byte = a.blob[a.o_ranges + 2 * wave_global] * 8u;
         piece_bytes = a.blob[a.o_ranges + 2 * wave_global + 1] * 8u;
     }
-    double* const row_lds = fast_row + (CONTIG ? wave * 2 * PIECE : 0);
+    double* const row_lds = fast_row + (CONTIG ? wave * 2 * PIECE : IO == 1 ? wave * SEQ::NVS * 64 : 0);
     fast_setup(seq, a, wave_global, lane, first_byte);
     if (grid_slot < a.batch) {  // (the guesses of the first system; every later one's a system ahead)
         if constexpr (CONTIG) {
@@ -1556,7 +1559,7 @@ __device__ __forceinline__ void solve_kernel_grid_fast(const JitArgs& a) {
             if constexpr (CONTIG)
                 wave_flags = fast_wave<2>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, row_lds + kp * PIECE, row_lds + (kp ^ 1u) * PIECE, first_byte, piece_bytes);
             else
-                wave_flags = fast_wave<0>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, nullptr);
+                wave_flags = fast_wave<IO>(seq, a, sys, sys_n, sys_n < a.batch, wave_global, lane, v, IO == 1 ? row_lds : nullptr);
             stamp();  // 1: both steps taken, stores issued
             if (lane == 63) {
 #pragma unroll

@@ -616,3 +616,49 @@ def test_drawn_systems_on_two_streams_of_one_system_object(E):
     for i, out in enumerate(outs):
         assert torch.equal(out, want), i
         assert torch.equal(sts[i], st), i
+
+
+def test_verdicts_not_waited_for_on_several_workgroups_long_launches(E):
+    """The 200 000-variable ladder (98 workgroups per system) has two compilations of the kernel that does not wait for verdicts
+    (jit.cpp: comp_jit_launch): launches of up to six rounds of the systems in flight take the one at four wavefronts per SIMD, longer
+    ones the one at three, whose values wait in LDS for stores that go out back to back.  Device-resident launches of 24 (the first)
+    and 72 systems (the second; a host call would arrive in pieces of ten), with systems whose verdicts are not the expected ones at
+    the start, in the middle and at the end -- converged at the start, one iteration enough, a failed pivot, barely off -- under
+    three configurations: every output equal to the oracle's bit for bit, and the short launch's to the long launch's."""
+    import torch
+
+    ref = T.load(T.gen_big_problem(50000))
+    n = ref.num_vars
+    lines = 50000
+    sysobj = E.System(ref.constraints, n)
+    assert sysobj.info()["grid_workgroups"] > 1 and sysobj.specialize(wait=True) == 2
+    B = 72
+    exact = np.zeros(n)
+    exact[0::4] = exact[2::4] = np.arange(lines)
+    exact[3::4] = 4.0
+    x0 = ref.guesses[None, :] + gen.keyed_uniform(178, B, n, -0.25, 0.25)
+    x0[0] = exact
+    x0[10] = exact + gen.keyed_uniform(179, 1, n, -1e-4, 1e-4)[0]
+    x0[18, 5] = np.nan
+    x0[27] = exact
+    x0[27, 2 * (lines // 2)] += 1e-6
+    x0[40] = exact
+    x0[B - 1] = exact
+    xin = torch.from_numpy(x0).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    seen = set()
+    for cfg in (E.Config(), E.Config(max_iterations=3), E.Config(step_tolerance=1e3)):
+        ocfg = O.Config(cfg.max_iterations, cfg.residual_tolerance, cfg.step_tolerance, cfg.initial_lambda)
+        rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0, ocfg, linsolve=O.LINSOLVE_SPARSE)
+        assert rc == 0
+        for count in (B, 24, B):
+            xd = torch.full((count, n), float("nan"), dtype=torch.float64, device="cuda")
+            std = torch.zeros((count, 32), dtype=torch.uint8, device="cuda")
+            sysobj.solve_batch_device(xin.data_ptr(), count, xd.data_ptr(), std.data_ptr(), 0, stream, cfg)
+            torch.cuda.synchronize()
+            st = std.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+            assert np.array_equal(st["iterations"], it[:count]) and np.array_equal(st["converged"], conv[:count]), (cfg, count)
+            assert np.array_equal(st["n_unsatisfied"], nun[:count]), (cfg, count)
+            assert np.array_equal(xd.cpu().numpy(), xo[:count], equal_nan=True), (cfg, count)
+        seen.update((int(i), int(c)) for i, c in zip(st["iterations"], st["converged"]))
+    assert {(0, 1), (1, 1), (2, 1), (3, 0)} <= seen, str(sorted(seen))
