@@ -945,9 +945,9 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                 static const char* env_fw = std::getenv("EZPZ_JIT_FAST_MINWAVES");  // occupancy hint, for measurements
                 // (several workgroups per system: the variant with a wavefront per SIMD less has the registers to let the values wait in
                 // LDS for stores that go out back to back; EZPZ_JIT_GRID_STAGE=0: slot by slot there too, for measurements)
-                static const bool grid_stage = [] {
+                static const int grid_stage = [] {
                     const char* e = std::getenv("EZPZ_JIT_GRID_STAGE");
-                    return !(e && e[0] == '0');
+                    return e ? std::atoi(e) : 1;  // (2 = its piece of the row as whole lines where contiguous: measured 2-6 % slower on the ladder)
                 }();
                 const int fast_waves = env_fw ? std::atoi(env_fw) : (fast_vg + 40 <= 128 ? 4 : fast_vg + 40 <= 168 ? 3 : 2);
                 // (twice: for the estimated occupancy and for one wavefront per SIMD less -- the loader takes the first that keeps its
@@ -956,7 +956,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
                     o += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(T * 64) + ", " + std::to_string(fast_waves - variant) +
                          ") ezpz_jit_solve_fast" + (variant ? "_b" : "") + "(const ezpz::jit::JitArgs a) {\n";
                     o += std::string("    ezpz::jit::") + (G > 1 ? "solve_kernel_grid_fast" : "solve_kernel_fast") + "<ezpz::jit::Slots<" + seq + ">, " + std::to_string(T) +
-                         (G > 1 ? (variant && grid_stage ? ", 1" : ", 0") : contiguous && T >= 4 ? ", true" : ", false") + ">(a);\n}\n";
+                         (G > 1 ? (variant && grid_stage ? (grid_stage >= 2 && contiguous && T >= 4 ? ", 2" : ", 1") : ", 0") : contiguous && T >= 4 ? ", true" : ", false") + ">(a);\n}\n";
                 }
                 if (G == 1) {
                     o += "extern \"C\" __global__ void __launch_bounds__(" + bounds + ") ezpz_jit_solve_list(const ezpz::jit::JitArgs a) {\n";
