@@ -599,10 +599,12 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
         double sq = 0.0, mx = __builtin_nan("");
         seq.each([&](auto& s, auto* cls, int index) {
             using C = typename class_of<decltype(cls)>::type;
-            // (by hand: the compiler's atomicAdd waits for the answer on the spot -- it folds the lanes of a wavefront into one
-            // request and hands every lane its share)
+            // (the answer is wanted after the slots' evaluation, and the COMPILER must know it is on its way: an instruction of its
+            // own that reads the register before then -- a spill -- waits for it.  Round 5 issued the atomic in an asm statement and
+            // waited in another: a register spilled between the two would have been saved before the answer arrived.  The kernels
+            // are compiled without the atomic optimizer (jit.cpp), whose wavefront-wide form reads the answer on the spot.)
             if (index == 0 && tickets && tid == 0)
-                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
+                drawn = __hip_atomic_fetch_add(a.ticket + ticket_c * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < C::NV; ++k) s.x[k] = x0[s.ids[k]];
             unsigned long long wm = 0;
@@ -620,7 +622,7 @@ __device__ __forceinline__ void solve_kernel(const JitArgs& a, double* smem) {
             }
         });
         if (tickets && tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn)::"memory");
+            asm volatile("" : "+v"(drawn));  // (the first use, here and not earlier: the compiler's wait for the answer comes with it)
             drawn_lds[parity] = (drawn - a.ticket_base[ticket_c]) * 8u + ticket_c;
         }
         // FUSE: eval()'s sums do not get a rendezvous of their own -- the wavefront's totals wait in scalar registers and ride in
@@ -1363,8 +1365,8 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     const uint32_t ticket_c = blockIdx.x & 7u;
     __shared__ unsigned int fast_drawn[2];
     unsigned int drawn = 0;
-    if (tickets && tid == 0)
-        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
+    // (the compiler's atomic, so that it knows an answer is on its way -- solve_kernel's note on its draw)
+    if (tickets && tid == 0) drawn = __hip_atomic_fetch_add(a.ticket + ticket_c * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SEQ seq;
     __shared__ double fast_part[2][4 * 16];  // [parity of k][value][wavefront]: the wavefronts' partials
     __shared__ int fast_pflag[2][16];
@@ -1393,7 +1395,7 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     uint64_t sys = blockIdx.x, sys_n = sys + gridDim.x;
     if (tickets) {
         if (tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn)::"memory");
+            asm volatile("" : "+v"(drawn));
             fast_drawn[1] = drawn;
         }
         __syncthreads();
@@ -1401,8 +1403,7 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
     }
     unsigned int kp = 0;
     for (; sys < a.batch; kp ^= 1u) {
-        if (tickets && tid == 0)
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(a.ticket + ticket_c * kTicketStride), "v"(1u) : "memory");
+        if (tickets && tid == 0) drawn = __hip_atomic_fetch_add(a.ticket + ticket_c * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double v[4];
         unsigned int wave_flags;
         if constexpr (CONTIG)
@@ -1411,7 +1412,7 @@ __device__ __forceinline__ void solve_kernel_fast(const JitArgs& a) {
             wave_flags = fast_wave<1>(seq, a, sys, sys_n, sys_n < a.batch, wave, lane, v, row_lds);
         uint64_t sys_nn = sys_n + gridDim.x;
         if (tickets && tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn)::"memory");
+            asm volatile("" : "+v"(drawn));
             if (NWAVES > 1) fast_drawn[kp] = drawn;
         }
         if constexpr (NWAVES == 1) {

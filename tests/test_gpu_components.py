@@ -662,3 +662,48 @@ def test_verdicts_not_waited_for_on_several_workgroups_long_launches(E):
             assert np.array_equal(xd.cpu().numpy(), xo[:count], equal_nan=True), (cfg, count)
         seen.update((int(i), int(c)) for i, c in zip(st["iterations"], st["converged"]))
     assert {(0, 1), (1, 1), (2, 1), (3, 0)} <= seen, str(sorted(seen))
+
+
+def test_drawn_systems_survive_register_spills(E, tmp_path):
+    """Workgroups draw their systems with one lane's atomic whose answer is wanted a system later (jit_kernel.hip.hpp: tickets).
+    Round 5 / 6 issued it in an asm statement and waited for it in another: a compilation under register pressure saved the
+    register to scratch memory in between -- before the answer had arrived -- and systems were skipped (found with a forced
+    occupancy: statuses untouched).  The draw is the compiler's atomic now, which waits before any read of its own.  Here: the
+    2400 x 2400 block system compiled for four wavefronts per SIMD (EZPZ_JIT_FAST_MINWAVES=4: 59 registers in scratch memory),
+    8192 systems per launch so that the workgroups draw; every system solved, a sample bitwise against the oracle."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import ezpz_amd as E, gen
+from oracle import oracle as O
+from oracle import textual as T
+lines = 600
+ref = T.load(T.gen_big_problem(lines))
+n = ref.num_vars
+s = E.System(ref.constraints, n)
+assert s.specialize(wait=True) == 2
+B = 8192
+x0 = ref.guesses[None, :] + gen.keyed_uniform(611, B, n, -0.25, 0.25)
+xin = torch.from_numpy(x0).cuda()
+for rep in range(3):
+    xd = torch.full((B, n), float("nan"), dtype=torch.float64, device="cuda")
+    std = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+    s.solve_batch_device(xin.data_ptr(), B, xd.data_ptr(), std.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = std.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+    x = xd.cpu().numpy()
+    assert np.all(st["iterations"] == 2) and np.all(st["converged"] == 1), (rep, int((st["iterations"] != 2).sum()))
+    assert not np.isnan(x).any()
+    exact = np.zeros(n); exact[0::4] = exact[2::4] = np.arange(lines); exact[3::4] = 4.0
+    assert np.max(np.abs(x - exact[None, :])) <= 1e-9
+    sample = np.arange(0, B, B // 64)
+    rc, xo, it, conv, nun = O.solve_batch(ref.constraints, x0[sample], linsolve=O.LINSOLVE_SPARSE)
+    assert rc == 0 and np.array_equal(x[sample], xo)
+print("ok")
+'''
+    env = dict(os.environ, EZPZ_JIT_FAST_MINWAVES="4", EZPZ_JIT_CACHE_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
