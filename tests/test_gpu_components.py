@@ -707,3 +707,16 @@ print("ok")
     env = dict(os.environ, EZPZ_JIT_FAST_MINWAVES="4", EZPZ_JIT_CACHE_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_random_linear_blocks_in_launches_whose_workgroups_draw(E):
+    """tools/stress_random_blocks.py, eight of its random block systems of the linear kinds: device-resident launches of 3000 ... 9001
+    systems -- more than the launch has workgroups, so they draw their systems -- through the kernels that do not wait for verdicts
+    and their redo lists.  Every value and status equal to the loop kernel alone (a call in place) bit for bit, whole batch, three
+    times over; and to the component interpreter wherever the residual test ends the solve.  (61 systems, the compilations forced
+    to other occupancies among them, ran clean at the end of round 6: profiles/r06_stress_blocks.txt.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stress_random_blocks as S
+
+    done, fast, redone, bad = S.run_trials(8, 97531)
+    assert bad == 0 and done >= 6 and fast >= 6

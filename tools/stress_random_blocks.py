@@ -1,0 +1,95 @@
+"""Stress: random block systems of the nine LINEAR kinds (3 ... 8 variables, 2 ... 7 constraints per block, 130 ... 900 blocks) through the
+run-time compiled kernels with DEVICE-RESIDENT batches larger than the launch's workgroups -- so that the workgroups draw their
+systems (tickets) -- against the component interpreter of a fresh system, bit for bit in every value and status, whole batch; plus
+one system against the oracle.  The host-entry tests of tests/test_gpu_components.py stay below the launch's workgroups.
+usage (GPU box): python tools/stress_random_blocks.py [trials] [seed]      (EZPZ_JIT_FAST_MINWAVES=5 / 6: compilations under register pressure)"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np, torch
+import ezpz_amd as E, gen
+from oracle import oracle as O
+
+
+def replicate(constraints, guesses, copies, seed=0, jitter=0.0):
+    n = len(guesses)
+    rng = np.random.default_rng(seed)
+    recs, gs = [], []
+    for r in range(copies):
+        for c in constraints:
+            c = c.copy()
+            c["ids"] = c["ids"] + r * n
+            recs.append(c)
+        gs.append(np.asarray(guesses) + (rng.uniform(-jitter, jitter, n) if jitter else 0.0))
+    return O.stack(recs), np.concatenate(gs)
+
+
+def run(sysobj, xin, B, n, cfg):
+    xd = torch.full((B, n), float("nan"), dtype=torch.float64, device="cuda")
+    std = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+    sysobj.solve_batch_device(xin.data_ptr(), B, xd.data_ptr(), std.data_ptr(), 0, torch.cuda.current_stream().cuda_stream, cfg)
+    torch.cuda.synchronize()
+    return xd.cpu().numpy(), std.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+
+
+def run_trials(trials, seed):
+    rng = np.random.default_rng(seed)
+    linear = [O.FIXED, O.SCALAR_EQUAL, O.VERTICAL, O.HORIZONTAL, O.VERTICAL_DISTANCE, O.HORIZONTAL_DISTANCE, O.CIRCLE_RADIUS, O.POINTS_COINCIDENT, O.MIDPOINT]
+    done = fast = redone = bad = 0
+    for trial in range(trials):
+        nv = int(rng.integers(3, 9))
+        cons = [gen.arb_constraint(rng, int(rng.choice(linear)), hi=nv) for _ in range(int(rng.integers(2, 8)))]
+        base = rng.uniform(-6.0, 6.0, nv)
+        copies = int(rng.choice([130, 200, 333, 500, 900]))
+        recs, g = replicate(cons, base, copies, seed=trial, jitter=0.05)
+        n = len(g)
+        B = int(rng.choice([3000, 5000, 9001]))
+        x0 = g[None, :] + gen.keyed_uniform(700 + trial, B, n, -0.5, 0.5)
+        x0[B // 2] = g
+        fresh = E.System(recs, n)
+        if fresh.info()["team_mode"] != 3:
+            continue
+        xin = torch.from_numpy(x0).cuda()
+        cfg = E.Config()
+        xw, stw = run(fresh, xin, B, n, cfg)  # the component interpreter
+        sysobj = E.System(recs, n)
+        if sysobj.specialize(wait=True) != 2:
+            print(f"trial {trial}: no specialised kernel", flush=True)
+            continue
+        src = E.specialized_source(recs, n)
+        is_fast = "ezpz_jit_solve_fast" in src
+        ok = True
+        # the loop kernel alone (a call in place: the kernels that do not wait need the guesses kept) -- what the redo list must reproduce
+        xi = xin.clone()
+        sti = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+        sysobj.solve_batch_device(xi.data_ptr(), B, xi.data_ptr(), sti.data_ptr(), 0, torch.cuda.current_stream().cuda_stream, cfg)
+        torch.cuda.synchronize()
+        xl, stl = xi.cpu().numpy(), sti.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+        # systems the residual test ends: the same bits from every kernel.  Contradictory systems end on the step test at the
+        # least-squares minimum after as many iterations as the noise in |d| and in the strict comparison of the sums takes -- the
+        # interpreter's own count there depends on the size of its launch, the oracle's is another (tests/test_gpu_components.py)
+        settled = (stw["converged"] == 1) & (stw["final_residual_inf"] <= 1e-8)
+        for rep in range(3):
+            x, st = run(sysobj, xin, B, n, cfg)
+            same_loop = np.array_equal(x, xl, equal_nan=True) and all(np.array_equal(st[f], stl[f], equal_nan=True) for f in st.dtype.names)
+            same_int = np.array_equal(x[settled], xw[settled], equal_nan=True) and all(np.array_equal(st[f][settled], stw[f][settled], equal_nan=True) for f in st.dtype.names)
+            if not (same_loop and same_int):
+                ok = False
+                nbad = int((~np.all((x == xl) | (np.isnan(x) & np.isnan(xl)), axis=1)).sum())
+                nbad2 = int((~np.all((x[settled] == xw[settled]) | (np.isnan(x[settled]) & np.isnan(xw[settled])), axis=1)).sum())
+                print(f"trial {trial} rep {rep}: MISMATCH: {nbad} of {B} systems differ from the loop kernel alone, {nbad2} of {int(settled.sum())} settled ones from the interpreter; statuses untouched {int((st['iterations'] == 0).sum())}", flush=True)
+        want = O.solve(recs, x0[0], linsolve=O.LINSOLVE_SPARSE)
+        if want.error != 0 or not np.array_equal(np.isnan(xw[0]), np.isnan(want.final_values)):
+            ok = False
+            print(f"trial {trial}: the oracle disagrees on system 0", flush=True)
+        done += 1
+        fast += is_fast
+        redone += int(np.any(stw["iterations"] != 2))
+        bad += not ok
+        print(f"trial {trial}: {nv} variables x {copies} blocks, {B} systems per launch, kernel that does not wait: {is_fast}, iterations {sorted(set(int(i) for i in st['iterations']))}, ended by the residual test {int(settled.sum())}: {'ok' if ok else 'FAILED'}", flush=True)
+    print(f"# {done} block systems, {fast} on the kernels that do not wait for verdicts, {redone} with systems on the redo list, {bad} failed")
+    return done, fast, redone, bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run_trials(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 97531)[3] else 0)
