@@ -91,5 +91,54 @@ def run_trials(trials, seed):
     return done, fast, redone, bad
 
 
+def run_trials_all_kinds(trials, seed):
+    """Blocks of ALL 25 kinds (weights 1 / 2.5): the loop kernel of the run-time compiled code in one launch whose workgroups draw
+    their systems against the same kernel in launches of 256 systems (fewer than it has workgroups: nobody draws), bit for bit."""
+    rng = np.random.default_rng(seed)
+    done = bad = 0
+    kinds = set()
+    for trial in range(trials):
+        nv = int(rng.integers(3, 9))
+        cons = []
+        for _ in range(int(rng.integers(1, 6))):
+            c = gen.arb_constraint(rng, int(rng.integers(0, O.NUM_KINDS)), hi=nv)
+            c["weight"] = float(rng.choice([1.0, 1.0, 2.5]))
+            cons.append(c)
+        base = rng.uniform(-6.0, 6.0, nv)
+        copies = int(rng.choice([130, 200, 333]))
+        recs, g = replicate(cons, base, copies, seed=trial, jitter=0.05)
+        n = len(g)
+        B = int(rng.choice([3000, 5000]))
+        x0 = g[None, :] + gen.keyed_uniform(900 + trial, B, n, -0.3, 0.3)
+        sysobj = E.System(recs, n)
+        if sysobj.info()["team_mode"] != 3 or sysobj.specialize(wait=True) != 2:
+            continue
+        kinds.update(int(c["kind"]) for c in cons)
+        xin = torch.from_numpy(x0).cuda()
+        cfg = E.Config(max_iterations=12)
+        x, st = run(sysobj, xin, B, n, cfg)
+        xs = np.empty_like(x)
+        sts = np.empty_like(st)
+        for lo in range(0, B, 256):
+            hi = min(B, lo + 256)
+            xs[lo:hi], sts[lo:hi] = run(sysobj, xin[lo:hi], hi - lo, n, cfg)
+        ok = True
+        for rep in range(2):
+            if rep:
+                x, st = run(sysobj, xin, B, n, cfg)
+            same = np.array_equal(x, xs, equal_nan=True) and all(np.array_equal(st[f], sts[f], equal_nan=True) for f in st.dtype.names)
+            if not same:
+                ok = False
+                rows = ~np.all((x == xs) | (np.isnan(x) & np.isnan(xs)), axis=1)
+                print(f"trial {trial} rep {rep}: MISMATCH in {int(rows.sum())} of {B} systems; statuses untouched {int((st['iterations'] == 0).sum())} / {int((sts['iterations'] == 0).sum())}; iterations differing {int((st['iterations'] != sts['iterations']).sum())}", flush=True)
+        done += 1
+        bad += not ok
+        print(f"trial {trial}: kinds {sorted(int(c['kind']) for c in cons)}, {nv} variables x {copies} blocks, {B} systems per launch, iterations {sorted(set(int(i) for i in st['iterations']))[:8]}: {'ok' if ok else 'FAILED'}", flush=True)
+    print(f"# all kinds: {done} block systems ({len(kinds)} kinds seen), {bad} failed")
+    return done, len(kinds), bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "all":
+        sys.exit(1 if run_trials_all_kinds(int(sys.argv[2]) if len(sys.argv) > 2 else 24, int(sys.argv[3]) if len(sys.argv) > 3 else 8642)[2] else 0)
     sys.exit(1 if run_trials(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 97531)[3] else 0)
