@@ -138,7 +138,59 @@ def run_trials_all_kinds(trials, seed):
     return done, len(kinds), bad
 
 
+def run_trials_grid(trials, seed):
+    """Linear blocks, so many that a system takes SEVERAL workgroups (the ladder's kernels: solve_kernel_grid_fast, both compilations --
+    launches of up to six rounds of the systems in flight and longer ones, jit.cpp: comp_jit_launch -- and the redo list through
+    solve_kernel_grid): device-resident launches of 12 and of 40 rounds' worth against the loop kernel alone (calls in place), bit for bit."""
+    rng = np.random.default_rng(seed)
+    linear = [O.FIXED, O.SCALAR_EQUAL, O.VERTICAL, O.HORIZONTAL, O.VERTICAL_DISTANCE, O.HORIZONTAL_DISTANCE, O.CIRCLE_RADIUS, O.POINTS_COINCIDENT, O.MIDPOINT]
+    done = bad = redone = 0
+    for trial in range(trials):
+        nv = int(rng.integers(3, 7))
+        cons = [gen.arb_constraint(rng, int(rng.choice(linear)), hi=nv) for _ in range(int(rng.integers(2, 6)))]
+        base = rng.uniform(-6.0, 6.0, nv)
+        copies = int(rng.choice([9000, 14000, 20000]))
+        recs, g = replicate(cons, base, copies, seed=trial, jitter=0.05)
+        n = len(g)
+        sysobj = E.System(recs, n)
+        info = sysobj.info()
+        if sysobj.specialize(wait=True) != 2:
+            print(f"trial {trial}: no specialised kernel ({info['team_mode']})", flush=True)
+            continue
+        G = sysobj.info()["grid_workgroups"]
+        if G <= 1:
+            print(f"trial {trial}: one workgroup per system", flush=True)
+            continue
+        slots = max(1, 1024 // G)
+        ok = True
+        for B in (2 * slots + 1, 8 * slots + 3):
+            x0 = g[None, :] + gen.keyed_uniform(1200 + trial, B, n, -0.5, 0.5)
+            x0[B // 2] = g
+            xin = torch.from_numpy(x0).cuda()
+            cfg = E.Config()
+            xi = xin.clone()
+            sti = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+            sysobj.solve_batch_device(xi.data_ptr(), B, xi.data_ptr(), sti.data_ptr(), 0, torch.cuda.current_stream().cuda_stream, cfg)
+            torch.cuda.synchronize()
+            xl, stl = xi.cpu().numpy(), sti.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
+            for rep in range(2):
+                x, st = run(sysobj, xin, B, n, cfg)
+                same = np.array_equal(x, xl, equal_nan=True) and all(np.array_equal(st[f], stl[f], equal_nan=True) for f in st.dtype.names)
+                if not same:
+                    ok = False
+                    rows = ~np.all((x == xl) | (np.isnan(x) & np.isnan(xl)), axis=1)
+                    print(f"trial {trial} B {B} rep {rep}: MISMATCH in {int(rows.sum())} of {B} systems; statuses untouched {int((st['iterations'] == 0).sum())}", flush=True)
+            redone += int(np.any(stl["iterations"] != 2))
+        done += 1
+        bad += not ok
+        print(f"trial {trial}: {nv} variables x {copies} blocks on {G} workgroups, launches of {2 * slots + 1} and {8 * slots + 3} systems, iterations {sorted(set(int(i) for i in stl['iterations']))[:8]}: {'ok' if ok else 'FAILED'}", flush=True)
+    print(f"# several workgroups per system: {done} block systems, {redone} launches with systems on the redo list, {bad} failed")
+    return done, redone, bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "grid":
+        sys.exit(1 if run_trials_grid(int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 1357)[2] else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "all":
         sys.exit(1 if run_trials_all_kinds(int(sys.argv[2]) if len(sys.argv) > 2 else 24, int(sys.argv[3]) if len(sys.argv) > 3 else 8642)[2] else 0)
     sys.exit(1 if run_trials(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 97531)[3] else 0)
