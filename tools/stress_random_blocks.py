@@ -67,7 +67,7 @@ def run_trials(trials, seed):
         xl, stl = xi.cpu().numpy(), sti.cpu().numpy().view(E.STATUS_DTYPE).reshape(-1)
         # systems the residual test ends: the same bits from every kernel.  Contradictory systems end on the step test at the
         # least-squares minimum after as many iterations as the noise in |d| and in the strict comparison of the sums takes -- the
-        # interpreter's own count there depends on the size of its launch, the oracle's is another (tests/test_gpu_components.py)
+        # interpreter (another number of wavefronts: another summation tree) may count differently there, the oracle's count is a third
         settled = (stw["converged"] == 1) & (stw["final_residual_inf"] <= 1e-8)
         for rep in range(3):
             x, st = run(sysobj, xin, B, n, cfg)
