@@ -125,7 +125,7 @@ int build_freedom(EzpzSystem* sys) {
 // *flagged says so (the caller polls the word instead of the stream: a stream query costs more than this kernel runs).
 int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* mask_dev, double* part_dev,
                    uint32_t* count_dev, hipStream_t stream, unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0,
-                   bool* flagged = nullptr) {
+                   bool* flagged = nullptr, bool chain_route = false) {
     auto& F = sys->freedom;
     // (a kernel of the calling thread's one-call path that waits on the device for its next request holds hipStreamPerThread: work
     // put there would queue behind it until its lease runs out, so it is told to leave -- unless this call has a stream of its own)
@@ -222,7 +222,9 @@ int freedom_device(EzpzSystem* sys, const double* x_dev, size_t batch, uint8_t* 
                 //     cannot take.
                 // EZPZ_FREEDOM_CHAIN=2 / 1 (read per call: tests switch it): not the first / only the last.
                 const char* const chain_env = std::getenv("EZPZ_FREEDOM_CHAIN");
-                const bool chain_only = chain_env && chain_env[0] == '1', no_resident = chain_env && chain_env[0] == '2';
+                // (chain_route: the caller's second attempt after a resident launch timed out -- not every workgroup of a cooperative
+                // launch becomes resident beside another process's or stream's kernels; the chain's launches wait for nobody)
+                const bool chain_only = chain_route || (chain_env && chain_env[0] == '1'), no_resident = chain_env && chain_env[0] == '2';
                 int coop = 0;
                 (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, sys->device);
                 uint64_t cap_resident = 0, cap_streaming = 0;
@@ -708,6 +710,15 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
             (void)hipGetLastError();
             return EZPZ_ERR_HIP;
         }
+        if (mask_poisoned(hmask, batch, n)) {
+            // the resident QR gave up waiting for workgroups that never became resident (a co-tenant): once more by the chain of launches
+            if (hip_debug()) std::fprintf(stderr, "[ezpz hip] the resident QR timed out -> the chain of launches\n");
+            if ((rc = freedom_device(sys, reinterpret_cast<const double*>(h), batch, hmask, hpart, nullptr, fstream, nullptr, 0, nullptr, true)) != EZPZ_OK) return rc;
+            if (hipStreamSynchronize(fstream) != hipSuccess) {
+                (void)hipGetLastError();
+                return EZPZ_ERR_HIP;
+            }
+        }
         std::memcpy(under_mask, hmask, batch * n);
         if (participation) std::memcpy(participation, hpart, x_bytes);
         return mask_poisoned(under_mask, batch, n) ? EZPZ_ERR_HIP : EZPZ_OK;
@@ -718,6 +729,11 @@ int ezpz_system_freedom_batch(EzpzSystem* sys, const double* x, size_t batch, ui
     HIP_TRY(hipMemcpy(F.x_in.p, x, batch * n * sizeof(double), hipMemcpyHostToDevice));
     if ((rc = freedom_device(sys, F.x_in.p, batch, F.mask.p, F.part.p, nullptr, nullptr)) != EZPZ_OK) return rc;
     HIP_TRY(hipMemcpy(under_mask, F.mask.p, batch * n, hipMemcpyDeviceToHost));
+    if (mask_poisoned(under_mask, batch, n)) {  // (as above: the resident QR timed out -> the chain of launches)
+        if (hip_debug()) std::fprintf(stderr, "[ezpz hip] the resident QR timed out -> the chain of launches\n");
+        if ((rc = freedom_device(sys, F.x_in.p, batch, F.mask.p, F.part.p, nullptr, nullptr, nullptr, 0, nullptr, true)) != EZPZ_OK) return rc;
+        HIP_TRY(hipMemcpy(under_mask, F.mask.p, batch * n, hipMemcpyDeviceToHost));
+    }
     if (participation) HIP_TRY(hipMemcpy(participation, F.part.p, batch * n * sizeof(double), hipMemcpyDeviceToHost));
     if (mask_poisoned(under_mask, batch, n)) return EZPZ_ERR_HIP;
     return EZPZ_OK;

@@ -161,3 +161,32 @@ def test_pivoted_qr_on_several_workgroups_is_repeatable(E, monkeypatch):
     for key, m in masks.items():
         assert np.array_equal(m, masks[("1", 3)][-len(m):] if len(m) == 3 else masks[("1", 3)][1:2]), key
     assert masks[("1", 3)].sum(axis=1).min() >= 5  # (five constraints dropped for good: the degrees of freedom are there)
+
+
+def test_large_qr_beside_a_co_running_kernel(E, tmp_path, monkeypatch):
+    """The resident route of the large pivoted QR is a cooperative launch over the whole device (250 workgroups of 1024 lanes at 2000
+    variables): beside another stream's or process's kernel some of them never become resident, the waiting ones give up after their
+    bound and flag the system.  The host entry then runs the chain of launches, which waits for nobody (round 6; before: EZPZ_ERR_HIP):
+    the analysis beside tools/noise.hip's kernel equals the one taken alone."""
+    import ctypes
+    import subprocess
+
+    so = str(tmp_path / "libnoise.so")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "noise.hip")],
+                          stderr=subprocess.DEVNULL)
+    N = ctypes.CDLL(so)
+    N.noise_start.argtypes = [ctypes.c_int]
+    recs, g = gen.connected_sketch(1000, 2000)
+    loose = E.System(recs[:-2], len(g), team_size=E.TEAM_AUTO_LATENCY)
+    x, st, _ = loose.solve_batch(g[None, :], E.Config(max_iterations=40))
+    monkeypatch.setenv("EZPZ_FREEDOM_PROBES", "0")
+    mask0, part0 = loose.freedom_batch(x)
+    assert mask0.sum() > 0
+    assert N.noise_start(160) == 0
+    try:
+        mask1, part1 = loose.freedom_batch(x)
+    finally:
+        assert N.noise_stop() == 0
+    assert np.array_equal(mask1, mask0) and np.allclose(part1, part0, atol=1e-9)
+    mask2, part2 = loose.freedom_batch(x)  # (and alone again: the resident route, the same bits as before)
+    assert np.array_equal(mask2, mask0) and np.array_equal(part2, part0)
