@@ -32,4 +32,12 @@ python -m pytest tests -m gpu -q 2>&1 | tail -6 > $out/pytest_gpu.txt
 cp gpurun_out/parity_bar.txt $out/parity_bar_raw.txt 2>/dev/null; cp gpurun_out/freedom_probes_fuzz.txt $out/freedom_probes_fuzz.txt 2>/dev/null
 python tools/parity_bar_summary.py $out/parity_bar_raw.txt "python -m pytest tests -m gpu (round 6, the whole GPU suite)" > $out/parity_bar.txt 2>/dev/null && rm -f $out/parity_bar_raw.txt
 python tools/reference_benches.py > $out/reference_benches.txt 2>/dev/null
+# the ladder's two compilations by systems per launch (EZPZ_JIT_GRID_STAGE=0: the first one whatever the launch)
+(echo "# EZPZ_JIT_GRID_STAGE=<0|1> python bench.py --workload massive50000 --batch <systems per launch> --steps 20 $B   (0 = the compilation at four wavefronts per SIMD whatever the launch: 10 systems in flight, values stored slot by slot; 1 = the default: beyond 60 systems per launch the compilation at three, 7 in flight, values staged in LDS and stored back to back)"
+for i in 1 2; do for w in 32 48 60 64 80 128 256 1024; do for v in 0 1; do echo "EZPZ_JIT_GRID_STAGE=$v --batch $w"; EZPZ_JIT_GRID_STAGE=$v python bench.py --workload massive50000 --batch $w --steps 20 $B 2>/dev/null | python -c "$P"; done; done; done) > $out/ladder_variants.txt
+(echo "# python tools/qr_routes.py  (FreedomAnalysis by the pivoted QR of 800 / 1400 / 2000 variables, ms per call by systems per call: chain of launches | EZPZ_FREEDOM_CHAIN=2 | default)"; python tools/qr_routes.py 2>&1 | grep -v amdgpu.ids) > $out/qr_routes_now.txt
+# the stress tools: random block systems whose workgroups draw, LDS patterns, a co-running kernel
+(echo "# python tools/stress_random_blocks.py 24; ... all 30; ... grid 10"; python tools/stress_random_blocks.py 24 2>&1 | grep -v amdgpu.ids; python tools/stress_random_blocks.py all 30 2>&1 | grep -v amdgpu.ids; python tools/stress_random_blocks.py grid 10 2>&1 | grep -v amdgpu.ids) > $out/stress_blocks_now.txt
+hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/liblds_poison.so tools/lds_poison.hip 2>/dev/null && (echo "# python tools/stress_lds_poison.py"; python tools/stress_lds_poison.py 2>&1 | grep -v amdgpu.ids) > $out/stress_lds_poison.txt
+hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/libnoise.so tools/noise.hip 2>/dev/null && (echo "# EZPZ_DEBUG=hip python tools/stress_noise.py"; EZPZ_DEBUG=hip timeout 1200 python tools/stress_noise.py 2>&1 | grep -v "amdgpu.ids\|cooperative launch attribute" | uniq -c) > $out/stress_noise.txt
 head -3 $out/massive_b65536_kernel_stats.csv; tail -3 $out/pytest_gpu.txt
