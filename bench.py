@@ -876,9 +876,14 @@ def main():
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(records, guesses, args.cpu_seconds, args.max_iterations)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        if not ok:
+            # a rate measured on wrong results is not a measurement: the line says so and the run fails
+            line["invalid"] = "the solves of the timed launches failed validation (statuses of the whole last batch, iteration count, oracle check): see results_ok, iters_to_converge, oracle_check"
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
