@@ -1009,7 +1009,7 @@ bool comp_plan_build(const EzpzConstraint* cs, size_t n_cs, size_t n_vars, const
 // overflow) would turn 0 x y_k into NaN on rows the serial order never touches, so `fin` reports whether every y_k was
 // finite and the kernel repeats the solve with the serial `tail` when not (pivots never see the right-hand side: `bad` is
 // the same either way; a non-finite entry of L fails its row's pivot in both orders).  wave_row_structure checks what that rests on (lists complete and compatible with one column order, fill closed) and the serial
-// `tail` stays when it does not hold (or EZPZ_JIT_WAVE_TAIL=0, A/B runs).
+// `tail` stays when it does not hold.
 struct WaveRows {
     bool ok = false;
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> col;  // per column k: (row i, slot) ascending in i
