@@ -252,6 +252,7 @@ struct FrontPlanner {
     bool home_fronts();
     void deal_workgroups();
     bool workgroup_shares();
+    bool wavefront_schedules(uint32_t g, const UVec& fl, std::vector<uint16_t>& sched, UVec& sched_par, UVec& sched_nkids);
     bool emit_workgroup(uint32_t g);
     bool emit();
     bool run() {
@@ -677,6 +678,118 @@ bool FrontPlanner::workgroup_shares() {
     return true;
 }
 
+// ---- the wavefronts' schedules: list scheduling of the workgroup's fronts on `waves` wavefronts by the cost model -- forward:
+//      a front is ready when its children in this workgroup are done (children elsewhere arrive as chunks, whenever), the
+//      ready front with the longest way up to the top goes to the wavefront that is free first; backward: ready when the
+//      parent is done, the longest way down first.  A wavefront runs its list in order and waits only for what its next
+//      front needs (front_kernel.hip.hpp): the per-level barriers cost the 300-variable sketch 11 rounds of fronts where
+//      the tree's critical path is 6.  (Deadlock-free: a front's dependencies start earlier in the simulated time than it
+//      does, on whatever wavefront, and every list is in simulated start order.)  Measured and not kept: ONE list in the
+//      order of the simulated starts from which a free wavefront takes the next front (a counter in LDS) -- it does not
+//      depend on the cost model's accuracy, but its in-order takes block more than they balance: one solve of 150 / 300 /
+//      2000 variables 96 -> 103, 179 -> 189, 450 -> 463 us (10 000: 924 -> 887).
+bool FrontPlanner::wavefront_schedules(const uint32_t g, const UVec& fl, std::vector<uint16_t>& sched, UVec& sched_par, UVec& sched_nkids) {
+    const uint32_t nf = (uint32_t)fl.size();
+    UVec loc_of(F, NONE);
+    for (uint32_t k = 0; k < nf; ++k) loc_of[fl[k]] = k;
+    UVec par(nf, NONE), nkids(nf, 0);
+    std::vector<UVec> kid_list(nf);
+    for (uint32_t k = 0; k < nf; ++k) {
+        const uint32_t p = fr[fl[k]].parent;
+        if (p != NONE && fr[p].wg == g) {
+            par[k] = loc_of[p];
+            ++nkids[par[k]];
+            kid_list[par[k]].push_back(k);
+        }
+    }
+    std::vector<double> cf(nf), cb(nf), up(nf, 0.0), down(nf, 0.0);
+    for (uint32_t k = 0; k < nf; ++k) {
+        cf[k] = front_cost(fr[fl[k]].K, fr[fl[k]].S, !fr[fl[k]].kids.empty());
+        cb[k] = front_bwd_cost(fr[fl[k]].K, fr[fl[k]].S);
+    }
+    // (fl is sorted by level: parents behind their children)
+    for (uint32_t k = nf; k-- > 0;) up[k] = cf[k] + (par[k] != NONE ? up[par[k]] : 0.0);
+    for (uint32_t k = 0; k < nf; ++k) {
+        down[k] += cb[k];
+        if (par[k] != NONE) down[par[k]] = std::max(down[par[k]], down[k]);
+    }
+    // (down[k] so far = cb[k] + the longest way below: recompute top-down as a priority = longest way down including itself)
+    auto run = [&](bool forward, std::vector<UVec>& lists) -> double {
+        lists.assign(waves, UVec());
+        std::vector<double> free_at(waves, 0.0), done_at(nf, 0.0);
+        UVec waiting(nf, 0);
+        std::vector<uint32_t> ready;
+        for (uint32_t k = 0; k < nf; ++k) {
+            waiting[k] = forward ? nkids[k] : (par[k] != NONE ? 1u : 0u);
+            if (!waiting[k]) ready.push_back(k);
+        }
+        std::vector<double> ready_at(nf, 0.0);
+        uint32_t left = nf;
+        double makespan = 0.0;
+        while (left) {
+            // the wavefront that is free first takes, of the fronts ready by then (or the one ready soonest), the one with
+            // the highest priority
+            uint32_t w = 0;
+            for (uint32_t i = 1; i < waves; ++i)
+                if (free_at[i] < free_at[w]) w = i;
+            double soonest = 1e300;
+            for (uint32_t k : ready) soonest = std::min(soonest, ready_at[k]);
+            const double now = std::max(free_at[w], soonest);
+            size_t best = ready.size();
+            for (size_t i = 0; i < ready.size(); ++i) {
+                const uint32_t k = ready[i];
+                if (ready_at[k] > now) continue;
+                const double pr = forward ? up[k] : down[k];
+                if (best == ready.size() || pr > (forward ? up[ready[best]] : down[ready[best]])) best = i;
+            }
+            const uint32_t k = ready[best];
+            ready.erase(ready.begin() + (long)best);
+            const double end = now + (forward ? cf[k] : cb[k]) + 60.0;
+            free_at[w] = end;
+            done_at[k] = end;
+            makespan = std::max(makespan, end);
+            lists[w].push_back(k);
+            --left;
+            if (forward) {
+                if (par[k] != NONE) {
+                    ready_at[par[k]] = std::max(ready_at[par[k]], end);
+                    if (--waiting[par[k]] == 0) ready.push_back(par[k]);
+                }
+            } else {
+                for (uint32_t c : kid_list[k]) {
+                    ready_at[c] = end;
+                    waiting[c] = 0;
+                    ready.push_back(c);
+                }
+            }
+        }
+        return makespan;
+    };
+    std::vector<UVec> fwd, bwd;
+    const double span_f = run(true, fwd), span_b = run(false, bwd);
+    sched.assign(2 * (waves + 1), 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<UVec>& L = pass ? bwd : fwd;
+        for (uint32_t w = 0; w < waves; ++w) {
+            sched[(size_t)pass * (waves + 1) + w] = (uint16_t)sched.size();
+            for (uint32_t k : L[w]) sched.push_back((uint16_t)k);
+        }
+        sched[(size_t)pass * (waves + 1) + waves] = (uint16_t)sched.size();
+    }
+    if (sched.size() >= 65535) return fail(why, "a workgroup's schedule does not fit 16-bit offsets");
+    if (sched.size() & 1) sched.push_back(0);
+    for (uint32_t k = 0; k < nf; ++k) {
+        sched_par.push_back(par[k]);
+        sched_nkids.push_back(nkids[k]);
+    }
+    // the model: the schedules' makespans instead of the levels' busiest wavefronts
+    if (g == 0)
+        model_top = span_f + span_b;
+    else
+        model_sub = std::max(model_sub, span_f + span_b);
+    return true;
+}
+
 // One workgroup's share of the plan: its fronts by level, the wavefronts' schedules, tables, assembly streams, workspace layout.
 bool FrontPlanner::emit_workgroup(const uint32_t g) {
     FrontWg& W = wgs[g];
@@ -705,117 +818,9 @@ bool FrontPlanner::emit_workgroup(const uint32_t g) {
         else
             model_sub = std::max(model_sub, up);
     }
-    // ---- the wavefronts' schedules: list scheduling of the workgroup's fronts on `waves` wavefronts by the cost model -- forward:
-    //      a front is ready when its children in this workgroup are done (children elsewhere arrive as chunks, whenever), the
-    //      ready front with the longest way up to the top goes to the wavefront that is free first; backward: ready when the
-    //      parent is done, the longest way down first.  A wavefront runs its list in order and waits only for what its next
-    //      front needs (front_kernel.hip.hpp): the per-level barriers cost the 300-variable sketch 11 rounds of fronts where
-    //      the tree's critical path is 6.  (Deadlock-free: a front's dependencies start earlier in the simulated time than it
-    //      does, on whatever wavefront, and every list is in simulated start order.)  Measured and not kept: ONE list in the
-    //      order of the simulated starts from which a free wavefront takes the next front (a counter in LDS) -- it does not
-    //      depend on the cost model's accuracy, but its in-order takes block more than they balance: one solve of 150 / 300 /
-    //      2000 variables 96 -> 103, 179 -> 189, 450 -> 463 us (10 000: 924 -> 887).
+    // (the wavefronts' schedules: wavefront_schedules, above)
     std::vector<uint16_t> sched;
-    {
-        const uint32_t nf = (uint32_t)fl.size();
-        UVec loc_of(F, NONE);
-        for (uint32_t k = 0; k < nf; ++k) loc_of[fl[k]] = k;
-        UVec par(nf, NONE), nkids(nf, 0);
-        std::vector<UVec> kid_list(nf);
-        for (uint32_t k = 0; k < nf; ++k) {
-            const uint32_t p = fr[fl[k]].parent;
-            if (p != NONE && fr[p].wg == g) {
-                par[k] = loc_of[p];
-                ++nkids[par[k]];
-                kid_list[par[k]].push_back(k);
-            }
-        }
-        std::vector<double> cf(nf), cb(nf), up(nf, 0.0), down(nf, 0.0);
-        for (uint32_t k = 0; k < nf; ++k) {
-            cf[k] = front_cost(fr[fl[k]].K, fr[fl[k]].S, !fr[fl[k]].kids.empty());
-            cb[k] = front_bwd_cost(fr[fl[k]].K, fr[fl[k]].S);
-        }
-        // (fl is sorted by level: parents behind their children)
-        for (uint32_t k = nf; k-- > 0;) up[k] = cf[k] + (par[k] != NONE ? up[par[k]] : 0.0);
-        for (uint32_t k = 0; k < nf; ++k) {
-            down[k] += cb[k];
-            if (par[k] != NONE) down[par[k]] = std::max(down[par[k]], down[k]);
-        }
-        // (down[k] so far = cb[k] + the longest way below: recompute top-down as a priority = longest way down including itself)
-        auto run = [&](bool forward, std::vector<UVec>& lists) -> double {
-            lists.assign(waves, UVec());
-            std::vector<double> free_at(waves, 0.0), done_at(nf, 0.0);
-            UVec waiting(nf, 0);
-            std::vector<uint32_t> ready;
-            for (uint32_t k = 0; k < nf; ++k) {
-                waiting[k] = forward ? nkids[k] : (par[k] != NONE ? 1u : 0u);
-                if (!waiting[k]) ready.push_back(k);
-            }
-            std::vector<double> ready_at(nf, 0.0);
-            uint32_t left = nf;
-            double makespan = 0.0;
-            while (left) {
-                // the wavefront that is free first takes, of the fronts ready by then (or the one ready soonest), the one with
-                // the highest priority
-                uint32_t w = 0;
-                for (uint32_t i = 1; i < waves; ++i)
-                    if (free_at[i] < free_at[w]) w = i;
-                double soonest = 1e300;
-                for (uint32_t k : ready) soonest = std::min(soonest, ready_at[k]);
-                const double now = std::max(free_at[w], soonest);
-                size_t best = ready.size();
-                for (size_t i = 0; i < ready.size(); ++i) {
-                    const uint32_t k = ready[i];
-                    if (ready_at[k] > now) continue;
-                    const double pr = forward ? up[k] : down[k];
-                    if (best == ready.size() || pr > (forward ? up[ready[best]] : down[ready[best]])) best = i;
-                }
-                const uint32_t k = ready[best];
-                ready.erase(ready.begin() + (long)best);
-                const double end = now + (forward ? cf[k] : cb[k]) + 60.0;
-                free_at[w] = end;
-                done_at[k] = end;
-                makespan = std::max(makespan, end);
-                lists[w].push_back(k);
-                --left;
-                if (forward) {
-                    if (par[k] != NONE) {
-                        ready_at[par[k]] = std::max(ready_at[par[k]], end);
-                        if (--waiting[par[k]] == 0) ready.push_back(par[k]);
-                    }
-                } else {
-                    for (uint32_t c : kid_list[k]) {
-                        ready_at[c] = end;
-                        waiting[c] = 0;
-                        ready.push_back(c);
-                    }
-                }
-            }
-            return makespan;
-        };
-        std::vector<UVec> fwd, bwd;
-        const double span_f = run(true, fwd), span_b = run(false, bwd);
-        sched.assign(2 * (waves + 1), 0);
-        for (int pass = 0; pass < 2; ++pass) {
-            const std::vector<UVec>& L = pass ? bwd : fwd;
-            for (uint32_t w = 0; w < waves; ++w) {
-                sched[(size_t)pass * (waves + 1) + w] = (uint16_t)sched.size();
-                for (uint32_t k : L[w]) sched.push_back((uint16_t)k);
-            }
-            sched[(size_t)pass * (waves + 1) + waves] = (uint16_t)sched.size();
-        }
-        if (sched.size() >= 65535) return fail(why, "a workgroup's schedule does not fit 16-bit offsets");
-        if (sched.size() & 1) sched.push_back(0);
-        for (uint32_t k = 0; k < nf; ++k) {
-            sched_par.push_back(par[k]);
-            sched_nkids.push_back(nkids[k]);
-        }
-        // the model: the schedules' makespans instead of the levels' busiest wavefronts
-        if (g == 0)
-            model_top = span_f + span_b;
-        else
-            model_sub = std::max(model_sub, span_f + span_b);
-    }
+    if (!wavefront_schedules(g, fl, sched, sched_par, sched_nkids)) return false;
     // local variables: own pivots in front order, ghosts behind
     UVec local_of(n, NONE);  // position -> local index
     UVec var_glob;
