@@ -104,7 +104,7 @@ static int front_launch_with(EzpzSystem& s, SolveArgs& args, hipStream_t stream,
 int front_launch(EzpzSystem& s, SolveArgs& args, hipStream_t stream) { return front_launch_with(s, args, stream, FrontProbe{}); }
 
 // The null-space probes of FreedomAnalysis (FrontArgs::probe_m): `m` probes of `batch` systems at the values x_dev ([batch][n_vars],
-// caller order), answers to y_dev ([batch][m][n_vars]); w_dev: the probes' vectors ([batch][m][n_vars]), or null = pseudo-random signs.
+// caller order), answers to y_dev ([batch][m][n_vars]); w_dev: the probes' vectors ([batch][m][n_vars]), or null = pseudo-random entries, uniform in [-1, 1).
 int front_launch_probe(EzpzSystem& s, const double* x_dev, size_t batch, double* y_dev, uint32_t m, hipStream_t stream, const double* w_dev,
                        double lambda_scale) {
     if (!s.fronts || !s.dev_fronts || !m) return EZPZ_ERR_INVALID_ARGUMENT;

@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(512, 1) front_solve_kernel(const FrontArgs a) 
         double lambda_probe = 0.0;
         for (;;) {
             if (mode == STEP && probing) {
-                // ---- probe j: w = pseudo-random signs (in x's place: the Jacobian is evaluated, x is not needed again), the
+                // ---- probe j: w = pseudo-random entries, uniform in [-1, 1) (in x's place: the Jacobian is evaluated, x is not needed again), the
                 //      right-hand side's residual vector J w (in r_next's place), lambda_p from J's largest entry ---------------------
                 {
                     double m2 = __builtin_nan(""), z0 = 0.0, z1 = __builtin_nan(""), z2 = 0.0;

@@ -152,7 +152,7 @@ struct FrontArgs {
     // of J).  A failed pivot writes NaN.  x_out / status / masks are not written.
     uint32_t probe_m;
     double* probe_out;
-    const double* probe_in;  // [batch][probe_m][n_vars] the vectors w_j themselves instead of the pseudo-random signs, or null
+    const double* probe_in;  // [batch][probe_m][n_vars] the vectors w_j themselves instead of the pseudo-random ones, or null
     double probe_scale;      // lambda_p = probe_scale x the largest squared entry of J (1e-11; 1e-14 for a second opinion)
     unsigned long long* stamps;  // diagnostic builds
     DoneWord done;
