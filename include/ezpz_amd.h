@@ -297,9 +297,10 @@ int ezpz_solve(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_id
  * null vectors are refined by subspace iteration -- the same sets, participation equal to rounding; more
  * than four degrees of freedom, a singular value within 1e-7 ... 3e-6 of J's largest entry, or more than 64 systems per call go
  * to the pivoted QR, like every call of the _device entry.  A large component's QR runs on many workgroups that wait for each other's chunks; should one
- * of them give up waiting (a device fault), the host entries return EZPZ_ERR_HIP and the asynchronous _device entry marks the
- * system: 0xFF in every byte of its mask, 0xFFFFFFFF as its count -- as a timed-out grid team's solve reports
- * EZPZ_ITERATIONS_TEAM_TIMEOUT. */
+ * of them give up waiting (workgroups that never became resident beside another process's or stream's kernels), the host entries
+ * run the analysis once more as a chain of launches that wait for nobody (EZPZ_ERR_HIP only if that fails too), and the
+ * asynchronous _device entry marks the system: 0xFF in every byte of its mask, 0xFFFFFFFF as its count -- as a timed-out grid
+ * team's solve reports EZPZ_ITERATIONS_TEAM_TIMEOUT. */
 int ezpz_solve_analysis(const EzpzConstraint* reqs, size_t n_reqs, const uint32_t* var_ids, const double* guesses,
                         size_t n_guesses, const EzpzConfig* cfg, double* x_out, uint64_t* unsat_ids,
                         EzpzWarning* warn_buf, size_t warn_cap, EzpzOutcome* out, uint32_t* under_out,
