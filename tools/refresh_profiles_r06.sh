@@ -40,4 +40,5 @@ for i in 1 2; do for w in 32 48 60 64 80 128 256 1024; do for v in 0 1; do echo 
 (echo "# python tools/stress_random_blocks.py 24; ... all 30; ... grid 10"; python tools/stress_random_blocks.py 24 2>&1 | grep -v amdgpu.ids; python tools/stress_random_blocks.py all 30 2>&1 | grep -v amdgpu.ids; python tools/stress_random_blocks.py grid 10 2>&1 | grep -v amdgpu.ids) > $out/stress_blocks_now.txt
 hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/liblds_poison.so tools/lds_poison.hip 2>/dev/null && (echo "# python tools/stress_lds_poison.py"; python tools/stress_lds_poison.py 2>&1 | grep -v amdgpu.ids) > $out/stress_lds_poison.txt
 hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/libnoise.so tools/noise.hip 2>/dev/null && (echo "# EZPZ_DEBUG=hip python tools/stress_noise.py"; EZPZ_DEBUG=hip timeout 1200 python tools/stress_noise.py 2>&1 | grep -v "amdgpu.ids\|cooperative launch attribute" | uniq -c) > $out/stress_noise.txt
+(echo "# python tools/stress_threads.py 12 120"; python tools/stress_threads.py 12 120 2>&1 | grep -v amdgpu.ids) > $out/stress_threads.txt
 head -3 $out/massive_b65536_kernel_stats.csv; tail -3 $out/pytest_gpu.txt
