@@ -54,6 +54,10 @@ def main():
     tensors = [(name, s, torch.from_numpy(x).cuda()) for name, s, x in work]
     torch.cuda.synchronize()
     refs = [run(s, xin, main_stream) for _, s, xin in tensors]
+    # ... and the host entry of the same systems (pageable buffers: the system's own staging buffers, one call at a time inside)
+    hosts = [np.ascontiguousarray(x[: min(len(x), 400)]) for _, _, x in work]
+    host_refs = [s.solve_batch(h, cfg) for (_, s, _), h in zip(work, hosts)]
+    host_calls = [0]
     errors = []
     counts = [0] * len(tensors)
 
@@ -64,6 +68,12 @@ def main():
             for c in range(calls):
                 k = int(rng.integers(0, len(tensors)))
                 name, s, xin = tensors[k]
+                if c % 4 == 3:
+                    xh, sth, _ = s.solve_batch(hosts[k], cfg)
+                    host_calls[0] += 1
+                    if not (np.array_equal(xh, host_refs[k][0], equal_nan=True) and all(np.array_equal(sth[f], host_refs[k][1][f], equal_nan=True) for f in sth.dtype.names)):
+                        errors.append(f"thread {tid} call {c}: {name}, host entry: differs")
+                    continue
                 x, st = run(s, xin, stream)
                 counts[k] += 1
                 if not (np.array_equal(x, refs[k][0], equal_nan=True) and np.array_equal(st, refs[k][1])):
@@ -77,6 +87,7 @@ def main():
     for t in threads: t.join()
     for (name, _, _), c in zip(tensors, counts):
         print(f"{name}: {c} concurrent calls")
+    print(f"host entries among them: {host_calls[0]} calls")
     print("\n".join(errors[:10]))
     print(f"# {n_threads} threads x {calls} calls: " + ("every result the same bits as alone" if not errors else f"{len(errors)} FAILED"))
     return 1 if errors else 0
