@@ -57,6 +57,10 @@ static int front_launch_kernel(EzpzSystem& s, FrontArgs& fa, hipStream_t stream)
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     else
         HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+    // (per LM iteration a factorisation's hops up and down the tree and the reductions of the LM control -- at most a few per level;
+    // the sequence numbers of the scratch start again before they wrap: system.hpp)
+    if (seq_budget_spent(s.front_seq_used, fa.batch, 16ull * ((uint64_t)fa.max_iterations + 4) * std::max<uint32_t>(1, plan.n_levels)))
+        HIP_TRY(hipMemsetAsync(s.front_scratch.p, 0, s.front_scratch.cap, stream));
     hipLaunchKernelGGL(kernel, dim3(slots * G), dim3(plan.threads), plan.lds_bytes, stream, fa);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev, stream));

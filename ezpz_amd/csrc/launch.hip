@@ -98,6 +98,9 @@ int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
         hipEvent_t& ev = g_grid_event[s.device & 15];
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+        // (three exchanges per LM iteration and a few around them; the sequence numbers start again before they wrap: system.hpp)
+        if (seq_budget_spent(s.grid_seq_used, args.batch, 3ull * ((uint64_t)args.max_iterations + 4)))
+            HIP_TRY(hipMemsetAsync(s.grid_scratch.p, 0, s.grid_scratch.cap * sizeof(GridScratch), stream));
         hipLaunchKernelGGL(kernel, dim3(slots * s.grid_wgs), dim3(s.block_threads), s.lds_bytes, stream, args);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev, stream));
@@ -214,6 +217,9 @@ int launch_jit_grid(EzpzSystem& s, const CompLaunch& L, hipStream_t stream) {
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     else
         HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+    // (the loop's three exchanges per LM iteration, the ring's one per system: the sequence numbers start again before they wrap)
+    if (seq_budget_spent(s.jit_seq_used, L.batch, 3ull * ((uint64_t)L.max_iterations + 4)))
+        HIP_TRY(hipMemsetAsync(s.jit_scratch.p, 0, s.jit_scratch.cap, stream));
     const unsigned int turn = s.jit_redo_turn;
     int rc = comp_jit_launch(s.jit, *s.comp, s.dev_comp, L, s.device, s.lim.cus, stream, s.jit_scratch.p, slots, lists ? fast_slots : 0,
                              lists ? s.jit_redo[turn].p : nullptr, lists ? s.jit_redo[turn ^ 1u].p : nullptr, s.jit_redo_seen_dev,

@@ -224,6 +224,11 @@ struct EzpzSystem {
     std::vector<ProgramView> host_grid_views;   // per workgroup; blob_bytes = offset of its slice in grid_blob
     size_t grid_stage_bytes = 0;
     uint64_t grid_capacity = 0;  // workgroups of the grid build the device holds at once (0 = not asked yet)
+    // The scratch areas through which the workgroups of one system talk inside a launch carry 32-bit sequence numbers that go on from
+    // launch to launch (grid_ops.hip.hpp, jit_kernel.hip.hpp, front_kernel.hip.hpp).  An upper bound of what the launches so far
+    // have used of them; past kSeqBudget the launch code zeroes the area first (ordered behind the last launch that used it), and
+    // the numbers start again -- a process that solves one such system for days never meets the wrap.
+    uint64_t grid_seq_used = 0, jit_seq_used = 0, front_seq_used = 0;
     void* dev_grid_blob = nullptr;
     DevBuf<ProgramView> grid_views;
     uint32_t prog_lds_doubles = 0;
@@ -300,6 +305,23 @@ namespace ezpz {
 // A system spread over several workgroups that wait for each other (a grid team, a multi-workgroup specialised kernel, fronts across
 // workgroups): its rendezvous can time out, and the status then says so (EZPZ_ITERATIONS_TEAM_TIMEOUT) -- every host entry turns
 // that into EZPZ_ERR_HIP.
+constexpr uint64_t kSeqBudget = 1ull << 31;
+// `used` += what a launch of `batch` systems with `per_system` exchanges each may add; true: the area is to be zeroed first.
+// (EZPZ_SEQ_BUDGET: a smaller budget, for the test that wants to see the numbers start again)
+inline bool seq_budget_spent(uint64_t& used, uint64_t batch, uint64_t per_system) {
+    static const uint64_t budget = [] {
+        const char* e = std::getenv("EZPZ_SEQ_BUDGET");
+        const long long v = e ? std::atoll(e) : 0;
+        return v > 0 ? (uint64_t)v : kSeqBudget;
+    }();
+    const uint64_t add = batch * per_system;
+    if (used + add > budget) {
+        used = add;
+        return true;
+    }
+    used += add;
+    return false;
+}
 inline bool can_time_out(const EzpzSystem& s) {
     return s.grid_wgs > 1 || (s.comp && s.comp->jit_wgs > 1) || (s.fronts && s.fronts->n_wgs > 1);
 }

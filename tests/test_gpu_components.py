@@ -720,3 +720,45 @@ def test_random_linear_blocks_in_launches_whose_workgroups_draw(E):
 
     done, fast, redone, bad = S.run_trials(8, 97531)
     assert bad == 0 and done >= 6 and fast >= 6
+
+
+def test_sequence_numbers_of_the_scratch_areas_start_again(E, tmp_path):
+    """The scratch areas through which a system's workgroups talk carry 32-bit sequence numbers that go on from launch to launch
+    (the ladder's ring and reductions, the list-walk grid team's reductions, the fronts' hops): before an upper bound of their use
+    reaches 2^31 the launch code zeroes the area behind the last launch that used it and the numbers start again (system.hpp:
+    seq_budget_spent) -- a process that solves such a system for days never meets the wrap.  Here with EZPZ_SEQ_BUDGET=2000 (a
+    reset every few launches): thirty calls each of the ladder (list walk, then compiled), and of a sketch on 14 workgroups, all
+    equal to the first call's results bit for bit."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import ezpz_amd as E, gen
+from oracle import textual as T
+lad = T.load(T.gen_big_problem(12000))
+n = lad.num_vars
+x0 = lad.guesses[None, :] + gen.keyed_uniform(71, 9, n, -0.25, 0.25)
+x0[4] = 0.0; x0[4, 0::4] = x0[4, 2::4] = np.arange(12000); x0[4, 3::4] = 4.0
+for compiled in (False, True):
+    s = E.System(lad.constraints, n)
+    if compiled:
+        assert s.specialize(wait=True) == 2
+    assert s.info()["grid_workgroups"] > 1
+    ref = s.solve_batch(x0)
+    assert np.all(ref[1]["converged"] == 1)
+    for rep in range(30):
+        x, st, _ = s.solve_batch(x0)
+        assert np.array_equal(x, ref[0]) and all(np.array_equal(st[f], ref[1][f]) for f in st.dtype.names), (compiled, rep)
+recs, g = gen.connected_sketch(1000, 2000)
+f = E.System(recs, len(g), team_size=E.TEAM_AUTO_LATENCY)
+assert f.info()["front_workgroups"] > 1
+xs = g[None, :] + np.random.default_rng(5).uniform(-0.01, 0.01, (3, len(g)))
+cfg = E.Config(max_iterations=40)
+ref = f.solve_batch(xs, cfg)
+for rep in range(30):
+    x, st, _ = f.solve_batch(xs, cfg)
+    assert np.array_equal(x, ref[0]) and all(np.array_equal(st[k], ref[1][k]) for k in st.dtype.names), rep
+print("ok")
+'''
+    env = dict(os.environ, EZPZ_SEQ_BUDGET="2000", EZPZ_JIT_CACHE_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
