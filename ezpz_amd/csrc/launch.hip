@@ -54,8 +54,13 @@ namespace {
 
 // Grid team: G workgroups per system, all of a launch's workgroups resident at once, as many systems in flight as
 // the device holds.
+bool stream_capturing(hipStream_t stream);
+
 template <bool LIN>
 int launch_grid_kernel(EzpzSystem& s, SolveArgs& args, hipStream_t stream) {
+    // (launches whose workgroups wait for each other are chained on a process-wide event and zero their scratch on first use: neither
+    // may end up inside a stream capture, which would be invalidated and leave the event unusable -- refused up front)
+    if (stream_capturing(stream)) return EZPZ_ERR_INVALID_ARGUMENT;
     auto kernel = lm_solve_kernel<64, MODE_PART, true, true, LIN, true>;
     if (s.grid_capacity == 0) {  // once per system: these two runtime calls cost more than the solve
         if (s.lds_bytes > 48 * 1024)
@@ -191,6 +196,7 @@ int jit_redo_lists(EzpzSystem& s, uint64_t batch, hipStream_t stream) {
 // flight as the device holds whole teams of; every workgroup of the launch must be resident (they wait for each other),
 // so launches of this kind are chained like the list-walk grid teams' (launch_grid_kernel).
 int launch_jit_grid(EzpzSystem& s, const CompLaunch& L, hipStream_t stream) {
+    if (stream_capturing(stream)) return EZPZ_ERR_INVALID_ARGUMENT;  // (as launch_grid_kernel)
     const uint32_t G = s.comp->jit_wgs;
     const uint64_t capacity = comp_jit_capacity(s.jit, *s.comp, s.device, s.lim.cus);
     if (capacity < G) return EZPZ_ERR_TOO_LARGE;

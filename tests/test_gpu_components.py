@@ -762,3 +762,41 @@ print("ok")
     env = dict(os.environ, EZPZ_SEQ_BUDGET="2000", EZPZ_JIT_CACHE_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_a_system_on_several_workgroups_refuses_stream_capture(E):
+    """Launches whose workgroups wait for each other are chained on a process-wide event and zero their scratch on first use; inside a
+    stream capture either would invalidate the capture and leave the event unusable.  They refuse up front (EZPZ_ERR_INVALID_ARGUMENT,
+    nothing enqueued), on the list walk and on the compiled kernels, and a direct call afterwards gives the results it always gave."""
+    import warnings
+
+    import torch
+
+    lad = T.load(T.gen_big_problem(12000))
+    n, B = lad.num_vars, 4
+    x0 = lad.guesses[None, :] + gen.keyed_uniform(81, B, n, -0.25, 0.25)
+    for compiled in (False, True):
+        s = E.System(lad.constraints, n)
+        if compiled:
+            assert s.specialize(wait=True) == 2
+        assert s.info()["grid_workgroups"] > 1
+        xin = torch.from_numpy(x0).cuda()
+        xo = torch.empty_like(xin)
+        st = torch.zeros((B, 32), dtype=torch.uint8, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            s.solve_batch_device(xin.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, side.cuda_stream)
+        side.synchronize()
+        want = xo.clone()
+        g = torch.cuda.CUDAGraph()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # ("The CUDA Graph is empty")
+            with pytest.raises(E.NonLinearSystemError) as err:
+                with torch.cuda.graph(g, stream=side):
+                    s.solve_batch_device(xin.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        assert "invalid argument" in str(err.value)
+        torch.cuda.synchronize()
+        xo.fill_(float("nan"))
+        s.solve_batch_device(xin.data_ptr(), B, xo.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(xo, want), compiled
